@@ -1,0 +1,42 @@
+// pxsom_common.h -- shared host-side plumbing for libpxsom.so (gfx950 only; no other target).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "pxsom.h"
+
+#define PXSOM_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace pxsom {
+
+// thread-local last-error text (pxsom_last_error)
+char *err_buf();
+int fail(int code, const char *fmt, ...);
+
+inline int hip_fail(hipError_t e, const char *what)
+{
+    return fail(PXSOM_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+#define PXSOM_HIP_TRY(expr)                                          \
+    do {                                                             \
+        hipError_t _e = (expr);                                      \
+        if (_e != hipSuccess) return ::pxsom::hip_fail(_e, #expr);   \
+    } while (0)
+
+// launch check: kernels are async, this only catches configuration errors
+#define PXSOM_LAUNCH_CHECK(name)                                     \
+    do {                                                             \
+        hipError_t _e = hipGetLastError();                           \
+        if (_e != hipSuccess) return ::pxsom::hip_fail(_e, name);    \
+    } while (0)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// number of CUs of the current device (256 on MI355X); cached per process
+int device_cu_count();
+
+}  // namespace pxsom

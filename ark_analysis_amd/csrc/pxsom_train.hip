@@ -1,0 +1,379 @@
+// pxsom_train.hip -- K6 (SOM training) + K8 (per-cluster sums) on gfx950.
+//
+//   pxsom_train_online  replaces pyFlowSOM.som (reference call site
+//                       /root/reference/src/ark/phenotyping/cluster_helpers.py:106-109): FlowSOM's
+//                       C_SOM loop, n*rlen strictly sequential steps.  One persistent workgroup;
+//                       thread <-> SOM node; the binary64 codebook lives in LDS ([channel][node], so a
+//                       wave's reads are conflict-free); the presented rows are gathered 64 steps
+//                       ahead into an LDS ring, so no step waits on HBM; one s_barrier per step.
+//                       Latency-bound by construction (neither roofline applies): DESIGN.md "K6a".
+//   pxsom_cluster_sums  replaces the pandas groupby-sum of compute_pixel_cluster_channel_avg
+//                       (pixel_cluster_utils.py:369-404) and is the accumulation half of the batch rule.
+//   pxsom_batch_update  the batch rule's codebook update (oracle of record: orc_batch_update).
+#include <cfloat>
+#include <cmath>
+
+#include "pxsom_common.h"
+
+namespace {
+
+#pragma clang fp contract(off)
+
+// ------------------------------------------------------------------------------------------------
+// exact online SOM
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(1024) void som_online_kernel(const T *__restrict__ x, int64_t n, int c,
+                                                          int64_t ldx, double *w, int xdim, int ydim,
+                                                          int rlen, double a0, double a1, double r0,
+                                                          double r1, const int64_t *__restrict__ order,
+                                                          int chunk)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int K = xdim * ydim;
+    const int tid = threadIdx.x, bd = blockDim.x;
+    const int lane = tid & 63, wv = tid >> 6, nwv = bd >> 6;
+    double *wt = reinterpret_cast<double *>(smem_raw);            // [c][K]
+    double *xs = wt + (size_t)c * K;                              // [2][chunk][c]
+    double *exd = xs + (size_t)2 * chunk * c;                     // [2][nwv] best distance per wave
+    int *exk = reinterpret_cast<int *>(exd + 2 * nwv);            // [2][nwv] best node per wave
+    double *red = reinterpret_cast<double *>(exk + 2 * nwv + (2 * nwv & 1));  // [nwv] change partials
+
+    const bool has_node = tid < K;
+    const int node = tid;
+    const int nx = node / ydim, ny = node % ydim;
+    if (has_node)
+        for (int j = 0; j < c; j++) wt[(size_t)j * K + node] = w[(size_t)node * c + j];
+
+    const int64_t niter = (int64_t)rlen * n;
+    double threshold = r0;
+    const double thresholdStep = (r0 - r1) / (double)niter;
+    double change = 1.0;   // uniform: the epoch's total, known after the epoch-boundary reduction
+    double mychange = 0.0; // this thread's share of the running epoch
+    const int per_thread = (chunk * c + bd - 1) / bd;  // gathered elements per thread per chunk
+    constexpr int kMaxPer = 16;
+    double pre[kMaxPer];
+
+    auto gather = [&](int64_t step0) {
+#pragma unroll
+        for (int u = 0; u < kMaxPer; u++) {
+            const int e = tid + u * bd;
+            double v = 0.0;
+            if (u < per_thread && e < chunk * c) {
+                const int s = e / c, j = e - s * c;
+                const int64_t st = step0 + s;
+                if (st < niter) v = (double)x[order[st] * ldx + j];
+            }
+            pre[u] = v;
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < kMaxPer; u++) {
+            const int e = tid + u * bd;
+            if (u < per_thread && e < chunk * c) xs[(size_t)buf * chunk * c + e] = pre[u];
+        }
+    };
+
+    gather(0);
+    commit(0);
+    __syncthreads();
+
+    bool done = false;
+    int par = 0;
+    for (int64_t step0 = 0; step0 < niter && !done; step0 += chunk) {
+        const int buf = (int)((step0 / chunk) & 1);
+        gather(step0 + chunk);  // in flight while this chunk computes
+        const double *xc = xs + (size_t)buf * chunk * c;
+        for (int s = 0; s < chunk; s++) {
+            const int64_t step = step0 + s;
+            if (step >= niter) break;
+            int64_t k = step;
+            if (step % n == 0) {
+                if (step > 0) {
+                    // epoch boundary: total |delta| of the finished epoch (summation order differs
+                    // from the oracle's sequential one; only `change < 1` is ever looked at)
+                    double v = mychange;
+                    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                    if (lane == 0) red[wv] = v;
+                    __syncthreads();
+                    change = 0.0;
+                    for (int i = 0; i < nwv; i++) change += red[i];
+                    __syncthreads();
+                }
+                if (change < 1.0) {
+                    k = niter;  // FlowSOM: body runs once more with k == niter, then the loop ends
+                    done = true;
+                }
+                change = 0.0;
+                mychange = 0.0;
+            }
+            const double *xr = xc + (size_t)s * c;
+            // distance of this thread's node (binary64, j ascending, sqrt) -- FlowSOM eucl()
+            double d = INFINITY;
+            if (has_node) {
+                double xdist = 0.0;
+                for (int j = 0; j < c; j++) {
+                    const double tmp = xr[j] - wt[(size_t)j * K + node];
+                    xdist += tmp * tmp;
+                }
+                d = sqrt(xdist);
+                if (!(d == d)) d = INFINITY;
+            }
+            int bk = has_node ? node : 0x7fffffff;
+            for (int off = 32; off > 0; off >>= 1) {
+                const double od = __shfl_xor(d, off);
+                const int ok = __shfl_xor(bk, off);
+                if (od < d || (od == d && ok < bk)) {
+                    d = od;
+                    bk = ok;
+                }
+            }
+            int nearest = bk;
+            if (nwv > 1) {
+                if (lane == 0) {
+                    exd[par * nwv + wv] = d;
+                    exk[par * nwv + wv] = bk;
+                }
+                __syncthreads();
+                double bd_ = exd[par * nwv];
+                nearest = exk[par * nwv];
+                for (int i = 1; i < nwv; i++) {
+                    const double od = exd[par * nwv + i];
+                    const int ok = exk[par * nwv + i];
+                    if (od < bd_ || (od == bd_ && ok < nearest)) {
+                        bd_ = od;
+                        nearest = ok;
+                    }
+                }
+                par ^= 1;
+            }
+            if (nearest >= K) nearest = 0;
+            if (threshold < 1.0) threshold = 0.5;
+            const double alpha = a0 - (a0 - a1) * (double)k / (double)niter;
+            if (has_node) {
+                const int bx = nearest / ydim, by = nearest % ydim;
+                const int dx = nx > bx ? nx - bx : bx - nx, dy = ny > by ? ny - by : by - ny;
+                const double nh = (double)(dx > dy ? dx : dy);
+                if (!(nh > threshold)) {
+                    for (int j = 0; j < c; j++) {
+                        const double wv_ = wt[(size_t)j * K + node];
+                        const double tmp = xr[j] - wv_;
+                        mychange += fabs(tmp);
+                        wt[(size_t)j * K + node] = wv_ + tmp * alpha;
+                    }
+                }
+            }
+            threshold -= thresholdStep;
+            if (done) break;
+        }
+        // publish the next chunk's rows (other buffer: nobody reads it during this chunk)
+        commit(buf ^ 1);
+        __syncthreads();
+    }
+    if (has_node)
+        for (int j = 0; j < c; j++) w[(size_t)node * c + j] = wt[(size_t)j * K + node];
+}
+
+// ------------------------------------------------------------------------------------------------
+// batch update: one workgroup; thread <-> (node, channel) pairs
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void batch_update_kernel(double *w, int xdim, int ydim, int c,
+                                                           const double *__restrict__ sums,
+                                                           const int64_t *__restrict__ counts,
+                                                           double thr, double alpha)
+{
+    const int K = xdim * ydim;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < K * c; e += gridDim.x * 256) {
+        const int k = e / c, j = e - k * c;
+        const int kx = k / ydim, ky = k % ydim;
+        double num = 0.0, den = 0.0;
+        for (int b = 0; b < K; b++) {
+            const int bx = b / ydim, by = b % ydim;
+            const int dx = kx > bx ? kx - bx : bx - kx, dy = ky > by ? ky - by : by - ky;
+            if ((double)(dx > dy ? dx : dy) > thr) continue;
+            den += (double)counts[b];
+            num += sums[(size_t)b * c + j];
+        }
+        if (den > 0.0) {
+            const double gain = 1.0 - pow(1.0 - alpha, den);
+            const double wv = w[e];
+            w[e] = wv + gain * (num / den - wv);
+        }
+    }
+}
+
+#pragma clang fp contract(fast)
+
+// ------------------------------------------------------------------------------------------------
+// per-cluster sums/counts.  Each workgroup owns a contiguous row range and a private binary64
+// table in LDS (ds_add_f64), flushed once with global_atomic_add_f64.
+// Loads are flat-coalesced: lane e reads element e of the row range.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void cluster_sums_kernel(const T *__restrict__ x, int64_t n, int c,
+                                                           int64_t ldx, const int32_t *__restrict__ labels,
+                                                           int k, double *sums, unsigned long long *counts,
+                                                           int64_t rows_per_block, int use_lds)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double *ls = reinterpret_cast<double *>(smem_raw);                 // [k*c]
+    unsigned *lc = reinterpret_cast<unsigned *>(ls + (size_t)k * c);   // [k]
+    const int tid = threadIdx.x;
+    if (use_lds) {
+        for (int e = tid; e < k * c; e += 256) ls[e] = 0.0;
+        for (int e = tid; e < k; e += 256) lc[e] = 0u;
+        __syncthreads();
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > n) r1 = n;
+    if (r0 < r1) {
+        // element e of the range <-> (row r0 + e / c, channel e % c); advance by 256 per iteration
+        const int64_t total = (r1 - r0) * c;
+        int64_t row = r0 + tid / c;
+        int ch = tid % c;
+        const int drow = 256 / c, dch = 256 % c;
+        for (int64_t e = tid; e < total; e += 256) {
+            const int lab = labels[row] - 1;
+            if (lab >= 0 && lab < k) {
+                const double v = (double)x[row * ldx + ch];
+                if (use_lds) {
+                    __hip_atomic_fetch_add(&ls[(size_t)lab * c + ch], v, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (ch == 0) atomicAdd(&lc[lab], 1u);
+                } else {
+                    __hip_atomic_fetch_add(&sums[(size_t)lab * c + ch], v, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    if (ch == 0) atomicAdd(&counts[lab], 1ull);
+                }
+            }
+            row += drow;
+            ch += dch;
+            if (ch >= c) {
+                ch -= c;
+                row += 1;
+            }
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int e = tid; e < k * c; e += 256) {
+            const double v = ls[e];
+            if (v != 0.0) __hip_atomic_fetch_add(&sums[e], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        for (int e = tid; e < k; e += 256)
+            if (lc[e]) atomicAdd(&counts[e], (unsigned long long)lc[e]);
+    }
+}
+
+template <typename T>
+int train_online_typed(const T *x, int64_t n, int c, int64_t ldx, double *w, int xdim, int ydim, int rlen,
+                       double a0, double a1, double r0, double r1, const int64_t *order, hipStream_t st)
+{
+    const int K = xdim * ydim;
+    const int bd = ((K + 63) / 64) * 64;
+    const int nwv = bd / 64;
+    const size_t fixed = (size_t)c * K * 8 + (size_t)2 * nwv * 8 + (size_t)(2 * nwv + 2) * 4 + (size_t)nwv * 8 + 64;
+    int chunk = 64;
+    while (chunk > 8 && fixed + (size_t)2 * chunk * c * 8 > 150 * 1024) chunk >>= 1;
+    while ((chunk * c + bd - 1) / bd > 16) chunk >>= 1;  // gather registers per thread
+    const size_t lds = fixed + (size_t)2 * chunk * c * 8;
+    if (chunk < 1 || lds > 160 * 1024)
+        return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "pxsom_train_online: codebook %dx%d does not fit LDS", K, c);
+    auto kern = som_online_kernel<T>;
+    PXSOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(1), dim3(bd), lds, st, x, n, c, ldx, w, xdim, ydim, rlen, a0, a1, r0, r1,
+                       order, chunk);
+    PXSOM_LAUNCH_CHECK("som_online_kernel");
+    return PXSOM_OK;
+}
+
+template <typename T>
+int cluster_sums_typed(const T *x, int64_t n, int c, int64_t ldx, const int32_t *labels, int k, double *sums,
+                       int64_t *counts, hipStream_t st)
+{
+    const size_t lds = (size_t)k * c * 8 + (size_t)k * 4;
+    const int use_lds = lds <= 150 * 1024;
+    const int cus = pxsom::device_cu_count();
+    int64_t grid = std::min<int64_t>((n + 1023) / 1024, (int64_t)cus * (lds <= 32 * 1024 ? 4 : 1));
+    if (grid < 1) grid = 1;
+    const int64_t rows_per_block = (n + grid - 1) / grid;
+    auto kern = cluster_sums_kernel<T>;
+    if (use_lds && lds > 48 * 1024)
+        PXSOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), use_lds ? lds : 0, st, x, n, c, ldx, labels, k,
+                       sums, reinterpret_cast<unsigned long long *>(counts), rows_per_block, use_lds);
+    PXSOM_LAUNCH_CHECK("cluster_sums_kernel");
+    return PXSOM_OK;
+}
+
+int check_matrix(const char *fn, const void *x, int64_t n, int c, int64_t ldx, int dtype)
+{
+    if (n < 0) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "%s: n=%lld < 0", fn, (long long)n);
+    if (c < 1 || c > PXSOM_MAX_CHANNELS)
+        return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "%s: c=%d outside [1, %d]", fn, c, PXSOM_MAX_CHANNELS);
+    if (ldx < c) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "%s: ldx=%lld < c=%d", fn, (long long)ldx, c);
+    if (dtype != PXSOM_F32 && dtype != PXSOM_F64) return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "%s: dtype %d", fn, dtype);
+    if (n > 0 && !x) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "%s: null matrix", fn);
+    return PXSOM_OK;
+}
+
+}  // namespace
+
+PXSOM_EXPORT int pxsom_train_online(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, double *w_dev,
+                                    int xdim, int ydim, int rlen, double a0, double a1, double r0, double r1,
+                                    const int64_t *order_dev, void *stream)
+{
+    int rc = check_matrix("pxsom_train_online", x_dev, n, c, ldx, dtype);
+    if (rc) return rc;
+    if (xdim < 1 || ydim < 1 || (int64_t)xdim * ydim > PXSOM_MAX_NODES)
+        return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "pxsom_train_online: grid %dx%d outside [1, %d] nodes", xdim,
+                           ydim, PXSOM_MAX_NODES);
+    if (rlen < 0 || !w_dev) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_train_online: bad rlen / null codebook");
+    if (n == 0 || rlen == 0) return PXSOM_OK;
+    if (!order_dev) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_train_online: null order");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == PXSOM_F32)
+        return train_online_typed<float>(reinterpret_cast<const float *>(x_dev), n, c, ldx, w_dev, xdim, ydim, rlen,
+                                         a0, a1, r0, r1, order_dev, st);
+    return train_online_typed<double>(reinterpret_cast<const double *>(x_dev), n, c, ldx, w_dev, xdim, ydim, rlen,
+                                      a0, a1, r0, r1, order_dev, st);
+}
+
+PXSOM_EXPORT int pxsom_cluster_sums(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype,
+                                    const int32_t *labels_dev, int k, double *sums_dev, int64_t *counts_dev,
+                                    void *stream)
+{
+    int rc = check_matrix("pxsom_cluster_sums", x_dev, n, c, ldx, dtype);
+    if (rc) return rc;
+    if (k < 1 || k > PXSOM_MAX_NODES)
+        return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "pxsom_cluster_sums: k=%d outside [1, %d]", k, PXSOM_MAX_NODES);
+    if (!sums_dev || !counts_dev || (n > 0 && !labels_dev))
+        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_cluster_sums: null pointer");
+    if (n == 0) return PXSOM_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == PXSOM_F32)
+        return cluster_sums_typed<float>(reinterpret_cast<const float *>(x_dev), n, c, ldx, labels_dev, k, sums_dev,
+                                         counts_dev, st);
+    return cluster_sums_typed<double>(reinterpret_cast<const double *>(x_dev), n, c, ldx, labels_dev, k, sums_dev,
+                                      counts_dev, st);
+}
+
+PXSOM_EXPORT int pxsom_batch_update(double *w_dev, int xdim, int ydim, int c, const double *sums_dev,
+                                    const int64_t *counts_dev, double thr, double alpha, void *stream)
+{
+    if (xdim < 1 || ydim < 1 || (int64_t)xdim * ydim > PXSOM_MAX_NODES || c < 1 || c > PXSOM_MAX_CHANNELS)
+        return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "pxsom_batch_update: shape %dx%d x %d", xdim, ydim, c);
+    if (!w_dev || !sums_dev || !counts_dev) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_batch_update: null pointer");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int K = xdim * ydim;
+    int grid = (K * c + 255) / 256;
+    if (grid > 64) grid = 64;
+    hipLaunchKernelGGL(batch_update_kernel, dim3(grid), dim3(256), 0, st, w_dev, xdim, ydim, c, sums_dev, counts_dev,
+                       thr, alpha);
+    PXSOM_LAUNCH_CHECK("batch_update_kernel");
+    return PXSOM_OK;
+}

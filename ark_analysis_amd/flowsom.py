@@ -1,0 +1,105 @@
+"""pyFlowSOM-compatible front end: ``som`` and ``map_data_to_nodes`` on MI355X.
+
+These are the only two foreign functions the reference's hot path calls
+(``from pyFlowSOM import map_data_to_nodes, som``,
+/root/reference/src/ark/phenotyping/cluster_helpers.py:14; call sites :106-109 and :152-157).
+Same names, argument meaning and return shapes, so ``cluster_helpers.py`` runs on the GPU by
+changing that one import.
+
+Seed handling (``som(..., seed=s)``): pyFlowSOM 0.1.16 is not available in this image, so its
+random stream cannot be verified; by the reference's contract only *same seed => same weights*
+holds (tests/phenotyping/cluster_helpers_test.py:323-332).  This build documents its own:
+  initial nodes      data[RandomState(seed).choice(n, K, replace=False)]
+  presentation order i_t = int(n * r_t / 2**31), r_t the glibc ``rand()`` stream after
+                     ``srand(seed)`` (restated in C, pinned against libc in the tests)
+Both are explicit inputs of the kernels (BASELINE.json: "given identical init weights and pixel
+presentation order"), see :func:`som_with_inputs`.
+"""
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+
+def nhbrdist(xdim: int, ydim: int) -> np.ndarray:
+    """Chebyshev distances between grid nodes, node k = x*ydim + y."""
+    gx, gy = np.divmod(np.arange(xdim * ydim), ydim)
+    return np.maximum(np.abs(gx[:, None] - gx[None, :]),
+                      np.abs(gy[:, None] - gy[None, :])).astype(np.float64)
+
+
+def default_radius_range(xdim: int, ydim: int) -> Tuple[float, float]:
+    """pyFlowSOM default: (quantile(nhbrdist, 0.67), 0) -- 6.0 for 10x10, 11.0 for 20x20."""
+    return float(np.quantile(nhbrdist(xdim, ydim), 0.67)), 0.0
+
+
+def som_init_and_order(n: int, k: int, rlen: int, seed: Optional[int]):
+    """(indices of the K initial nodes, presentation order int64 [n*rlen]) for ``seed``."""
+    from . import _capi
+    if n < k:
+        raise ValueError(f"som needs at least as many rows ({n}) as nodes ({k})")
+    rs = np.random.RandomState(seed)
+    init_idx = rs.choice(n, k, replace=False)
+    stream_seed = int(seed) if seed is not None else int(rs.randint(1, 2 ** 31 - 1))
+    r = _capi.glibc_rand(stream_seed, n * rlen)
+    order = (n * (r.astype(np.float64) / 2147483648.0)).astype(np.int64)
+    return init_idx, order
+
+
+def _as_device_matrix(data, device):
+    import torch
+    if isinstance(data, torch.Tensor):
+        return data.to(device)
+    arr = np.asarray(data)
+    if arr.dtype not in (np.float32, np.float64):
+        arr = arr.astype(np.float64)
+    return torch.from_numpy(np.ascontiguousarray(arr)).to(device)
+
+
+def som_with_inputs(data, init_nodes, order, xdim: int = 10, ydim: int = 10, rlen: int = 10,
+                    alpha_range: Sequence[float] = (0.05, 0.01),
+                    radius_range: Optional[Sequence[float]] = None) -> np.ndarray:
+    """Exact online SOM with explicit initial nodes [K, C] and presentation order [n*rlen]."""
+    import torch
+    from . import _capi, som_device
+    dev = _capi.require_gpu()
+    x = _as_device_matrix(data, dev)
+    w = torch.from_numpy(np.ascontiguousarray(init_nodes, dtype=np.float64)).to(dev)
+    od = torch.from_numpy(np.ascontiguousarray(order, dtype=np.int64)).to(dev)
+    if radius_range is None:
+        radius_range = default_radius_range(xdim, ydim)
+    som_device.train_online(x, w, xdim, ydim, rlen, alpha_range, radius_range, od)
+    return w.cpu().numpy()
+
+
+def som(data, xdim: int = 10, ydim: int = 10, rlen: int = 10,
+        alpha_range: Sequence[float] = (0.05, 0.01), radius_range=None, distf: int = 2,
+        nodes=None, importance=None, seed=None) -> np.ndarray:
+    """Drop-in for ``pyFlowSOM.som``: returns the trained codebook [xdim*ydim, C] (float64)."""
+    if distf != 2:
+        raise NotImplementedError("only the Euclidean distance (distf=2) is built; ark uses no other")
+    data = np.asarray(data) if not hasattr(data, "is_cuda") else data
+    if importance is not None:
+        data = np.asarray(data, dtype=np.float64) * np.asarray(importance, dtype=np.float64)
+    n = data.shape[0]
+    k = xdim * ydim
+    init_idx, order = som_init_and_order(n, k, rlen, seed)
+    if nodes is None:
+        src = data[init_idx]
+        nodes = src.cpu().numpy() if hasattr(src, "cpu") else np.asarray(src)
+    return som_with_inputs(data, np.asarray(nodes, dtype=np.float64), order, xdim, ydim, rlen,
+                           alpha_range, radius_range)
+
+
+def map_data_to_nodes(nodes, newdata, distf: int = 2):
+    """Drop-in for ``pyFlowSOM.map_data_to_nodes``: (labels 1-based, distances) of every row."""
+    import torch
+    from . import _capi, som_device
+    if distf != 2:
+        raise NotImplementedError("only the Euclidean distance (distf=2) is built; ark uses no other")
+    dev = _capi.require_gpu()
+    x = _as_device_matrix(newdata, dev)
+    if x.dim() == 1:
+        x = x.reshape(1, -1)
+    w = torch.from_numpy(np.ascontiguousarray(nodes, dtype=np.float64)).to(dev)
+    labels, dists = som_device.assign(x, w, want_dists=True)
+    return labels.cpu().numpy(), dists.cpu().numpy()

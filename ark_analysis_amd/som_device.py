@@ -1,0 +1,126 @@
+"""Device-level SOM operations: thin, typed wrappers over the C ABI working on torch tensors.
+
+Tensors are only device-memory holders here (``data_ptr()`` goes across the ABI); every
+function launches on torch's current HIP stream and returns without synchronising.
+"""
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _capi
+
+
+def _matrix_args(x: torch.Tensor) -> Tuple[int, int, int, int]:
+    if x.dim() != 2:
+        raise ValueError("pixel matrix must be 2-D [rows, channels]")
+    if not x.is_cuda:
+        raise ValueError("pixel matrix must live in HBM (a cuda/HIP tensor)")
+    if x.stride(1) != 1:
+        raise ValueError("pixel matrix rows must be contiguous (stride(1) == 1)")
+    n, c = x.shape
+    ldx = x.stride(0) if n > 1 else max(c, x.stride(0))
+    return n, c, ldx, _capi.dtype_code(x)
+
+
+def _codebook(w: torch.Tensor) -> torch.Tensor:
+    if w.dtype != torch.float64 or not w.is_cuda or not w.is_contiguous() or w.dim() != 2:
+        raise ValueError("codebook must be a contiguous float64 [K, C] HBM tensor")
+    return w
+
+
+class AssignWorkspace:
+    """Scratch for pxsom_assign, reusable across calls of the same (n_max, c, k)."""
+
+    def __init__(self, n_max: int, c: int, k: int, device):
+        self.bytes = _capi.lib().pxsom_assign_workspace_bytes(int(n_max), int(c), int(k))
+        if self.bytes == 0:
+            raise _capi.PxsomError(f"unsupported assign shape n={n_max} c={c} k={k}")
+        self.n_max, self.c, self.k = int(n_max), int(c), int(k)
+        self.buf = torch.empty(self.bytes, dtype=torch.uint8, device=device)
+
+    def fits(self, n: int, c: int, k: int) -> bool:
+        return c == self.c and k == self.k and n <= self.n_max
+
+
+def assign(x: torch.Tensor, w: torch.Tensor, labels: Optional[torch.Tensor] = None,
+           dists: Optional[torch.Tensor] = None, want_dists: bool = False,
+           workspace: Optional[AssignWorkspace] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """BMU labels (int32, 1-based) of every row of ``x`` against codebook ``w`` [K, C] f64."""
+    n, c, ldx, dt = _matrix_args(x)
+    w = _codebook(w)
+    k = w.shape[0]
+    if w.shape[1] != c:
+        raise ValueError(f"codebook has {w.shape[1]} channels, matrix has {c}")
+    if labels is None:
+        labels = torch.empty(n, dtype=torch.int32, device=x.device)
+    if want_dists and dists is None:
+        dists = torch.empty(n, dtype=torch.float64, device=x.device)
+    if workspace is None or not workspace.fits(n, c, k):
+        workspace = AssignWorkspace(n, c, k, x.device)
+    rc = _capi.lib().pxsom_assign(x.data_ptr(), n, c, ldx, dt, w.data_ptr(), k, labels.data_ptr(),
+                                  dists.data_ptr() if dists is not None else None,
+                                  workspace.buf.data_ptr(), workspace.bytes, _capi.stream_ptr())
+    _capi.check(rc, "pxsom_assign")
+    assign.last_workspace = workspace
+    return labels, dists
+
+
+def last_exact_rows(workspace: AssignWorkspace) -> int:
+    import ctypes
+    out = ctypes.c_int64(0)
+    _capi.check(_capi.lib().pxsom_assign_last_exact_rows(workspace.buf.data_ptr(), _capi.stream_ptr(),
+                                                         ctypes.byref(out)),
+                "pxsom_assign_last_exact_rows")
+    return int(out.value)
+
+
+def cluster_sums(x: torch.Tensor, labels: torch.Tensor, k: int,
+                 sums: Optional[torch.Tensor] = None, counts: Optional[torch.Tensor] = None):
+    """Adds per-label channel sums [k, C] f64 and counts [k] i64 of the rows of ``x``."""
+    n, c, ldx, dt = _matrix_args(x)
+    if labels.dtype != torch.int32 or labels.numel() != n or not labels.is_contiguous():
+        raise ValueError("labels must be a contiguous int32 vector with one entry per row")
+    if sums is None:
+        sums = torch.zeros((k, c), dtype=torch.float64, device=x.device)
+    if counts is None:
+        counts = torch.zeros(k, dtype=torch.int64, device=x.device)
+    rc = _capi.lib().pxsom_cluster_sums(x.data_ptr(), n, c, ldx, dt, labels.data_ptr(), int(k),
+                                        sums.data_ptr(), counts.data_ptr(), _capi.stream_ptr())
+    _capi.check(rc, "pxsom_cluster_sums")
+    return sums, counts
+
+
+def train_online(x: torch.Tensor, w: torch.Tensor, xdim: int, ydim: int, rlen: int,
+                 alpha_range, radius_range, order: torch.Tensor) -> torch.Tensor:
+    """Exact online SOM (FlowSOM C_SOM) in place on ``w`` [xdim*ydim, C] f64."""
+    n, c, ldx, dt = _matrix_args(x)
+    w = _codebook(w)
+    if w.shape != (xdim * ydim, c):
+        raise ValueError(f"codebook shape {tuple(w.shape)} != ({xdim * ydim}, {c})")
+    if order.dtype != torch.int64 or not order.is_cuda or order.numel() != n * rlen:
+        raise ValueError("order must be an int64 HBM vector of n*rlen row indices")
+    rc = _capi.lib().pxsom_train_online(x.data_ptr(), n, c, ldx, dt, w.data_ptr(), int(xdim),
+                                        int(ydim), int(rlen), float(alpha_range[0]),
+                                        float(alpha_range[1]), float(radius_range[0]),
+                                        float(radius_range[1]), order.data_ptr(),
+                                        _capi.stream_ptr())
+    _capi.check(rc, "pxsom_train_online")
+    return w
+
+
+def batch_update(w: torch.Tensor, xdim: int, ydim: int, sums: torch.Tensor, counts: torch.Tensor,
+                 thr: float, alpha: float) -> torch.Tensor:
+    w = _codebook(w)
+    c = w.shape[1]
+    if sums.dtype != torch.float64 or counts.dtype != torch.int64:
+        raise ValueError("sums must be float64 and counts int64")
+    rc = _capi.lib().pxsom_batch_update(w.data_ptr(), int(xdim), int(ydim), c, sums.data_ptr(),
+                                        counts.data_ptr(), float(thr), float(alpha),
+                                        _capi.stream_ptr())
+    _capi.check(rc, "pxsom_batch_update")
+    return w
+
+
+def to_numpy(t: torch.Tensor) -> np.ndarray:
+    return t.detach().cpu().numpy()

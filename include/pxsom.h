@@ -1,0 +1,117 @@
+/*
+ * pxsom.h -- C ABI of libpxsom.so: the MI355X (gfx950) implementation of ark-analysis' Pixie
+ * pixel/cell SOM hot path.
+ *
+ * The reference (pure Python) reaches its native arithmetic through exactly two foreign calls
+ * into the Cython package pyFlowSOM (/root/reference/src/ark/phenotyping/cluster_helpers.py:14):
+ *     som(data, xdim, ydim, rlen, alpha_range, seed)            cluster_helpers.py:106-109
+ *     map_data_to_nodes(weights, data)[0]                       cluster_helpers.py:152-157
+ * plus numpy/scipy/pandas loops for normalisation, blur, quantiles and per-cluster means
+ * (pixie_preprocessing.py:47-75, pixel_cluster_utils.py:16-142, 369-404).  Every entry point
+ * below names the reference interface it replaces.  INTEGRATION.md shows the ctypes binding a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the ABI; every function returns PXSOM_OK (0) or a negative
+ *     pxsom_status; pxsom_last_error() returns a thread-local message for the last failure.
+ *   - "dev" pointers are device (HBM) pointers owned by the caller (e.g. torch tensors'
+ *     data_ptr()); the library allocates nothing persistent.  Scratch comes from a caller
+ *     workspace sized by the matching *_workspace_bytes() query.
+ *   - every launch is ordered on the caller's stream (void* = hipStream_t; NULL = default
+ *     stream); calls are asynchronous unless documented otherwise; re-entrant per stream.
+ *   - matrices are row-major [rows, c] with a row stride ldx given in ELEMENTS.
+ *   - SOM nodes: node k = x*ydim + y on the xdim*ydim grid; labels are 1-based (k+1), as
+ *     pyFlowSOM returns them (tests/phenotyping/cluster_helpers_test.py:388-391 of the reference).
+ */
+#ifndef PXSOM_H
+#define PXSOM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PXSOM_ABI_VERSION 1
+
+typedef enum pxsom_status {
+    PXSOM_OK = 0,
+    PXSOM_ERR_INVALID_ARG = -1,
+    PXSOM_ERR_UNSUPPORTED = -2, /* shape / dtype outside what the kernels are built for */
+    PXSOM_ERR_WORKSPACE = -3,   /* workspace NULL or too small */
+    PXSOM_ERR_HIP = -4          /* a HIP runtime call failed; see pxsom_last_error() */
+} pxsom_status;
+
+typedef enum pxsom_dtype {
+    PXSOM_F32 = 0, /* IEEE binary32 pixel matrix (BASELINE.json configs 2-4) */
+    PXSOM_F64 = 1  /* IEEE binary64 pixel matrix (what the reference's feather tables hold) */
+} pxsom_dtype;
+
+/* Limits of the gfx950 kernels in this build. */
+#define PXSOM_MAX_CHANNELS 128
+#define PXSOM_MAX_NODES 1024
+
+int pxsom_abi_version(void);
+const char *pxsom_last_error(void);
+
+/* ---- host helper (no GPU) ------------------------------------------------------------------
+ * glibc rand() stream (TYPE_3 additive feedback), the presentation-order generator of the
+ * pyFlowSOM-compatible som() front end (replaces the libc srand/rand pair inside pyFlowSOM's
+ * Cython loop, cluster_helpers.py:106-109 passes `seed`). out[i] in [0, 2^31). */
+int pxsom_host_glibc_rand_fill(uint32_t seed, int64_t count, int32_t *out);
+
+/* ---- BMU assignment: replaces pyFlowSOM.map_data_to_nodes -----------------------------------
+ * reference: cluster_helpers.py:150-157 (PixieSOMCluster.generate_som_clusters).
+ * labels_dev[i] = 1 + argmin_k sqrt(sum_j (x_ij - w_kj)^2), evaluated as the reference does in
+ * binary64 with first-minimum tie-break; rows containing NaN get label 0 (FlowSOM's minid=-1).
+ *   x_dev      [n, c] row-major, dtype, row stride ldx elements
+ *   w_dev      [k, c] row-major binary64 codebook
+ *   labels_dev [n] int32 out
+ *   dist_dev   [n] binary64 out, or NULL (the reference discards it: `[0]` at :157)
+ * Mechanism: fp16-split MFMA filter + exact binary64 re-evaluation of every row whose two best
+ * scores are closer than a rigorous error bound (DESIGN.md "K7").  Result is independent of
+ * the filter: bit-identical to the oracle. */
+size_t pxsom_assign_workspace_bytes(int64_t n, int c, int k);
+int pxsom_assign(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev,
+                 int k, int32_t *labels_dev, double *dist_dev, void *workspace_dev,
+                 size_t workspace_bytes, void *stream);
+
+/* Number of rows the last pxsom_assign on this workspace sent to the exact binary64 path
+ * (diagnostic; synchronises the stream). */
+int pxsom_assign_last_exact_rows(const void *workspace_dev, void *stream, int64_t *out_rows);
+
+/* ---- per-cluster sums / counts: replaces the pandas groupby in compute_pixel_cluster_channel_avg
+ * reference: pixel_cluster_utils.py:369-404.  ADDS into sums_dev [k, c] binary64 and
+ * counts_dev [k] int64 (caller zeroes them; lets several FOVs / ranks accumulate):
+ *   sums[labels[i]-1, :] += x[i, :];  counts[labels[i]-1] += 1     (labels outside 1..k skipped)
+ * Also the accumulation half of the batch SOM rule (step 2 of DESIGN.md "K6b"). */
+int pxsom_cluster_sums(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype,
+                       const int32_t *labels_dev, int k, double *sums_dev, int64_t *counts_dev,
+                       void *stream);
+
+/* ---- exact online SOM training: replaces pyFlowSOM.som -------------------------------------
+ * reference: cluster_helpers.py:106-109 (PixieSOMCluster.train_som), FlowSOM C_SOM semantics:
+ * n*rlen strictly sequential steps; step t presents row order_dev[t]; Euclidean BMU (first
+ * minimum); every node within Chebyshev grid distance <= threshold of the BMU moves by
+ * alpha*(x - w); alpha and threshold decay linearly (a0->a1, r0->r1; threshold pinned to 0.5
+ * once below 1).  All arithmetic binary64, one rounding per operation, in the oracle's order.
+ *   w_dev [k=xdim*ydim, c] binary64, in: initial nodes, out: trained nodes
+ *   order_dev [n*rlen] int64 presentation order (explicit input, never generated here) */
+int pxsom_train_online(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, double *w_dev,
+                       int xdim, int ydim, int rlen, double a0, double a1, double r0, double r1,
+                       const int64_t *order_dev, void *stream);
+
+/* ---- batch SOM update (throughput mode; no pyFlowSOM analogue) ------------------------------
+ * Applies one mini-batch step from accumulated per-BMU sums/counts (already all-reduced across
+ * ranks by the caller):
+ *   num[k] = sum_{b: cheb(k,b) <= thr} sums[b], den[k] = sum_{b: ...} counts[b]
+ *   den[k] > 0:  w[k] += (1 - (1-alpha)^den[k]) * (num[k]/den[k] - w[k])
+ * Oracle of record: oracle/pxsom_oracle.c orc_batch_update. */
+int pxsom_batch_update(double *w_dev, int xdim, int ydim, int c, const double *sums_dev,
+                       const int64_t *counts_dev, double thr, double alpha, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PXSOM_H */

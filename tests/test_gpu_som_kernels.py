@@ -1,0 +1,199 @@
+"""Parity of the HIP kernels (through the C ABI) with the CPU oracle.  `-m gpu` only.
+
+Bars: BMU labels bit-exact; exact-online codebook bit-exact (asserted as equality of the
+binary64 arrays); batch-rule codebook / per-cluster tables within 1e-12 relative (far inside
+the 1e-5 of BASELINE.json's north_star; the slack is libm pow / atomic summation order).
+"""
+import numpy as np
+import pytest
+import torch
+
+from ark_analysis_amd import som_device as sd
+from ark_analysis_amd import synth
+from ark_analysis_amd.flowsom import default_radius_range
+
+pytestmark = pytest.mark.gpu
+
+
+def _codebook(x, k, seed=3):
+    rs = np.random.RandomState(seed)
+    idx = rs.choice(x.shape[0], size=k, replace=x.shape[0] < k)
+    return np.ascontiguousarray(x[idx].astype(np.float64))
+
+
+def _gpu_assign(gpu, x, w, want_dists=False):
+    xd = torch.from_numpy(x).to(gpu)
+    wd = torch.from_numpy(w).to(gpu)
+    labels, dists = sd.assign(xd, wd, want_dists=want_dists)
+    torch.cuda.synchronize()
+    return labels.cpu().numpy(), (dists.cpu().numpy() if dists is not None else None)
+
+
+@pytest.mark.parametrize("n,c,k,dtype", [
+    (100_003, 22, 100, np.float32),   # BASELINE config 2 shape (register-resident codebook path)
+    (50_001, 22, 100, np.float64),    # reference's own dtype
+    (20_000, 8, 100, np.float32),     # BASELINE config 1 shape
+    (4_097, 7, 100, np.float32),      # odd channel count: scalar-load path
+    (3_000, 40, 400, np.float32),     # config 5 shape: two channel chunks, 25 node blocks
+    (2_000, 100, 100, np.float32),    # config 4 (cell SOM) shape: four channel chunks
+    (1_500, 15, 200, np.float64),     # reference test shape (20x10 grid)
+    (777, 22, 25, np.float32),
+    (64, 3, 4, np.float32),
+    (1, 22, 100, np.float32),
+    (5, 22, 1, np.float32),
+])
+def test_assign_matches_oracle(gpu, oracle, n, c, k, dtype):
+    x = synth.make_fov_numpy(max(n, 2 * k), c, seed=11, dtype=dtype)[:n]
+    w = _codebook(synth.make_fov_numpy(4 * k + 50, c, seed=12, dtype=np.float64), k)
+    w += 1e-3 * np.random.RandomState(1).standard_normal(w.shape)
+    got, _ = _gpu_assign(gpu, x, w)
+    want, _ = oracle.map_data_to_nodes(w, x.astype(np.float64))
+    assert got.dtype == np.int32 and got.shape == (n,)
+    np.testing.assert_array_equal(got, want)
+    assert got.min() >= 1 and got.max() <= k
+
+
+def test_assign_empty(gpu):
+    x = torch.empty((0, 22), dtype=torch.float32, device=gpu)
+    w = torch.rand((100, 22), dtype=torch.float64, device=gpu)
+    labels, _ = sd.assign(x, w)
+    assert labels.numel() == 0
+
+
+def test_assign_exact_ties_and_near_ties(gpu, oracle):
+    """Duplicate codebook rows (exact ties -> first index wins), rows sitting exactly on nodes,
+    and rows within a few ulp of the midpoint between two nodes."""
+    c, k = 22, 100
+    base = synth.make_fov_numpy(5000, c, seed=21, dtype=np.float32)
+    w = _codebook(base.astype(np.float64), k, seed=5)
+    w[37] = w[3]          # exact duplicates: label must be 4, never 38
+    w[99] = w[98]
+    rows = [base[:2000]]
+    rows.append(w[[3, 37, 98, 99, 0, 50]].astype(np.float32))          # rows (nearly) on nodes
+    mid = (0.5 * (w[10] + w[11]))[None, :].repeat(200, axis=0)
+    mid += 1e-7 * np.random.RandomState(2).standard_normal(mid.shape)   # near-ties
+    rows.append(mid.astype(np.float32))
+    x = np.ascontiguousarray(np.concatenate(rows))
+    for dtype in (np.float32, np.float64):
+        xx = x.astype(dtype)
+        got, _ = _gpu_assign(gpu, xx, w)
+        want, _ = oracle.map_data_to_nodes(w, xx.astype(np.float64))
+        np.testing.assert_array_equal(got, want)
+    assert 38 not in got and 100 not in got
+
+
+def test_assign_identical_codebook_rows_all_ambiguous(gpu, oracle):
+    """Degenerate codebook: every row ties everywhere -> every row takes the exact path."""
+    x = synth.make_fov_numpy(3000, 22, seed=4)
+    w = np.tile(x[:1].astype(np.float64), (100, 1))
+    got, _ = _gpu_assign(gpu, x, w)
+    np.testing.assert_array_equal(got, np.ones(3000, dtype=np.int32))
+    assert sd.last_exact_rows(sd.assign.last_workspace) == 3000
+
+
+def test_assign_nonfinite_rows(gpu, oracle):
+    x = synth.make_fov_numpy(1000, 22, seed=6)
+    x[5, 3] = np.nan
+    x[17, :] = np.nan
+    x[40, 0] = np.inf
+    x[41, 2] = 1e30          # finite but far outside fp16 range: exact path, ordinary label
+    w = _codebook(x[100:].astype(np.float64), 100)
+    got, _ = _gpu_assign(gpu, x, w)
+    want, _ = oracle.map_data_to_nodes(w, x.astype(np.float64))
+    np.testing.assert_array_equal(got, want)
+    assert got[5] == 0 and got[17] == 0 and got[40] == 0 and got[41] >= 1
+
+
+def test_assign_large_and_tiny_magnitudes(gpu, oracle):
+    """Un-normalised scales (cell tables: counts / areas) must not break the fp16 filter."""
+    rs = np.random.RandomState(8)
+    for scale in (1e-6, 1e4):
+        x = (synth.make_fov_numpy(5000, 16, seed=9, dtype=np.float64) * scale)
+        w = _codebook(x, 100) * (1 + 1e-3 * rs.standard_normal((100, 16)))
+        got, _ = _gpu_assign(gpu, x, w)
+        want, _ = oracle.map_data_to_nodes(w, x)
+        np.testing.assert_array_equal(got, want)
+
+
+def test_assign_strided_rows_and_dists(gpu, oracle):
+    """ldx > c (mini-batch views x[t::M]) and the optional distance output."""
+    x = synth.make_fov_numpy(40_000, 22, seed=13)
+    w = _codebook(x.astype(np.float64), 100)
+    xd = torch.from_numpy(x).to(gpu)
+    wd = torch.from_numpy(w).to(gpu)
+    view = xd[3::7]
+    assert not view.is_contiguous()
+    labels, dists = sd.assign(view, wd, want_dists=True)
+    want_l, want_d = oracle.map_data_to_nodes(w, x[3::7].astype(np.float64))
+    np.testing.assert_array_equal(labels.cpu().numpy(), want_l)
+    np.testing.assert_array_equal(dists.cpu().numpy(), want_d)
+
+
+def test_cluster_sums_matches_oracle(gpu, oracle):
+    for (n, c, k, dtype) in [(100_000, 22, 100, np.float32), (30_000, 40, 400, np.float64),
+                             (999, 5, 7, np.float32)]:
+        x = synth.make_fov_numpy(n, c, seed=14, dtype=dtype)
+        labels = np.random.RandomState(1).randint(0, k + 1, size=n).astype(np.int32)  # 0 = skipped
+        s, cnt = sd.cluster_sums(torch.from_numpy(x).to(gpu), torch.from_numpy(labels).to(gpu), k)
+        ws, wc = oracle.cluster_sums(x.astype(np.float64), labels, k)
+        np.testing.assert_array_equal(cnt.cpu().numpy(), wc)
+        np.testing.assert_allclose(s.cpu().numpy(), ws, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("n,c,xdim,ydim,rlen,dtype", [
+    (20_000, 22, 10, 10, 1, np.float32),
+    (5_000, 22, 10, 10, 2, np.float64),
+    (3_000, 8, 10, 10, 1, np.float32),
+    (2_000, 15, 20, 10, 1, np.float64),   # reference test grid (cluster_helpers_test: xdim=20, ydim=10)
+    (1_000, 40, 20, 20, 1, np.float32),   # config 5 grid
+    (300, 4, 3, 2, 3, np.float32),
+])
+def test_train_online_bit_exact(gpu, oracle, n, c, xdim, ydim, rlen, dtype):
+    k = xdim * ydim
+    x = synth.make_fov_numpy(max(n, k), c, seed=15, dtype=dtype)[:n]
+    rs = np.random.RandomState(16)
+    w0 = np.ascontiguousarray(x[rs.choice(n, k, replace=n < k)].astype(np.float64))
+    order = rs.randint(0, n, size=n * rlen).astype(np.int64)
+    ar, rr = (0.05, 0.01), default_radius_range(xdim, ydim)
+    want = oracle.som_online(x.astype(np.float64), w0, xdim, ydim, rlen, ar, rr, order)
+    wd = torch.from_numpy(w0.copy()).to(gpu)
+    sd.train_online(torch.from_numpy(x).to(gpu), wd, xdim, ydim, rlen, ar, rr,
+                    torch.from_numpy(order).to(gpu))
+    got = wd.cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+
+
+def test_batch_update_matches_oracle(gpu, oracle):
+    rs = np.random.RandomState(17)
+    for (xdim, ydim, c) in [(10, 10, 22), (20, 20, 40), (3, 2, 4)]:
+        k = xdim * ydim
+        w = rs.uniform(size=(k, c))
+        sums = rs.uniform(size=(k, c)) * 50
+        counts = rs.randint(0, 100, size=k).astype(np.int64)
+        counts[::7] = 0
+        for thr, alpha in [(6.0, 0.05), (1.2, 0.03), (0.5, 0.01)]:
+            want = oracle.batch_update(w, xdim, ydim, sums, counts, thr, alpha)
+            wd = torch.from_numpy(w.copy()).to(gpu)
+            sd.batch_update(wd, xdim, ydim, torch.from_numpy(sums).to(gpu),
+                            torch.from_numpy(counts).to(gpu), thr, alpha)
+            np.testing.assert_allclose(wd.cpu().numpy(), want, rtol=1e-12, atol=0)
+
+
+def test_assign_full_size_sampled_against_oracle(gpu, oracle):
+    """BASELINE config 2 size on one GPU (10 x 1024^2 x 22 fp32, K=100): rows are independent, so
+    the oracle on a random sample of rows must agree exactly; plus idempotence and range."""
+    n, c, k = 10 * 1024 * 1024, 22, 100
+    x = synth.make_fov_torch(n, c, seed=1000, device=gpu)
+    wd = x[torch.randperm(n, device=gpu)[:k]].to(torch.float64).contiguous()
+    labels, _ = sd.assign(x, wd)
+    labels2, _ = sd.assign(x, wd)
+    assert torch.equal(labels, labels2)
+    assert int(labels.min()) >= 1 and int(labels.max()) <= k
+    exact_rows = sd.last_exact_rows(sd.assign.last_workspace)
+    assert exact_rows < n // 20, f"{exact_rows} of {n} rows took the exact path"
+    idx = torch.randperm(n, device=gpu)[:200_000]
+    want, _ = oracle.map_data_to_nodes(wd.cpu().numpy(), x[idx].double().cpu().numpy())
+    np.testing.assert_array_equal(labels[idx].cpu().numpy(), want)
+    # checksum of checksums: per-cluster counts add up to n
+    _, cnt = sd.cluster_sums(x, labels, k)
+    assert int(cnt.sum()) == n
