@@ -10,7 +10,10 @@ import subprocess
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 SO_PATH = os.path.join(_PKG, "libpxsom.so")
-SOURCES = ["pxsom_api.hip", "pxsom_assign.hip", "pxsom_train.hip", "pxsom_pre.hip"]
+SOURCES = ["pxsom_api.hip", "pxsom_assign.hip", "pxsom_assign_filter.hip", "pxsom_train.hip",
+           "pxsom_pre.hip"]
+# per-file extra flags: the filter works on provably finite scores (see the file header)
+EXTRA_FLAGS = {"pxsom_assign_filter.hip": ["-ffinite-math-only"]}
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
                "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
 
@@ -27,7 +30,8 @@ def needs_build() -> bool:
         return True
     so_m = os.path.getmtime(SO_PATH)
     deps = [os.path.join(_PKG, "csrc", s) for s in SOURCES if os.path.exists(os.path.join(_PKG, "csrc", s))]
-    deps += [os.path.join(_PKG, "csrc", "pxsom_common.h"), os.path.join(_ROOT, "include", "pxsom.h")]
+    deps += [os.path.join(_PKG, "csrc", "pxsom_common.h"), os.path.join(_PKG, "csrc", "pxsom_assign.h"),
+             os.path.join(_ROOT, "include", "pxsom.h")]
     return any(os.path.getmtime(d) > so_m for d in deps)
 
 
@@ -45,7 +49,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if not os.path.exists(sp):
             continue
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc, *HIPCC_FLAGS, "-I", os.path.join(_ROOT, "include"), "-I",
+        cmd = [hipcc, *HIPCC_FLAGS, *EXTRA_FLAGS.get(src, []), "-I", os.path.join(_ROOT, "include"), "-I",
                os.path.join(_PKG, "csrc"), "-c", sp, "-o", obj]
         if verbose:
             print(" ".join(cmd))

@@ -25,6 +25,10 @@ _vp, _i32, _i64, _f64, _sz = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, cty
 SYMBOLS = {
     "pxsom_abi_version": (_i32, []),
     "pxsom_last_error": (ctypes.c_char_p, []),
+    "pxsom_prof_create": (_i32, [ctypes.POINTER(ctypes.c_void_p)]),
+    "pxsom_prof_destroy": (_i32, [_vp]),
+    "pxsom_prof_attach": (_i32, [_vp, _i64]),
+    "pxsom_prof_collect": (_i32, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
     "pxsom_host_glibc_rand_fill": (_i32, [ctypes.c_uint32, _i64, _vp]),
     "pxsom_assign_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "pxsom_assign": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
@@ -97,3 +101,32 @@ def glibc_rand(seed: int, count: int):
     check(lib().pxsom_host_glibc_rand_fill(int(seed) & 0xFFFFFFFF, int(count),
                                            out.ctypes.data), "pxsom_host_glibc_rand_fill")
     return out
+
+
+class KernelTimer:
+    """HIP-event timer around the BMU filter kernel of every assign call with >= min_rows rows."""
+
+    def __init__(self, min_rows: int = 0):
+        self._h = ctypes.c_void_p()
+        check(lib().pxsom_prof_create(ctypes.byref(self._h)), "pxsom_prof_create")
+        self.min_rows = int(min_rows)
+
+    def __enter__(self):
+        check(lib().pxsom_prof_attach(self._h, self.min_rows), "pxsom_prof_attach")
+        return self
+
+    def __exit__(self, *exc):
+        lib().pxsom_prof_attach(None, 0)
+
+    def collect(self):
+        """(total_ms, launches) since the last collect/attach; synchronises."""
+        ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
+        check(lib().pxsom_prof_collect(self._h, ctypes.byref(ms), ctypes.byref(cnt)),
+              "pxsom_prof_collect")
+        return ms.value, cnt.value
+
+    def __del__(self):
+        try:
+            lib().pxsom_prof_destroy(self._h)
+        except Exception:
+            pass

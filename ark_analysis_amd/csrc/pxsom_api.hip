@@ -1,5 +1,7 @@
 // pxsom_api.hip -- ABI bookkeeping + host-only helpers of libpxsom.so.
 #include <cstring>
+#include <utility>
+#include <vector>
 
 #include "pxsom_common.h"
 
@@ -32,7 +34,85 @@ int device_cu_count()
     return cached;
 }
 
+struct Prof {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    size_t used = 0;
+    int64_t min_rows = 0;
+    bool open = false;
+};
+
+static thread_local Prof *g_prof = nullptr;
+
+Prof *current_prof() { return g_prof; }
+
+void prof_mark(Prof *p, hipStream_t st, bool start, int64_t rows)
+{
+    if (!p || rows < p->min_rows) return;
+    if (start) {
+        if (p->used == p->ev.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            p->ev.emplace_back(a, b);
+        }
+        (void)hipEventRecord(p->ev[p->used].first, st);
+        p->open = true;
+    } else if (p->open) {
+        (void)hipEventRecord(p->ev[p->used].second, st);
+        p->used++;
+        p->open = false;
+    }
+}
+
 }  // namespace pxsom
+
+PXSOM_EXPORT int pxsom_prof_create(void **out)
+{
+    if (!out) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_prof_create: null");
+    *out = new pxsom::Prof();
+    return PXSOM_OK;
+}
+
+PXSOM_EXPORT int pxsom_prof_destroy(void *h)
+{
+    auto *p = reinterpret_cast<pxsom::Prof *>(h);
+    if (!p) return PXSOM_OK;
+    if (pxsom::g_prof == p) pxsom::g_prof = nullptr;
+    for (auto &e : p->ev) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    delete p;
+    return PXSOM_OK;
+}
+
+PXSOM_EXPORT int pxsom_prof_attach(void *h, int64_t min_rows)
+{
+    auto *p = reinterpret_cast<pxsom::Prof *>(h);
+    pxsom::g_prof = p;
+    if (p) {
+        p->min_rows = min_rows;
+        p->used = 0;
+        p->open = false;
+    }
+    return PXSOM_OK;
+}
+
+PXSOM_EXPORT int pxsom_prof_collect(void *h, double *total_ms, int64_t *launches)
+{
+    auto *p = reinterpret_cast<pxsom::Prof *>(h);
+    if (!p || !total_ms || !launches) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_prof_collect: null");
+    double tot = 0.0;
+    for (size_t i = 0; i < p->used; i++) {
+        PXSOM_HIP_TRY(hipEventSynchronize(p->ev[i].second));
+        float ms = 0.f;
+        PXSOM_HIP_TRY(hipEventElapsedTime(&ms, p->ev[i].first, p->ev[i].second));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = (int64_t)p->used;
+    p->used = 0;
+    return PXSOM_OK;
+}
 
 PXSOM_EXPORT int pxsom_abi_version(void) { return PXSOM_ABI_VERSION; }
 

@@ -1,0 +1,62 @@
+// pxsom_assign.h -- declarations shared by the BMU-assignment translation units.
+#pragma once
+#include "pxsom_common.h"
+
+namespace pxsom_bmu {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kHdrBytes = 256;
+constexpr int kTilesPerIter = 4;  // 4 tiles x 16 pixels = one 64-row group per wave iteration
+constexpr float kNegBig = -3.0e38f;
+
+// workspace header (one per pxsom_assign workspace)
+struct AssignHdr {
+    unsigned amb_count;   // rows appended to the exact list by the filter kernel
+    float scale;          // power-of-two scale applied to x and w before the fp16 split
+    float wn_max;         // max_k |scale*w_k|_2, rounded up
+    float tol_rel;        // tol = tol_rel * (|X|*wn_max + 0.5*wn_max^2) + tol_abs*(|X| + wn_max)
+    float tol_abs;
+    float x_limit;        // rows with |X|_2 >= x_limit (or non-finite) go to the exact path
+    int nb;               // node blocks of 16
+    int nch;              // 32-slot channel chunks
+    int cpl;              // channels per lane per chunk (even, <= 8)
+    int idx_bits;
+    int node_bits;        // bits of the node index packed into the winner at the cross-lane merge
+    int force_exact;      // codebook not representable by the filter: list every row
+};
+
+struct Layout {
+    int nb, nch, cpl, nsteps, idx_bits, node_bits;
+    size_t off_wfrag, off_bias, off_list, total;
+};
+
+inline Layout make_layout(int64_t n, int c, int k)
+{
+    Layout L;
+    L.nb = (k + 15) / 16;
+    L.nch = (c + 31) / 32;
+    int per_chunk = (c + L.nch - 1) / L.nch;          // channels per chunk
+    int cpl = (per_chunk + 3) / 4;                     // per lane (4 lane groups)
+    cpl = (cpl + 1) & ~1;                              // even, so float2/double2 loads stay aligned
+    if (cpl > 8) cpl = 8;
+    L.cpl = cpl;
+    L.nsteps = 2 * L.nch;  // stored fragments per node block: {Wh, Wl} per chunk
+    L.idx_bits = L.nb <= 16 ? 6 : 10;
+    L.node_bits = 4;
+    while ((1 << L.node_bits) < L.nb * 16) L.node_bits++;
+    L.off_wfrag = kHdrBytes;
+    L.off_bias = L.off_wfrag + (size_t)L.nb * L.nsteps * 64 * sizeof(half8);
+    L.off_list = pxsom::align_up(L.off_bias + (size_t)L.nb * 64 * sizeof(f32x4), 256);
+    L.total = L.off_list + (size_t)(n > 0 ? n : 1) * sizeof(unsigned);
+    return L;
+}
+
+
+// filter stage (pxsom_assign_filter.hip, compiled with -ffinite-math-only)
+template <typename T>
+void launch_filter_any(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L,
+                       int32_t *labels, hipStream_t st);
+
+}  // namespace pxsom_bmu

@@ -20,61 +20,19 @@
 #include <cfloat>
 #include <cmath>
 
-#include "pxsom_common.h"
+#include "pxsom_assign.h"
+
+using namespace pxsom_bmu;
 
 namespace {
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kHdrBytes = 256;
-constexpr int kTilesPerIter = 4;  // 4 tiles x 16 pixels = one 64-row group per wave iteration
-constexpr float kNegBig = -3.0e38f;
-
-// workspace header (one per pxsom_assign workspace)
-struct AssignHdr {
-    unsigned amb_count;   // rows appended to the exact list by the filter kernel
-    float scale;          // power-of-two scale applied to x and w before the fp16 split
-    float wn_max;         // max_k |scale*w_k|_2, rounded up
-    float tol_rel;        // tol = tol_rel * (|X|*wn_max + 0.5*wn_max^2) + tol_abs*(|X| + wn_max)
-    float tol_abs;
-    float x_limit;        // rows with |X|_2 >= x_limit (or non-finite) go to the exact path
-    int nb;               // node blocks of 16
-    int nch;              // 32-slot channel chunks
-    int cpl;              // channels per lane per chunk (even, <= 8)
-    int idx_bits;
-};
-
-struct Layout {
-    int nb, nch, cpl, nsteps, idx_bits;
-    size_t off_wfrag, off_bias, off_list, total;
-};
-
-inline Layout make_layout(int64_t n, int c, int k)
-{
-    Layout L;
-    L.nb = (k + 15) / 16;
-    L.nch = (c + 31) / 32;
-    int per_chunk = (c + L.nch - 1) / L.nch;          // channels per chunk
-    int cpl = (per_chunk + 3) / 4;                     // per lane (4 lane groups)
-    cpl = (cpl + 1) & ~1;                              // even, so float2/double2 loads stay aligned
-    if (cpl > 8) cpl = 8;
-    L.cpl = cpl;
-    L.nsteps = 2 * L.nch;  // stored fragments per node block: {Wh, Wl} per chunk
-    L.idx_bits = L.nb <= 16 ? 6 : 10;
-    L.off_wfrag = kHdrBytes;
-    L.off_bias = L.off_wfrag + (size_t)L.nb * L.nsteps * 64 * sizeof(half8);
-    L.off_list = pxsom::align_up(L.off_bias + (size_t)L.nb * 64 * sizeof(f32x4), 256);
-    L.total = L.off_list + (size_t)(n > 0 ? n : 1) * sizeof(unsigned);
-    return L;
-}
 
 // ------------------------------------------------------------------------------------------------
 // 1. prep: one workgroup of 256 threads.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict__ w, int k, int c,
                                                        AssignHdr *hdr, half8 *wfrag, f32x4 *bias,
-                                                       int nb, int nch, int cpl, int idx_bits)
+                                                       int nb, int nch, int cpl, int idx_bits,
+                                                       int node_bits)
 {
     __shared__ double s_norm2[PXSOM_MAX_NODES];
     __shared__ double s_red[256];
@@ -128,12 +86,14 @@ __global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict_
         hdr->amb_count = 0;
         hdr->scale = (float)scale;
         // rounded up by a hair; an infinite wn_max makes every row take the exact path
-        hdr->wn_max = bad ? INFINITY : (float)(sqrt(s_red[0]) * scale * (1.0 + 1e-6));
+        hdr->wn_max = bad ? 0.f : (float)(sqrt(s_red[0]) * scale * (1.0 + 1e-6));
+        hdr->force_exact = bad ? 1 : 0;  // NaN/Inf/huge codebook: every row takes the exact path
         // coefficient of the rigorous |filter - exact| bound, see DESIGN.md "K7 error bound":
         //   index packing 2^-(23-idx_bits), fp32 accumulation (3C+2)*2^-24, split residual 2^-19,
         //   f64->f32 input rounding 2^-23;  tol = 2 * 1.25 * E
-        const double coef = ldexp(1.0, -(23 - idx_bits)) + (3.0 * c + 2.0) * ldexp(1.0, -24) +
-                            ldexp(1.0, -19) + ldexp(1.0, -23);
+        // (the cross-lane merge re-packs the winner's low node_bits bits, counted separately)
+        const double coef = ldexp(1.0, -(23 - idx_bits)) + ldexp(1.0, -(23 - node_bits)) +
+                            (3.0 * c + 2.0) * ldexp(1.0, -24) + ldexp(1.0, -19) + ldexp(1.0, -23);
         hdr->tol_rel = (float)(2.5 * coef);
         hdr->tol_abs = (float)(2.5 * ldexp(1.0, -24) * sqrt((double)c));  // fp16 subnormal floor
         hdr->x_limit = 60000.0f;
@@ -141,6 +101,7 @@ __global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict_
         hdr->nch = nch;
         hdr->cpl = cpl;
         hdr->idx_bits = idx_bits;
+        hdr->node_bits = node_bits;
     }
 
     // A-fragments: wfrag[(b*nsteps + s)*64 + lane], lane = (q<<4 | m): node 16b+m,
@@ -170,216 +131,6 @@ __global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict_
             bv[r] = node < k ? (float)(-0.5 * s_norm2[node] * scale * scale) : kNegBig;
         }
         bias[f] = bv;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// 2. filter
-// ------------------------------------------------------------------------------------------------
-template <typename T>
-struct Pair;
-template <>
-struct Pair<float> {
-    typedef float2 type;
-};
-template <>
-struct Pair<double> {
-    typedef double2 type;
-};
-
-__device__ __forceinline__ float pack_idx(float v, unsigned idx, unsigned mask)
-{
-    return __uint_as_float((__float_as_uint(v) & ~mask) | idx);
-}
-
-// NB_T > 0: codebook fragments + bias live in registers (NCH_T*2*NB_T*4 + NB_T*4 VGPRs);
-// NB_T == 0: fragments are streamed from the workspace (L1/L2 resident), any K.
-// CPL_T > 0: compile-time channels-per-lane; 0: runtime.
-// PREFETCH: the next 64-row group's loads are issued before the current group's MFMA work.
-template <typename T, int NCH_T, int CPL_T, int NB_T, bool VEC2, bool PREFETCH>
-__global__ __launch_bounds__(256, 2) void bmu_filter_kernel(
-    const T *__restrict__ x, int64_t n, int c, int64_t ldx, const half8 *__restrict__ wfrag,
-    const f32x4 *__restrict__ bias, AssignHdr *hdr, unsigned *__restrict__ amb_list,
-    int32_t *__restrict__ labels)
-{
-    constexpr int NCH = NCH_T;
-    constexpr int NFR = 2 * NCH;  // stored fragments per node block
-    constexpr int CPLMAX = CPL_T > 0 ? CPL_T : 8;
-    const int cpl = CPL_T > 0 ? CPL_T : hdr->cpl;
-    const int nb = NB_T > 0 ? NB_T : hdr->nb;
-    const unsigned idx_mask = NB_T > 0 ? 63u : ((1u << hdr->idx_bits) - 1u);
-    const float scale = hdr->scale, wn_max = hdr->wn_max, tol_rel = hdr->tol_rel,
-                tol_abs = hdr->tol_abs, x_limit = hdr->x_limit;
-
-    const int lane = threadIdx.x & 63;
-    const int pix = lane & 15, q = lane >> 4;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
-    const int64_t ngroups = (n + 63) / 64;
-
-    // register-resident codebook
-    half8 wreg[NB_T > 0 ? NB_T : 1][NFR];
-    f32x4 breg[NB_T > 0 ? NB_T : 1];
-    if constexpr (NB_T > 0) {
-#pragma unroll
-        for (int b = 0; b < NB_T; b++) {
-#pragma unroll
-            for (int s = 0; s < NFR; s++) wreg[b][s] = wfrag[(b * NFR + s) * 64 + lane];
-            breg[b] = bias[b * 64 + lane];
-        }
-    }
-
-    // dst[h][i]: channel h*4*cpl + q*cpl + i of row g*64 + t*16 + pix
-    auto load_tile = [&](int64_t g, int t, T(&dst)[NCH][CPLMAX]) {
-        const int64_t row = g * 64 + t * 16 + pix;
-        const bool rok = row < n;
-        const T *rp = x + row * ldx;
-#pragma unroll
-        for (int h = 0; h < NCH; h++) {
-            const int ch0 = h * 4 * cpl + q * cpl;
-            if constexpr (VEC2) {
-#pragma unroll
-                for (int i = 0; i < CPLMAX; i += 2) {
-                    typename Pair<T>::type v;
-                    v.x = (T)0;
-                    v.y = (T)0;
-                    if (rok && i < cpl && ch0 + i < c)
-                        v = *reinterpret_cast<const typename Pair<T>::type *>(rp + ch0 + i);
-                    dst[h][i] = v.x;
-                    dst[h][i + 1] = v.y;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < CPLMAX; i++) {
-                    T v = (T)0;
-                    if (rok && i < cpl && ch0 + i < c) v = rp[ch0 + i];
-                    dst[h][i] = v;
-                }
-            }
-        }
-    };
-
-    T raw[PREFETCH ? kTilesPerIter : 1][NCH][CPLMAX];
-
-    int64_t g = wave;
-    if constexpr (PREFETCH) {
-        if (g < ngroups) {
-#pragma unroll
-            for (int t = 0; t < kTilesPerIter; t++) load_tile(g, t, raw[t]);
-        }
-    }
-    for (; g < ngroups; g += nwaves) {
-        half8 bh[PREFETCH ? kTilesPerIter : 1][NCH], bl[PREFETCH ? kTilesPerIter : 1][NCH];
-        float ss[PREFETCH ? kTilesPerIter : 1];
-        auto convert = [&](int slot) {
-            float acc2 = 0.f;
-#pragma unroll
-            for (int h = 0; h < NCH; h++) {
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    float xf = 0.f;
-                    if (i < CPLMAX) xf = (float)raw[slot][h][i < CPLMAX ? i : 0] * scale;
-                    acc2 = fmaf(xf, xf, acc2);
-                    const _Float16 hi = (_Float16)xf;
-                    bh[slot][h][i] = hi;
-                    bl[slot][h][i] = (_Float16)(xf - (float)hi);
-                }
-            }
-            ss[slot] = acc2;
-        };
-        if constexpr (PREFETCH) {
-            // convert the current group's rows to fp16 hi/lo B-fragments, then prefetch the next
-#pragma unroll
-            for (int t = 0; t < kTilesPerIter; t++) convert(t);
-            const int64_t gnext = g + nwaves;
-            if (gnext < ngroups) {
-#pragma unroll
-                for (int t = 0; t < kTilesPerIter; t++) load_tile(gnext, t, raw[t]);
-            }
-        }
-
-        int my_label = 0;
-        bool my_amb = false;
-#pragma unroll
-        for (int t = 0; t < kTilesPerIter; t++) {
-            const int slot = PREFETCH ? t : 0;
-            if constexpr (!PREFETCH) {
-                load_tile(g, t, raw[0]);
-                convert(0);
-            }
-            float m1 = kNegBig, m2 = kNegBig;
-            auto consume = [&](const f32x4 &acc, int b) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const float v = pack_idx(acc[r], (unsigned)(b * 4 + r), idx_mask);
-                    m2 = __builtin_amdgcn_fmed3f(m1, m2, v);
-                    m1 = fmaxf(m1, v);
-                }
-            };
-            // per chunk: Wh*Xh + Wh*Xl + Wl*Xh
-            if constexpr (NB_T > 0) {
-#pragma unroll
-                for (int b = 0; b < NB_T; b++) {
-                    f32x4 acc = breg[b];
-#pragma unroll
-                    for (int h = 0; h < NCH; h++) {
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b][2 * h], bh[slot][h], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b][2 * h], bl[slot][h], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b][2 * h + 1], bh[slot][h], acc, 0, 0, 0);
-                    }
-                    consume(acc, b);
-                }
-            } else {
-                for (int b = 0; b < nb; b++) {
-                    f32x4 acc = bias[b * 64 + lane];
-#pragma unroll
-                    for (int h = 0; h < NCH; h++) {
-                        const half8 wh = wfrag[(b * NFR + 2 * h) * 64 + lane];
-                        const half8 wl = wfrag[(b * NFR + 2 * h + 1) * 64 + lane];
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh[slot][h], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl[slot][h], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh[slot][h], acc, 0, 0, 0);
-                    }
-                    consume(acc, b);
-                }
-            }
-            // packed register index -> node index 16b + 4q + r
-            const unsigned idx = __float_as_uint(m1) & idx_mask;
-            int node = (int)(((idx >> 2) << 4) | ((unsigned)q << 2) | (idx & 3u));
-            float s2 = ss[slot];
-            // merge the 4 lane groups that share this pixel (lanes pix, pix+16, pix+32, pix+48)
-#pragma unroll
-            for (int off = 16; off <= 32; off <<= 1) {
-                const float o1 = __shfl_xor(m1, off);
-                const float o2 = __shfl_xor(m2, off);
-                const int on = __shfl_xor(node, off);
-                s2 += __shfl_xor(s2, off);
-                const bool take = (o1 > m1) || (o1 == m1 && on < node);
-                m2 = fmaxf(fminf(m1, o1), fmaxf(m2, o2));
-                m1 = take ? o1 : m1;
-                node = take ? on : node;
-            }
-            const float xn = sqrtf(s2);
-            const float tol = tol_rel * (xn * wn_max + 0.5f * wn_max * wn_max) + tol_abs * (xn + wn_max);
-            // NaN-safe: anything not provably unique goes to the exact path
-            const bool amb = !((m1 - m2) > tol) || !(xn < x_limit);
-            if (q == t) {
-                my_label = node + 1;
-                my_amb = amb;
-            }
-        }
-        // lane (q, pix) now owns row g*64 + q*16 + pix == g*64 + lane
-        const int64_t row = g * 64 + lane;
-        const bool valid = row < n;
-        if (valid) labels[row] = my_label;
-        const bool push = valid && my_amb;
-        const unsigned long long mask = __ballot(push);
-        if (mask) {
-            unsigned base = 0;
-            if (lane == 0) base = atomicAdd(&hdr->amb_count, (unsigned)__popcll(mask));
-            base = __shfl(base, 0);
-            if (push) amb_list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned)row;
-        }
     }
 }
 
@@ -465,49 +216,20 @@ __global__ __launch_bounds__(256) void bmu_dist_kernel(const T *__restrict__ x, 
 }
 #pragma clang fp contract(fast)
 
-template <typename T, int NCH, int CPL, int NB, bool VEC2>
-void launch_filter(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels,
-                   hipStream_t st, int grid)
-{
-    hipLaunchKernelGGL((bmu_filter_kernel<T, NCH, CPL, NB, VEC2, (NCH == 1)>), dim3(grid), dim3(256), 0, st, x, n, c,
-                       ldx, reinterpret_cast<const half8 *>(ws + L.off_wfrag),
-                       reinterpret_cast<const f32x4 *>(ws + L.off_bias), reinterpret_cast<AssignHdr *>(ws),
-                       reinterpret_cast<unsigned *>(ws + L.off_list), labels);
-}
-
 template <typename T>
 int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int k, int32_t *labels,
                  double *dist, char *ws, const Layout &L, hipStream_t st)
 {
     hipLaunchKernelGGL(bmu_prep_kernel, dim3(1), dim3(256), 0, st, w, k, c, reinterpret_cast<AssignHdr *>(ws),
                        reinterpret_cast<half8 *>(ws + L.off_wfrag), reinterpret_cast<f32x4 *>(ws + L.off_bias),
-                       L.nb, L.nch, L.cpl, L.idx_bits);
+                       L.nb, L.nch, L.cpl, L.idx_bits, L.node_bits);
     PXSOM_LAUNCH_CHECK("bmu_prep_kernel");
 
     const int cus = pxsom::device_cu_count();
-    const int64_t ngroups = (n + 63) / 64;
-    int grid = (int)std::min<int64_t>((ngroups + 3) / 4, (int64_t)cus * 2);
-    if (grid < 1) grid = 1;
-    // pair loads need 2-element alignment of every row start and of the base pointer
-    const bool vec2 = (c % 2 == 0) && (ldx % 2 == 0) &&
-                      (reinterpret_cast<uintptr_t>(x) % (2 * sizeof(T)) == 0);
-    // headline shape (BASELINE.json configs 2/3: C=22, K=100): register-resident codebook
-    if (vec2 && L.nch == 1 && L.cpl == 6 && L.nb == 7)
-        launch_filter<T, 1, 6, 7, true>(x, n, c, ldx, ws, L, labels, st, grid);
-    else if (vec2 && L.nch == 1 && L.cpl == 2 && L.nb == 7)  // config 1 (C=8, K=100)
-        launch_filter<T, 1, 2, 7, true>(x, n, c, ldx, ws, L, labels, st, grid);
-    else if (L.nch == 1)
-        vec2 ? launch_filter<T, 1, 0, 0, true>(x, n, c, ldx, ws, L, labels, st, grid)
-             : launch_filter<T, 1, 0, 0, false>(x, n, c, ldx, ws, L, labels, st, grid);
-    else if (L.nch == 2)
-        vec2 ? launch_filter<T, 2, 0, 0, true>(x, n, c, ldx, ws, L, labels, st, grid)
-             : launch_filter<T, 2, 0, 0, false>(x, n, c, ldx, ws, L, labels, st, grid);
-    else if (L.nch == 3)
-        vec2 ? launch_filter<T, 3, 0, 0, true>(x, n, c, ldx, ws, L, labels, st, grid)
-             : launch_filter<T, 3, 0, 0, false>(x, n, c, ldx, ws, L, labels, st, grid);
-    else
-        vec2 ? launch_filter<T, 4, 0, 0, true>(x, n, c, ldx, ws, L, labels, st, grid)
-             : launch_filter<T, 4, 0, 0, false>(x, n, c, ldx, ws, L, labels, st, grid);
+    pxsom::Prof *prof = pxsom::current_prof();
+    pxsom::prof_mark(prof, st, true, n);
+    launch_filter_any<T>(x, n, c, ldx, ws, L, labels, st);
+    pxsom::prof_mark(prof, st, false, n);
     PXSOM_LAUNCH_CHECK("bmu_filter_kernel");
 
     const size_t wt_bytes = (size_t)k * c * sizeof(double);

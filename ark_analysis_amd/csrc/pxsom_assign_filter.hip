@@ -1,0 +1,371 @@
+// pxsom_assign_filter.hip -- stage 2 of K7: the streaming fp16-split MFMA filter (gfx950).
+//
+// Compiled with -ffinite-math-only (see _build.py): the scores handled here are provably finite
+// whenever a row is *not* sent to the exact path, so fmaxf/fminf lower to bare v_max_f32 /
+// v_max3_f32 / v_min_f32 (no canonicalising v_max v,v in front of every bit-packed operand) and
+// stay visible to the instruction scheduler.  Non-finite input rows are detected with integer
+// tests on the squared-norm's bit pattern, which no floating-point assumption can fold away.
+//
+// Work decomposition (one wave, one iteration = 64 rows = 4 tiles of 16 pixels):
+//   lane = (q << 4) | pix.  MFMA v_mfma_f32_16x16x32_f16:  D[node 16][pixel 16] += A[node][k 32] B[k][pixel]
+//   A = codebook fragment of node block b (lane holds node b*16+pix... see prep), B = pixel rows:
+//   lane (q, pix) holds k-slots q*8..q*8+7 = channels q*cpl .. q*cpl+cpl-1 of pixel `pix`.
+//   D: lane (q, pix) holds scores of pixel `pix` for nodes 16b + 4q + r, r = 0..3.
+//   Score s = X.W - |W|^2/2 with the 3-term split  Xh*Wh + Xl*Wh + Xh*Wl  (three MFMAs per block).
+// Two tiles are in flight at once so each accumulator's 3-MFMA chain is interleaved with an
+// independent one; the register-local top-2 (2.5 VALU ops per score) of a block overlaps the next
+// block's MFMAs.
+#include <cfloat>
+#include <cmath>
+
+#include "pxsom_assign.h"
+
+namespace pxsom_bmu {
+namespace {
+
+template <typename T>
+struct Pair;
+template <>
+struct Pair<float> {
+    typedef float2 type;
+};
+template <>
+struct Pair<double> {
+    typedef double2 type;
+};
+
+__device__ __forceinline__ float pack_idx(float v, unsigned idx, unsigned mask)
+{
+    return __uint_as_float((__float_as_uint(v) & ~mask) | idx);
+}
+
+// {own, partner} of a value across lanes l <-> l^16 / l^32, in lane-dependent order: only ever fed
+// to symmetric functions (max/min/add), so no select is needed.  VALU only, no LDS crossbar.
+struct F2 {
+    float a, b;
+};
+__device__ __forceinline__ F2 xchg16(float v)
+{
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return {__uint_as_float(r[0]), __uint_as_float(r[1])};
+}
+__device__ __forceinline__ F2 xchg32(float v)
+{
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return {__uint_as_float(r[0]), __uint_as_float(r[1])};
+}
+
+// running top-2 (m1 >= m2) absorbs two values per update:
+//   m1' = max3(m1, a, b);   m2' = max(med3(m1, a, b), m2)
+__device__ __forceinline__ void top2_pair(float &m1, float &m2, float a, float b)
+{
+    const float tm = __builtin_amdgcn_fmed3f(m1, a, b);
+    m1 = fmaxf(fmaxf(m1, a), b);
+    m2 = fmaxf(tm, m2);
+}
+
+__device__ __forceinline__ void consume(float &m1, float &m2, const f32x4 &acc, int b, unsigned idx_mask)
+{
+    const float p0 = pack_idx(acc[0], (unsigned)(b * 4 + 0), idx_mask);
+    const float p1 = pack_idx(acc[1], (unsigned)(b * 4 + 1), idx_mask);
+    const float p2 = pack_idx(acc[2], (unsigned)(b * 4 + 2), idx_mask);
+    const float p3 = pack_idx(acc[3], (unsigned)(b * 4 + 3), idx_mask);
+    top2_pair(m1, m2, p0, p1);
+    top2_pair(m1, m2, p2, p3);
+}
+
+// NB_T > 0: codebook fragments + bias live in registers (NCH_T*2*NB_T*4 + NB_T*4 VGPRs);
+// NB_T == 0: fragments are streamed from the workspace (L1/L2 resident), any K.
+// CPL_T > 0: compile-time channels-per-lane; 0: runtime.
+// PREFETCH: the next 64-row group's loads are issued before the current group's MFMA work.
+// TP: tiles in flight (2 for the register-resident shapes, 1 otherwise).
+//
+// Loads never branch: rows past n are clamped to row n-1 (their results are discarded) and
+// channel slots past c re-read the row's last valid pair (their codebook slots are zero).
+template <typename T, int NCH_T, int CPL_T, int NB_T, bool VEC2, bool PREFETCH, int TP>
+__global__ __launch_bounds__(256, 2) void bmu_filter_kernel(
+    const T *__restrict__ x, int64_t n, int c, int64_t ldx, const half8 *__restrict__ wfrag,
+    const f32x4 *__restrict__ bias, AssignHdr *hdr, unsigned *__restrict__ amb_list,
+    int32_t *__restrict__ labels)
+{
+    constexpr int NCH = NCH_T;
+    constexpr int NFR = 2 * NCH;  // stored fragments per node block
+    constexpr int CPLMAX = CPL_T > 0 ? CPL_T : 8;
+    const int cpl = CPL_T > 0 ? CPL_T : hdr->cpl;
+    const int nb = NB_T > 0 ? NB_T : hdr->nb;
+    const unsigned idx_mask = NB_T > 0 ? 63u : ((1u << hdr->idx_bits) - 1u);
+    const unsigned node_mask = NB_T > 0 ? ((NB_T * 16 <= 64) ? 63u : (NB_T * 16 <= 128 ? 127u : 255u))
+                                        : ((1u << hdr->node_bits) - 1u);
+    const float scale = hdr->scale, wn_max = hdr->wn_max, tol_rel = hdr->tol_rel,
+                tol_abs = hdr->tol_abs, x_limit = hdr->x_limit;
+    const bool force_exact = hdr->force_exact != 0;
+
+    const int lane = threadIdx.x & 63;
+    const int pix = lane & 15, q = lane >> 4;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t ngroups = (n + 63) / 64;
+
+    // register-resident codebook
+    half8 wreg[NB_T > 0 ? NB_T : 1][NFR];
+    f32x4 breg[NB_T > 0 ? NB_T : 1];
+    if constexpr (NB_T > 0) {
+#pragma unroll
+        for (int b = 0; b < NB_T; b++) {
+#pragma unroll
+            for (int s = 0; s < NFR; s++) wreg[b][s] = wfrag[(b * NFR + s) * 64 + lane];
+            breg[b] = bias[b * 64 + lane];
+        }
+    }
+
+    // per-lane element offsets inside a row (clamped into the row): slot (h, i)
+    int choff[NCH][CPLMAX];
+#pragma unroll
+    for (int h = 0; h < NCH; h++) {
+#pragma unroll
+        for (int i = 0; i < CPLMAX; i++) {
+            int ch = h * 4 * cpl + q * cpl + (i < cpl ? i : 0);
+            if constexpr (VEC2) {
+                if (i & 1) ch = 0;  // unused: pairs are addressed by their even slot
+                else if (ch > c - 2) ch = c - 2;
+            } else {
+                if (ch > c - 1) ch = c - 1;
+            }
+            choff[h][i] = ch;
+        }
+    }
+
+    // dst[h][i]: channel h*4*cpl + q*cpl + i of row g*64 + t*16 + pix
+    auto load_tile = [&](int64_t g, int t, T(&dst)[NCH][CPLMAX]) {
+        int64_t row = g * 64 + t * 16 + pix;
+        if (row > n - 1) row = n - 1;
+        const T *rp = x + row * ldx;
+#pragma unroll
+        for (int h = 0; h < NCH; h++) {
+            if constexpr (VEC2) {
+#pragma unroll
+                for (int i = 0; i < CPLMAX; i += 2) {
+                    const typename Pair<T>::type v =
+                        *reinterpret_cast<const typename Pair<T>::type *>(rp + choff[h][i]);
+                    dst[h][i] = v.x;
+                    dst[h][i + 1] = v.y;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < CPLMAX; i++) dst[h][i] = rp[choff[h][i]];
+            }
+        }
+    };
+
+    // fp32 row slice -> fp16 hi / lo B-fragments + partial squared norm
+    auto convert = [&](const T(&src)[NCH][CPLMAX], half8(&bh)[NCH], half8(&bl)[NCH], float &ss) {
+        float acc2 = 0.f;
+#pragma unroll
+        for (int h = 0; h < NCH; h++) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                float xf = 0.f;
+                if (i < CPLMAX) xf = (float)src[h][i < CPLMAX ? i : 0] * scale;
+                acc2 = fmaf(xf, xf, acc2);
+                const _Float16 hi = (_Float16)xf;
+                bh[h][i] = hi;
+                bl[h][i] = (_Float16)(xf - (float)hi);
+            }
+        }
+        ss = acc2;
+    };
+
+    // finish one tile: node index into the winner, merge the 4 lane groups of a pixel, decide
+    auto finish = [&](float m1, float m2, float s2, float &out_m1, bool &out_amb, int t) {
+        {
+            const unsigned bits = __float_as_uint(m1);
+            const unsigned idx = bits & idx_mask;
+            const unsigned node = ((idx >> 2) << 4) | ((unsigned)q << 2) | (idx & 3u);
+            m1 = __uint_as_float((bits & ~node_mask) | node);
+        }
+        F2 e1 = xchg16(m1), e2 = xchg16(m2), es = xchg16(s2);
+        m1 = fmaxf(e1.a, e1.b);
+        m2 = fmaxf(fmaxf(fminf(e1.a, e1.b), e2.a), e2.b);
+        s2 = es.a + es.b;
+        e1 = xchg32(m1);
+        e2 = xchg32(m2);
+        es = xchg32(s2);
+        m1 = fmaxf(e1.a, e1.b);
+        m2 = fmaxf(fmaxf(fminf(e1.a, e1.b), e2.a), e2.b);
+        s2 = es.a + es.b;
+        if (q == t) {
+            // |X| up to 2^-20 relative; integer test catches NaN/Inf rows under finite-math
+            const float xn = __builtin_amdgcn_sqrtf(s2) * 1.000001f;
+            const float tol = tol_rel * (xn * wn_max + 0.5f * wn_max * wn_max) + tol_abs * (xn + wn_max);
+            // launder the bits through an empty asm: under -ffinite-math-only the optimiser would
+            // otherwise fold this exponent test (it recognises it as an is-nan-or-inf query) to false
+            unsigned sbits = __float_as_uint(s2);
+            asm volatile("" : "+v"(sbits));
+            const bool nonfinite = (sbits & 0x7f800000u) == 0x7f800000u;
+            out_amb = !((m1 - m2) > tol) || !(xn < x_limit) || nonfinite || force_exact;
+            out_m1 = m1;
+        }
+    };
+
+    T raw[PREFETCH ? kTilesPerIter : TP][NCH][CPLMAX];
+
+    int64_t g = wave;
+    if constexpr (PREFETCH) {
+        if (g < ngroups) {
+#pragma unroll
+            for (int t = 0; t < kTilesPerIter; t++) load_tile(g, t, raw[t]);
+        }
+    }
+    for (; g < ngroups; g += nwaves) {
+        half8 bh[PREFETCH ? kTilesPerIter : TP][NCH], bl[PREFETCH ? kTilesPerIter : TP][NCH];
+        float ss[PREFETCH ? kTilesPerIter : TP];
+        if constexpr (PREFETCH) {
+            // convert the current group's rows, then issue the next group's loads
+#pragma unroll
+            for (int t = 0; t < kTilesPerIter; t++) convert(raw[t], bh[t], bl[t], ss[t]);
+            int64_t gnext = g + nwaves;
+            if (gnext > ngroups - 1) gnext = ngroups - 1;  // harmless re-read on the last trip
+#pragma unroll
+            for (int t = 0; t < kTilesPerIter; t++) load_tile(gnext, t, raw[t]);
+        }
+
+        float my_m1 = 0.f;
+        bool my_amb = false;
+#pragma unroll
+        for (int t0 = 0; t0 < kTilesPerIter; t0 += TP) {
+            if constexpr (!PREFETCH) {
+#pragma unroll
+                for (int u = 0; u < TP; u++) {
+                    load_tile(g, t0 + u, raw[u]);
+                    convert(raw[u], bh[u], bl[u], ss[u]);
+                }
+            }
+            float m1[TP], m2[TP];
+#pragma unroll
+            for (int u = 0; u < TP; u++) m1[u] = m2[u] = kNegBig;
+
+            if constexpr (NB_T > 0) {
+#pragma unroll
+                for (int b = 0; b < NB_T; b++) {
+                    f32x4 acc[TP];
+#pragma unroll
+                    for (int u = 0; u < TP; u++) acc[u] = breg[b];
+                    // per chunk: Wh*Xh + Wh*Xl + Wl*Xh, the TP chains interleaved
+#pragma unroll
+                    for (int h = 0; h < NCH; h++) {
+#pragma unroll
+                        for (int u = 0; u < TP; u++) {
+                            const int sl = PREFETCH ? t0 + u : u;
+                            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b][2 * h], bh[sl][h], acc[u], 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int u = 0; u < TP; u++) {
+                            const int sl = PREFETCH ? t0 + u : u;
+                            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b][2 * h], bl[sl][h], acc[u], 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int u = 0; u < TP; u++) {
+                            const int sl = PREFETCH ? t0 + u : u;
+                            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b][2 * h + 1], bh[sl][h], acc[u], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < TP; u++) consume(m1[u], m2[u], acc[u], b, idx_mask);
+                }
+            } else {
+                for (int b = 0; b < nb; b++) {
+                    f32x4 acc[TP];
+                    const f32x4 bv = bias[b * 64 + lane];
+#pragma unroll
+                    for (int u = 0; u < TP; u++) acc[u] = bv;
+#pragma unroll
+                    for (int h = 0; h < NCH; h++) {
+                        const half8 wh = wfrag[(b * NFR + 2 * h) * 64 + lane];
+                        const half8 wl = wfrag[(b * NFR + 2 * h + 1) * 64 + lane];
+#pragma unroll
+                        for (int u = 0; u < TP; u++) {
+                            const int sl = PREFETCH ? t0 + u : u;
+                            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh[sl][h], acc[u], 0, 0, 0);
+                            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl[sl][h], acc[u], 0, 0, 0);
+                            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh[sl][h], acc[u], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < TP; u++) consume(m1[u], m2[u], acc[u], b, idx_mask);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < TP; u++)
+                finish(m1[u], m2[u], ss[PREFETCH ? t0 + u : u], my_m1, my_amb, t0 + u);
+        }
+        // lane (q, pix) now owns row g*64 + q*16 + pix == g*64 + lane
+        const int64_t row = g * 64 + lane;
+        const bool valid = row < n;
+        if (valid) labels[row] = (int)(__float_as_uint(my_m1) & node_mask) + 1;
+        const bool push = valid && my_amb;
+        const unsigned long long mask = __ballot(push);
+        if (mask) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&hdr->amb_count, (unsigned)__popcll(mask));
+            base = __shfl(base, 0);
+            if (push) amb_list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned)row;
+        }
+    }
+}
+
+template <typename T, int NCH, int CPL, int NB, bool VEC2>
+void launch_filter(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels,
+                   hipStream_t st)
+{
+    constexpr bool PF = (NCH == 1);
+    constexpr int TP = (NB > 0) ? 2 : 1;
+    auto kern = bmu_filter_kernel<T, NCH, CPL, NB, VEC2, PF, TP>;
+    // persistent grid: exactly as many workgroups as are resident (VGPR-limited), capped by the work
+    static int blocks_per_cu = 0;
+    if (blocks_per_cu == 0) {
+        int nbk = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, kern, 256, 0) != hipSuccess || nbk < 1) nbk = 2;
+        blocks_per_cu = nbk > 8 ? 8 : nbk;
+    }
+    const int64_t ngroups = (n + 63) / 64;
+    int grid = (int)std::min<int64_t>((ngroups + 3) / 4, (int64_t)pxsom::device_cu_count() * blocks_per_cu);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, x, n, c, ldx,
+                       reinterpret_cast<const half8 *>(ws + L.off_wfrag),
+                       reinterpret_cast<const f32x4 *>(ws + L.off_bias), reinterpret_cast<AssignHdr *>(ws),
+                       reinterpret_cast<unsigned *>(ws + L.off_list), labels);
+}
+
+}  // namespace
+
+template <typename T>
+void launch_filter_any(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L,
+                       int32_t *labels, hipStream_t st)
+{
+    // pair loads need 2-element alignment of every row start and of the base pointer
+    const bool vec2 = (c % 2 == 0) && (ldx % 2 == 0) && (reinterpret_cast<uintptr_t>(x) % (2 * sizeof(T)) == 0);
+    // headline shape (BASELINE.json configs 2/3: C=22, K=100): register-resident codebook
+    if (vec2 && L.nch == 1 && L.cpl == 6 && L.nb == 7)
+        launch_filter<T, 1, 6, 7, true>(x, n, c, ldx, ws, L, labels, st);
+    else if (vec2 && L.nch == 1 && L.cpl == 2 && L.nb == 7)  // config 1 (C=8, K=100)
+        launch_filter<T, 1, 2, 7, true>(x, n, c, ldx, ws, L, labels, st);
+    else if (L.nch == 1)
+        vec2 ? launch_filter<T, 1, 0, 0, true>(x, n, c, ldx, ws, L, labels, st)
+             : launch_filter<T, 1, 0, 0, false>(x, n, c, ldx, ws, L, labels, st);
+    else if (L.nch == 2)
+        vec2 ? launch_filter<T, 2, 0, 0, true>(x, n, c, ldx, ws, L, labels, st)
+             : launch_filter<T, 2, 0, 0, false>(x, n, c, ldx, ws, L, labels, st);
+    else if (L.nch == 3)
+        vec2 ? launch_filter<T, 3, 0, 0, true>(x, n, c, ldx, ws, L, labels, st)
+             : launch_filter<T, 3, 0, 0, false>(x, n, c, ldx, ws, L, labels, st);
+    else
+        vec2 ? launch_filter<T, 4, 0, 0, true>(x, n, c, ldx, ws, L, labels, st)
+             : launch_filter<T, 4, 0, 0, false>(x, n, c, ldx, ws, L, labels, st);
+}
+
+template void launch_filter_any<float>(const float *, int64_t, int, int64_t, char *, const Layout &, int32_t *,
+                                       hipStream_t);
+template void launch_filter_any<double>(const double *, int64_t, int, int64_t, char *, const Layout &, int32_t *,
+                                        hipStream_t);
+
+}  // namespace pxsom_bmu

@@ -39,4 +39,11 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // number of CUs of the current device (256 on MI355X); cached per process
 int device_cu_count();
 
+// Optional in-library kernel timer (pxsom_prof_*): HIP event pairs recorded on the launch stream
+// immediately around the dominant kernel of a call, so a caller can report that kernel's
+// duration without a profiler attached.
+struct Prof;
+Prof *current_prof();
+void prof_mark(Prof *p, hipStream_t st, bool start, int64_t rows);
+
 }  // namespace pxsom

@@ -1,0 +1,124 @@
+"""FOV-sharded batch SOM training: one process per GPU, per-step codebook statistics
+all-reduced over RCCL (``torch.distributed`` backend "nccl" on ROCm).
+
+The reference has no analogue (its training is pyFlowSOM's sequential loop,
+/root/reference/src/ark/phenotyping/cluster_helpers.py:106-109, "replicas only" in DESIGN.md).
+This is the throughput-mode rule BASELINE.json's north_star asks for: pixels never leave their
+GPU; the only exchange is one all-reduce of the packed [K, C+1] binary64 statistics per
+mini-batch step (9.2 KB at K=100, C=22 -- latency-bound, xGMI bandwidth is irrelevant).
+
+One pass = ``batch_steps`` mini-batch steps; step g (of G = rlen*batch_steps) uses the local
+rows i with i % batch_steps == g % batch_steps:
+    labels = BMU(rows, W)                       (exact rule, pxsom_assign)
+    S[b] += x_i, n[b] += 1                      (pxsom_cluster_sums)      -> all-reduce(S, n)
+    thr = r0 - (r0-r1) g/G (0.5 once < 1);  alpha = a0 - (a0-a1) g/G
+    W_k += (1 - (1-alpha)^den_k) (num_k/den_k - W_k)                      (pxsom_batch_update)
+Oracle of record: oracle/pxsom_oracle.c (orc_som_batch).
+"""
+from typing import Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def batch_schedule(g: int, total_steps: int, alpha_range: Sequence[float],
+                   radius_range: Sequence[float]) -> Tuple[float, float]:
+    """(neighbourhood threshold, learning rate) of mini-batch step g -- the online schedule
+    sampled at the step's first presentation."""
+    a0, a1 = float(alpha_range[0]), float(alpha_range[1])
+    r0, r1 = float(radius_range[0]), float(radius_range[1])
+    thr = r0 - (r0 - r1) * float(g) / float(total_steps)
+    if thr < 1.0:
+        thr = 0.5
+    alpha = a0 - (a0 - a1) * float(g) / float(total_steps)
+    return thr, alpha
+
+
+class HipKernels:
+    """The product kernel set: libpxsom.so through the C ABI (no other implementation ships)."""
+
+    def __init__(self):
+        from . import som_device
+        self._sd = som_device
+        self._ws = None
+
+    def assign(self, x: torch.Tensor, w: torch.Tensor, labels: Optional[torch.Tensor] = None):
+        n, c = x.shape
+        if self._ws is None or not self._ws.fits(n, c, w.shape[0]):
+            self._ws = self._sd.AssignWorkspace(n, c, w.shape[0], x.device)
+        return self._sd.assign(x, w, labels=labels, workspace=self._ws)[0]
+
+    def cluster_sums(self, x, labels, k, sums, counts):
+        return self._sd.cluster_sums(x, labels, k, sums, counts)
+
+    def batch_update(self, w, xdim, ydim, sums, counts, thr, alpha):
+        return self._sd.batch_update(w, xdim, ydim, sums, counts, thr, alpha)
+
+
+def _world(group) -> int:
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+class BatchSOMTrainer:
+    """Holds the per-rank buffers of the batch rule so repeated passes allocate nothing."""
+
+    def __init__(self, xdim: int, ydim: int, channels: int, device, batch_steps: int = 64,
+                 alpha_range: Sequence[float] = (0.05, 0.01),
+                 radius_range: Optional[Sequence[float]] = None, group=None, kernels=None):
+        from .flowsom import default_radius_range
+        self.xdim, self.ydim, self.k, self.c = int(xdim), int(ydim), int(xdim * ydim), int(channels)
+        self.batch_steps = int(batch_steps)
+        if self.batch_steps < 1:
+            raise ValueError("batch_steps must be >= 1")
+        self.alpha_range = tuple(alpha_range)
+        self.radius_range = tuple(radius_range) if radius_range is not None else \
+            default_radius_range(xdim, ydim)
+        self.group = group
+        self.kernels = kernels if kernels is not None else HipKernels()
+        # packed statistics: [K*C sums | K counts-as-f64] so one all-reduce moves both
+        self.packed = torch.zeros(self.k * self.c + self.k, dtype=torch.float64, device=device)
+        self.sums = self.packed[: self.k * self.c].view(self.k, self.c)
+        self.counts_f = self.packed[self.k * self.c:]
+        self.counts = torch.zeros(self.k, dtype=torch.int64, device=device)
+        self.label_buf = None
+
+    def step(self, x_local: torch.Tensor, w: torch.Tensor, g: int, total_steps: int) -> None:
+        """One mini-batch step g on this rank's shard; collective when world_size > 1."""
+        m = self.batch_steps
+        view = x_local[(g % m)::m]
+        nrows = view.shape[0]
+        if self.label_buf is None or self.label_buf.numel() < nrows:
+            self.label_buf = torch.empty(max(nrows, 1), dtype=torch.int32, device=x_local.device)
+        labels = self.label_buf[:nrows]
+        self.packed.zero_()
+        self.counts.zero_()
+        if nrows > 0:
+            self.kernels.assign(view, w, labels)
+            self.kernels.cluster_sums(view, labels, self.k, self.sums, self.counts)
+        if _world(self.group) > 1:
+            self.counts_f.copy_(self.counts)          # exact below 2^53 rows
+            dist.all_reduce(self.packed, op=dist.ReduceOp.SUM, group=self.group)
+            self.counts.copy_(self.counts_f)
+        thr, alpha = batch_schedule(g, total_steps, self.alpha_range, self.radius_range)
+        self.kernels.batch_update(w, self.xdim, self.ydim, self.sums, self.counts, thr, alpha)
+
+    def train(self, x_local: torch.Tensor, w: torch.Tensor, num_passes: int = 1) -> torch.Tensor:
+        """Runs num_passes passes in place on ``w`` [K, C] f64 (identical on every rank)."""
+        total = int(num_passes) * self.batch_steps
+        for g in range(total):
+            self.step(x_local, w, g, total)
+        return w
+
+
+def broadcast_codebook(w: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
+    if _world(group) > 1:
+        dist.broadcast(w, src=src, group=group)
+    return w
+
+
+def allreduce_cluster_tables(sums: torch.Tensor, counts: torch.Tensor, group=None):
+    """K8 across ranks: one sum all-reduce each for the [K, C] f64 sums and [K] i64 counts."""
+    if _world(group) > 1:
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    return sums, counts

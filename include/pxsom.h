@@ -55,6 +55,17 @@ typedef enum pxsom_dtype {
 int pxsom_abi_version(void);
 const char *pxsom_last_error(void);
 
+/* ---- in-library kernel timer --------------------------------------------------------------
+ * HIP event pairs recorded on the launch stream immediately around the dominant kernel of each
+ * pxsom_assign call (the BMU filter kernel) whose row count is >= min_rows, while a profiler is
+ * attached to the calling thread.  pxsom_prof_collect synchronises on the recorded events and
+ * returns the summed kernel time and the number of launches, then resets.  bench.py uses it for
+ * the roofline figure (the same duration rocprofv3 --kernel-trace reports for that kernel). */
+int pxsom_prof_create(void **out_handle);
+int pxsom_prof_destroy(void *handle);
+int pxsom_prof_attach(void *handle_or_null, int64_t min_rows);
+int pxsom_prof_collect(void *handle, double *total_ms, int64_t *launches);
+
 /* ---- host helper (no GPU) ------------------------------------------------------------------
  * glibc rand() stream (TYPE_3 additive feedback), the presentation-order generator of the
  * pyFlowSOM-compatible som() front end (replaces the libc srand/rand pair inside pyFlowSOM's
