@@ -28,13 +28,14 @@ struct AssignHdr {
 };
 
 struct Layout {
-    int nb, nch, cpl, nsteps, idx_bits, node_bits;
+    int k, nb, nch, cpl, nsteps, idx_bits, node_bits;
     size_t off_wfrag, off_bias, off_list, total;
 };
 
 inline Layout make_layout(int64_t n, int c, int k)
 {
     Layout L;
+    L.k = k;
     L.nb = (k + 15) / 16;
     L.nch = (c + 31) / 32;
     int per_chunk = (c + L.nch - 1) / L.nch;          // channels per chunk
@@ -53,6 +54,15 @@ inline Layout make_layout(int64_t n, int c, int k)
     return L;
 }
 
+
+// Node <-> MFMA row mapping.  Row m (= 4q + r in the accumulator layout) of node block b holds node
+// 16b + m, except in the LAST block, whose 4x4 (q, r) index grid is transposed so that its valid
+// nodes fill register r = 0 of every lane group first: node = 16b + 4r + q.  With K = 100 the last
+// block's 4 nodes then sit in one accumulator register and the other three are never examined.
+__host__ __device__ inline int node_of_row(int b, int m, int nb)
+{
+    return b == nb - 1 ? 16 * b + 4 * (m & 3) + (m >> 2) : 16 * b + m;
+}
 
 // filter stage (pxsom_assign_filter.hip, compiled with -ffinite-math-only)
 template <typename T>

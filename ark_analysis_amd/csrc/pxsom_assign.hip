@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict_
     for (int f = tid; f < nb * nsteps * 64; f += 256) {
         const int lane = f & 63, s = (f >> 6) % nsteps, b = (f >> 6) / nsteps;
         const int m = lane & 15, q = lane >> 4, h = s / 2, t = s % 2;
-        const int node = b * 16 + m;
+        const int node = node_of_row(b, m, nb);
         half8 frag;
         for (int i = 0; i < 8; i++) {
             const int ch = h * 4 * cpl + q * cpl + i;
@@ -122,12 +122,12 @@ __global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict_
         }
         wfrag[f] = frag;
     }
-    // bias[b*64 + lane][r] for accumulator row (lane>>4)*4 + r <-> node 16b + 4q + r
+    // bias[b*64 + lane][r] for accumulator row (lane>>4)*4 + r <-> node_of_row(b, 4q + r)
     for (int f = tid; f < nb * 64; f += 256) {
         const int lane = f & 63, b = f >> 6, q = lane >> 4;
         f32x4 bv;
         for (int r = 0; r < 4; r++) {
-            const int node = b * 16 + q * 4 + r;
+            const int node = node_of_row(b, q * 4 + r, nb);
             bv[r] = node < k ? (float)(-0.5 * s_norm2[node] * scale * scale) : kNegBig;
         }
         bias[f] = bv;

