@@ -36,6 +36,7 @@ SYMBOLS = {
     "pxsom_cluster_sums": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _i32, _vp, _vp, _vp]),
     "pxsom_train_online": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _i32, _i32, _i32, _f64, _f64,
                                   _f64, _f64, _vp, _vp]),
+    "pxsom_batch_accumulate": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pxsom_batch_update": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _f64, _f64, _vp]),
 }
 

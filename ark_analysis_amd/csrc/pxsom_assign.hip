@@ -32,13 +32,21 @@ namespace {
 __global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict__ w, int k, int c,
                                                        AssignHdr *hdr, half8 *wfrag, f32x4 *bias,
                                                        int nb, int nch, int cpl, int idx_bits,
-                                                       int node_bits)
+                                                       int node_bits, int stage)
 {
     __shared__ double s_norm2[PXSOM_MAX_NODES];
     __shared__ double s_red[256];
     __shared__ int s_bad;
+    extern __shared__ __attribute__((aligned(16))) char prep_smem[];
     const int tid = threadIdx.x;
     if (tid == 0) s_bad = 0;
+    // small codebooks are staged in LDS with one coalesced sweep; every later read is an LDS read
+    const double *wl = w;
+    if (stage) {
+        double *sw = reinterpret_cast<double *>(prep_smem);
+        for (int e = tid; e < k * c; e += 256) sw[e] = w[e];
+        wl = sw;
+    }
     __syncthreads();
 
     // per-node squared norm (binary64) and global max |w|
@@ -46,7 +54,7 @@ __global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict_
     for (int node = tid; node < k; node += 256) {
         double s = 0.0;
         for (int j = 0; j < c; j++) {
-            double v = w[(size_t)node * c + j];
+            double v = wl[(size_t)node * c + j];
             if (!(fabs(v) <= DBL_MAX)) s_bad = 1;  // NaN / Inf in the codebook
             s += v * v;
             mymax = fmax(mymax, fabs(v));
@@ -115,7 +123,7 @@ __global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict_
         for (int i = 0; i < 8; i++) {
             const int ch = h * 4 * cpl + q * cpl + i;
             float W = 0.f;
-            if (i < cpl && ch < c && node < k) W = (float)(w[(size_t)node * c + ch] * scale);
+            if (i < cpl && ch < c && node < k) W = (float)(wl[(size_t)node * c + ch] * scale);
             const _Float16 hi = (_Float16)W;
             const _Float16 lo = (_Float16)(W - (float)hi);
             frag[i] = (t == 1) ? lo : hi;
@@ -159,34 +167,78 @@ __global__ __launch_bounds__(256) void bmu_exact_kernel(const T *__restrict__ x,
     }
     const int lane = threadIdx.x & 63;
     const unsigned wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
-    for (unsigned e = wave; e < count; e += nwaves) {
-        const int64_t row = amb_list[e];
-        const T *rp = x + row * ldx;
-        double best = DBL_MAX;
-        int bestk = 0x7fffffff;
-        for (int node = lane; node < k; node += 64) {
-            double xdist = 0.0;
+    // RB listed rows per wave iteration: the codebook element read from LDS is shared by the RB rows
+    // and their independent binary64 chains hide each other's latency.  Each row is fetched once
+    // (lane j holds channels j and j+64) and broadcast with v_readlane (j is wave-uniform).
+    constexpr int RB = 4;
+    for (unsigned e0 = wave * RB; e0 < count; e0 += nwaves * RB) {
+        int64_t rows[RB];
+        unsigned x_lo[RB][2], x_hi[RB][2];
+#pragma unroll
+        for (int u = 0; u < RB; u++) {
+            const unsigned e = e0 + u < count ? e0 + u : count - 1;  // surplus slots redo the last row
+            rows[u] = amb_list[e];
+            const T *rp = x + rows[u] * ldx;
+            const double xa = lane < c ? (double)rp[lane] : 0.0;
+            const double xb = lane + 64 < c ? (double)rp[lane + 64] : 0.0;
+            x_lo[u][0] = (unsigned)__double_as_longlong(xa);
+            x_hi[u][0] = (unsigned)(__double_as_longlong(xa) >> 32);
+            x_lo[u][1] = (unsigned)__double_as_longlong(xb);
+            x_hi[u][1] = (unsigned)(__double_as_longlong(xb) >> 32);
+        }
+        double best[RB];
+        int bestk[RB];
+#pragma unroll
+        for (int u = 0; u < RB; u++) {
+            best[u] = DBL_MAX;
+            bestk[u] = 0x7fffffff;
+        }
+        for (int base = 0; base < k; base += 128) {
+            const int n0 = base + lane, n1 = base + 64 + lane;
+            const int c0 = n0 < k ? n0 : k - 1, c1 = n1 < k ? n1 : k - 1;
+            double d0[RB], d1[RB];
+#pragma unroll
+            for (int u = 0; u < RB; u++) d0[u] = d1[u] = 0.0;
             for (int j = 0; j < c; j++) {
-                const double wv = use_lds ? wt[(size_t)j * k + node] : w[(size_t)node * c + j];
-                const double tmp = (double)rp[j] - wv;
-                xdist += tmp * tmp;
+                const double w0 = use_lds ? wt[(size_t)j * k + c0] : w[(size_t)c0 * c + j];
+                const double w1 = use_lds ? wt[(size_t)j * k + c1] : w[(size_t)c1 * c + j];
+                const int h = j >> 6, jj = j & 63;
+#pragma unroll
+                for (int u = 0; u < RB; u++) {
+                    const unsigned lo = __builtin_amdgcn_readlane(h ? x_lo[u][1] : x_lo[u][0], jj);
+                    const unsigned hi = __builtin_amdgcn_readlane(h ? x_hi[u][1] : x_hi[u][0], jj);
+                    const double xj = __longlong_as_double(((long long)hi << 32) | lo);
+                    const double t0 = xj - w0, t1 = xj - w1;
+                    d0[u] += t0 * t0;
+                    d1[u] += t1 * t1;
+                }
             }
-            const double d = sqrt(xdist);
-            if (d < best) {
-                best = d;
-                bestk = node;
+#pragma unroll
+            for (int u = 0; u < RB; u++) {
+                const double s0 = sqrt(d0[u]), s1 = sqrt(d1[u]);
+                if (n0 < k && s0 < best[u]) {
+                    best[u] = s0;
+                    bestk[u] = n0;
+                }
+                if (n1 < k && s1 < best[u]) {
+                    best[u] = s1;
+                    bestk[u] = n1;
+                }
             }
         }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double od = __shfl_xor(best, off);
-            const int ok = __shfl_xor(bestk, off);
-            if (od < best || (od == best && ok < bestk)) {
-                best = od;
-                bestk = ok;
+        for (int u = 0; u < RB; u++) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double od = __shfl_xor(best[u], off);
+                const int ok = __shfl_xor(bestk[u], off);
+                if (od < best[u] || (od == best[u] && ok < bestk[u])) {
+                    best[u] = od;
+                    bestk[u] = ok;
+                }
             }
+            if (lane == 0) labels[rows[u]] = bestk[u] == 0x7fffffff ? 0 : bestk[u] + 1;
         }
-        if (lane == 0) labels[row] = bestk == 0x7fffffff ? 0 : bestk + 1;
     }
 }
 
@@ -220,9 +272,12 @@ template <typename T>
 int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int k, int32_t *labels,
                  double *dist, char *ws, const Layout &L, hipStream_t st)
 {
-    hipLaunchKernelGGL(bmu_prep_kernel, dim3(1), dim3(256), 0, st, w, k, c, reinterpret_cast<AssignHdr *>(ws),
+    const size_t stage_bytes = (size_t)k * c * sizeof(double);
+    const int stage = stage_bytes <= 40 * 1024;
+    hipLaunchKernelGGL(bmu_prep_kernel, dim3(1), dim3(256), stage ? stage_bytes : 0, st, w, k, c,
+                       reinterpret_cast<AssignHdr *>(ws),
                        reinterpret_cast<half8 *>(ws + L.off_wfrag), reinterpret_cast<f32x4 *>(ws + L.off_bias),
-                       L.nb, L.nch, L.cpl, L.idx_bits, L.node_bits);
+                       L.nb, L.nch, L.cpl, L.idx_bits, L.node_bits, stage);
     PXSOM_LAUNCH_CHECK("bmu_prep_kernel");
 
     const int cus = pxsom::device_cu_count();
@@ -234,7 +289,8 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
 
     const size_t wt_bytes = (size_t)k * c * sizeof(double);
     const int use_lds = wt_bytes <= 64 * 1024;
-    int egrid = (int)std::min<int64_t>((n + 3) / 4, (int64_t)cus * 4);
+    // listed rows are a small fraction of n; the kernel grid-strides over the list anyway
+    int egrid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)cus * 4);
     if (egrid < 1) egrid = 1;
     hipLaunchKernelGGL(bmu_exact_kernel<T>, dim3(egrid), dim3(256), use_lds ? wt_bytes : 0, st, x, c, ldx, w,
                        k, reinterpret_cast<const AssignHdr *>(ws),

@@ -176,30 +176,32 @@ __global__ __launch_bounds__(1024) void som_online_kernel(const T *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// batch update: one workgroup; thread <-> (node, channel) pairs
+// batch update: one workgroup per node k, thread <-> channel.  Only the Chebyshev window of k is
+// visited, in ascending node order b (the oracle's summation order: skipping the nodes it skips).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void batch_update_kernel(double *w, int xdim, int ydim, int c,
+__global__ __launch_bounds__(128) void batch_update_kernel(double *w, int xdim, int ydim, int c,
                                                            const double *__restrict__ sums,
                                                            const int64_t *__restrict__ counts,
                                                            double thr, double alpha)
 {
-    const int K = xdim * ydim;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < K * c; e += gridDim.x * 256) {
-        const int k = e / c, j = e - k * c;
-        const int kx = k / ydim, ky = k % ydim;
-        double num = 0.0, den = 0.0;
-        for (int b = 0; b < K; b++) {
-            const int bx = b / ydim, by = b % ydim;
-            const int dx = kx > bx ? kx - bx : bx - kx, dy = ky > by ? ky - by : by - ky;
-            if ((double)(dx > dy ? dx : dy) > thr) continue;
+    const int k = blockIdx.x, j = threadIdx.x;
+    if (j >= c) return;
+    const int kx = k / ydim, ky = k % ydim;
+    // nodes b with max(|dx|, |dy|) <= thr  <=>  |dx|, |dy| <= floor(thr)   (integer distances)
+    int r = thr < 0.0 ? -1 : (thr > 1.0e6 ? 1000000 : (int)floor(thr));
+    const int x0 = kx - r < 0 ? 0 : kx - r, x1 = kx + r > xdim - 1 ? xdim - 1 : kx + r;
+    const int y0 = ky - r < 0 ? 0 : ky - r, y1 = ky + r > ydim - 1 ? ydim - 1 : ky + r;
+    double num = 0.0, den = 0.0;
+    for (int bx = x0; bx <= x1; bx++)
+        for (int by = y0; by <= y1; by++) {
+            const int b = bx * ydim + by;
             den += (double)counts[b];
             num += sums[(size_t)b * c + j];
         }
-        if (den > 0.0) {
-            const double gain = 1.0 - pow(1.0 - alpha, den);
-            const double wv = w[e];
-            w[e] = wv + gain * (num / den - wv);
-        }
+    if (den > 0.0) {
+        const double gain = 1.0 - pow(1.0 - alpha, den);
+        const double wv = w[(size_t)k * c + j];
+        w[(size_t)k * c + j] = wv + gain * (num / den - wv);
     }
 }
 
@@ -229,30 +231,41 @@ __global__ __launch_bounds__(256) void cluster_sums_kernel(const T *__restrict__
     int64_t r1 = r0 + rows_per_block;
     if (r1 > n) r1 = n;
     if (r0 < r1) {
-        // element e of the range <-> (row r0 + e / c, channel e % c); advance by 256 per iteration
+        // element e of the range <-> (row r0 + e / c, channel e % c); advance by 256 per element,
+        // four elements in flight per thread (loads issued before the dependent atomics)
         const int64_t total = (r1 - r0) * c;
         int64_t row = r0 + tid / c;
         int ch = tid % c;
         const int drow = 256 / c, dch = 256 % c;
-        for (int64_t e = tid; e < total; e += 256) {
-            const int lab = labels[row] - 1;
-            if (lab >= 0 && lab < k) {
-                const double v = (double)x[row * ldx + ch];
-                if (use_lds) {
-                    __hip_atomic_fetch_add(&ls[(size_t)lab * c + ch], v, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (ch == 0) atomicAdd(&lc[lab], 1u);
-                } else {
-                    __hip_atomic_fetch_add(&sums[(size_t)lab * c + ch], v, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-                    if (ch == 0) atomicAdd(&counts[lab], 1ull);
+        for (int64_t e = tid; e < total; e += 1024) {
+            int cc[4], lab[4];
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                cc[u] = ch;
+                const bool ok = e + 256 * u < total;
+                lab[u] = ok ? labels[row] - 1 : -1;
+                v[u] = ok ? (double)x[row * ldx + ch] : 0.0;
+                row += drow;
+                ch += dch;
+                if (ch >= c) {
+                    ch -= c;
+                    row += 1;
                 }
             }
-            row += drow;
-            ch += dch;
-            if (ch >= c) {
-                ch -= c;
-                row += 1;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (lab[u] >= 0 && lab[u] < k) {
+                    if (use_lds) {
+                        __hip_atomic_fetch_add(&ls[(size_t)lab[u] * c + cc[u]], v[u], __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (cc[u] == 0) atomicAdd(&lc[lab[u]], 1u);
+                    } else {
+                        __hip_atomic_fetch_add(&sums[(size_t)lab[u] * c + cc[u]], v[u], __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                        if (cc[u] == 0) atomicAdd(&counts[lab[u]], 1ull);
+                    }
+                }
             }
         }
     }
@@ -297,7 +310,7 @@ int cluster_sums_typed(const T *x, int64_t n, int c, int64_t ldx, const int32_t 
     const size_t lds = (size_t)k * c * 8 + (size_t)k * 4;
     const int use_lds = lds <= 150 * 1024;
     const int cus = pxsom::device_cu_count();
-    int64_t grid = std::min<int64_t>((n + 1023) / 1024, (int64_t)cus * (lds <= 32 * 1024 ? 4 : 1));
+    int64_t grid = std::min<int64_t>((n + 255) / 256, (int64_t)cus * (lds <= 32 * 1024 ? 4 : 1));
     if (grid < 1) grid = 1;
     const int64_t rows_per_block = (n + grid - 1) / grid;
     auto kern = cluster_sums_kernel<T>;
@@ -370,10 +383,31 @@ PXSOM_EXPORT int pxsom_batch_update(double *w_dev, int xdim, int ydim, int c, co
     if (!w_dev || !sums_dev || !counts_dev) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_batch_update: null pointer");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int K = xdim * ydim;
-    int grid = (K * c + 255) / 256;
-    if (grid > 64) grid = 64;
-    hipLaunchKernelGGL(batch_update_kernel, dim3(grid), dim3(256), 0, st, w_dev, xdim, ydim, c, sums_dev, counts_dev,
+    hipLaunchKernelGGL(batch_update_kernel, dim3(K), dim3(128), 0, st, w_dev, xdim, ydim, c, sums_dev, counts_dev,
                        thr, alpha);
     PXSOM_LAUNCH_CHECK("batch_update_kernel");
     return PXSOM_OK;
+}
+
+// One mini-batch step's accumulation half: zero the statistics, BMU of every row, per-BMU sums.
+PXSOM_EXPORT int pxsom_batch_accumulate(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype,
+                                        const double *w_dev, int k, int32_t *labels_dev, double *sums_dev,
+                                        int64_t *counts_dev, void *workspace_dev, size_t workspace_bytes,
+                                        void *stream)
+{
+    if (!sums_dev || !counts_dev || k < 1 || k > PXSOM_MAX_NODES || c < 1 || c > PXSOM_MAX_CHANNELS)
+        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_batch_accumulate: bad statistics buffers / shape");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t sbytes = (size_t)k * c * sizeof(double), cbytes = (size_t)k * sizeof(int64_t);
+    if (reinterpret_cast<char *>(sums_dev) + sbytes == reinterpret_cast<char *>(counts_dev)) {
+        PXSOM_HIP_TRY(hipMemsetAsync(sums_dev, 0, sbytes + cbytes, st));
+    } else {
+        PXSOM_HIP_TRY(hipMemsetAsync(sums_dev, 0, sbytes, st));
+        PXSOM_HIP_TRY(hipMemsetAsync(counts_dev, 0, cbytes, st));
+    }
+    if (n == 0) return PXSOM_OK;
+    int rc = pxsom_assign(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, nullptr, workspace_dev, workspace_bytes,
+                          stream);
+    if (rc) return rc;
+    return pxsom_cluster_sums(x_dev, n, c, ldx, dtype, labels_dev, k, sums_dev, counts_dev, stream);
 }

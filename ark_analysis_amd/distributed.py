@@ -42,14 +42,13 @@ class HipKernels:
         self._sd = som_device
         self._ws = None
 
-    def assign(self, x: torch.Tensor, w: torch.Tensor, labels: Optional[torch.Tensor] = None):
+    def accumulate(self, x: torch.Tensor, w: torch.Tensor, labels: torch.Tensor, sums: torch.Tensor,
+                   counts: torch.Tensor) -> None:
+        """zero(sums, counts); labels = BMU(x, w); sums[label] += x; counts[label] += 1."""
         n, c = x.shape
         if self._ws is None or not self._ws.fits(n, c, w.shape[0]):
             self._ws = self._sd.AssignWorkspace(n, c, w.shape[0], x.device)
-        return self._sd.assign(x, w, labels=labels, workspace=self._ws)[0]
-
-    def cluster_sums(self, x, labels, k, sums, counts):
-        return self._sd.cluster_sums(x, labels, k, sums, counts)
+        self._sd.batch_accumulate(x, w, labels, sums, counts, self._ws)
 
     def batch_update(self, w, xdim, ydim, sums, counts, thr, alpha):
         return self._sd.batch_update(w, xdim, ydim, sums, counts, thr, alpha)
@@ -75,11 +74,12 @@ class BatchSOMTrainer:
             default_radius_range(xdim, ydim)
         self.group = group
         self.kernels = kernels if kernels is not None else HipKernels()
-        # packed statistics: [K*C sums | K counts-as-f64] so one all-reduce moves both
+        # statistics: [K*C f64 sums | K i64 counts] contiguous, so the kernels' memset is one call;
+        # for the all-reduce the counts ride along as f64 in `packed` (exact below 2^53 rows)
+        self.stats = torch.zeros(self.k * self.c + self.k, dtype=torch.float64, device=device)
+        self.sums = self.stats[: self.k * self.c].view(self.k, self.c)
+        self.counts = self.stats[self.k * self.c:].view(torch.int64)
         self.packed = torch.zeros(self.k * self.c + self.k, dtype=torch.float64, device=device)
-        self.sums = self.packed[: self.k * self.c].view(self.k, self.c)
-        self.counts_f = self.packed[self.k * self.c:]
-        self.counts = torch.zeros(self.k, dtype=torch.int64, device=device)
         self.label_buf = None
 
     def step(self, x_local: torch.Tensor, w: torch.Tensor, g: int, total_steps: int) -> None:
@@ -89,16 +89,14 @@ class BatchSOMTrainer:
         nrows = view.shape[0]
         if self.label_buf is None or self.label_buf.numel() < nrows:
             self.label_buf = torch.empty(max(nrows, 1), dtype=torch.int32, device=x_local.device)
-        labels = self.label_buf[:nrows]
-        self.packed.zero_()
-        self.counts.zero_()
-        if nrows > 0:
-            self.kernels.assign(view, w, labels)
-            self.kernels.cluster_sums(view, labels, self.k, self.sums, self.counts)
+        self.kernels.accumulate(view, w, self.label_buf, self.sums, self.counts)
         if _world(self.group) > 1:
-            self.counts_f.copy_(self.counts)          # exact below 2^53 rows
+            kc = self.k * self.c
+            self.packed[:kc].copy_(self.stats[:kc])
+            self.packed[kc:].copy_(self.counts)
             dist.all_reduce(self.packed, op=dist.ReduceOp.SUM, group=self.group)
-            self.counts.copy_(self.counts_f)
+            self.stats[:kc].copy_(self.packed[:kc])
+            self.counts.copy_(self.packed[kc:])
         thr, alpha = batch_schedule(g, total_steps, self.alpha_range, self.radius_range)
         self.kernels.batch_update(w, self.xdim, self.ydim, self.sums, self.counts, thr, alpha)
 

@@ -91,6 +91,23 @@ def cluster_sums(x: torch.Tensor, labels: torch.Tensor, k: int,
     return sums, counts
 
 
+def batch_accumulate(x: torch.Tensor, w: torch.Tensor, labels: torch.Tensor, sums: torch.Tensor,
+                     counts: torch.Tensor, workspace: AssignWorkspace) -> None:
+    """Zero ``sums``/``counts``, label every row of ``x`` and accumulate per-BMU sums (one call)."""
+    n, c, ldx, dt = _matrix_args(x)
+    w = _codebook(w)
+    k = w.shape[0]
+    if not workspace.fits(n, c, k):
+        raise ValueError("assign workspace too small for this mini-batch")
+    if labels.dtype != torch.int32 or labels.numel() < n:
+        raise ValueError("labels scratch must be int32 with at least n entries")
+    rc = _capi.lib().pxsom_batch_accumulate(x.data_ptr(), n, c, ldx, dt, w.data_ptr(), k,
+                                            labels.data_ptr(), sums.data_ptr(), counts.data_ptr(),
+                                            workspace.buf.data_ptr(), workspace.bytes,
+                                            _capi.stream_ptr())
+    _capi.check(rc, "pxsom_batch_accumulate")
+
+
 def train_online(x: torch.Tensor, w: torch.Tensor, xdim: int, ydim: int, rlen: int,
                  alpha_range, radius_range, order: torch.Tensor) -> torch.Tensor:
     """Exact online SOM (FlowSOM C_SOM) in place on ``w`` [xdim*ydim, C] f64."""

@@ -113,6 +113,16 @@ int pxsom_train_online(const void *x_dev, int64_t n, int c, int64_t ldx, int dty
                        int xdim, int ydim, int rlen, double a0, double a1, double r0, double r1,
                        const int64_t *order_dev, void *stream);
 
+/* ---- batch SOM accumulation (throughput mode; no pyFlowSOM analogue) -------------------------
+ * The accumulation half of one mini-batch step, as one host call:
+ *   zero sums_dev [k, c] / counts_dev [k]; labels = BMU(x rows, w) (pxsom_assign); per-BMU sums
+ *   (pxsom_cluster_sums).  labels_dev [n] int32 is scratch that also returns the labels.
+ * If counts_dev directly follows sums_dev in memory one memset covers both. */
+int pxsom_batch_accumulate(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype,
+                           const double *w_dev, int k, int32_t *labels_dev, double *sums_dev,
+                           int64_t *counts_dev, void *workspace_dev, size_t workspace_bytes,
+                           void *stream);
+
 /* ---- batch SOM update (throughput mode; no pyFlowSOM analogue) ------------------------------
  * Applies one mini-batch step from accumulated per-BMU sums/counts (already all-reduced across
  * ranks by the caller):
