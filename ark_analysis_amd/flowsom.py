@@ -103,3 +103,18 @@ def map_data_to_nodes(nodes, newdata, distf: int = 2):
     w = torch.from_numpy(np.ascontiguousarray(nodes, dtype=np.float64)).to(dev)
     labels, dists = som_device.assign(x, w, want_dists=True)
     return labels.cpu().numpy(), dists.cpu().numpy()
+
+
+def cluster_sums(data, labels, k: int):
+    """Per-label channel sums [k, C] (float64) and counts [k] (int64) of the rows of ``data``.
+
+    Device-backed replacement for the pandas ``groupby(cluster)[channels].sum()`` / ``.size()``
+    pair of compute_pixel_cluster_channel_avg (pixel_cluster_utils.py:369-384).  ``labels`` are
+    1-based; rows with labels outside 1..k are ignored."""
+    import torch
+    from . import _capi, som_device
+    dev = _capi.require_gpu()
+    x = _as_device_matrix(data, dev)
+    lab = torch.from_numpy(np.ascontiguousarray(labels, dtype=np.int32)).to(dev)
+    sums, counts = som_device.cluster_sums(x, lab, int(k))
+    return sums.cpu().numpy(), counts.cpu().numpy()

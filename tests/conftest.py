@@ -27,3 +27,39 @@ def gpu():
     from ark_analysis_amd import _capi
     _capi.lib()
     return torch.device("cuda:0")
+
+
+@pytest.fixture(params=[pytest.param("oracle"), pytest.param("hip", marks=pytest.mark.gpu)])
+def som_backend(request, monkeypatch):
+    """Runs a host-logic test twice: on CPU with the three device entry points of
+    ark_analysis_amd.flowsom swapped for the oracle (test infrastructure; `-m "not gpu"`), and on
+    the GPU box with the real HIP path (`-m gpu`)."""
+    if request.param == "hip":
+        import torch
+        if not torch.cuda.is_available():
+            pytest.skip("no HIP device")
+        return "hip"
+    import numpy as np
+    from tests import oracle_binding as ob
+    from ark_analysis_amd import flowsom
+
+    def som(data, xdim=10, ydim=10, rlen=10, alpha_range=(0.05, 0.01), radius_range=None, distf=2,
+            nodes=None, importance=None, seed=None):
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        init_idx, order = flowsom.som_init_and_order(data.shape[0], xdim * ydim, rlen, seed)
+        codes = data[init_idx].copy() if nodes is None else np.array(nodes, dtype=np.float64)
+        if radius_range is None:
+            radius_range = flowsom.default_radius_range(xdim, ydim)
+        return ob.som_online(data, codes, xdim, ydim, rlen, alpha_range, radius_range, order)
+
+    def map_data_to_nodes(nodes, newdata, distf=2):
+        return ob.map_data_to_nodes(np.asarray(nodes, dtype=np.float64),
+                                    np.asarray(newdata, dtype=np.float64))
+
+    def cluster_sums(data, labels, k):
+        return ob.cluster_sums(np.asarray(data, dtype=np.float64), labels, int(k))
+
+    monkeypatch.setattr(flowsom, "som", som)
+    monkeypatch.setattr(flowsom, "map_data_to_nodes", map_data_to_nodes)
+    monkeypatch.setattr(flowsom, "cluster_sums", cluster_sums)
+    return "oracle"

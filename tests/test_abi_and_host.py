@@ -1,0 +1,111 @@
+"""CPU-side checks of the C-ABI library and the host logic that needs no GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "pxsom.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pxsom_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    """No compute call: dlopen + dlsym of everything include/pxsom.h declares."""
+    from ark_analysis_amd import _capi
+    lib = _capi.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 14
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/pxsom.h but not exported"
+    assert set(declared) == set(_capi.SYMBOLS), "ctypes prototype table and header disagree"
+    assert lib.pxsom_abi_version() == 1
+
+
+def test_argument_validation_without_gpu():
+    """Status codes + pxsom_last_error for bad arguments (rejected before any HIP call)."""
+    from ark_analysis_amd import _capi
+    lib = _capi.lib()
+    assert lib.pxsom_assign_workspace_bytes(1000, 22, 100) > 1000 * 4
+    assert lib.pxsom_assign_workspace_bytes(1000, 0, 100) == 0
+    assert lib.pxsom_assign_workspace_bytes(1000, 22, 5000) == 0
+    rc = lib.pxsom_assign(None, 10, 500, 500, 0, None, 100, None, None, None, 0, None)
+    assert rc == -2 and b"c=500" in lib.pxsom_last_error()
+    rc = lib.pxsom_assign(None, 10, 22, 22, 7, None, 100, None, None, None, 0, None)
+    assert rc == -2
+    rc = lib.pxsom_train_online(None, 0, 22, 22, 0, None, 40, 40, 1, 0.05, 0.01, 6.0, 0.0, None, None)
+    assert rc == -2 and b"grid" in lib.pxsom_last_error()
+    rc = lib.pxsom_cluster_sums(None, -1, 22, 22, 0, None, 100, None, None, None)
+    assert rc == -1
+    with pytest.raises(_capi.PxsomError):
+        _capi.check(rc, "pxsom_cluster_sums")
+
+
+def test_glibc_rand_host_helper_matches_libc():
+    from ark_analysis_amd import _capi
+    libc = ctypes.CDLL("libc.so.6")
+    for seed in (42, 7):
+        libc.srand(seed)
+        ref = np.array([libc.rand() for _ in range(1000)], dtype=np.int32)
+        np.testing.assert_array_equal(_capi.glibc_rand(seed, 1000), ref)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-box behaviour")
+def test_product_path_fails_loudly_without_gpu():
+    """No CPU fallback: the pyFlowSOM-compatible entry points raise when no HIP device exists."""
+    from ark_analysis_amd import flowsom
+    x = np.random.rand(300, 4)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        flowsom.som(x, xdim=5, ydim=5, rlen=1, seed=1)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        flowsom.map_data_to_nodes(x[:25], x)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        flowsom.cluster_sums(x, np.ones(300, dtype=np.int32), 3)
+
+
+def test_product_package_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under ark_analysis_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "ark_analysis_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle_binding" not in text and "libpxsom_oracle" not in text, f
+
+
+def test_seed_handling_and_radius_defaults():
+    from ark_analysis_amd import flowsom
+    assert flowsom.default_radius_range(10, 10) == (6.0, 0.0)
+    assert flowsom.default_radius_range(20, 20) == (11.0, 0.0)
+    assert flowsom.default_radius_range(20, 10) == (9.0, 0.0)
+    i1, o1 = flowsom.som_init_and_order(1000, 100, 2, 42)
+    i2, o2 = flowsom.som_init_and_order(1000, 100, 2, 42)
+    assert np.array_equal(i1, i2) and np.array_equal(o1, o2)        # same seed -> same inputs
+    assert len(set(i1.tolist())) == 100 and o1.shape == (2000,) and o1.min() >= 0 and o1.max() < 1000
+    i3, o3 = flowsom.som_init_and_order(1000, 100, 2, 43)
+    assert not np.array_equal(o1, o3)
+    with pytest.raises(ValueError):
+        flowsom.som_init_and_order(50, 100, 1, 1)
+
+
+def test_host_utils_natsort_and_verifiers(tmp_path):
+    from ark_analysis_amd import host_utils as hu
+    assert hu.natsorted(["chan10", "chan2", "chan1"]) == ["chan1", "chan2", "chan10"]
+    for n in ("fov10.feather", "fov2.feather", ".hidden", "fov1.feather"):
+        (tmp_path / n).write_text("x")
+    (tmp_path / "sub").mkdir()
+    assert hu.list_files(str(tmp_path), substrs=".feather") == ["fov1.feather", "fov2.feather", "fov10.feather"]
+    assert hu.remove_file_extensions(["a.feather"]) == ["a"]
+    with pytest.raises(FileNotFoundError):
+        hu.validate_paths([str(tmp_path / "nope")])
+    with pytest.raises(ValueError):
+        hu.verify_in_list(a=["x", "y"], b=["x"])
+    with pytest.raises(ValueError):
+        hu.verify_same_elements(enforce_order=True, a=["x", "y"], b=["y", "x"])
+    assert hu.verify_same_elements(a=["x", "y"], b=["y", "x"])

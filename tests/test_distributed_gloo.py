@@ -1,0 +1,97 @@
+"""The FOV-sharded batch trainer on two CPU processes (gloo): sharding, the per-step packed
+all-reduce and the identical-on-every-rank codebook, checked against the single-process oracle.
+The compute kernels are the oracle here (test infrastructure) -- this exercises the host logic
+of ark_analysis_amd.distributed, which is backend-agnostic; the HIP kernels are covered by the
+`-m gpu` tests."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ark_analysis_amd.distributed import (BatchSOMTrainer, allreduce_cluster_tables, batch_schedule,
+                                          broadcast_codebook)
+
+
+class OracleKernels:
+    """Same interface as distributed.HipKernels, backed by oracle/pxsom_oracle.c (tests only)."""
+
+    def accumulate(self, x, w, labels, sums, counts):
+        from tests import oracle_binding as ob
+        xn = np.ascontiguousarray(x.numpy(), dtype=np.float64)
+        lab, _ = ob.map_data_to_nodes(w.numpy(), xn)
+        s, c = ob.cluster_sums(xn, lab, w.shape[0])
+        labels[: len(lab)].copy_(torch.from_numpy(lab))
+        sums.copy_(torch.from_numpy(s))
+        counts.copy_(torch.from_numpy(c))
+
+    def batch_update(self, w, xdim, ydim, sums, counts, thr, alpha):
+        from tests import oracle_binding as ob
+        w.copy_(torch.from_numpy(ob.batch_update(w.numpy(), xdim, ydim, sums.numpy(), counts.numpy(), thr, alpha)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, shards, w0, xdim, ydim, m, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x = torch.from_numpy(shards[rank])
+    w = torch.from_numpy(w0.copy()) if rank == 0 else torch.zeros(w0.shape, dtype=torch.float64)
+    broadcast_codebook(w, 0)
+    trainer = BatchSOMTrainer(xdim, ydim, x.shape[1], "cpu", batch_steps=m, kernels=OracleKernels())
+    trainer.train(x, w, num_passes=2)
+    # K8 across ranks: per-cluster tables of the final labels
+    labels = torch.empty(x.shape[0], dtype=torch.int32)
+    sums = torch.zeros((xdim * ydim, x.shape[1]), dtype=torch.float64)
+    counts = torch.zeros(xdim * ydim, dtype=torch.int64)
+    trainer.kernels.accumulate(x, w, labels, sums, counts)
+    allreduce_cluster_tables(sums, counts)
+    gathered = [torch.zeros_like(w) for _ in range(world)]
+    dist.all_gather(gathered, w)
+    if rank == 0:
+        np.savez(out_path, w=w.numpy(), same=np.array([bool(torch.equal(g, w)) for g in gathered]),
+                 sums=sums.numpy(), counts=counts.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_batch_training_matches_single_process_oracle(oracle, tmp_path):
+    from ark_analysis_amd.flowsom import default_radius_range
+    xdim = ydim = 5
+    k, c, m, n_local = 25, 6, 8, 400
+    rs = np.random.RandomState(0)
+    shards = [rs.gamma(0.8, 0.4, size=(n_local, c)) for _ in range(2)]
+    w0 = shards[0][rs.choice(n_local, k, replace=False)].copy()
+    out = str(tmp_path / "rank0.npz")
+    mp.spawn(_worker, args=(2, _free_port(), shards, w0, xdim, ydim, m, out), nprocs=2, join=True)
+    res = np.load(out)
+    assert res["same"].all(), "codebook differs between ranks"
+    # single-process equivalent: interleave the shards in blocks of m rows so that global row i % m
+    # selects exactly the union of both ranks' local mini-batch (i % m)
+    blocks = []
+    for j in range(n_local // m):
+        for r in range(2):
+            blocks.append(shards[r][j * m:(j + 1) * m])
+    g = np.concatenate(blocks)
+    want = oracle.som_batch(g, w0, xdim, ydim, 2, (0.05, 0.01), default_radius_range(xdim, ydim), m)
+    np.testing.assert_allclose(res["w"], want, rtol=1e-10, atol=0)
+    lab, _ = oracle.map_data_to_nodes(want, g)
+    s, cnt = oracle.cluster_sums(g, lab, k)
+    np.testing.assert_array_equal(res["counts"], cnt)
+    np.testing.assert_allclose(res["sums"], s, rtol=1e-9, atol=1e-12)
+
+
+def test_batch_schedule_endpoints():
+    assert batch_schedule(0, 64, (0.05, 0.01), (6.0, 0.0)) == (6.0, 0.05)
+    thr, alpha = batch_schedule(63, 64, (0.05, 0.01), (6.0, 0.0))
+    assert thr == 0.5 and abs(alpha - (0.05 - 0.04 * 63 / 64)) < 1e-15   # below 1 -> BMU only
+    assert batch_schedule(32, 64, (0.05, 0.01), (6.0, 0.0))[0] == 3.0

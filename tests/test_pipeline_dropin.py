@@ -1,0 +1,227 @@
+"""The drop-in pipeline functions (ark_analysis_amd.phenotyping.*) against fixtures produced by
+the REFERENCE's own train_pixel_som / cluster_pixels / generate_som_avg_files / train_cell_som /
+cluster_cells (tests/golden/g7_*.npz; SOM arithmetic inside = oracle of record), plus mirrors of
+the reference's own unit tests for these functions.  Every test runs on CPU with the oracle
+standing in for the three device entry points and, under -m gpu, on the real HIP path."""
+import os
+import warnings
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from ark_analysis_amd.phenotyping import (cell_som_clustering, cluster_helpers, pixel_cluster_utils,
+                                          pixel_som_clustering)
+from ark_analysis_amd.phenotyping.cluster_helpers import read_dataframe, write_dataframe
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CHANS = ["chan%d" % i for i in range(4)]
+FOVS = ["fov0", "fov1", "fov2"]
+
+
+def _build_pixel_dirs(td, g):
+    os.mkdir(os.path.join(td, "pixel_mat_data"))
+    os.mkdir(os.path.join(td, "pixel_mat_subsetted"))
+    write_dataframe(pd.DataFrame(g["norm"][None, :], columns=CHANS),
+                    os.path.join(td, "post_rowsum_chan_norm.feather"))
+    for fov in FOVS:
+        df = pd.DataFrame(g["data_" + fov], columns=CHANS)
+        df["fov"] = fov
+        meta = g["meta_" + fov]
+        df["row_index"], df["column_index"], df["label"] = meta[:, 0], meta[:, 1], meta[:, 2]
+        write_dataframe(df, os.path.join(td, "pixel_mat_data", fov + ".feather"))
+        write_dataframe(df.iloc[g["subidx_" + fov]], os.path.join(td, "pixel_mat_subsetted", fov + ".feather"))
+
+
+def test_pixel_pipeline_matches_reference_run(som_backend, tmp_path, capsys):
+    g = np.load(os.path.join(GOLD, "g7_pixel_pipeline.npz"))
+    td = str(tmp_path)
+    _build_pixel_dirs(td, g)
+    obj = pixel_som_clustering.train_pixel_som(FOVS, CHANS, td, num_passes=1, seed=42)
+    pixel_som_clustering.cluster_pixels(FOVS, td, obj)
+    pixel_som_clustering.generate_som_avg_files(FOVS, CHANS, td, obj, data_dir="pixel_mat_data")
+    assert capsys.readouterr().out == str(g["stdout"])
+    # trained codebook: bit-equal (exact online mode), columns in training order
+    assert list(obj.weights.columns) == CHANS
+    np.testing.assert_array_equal(obj.weights.values, g["weights"])
+    np.testing.assert_array_equal(read_dataframe(os.path.join(td, "pixel_som_weights.feather")).values,
+                                  g["weights"])
+    for fov in FOVS:
+        res = read_dataframe(os.path.join(td, "pixel_mat_data", fov + ".feather"))
+        np.testing.assert_array_equal(res["pixel_som_cluster"].values, g["labels_" + fov])
+        np.testing.assert_array_equal(res[CHANS].values, g["normed_" + fov])   # 99.9 %-normalised write-back
+    assert not os.path.exists(os.path.join(td, "pixel_mat_data_temp"))
+    assert sorted(int(v) for v in obj.som_clusters_seen) == list(g["clusters_seen"])
+    avg = pd.read_csv(os.path.join(td, "pixel_channel_avg_som_cluster.csv"))
+    np.testing.assert_array_equal(avg["pixel_som_cluster"].values, g["avg_clusters"])
+    np.testing.assert_array_equal(avg["count"].values, g["avg_count"])
+    np.testing.assert_allclose(avg[CHANS].values, g["avg_means"], rtol=1e-12, atol=0)
+
+
+def test_cell_pipeline_matches_reference_run(som_backend, tmp_path, capsys):
+    g = np.load(os.path.join(GOLD, "g7_cell_pipeline.npz"))
+    cols = ["pixel_meta_cluster_%d" % i for i in range(1, 9)]
+    cell = pd.DataFrame(g["cell"], columns=cols)
+    cell["fov"] = g["fov"]
+    cell["segmentation_label"] = np.arange(len(cell))
+    cell["cell_size"] = g["cell_size"]
+    td = str(tmp_path)
+    open(os.path.join(td, "cell_table.csv"), "w").write("x\n")
+    cobj = cell_som_clustering.train_cell_som(["fov0", "fov1"], td, os.path.join(td, "cell_table.csv"),
+                                              cols, cell.copy(), seed=42)
+    res = cell_som_clustering.cluster_cells(td, cobj, cols)
+    assert capsys.readouterr().out == str(g["stdout"])
+    np.testing.assert_array_equal(cobj.weights.values, g["weights"])
+    np.testing.assert_array_equal(res[cols].values, g["normed"])
+    np.testing.assert_array_equal(res["cell_som_cluster"].values, g["labels"])
+    # second call without overwrite returns immediately (cell_som_clustering.py:104-108)
+    cell_som_clustering.cluster_cells(td, cobj, cols)
+    assert capsys.readouterr().out == "SOM clusters already assigned to each cell\n"
+    cell_som_clustering.generate_som_avg_files(td, res, cols, "avgs.csv")
+    avg = pd.read_csv(os.path.join(td, "avgs.csv"))
+    assert list(avg.columns) == ["cell_som_cluster"] + cols + ["count"]
+    assert avg["count"].sum() == len(res)
+
+
+# ---- mirrors of the reference's own tests (tests/phenotyping/cluster_helpers_test.py:286-420) ----
+@pytest.fixture()
+def pixel_objs(som_backend, tmp_path):
+    rs = np.random.RandomState(0)
+    cols = [f"Marker{i}" for i in range(1, 7)]
+    fovs = [f"fov{i}" for i in range(3)]
+    sub = tmp_path / "pixel_mat_subsetted"
+    sub.mkdir()
+    for fov in fovs:
+        df = pd.DataFrame(rs.rand(100, 6), columns=cols)
+        df["fov"] = fov
+        df["row_index"] = rs.randint(0, 10, 100)
+        df["column_index"] = rs.randint(0, 10, 100)
+        df["label"] = rs.randint(0, 5, 100)
+        write_dataframe(df, str(sub / f"{fov}.feather"))
+    norm_path = str(tmp_path / "norm.feather")
+    write_dataframe(pd.DataFrame(np.expand_dims(np.repeat(0.5, 6), 0), columns=cols), norm_path)
+    weights_path = str(tmp_path / "weights_new.feather")
+    obj = cluster_helpers.PixelSOMCluster(str(sub), norm_path, weights_path, fovs, cols, xdim=20, ydim=10)
+    return obj, cols, rs
+
+
+def test_reference_normalize_data(pixel_objs):
+    obj, cols, rs = pixel_objs
+    meta = ["fov", "row_index", "column_index", "label"]
+    ext = pd.DataFrame(rs.rand(1000, 10), columns=cols + meta)
+    out = obj.normalize_data(ext)
+    assert np.allclose(ext[cols].values / 0.5, out[cols].values)
+
+
+def test_reference_train_som_behaviour(pixel_objs):
+    obj, cols, rs = pixel_objs
+    obj.train_som()
+    assert os.path.exists(obj.weights_path)
+    assert list(obj.weights.columns.values) == cols          # order preserved
+    assert obj.weights.shape == (200, 6)
+    with pytest.warns(UserWarning, match="Pixel SOM already trained on specified markers"):
+        obj.train_som()
+    first = obj.weights.copy()
+    with pytest.warns(UserWarning, match="Overwrite flag set, retraining SOM"):
+        obj.train_som(overwrite=True)
+    assert np.allclose(first.values, obj.weights.values)      # same seed -> same weights
+    obj.columns = cols[:-1]
+    with pytest.warns(UserWarning, match="New markers specified, retraining"):
+        obj.train_som()
+    assert list(obj.weights.columns.values) == cols[:-1]
+
+
+def test_reference_assign_som_clusters(pixel_objs):
+    obj, cols, rs = pixel_objs
+    obj.train_som()
+    meta = ["fov", "row_index", "column_index", "label"]
+    for npp in (10, 10000):
+        ext = pd.DataFrame(rs.rand(1000, 10), columns=cols[::-1] + meta)   # shuffled column order
+        out = obj.assign_som_clusters(ext, num_parallel_pixels=npp)
+        assert out["pixel_som_cluster"].dtype.kind in "iu"
+        assert out["pixel_som_cluster"].min() >= 1 and out["pixel_som_cluster"].max() <= 200
+        again = obj.assign_som_clusters(out.drop(columns="pixel_som_cluster"), normalize_data=False,
+                                        num_parallel_pixels=npp)
+        assert np.array_equal(again[cols].values, out[cols].values)
+        assert np.array_equal(again["pixel_som_cluster"].values, out["pixel_som_cluster"].values)
+    with pytest.raises(ValueError):
+        obj.generate_som_clusters(ext, num_parallel_obs=0)
+    empty = obj.generate_som_clusters(ext.iloc[:0])
+    assert empty.shape == (0,)
+
+
+# ---- mirrors of tests/phenotyping/pixel_som_clustering_test.py -------------------------------
+def test_reference_train_pixel_som_errors(som_backend, tmp_path):
+    g = np.load(os.path.join(GOLD, "g7_pixel_pipeline.npz"))
+    td = str(tmp_path)
+    _build_pixel_dirs(td, g)
+    with pytest.raises(FileNotFoundError):
+        pixel_som_clustering.train_pixel_som(FOVS, CHANS, td, subset_dir="bad_path")
+    with pytest.raises(FileNotFoundError):
+        pixel_som_clustering.train_pixel_som(FOVS, CHANS, td, norm_vals_name="bad.feather")
+    with pytest.raises(ValueError):
+        pixel_som_clustering.train_pixel_som(["fov0", "fov9"], CHANS, td)
+    with pytest.raises(ValueError):
+        pixel_som_clustering.train_pixel_som(FOVS, ["chan0", "nope"], td)
+
+
+@pytest.mark.parametrize("multiprocess", [False, True])
+def test_reference_cluster_pixels_behaviour(som_backend, tmp_path, capsys, multiprocess):
+    g = np.load(os.path.join(GOLD, "g7_pixel_pipeline.npz"))
+    td = str(tmp_path)
+    _build_pixel_dirs(td, g)
+    norm_path = os.path.join(td, "post_rowsum_chan_norm.feather")
+    untrained = cluster_helpers.PixelSOMCluster(os.path.join(td, "pixel_mat_subsetted"), norm_path,
+                                                os.path.join(td, "none.feather"), FOVS, CHANS)
+    with pytest.raises(ValueError, match="Using untrained pixel_pysom object"):
+        pixel_som_clustering.cluster_pixels(FOVS, td, untrained)
+    obj = pixel_som_clustering.train_pixel_som(FOVS, CHANS, td)
+    capsys.readouterr()
+    # corrupt one FOV: reported, skipped, dropped from the output directory
+    with open(os.path.join(td, "pixel_mat_data", "fov1.feather"), "w") as f:
+        f.write("baddatabaddatabaddata")
+    pixel_som_clustering.cluster_pixels(FOVS, td, obj, multiprocess=multiprocess, batch_size=2)
+    out = capsys.readouterr().out
+    assert "The data for FOV fov1 has been corrupted, skipping\n" in out
+    assert not os.path.exists(os.path.join(td, "pixel_mat_data_temp"))
+    assert sorted(os.listdir(os.path.join(td, "pixel_mat_data"))) == ["fov0.feather", "fov2.feather"]
+    for fov in ("fov0", "fov2"):
+        res = read_dataframe(os.path.join(td, "pixel_mat_data", fov + ".feather"))
+        assert res["pixel_som_cluster"].max() <= 100
+        np.testing.assert_array_equal(res["pixel_som_cluster"].values, g["labels_" + fov])
+    # nothing left to do
+    pixel_som_clustering.cluster_pixels(["fov0", "fov2"], td, obj, multiprocess=multiprocess)
+    assert capsys.readouterr().out == "There are no more FOVs to assign SOM labels to, skipping\n"
+    # overwrite: data on disk is already normalised -> labels unchanged
+    pixel_som_clustering.cluster_pixels(["fov0", "fov2"], td, obj, multiprocess=multiprocess, overwrite=True)
+    out = capsys.readouterr().out
+    assert out.startswith("Overwrite flag set, reassigning SOM cluster labels to all FOVs\n")
+    res = read_dataframe(os.path.join(td, "pixel_mat_data", "fov0.feather"))
+    np.testing.assert_array_equal(res["pixel_som_cluster"].values, g["labels_fov0"])
+    np.testing.assert_array_equal(res[CHANS].values, g["normed_fov0"])
+
+
+def test_reference_generate_som_avg_files(som_backend, tmp_path, capsys):
+    g = np.load(os.path.join(GOLD, "g7_pixel_pipeline.npz"))
+    td = str(tmp_path)
+    _build_pixel_dirs(td, g)
+    obj = pixel_som_clustering.train_pixel_som(FOVS, CHANS, td)
+    pixel_som_clustering.cluster_pixels(FOVS, td, obj)
+    capsys.readouterr()
+    pixel_som_clustering.generate_som_avg_files(FOVS, CHANS, td, obj, data_dir="pixel_mat_data")
+    assert capsys.readouterr().out == "Computing average channel expression across pixel SOM clusters\n"
+    pixel_som_clustering.generate_som_avg_files(FOVS, CHANS, td, obj, data_dir="pixel_mat_data")
+    assert capsys.readouterr().out == "Already generated SOM cluster channel average file, skipping\n"
+    pixel_som_clustering.generate_som_avg_files(FOVS, CHANS, td, obj, data_dir="pixel_mat_data", overwrite=True)
+    assert capsys.readouterr().out.startswith(
+        "Overwrite flag set, regenerating SOM cluster channel average file\n")
+    # clusters lost by FOV sub-sampling -> ValueError, file not written
+    obj.som_clusters_seen = set(range(1, 151))
+    os.remove(os.path.join(td, "pixel_channel_avg_som_cluster.csv"))
+    with pytest.raises(ValueError, match="Average expression file not written"):
+        pixel_som_clustering.generate_som_avg_files(FOVS, CHANS, td, obj, data_dir="pixel_mat_data")
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        pixel_cluster_utils.compute_pixel_cluster_channel_avg(FOVS, CHANS, td, "pixel_som_cluster", None,
+                                                              "pixel_mat_data", num_fovs_subset=100)
+    assert any("Provided num_fovs_subset" in str(w.message) for w in wlist)
