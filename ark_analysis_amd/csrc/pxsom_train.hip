@@ -19,11 +19,45 @@ namespace {
 
 #pragma clang fp contract(off)
 
+// wave-wide minimum of a non-NaN double, result in every lane.  Rows of 16 lanes reduce with DPP
+// (quad_perm xor1 / xor2, row_half_mirror, row_mirror), rows combine with v_permlane16/32_swap:
+// no LDS crossbar round trips on the per-step critical path.
+__device__ __forceinline__ double dpp_f64(double v, int ctrl_sel)
+{
+    int lo = (int)__double_as_longlong(v), hi = (int)(__double_as_longlong(v) >> 32);
+    switch (ctrl_sel) {
+        case 0: lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false); break;   // quad_perm [1,0,3,2]
+        case 1: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false); break;   // quad_perm [2,3,0,1]
+        case 2: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, 0xF, false); break; // row_half_mirror
+        default: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x140, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x140, 0xF, 0xF, false); break; // row_mirror
+    }
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+__device__ __forceinline__ double wave_min_f64(double v)
+{
+    v = fmin(v, dpp_f64(v, 0));
+    v = fmin(v, dpp_f64(v, 1));
+    v = fmin(v, dpp_f64(v, 2));
+    v = fmin(v, dpp_f64(v, 3));
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    unsigned lo = (unsigned)__double_as_longlong(v), hi = (unsigned)(__double_as_longlong(v) >> 32);
+    u2 rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = fmin(__longlong_as_double(((long long)rh[0] << 32) | rl[0]), __longlong_as_double(((long long)rh[1] << 32) | rl[1]));
+    lo = (unsigned)__double_as_longlong(v);
+    hi = (unsigned)(__double_as_longlong(v) >> 32);
+    rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return fmin(__longlong_as_double(((long long)rh[0] << 32) | rl[0]), __longlong_as_double(((long long)rh[1] << 32) | rl[1]));
+}
+
 // ------------------------------------------------------------------------------------------------
-// exact online SOM
+// exact online SOM.  CMAX > 0: this thread's node (CMAX doubles) and the presented row live in
+// registers -- per step one burst of LDS reads for the row, then pure register arithmetic in the
+// oracle's order.  CMAX == 0: any channel count, codebook in LDS ([channel][node]).
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(1024) void som_online_kernel(const T *__restrict__ x, int64_t n, int c,
+template <typename T, int CMAX, int MAXT>
+__global__ __launch_bounds__(MAXT) void som_online_kernel(const T *__restrict__ x, int64_t n, int c,
                                                           int64_t ldx, double *w, int xdim, int ydim,
                                                           int rlen, double a0, double a1, double r0,
                                                           double r1, const int64_t *__restrict__ order,
@@ -33,23 +67,33 @@ __global__ __launch_bounds__(1024) void som_online_kernel(const T *__restrict__ 
     const int K = xdim * ydim;
     const int tid = threadIdx.x, bd = blockDim.x;
     const int lane = tid & 63, wv = tid >> 6, nwv = bd >> 6;
-    double *wt = reinterpret_cast<double *>(smem_raw);            // [c][K]
-    double *xs = wt + (size_t)c * K;                              // [2][chunk][c]
-    double *exd = xs + (size_t)2 * chunk * c;                     // [2][nwv] best distance per wave
+    constexpr bool REG = CMAX > 0;
+    double *wt = reinterpret_cast<double *>(smem_raw);            // [c][K] (LDS codebook; unused if REG)
+    const int cs = REG ? CMAX : c;                                // row stride of the LDS ring
+    double *xs = wt + (REG ? 0 : (size_t)c * K);                  // [2][chunk][cs] (pad slots stay 0)
+    double *exd = xs + (size_t)2 * chunk * cs;                    // [2][nwv] best distance per wave
     int *exk = reinterpret_cast<int *>(exd + 2 * nwv);            // [2][nwv] best node per wave
-    double *red = reinterpret_cast<double *>(exk + 2 * nwv + (2 * nwv & 1));  // [nwv] change partials
+    double *red = reinterpret_cast<double *>(exk + 2 * nwv);      // [nwv] change partials
+    double *alpha_ring = red + nwv;                               // [2][chunk] learning rate per step
 
     const bool has_node = tid < K;
     const int node = tid;
     const int nx = node / ydim, ny = node % ydim;
-    if (has_node)
-        for (int j = 0; j < c; j++) wt[(size_t)j * K + node] = w[(size_t)node * c + j];
+    double wr[REG ? CMAX : 1];
+    if constexpr (REG) {
+#pragma unroll
+        for (int j = 0; j < CMAX; j++) wr[j] = (has_node && j < c) ? w[(size_t)node * c + j] : 0.0;
+    } else {
+        if (has_node)
+            for (int j = 0; j < c; j++) wt[(size_t)j * K + node] = w[(size_t)node * c + j];
+    }
 
     const int64_t niter = (int64_t)rlen * n;
     double threshold = r0;
     const double thresholdStep = (r0 - r1) / (double)niter;
     double change = 1.0;   // uniform: the epoch's total, known after the epoch-boundary reduction
     double mychange = 0.0; // this thread's share of the running epoch
+    const bool track = rlen > 1;
     const int per_thread = (chunk * c + bd - 1) / bd;  // gathered elements per thread per chunk
     constexpr int kMaxPer = 16;
     double pre[kMaxPer];
@@ -67,29 +111,49 @@ __global__ __launch_bounds__(1024) void som_online_kernel(const T *__restrict__ 
             pre[u] = v;
         }
     };
+    // the oracle's alpha = a0 - (a0 - a1) * k / niter (same operation order), one lane per step,
+    // so the binary64 division is off the per-step critical path
+    auto alphas = [&](int buf, int64_t step0) {
+        if (tid < chunk) {
+            const int64_t kk = step0 + tid;
+            alpha_ring[buf * chunk + tid] = a0 - (a0 - a1) * (double)kk / (double)niter;
+        }
+    };
     auto commit = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < kMaxPer; u++) {
             const int e = tid + u * bd;
-            if (u < per_thread && e < chunk * c) xs[(size_t)buf * chunk * c + e] = pre[u];
+            if (u < per_thread && e < chunk * c) {
+                const int srow = e / c, j = e - srow * c;
+                xs[((size_t)buf * chunk + srow) * cs + j] = pre[u];
+            }
         }
     };
 
+    // zero the ring once: slots j >= c of every row are never written again, so the unguarded
+    // CMAX-long register loops below add exact zeros (x + 0 == x: bit-exactness is preserved)
+    for (int e = tid; e < 2 * chunk * cs; e += bd) xs[e] = 0.0;
+    __syncthreads();
     gather(0);
     commit(0);
+    alphas(0, 0);
     __syncthreads();
 
     bool done = false;
     int par = 0;
+    int64_t in_epoch = 0;  // step % n without a 64-bit division per step
+    int cur_buf = 0;
     for (int64_t step0 = 0; step0 < niter && !done; step0 += chunk) {
-        const int buf = (int)((step0 / chunk) & 1);
+        const int buf = cur_buf;
         gather(step0 + chunk);  // in flight while this chunk computes
-        const double *xc = xs + (size_t)buf * chunk * c;
+        const double *xc = xs + (size_t)buf * chunk * cs;
         for (int s = 0; s < chunk; s++) {
             const int64_t step = step0 + s;
             if (step >= niter) break;
             int64_t k = step;
-            if (step % n == 0) {
+            const bool epoch_start = in_epoch == 0;
+            if (++in_epoch == n) in_epoch = 0;
+            if (epoch_start) {
                 if (step > 0) {
                     // epoch boundary: total |delta| of the finished epoch (summation order differs
                     // from the oracle's sequential one; only `change < 1` is ever looked at)
@@ -108,59 +172,103 @@ __global__ __launch_bounds__(1024) void som_online_kernel(const T *__restrict__ 
                 change = 0.0;
                 mychange = 0.0;
             }
-            const double *xr = xc + (size_t)s * c;
-            // distance of this thread's node (binary64, j ascending, sqrt) -- FlowSOM eucl()
-            double d = INFINITY;
-            if (has_node) {
+            const double *xr = xc + (size_t)s * cs;
+            // squared distance of this thread's node (binary64, j ascending) -- FlowSOM eucl() before
+            // its sqrt.  The oracle compares sqrt(d2) values with a strict '<' (first minimum wins).
+            // sqrt is monotone, so whenever the smallest d2 is isolated by more than a few ulps its
+            // node is the answer and no sqrt is evaluated; only near-coincident candidates (d2 within
+            // 2^-50 relative of the minimum) take the sqrt path, which reproduces the oracle's ties.
+            double xreg[REG ? CMAX : 1];
+            double d2 = INFINITY;
+            if constexpr (REG) {
+#pragma unroll
+                for (int j = 0; j < CMAX; j++) xreg[j] = xr[j];  // one burst of broadcast LDS reads
+                double xdist = 0.0;
+#pragma unroll
+                for (int j = 0; j < CMAX; j++) {
+                    const double tmp = xreg[j] - wr[j];  // pad slots: 0 - 0
+                    xdist += tmp * tmp;
+                }
+                if (has_node && xdist == xdist) d2 = xdist;
+            } else if (has_node) {
                 double xdist = 0.0;
                 for (int j = 0; j < c; j++) {
                     const double tmp = xr[j] - wt[(size_t)j * K + node];
                     xdist += tmp * tmp;
                 }
-                d = sqrt(xdist);
-                if (!(d == d)) d = INFINITY;
+                if (xdist == xdist) d2 = xdist;
             }
-            int bk = has_node ? node : 0x7fffffff;
-            for (int off = 32; off > 0; off >>= 1) {
-                const double od = __shfl_xor(d, off);
-                const int ok = __shfl_xor(bk, off);
-                if (od < d || (od == d && ok < bk)) {
-                    d = od;
-                    bk = ok;
-                }
+            const double near_eps = 8.881784197001252e-16;  // 2^-50
+            double wmin = wave_min_f64(d2);
+            unsigned long long cand = __ballot(d2 <= wmin + wmin * near_eps);
+            int bk;
+            double bd2;
+            if (__popcll(cand) == 1) {
+                bk = (wv << 6) + (int)__ffsll((long long)cand) - 1;
+                bd2 = wmin;
+            } else {
+                const double sd = sqrt(d2);
+                const double smin = wave_min_f64(sd);
+                cand = __ballot(sd == smin);
+                const int first = cand ? (int)__ffsll((long long)cand) - 1 : 0;
+                bk = (wv << 6) + first;
+                bd2 = __shfl(d2, first);
             }
+            if (bk >= K) bk = 0x7fffffff;  // only padding lanes (all-infinite wave)
             int nearest = bk;
             if (nwv > 1) {
                 if (lane == 0) {
-                    exd[par * nwv + wv] = d;
+                    exd[par * nwv + wv] = bd2;
                     exk[par * nwv + wv] = bk;
                 }
                 __syncthreads();
-                double bd_ = exd[par * nwv];
-                nearest = exk[par * nwv];
-                for (int i = 1; i < nwv; i++) {
-                    const double od = exd[par * nwv + i];
-                    const int ok = exk[par * nwv + i];
-                    if (od < bd_ || (od == bd_ && ok < nearest)) {
-                        bd_ = od;
-                        nearest = ok;
+                double gmin = exd[par * nwv];
+                for (int i = 1; i < nwv; i++) gmin = fmin(gmin, exd[par * nwv + i]);
+                const double lim = gmin + gmin * near_eps;
+                int ncand = 0;
+                for (int i = 0; i < nwv; i++) {
+                    if (exd[par * nwv + i] <= lim) {
+                        if (ncand == 0) nearest = exk[par * nwv + i];
+                        ncand++;
+                    }
+                }
+                if (ncand > 1) {  // near-coincident minima in different waves: compare like the oracle
+                    double best = INFINITY;
+                    nearest = 0x7fffffff;
+                    for (int i = 0; i < nwv; i++) {
+                        const double sdi = sqrt(exd[par * nwv + i]);
+                        const int ki = exk[par * nwv + i];
+                        if (sdi < best || (sdi == best && ki < nearest)) {
+                            best = sdi;
+                            nearest = ki;
+                        }
                     }
                 }
                 par ^= 1;
             }
             if (nearest >= K) nearest = 0;
             if (threshold < 1.0) threshold = 0.5;
-            const double alpha = a0 - (a0 - a1) * (double)k / (double)niter;
+            const double alpha = k == step ? alpha_ring[buf * chunk + s]
+                                           : a0 - (a0 - a1) * (double)k / (double)niter;  // early-stop step
             if (has_node) {
                 const int bx = nearest / ydim, by = nearest % ydim;
                 const int dx = nx > bx ? nx - bx : bx - nx, dy = ny > by ? ny - by : by - ny;
                 const double nh = (double)(dx > dy ? dx : dy);
                 if (!(nh > threshold)) {
-                    for (int j = 0; j < c; j++) {
-                        const double wv_ = wt[(size_t)j * K + node];
-                        const double tmp = xr[j] - wv_;
-                        mychange += fabs(tmp);
-                        wt[(size_t)j * K + node] = wv_ + tmp * alpha;
+                    if constexpr (REG) {
+#pragma unroll
+                        for (int j = 0; j < CMAX; j++) {
+                            const double tmp = xreg[j] - wr[j];
+                            if (track) mychange += fabs(tmp);  // only ever consulted when rlen > 1
+                            wr[j] = wr[j] + tmp * alpha;
+                        }
+                    } else {
+                        for (int j = 0; j < c; j++) {
+                            const double wv_ = wt[(size_t)j * K + node];
+                            const double tmp = xr[j] - wv_;
+                            mychange += fabs(tmp);
+                            wt[(size_t)j * K + node] = wv_ + tmp * alpha;
+                        }
                     }
                 }
             }
@@ -169,10 +277,19 @@ __global__ __launch_bounds__(1024) void som_online_kernel(const T *__restrict__ 
         }
         // publish the next chunk's rows (other buffer: nobody reads it during this chunk)
         commit(buf ^ 1);
+        alphas(buf ^ 1, step0 + chunk);
+        cur_buf ^= 1;
         __syncthreads();
     }
-    if (has_node)
-        for (int j = 0; j < c; j++) w[(size_t)node * c + j] = wt[(size_t)j * K + node];
+    if (has_node) {
+        if constexpr (REG) {
+#pragma unroll
+            for (int j = 0; j < CMAX; j++)
+                if (j < c) w[(size_t)node * c + j] = wr[j];
+        } else {
+            for (int j = 0; j < c; j++) w[(size_t)node * c + j] = wt[(size_t)j * K + node];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -280,27 +397,48 @@ __global__ __launch_bounds__(256) void cluster_sums_kernel(const T *__restrict__
     }
 }
 
-template <typename T>
-int train_online_typed(const T *x, int64_t n, int c, int64_t ldx, double *w, int xdim, int ydim, int rlen,
-                       double a0, double a1, double r0, double r1, const int64_t *order, hipStream_t st)
+template <typename T, int CMAX, int MAXT>
+int launch_online(const T *x, int64_t n, int c, int64_t ldx, double *w, int xdim, int ydim, int rlen, double a0,
+                  double a1, double r0, double r1, const int64_t *order, hipStream_t st)
 {
     const int K = xdim * ydim;
     const int bd = ((K + 63) / 64) * 64;
     const int nwv = bd / 64;
-    const size_t fixed = (size_t)c * K * 8 + (size_t)2 * nwv * 8 + (size_t)(2 * nwv + 2) * 4 + (size_t)nwv * 8 + 64;
+    const size_t fixed = (CMAX > 0 ? 0 : (size_t)c * K * 8) + (size_t)2 * nwv * 8 + (size_t)2 * nwv * 4 +
+                         (size_t)nwv * 8 + 2 * 64 * 8 + 64;
     int chunk = 64;
-    while (chunk > 8 && fixed + (size_t)2 * chunk * c * 8 > 150 * 1024) chunk >>= 1;
+    const int cs = CMAX > 0 ? CMAX : c;
+    while (chunk > 8 && fixed + (size_t)2 * chunk * cs * 8 > 150 * 1024) chunk >>= 1;
     while ((chunk * c + bd - 1) / bd > 16) chunk >>= 1;  // gather registers per thread
-    const size_t lds = fixed + (size_t)2 * chunk * c * 8;
+    const size_t lds = fixed + (size_t)2 * chunk * cs * 8;
     if (chunk < 1 || lds > 160 * 1024)
         return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "pxsom_train_online: codebook %dx%d does not fit LDS", K, c);
-    auto kern = som_online_kernel<T>;
+    auto kern = som_online_kernel<T, CMAX, MAXT>;
     PXSOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(1), dim3(bd), lds, st, x, n, c, ldx, w, xdim, ydim, rlen, a0, a1, r0, r1,
                        order, chunk);
     PXSOM_LAUNCH_CHECK("som_online_kernel");
     return PXSOM_OK;
+}
+
+template <typename T>
+int train_online_typed(const T *x, int64_t n, int c, int64_t ldx, double *w, int xdim, int ydim, int rlen,
+                       double a0, double a1, double r0, double r1, const int64_t *order, hipStream_t st)
+{
+#define PXSOM_ONLINE(CM, MT) \
+    return launch_online<T, CM, MT>(x, n, c, ldx, w, xdim, ydim, rlen, a0, a1, r0, r1, order, st)
+    // <= 256 nodes: 4 waves at most, the whole register file is available per thread
+    if (xdim * ydim <= 256) {
+        if (c <= 8) PXSOM_ONLINE(8, 256);
+        if (c <= 16) PXSOM_ONLINE(16, 256);
+        if (c <= 24) PXSOM_ONLINE(24, 256);
+        if (c <= 40) PXSOM_ONLINE(40, 256);
+        if (c <= 64) PXSOM_ONLINE(64, 256);
+        PXSOM_ONLINE(0, 256);
+    }
+    PXSOM_ONLINE(0, 1024);  // > 256 nodes: 128 VGPRs per thread, codebook stays in LDS
+#undef PXSOM_ONLINE
 }
 
 template <typename T>
