@@ -1,0 +1,420 @@
+// pxsom_pre.hip -- pixel-matrix pre-processing on gfx950 (create_fov_pixel_data and the 99.9 % values).
+//
+//   pxsom_gaussian_blur_hwc        scipy.ndimage.gaussian_filter(plane, sigma) per channel
+//                                  (/root/reference/src/ark/phenotyping/pixie_preprocessing.py:47-49)
+//   pxsom_rowsum_filter_normalize  row-sum threshold + non-zero filter + row normalisation + compaction
+//                                  (pixie_preprocessing.py:67-75, pixel_cluster_utils.py:126-130)
+//   pxsom_normalize_columns        x[:, j] / norm[j]  (cluster_helpers.py:242-246)
+//   pxsom_quantile_nonzero         type-7 quantile of the non-zero values of each column
+//                                  (pixie_preprocessing.py:406-408, cluster_helpers.py:366,
+//                                   pixel_cluster_utils.py:47-51)
+// All binary64 with one rounding per operation in the reference's order (fp contraction off), so the
+// results equal the oracle's, which is pinned to scipy / pandas / numpy (tests/test_oracle_golden.py).
+// These kernels are HBM-streaming: every element is read and written O(1) times; the 17-tap windows are
+// served by L1/L2.
+#include <cfloat>
+#include <cmath>
+
+#include "pxsom_common.h"
+
+namespace {
+
+#pragma clang fp contract(off)
+
+constexpr int kMaxRadius = 64;
+
+struct Taps {
+    double w[kMaxRadius + 1];  // w[0] centre, w[d] weight at distance d (symmetric kernel)
+    int radius;
+};
+
+// scipy NI_EXTEND_REFLECT: (d c b a | a b c d | d c b a)
+__device__ __forceinline__ int reflect_idx(int i, int len)
+{
+    if (len == 1) return 0;
+    const int sz2 = 2 * len;
+    if (i < 0) {
+        if (i < -sz2) i = sz2 * (-i / sz2) + i;
+        i = i < -len ? i + sz2 : -i - 1;
+    } else if (i >= len) {
+        i -= sz2 * (i / sz2);
+        if (i >= len) i = sz2 - i - 1;
+    }
+    return i;
+}
+
+// One pass of scipy's correlate1d, symmetric-kernel branch:
+//   tmp = in[0]*w[0];  for d = r .. 1:  tmp += (in[-d] + in[+d]) * w[d]
+// AXIS 0: along image rows (stride W*C), AXIS 1: along image columns (stride C).
+// Thread <-> one output element; consecutive threads walk (x, c), so every tap is a coalesced read.
+template <int AXIS>
+__global__ __launch_bounds__(256) void blur_pass_kernel(const double *__restrict__ in, double *__restrict__ out,
+                                                        int H, int W, int C, Taps taps)
+{
+    const int64_t total = (int64_t)H * W * C;
+    const int64_t wc = (int64_t)W * C;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int y = (int)(e / wc);
+        const int64_t rem = e - (int64_t)y * wc;
+        const int xcol = (int)(rem / C);
+        const int pos = AXIS == 0 ? y : xcol, len = AXIS == 0 ? H : W;
+        const int64_t stride = AXIS == 0 ? wc : C;
+        const int64_t base = e - (int64_t)pos * stride;
+        double tmp = in[e] * taps.w[0];
+        const bool interior = pos >= taps.radius && pos + taps.radius < len;
+        for (int d = taps.radius; d >= 1; d--) {
+            const int lo = interior ? pos - d : reflect_idx(pos - d, len);
+            const int hi = interior ? pos + d : reflect_idx(pos + d, len);
+            tmp += (in[base + (int64_t)lo * stride] + in[base + (int64_t)hi * stride]) * taps.w[d];
+        }
+        out[e] = tmp;
+    }
+}
+
+// ---- row filter + normalise + compaction ---------------------------------------------------------
+// pass A: keep flag per row and per-workgroup kept counts; pass B: exclusive scan of the counts (one
+// workgroup); pass C: rows rewritten as x / rowsum at their compacted position, in pixel order.
+__device__ __forceinline__ bool row_keep(const double *__restrict__ row, int c, double thresh, double &s)
+{
+    double acc = 0.0;  // left-to-right, as pandas' DataFrame.sum(axis=1) adds the columns
+    bool any = false;
+    for (int j = 0; j < c; j++) {
+        const double v = row[j];
+        acc += v;
+        any |= (v != 0.0);
+    }
+    s = acc;
+    return (acc > thresh) && any;
+}
+
+__global__ __launch_bounds__(256) void rowfilter_count_kernel(const double *__restrict__ x, int64_t n, int c,
+                                                              double thresh, unsigned *__restrict__ block_counts)
+{
+    __shared__ unsigned s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool keep = false;
+    if (row < n) {
+        double s;
+        keep = row_keep(x + row * c, c, thresh, s);
+    }
+    const unsigned long long m = __ballot(keep);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&s_cnt, (unsigned)__popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = s_cnt;
+}
+
+__global__ __launch_bounds__(1024) void block_scan_kernel(unsigned *__restrict__ block_counts, int64_t nblocks,
+                                                          int64_t *__restrict__ total_out)
+{
+    // exclusive scan in place (int64 running offset kept in shared memory between 1024-wide sweeps)
+    __shared__ unsigned long long s_part[1024];
+    __shared__ unsigned long long s_base;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (int64_t b0 = 0; b0 < nblocks; b0 += 1024) {
+        const int64_t i = b0 + threadIdx.x;
+        const unsigned v = i < nblocks ? block_counts[i] : 0u;
+        s_part[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const unsigned long long t = threadIdx.x >= off ? s_part[threadIdx.x - off] : 0ull;
+            __syncthreads();
+            s_part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const unsigned long long incl = s_part[threadIdx.x], base = s_base;
+        if (i < nblocks) block_counts[i] = (unsigned)(base + incl - v);  // < 2^32 rows per call
+        __syncthreads();
+        if (threadIdx.x == 1023) s_base = base + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = (int64_t)s_base;
+}
+
+__global__ __launch_bounds__(256) void rowfilter_write_kernel(const double *__restrict__ x, int64_t n, int c,
+                                                              double thresh, const unsigned *__restrict__ block_off,
+                                                              double *__restrict__ out_rows,
+                                                              int64_t *__restrict__ out_index)
+{
+    __shared__ unsigned s_wave[4];
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    bool keep = false;
+    double s = 0.0;
+    if (row < n) keep = row_keep(x + row * c, c, thresh, s);
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) s_wave[wv] = (unsigned)__popcll(m);
+    __syncthreads();
+    unsigned off = block_off[blockIdx.x];
+    for (int i = 0; i < wv; i++) off += s_wave[i];
+    if (keep) {
+        const int64_t dst = (int64_t)off + __popcll(m & ((1ull << lane) - 1ull));
+        const double *src = x + row * c;
+        double *d = out_rows + dst * c;
+        for (int j = 0; j < c; j++) d[j] = src[j] / s;
+        out_index[dst] = row;
+    }
+}
+
+__global__ __launch_bounds__(256) void normalize_columns_kernel(const double *__restrict__ x, int64_t n, int c,
+                                                                int64_t ldx, const double *__restrict__ norm,
+                                                                double *__restrict__ out, int64_t ldo)
+{
+    const int64_t total = n * c;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t row = e / c;
+        const int j = (int)(e - row * c);
+        out[row * ldo + j] = x[row * ldx + j] / norm[j];
+    }
+}
+
+// ---- exact quantile of the non-zero values of each column (MSB-first radix select on binary64) ----
+// key(v): order-preserving 64-bit integer image of a double.
+__device__ __forceinline__ unsigned long long f64_key(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_f64(unsigned long long k)
+{
+    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+__device__ __forceinline__ bool q_keep(double v, int keep_mode) { return keep_mode == 0 ? (v != 0.0 && v == v) : (v > 0.0); }
+
+struct QState {              // per column, in the workspace
+    unsigned long long prefix;   // key bits fixed so far (high bits)
+    unsigned long long m;        // number of kept values
+    unsigned long long rank;     // rank still to find inside the current prefix bucket
+    unsigned long long lo_key, hi_key;
+    unsigned long long count_le; // kept values with key <= lo_key
+};
+
+// pass (shift = 56, 48, ..., 0): histogram of byte (key >> shift) over kept values whose higher bits equal
+// prefix.  hist [c][256] u64 in the workspace (zeroed before every pass).
+__global__ __launch_bounds__(256) void q_hist_kernel(const double *__restrict__ x, int64_t n, int c, int64_t ldx,
+                                                     int keep_mode, int shift, const QState *__restrict__ st,
+                                                     unsigned long long *__restrict__ hist, int first_pass)
+{
+    __shared__ unsigned s_h[256];
+    const int col = blockIdx.y;
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned long long prefix = first_pass ? 0ull : st[col].prefix;
+    const unsigned long long himask = shift >= 56 ? 0ull : (~0ull << (shift + 8));
+    for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < n; row += (int64_t)gridDim.x * 256) {
+        const double v = x[row * ldx + col];
+        if (!q_keep(v, keep_mode)) continue;
+        const unsigned long long k = f64_key(v);
+        if ((k & himask) != (prefix & himask)) continue;
+        atomicAdd(&s_h[(unsigned)(k >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (s_h[threadIdx.x]) atomicAdd(&hist[(size_t)col * 256 + threadIdx.x], (unsigned long long)s_h[threadIdx.x]);
+}
+
+// one thread per column: locate the bucket holding `rank`, narrow the prefix.  On the first pass also
+// derive m and the target rank lo = floor(q*(m-1)).
+__global__ void q_select_kernel(QState *st, unsigned long long *hist, int c, int shift, double q, int first_pass)
+{
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= c) return;
+    unsigned long long *h = hist + (size_t)col * 256;
+    QState s = st[col];
+    if (first_pass) {
+        unsigned long long m = 0;
+        for (int b = 0; b < 256; b++) m += h[b];
+        s.m = m;
+        s.prefix = 0;
+        double vi = q * (double)(m > 0 ? m - 1 : 0);
+        unsigned long long lo = (unsigned long long)floor(vi);
+        if (m > 0 && lo > m - 1) lo = m - 1;
+        s.rank = lo;
+    }
+    if (s.m > 0) {
+        unsigned long long acc = 0;
+        int b = 0;
+        for (; b < 256; b++) {
+            if (acc + h[b] > s.rank) break;
+            acc += h[b];
+        }
+        if (b > 255) b = 255;
+        s.rank -= acc;
+        s.prefix |= (unsigned long long)b << shift;
+    }
+    for (int b = 0; b < 256; b++) h[b] = 0;  // ready for the next pass
+    st[col] = s;
+}
+
+// after the last pass prefix == key of the order statistic lo.  One more sweep: count keys <= lo_key and
+// find the smallest key above it (the next order statistic unless lo_key is repeated).
+__global__ __launch_bounds__(256) void q_next_kernel(const double *__restrict__ x, int64_t n, int c, int64_t ldx,
+                                                     int keep_mode, QState *st)
+{
+    __shared__ unsigned long long s_min;
+    __shared__ unsigned s_cnt;
+    const int col = blockIdx.y;
+    if (threadIdx.x == 0) {
+        s_min = ~0ull;
+        s_cnt = 0;
+    }
+    __syncthreads();
+    const unsigned long long lo_key = st[col].prefix;
+    unsigned long long mymin = ~0ull;
+    unsigned mycnt = 0;
+    for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < n; row += (int64_t)gridDim.x * 256) {
+        const double v = x[row * ldx + col];
+        if (!q_keep(v, keep_mode)) continue;
+        const unsigned long long k = f64_key(v);
+        if (k <= lo_key) mycnt++;
+        else if (k < mymin) mymin = k;
+    }
+    atomicMin(&s_min, mymin);
+    atomicAdd(&s_cnt, mycnt);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMin(&st[col].hi_key, s_min);
+        atomicAdd(&st[col].count_le, (unsigned long long)s_cnt);
+    }
+}
+
+// numpy's linear interpolation (_lerp): a + (b-a)*g for g < 0.5, b - (b-a)*(1-g) otherwise.
+__global__ void q_finish_kernel(const QState *st, int c, double q, double *out)
+{
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= c) return;
+    const QState s = st[col];
+    if (s.m == 0) {
+        out[col] = __longlong_as_double(0x7ff8000000000000ll);  // NaN, like pandas for an all-zero column
+        return;
+    }
+    const double vi = q * (double)(s.m - 1);
+    unsigned long long lo = (unsigned long long)floor(vi);
+    if (lo > s.m - 1) lo = s.m - 1;
+    const unsigned long long hi = lo + 1 > s.m - 1 ? s.m - 1 : lo + 1;
+    const double g = vi - (double)lo;
+    const double a = key_f64(s.prefix);
+    // order statistic hi: still lo's value if that value occupies ranks beyond lo
+    const double b = (hi == lo || s.count_le > hi) ? a : key_f64(s.hi_key);
+    const double diff = b - a;
+    out[col] = g >= 0.5 ? b - diff * (1.0 - g) : a + diff * g;
+}
+
+__global__ void q_init_kernel(QState *st, int c)
+{
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= c) return;
+    QState s;
+    s.prefix = 0;
+    s.m = 0;
+    s.rank = 0;
+    s.lo_key = 0;
+    s.hi_key = ~0ull;
+    s.count_le = 0;
+    st[col] = s;
+}
+
+#pragma clang fp contract(fast)
+
+}  // namespace
+
+PXSOM_EXPORT int pxsom_gaussian_blur_hwc(double *img_dev, double *tmp_dev, int h, int w, int c,
+                                         const double *weights_host, int radius, void *stream)
+{
+    if (!img_dev || !tmp_dev || !weights_host || h < 1 || w < 1 || c < 1)
+        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_gaussian_blur_hwc: bad arguments");
+    if (radius < 0 || radius > kMaxRadius)
+        return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "pxsom_gaussian_blur_hwc: radius %d outside [0, %d]", radius, kMaxRadius);
+    Taps taps;
+    taps.radius = radius;
+    for (int d = 0; d <= radius; d++) taps.w[d] = weights_host[radius + d];  // symmetric: w[r+d] == w[r-d]
+    for (int d = radius + 1; d <= kMaxRadius; d++) taps.w[d] = 0.0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t total = (int64_t)h * w * c;
+    const int grid = (int)std::min<int64_t>((total + 255) / 256, (int64_t)pxsom::device_cu_count() * 16);
+    hipLaunchKernelGGL(blur_pass_kernel<0>, dim3(grid), dim3(256), 0, st, img_dev, tmp_dev, h, w, c, taps);
+    PXSOM_LAUNCH_CHECK("blur_pass_kernel<0>");
+    hipLaunchKernelGGL(blur_pass_kernel<1>, dim3(grid), dim3(256), 0, st, tmp_dev, img_dev, h, w, c, taps);
+    PXSOM_LAUNCH_CHECK("blur_pass_kernel<1>");
+    return PXSOM_OK;
+}
+
+PXSOM_EXPORT size_t pxsom_rownorm_workspace_bytes(int64_t n)
+{
+    if (n < 0) return 0;
+    return pxsom::align_up((size_t)((n + 255) / 256 + 1) * sizeof(unsigned), 256);
+}
+
+PXSOM_EXPORT int pxsom_rowsum_filter_normalize(const double *x_dev, int64_t n, int c, double thresh,
+                                               double *out_rows_dev, int64_t *out_index_dev, int64_t *out_count_dev,
+                                               void *workspace_dev, size_t workspace_bytes, void *stream)
+{
+    if (n < 0 || n > 0x7fffffffLL || c < 1 || !out_count_dev || (n > 0 && (!x_dev || !out_rows_dev || !out_index_dev)))
+        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_rowsum_filter_normalize: bad arguments");
+    if (!workspace_dev || workspace_bytes < pxsom_rownorm_workspace_bytes(n))
+        return pxsom::fail(PXSOM_ERR_WORKSPACE, "pxsom_rowsum_filter_normalize: workspace too small");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (n == 0) {
+        PXSOM_HIP_TRY(hipMemsetAsync(out_count_dev, 0, sizeof(int64_t), st));
+        return PXSOM_OK;
+    }
+    unsigned *counts = reinterpret_cast<unsigned *>(workspace_dev);
+    const int64_t nblocks = (n + 255) / 256;
+    hipLaunchKernelGGL(rowfilter_count_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, x_dev, n, c, thresh, counts);
+    PXSOM_LAUNCH_CHECK("rowfilter_count_kernel");
+    hipLaunchKernelGGL(block_scan_kernel, dim3(1), dim3(1024), 0, st, counts, nblocks, out_count_dev);
+    PXSOM_LAUNCH_CHECK("block_scan_kernel");
+    hipLaunchKernelGGL(rowfilter_write_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, x_dev, n, c, thresh, counts,
+                       out_rows_dev, out_index_dev);
+    PXSOM_LAUNCH_CHECK("rowfilter_write_kernel");
+    return PXSOM_OK;
+}
+
+PXSOM_EXPORT int pxsom_normalize_columns(const double *x_dev, int64_t n, int c, int64_t ldx, const double *norm_dev,
+                                         double *out_dev, int64_t ldo, void *stream)
+{
+    if (n < 0 || c < 1 || ldx < c || ldo < c || !norm_dev || (n > 0 && (!x_dev || !out_dev)))
+        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_normalize_columns: bad arguments");
+    if (n == 0) return PXSOM_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int grid = (int)std::min<int64_t>((n * c + 255) / 256, (int64_t)pxsom::device_cu_count() * 16);
+    hipLaunchKernelGGL(normalize_columns_kernel, dim3(grid), dim3(256), 0, st, x_dev, n, c, ldx, norm_dev, out_dev, ldo);
+    PXSOM_LAUNCH_CHECK("normalize_columns_kernel");
+    return PXSOM_OK;
+}
+
+PXSOM_EXPORT size_t pxsom_quantile_workspace_bytes(int64_t n, int c)
+{
+    if (n < 0 || c < 1) return 0;
+    (void)n;
+    return pxsom::align_up((size_t)c * sizeof(QState), 256) + (size_t)c * 256 * sizeof(unsigned long long);
+}
+
+PXSOM_EXPORT int pxsom_quantile_nonzero(const double *x_dev, int64_t n, int c, int64_t ldx, double q, int keep_mode,
+                                        double *out_dev, void *workspace_dev, size_t workspace_bytes, void *stream)
+{
+    if (n < 0 || c < 1 || c > 65535 || ldx < c || !(q >= 0.0 && q <= 1.0) || !out_dev || (n > 0 && !x_dev))
+        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_quantile_nonzero: bad arguments");
+    if (!workspace_dev || workspace_bytes < pxsom_quantile_workspace_bytes(n, c))
+        return pxsom::fail(PXSOM_ERR_WORKSPACE, "pxsom_quantile_nonzero: workspace too small");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    QState *qs = reinterpret_cast<QState *>(workspace_dev);
+    unsigned long long *hist =
+        reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(workspace_dev) + pxsom::align_up((size_t)c * sizeof(QState), 256));
+    const int cgrid = (c + 63) / 64;
+    hipLaunchKernelGGL(q_init_kernel, dim3(cgrid), dim3(64), 0, st, qs, c);
+    PXSOM_HIP_TRY(hipMemsetAsync(hist, 0, (size_t)c * 256 * sizeof(unsigned long long), st));
+    int rgrid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)pxsom::device_cu_count() * 2);
+    if (rgrid < 1) rgrid = 1;
+    for (int shift = 56, first = 1; shift >= 0; shift -= 8, first = 0) {
+        hipLaunchKernelGGL(q_hist_kernel, dim3(rgrid, c), dim3(256), 0, st, x_dev, n, c, ldx, keep_mode, shift, qs, hist,
+                           first);
+        hipLaunchKernelGGL(q_select_kernel, dim3(cgrid), dim3(64), 0, st, qs, hist, c, shift, q, first);
+    }
+    hipLaunchKernelGGL(q_next_kernel, dim3(rgrid, c), dim3(256), 0, st, x_dev, n, c, ldx, keep_mode, qs);
+    hipLaunchKernelGGL(q_finish_kernel, dim3(cgrid), dim3(64), 0, st, qs, c, q, out_dev);
+    PXSOM_LAUNCH_CHECK("pxsom_quantile_nonzero");
+    return PXSOM_OK;
+}

@@ -139,5 +139,74 @@ def batch_update(w: torch.Tensor, xdim: int, ydim: int, sums: torch.Tensor, coun
     return w
 
 
+def gaussian_kernel1d(sigma: float, truncate: float = 4.0):
+    """scipy.ndimage._filters._gaussian_kernel1d(sigma, 0, radius): host numpy, as scipy builds it."""
+    radius = int(truncate * float(sigma) + 0.5)
+    sigma2 = sigma * sigma
+    xs = np.arange(-radius, radius + 1)
+    phi_x = np.exp(-0.5 / sigma2 * xs ** 2)
+    phi_x = phi_x / phi_x.sum()
+    return np.ascontiguousarray(phi_x[::-1], dtype=np.float64), radius
+
+
+def gaussian_blur_hwc(img: torch.Tensor, sigma: float, tmp: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """In-place per-channel Gaussian blur of an [H, W, C] float64 HBM image (scipy semantics)."""
+    if img.dtype != torch.float64 or not img.is_cuda or not img.is_contiguous() or img.dim() != 3:
+        raise ValueError("image must be a contiguous float64 [H, W, C] HBM tensor")
+    h, w, c = img.shape
+    if tmp is None:
+        tmp = torch.empty_like(img)
+    weights, radius = gaussian_kernel1d(sigma)
+    rc = _capi.lib().pxsom_gaussian_blur_hwc(img.data_ptr(), tmp.data_ptr(), h, w, c,
+                                             weights.ctypes.data, radius, _capi.stream_ptr())
+    _capi.check(rc, "pxsom_gaussian_blur_hwc")
+    return img
+
+
+def rowsum_filter_normalize(x: torch.Tensor, thresh: float):
+    """(rows [m, C] f64 = x_i / rowsum_i for kept pixels, flat pixel index [m] i64), compacted in order."""
+    if x.dtype != torch.float64 or not x.is_cuda or not x.is_contiguous() or x.dim() != 2:
+        raise ValueError("matrix must be a contiguous float64 [N, C] HBM tensor")
+    n, c = x.shape
+    out = torch.empty_like(x)
+    idx = torch.empty(n, dtype=torch.int64, device=x.device)
+    cnt = torch.zeros(1, dtype=torch.int64, device=x.device)
+    wsb = _capi.lib().pxsom_rownorm_workspace_bytes(n)
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=x.device)
+    rc = _capi.lib().pxsom_rowsum_filter_normalize(x.data_ptr(), n, c, float(thresh), out.data_ptr(),
+                                                   idx.data_ptr(), cnt.data_ptr(), ws.data_ptr(), wsb,
+                                                   _capi.stream_ptr())
+    _capi.check(rc, "pxsom_rowsum_filter_normalize")
+    m = int(cnt.item())
+    return out[:m], idx[:m]
+
+
+def normalize_columns(x: torch.Tensor, norm: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if x.dtype != torch.float64 or norm.dtype != torch.float64:
+        raise ValueError("normalize_columns works in float64 like the reference")
+    n, c = x.shape
+    if out is None:
+        out = torch.empty((n, c), dtype=torch.float64, device=x.device)
+    rc = _capi.lib().pxsom_normalize_columns(x.data_ptr(), n, c, x.stride(0) if n > 1 else c, norm.data_ptr(),
+                                             out.data_ptr(), out.stride(0) if n > 1 else c, _capi.stream_ptr())
+    _capi.check(rc, "pxsom_normalize_columns")
+    return out
+
+
+def quantile_nonzero(x: torch.Tensor, q: float, keep_mode: int = 0) -> torch.Tensor:
+    """Exact type-7 quantile of the kept (non-zero / positive) values of every column -> [C] f64."""
+    if x.dtype != torch.float64 or not x.is_cuda or x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("matrix must be a float64 [N, C] HBM tensor with contiguous rows")
+    n, c = x.shape
+    out = torch.empty(c, dtype=torch.float64, device=x.device)
+    wsb = _capi.lib().pxsom_quantile_workspace_bytes(n, c)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+    rc = _capi.lib().pxsom_quantile_nonzero(x.data_ptr(), n, c, x.stride(0) if n > 1 else c, float(q),
+                                            int(keep_mode), out.data_ptr(), ws.data_ptr(), wsb,
+                                            _capi.stream_ptr())
+    _capi.check(rc, "pxsom_quantile_nonzero")
+    return out
+
+
 def to_numpy(t: torch.Tensor) -> np.ndarray:
     return t.detach().cpu().numpy()

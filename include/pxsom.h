@@ -132,6 +132,41 @@ int pxsom_batch_accumulate(const void *x_dev, int64_t n, int c, int64_t ldx, int
 int pxsom_batch_update(double *w_dev, int xdim, int ydim, int c, const double *sums_dev,
                        const int64_t *counts_dev, double thr, double alpha, void *stream);
 
+/* ---- pre-processing (create_fov_pixel_data and the 99.9 % values) -----------------------------
+ * reference: pixie_preprocessing.py:47-49 -> scipy.ndimage.gaussian_filter(plane, sigma) per channel:
+ * separable, 'reflect' boundary, axis 0 then axis 1, binary64, scipy's symmetric-kernel summation
+ * order.  weights_host [2*radius+1] is the normalised kernel exactly as scipy builds it
+ * (numpy exp / sum on the host: part of the reference numerics), radius = int(4*sigma + 0.5).
+ * img_dev [h, w, c] binary64 interleaved, blurred in place; tmp_dev: same-size scratch. */
+int pxsom_gaussian_blur_hwc(double *img_dev, double *tmp_dev, int h, int w, int c,
+                            const double *weights_host, int radius, void *stream);
+
+/* reference: pixie_preprocessing.py:67-75 + pixel_cluster_utils.normalize_rows (:126-130):
+ * keep pixel i iff rowsum_i > thresh and any(x_ij != 0); out row = x_i / rowsum_i (left-to-right
+ * binary64 row sum, as pandas computes it).  Kept rows are compacted in pixel order.
+ *   out_rows_dev [<= n, c] binary64, out_index_dev [<= n] int64 flat pixel index of each kept row,
+ *   out_count_dev [1] int64.  workspace from pxsom_rownorm_workspace_bytes(n). */
+size_t pxsom_rownorm_workspace_bytes(int64_t n);
+int pxsom_rowsum_filter_normalize(const double *x_dev, int64_t n, int c, double thresh,
+                                  double *out_rows_dev, int64_t *out_index_dev,
+                                  int64_t *out_count_dev, void *workspace_dev,
+                                  size_t workspace_bytes, void *stream);
+
+/* reference: PixelSOMCluster.normalize_data (cluster_helpers.py:242-246): x[:, j] / norm[j] in
+ * binary64 (in place allowed: out_dev may equal x_dev). */
+int pxsom_normalize_columns(const double *x_dev, int64_t n, int c, int64_t ldx,
+                            const double *norm_dev, double *out_dev, int64_t ldo, void *stream);
+
+/* reference: df.replace(0, nan).quantile(q) per column (pixie_preprocessing.py:406-408,
+ * cluster_helpers.py:366) / np.quantile(img[img > 0], q) (pixel_cluster_utils.py:47-51):
+ * type-7 (linear) quantile of the kept values (keep_mode 0: != 0 and not NaN, 1: > 0) of each column.
+ * out_dev [c] binary64 (NaN for a column with no kept value).  Exact: MSB-first radix select on the
+ * binary64 bit patterns, then numpy's interpolation formula.  Note pandas' effective q is (q*100)/100. */
+size_t pxsom_quantile_workspace_bytes(int64_t n, int c);
+int pxsom_quantile_nonzero(const double *x_dev, int64_t n, int c, int64_t ldx, double q,
+                           int keep_mode, double *out_dev, void *workspace_dev,
+                           size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,113 @@
+"""Parity of the pre-processing HIP kernels with fixtures produced by the reference's own numerics
+(scipy.ndimage.gaussian_filter, create_fov_pixel_data, pandas / numpy quantiles) and with the
+oracle.  `-m gpu` only."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from ark_analysis_amd import som_device as sd
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_gaussian_blur_matches_scipy_fixture_and_oracle(gpu, oracle, tag):
+    g = np.load(os.path.join(GOLD, f"g2_fovpixel_{tag}.npz"))
+    img = torch.from_numpy(g["img"].copy()).to(gpu)
+    sd.gaussian_blur_hwc(img, 2.0)
+    got = img.cpu().numpy()
+    np.testing.assert_allclose(got, g["blurred"], rtol=1e-13, atol=1e-300)        # scipy's output
+    np.testing.assert_array_equal(got, oracle.gaussian_blur_hwc(g["img"], 2.0))   # same op order: bit-equal
+
+
+def test_gaussian_blur_small_and_odd_shapes(gpu, oracle):
+    rs = np.random.RandomState(0)
+    for (h, w, c, sigma) in [(1, 1, 1, 2.0), (3, 50, 2, 2.0), (40, 5, 3, 1.0), (9, 9, 4, 3.0), (64, 64, 22, 2.0)]:
+        img = rs.rand(h, w, c)
+        t = torch.from_numpy(img.copy()).to(gpu)
+        sd.gaussian_blur_hwc(t, sigma)
+        np.testing.assert_array_equal(t.cpu().numpy(), oracle.gaussian_blur_hwc(img, sigma))
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_rowsum_filter_normalize_matches_reference_fixture(gpu, tag):
+    g = np.load(os.path.join(GOLD, f"g2_fovpixel_{tag}.npz"))
+    h, w, c = g["img"].shape
+    x = torch.from_numpy(g["blurred"].reshape(-1, c).copy()).to(gpu)
+    rows, kept = sd.rowsum_filter_normalize(x, float(g["thresh"]))
+    np.testing.assert_array_equal(kept.cpu().numpy(), g["kept_index"])
+    np.testing.assert_array_equal(rows.cpu().numpy(), g["rows"])
+
+
+def test_rowsum_filter_normalize_edge_cases(gpu, oracle):
+    rs = np.random.RandomState(1)
+    x = rs.gamma(0.5, 1.0, size=(70_001, 22))
+    x[rs.rand(70_001) < 0.3] = 0.0                      # all-zero rows
+    for thresh in (0.0, 3.0, 1e9):                      # keep most / some / none
+        rows, kept = sd.rowsum_filter_normalize(torch.from_numpy(x).to(gpu), thresh)
+        wr, wk = oracle.rowsum_filter_normalize(x, thresh, sum_mode=0)
+        np.testing.assert_array_equal(kept.cpu().numpy(), wk)
+        np.testing.assert_array_equal(rows.cpu().numpy(), wr)
+    rows, kept = sd.rowsum_filter_normalize(torch.empty((0, 5), dtype=torch.float64, device=gpu), 0.0)
+    assert rows.shape == (0, 5) and kept.numel() == 0
+
+
+def test_create_fov_pixel_data_matches_reference_fixture(gpu):
+    """The drop-in function end to end (blur + filter + normalise on the GPU, DataFrame on the host)."""
+    from ark_analysis_amd.phenotyping import pixie_preprocessing
+    for tag in ("a", "c"):
+        g = np.load(os.path.join(GOLD, f"g2_fovpixel_{tag}.npz"))
+        h, w, c = g["img"].shape
+        chans = ["chan%d" % i for i in range(c)]
+        np.random.seed(7)
+        full, sub = pixie_preprocessing.create_fov_pixel_data("fov0", list(chans), g["img"].copy(), None,
+                                                              pixel_thresh_val=float(g["thresh"]))
+        assert list(full.columns) == chans + ["fov", "row_index", "column_index"]
+        np.testing.assert_array_equal(full["row_index"].values * w + full["column_index"].values, g["kept_index"])
+        np.testing.assert_allclose(full[chans].values, g["rows"], rtol=1e-12, atol=0)
+        assert np.allclose(full[chans].values.sum(axis=1), 1.0)
+        assert len(sub) == int(g["subset_len"])
+
+
+def test_normalize_columns_matches_reference_fixture(gpu):
+    g = np.load(os.path.join(GOLD, "g1_normalize.npz"))
+    out = sd.normalize_columns(torch.from_numpy(g["x"]).to(gpu), torch.from_numpy(g["norm"]).to(gpu))
+    np.testing.assert_array_equal(out.cpu().numpy(), g["out"])
+
+
+def test_quantile_matches_pandas_numpy_fixture(gpu):
+    g = np.load(os.path.join(GOLD, "g3_quantiles.npz"))
+    for i in range(8):
+        x = torch.from_numpy(g["x%d" % i].reshape(-1, 1).copy()).to(gpu)
+        for key, q, mode in (("q999_%d", (0.999 * 100) / 100, 0), ("q99pos_%d", 0.99, 1)):
+            want = float(g[key % i])
+            got = float(sd.quantile_nonzero(x, q, keep_mode=mode).cpu()[0])
+            assert (np.isnan(got) and np.isnan(want)) or got == want, (key % i, got, want)
+
+
+def test_quantile_many_columns_against_pandas(gpu):
+    """The cohort statistic of create_pixel_matrix: per-channel 99.9 % of the non-zero values."""
+    rs = np.random.RandomState(3)
+    x = rs.gamma(0.4, 1.0, size=(200_003, 22))
+    x[rs.rand(*x.shape) < 0.25] = 0.0
+    x[:, 5] = 0.0                       # all-zero column -> NaN
+    x[:, 6] = np.round(x[:, 6], 1)      # heavy duplicates
+    x[:1000, 7] *= -1                   # negative values sort below the positive ones
+    got = sd.quantile_nonzero(torch.from_numpy(x).to(gpu), (0.999 * 100) / 100, keep_mode=0).cpu().numpy()
+    want = pd.DataFrame(x).replace(0, np.nan).quantile(q=0.999, axis=0).values
+    assert np.isnan(got[5]) and np.isnan(want[5])
+    ok = ~np.isnan(want)
+    np.testing.assert_array_equal(got[ok], want[ok])
+    # strided view (one FOV's slice of a bigger matrix) and another q
+    got2 = sd.quantile_nonzero(torch.from_numpy(x).to(gpu)[:, 3:9], 0.05, keep_mode=1).cpu().numpy()
+    for j in range(6):
+        col = x[:, 3 + j]
+        pos = col[col > 0]
+        if len(pos):
+            assert got2[j] == np.quantile(pos, 0.05)
+        else:
+            assert np.isnan(got2[j])
