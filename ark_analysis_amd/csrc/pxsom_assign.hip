@@ -130,13 +130,58 @@ __global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict_
         }
         wfrag[f] = frag;
     }
+    // Exact duplicates of an EARLIER node can never be the answer (their distance is identical and the
+    // reference keeps the first minimum), so they are masked out of the filter.  This matters in batch
+    // training: while the neighbourhood radius still spans the grid, all central nodes receive the same
+    // update and are bit-identical, which would otherwise send every row they win to the exact path.
+    // (s_dup reuses s_red's storage class: one flag per node.)
+    __shared__ unsigned char s_dup[PXSOM_MAX_NODES];
+    for (int node = tid; node < k; node += 256) s_dup[node] = 0;
+    __syncthreads();
+    // hash table keyed by the norm's bit pattern (equal rows have equal norms): slot <- smallest node
+    // index hashing there; a node is a duplicate iff an earlier node with identical channels exists.
+    {
+        __shared__ int s_tab[1024];
+        for (int i = tid; i < 1024; i += 256) s_tab[i] = 0x7fffffff;
+        __syncthreads();
+        auto slot_of = [&](int node) {
+            const unsigned long long b = (unsigned long long)__double_as_longlong(s_norm2[node]);
+            return (int)((b ^ (b >> 17) ^ (b >> 41)) & 1023ull);
+        };
+        for (int node = tid; node < k; node += 256) atomicMin(&s_tab[slot_of(node)], node);
+        __syncthreads();
+        for (int node = tid; node < k; node += 256) {
+            const int first = s_tab[slot_of(node)];
+            if (first >= node) continue;
+            auto same_as = [&](int prev) {
+                if (s_norm2[prev] != s_norm2[node]) return false;
+                for (int j = 0; j < c; j++)
+                    if (wl[(size_t)prev * c + j] != wl[(size_t)node * c + j]) return false;
+                return true;
+            };
+            bool dup = same_as(first);
+            if (!dup) {  // slot shared with a different earlier node: scan the norms (no early exit, so
+                         // the LDS reads pipeline), full comparison only on a norm match
+                const double n2 = s_norm2[node];
+                int hit = -1;
+#pragma unroll 8
+                for (int prev = 0; prev < node; prev++)
+                    if (s_norm2[prev] == n2 && prev != first && hit < 0) hit = prev;
+                if (hit >= 0) {
+                    for (int prev = hit; prev < node && !dup; prev++) dup = same_as(prev);
+                }
+            }
+            if (dup) s_dup[node] = 1;
+        }
+    }
+    __syncthreads();
     // bias[b*64 + lane][r] for accumulator row (lane>>4)*4 + r <-> node_of_row(b, 4q + r)
     for (int f = tid; f < nb * 64; f += 256) {
         const int lane = f & 63, b = f >> 6, q = lane >> 4;
         f32x4 bv;
         for (int r = 0; r < 4; r++) {
             const int node = node_of_row(b, q * 4 + r, nb);
-            bv[r] = node < k ? (float)(-0.5 * s_norm2[node] * scale * scale) : kNegBig;
+            bv[r] = (node < k && !s_dup[node]) ? (float)(-0.5 * s_norm2[node] * scale * scale) : kNegBig;
         }
         bias[f] = bv;
     }

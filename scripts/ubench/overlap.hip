@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float seed, int 
     out[blockIdx.x * 256 + threadIdx.x] = acc[0] + acc[1] + acc[2] + acc[3] + v0 + v1 + v2 + v3;
 }
 
-float run(int mode, int iters_m)
+float run(int mode, int iters_m, int nblocks = 512)
 {
     float *out;
     int *roles;
@@ -51,9 +51,9 @@ float run(int mode, int iters_m)
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
-    k<<<512, 256>>>(out, 10, 1e-3f, mode, nullptr);
+    k<<<nblocks, 256>>>(out, 10, 1e-3f, mode, nullptr);
     (void)hipEventRecord(e0);
-    k<<<512, 256>>>(out, iters_m, 1e-3f, mode, roles);
+    k<<<nblocks, 256>>>(out, iters_m, 1e-3f, mode, roles);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms;
@@ -81,6 +81,7 @@ int main()
     int it = 20000;
     float tm = run(0, it), tv = run(1, it);
     printf("all MFMA  : %.3f ms\nall VALU  : %.3f ms\n", tm, tv);
+    printf("one MFMA wave per SIMD alone : %.3f ms\none VALU wave per SIMD alone : %.3f ms\n", run(0, it, 256), run(1, it, 256));
     float t2 = run(2, it);
     printf("mixed by blockIdx parity      : %.3f ms\n", t2);
     float t3 = run(3, it);

@@ -82,13 +82,21 @@ def test_assign_exact_ties_and_near_ties(gpu, oracle):
     assert 38 not in got and 100 not in got
 
 
-def test_assign_identical_codebook_rows_all_ambiguous(gpu, oracle):
-    """Degenerate codebook: every row ties everywhere -> every row takes the exact path."""
+def test_assign_identical_codebook_rows(gpu, oracle):
+    """Degenerate codebooks.  Exact duplicates of an earlier node are masked in the filter (they can
+    never win under first-minimum tie-break), so an all-identical codebook is resolved without the
+    exact path; nodes that differ by one ulp in one channel are NOT duplicates and every row whose
+    scores tie within the error bound must take the exact path."""
     x = synth.make_fov_numpy(3000, 22, seed=4)
     w = np.tile(x[:1].astype(np.float64), (100, 1))
     got, _ = _gpu_assign(gpu, x, w)
     np.testing.assert_array_equal(got, np.ones(3000, dtype=np.int32))
-    # (the last, partial 64-row window is shifted back over rows already seen: those are listed twice)
+    assert sd.last_exact_rows(sd.assign.last_workspace) < 300
+    w2 = w.copy()
+    w2[1:, 3] = np.nextafter(w2[1:, 3], 10.0) + np.arange(99) * 1e-15   # all distinct, all near-ties
+    got, _ = _gpu_assign(gpu, x, w2)
+    want, _ = oracle.map_data_to_nodes(w2, x.astype(np.float64))
+    np.testing.assert_array_equal(got, want)
     assert sd.last_exact_rows(sd.assign.last_workspace) >= 3000
 
 
