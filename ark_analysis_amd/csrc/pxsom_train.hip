@@ -298,7 +298,7 @@ __global__ __launch_bounds__(MAXT) void som_online_kernel(const T *__restrict__ 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(128) void batch_update_kernel(double *w, int xdim, int ydim, int c,
                                                            const double *__restrict__ sums,
-                                                           const int64_t *__restrict__ counts,
+                                                           const double *__restrict__ counts,
                                                            double thr, double alpha)
 {
     const int k = blockIdx.x, j = threadIdx.x;
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(128) void batch_update_kernel(double *w, int xdim, 
     for (int bx = x0; bx <= x1; bx++)
         for (int by = y0; by <= y1; by++) {
             const int b = bx * ydim + by;
-            den += (double)counts[b];
+            den += counts[b];
             num += sums[(size_t)b * c + j];
         }
     if (den > 0.0) {
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(128) void batch_update_kernel(double *w, int xdim, 
 // table in LDS (ds_add_f64), flushed once with global_atomic_add_f64.
 // Loads are flat-coalesced: lane e reads element e of the row range.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool COUNT_F64>
 __global__ __launch_bounds__(256) void cluster_sums_kernel(const T *__restrict__ x, int64_t n, int c,
                                                            int64_t ldx, const int32_t *__restrict__ labels,
                                                            int k, double *sums, unsigned long long *counts,
@@ -380,7 +380,13 @@ __global__ __launch_bounds__(256) void cluster_sums_kernel(const T *__restrict__
                     } else {
                         __hip_atomic_fetch_add(&sums[(size_t)lab[u] * c + cc[u]], v[u], __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT);
-                        if (cc[u] == 0) atomicAdd(&counts[lab[u]], 1ull);
+                        if (cc[u] == 0) {
+                            if constexpr (COUNT_F64)
+                                __hip_atomic_fetch_add(reinterpret_cast<double *>(counts) + lab[u], 1.0, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
+                            else
+                                atomicAdd(&counts[lab[u]], 1ull);
+                        }
                     }
                 }
             }
@@ -393,7 +399,13 @@ __global__ __launch_bounds__(256) void cluster_sums_kernel(const T *__restrict__
             if (v != 0.0) __hip_atomic_fetch_add(&sums[e], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         for (int e = tid; e < k; e += 256)
-            if (lc[e]) atomicAdd(&counts[e], (unsigned long long)lc[e]);
+            if (lc[e]) {
+                if constexpr (COUNT_F64)
+                    __hip_atomic_fetch_add(reinterpret_cast<double *>(counts) + e, (double)lc[e], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                else
+                    atomicAdd(&counts[e], (unsigned long long)lc[e]);
+            }
     }
 }
 
@@ -441,7 +453,7 @@ int train_online_typed(const T *x, int64_t n, int c, int64_t ldx, double *w, int
 #undef PXSOM_ONLINE
 }
 
-template <typename T>
+template <typename T, bool COUNT_F64 = false>
 int cluster_sums_typed(const T *x, int64_t n, int c, int64_t ldx, const int32_t *labels, int k, double *sums,
                        int64_t *counts, hipStream_t st)
 {
@@ -451,7 +463,7 @@ int cluster_sums_typed(const T *x, int64_t n, int c, int64_t ldx, const int32_t 
     int64_t grid = std::min<int64_t>((n + 255) / 256, (int64_t)cus * (lds <= 32 * 1024 ? 4 : 1));
     if (grid < 1) grid = 1;
     const int64_t rows_per_block = (n + grid - 1) / grid;
-    auto kern = cluster_sums_kernel<T>;
+    auto kern = cluster_sums_kernel<T, COUNT_F64>;
     if (use_lds && lds > 48 * 1024)
         PXSOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -514,7 +526,7 @@ PXSOM_EXPORT int pxsom_cluster_sums(const void *x_dev, int64_t n, int c, int64_t
 }
 
 PXSOM_EXPORT int pxsom_batch_update(double *w_dev, int xdim, int ydim, int c, const double *sums_dev,
-                                    const int64_t *counts_dev, double thr, double alpha, void *stream)
+                                    const double *counts_dev, double thr, double alpha, void *stream)
 {
     if (xdim < 1 || ydim < 1 || (int64_t)xdim * ydim > PXSOM_MAX_NODES || c < 1 || c > PXSOM_MAX_CHANNELS)
         return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "pxsom_batch_update: shape %dx%d x %d", xdim, ydim, c);
@@ -528,24 +540,26 @@ PXSOM_EXPORT int pxsom_batch_update(double *w_dev, int xdim, int ydim, int c, co
 }
 
 // One mini-batch step's accumulation half: zero the statistics, BMU of every row, per-BMU sums.
+// stats_dev = [k*c sums | k counts], all binary64 (counts are exact integers below 2^53), so the
+// multi-GPU all-reduce is a single sum over one buffer.
 PXSOM_EXPORT int pxsom_batch_accumulate(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype,
-                                        const double *w_dev, int k, int32_t *labels_dev, double *sums_dev,
-                                        int64_t *counts_dev, void *workspace_dev, size_t workspace_bytes,
-                                        void *stream)
+                                        const double *w_dev, int k, int32_t *labels_dev, double *stats_dev,
+                                        void *workspace_dev, size_t workspace_bytes, void *stream)
 {
-    if (!sums_dev || !counts_dev || k < 1 || k > PXSOM_MAX_NODES || c < 1 || c > PXSOM_MAX_CHANNELS)
-        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_batch_accumulate: bad statistics buffers / shape");
+    if (!stats_dev || k < 1 || k > PXSOM_MAX_NODES || c < 1 || c > PXSOM_MAX_CHANNELS)
+        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_batch_accumulate: bad statistics buffer / shape");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const size_t sbytes = (size_t)k * c * sizeof(double), cbytes = (size_t)k * sizeof(int64_t);
-    if (reinterpret_cast<char *>(sums_dev) + sbytes == reinterpret_cast<char *>(counts_dev)) {
-        PXSOM_HIP_TRY(hipMemsetAsync(sums_dev, 0, sbytes + cbytes, st));
-    } else {
-        PXSOM_HIP_TRY(hipMemsetAsync(sums_dev, 0, sbytes, st));
-        PXSOM_HIP_TRY(hipMemsetAsync(counts_dev, 0, cbytes, st));
-    }
+    PXSOM_HIP_TRY(hipMemsetAsync(stats_dev, 0, (size_t)k * (c + 1) * sizeof(double), st));
     if (n == 0) return PXSOM_OK;
-    int rc = pxsom_assign(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, nullptr, workspace_dev, workspace_bytes,
-                          stream);
+    int rc = check_matrix("pxsom_batch_accumulate", x_dev, n, c, ldx, dtype);
     if (rc) return rc;
-    return pxsom_cluster_sums(x_dev, n, c, ldx, dtype, labels_dev, k, sums_dev, counts_dev, stream);
+    rc = pxsom_assign(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, nullptr, workspace_dev, workspace_bytes, stream);
+    if (rc) return rc;
+    double *sums = stats_dev;
+    int64_t *counts = reinterpret_cast<int64_t *>(stats_dev + (size_t)k * c);
+    if (dtype == PXSOM_F32)
+        return cluster_sums_typed<float, true>(reinterpret_cast<const float *>(x_dev), n, c, ldx, labels_dev, k, sums,
+                                               counts, st);
+    return cluster_sums_typed<double, true>(reinterpret_cast<const double *>(x_dev), n, c, ldx, labels_dev, k, sums,
+                                            counts, st);
 }

@@ -4,7 +4,7 @@ all-reduced over RCCL (``torch.distributed`` backend "nccl" on ROCm).
 The reference has no analogue (its training is pyFlowSOM's sequential loop,
 /root/reference/src/ark/phenotyping/cluster_helpers.py:106-109, "replicas only" in DESIGN.md).
 This is the throughput-mode rule BASELINE.json's north_star asks for: pixels never leave their
-GPU; the only exchange is one all-reduce of the packed [K, C+1] binary64 statistics per
+GPU; the only exchange is one all-reduce of the [K, C+1] binary64 statistics per
 mini-batch step (9.2 KB at K=100, C=22 -- latency-bound, xGMI bandwidth is irrelevant).
 
 One pass = ``batch_steps`` mini-batch steps; step g (of G = rlen*batch_steps) uses the local
@@ -42,13 +42,12 @@ class HipKernels:
         self._sd = som_device
         self._ws = None
 
-    def accumulate(self, x: torch.Tensor, w: torch.Tensor, labels: torch.Tensor, sums: torch.Tensor,
-                   counts: torch.Tensor) -> None:
-        """zero(sums, counts); labels = BMU(x, w); sums[label] += x; counts[label] += 1."""
+    def accumulate(self, x: torch.Tensor, w: torch.Tensor, labels: torch.Tensor, stats: torch.Tensor) -> None:
+        """zero(stats); labels = BMU(x, w); stats[label] += [x, 1]  (stats = [K*C sums | K counts] f64)."""
         n, c = x.shape
         if self._ws is None or not self._ws.fits(n, c, w.shape[0]):
             self._ws = self._sd.AssignWorkspace(n, c, w.shape[0], x.device)
-        self._sd.batch_accumulate(x, w, labels, sums, counts, self._ws)
+        self._sd.batch_accumulate(x, w, labels, stats, self._ws)
 
     def batch_update(self, w, xdim, ydim, sums, counts, thr, alpha):
         return self._sd.batch_update(w, xdim, ydim, sums, counts, thr, alpha)
@@ -74,12 +73,11 @@ class BatchSOMTrainer:
             default_radius_range(xdim, ydim)
         self.group = group
         self.kernels = kernels if kernels is not None else HipKernels()
-        # statistics: [K*C f64 sums | K i64 counts] contiguous, so the kernels' memset is one call;
-        # for the all-reduce the counts ride along as f64 in `packed` (exact below 2^53 rows)
+        # statistics: [K*C sums | K counts], all float64 (counts are exact integers): one memset, one
+        # all-reduce, no conversions
         self.stats = torch.zeros(self.k * self.c + self.k, dtype=torch.float64, device=device)
         self.sums = self.stats[: self.k * self.c].view(self.k, self.c)
-        self.counts = self.stats[self.k * self.c:].view(torch.int64)
-        self.packed = torch.zeros(self.k * self.c + self.k, dtype=torch.float64, device=device)
+        self.counts = self.stats[self.k * self.c:]
         self.label_buf = None
 
     def step(self, x_local: torch.Tensor, w: torch.Tensor, g: int, total_steps: int) -> None:
@@ -89,14 +87,9 @@ class BatchSOMTrainer:
         nrows = view.shape[0]
         if self.label_buf is None or self.label_buf.numel() < nrows:
             self.label_buf = torch.empty(max(nrows, 1), dtype=torch.int32, device=x_local.device)
-        self.kernels.accumulate(view, w, self.label_buf, self.sums, self.counts)
+        self.kernels.accumulate(view, w, self.label_buf, self.stats)
         if _world(self.group) > 1:
-            kc = self.k * self.c
-            self.packed[:kc].copy_(self.stats[:kc])
-            self.packed[kc:].copy_(self.counts)
-            dist.all_reduce(self.packed, op=dist.ReduceOp.SUM, group=self.group)
-            self.stats[:kc].copy_(self.packed[:kc])
-            self.counts.copy_(self.packed[kc:])
+            dist.all_reduce(self.stats, op=dist.ReduceOp.SUM, group=self.group)
         thr, alpha = batch_schedule(g, total_steps, self.alpha_range, self.radius_range)
         self.kernels.batch_update(w, self.xdim, self.ydim, self.sums, self.counts, thr, alpha)
 

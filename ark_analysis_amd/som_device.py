@@ -91,9 +91,9 @@ def cluster_sums(x: torch.Tensor, labels: torch.Tensor, k: int,
     return sums, counts
 
 
-def batch_accumulate(x: torch.Tensor, w: torch.Tensor, labels: torch.Tensor, sums: torch.Tensor,
-                     counts: torch.Tensor, workspace: AssignWorkspace) -> None:
-    """Zero ``sums``/``counts``, label every row of ``x`` and accumulate per-BMU sums (one call)."""
+def batch_accumulate(x: torch.Tensor, w: torch.Tensor, labels: torch.Tensor, stats: torch.Tensor,
+                     workspace: AssignWorkspace) -> None:
+    """Zero ``stats`` ([K*C sums | K counts], float64), label every row of ``x`` and accumulate."""
     n, c, ldx, dt = _matrix_args(x)
     w = _codebook(w)
     k = w.shape[0]
@@ -101,8 +101,10 @@ def batch_accumulate(x: torch.Tensor, w: torch.Tensor, labels: torch.Tensor, sum
         raise ValueError("assign workspace too small for this mini-batch")
     if labels.dtype != torch.int32 or labels.numel() < n:
         raise ValueError("labels scratch must be int32 with at least n entries")
+    if stats.dtype != torch.float64 or stats.numel() != k * (c + 1) or not stats.is_contiguous():
+        raise ValueError("stats must be a contiguous float64 vector of K*(C+1) entries")
     rc = _capi.lib().pxsom_batch_accumulate(x.data_ptr(), n, c, ldx, dt, w.data_ptr(), k,
-                                            labels.data_ptr(), sums.data_ptr(), counts.data_ptr(),
+                                            labels.data_ptr(), stats.data_ptr(),
                                             workspace.buf.data_ptr(), workspace.bytes,
                                             _capi.stream_ptr())
     _capi.check(rc, "pxsom_batch_accumulate")
@@ -130,8 +132,8 @@ def batch_update(w: torch.Tensor, xdim: int, ydim: int, sums: torch.Tensor, coun
                  thr: float, alpha: float) -> torch.Tensor:
     w = _codebook(w)
     c = w.shape[1]
-    if sums.dtype != torch.float64 or counts.dtype != torch.int64:
-        raise ValueError("sums must be float64 and counts int64")
+    if sums.dtype != torch.float64 or counts.dtype != torch.float64:
+        raise ValueError("sums and counts must be float64 (counts are exact integers)")
     rc = _capi.lib().pxsom_batch_update(w.data_ptr(), int(xdim), int(ydim), c, sums.data_ptr(),
                                         counts.data_ptr(), float(thr), float(alpha),
                                         _capi.stream_ptr())

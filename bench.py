@@ -64,9 +64,12 @@ def main():
     _capi.require_gpu()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ     # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
     F, P, C, K = args.fovs_per_gpu, PIXELS_PER_FOV, CHANNELS, XDIM * YDIM
     n_all = F * P
@@ -93,7 +96,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -115,14 +118,14 @@ def main():
         t1 = time.perf_counter()
         kern_ms, kern_launches = timer.collect()
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed_s = float(elapsed.item())
     train_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_train]))
     exact_rows = som_device.last_exact_rows(ws_all)
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -208,7 +211,7 @@ def main():
                 out["online_train"]["codebook_bit_equal_to_oracle"] = bool(
                     np.array_equal(wo.cpu().numpy(), oracle_w))
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

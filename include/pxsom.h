@@ -113,24 +113,20 @@ int pxsom_train_online(const void *x_dev, int64_t n, int c, int64_t ldx, int dty
                        int xdim, int ydim, int rlen, double a0, double a1, double r0, double r1,
                        const int64_t *order_dev, void *stream);
 
-/* ---- batch SOM accumulation (throughput mode; no pyFlowSOM analogue) -------------------------
- * The accumulation half of one mini-batch step, as one host call:
- *   zero sums_dev [k, c] / counts_dev [k]; labels = BMU(x rows, w) (pxsom_assign); per-BMU sums
- *   (pxsom_cluster_sums).  labels_dev [n] int32 is scratch that also returns the labels.
- * If counts_dev directly follows sums_dev in memory one memset covers both. */
+/* ---- batch SOM training (throughput mode; no pyFlowSOM analogue) -----------------------------
+ * One mini-batch step = pxsom_batch_accumulate [+ all-reduce of stats across ranks] + pxsom_batch_update.
+ * stats_dev is [k*c sums | k counts], all binary64 (counts are exact integers), so the collective is a
+ * single sum over one buffer.
+ *   accumulate: zero stats; labels = BMU(x rows, w) (pxsom_assign; labels_dev [n] int32 scratch that also
+ *               returns them); stats[b, :] += x_i, stats_count[b] += 1 for b = label_i - 1.
+ *   update:     num[k] = sum_{b: cheb(k,b) <= thr} sums[b], den[k] = sum_{b: ...} counts[b]
+ *               den[k] > 0:  w[k] += (1 - (1-alpha)^den[k]) * (num[k]/den[k] - w[k])
+ * Oracle of record: oracle/pxsom_oracle.c orc_cluster_sums / orc_batch_update. */
 int pxsom_batch_accumulate(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype,
-                           const double *w_dev, int k, int32_t *labels_dev, double *sums_dev,
-                           int64_t *counts_dev, void *workspace_dev, size_t workspace_bytes,
-                           void *stream);
-
-/* ---- batch SOM update (throughput mode; no pyFlowSOM analogue) ------------------------------
- * Applies one mini-batch step from accumulated per-BMU sums/counts (already all-reduced across
- * ranks by the caller):
- *   num[k] = sum_{b: cheb(k,b) <= thr} sums[b], den[k] = sum_{b: ...} counts[b]
- *   den[k] > 0:  w[k] += (1 - (1-alpha)^den[k]) * (num[k]/den[k] - w[k])
- * Oracle of record: oracle/pxsom_oracle.c orc_batch_update. */
+                           const double *w_dev, int k, int32_t *labels_dev, double *stats_dev,
+                           void *workspace_dev, size_t workspace_bytes, void *stream);
 int pxsom_batch_update(double *w_dev, int xdim, int ydim, int c, const double *sums_dev,
-                       const int64_t *counts_dev, double thr, double alpha, void *stream);
+                       const double *counts_dev, double thr, double alpha, void *stream);
 
 /* ---- pre-processing (create_fov_pixel_data and the 99.9 % values) -----------------------------
  * reference: pixie_preprocessing.py:47-49 -> scipy.ndimage.gaussian_filter(plane, sigma) per channel:

@@ -18,18 +18,20 @@ from ark_analysis_amd.distributed import (BatchSOMTrainer, allreduce_cluster_tab
 class OracleKernels:
     """Same interface as distributed.HipKernels, backed by oracle/pxsom_oracle.c (tests only)."""
 
-    def accumulate(self, x, w, labels, sums, counts):
+    def accumulate(self, x, w, labels, stats):
         from tests import oracle_binding as ob
         xn = np.ascontiguousarray(x.numpy(), dtype=np.float64)
+        k, c = w.shape
         lab, _ = ob.map_data_to_nodes(w.numpy(), xn)
-        s, c = ob.cluster_sums(xn, lab, w.shape[0])
+        s, cnt = ob.cluster_sums(xn, lab, k)
         labels[: len(lab)].copy_(torch.from_numpy(lab))
-        sums.copy_(torch.from_numpy(s))
-        counts.copy_(torch.from_numpy(c))
+        stats[: k * c].copy_(torch.from_numpy(s.reshape(-1)))
+        stats[k * c:].copy_(torch.from_numpy(cnt.astype(np.float64)))
 
     def batch_update(self, w, xdim, ydim, sums, counts, thr, alpha):
         from tests import oracle_binding as ob
-        w.copy_(torch.from_numpy(ob.batch_update(w.numpy(), xdim, ydim, sums.numpy(), counts.numpy(), thr, alpha)))
+        w.copy_(torch.from_numpy(ob.batch_update(w.numpy(), xdim, ydim, sums.numpy(),
+                                                 counts.numpy().astype(np.int64), thr, alpha)))
 
 
 def _free_port():
@@ -51,9 +53,11 @@ def _worker(rank, world, port, shards, w0, xdim, ydim, m, out_path):
     trainer.train(x, w, num_passes=2)
     # K8 across ranks: per-cluster tables of the final labels
     labels = torch.empty(x.shape[0], dtype=torch.int32)
-    sums = torch.zeros((xdim * ydim, x.shape[1]), dtype=torch.float64)
-    counts = torch.zeros(xdim * ydim, dtype=torch.int64)
-    trainer.kernels.accumulate(x, w, labels, sums, counts)
+    kc = xdim * ydim * x.shape[1]
+    stats = torch.zeros(kc + xdim * ydim, dtype=torch.float64)
+    trainer.kernels.accumulate(x, w, labels, stats)
+    sums = stats[:kc].view(xdim * ydim, x.shape[1]).clone()
+    counts = stats[kc:].to(torch.int64)
     allreduce_cluster_tables(sums, counts)
     gathered = [torch.zeros_like(w) for _ in range(world)]
     dist.all_gather(gathered, w)

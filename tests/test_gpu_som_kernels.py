@@ -184,7 +184,7 @@ def test_batch_update_matches_oracle(gpu, oracle):
             want = oracle.batch_update(w, xdim, ydim, sums, counts, thr, alpha)
             wd = torch.from_numpy(w.copy()).to(gpu)
             sd.batch_update(wd, xdim, ydim, torch.from_numpy(sums).to(gpu),
-                            torch.from_numpy(counts).to(gpu), thr, alpha)
+                            torch.from_numpy(counts.astype(np.float64)).to(gpu), thr, alpha)
             np.testing.assert_allclose(wd.cpu().numpy(), want, rtol=1e-12, atol=0)
 
 
