@@ -338,8 +338,11 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
     int32_t *__restrict__ labels)
 {
     constexpr int NP = CPL / 2;  // pair loads per lane per tile
-    constexpr unsigned idx_mask = 63u;
-    constexpr unsigned node_mask = NB * 16 <= 64 ? 63u : 127u;
+    // scores carry (b*4 + r) in their low 7 mantissa bits (inline constants <= 27: one v_and_or_b32 each);
+    // OR-ing (q << 5) in yields a 7-bit id (q, b, r) that is mapped to the node once per group
+    constexpr unsigned idx_mask = 127u;
+    constexpr unsigned node_mask = 127u;
+    static_assert(NB <= 8, "7-bit packed node index");
     const float scale = hdr->scale, wn_max = hdr->wn_max, tol_rel = hdr->tol_rel,
                 tol_abs = hdr->tol_abs, x_limit = hdr->x_limit;
     const bool force_exact = hdr->force_exact != 0;
@@ -372,16 +375,32 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
 
     typedef typename Pair<T>::type P2;
     P2 raw[kTilesPerIter][NP];
+    // Buffer loads: the 64-row group is a descriptor of its own (base = x + row0*ldx*sizeof(T), built
+    // from wave-uniform values on the scalar unit), the tile offset rides in soffset and the lane offset in
+    // voffset -- no per-load VALU address arithmetic.
     auto load_group = [&](int64_t g) {
         if constexpr (MODE >= 2) g = wave;
         int64_t row0 = g * 64;
         if (row0 > n - 64) row0 = n - 64;
         const char *gb = reinterpret_cast<const char *>(x) + row0 * ldx * (int64_t)sizeof(T);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char *>(gb), (short)0, (int)(64 * ldx * (int64_t)sizeof(T)), 0x00020000);
 #pragma unroll
         for (int t = 0; t < kTilesPerIter; t++) {
+            const int soff = (int)(t * tile_bytes);
 #pragma unroll
-            for (int p = 0; p < NP; p++)
-                raw[t][p] = *reinterpret_cast<const P2 *>(gb + t * tile_bytes + loff[p]);
+            for (int p = 0; p < NP; p++) {
+                if constexpr (sizeof(T) == 4) {
+                    const uint2v v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)loff[p], soff, 0);
+                    raw[t][p].x = __uint_as_float(v[0]);
+                    raw[t][p].y = __uint_as_float(v[1]);
+                } else {
+                    typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+                    const uint4v v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)loff[p], soff, 0);
+                    raw[t][p].x = __longlong_as_double(((long long)v[1] << 32) | v[0]);
+                    raw[t][p].y = __longlong_as_double(((long long)v[3] << 32) | v[2]);
+                }
+            }
         }
     };
 
@@ -457,7 +476,10 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
                         if (b < NB - 1 || RU == 4) {
-                            consume(m1[u], m2[u], acc[u], b, idx_mask);
+                            top2_pair(m1[u], m2[u], pack_idx(acc[u][0], (unsigned)(b * 4 + 0), idx_mask),
+                                      pack_idx(acc[u][1], (unsigned)(b * 4 + 1), idx_mask));
+                            top2_pair(m1[u], m2[u], pack_idx(acc[u][2], (unsigned)(b * 4 + 2), idx_mask),
+                                      pack_idx(acc[u][3], (unsigned)(b * 4 + 3), idx_mask));
                         } else {
                             // last block: only registers 0..RU-1 hold real nodes
                             const float p0 = pack_idx(acc[u][0], (unsigned)(b * 4 + 0), idx_mask);
@@ -478,14 +500,8 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
                 }
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
-                    // register index (b*4 + r) -> node index in the low bits (branch-free select)
-                    const unsigned bits = __float_as_uint(m1[u]);
-                    const unsigned idx = bits & idx_mask;
-                    const unsigned bb = idx >> 2, r = idx & 3u;
-                    const unsigned sel = 0u - (unsigned)(bb == (unsigned)(NB - 1));
-                    const unsigned low_a = ((unsigned)q << 2) | r, low_b = (r << 2) | (unsigned)q;
-                    const unsigned node = (bb << 4) | ((low_a & ~sel) | (low_b & sel));
-                    tm1[t0 + u] = __uint_as_float((bits & ~node_mask) | node);
+                    // (b*4 + r) -> id (q << 5 | b*4 + r): one OR
+                    tm1[t0 + u] = __uint_as_float(__float_as_uint(m1[u]) | ((unsigned)q << 5));
                     tm2[t0 + u] = m2[u];
                 }
             }
@@ -545,7 +561,13 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
         int64_t row0 = g * 64;
         if (row0 > n - 64) row0 = n - 64;
         const int64_t row = row0 + lane;
-        labels[row] = (int)(__float_as_uint(my_m1) & node_mask) + 1;
+        {
+            // id (q, b, r) -> node: 16 b + 4 q + r, the last block's 4x4 (q, r) grid transposed (node_of_row)
+            const unsigned id = __float_as_uint(my_m1) & node_mask;
+            const unsigned wq = id >> 5, wb = (id >> 2) & 7u, wr = id & 3u;
+            const unsigned real = wb == (unsigned)(NB - 1) ? 16u * wb + 4u * wr + wq : 16u * wb + 4u * wq + wr;
+            labels[row] = (int)real + 1;
+        }
         const unsigned long long mask = __ballot(my_amb);
         if (mask) {
             unsigned base = 0;
