@@ -328,8 +328,10 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_kernel(
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef unsigned uint2v __attribute__((ext_vector_type(2)));
 
+// SGB_VALU > 0 forces a 1-MFMA : SGB_VALU-VALU cadence with sched_group_barrier.  Measured (bench.py,
+// filter kernel): 0 -> 0.237 ms, 3 -> 0.252, 5 -> 0.249, 8 -> 0.247: the compiler's own order wins.
 #ifndef SGB_VALU
-#define SGB_VALU 5
+#define SGB_VALU 0
 #endif
 template <typename T, int CPL, int NB, int RU, int MODE>
 __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
         // and the two pipes would take turns instead of overlapping (measured: VALU-active + MFMA-busy
         // ~= 100 % of the runtime).  Ask the scheduler for a fine interleave inside each wave:
         // every MFMA is followed by VALU work that does not depend on it.
-        if constexpr (MODE != 1) {
+        if constexpr (MODE != 1 && SGB_VALU > 0) {
 #pragma unroll
             for (int i = 0; i < kTilesPerIter * NB * 3; i++) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
