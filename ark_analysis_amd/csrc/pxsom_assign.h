@@ -44,9 +44,12 @@ inline Layout make_layout(int64_t n, int c, int k)
     if (cpl > 8) cpl = 8;
     L.cpl = cpl;
     L.nsteps = 2 * L.nch;  // stored fragments per node block: {Wh, Wl} per chunk
-    L.idx_bits = L.nb <= 16 ? 6 : 10;
-    L.node_bits = 4;
-    while ((1 << L.node_bits) < L.nb * 16) L.node_bits++;
+    // bits of the per-lane register index b*4 + r packed into the scores' low mantissa bits (the fast
+    // kernel packs a 7-bit (q, b, r) id): the only perturbation the top-2 logic adds
+    L.idx_bits = 4;
+    while ((1 << L.idx_bits) < L.nb * 4) L.idx_bits++;
+    if (L.idx_bits < 7 && L.nb <= 8) L.idx_bits = 7;
+    L.node_bits = L.idx_bits;
     L.off_wfrag = kHdrBytes;
     L.off_bias = L.off_wfrag + (size_t)L.nb * L.nsteps * 64 * sizeof(half8);
     L.off_list = pxsom::align_up(L.off_bias + (size_t)L.nb * 64 * sizeof(f32x4), 256);

@@ -97,10 +97,10 @@ __global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict_
         hdr->wn_max = bad ? 0.f : (float)(sqrt(s_red[0]) * scale * (1.0 + 1e-6));
         hdr->force_exact = bad ? 1 : 0;  // NaN/Inf/huge codebook: every row takes the exact path
         // coefficient of the rigorous |filter - exact| bound, see DESIGN.md "K7 error bound":
-        //   index packing 2^-(23-idx_bits), fp32 accumulation (3C+2)*2^-24, split residual 2^-19,
+        //   index packing 2^-(23-idx_bits) (idx_bits low mantissa bits replaced), fp32 accumulation
+        //   (3C+2)*2^-24, split residual 2^-19,
         //   f64->f32 input rounding 2^-23;  tol = 2 * 1.25 * E
-        // (the cross-lane merge re-packs the winner's low node_bits bits, counted separately)
-        const double coef = ldexp(1.0, -(23 - idx_bits)) + ldexp(1.0, -(23 - node_bits)) +
+        const double coef = ldexp(1.0, -(23 - idx_bits)) +
                             (3.0 * c + 2.0) * ldexp(1.0, -24) + ldexp(1.0, -19) + ldexp(1.0, -23);
         hdr->tol_rel = (float)(2.5 * coef);
         hdr->tol_abs = (float)(2.5 * ldexp(1.0, -24) * sqrt((double)c));  // fp16 subnormal floor

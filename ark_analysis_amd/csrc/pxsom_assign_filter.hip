@@ -95,8 +95,6 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_kernel(
     const int cpl = CPL_T > 0 ? CPL_T : hdr->cpl;
     const int nb = NB_T > 0 ? NB_T : hdr->nb;
     const unsigned idx_mask = NB_T > 0 ? 63u : ((1u << hdr->idx_bits) - 1u);
-    const unsigned node_mask = NB_T > 0 ? ((NB_T * 16 <= 64) ? 63u : (NB_T * 16 <= 128 ? 127u : 255u))
-                                        : ((1u << hdr->node_bits) - 1u);
     const float scale = hdr->scale, wn_max = hdr->wn_max, tol_rel = hdr->tol_rel,
                 tol_abs = hdr->tol_abs, x_limit = hdr->x_limit;
     const bool force_exact = hdr->force_exact != 0;
@@ -177,25 +175,30 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_kernel(
     };
 
     // finish one tile: node index into the winner, merge the 4 lane groups of a pixel, decide
-    auto finish = [&](float m1, float m2, float s2, float &out_m1, bool &out_amb, int t) {
+    auto finish = [&](float m1, float m2, float s2, int &out_node, bool &out_amb, int t) {
+        // the node index travels beside the score through the merge (no second packing: the only
+        // perturbation of the scores is the idx_bits-wide register index)
+        int node;
         {
-            const unsigned bits = __float_as_uint(m1);
-            const unsigned idx = bits & idx_mask;
+            const unsigned idx = __float_as_uint(m1) & idx_mask;
             const unsigned bb = idx >> 2, r = idx & 3u;
-            const unsigned node = (int)bb == nb - 1 ? (bb << 4) | (r << 2) | (unsigned)q
-                                                    : (bb << 4) | ((unsigned)q << 2) | r;
-            m1 = __uint_as_float((bits & ~node_mask) | node);
+            node = (int)((int)bb == nb - 1 ? (bb << 4) | (r << 2) | (unsigned)q : (bb << 4) | ((unsigned)q << 2) | r);
         }
-        F2 e1 = xchg16(m1), e2 = xchg16(m2), es = xchg16(s2);
-        m1 = fmaxf(e1.a, e1.b);
-        m2 = fmaxf(fmaxf(fminf(e1.a, e1.b), e2.a), e2.b);
-        s2 = es.a + es.b;
-        e1 = xchg32(m1);
-        e2 = xchg32(m2);
-        es = xchg32(s2);
-        m1 = fmaxf(e1.a, e1.b);
-        m2 = fmaxf(fmaxf(fminf(e1.a, e1.b), e2.a), e2.b);
-        s2 = es.a + es.b;
+        // xchg(v) returns (value of the lower lane, value of the upper lane) in BOTH partner lanes, so the
+        // selection below is identical on the two sides
+        auto merge_step = [&](bool wide) {
+            const F2 e1 = wide ? xchg32(m1) : xchg16(m1), e2 = wide ? xchg32(m2) : xchg16(m2),
+                     es = wide ? xchg32(s2) : xchg16(s2),
+                     en = wide ? xchg32(__int_as_float(node)) : xchg16(__int_as_float(node));
+            const int na = __float_as_int(en.a), nb_ = __float_as_int(en.b);
+            const bool take_b = e1.b > e1.a || (e1.b == e1.a && nb_ < na);
+            m2 = fmaxf(fmaxf(fminf(e1.a, e1.b), e2.a), e2.b);
+            m1 = take_b ? e1.b : e1.a;
+            node = take_b ? nb_ : na;
+            s2 = es.a + es.b;
+        };
+        merge_step(false);
+        merge_step(true);
         if (q == t) {
             // |X| up to 2^-20 relative; integer test catches NaN/Inf rows under finite-math
             const float xn = __builtin_amdgcn_sqrtf(s2) * 1.000001f;
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_kernel(
             asm volatile("" : "+v"(sbits));
             const bool nonfinite = (sbits & 0x7f800000u) == 0x7f800000u;
             out_amb = !((m1 - m2) > tol) || !(xn < x_limit) || nonfinite || force_exact;
-            out_m1 = m1;
+            out_node = node;
         }
     };
 
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_kernel(
             for (int t = 0; t < kTilesPerIter; t++) load_tile(gnext, t, raw[t]);
         }
 
-        float my_m1 = 0.f;
+        int my_node = 0;
         bool my_amb = false;
 #pragma unroll
         for (int t0 = 0; t0 < kTilesPerIter; t0 += TP) {
@@ -299,12 +302,12 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_kernel(
             }
 #pragma unroll
             for (int u = 0; u < TP; u++)
-                finish(m1[u], m2[u], ss[PREFETCH ? t0 + u : u], my_m1, my_amb, t0 + u);
+                finish(m1[u], m2[u], ss[PREFETCH ? t0 + u : u], my_node, my_amb, t0 + u);
         }
         // lane (q, pix) now owns row g*64 + q*16 + pix == g*64 + lane
         const int64_t row = g * 64 + lane;
         const bool valid = row < n;
-        if (valid) labels[row] = (int)(__float_as_uint(my_m1) & node_mask) + 1;
+        if (valid) labels[row] = my_node + 1;
         const bool push = valid && my_amb;
         const unsigned long long mask = __ballot(push);
         if (mask) {
