@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_kernel(
 //     is shifted back to rows [n-64, n) instead of being clamped (identical labels are rewritten).
 //   * conversion: hi = f16(x*s), lo = f16(x*s - hi) as v_fma_mix ops; |X|^2 from v_dot2_f32_f16.
 //   * last node block: only its first RU accumulator registers hold real nodes (node_of_row).
-// MODE (experiments only): 1 = stream without MFMA/top-2, 2 = cache-hot loads.
+// MODE (scripts/assign_microbench.py only): 1 = stream without MFMA/top-2, 2 = cache-hot loads.
 // ------------------------------------------------------------------------------------------------
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef unsigned uint2v __attribute__((ext_vector_type(2)));
@@ -457,13 +457,6 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
                 for (int b = 0; b < NB; b++) {
                     f32x4 acc[2];
                     // Wh*Xh + Wh*Xl + Wl*Xh, the two tiles' chains interleaved
-                    if constexpr (MODE == 4) {  // experiment: VALU only (no MFMA)
-#pragma unroll
-                        for (int u = 0; u < 2; u++) {
-                            acc[u] = breg[b];
-                            acc[u][0] += ss[t0 + u];
-                        }
-                    } else {
 #pragma unroll
                     for (int u = 0; u < 2; u++)
                         acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b][0], bh[t0 + u], breg[b], 0, 0, 0);
@@ -473,11 +466,6 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
 #pragma unroll
                     for (int u = 0; u < 2; u++)
                         acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b][1], bh[t0 + u], acc[u], 0, 0, 0);
-                    }
-                    if constexpr (MODE == 3) {  // experiment: MFMA only (no top-2)
-#pragma unroll
-                        for (int u = 0; u < 2; u++) m1[u] = fmaxf(m1[u], acc[u][0] + acc[u][1] + acc[u][2] + acc[u][3]);
-                    } else
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
                         if (b < NB - 1 || RU == 4) {
@@ -588,12 +576,10 @@ void launch_fast(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layo
                  hipStream_t st)
 {
     auto kern = bmu_filter_fast<T, CPL, NB, RU, 0>;
-    if constexpr (NB == 7 && CPL == 6 && sizeof(T) == 4) {  // experiment hook (headline shape only)
+    if constexpr (NB == 7 && CPL == 6 && sizeof(T) == 4) {  // microbench hook (headline shape only)
         const char *m = getenv("PXSOM_FILTER_MODE");
         if (m && m[0] == '1') kern = bmu_filter_fast<T, CPL, NB, RU, 1>;
         if (m && m[0] == '2') kern = bmu_filter_fast<T, CPL, NB, RU, 2>;
-        if (m && m[0] == '3') kern = bmu_filter_fast<T, CPL, NB, RU, 3>;
-        if (m && m[0] == '4') kern = bmu_filter_fast<T, CPL, NB, RU, 4>;
     }
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
@@ -648,13 +634,18 @@ void launch_filter_any(const T *x, int64_t n, int c, int64_t ldx, char *ws, cons
 {
     // pair loads need 2-element alignment of every row start and of the base pointer
     const bool vec2 = (c % 2 == 0) && (ldx % 2 == 0) && (reinterpret_cast<uintptr_t>(x) % (2 * sizeof(T)) == 0);
-    // register-resident fast path; the last block of K = 100 holds 4 nodes -> RU = 1
+    // register-resident fast path: one channel chunk (C <= 32, even), K = 97..100 (ark's default 10x10
+    // SOM; the last block's 4 nodes sit in one accumulator register -> RU = 1)
     const int nv_last = L.k - 16 * (L.nb - 1), ru = (nv_last + 3) / 4;
     const bool fast_ok = vec2 && L.nch == 1 && n >= 64 && L.nb == 7 && ru == 1 &&
                          tile_offsets_fit<T>(ldx);
-    if (fast_ok && L.cpl == 6)       // BASELINE.json configs 2/3: C = 22, K = 100
+    if (fast_ok && L.cpl == 6)       // C = 18..24 (BASELINE.json configs 2/3: C = 22)
         launch_fast<T, 6, 7, 1>(x, n, c, ldx, ws, L, labels, st);
-    else if (fast_ok && L.cpl == 2)  // config 1: C = 8, K = 100
+    else if (fast_ok && L.cpl == 8)  // C = 26..32
+        launch_fast<T, 8, 7, 1>(x, n, c, ldx, ws, L, labels, st);
+    else if (fast_ok && L.cpl == 4)  // C = 10..16
+        launch_fast<T, 4, 7, 1>(x, n, c, ldx, ws, L, labels, st);
+    else if (fast_ok && L.cpl == 2)  // C <= 8 (config 1)
         launch_fast<T, 2, 7, 1>(x, n, c, ldx, ws, L, labels, st);
     else if (L.nch == 1)
         vec2 ? launch_filter<T, 1, 0, 0, true>(x, n, c, ldx, ws, L, labels, st)

@@ -309,12 +309,23 @@ __global__ __launch_bounds__(128) void batch_update_kernel(double *w, int xdim, 
     const int x0 = kx - r < 0 ? 0 : kx - r, x1 = kx + r > xdim - 1 ? xdim - 1 : kx + r;
     const int y0 = ky - r < 0 ? 0 : ky - r, y1 = ky + r > ydim - 1 ? ydim - 1 : ky + r;
     double num = 0.0, den = 0.0;
-    for (int bx = x0; bx <= x1; bx++)
-        for (int by = y0; by <= y1; by++) {
+    for (int bx = x0; bx <= x1; bx++) {
+        // the loads of a window row are independent: issue them 4 at a time, accumulate in node order
+        int by = y0;
+        for (; by + 3 <= y1; by += 4) {
+            const int b = bx * ydim + by;
+            const double c0 = counts[b], c1 = counts[b + 1], c2 = counts[b + 2], c3 = counts[b + 3];
+            const double s0 = sums[(size_t)b * c + j], s1 = sums[(size_t)(b + 1) * c + j],
+                         s2 = sums[(size_t)(b + 2) * c + j], s3 = sums[(size_t)(b + 3) * c + j];
+            den += c0; den += c1; den += c2; den += c3;
+            num += s0; num += s1; num += s2; num += s3;
+        }
+        for (; by <= y1; by++) {
             const int b = bx * ydim + by;
             den += counts[b];
             num += sums[(size_t)b * c + j];
         }
+    }
     if (den > 0.0) {
         const double gain = 1.0 - pow(1.0 - alpha, den);
         const double wv = w[(size_t)k * c + j];
@@ -460,7 +471,8 @@ int cluster_sums_typed(const T *x, int64_t n, int c, int64_t ldx, const int32_t 
     const size_t lds = (size_t)k * c * 8 + (size_t)k * 4;
     const int use_lds = lds <= 150 * 1024;
     const int cus = pxsom::device_cu_count();
-    int64_t grid = std::min<int64_t>((n + 255) / 256, (int64_t)cus * (lds <= 32 * 1024 ? 4 : 1));
+    // small inputs: latency-bound per workgroup, so spread them wide (128 rows per workgroup)
+    int64_t grid = std::min<int64_t>((n + 127) / 128, (int64_t)cus * (lds <= 32 * 1024 ? 4 : 1));
     if (grid < 1) grid = 1;
     const int64_t rows_per_block = (n + grid - 1) / grid;
     auto kern = cluster_sums_kernel<T, COUNT_F64>;

@@ -33,6 +33,10 @@ def _gpu_assign(gpu, x, w, want_dists=False):
     (100_003, 22, 100, np.float32),   # BASELINE config 2 shape (register-resident codebook path)
     (50_001, 22, 100, np.float64),    # reference's own dtype
     (20_000, 8, 100, np.float32),     # BASELINE config 1 shape
+    (30_011, 16, 100, np.float32),    # fast path, 4 channels per lane
+    (30_010, 30, 100, np.float64),    # fast path, 8 channels per lane
+    (10_000, 12, 97, np.float32),     # fast path, K = 97
+    (63, 22, 100, np.float32),        # below one 64-row group: generic path
     (4_097, 7, 100, np.float32),      # odd channel count: scalar-load path
     (3_000, 40, 400, np.float32),     # config 5 shape: two channel chunks, 25 node blocks
     (2_000, 100, 100, np.float32),    # config 4 (cell SOM) shape: four channel chunks
