@@ -96,19 +96,19 @@ __global__ __launch_bounds__(MAXT) void som_online_kernel(const T *__restrict__ 
     const bool track = rlen > 1;
     const int per_thread = (chunk * c + bd - 1) / bd;  // gathered elements per thread per chunk
     constexpr int kMaxPer = 16;
-    double pre[kMaxPer];
+    T pre[kMaxPer];  // converted at commit: no use of a loaded value before its chunk is over
 
+    // branch-free per lane (clamped element and step index): a load guarded by a divergent branch
+    // gets its s_waitcnt right behind it, which serialises the HBM round trips
     auto gather = [&](int64_t step0) {
 #pragma unroll
         for (int u = 0; u < kMaxPer; u++) {
-            const int e = tid + u * bd;
-            double v = 0.0;
-            if (u < per_thread && e < chunk * c) {
+            if (u < per_thread) {  // uniform
+                const int e = min(tid + u * bd, chunk * c - 1);
                 const int s = e / c, j = e - s * c;
-                const int64_t st = step0 + s;
-                if (st < niter) v = (double)x[order[st] * ldx + j];
+                const int64_t st = step0 + s < niter ? step0 + s : niter - 1;
+                pre[u] = x[order[st] * ldx + j];
             }
-            pre[u] = v;
         }
     };
     // the oracle's alpha = a0 - (a0 - a1) * k / niter (same operation order), one lane per step,
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(MAXT) void som_online_kernel(const T *__restrict__ 
             const int e = tid + u * bd;
             if (u < per_thread && e < chunk * c) {
                 const int srow = e / c, j = e - srow * c;
-                xs[((size_t)buf * chunk + srow) * cs + j] = pre[u];
+                xs[((size_t)buf * chunk + srow) * cs + j] = (double)pre[u];
             }
         }
     };
@@ -293,6 +293,290 @@ __global__ __launch_bounds__(MAXT) void som_online_kernel(const T *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// exact online SOM, split form: L adjacent lanes share one node, each owning CH consecutive channels
+// (K * L <= 256 threads: the Pixie default 10x10 x <= 24 markers runs as 4 waves, one per SIMD, 12
+// channels per lane).  binary64 issue (~6.75 cycles per wave instruction) bounds the thread<->node
+// form; splitting the channels cuts the per-wave instruction count while keeping the oracle's
+// arithmetic: the squared distance is still accumulated strictly left to right -- lane q continues
+// the partial sum of lane q-1 (row_shr:1 DPP), so after L phases lane L-1 of the group holds the
+// oracle's value bit for bit.  The codebook update is element-wise and splits trivially.
+// The wave minimum runs on the upper 32 bits of d2 (one v_min_u32 DPP per stage); only when the
+// smallest key is shared does the binary64 / sqrt comparison of the thread<->node form run.
+// ------------------------------------------------------------------------------------------------
+// scripts/ubench/online_step_timing.hip includes this file with PXSOM_STEP_TIMING defined: s_memtime
+// deltas per step segment, accumulated by wave 0 (changes the schedule slightly; diagnosis only)
+#ifdef PXSOM_STEP_TIMING
+__device__ long long g_step_ticks[8];
+#define PXSOM_TICK(i)                                 \
+    do {                                              \
+        const long long t_now = clock64();            \
+        tick_acc[i] += t_now - tick_prev;             \
+        tick_prev = t_now;                            \
+    } while (0)
+#else
+#define PXSOM_TICK(i) \
+    do {              \
+    } while (0)
+#endif
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+    // v_min_u32 with the DPP operand fused (the compiler emits mov + mov_dpp + min per stage)
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
+        : "+v"(v));
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    u2 r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    v = min(r[0], r[1]);
+    r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return min(r[0], r[1]);
+}
+
+// value of the lane to the left inside a 16-lane row (row_shr:1); lane 0 of a row keeps its own
+__device__ __forceinline__ double shr1_f64(double v)
+{
+    int lo = (int)__double_as_longlong(v), hi = (int)(__double_as_longlong(v) >> 32);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x111, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x111, 0xF, 0xF, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane((int)__double_as_longlong(v), l);
+    const int hi = __builtin_amdgcn_readlane((int)(__double_as_longlong(v) >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+template <typename T, int CH, int L>
+__global__ __launch_bounds__(256) void som_online_split_kernel(const T *__restrict__ x, int64_t n, int c,
+                                                               int64_t ldx, double *w, int xdim, int ydim,
+                                                               int rlen, double a0, double a1, double r0,
+                                                               double r1, const int64_t *__restrict__ order,
+                                                               int chunk)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int CMAX = CH * L;
+    constexpr int LOG_L = L == 4 ? 2 : 1;
+    constexpr int NS = 128;  // distance slots per parity (K <= 128); slots >= K stay +inf
+    const int K = xdim * ydim;
+    const int tid = threadIdx.x, bd = blockDim.x;
+    const int lane = tid & 63, wv = tid >> 6, nwv = bd >> 6;
+    double *xs = reinterpret_cast<double *>(smem_raw);        // [2][chunk][CMAX] (pad slots stay 0)
+    double *dall = xs + (size_t)2 * chunk * CMAX;             // [2][NS] squared distance of every node
+    double *red = dall + 2 * NS;                              // [4] change partials
+    int64_t *ordl = reinterpret_cast<int64_t *>(red + 4);     // [chunk] rows presented in the next chunk
+    double *alpha_ring = reinterpret_cast<double *>(ordl + chunk);  // [2][chunk] (+ CMAX doubles of slack:
+                                                                    //  the one-step-ahead reads may overrun)
+
+    const int node = tid >> LOG_L, q = tid & (L - 1);
+    const bool has_node = node < K;
+    const bool owner = has_node && q == L - 1;                // this lane ends up with the node's d2
+    const int nx = node / ydim, ny = node % ydim;
+    // every wave searches all K distances after the exchange: lane l looks at nodes 2l and 2l + 1
+    const int pk0 = (2 * lane) | (((2 * lane) / ydim) << 8) | (((2 * lane) % ydim) << 16);
+    const int pk1 = (2 * lane + 1) | (((2 * lane + 1) / ydim) << 8) | (((2 * lane + 1) % ydim) << 16);
+    const int ch0 = q * CH;
+    double wr[CH];
+#pragma unroll
+    for (int j = 0; j < CH; j++) wr[j] = (has_node && ch0 + j < c) ? w[(size_t)node * c + ch0 + j] : 0.0;
+
+    const int64_t niter = (int64_t)rlen * n;
+    double threshold = r0;
+    const double thresholdStep = (r0 - r1) / (double)niter;
+    double change = 1.0, mychange = 0.0;
+    const bool track = rlen > 1;
+    const int per_thread = (chunk * c + bd - 1) / bd;
+    constexpr int kMaxPer = 16;
+    T pre[kMaxPer];
+    int64_t ord_pre = 0;
+
+    // presented rows travel HBM -> registers -> LDS one chunk ahead of their use; their row numbers
+    // (order[]) two chunks ahead, so neither dependent HBM round trip is ever waited on mid-chunk
+    auto fetch_order = [&](int64_t step0) {  // branch-free as well (steps past the end re-read the last)
+        const int64_t st = step0 + min(tid, chunk - 1);
+        ord_pre = order[st < niter ? st : niter - 1];
+    };
+    auto publish_order = [&]() {
+        if (tid < chunk) ordl[tid] = ord_pre;
+    };
+    // branch-free per lane (clamped element index, row 0 past the end): a load guarded by a divergent
+    // branch gets its s_waitcnt right behind it, which serialises the HBM round trips
+    auto gather = [&](int64_t) {
+#pragma unroll
+        for (int u = 0; u < kMaxPer; u++) {
+            if (u < per_thread) {  // uniform
+                const int e = min(tid + u * bd, chunk * c - 1);
+                const int s = e / c, j = e - s * c;
+                pre[u] = x[ordl[s] * ldx + j];
+            }
+        }
+    };
+    auto commit = [&](int buf, int64_t step0) {
+#pragma unroll
+        for (int u = 0; u < kMaxPer; u++) {
+            const int e = tid + u * bd;
+            if (u < per_thread && e < chunk * c) {
+                const int srow = e / c, j = e - srow * c;
+                xs[((size_t)buf * chunk + srow) * CMAX + j] = (double)pre[u];
+            }
+        }
+        if (tid < chunk) {
+            const int64_t kk = step0 + tid;
+            alpha_ring[buf * chunk + tid] = a0 - (a0 - a1) * (double)kk / (double)niter;
+        }
+    };
+
+    for (int e = tid; e < 2 * chunk * CMAX; e += bd) xs[e] = 0.0;
+    for (int e = tid; e < 2 * NS; e += bd) dall[e] = INFINITY;
+    fetch_order(0);
+    publish_order();
+    __syncthreads();
+    gather(0);
+    fetch_order(chunk);
+    commit(0, 0);
+    __syncthreads();  // everyone has consumed ordl (the loads above have returned)
+    publish_order();
+    __syncthreads();
+    // nothing issued so far is still in flight: without this the s_waitcnt pass keeps a vmcnt(0) at
+    // the top of the step loop, which would wait for every chunk's prefetch
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+
+    bool done = false;
+    int par = 0, buf = 0;
+    int64_t in_epoch = 0;
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+#ifdef PXSOM_STEP_TIMING
+    long long tick_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tick_prev = clock64();
+#endif
+    for (int64_t step0 = 0; step0 < niter && !done; step0 += chunk) {
+        fetch_order(step0 + 2 * chunk);  // row numbers of the chunk after the next
+        gather(step0 + chunk);           // rows of the next chunk (their numbers are in ordl)
+        const double *xc = xs + (size_t)buf * chunk * CMAX + ch0;
+        PXSOM_TICK(7);
+        // the row and learning rate of step s + 1 are read from LDS while step s computes
+        double xcur[CH], alpha_cur = alpha_ring[buf * chunk];
+#pragma unroll
+        for (int j = 0; j < CH; j++) xcur[j] = xc[j];
+        for (int s = 0; s < chunk; s++) {
+            const int64_t step = step0 + s;
+            if (step >= niter) break;
+            int64_t k = step;
+            const bool epoch_start = in_epoch == 0;
+            if (++in_epoch == n) in_epoch = 0;
+            if (epoch_start) {
+                if (step > 0) {
+                    double v = mychange;
+                    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                    if (lane == 0) red[wv] = v;
+                    __syncthreads();
+                    change = 0.0;
+                    for (int i = 0; i < nwv; i++) change += red[i];
+                    __syncthreads();
+                }
+                if (change < 1.0) {
+                    k = niter;
+                    done = true;
+                }
+                change = 0.0;
+                mychange = 0.0;
+            }
+            PXSOM_TICK(0);
+            double tmp[CH], sq[CH];
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                tmp[j] = xcur[j] - wr[j];  // pad slots: 0 - 0
+                sq[j] = tmp[j] * tmp[j];
+            }
+            const double alpha_ring_s = alpha_cur;
+            {
+                const double *xr = xc + (size_t)(s + 1) * CMAX;  // s + 1 == chunk: in-bounds, unused
+#pragma unroll
+                for (int j = 0; j < CH; j++) xcur[j] = xr[j];
+                alpha_cur = alpha_ring[buf * chunk + s + 1];
+            }
+            // FlowSOM eucl() before its sqrt: xdist = 0; xdist += tmp_j^2, j ascending over the node's
+            // channels (0 + sq_0 == sq_0 exactly).  Lane q is correct after phase q.
+            double acc = sq[0];
+#pragma unroll
+            for (int j = 1; j < CH; j++) acc += sq[j];
+#pragma unroll
+            for (int p = 1; p < L; p++) {
+                double t = shr1_f64(acc);
+#pragma unroll
+                for (int j = 0; j < CH; j++) t += sq[j];
+                acc = q == 0 ? acc : t;
+            }
+            PXSOM_TICK(1);
+            // all-to-all through LDS: one write, one barrier, one 16-byte read per lane; every wave then
+            // finds the minimum of all K distances itself (no second exchange of per-wave winners)
+            if (owner) dall[par * NS + node] = acc == acc ? acc : INFINITY;
+            __syncthreads();
+            PXSOM_TICK(2);
+            const d2_t dd = *reinterpret_cast<const d2_t *>(dall + par * NS + 2 * lane);
+            par ^= 1;
+            // the oracle compares sqrt(d2) with a strict '<' in node order.  sqrt is monotone: a node
+            // whose d2 is the only one with the smallest upper 32 bits (gap >= 2^-21 relative) wins
+            // outright; keys shared by several nodes are settled on the sqrt values themselves.
+            const unsigned key0 = (unsigned)(__double_as_longlong(dd[0]) >> 32);
+            const unsigned key1 = (unsigned)(__double_as_longlong(dd[1]) >> 32);
+            const unsigned kmin = wave_min_u32(min(key0, key1));
+            unsigned long long cand0 = __ballot(key0 == kmin), cand1 = __ballot(key1 == kmin);
+            int nearest;
+            if (__popcll(cand0) + __popcll(cand1) == 1) {
+                nearest = cand0 ? __builtin_amdgcn_readlane(pk0, (int)__ffsll((long long)cand0) - 1)
+                                : __builtin_amdgcn_readlane(pk1, (int)__ffsll((long long)cand1) - 1);
+            } else {
+                const double s0 = key0 == kmin ? sqrt(dd[0]) : INFINITY;
+                const double s1 = key1 == kmin ? sqrt(dd[1]) : INFINITY;
+                const double sl = fmin(s0, s1);
+                const double smin = wave_min_f64(sl);
+                const unsigned long long cl = __ballot(sl == smin);
+                const int first = (int)__ffsll((long long)cl) - 1;  // lanes ascend in node order
+                const int p0 = __builtin_amdgcn_readlane(pk0, first), p1 = __builtin_amdgcn_readlane(pk1, first);
+                const bool zero_first = (__ballot(s0 == smin) >> first) & 1ull;
+                nearest = zero_first ? p0 : p1;
+                // no finite distance anywhere (NaN row, overflow): FlowSOM's loop never replaces node 0
+                if (!(smin < INFINITY)) nearest = 0;
+            }
+            PXSOM_TICK(4);
+            if (threshold < 1.0) threshold = 0.5;
+            const double alpha = k == step ? alpha_ring_s : a0 - (a0 - a1) * (double)k / (double)niter;
+            const int bx = (nearest >> 8) & 0xff, by = (nearest >> 16) & 0xff;
+            const int dx = nx > bx ? nx - bx : bx - nx, dy = ny > by ? ny - by : by - ny;
+            const double nh = (double)(dx > dy ? dx : dy);
+            if (has_node && !(nh > threshold)) {
+#pragma unroll
+                for (int j = 0; j < CH; j++) wr[j] = wr[j] + tmp[j] * alpha;
+                if (track) {  // only ever consulted when rlen > 1
+#pragma unroll
+                    for (int j = 0; j < CH; j++) mychange += fabs(tmp[j]);
+                }
+            }
+            threshold -= thresholdStep;
+            PXSOM_TICK(5);
+            if (done) break;
+        }
+        commit(buf ^ 1, step0 + chunk);
+        publish_order();
+        buf ^= 1;
+        __syncthreads();
+        PXSOM_TICK(6);
+    }
+#ifdef PXSOM_STEP_TIMING
+    if (tid == 0)
+        for (int i = 0; i < 8; i++) g_step_ticks[i] = tick_acc[i];
+#endif
+    if (has_node) {
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+            if (ch0 + j < c) w[(size_t)node * c + ch0 + j] = wr[j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // batch update: one workgroup per node k, thread <-> channel.  Only the Chebyshev window of k is
 // visited, in ascending node order b (the oracle's summation order: skipping the nodes it skips).
 // ------------------------------------------------------------------------------------------------
@@ -445,12 +729,44 @@ int launch_online(const T *x, int64_t n, int c, int64_t ldx, double *w, int xdim
     return PXSOM_OK;
 }
 
+template <typename T, int CH, int L>
+int launch_online_split(const T *x, int64_t n, int c, int64_t ldx, double *w, int xdim, int ydim, int rlen,
+                        double a0, double a1, double r0, double r1, const int64_t *order, hipStream_t st)
+{
+    const int K = xdim * ydim;
+    const int bd = ((K * L + 63) / 64) * 64;
+    int chunk = 64;
+    while ((chunk * c + bd - 1) / bd > 16) chunk >>= 1;  // gather registers per thread
+    const size_t lds = (size_t)2 * chunk * CH * L * 8 + (2 * 128 + 4) * 8 + (size_t)chunk * 8 +
+                       (size_t)2 * chunk * 8 + (size_t)(CH * L + 2) * 8;
+    auto kern = som_online_split_kernel<T, CH, L>;
+    hipLaunchKernelGGL(kern, dim3(1), dim3(bd), lds, st, x, n, c, ldx, w, xdim, ydim, rlen, a0, a1, r0, r1,
+                       order, chunk);
+    PXSOM_LAUNCH_CHECK("som_online_split_kernel");
+    return PXSOM_OK;
+}
+
 template <typename T>
 int train_online_typed(const T *x, int64_t n, int c, int64_t ldx, double *w, int xdim, int ydim, int rlen,
                        double a0, double a1, double r0, double r1, const int64_t *order, hipStream_t st)
 {
 #define PXSOM_ONLINE(CM, MT) \
     return launch_online<T, CM, MT>(x, n, c, ldx, w, xdim, ydim, rlen, a0, a1, r0, r1, order, st)
+#define PXSOM_ONLINE_SPLIT(CH, L) \
+    return launch_online_split<T, CH, L>(x, n, c, ldx, w, xdim, ydim, rlen, a0, a1, r0, r1, order, st)
+    // small maps: several lanes per node (fewer binary64 instructions per wave per step)
+    if (xdim * ydim <= 64 && c <= 40) {
+        if (c <= 16) PXSOM_ONLINE_SPLIT(4, 4);
+        if (c <= 24) PXSOM_ONLINE_SPLIT(6, 4);
+        PXSOM_ONLINE_SPLIT(10, 4);
+    }
+    if (xdim * ydim <= 128 && c <= 40) {
+        if (c <= 8) PXSOM_ONLINE_SPLIT(4, 2);
+        if (c <= 16) PXSOM_ONLINE_SPLIT(8, 2);
+        if (c <= 24) PXSOM_ONLINE_SPLIT(12, 2);
+        PXSOM_ONLINE_SPLIT(20, 2);
+    }
+#undef PXSOM_ONLINE_SPLIT
     // <= 256 nodes: 4 waves at most, the whole register file is available per thread
     if (xdim * ydim <= 256) {
         if (c <= 8) PXSOM_ONLINE(8, 256);

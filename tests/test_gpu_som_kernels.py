@@ -160,6 +160,13 @@ def test_cluster_sums_matches_oracle(gpu, oracle):
     (2_000, 15, 20, 10, 1, np.float64),   # reference test grid (cluster_helpers_test: xdim=20, ydim=10)
     (1_000, 40, 20, 20, 1, np.float32),   # config 5 grid
     (300, 4, 3, 2, 3, np.float32),
+    (2_000, 20, 8, 8, 1, np.float32),     # 4 lanes per node, 6 channels per lane
+    (1_500, 33, 6, 5, 2, np.float64),     # 4 lanes per node, 10 channels per lane
+    (2_000, 5, 10, 10, 1, np.float64),    # 2 lanes per node, 4 channels per lane
+    (2_000, 14, 11, 11, 1, np.float32),   # 2 lanes per node, 8 channels per lane
+    (1_500, 37, 10, 12, 1, np.float32),   # 2 lanes per node, 20 channels per lane
+    (1_000, 45, 10, 10, 1, np.float32),   # thread <-> node form (c > 40)
+    (1_000, 70, 12, 12, 1, np.float64),   # thread <-> node form, codebook in LDS
 ])
 def test_train_online_bit_exact(gpu, oracle, n, c, xdim, ydim, rlen, dtype):
     k = xdim * ydim
@@ -174,6 +181,24 @@ def test_train_online_bit_exact(gpu, oracle, n, c, xdim, ydim, rlen, dtype):
                     torch.from_numpy(order).to(gpu))
     got = wd.cpu().numpy()
     np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("c,xdim,ydim", [(22, 10, 10), (6, 7, 9), (12, 5, 5), (30, 16, 16)])
+def test_train_online_ties_bit_exact(gpu, oracle, c, xdim, ydim):
+    """Coarsely quantised rows and duplicated initial nodes: equal and near-equal distances are the
+    rule, so the first-strict-minimum path (sqrt comparison, lowest node wins) is what is tested."""
+    k = xdim * ydim
+    n = 4_000
+    rs = np.random.RandomState(61)
+    x = rs.randint(0, 3, size=(n, c)).astype(np.float32)
+    x[::11] = 0.0
+    w0 = np.ascontiguousarray(x[rs.randint(0, n // 50, size=k)].astype(np.float64))
+    order = rs.randint(0, n, size=n).astype(np.int64)
+    ar, rr = (0.05, 0.01), default_radius_range(xdim, ydim)
+    want = oracle.som_online(x.astype(np.float64), w0, xdim, ydim, 1, ar, rr, order)
+    wd = torch.from_numpy(w0.copy()).to(gpu)
+    sd.train_online(torch.from_numpy(x).to(gpu), wd, xdim, ydim, 1, ar, rr, torch.from_numpy(order).to(gpu))
+    np.testing.assert_array_equal(wd.cpu().numpy(), want)
 
 
 def test_batch_update_matches_oracle(gpu, oracle):
