@@ -68,8 +68,18 @@ __host__ __device__ inline int node_of_row(int b, int m, int nb)
 }
 
 // filter stage (pxsom_assign_filter.hip, compiled with -ffinite-math-only)
+// stats != nullptr (only when filter_fast_path() holds): the filter also accumulates the batch rule's
+// [k*c sums | k counts] for every row it does not list
 template <typename T>
 void launch_filter_any(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L,
-                       int32_t *labels, hipStream_t st);
+                       int32_t *labels, double *stats, hipStream_t st);
+template <typename T>
+bool filter_fast_path(const T *x, int64_t n, int c, int64_t ldx, const Layout &L);
+
+// pxsom_assign with the batch rule's accumulation fused in (pxsom_assign.hip).  *fused = false: the shape
+// is outside the fused path, nothing was done, the caller runs assign + cluster sums separately.
+int assign_accumulate(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev, int k,
+                      int32_t *labels_dev, double *stats_dev, void *workspace_dev, size_t workspace_bytes,
+                      hipStream_t st, bool *fused);
 
 }  // namespace pxsom_bmu

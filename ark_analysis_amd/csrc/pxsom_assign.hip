@@ -21,10 +21,25 @@
 #include <cmath>
 
 #include "pxsom_assign.h"
+#include "pxsom_wave.h"
 
 using namespace pxsom_bmu;
 
 namespace {
+
+// scripts/ubench/assign_phase_timing.hip includes this file with PXSOM_PHASE_TIMING defined: s_memtime at
+// phase boundaries of the single-workgroup prep kernel and of workgroup 0 of the exact kernel
+#ifdef PXSOM_PHASE_TIMING
+__device__ long long g_phase_ticks[32];
+#define PXSOM_PHASE(i)                                          \
+    do {                                                        \
+        if (threadIdx.x == 0 && blockIdx.x == 0) g_phase_ticks[i] = clock64(); \
+    } while (0)
+#else
+#define PXSOM_PHASE(i) \
+    do {               \
+    } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // 1. prep: one workgroup of 256 threads.
@@ -32,42 +47,69 @@ namespace {
 __global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict__ w, int k, int c,
                                                        AssignHdr *hdr, half8 *wfrag, f32x4 *bias,
                                                        int nb, int nch, int cpl, int idx_bits,
-                                                       int node_bits, int stage)
+                                                       int node_bits, int stage, double *zero_ptr,
+                                                       int zero_count)
 {
+    PXSOM_PHASE(0);
+    // fused batch accumulation: the statistics buffer is cleared here instead of by a memset node
+    for (int e = threadIdx.x; e < zero_count; e += 256) zero_ptr[e] = 0.0;
     __shared__ double s_norm2[PXSOM_MAX_NODES];
-    __shared__ double s_red[256];
+    __shared__ double s_red[8];
     __shared__ int s_bad;
     extern __shared__ __attribute__((aligned(16))) char prep_smem[];
     const int tid = threadIdx.x;
     if (tid == 0) s_bad = 0;
-    // small codebooks are staged in LDS with one coalesced sweep; every later read is an LDS read
+    // small codebooks are staged in LDS with one coalesced sweep (8 loads in flight per thread); every
+    // later read is an LDS read
     const double *wl = w;
     if (stage) {
         double *sw = reinterpret_cast<double *>(prep_smem);
-        for (int e = tid; e < k * c; e += 256) sw[e] = w[e];
+        for (int e0 = tid; e0 < k * c; e0 += 8 * 256) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = w[e0 + u * 256 < k * c ? e0 + u * 256 : 0];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (e0 + u * 256 < k * c) sw[e0 + u * 256] = v[u];
+        }
         wl = sw;
     }
     __syncthreads();
+    PXSOM_PHASE(1);
 
-    // per-node squared norm (binary64) and global max |w|
-    double mymax = 0.0;
-    for (int node = tid; node < k; node += 256) {
-        double s = 0.0;
-        for (int j = 0; j < c; j++) {
-            double v = wl[(size_t)node * c + j];
-            if (!(fabs(v) <= DBL_MAX)) s_bad = 1;  // NaN / Inf in the codebook
-            s += v * v;
+    // per-node squared norm (binary64), max |w| and max norm.  `parts` adjacent lanes share a node
+    // (interleaved channels, butterfly sum: every node is summed in the same order, so bit-identical
+    // rows get bit-identical norms -- the duplicate test below relies on it).
+    const int parts = k <= 64 ? 4 : (k <= 128 ? 2 : 1);
+    const int pshift = parts == 4 ? 2 : (parts == 2 ? 1 : 0);
+    double mymax = 0.0, mynorm = 0.0;
+    bool bad = false;
+    for (int p = tid; p < (k << pshift); p += 256) {
+        const int node = p >> pshift, part = p & (parts - 1);
+        double sum = 0.0;
+        for (int j = part; j < c; j += parts) {
+            const double v = wl[(size_t)node * c + j];
+            bad |= !(fabs(v) <= DBL_MAX);  // NaN / Inf in the codebook
+            sum += v * v;
             mymax = fmax(mymax, fabs(v));
         }
-        s_norm2[node] = s;
+        if (parts >= 2) sum += __shfl_xor(sum, 1);
+        if (parts == 4) sum += __shfl_xor(sum, 2);
+        if (part == 0) s_norm2[node] = sum;
+        mynorm = fmax(mynorm, sum);
     }
-    s_red[tid] = mymax;
+    if (bad) s_bad = 1;
+    // both maxima: DPP wave reduction (max(a, b) = -min(-a, -b)), then 4 partials through LDS
+    mymax = -pxsom::wave_min_f64(-mymax);
+    mynorm = mynorm == mynorm ? -pxsom::wave_min_f64(-mynorm) : mynorm;
+    if ((tid & 63) == 0) {
+        s_red[tid >> 6] = mymax;
+        s_red[4 + (tid >> 6)] = mynorm;
+    }
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (tid < off) s_red[tid] = fmax(s_red[tid], s_red[tid + off]);
-        __syncthreads();
-    }
-    const double maxabs = s_red[0];
+    PXSOM_PHASE(2);
+    const double maxabs = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+    const double wn2max = fmax(fmax(s_red[4], s_red[5]), fmax(s_red[6], s_red[7]));
     // scale = 2^e with maxabs*scale in [128, 256): fp16 keeps 11 significant bits there and the
     // low halves of the split stay normal down to |x| ~ 1e-4 * maxabs.
     int e = 0;
@@ -79,23 +121,14 @@ __global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict_
         if (e < -100) e = -100;
     }
     const double scale = ldexp(1.0, e);
-
-    double wn2max = 0.0;
-    for (int node = tid; node < k; node += 256) wn2max = fmax(wn2max, s_norm2[node]);
-    __syncthreads();
-    s_red[tid] = wn2max;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (tid < off) s_red[tid] = fmax(s_red[tid], s_red[tid + off]);
-        __syncthreads();
-    }
+    PXSOM_PHASE(3);
     if (tid == 0) {
-        const bool bad = s_bad != 0 || !(s_red[0] * scale * scale <= 1.0e30);
+        const bool badw = s_bad != 0 || !(wn2max * scale * scale <= 1.0e30);
         hdr->amb_count = 0;
         hdr->scale = (float)scale;
         // rounded up by a hair; an infinite wn_max makes every row take the exact path
-        hdr->wn_max = bad ? 0.f : (float)(sqrt(s_red[0]) * scale * (1.0 + 1e-6));
-        hdr->force_exact = bad ? 1 : 0;  // NaN/Inf/huge codebook: every row takes the exact path
+        hdr->wn_max = badw ? 0.f : (float)(sqrt(wn2max) * scale * (1.0 + 1e-6));
+        hdr->force_exact = badw ? 1 : 0;  // NaN/Inf/huge codebook: every row takes the exact path
         // coefficient of the rigorous |filter - exact| bound, see DESIGN.md "K7 error bound":
         //   index packing 2^-(23-idx_bits) (idx_bits low mantissa bits replaced), fp32 accumulation
         //   (3C+2)*2^-24, split residual 2^-19,
@@ -113,22 +146,25 @@ __global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict_
     }
 
     // A-fragments: wfrag[(b*nsteps + s)*64 + lane], lane = (q<<4 | m): node 16b+m,
-    // slot i of lane group q in chunk h <-> channel h*4*cpl + q*cpl + i (i < cpl)
+    // slot i of lane group q in chunk h <-> channel h*4*cpl + q*cpl + i (i < cpl); s = 2h: hi, 2h+1: lo
     const int nsteps = 2 * nch;
-    for (int f = tid; f < nb * nsteps * 64; f += 256) {
-        const int lane = f & 63, s = (f >> 6) % nsteps, b = (f >> 6) / nsteps;
-        const int m = lane & 15, q = lane >> 4, h = s / 2, t = s % 2;
+    PXSOM_PHASE(4);
+    for (int f = tid; f < nb * nch * 64; f += 256) {
+        const int lane = f & 63, h = (f >> 6) % nch, b = (f >> 6) / nch;
+        const int m = lane & 15, q = lane >> 4;
         const int node = node_of_row(b, m, nb);
-        half8 frag;
+        half8 fhi, flo;
+#pragma unroll
         for (int i = 0; i < 8; i++) {
             const int ch = h * 4 * cpl + q * cpl + i;
             float W = 0.f;
             if (i < cpl && ch < c && node < k) W = (float)(wl[(size_t)node * c + ch] * scale);
             const _Float16 hi = (_Float16)W;
-            const _Float16 lo = (_Float16)(W - (float)hi);
-            frag[i] = (t == 1) ? lo : hi;
+            fhi[i] = hi;
+            flo[i] = (_Float16)(W - (float)hi);
         }
-        wfrag[f] = frag;
+        wfrag[(size_t)(b * nsteps + 2 * h) * 64 + lane] = fhi;
+        wfrag[(size_t)(b * nsteps + 2 * h + 1) * 64 + lane] = flo;
     }
     // Exact duplicates of an EARLIER node can never be the answer (their distance is identical and the
     // reference keeps the first minimum), so they are masked out of the filter.  This matters in batch
@@ -136,8 +172,42 @@ __global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict_
     // update and are bit-identical, which would otherwise send every row they win to the exact path.
     // (s_dup reuses s_red's storage class: one flag per node.)
     __shared__ unsigned char s_dup[PXSOM_MAX_NODES];
+    PXSOM_PHASE(5);
     for (int node = tid; node < k; node += 256) s_dup[node] = 0;
     __syncthreads();
+    auto same_rows = [&](int prev, int node) {
+        if (s_norm2[prev] != s_norm2[node]) return false;
+        for (int j = 0; j < c; j++)
+            if (wl[(size_t)prev * c + j] != wl[(size_t)node * c + j]) return false;
+        return true;
+    };
+    if (k <= 256) {
+        // all pairs on the norms (equal rows have equal norms), the range of earlier nodes split over
+        // 256/k threads per node; full channel comparison only on a norm match
+        __shared__ int s_first[256];
+        for (int node = tid; node < k; node += 256) s_first[node] = 0x7fffffff;
+        __syncthreads();
+        int sp = 1;
+        while (sp * 2 * k <= 256) sp *= 2;
+        const int len = (k + sp - 1) / sp;
+        for (int p = tid; p < k * sp; p += 256) {
+            const int node = p / sp, part = p - node * sp;
+            const int lo = part * len, hi = min(node, lo + len);
+            const double n2 = s_norm2[node];
+            int hit = 0x7fffffff;
+#pragma unroll 8
+            for (int prev = lo; prev < hi; prev++) hit = min(hit, s_norm2[prev] == n2 ? prev : 0x7fffffff);
+            if (hit != 0x7fffffff) atomicMin(&s_first[node], hit);
+        }
+        __syncthreads();
+        for (int node = tid; node < k; node += 256) {
+            const int first = s_first[node];
+            if (first >= node) continue;
+            bool dup = same_rows(first, node);
+            for (int prev = first + 1; prev < node && !dup; prev++) dup = same_rows(prev, node);  // norm collision
+            if (dup) s_dup[node] = 1;
+        }
+    } else
     // hash table keyed by the norm's bit pattern (equal rows have equal norms): slot <- smallest node
     // index hashing there; a node is a duplicate iff an earlier node with identical channels exists.
     {
@@ -175,6 +245,7 @@ __global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict_
         }
     }
     __syncthreads();
+    PXSOM_PHASE(6);
     // bias[b*64 + lane][r] for accumulator row (lane>>4)*4 + r <-> node_of_row(b, 4q + r)
     for (int f = tid; f < nb * 64; f += 256) {
         const int lane = f & 63, b = f >> 6, q = lane >> 4;
@@ -185,6 +256,7 @@ __global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict_
         }
         bias[f] = bv;
     }
+    PXSOM_PHASE(7);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -192,45 +264,50 @@ __global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict_
 //    binary64, no contraction, j ascending, sqrt, first strict minimum (FlowSOM C_mapDataToCodes).
 // ------------------------------------------------------------------------------------------------
 #pragma clang fp contract(off)
-template <typename T>
-__global__ __launch_bounds__(256) void bmu_exact_kernel(const T *__restrict__ x, int c, int64_t ldx,
-                                                        const double *__restrict__ w, int k,
-                                                        const AssignHdr *hdr,
-                                                        const unsigned *__restrict__ amb_list,
-                                                        int32_t *__restrict__ labels, int use_lds)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double *wt = reinterpret_cast<double *>(smem_raw);  // [c][k] transposed codebook
-    const unsigned count = hdr->amb_count;
-    if (blockIdx.x * 4u >= count) return;  // uniform per workgroup: nothing listed for it
-    if (use_lds) {
-        for (int e = threadIdx.x; e < k * c; e += 256) {
-            const int node = e / c, j = e - node * c;
-            wt[(size_t)j * k + node] = w[e];
-        }
-        __syncthreads();
-    }
-    const int lane = threadIdx.x & 63;
-    const unsigned wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
-    // RB listed rows per wave iteration: the codebook element read from LDS is shared by the RB rows
-    // and their independent binary64 chains hide each other's latency.  Each row is fetched once
-    // (lane j holds channels j and j+64) and broadcast with v_readlane (j is wave-uniform).
-    constexpr int RB = 4;
-    for (unsigned e0 = wave * RB; e0 < count; e0 += nwaves * RB) {
-        int64_t rows[RB];
-        unsigned x_lo[RB][2], x_hi[RB][2];
+// One batch of RB listed rows on one wave.  RB = 4: the codebook element read from LDS is shared by four
+// rows and their independent binary64 chains hide each other's latency (long lists); RB = 1: one row per
+// wave, so a short list (a training mini-batch lists a handful of rows) spreads over many waves and
+// finishes in one row's latency.
+template <typename T, int RB>
+struct ExactRows {
+    int64_t rows[RB];
+    unsigned x_lo[RB][2], x_hi[RB][2];
+
+    // row numbers, then the rows themselves (lane j holds channels j and j+64): two dependent HBM/L2
+    // round trips, issued for the NEXT batch before the current one is evaluated
+    __device__ __forceinline__ void load(const T *__restrict__ x, int c, int64_t ldx,
+                                         const unsigned *__restrict__ amb_list, unsigned e0, unsigned count, int lane)
+    {
 #pragma unroll
         for (int u = 0; u < RB; u++) {
             const unsigned e = e0 + u < count ? e0 + u : count - 1;  // surplus slots redo the last row
             rows[u] = amb_list[e];
+        }
+#pragma unroll
+        for (int u = 0; u < RB; u++) {
             const T *rp = x + rows[u] * ldx;
-            const double xa = lane < c ? (double)rp[lane] : 0.0;
-            const double xb = lane + 64 < c ? (double)rp[lane + 64] : 0.0;
+            const double xa = (double)rp[lane < c ? lane : 0];
+            const double xb = (double)rp[lane + 64 < c ? lane + 64 : 0];
             x_lo[u][0] = (unsigned)__double_as_longlong(xa);
             x_hi[u][0] = (unsigned)(__double_as_longlong(xa) >> 32);
             x_lo[u][1] = (unsigned)__double_as_longlong(xb);
             x_hi[u][1] = (unsigned)(__double_as_longlong(xb) >> 32);
         }
+    }
+};
+
+template <typename T, int RB>
+__device__ __forceinline__ void exact_rows_loop(const T *__restrict__ x, int c, int64_t ldx,
+                                                const double *__restrict__ w, const double *wt, int k,
+                                                unsigned count, const unsigned *__restrict__ amb_list,
+                                                int32_t *__restrict__ labels, int use_lds,
+                                                double *__restrict__ stats, unsigned wave, unsigned nwaves,
+                                                int lane, ExactRows<T, RB> &cur)
+{
+    for (unsigned e0 = wave * RB; e0 < count; e0 += nwaves * RB) {
+        ExactRows<T, RB> nxt;
+        const unsigned en = e0 + nwaves * RB;
+        if (en < count) nxt.load(x, c, ldx, amb_list, en, count, lane);
         double best[RB];
         int bestk[RB];
 #pragma unroll
@@ -244,14 +321,15 @@ __global__ __launch_bounds__(256) void bmu_exact_kernel(const T *__restrict__ x,
             double d0[RB], d1[RB];
 #pragma unroll
             for (int u = 0; u < RB; u++) d0[u] = d1[u] = 0.0;
+#pragma unroll 2
             for (int j = 0; j < c; j++) {
                 const double w0 = use_lds ? wt[(size_t)j * k + c0] : w[(size_t)c0 * c + j];
                 const double w1 = use_lds ? wt[(size_t)j * k + c1] : w[(size_t)c1 * c + j];
                 const int h = j >> 6, jj = j & 63;
 #pragma unroll
                 for (int u = 0; u < RB; u++) {
-                    const unsigned lo = __builtin_amdgcn_readlane(h ? x_lo[u][1] : x_lo[u][0], jj);
-                    const unsigned hi = __builtin_amdgcn_readlane(h ? x_hi[u][1] : x_hi[u][0], jj);
+                    const unsigned lo = __builtin_amdgcn_readlane(h ? cur.x_lo[u][1] : cur.x_lo[u][0], jj);
+                    const unsigned hi = __builtin_amdgcn_readlane(h ? cur.x_hi[u][1] : cur.x_hi[u][0], jj);
                     const double xj = __longlong_as_double(((long long)hi << 32) | lo);
                     const double t0 = xj - w0, t1 = xj - w1;
                     d0[u] += t0 * t0;
@@ -271,20 +349,83 @@ __global__ __launch_bounds__(256) void bmu_exact_kernel(const T *__restrict__ x,
                 }
             }
         }
+        PXSOM_PHASE(11);
 #pragma unroll
         for (int u = 0; u < RB; u++) {
+            // first strict minimum over the wave: smallest distance (NaN distances never replaced
+            // DBL_MAX), then the smallest node index among the lanes that hold it -- DPP/permlane only
+            const double smin = pxsom::wave_min_f64(best[u]);
+            const unsigned cand = best[u] == smin ? (unsigned)bestk[u] : 0xffffffffu;
+            const int win = (int)pxsom::wave_min_u32(cand);  // 0x7fffffff: no finite distance (NaN row)
+            if (lane == 0) labels[cur.rows[u]] = win == 0x7fffffff ? 0 : win + 1;
+            // fused batch accumulation: the filter left this row's contribution to us
+            if (stats && e0 + u < count && win != 0x7fffffff) {
+                double *dst = stats + (size_t)win * c;
+                if (lane < c)
+                    __hip_atomic_fetch_add(dst + lane,
+                                           __longlong_as_double(((long long)cur.x_hi[u][0] << 32) | cur.x_lo[u][0]),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane + 64 < c)
+                    __hip_atomic_fetch_add(dst + lane + 64,
+                                           __longlong_as_double(((long long)cur.x_hi[u][1] << 32) | cur.x_lo[u][1]),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0)
+                    __hip_atomic_fetch_add(stats + (size_t)k * c + win, 1.0, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        PXSOM_PHASE(12);
+        if (en < count) cur = nxt;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bmu_exact_kernel(const T *__restrict__ x, int c, int64_t ldx,
+                                                        const double *__restrict__ w, int k,
+                                                        const AssignHdr *hdr,
+                                                        const unsigned *__restrict__ amb_list,
+                                                        int32_t *__restrict__ labels, int use_lds,
+                                                        double *__restrict__ stats)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double *wt = reinterpret_cast<double *>(smem_raw);  // [c][k] transposed codebook
+    PXSOM_PHASE(8);
+    const unsigned count = hdr->amb_count;
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const bool wide = count > nwaves;  // uniform over the grid: more rows than waves -> 4 rows per wave
+    if (blockIdx.x * 4u * (wide ? 4u : 1u) >= count) return;  // uniform per workgroup: nothing listed for it
+    PXSOM_PHASE(9);
+    // the first batch's two dependent round trips overlap the codebook staging below
+    ExactRows<T, 4> cur4;
+    ExactRows<T, 1> cur1;
+    if (wide) {
+        if (wave * 4u < count) cur4.load(x, c, ldx, amb_list, wave * 4u, count, lane);
+    } else {
+        if (wave < count) cur1.load(x, c, ldx, amb_list, wave, count, lane);
+    }
+    if (use_lds) {
+        // 8 independent loads in flight per thread (a one-load-per-trip loop pays the L2 latency per trip)
+        for (int e0 = threadIdx.x; e0 < k * c; e0 += 8 * 256) {
+            double v[8];
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const double od = __shfl_xor(best[u], off);
-                const int ok = __shfl_xor(bestk[u], off);
-                if (od < best[u] || (od == best[u] && ok < bestk[u])) {
-                    best[u] = od;
-                    bestk[u] = ok;
+            for (int u = 0; u < 8; u++) v[u] = w[e0 + u * 256 < k * c ? e0 + u * 256 : 0];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int e = e0 + u * 256;
+                if (e < k * c) {
+                    const int node = e / c, j = e - node * c;
+                    wt[(size_t)j * k + node] = v[u];
                 }
             }
-            if (lane == 0) labels[rows[u]] = bestk[u] == 0x7fffffff ? 0 : bestk[u] + 1;
         }
+        __syncthreads();
     }
+    PXSOM_PHASE(10);
+    if (wide)
+        exact_rows_loop<T, 4>(x, c, ldx, w, wt, k, count, amb_list, labels, use_lds, stats, wave, nwaves, lane, cur4);
+    else
+        exact_rows_loop<T, 1>(x, c, ldx, w, wt, k, count, amb_list, labels, use_lds, stats, wave, nwaves, lane, cur1);
 }
 
 // distance of every row to its labelled node (only when the caller asks for dists)
@@ -315,20 +456,20 @@ __global__ __launch_bounds__(256) void bmu_dist_kernel(const T *__restrict__ x, 
 
 template <typename T>
 int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int k, int32_t *labels,
-                 double *dist, char *ws, const Layout &L, hipStream_t st)
+                 double *dist, char *ws, const Layout &L, hipStream_t st, double *stats = nullptr)
 {
     const size_t stage_bytes = (size_t)k * c * sizeof(double);
     const int stage = stage_bytes <= 40 * 1024;
     hipLaunchKernelGGL(bmu_prep_kernel, dim3(1), dim3(256), stage ? stage_bytes : 0, st, w, k, c,
                        reinterpret_cast<AssignHdr *>(ws),
                        reinterpret_cast<half8 *>(ws + L.off_wfrag), reinterpret_cast<f32x4 *>(ws + L.off_bias),
-                       L.nb, L.nch, L.cpl, L.idx_bits, L.node_bits, stage);
+                       L.nb, L.nch, L.cpl, L.idx_bits, L.node_bits, stage, stats, stats ? k * (c + 1) : 0);
     PXSOM_LAUNCH_CHECK("bmu_prep_kernel");
 
     const int cus = pxsom::device_cu_count();
     pxsom::Prof *prof = pxsom::current_prof();
     pxsom::prof_mark(prof, st, true, n);
-    launch_filter_any<T>(x, n, c, ldx, ws, L, labels, st);
+    launch_filter_any<T>(x, n, c, ldx, ws, L, labels, stats, st);
     pxsom::prof_mark(prof, st, false, n);
     PXSOM_LAUNCH_CHECK("bmu_filter_kernel");
 
@@ -339,7 +480,7 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
     if (egrid < 1) egrid = 1;
     hipLaunchKernelGGL(bmu_exact_kernel<T>, dim3(egrid), dim3(256), use_lds ? wt_bytes : 0, st, x, c, ldx, w,
                        k, reinterpret_cast<const AssignHdr *>(ws),
-                       reinterpret_cast<const unsigned *>(ws + L.off_list), labels, use_lds);
+                       reinterpret_cast<const unsigned *>(ws + L.off_list), labels, use_lds, stats);
     PXSOM_LAUNCH_CHECK("bmu_exact_kernel");
 
     if (dist) {
@@ -389,6 +530,32 @@ PXSOM_EXPORT int pxsom_assign(const void *x_dev, int64_t n, int c, int64_t ldx, 
                                    dist_dev, ws, L, st);
     return assign_typed<double>(reinterpret_cast<const double *>(x_dev), n, c, ldx, w_dev, k, labels_dev,
                                 dist_dev, ws, L, st);
+}
+
+int pxsom_bmu::assign_accumulate(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev,
+                                 int k, int32_t *labels_dev, double *stats_dev, void *workspace_dev,
+                                 size_t workspace_bytes, hipStream_t st, bool *fused)
+{
+    *fused = false;
+    if (n < 64 || n > 0x7fffffffLL || c < 1 || c > PXSOM_MAX_CHANNELS || k < 1 || k > PXSOM_MAX_NODES || ldx < c ||
+        !x_dev || !w_dev || !labels_dev || !stats_dev || !workspace_dev)
+        return PXSOM_OK;  // the unfused route reports what is wrong with the arguments
+    const Layout L = make_layout(n, c, k);
+    if (workspace_bytes < L.total) return PXSOM_OK;
+    char *ws = reinterpret_cast<char *>(workspace_dev);
+    if (dtype == PXSOM_F32) {
+        const float *x = reinterpret_cast<const float *>(x_dev);
+        if (!filter_fast_path<float>(x, n, c, ldx, L)) return PXSOM_OK;
+        *fused = true;
+        return assign_typed<float>(x, n, c, ldx, w_dev, k, labels_dev, nullptr, ws, L, st, stats_dev);
+    }
+    if (dtype == PXSOM_F64) {
+        const double *x = reinterpret_cast<const double *>(x_dev);
+        if (!filter_fast_path<double>(x, n, c, ldx, L)) return PXSOM_OK;
+        *fused = true;
+        return assign_typed<double>(x, n, c, ldx, w_dev, k, labels_dev, nullptr, ws, L, st, stats_dev);
+    }
+    return PXSOM_OK;
 }
 
 PXSOM_EXPORT int pxsom_assign_last_exact_rows(const void *workspace_dev, void *stream, int64_t *out_rows)

@@ -336,12 +336,22 @@ typedef unsigned uint2v __attribute__((ext_vector_type(2)));
 #ifndef SGB_VALU
 #define SGB_VALU 0
 #endif
-template <typename T, int CPL, int NB, int RU, int MODE>
+// ACC (batch-rule accumulation fused in, pxsom_batch_accumulate): every row the filter is sure of adds
+// itself to a per-workgroup binary64 table [K*c sums | K counts] in LDS (ds_add_f64), flushed once with
+// global atomics into `stats`; listed rows are left to the exact kernel, which adds them after deciding.
+// One pass over x instead of two and two launches fewer per mini-batch step.
+template <typename T, int CPL, int NB, int RU, int MODE, bool ACC>
 __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
     const T *__restrict__ x, int64_t n, int c, int64_t ldx, const half8 *__restrict__ wfrag,
     const f32x4 *__restrict__ bias, AssignHdr *hdr, unsigned *__restrict__ amb_list,
-    int32_t *__restrict__ labels)
+    int32_t *__restrict__ labels, int k, double *__restrict__ stats)
 {
+    extern __shared__ __attribute__((aligned(16))) char acc_smem[];
+    double *ls = reinterpret_cast<double *>(acc_smem);  // [k*c + k]
+    if constexpr (ACC) {
+        for (int e = threadIdx.x; e < k * c + k; e += 256) ls[e] = 0.0;
+        __syncthreads();
+    }
     constexpr int NP = CPL / 2;  // pair loads per lane per tile
     // scores carry (b*4 + r) in their low 7 mantissa bits (inline constants <= 27: one v_and_or_b32 each);
     // OR-ing (q << 5) in yields a 7-bit id (q, b, r) that is mapped to the node once per group
@@ -380,6 +390,7 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
 
     typedef typename Pair<T>::type P2;
     P2 raw[kTilesPerIter][NP];
+    P2 keep[ACC ? kTilesPerIter : 1][NP];  // ACC: the group's rows outlive the prefetch of the next
     // Buffer loads: the 64-row group is a descriptor of its own (base = x + row0*ldx*sizeof(T), built
     // from wave-uniform values on the scalar unit), the tile offset rides in soffset and the lane offset in
     // voffset -- no per-load VALU address arithmetic.
@@ -434,6 +445,12 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
                 bl[t][2 * p + 1] = l2[1];
             }
             ss[t] = acc2;
+        }
+        if constexpr (ACC) {
+#pragma unroll
+            for (int t = 0; t < kTilesPerIter; t++)
+#pragma unroll
+                for (int p = 0; p < NP; p++) keep[t][p] = raw[t][p];
         }
         {
             int64_t gnext = g + nwaves;
@@ -554,12 +571,39 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
         int64_t row0 = g * 64;
         if (row0 > n - 64) row0 = n - 64;
         const int64_t row = row0 + lane;
+        // rows of a shifted last group that the previous group already covered are not listed again
+        // (a row listed twice would be accumulated twice by the exact kernel)
+        my_amb = my_amb && row >= g * 64;
         {
             // id (q, b, r) -> node: 16 b + 4 q + r, the last block's 4x4 (q, r) grid transposed (node_of_row)
             const unsigned id = __float_as_uint(my_m1) & node_mask;
             const unsigned wq = id >> 5, wb = (id >> 2) & 7u, wr = id & 3u;
             const unsigned real = wb == (unsigned)(NB - 1) ? 16u * wb + 4u * wr + wq : 16u * wb + 4u * wq + wr;
             labels[row] = (int)real + 1;
+            if constexpr (ACC) {
+                // lane (q, pix) holds channels q*CPL.. of rows (t, pix), t = 0..3; their labels sit in
+                // lanes (t, pix).  Skipped: listed rows, rows a previous group already added.
+                const unsigned mine = real | ((my_amb || row < g * 64) ? 0x80000000u : 0u);
+#pragma unroll
+                for (int t = 0; t < kTilesPerIter; t++) {
+                    const unsigned v = (unsigned)__shfl((int)mine, t * 16 + pix);
+                    if (!(v >> 31)) {
+                        double *dst = ls + (size_t)v * c + q * CPL;
+#pragma unroll
+                        for (int p = 0; p < NP; p++) {
+                            if (q * CPL + 2 * p <= c - 2) {  // clamped slots re-read the last pair: not theirs
+                                __hip_atomic_fetch_add(dst + 2 * p, (double)keep[t][p].x, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                                __hip_atomic_fetch_add(dst + 2 * p + 1, (double)keep[t][p].y, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                        }
+                        if (q == 0)
+                            __hip_atomic_fetch_add(ls + (size_t)k * c + v, 1.0, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
         }
         const unsigned long long mask = __ballot(my_amb);
         if (mask) {
@@ -569,31 +613,41 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
             if (my_amb) amb_list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned)row;
         }
     }
+    if constexpr (ACC) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < k * c + k; e += 256) {
+            const double v = ls[e];
+            if (v != 0.0) __hip_atomic_fetch_add(stats + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 template <typename T, int CPL, int NB, int RU>
 void launch_fast(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels,
-                 hipStream_t st)
+                 double *stats, hipStream_t st)
 {
-    auto kern = bmu_filter_fast<T, CPL, NB, RU, 0>;
+    auto kern = bmu_filter_fast<T, CPL, NB, RU, 0, false>;
     if constexpr (NB == 7 && CPL == 6 && sizeof(T) == 4) {  // microbench hook (headline shape only)
         const char *m = getenv("PXSOM_FILTER_MODE");
-        if (m && m[0] == '1') kern = bmu_filter_fast<T, CPL, NB, RU, 1>;
-        if (m && m[0] == '2') kern = bmu_filter_fast<T, CPL, NB, RU, 2>;
+        if (m && m[0] == '1') kern = bmu_filter_fast<T, CPL, NB, RU, 1, false>;
+        if (m && m[0] == '2') kern = bmu_filter_fast<T, CPL, NB, RU, 2, false>;
     }
-    static int blocks_per_cu = 0;
-    if (blocks_per_cu == 0) {
+    const size_t lds = stats ? ((size_t)L.k * c + L.k) * sizeof(double) : 0;
+    if (stats) kern = bmu_filter_fast<T, CPL, NB, RU, 0, true>;
+    static int blocks_per_cu[2] = {0, 0};
+    int &bpc = blocks_per_cu[stats ? 1 : 0];
+    if (bpc == 0) {
         int nbk = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, kern, 256, 0) != hipSuccess || nbk < 1) nbk = 2;
-        blocks_per_cu = nbk > 8 ? 8 : nbk;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, kern, 256, lds) != hipSuccess || nbk < 1) nbk = 2;
+        bpc = nbk > 8 ? 8 : nbk;
     }
     const int64_t ngroups = (n + 63) / 64;
-    int grid = (int)std::min<int64_t>((ngroups + 3) / 4, (int64_t)pxsom::device_cu_count() * blocks_per_cu);
+    int grid = (int)std::min<int64_t>((ngroups + 3) / 4, (int64_t)pxsom::device_cu_count() * bpc);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, x, n, c, ldx,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, x, n, c, ldx,
                        reinterpret_cast<const half8 *>(ws + L.off_wfrag),
                        reinterpret_cast<const f32x4 *>(ws + L.off_bias), reinterpret_cast<AssignHdr *>(ws),
-                       reinterpret_cast<unsigned *>(ws + L.off_list), labels);
+                       reinterpret_cast<unsigned *>(ws + L.off_list), labels, L.k, stats);
 }
 
 template <typename T, int NCH, int CPL, int NB, bool VEC2>
@@ -628,25 +682,31 @@ static bool tile_offsets_fit(int64_t ldx)
     return 64 * ldx * (int64_t)sizeof(T) < (int64_t)0x7fffffff;
 }
 
+// register-resident fast path: one channel chunk (C <= 32, even), K = 97..100 (ark's default 10x10 SOM;
+// the last block's 4 nodes sit in one accumulator register -> RU = 1); pair loads need 2-element
+// alignment of every row start and of the base pointer
+template <typename T>
+bool filter_fast_path(const T *x, int64_t n, int c, int64_t ldx, const Layout &L)
+{
+    const bool vec2 = (c % 2 == 0) && (ldx % 2 == 0) && (reinterpret_cast<uintptr_t>(x) % (2 * sizeof(T)) == 0);
+    const int nv_last = L.k - 16 * (L.nb - 1), ru = (nv_last + 3) / 4;
+    return vec2 && L.nch == 1 && n >= 64 && L.nb == 7 && ru == 1 && tile_offsets_fit<T>(ldx);
+}
+
 template <typename T>
 void launch_filter_any(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L,
-                       int32_t *labels, hipStream_t st)
+                       int32_t *labels, double *stats, hipStream_t st)
 {
-    // pair loads need 2-element alignment of every row start and of the base pointer
     const bool vec2 = (c % 2 == 0) && (ldx % 2 == 0) && (reinterpret_cast<uintptr_t>(x) % (2 * sizeof(T)) == 0);
-    // register-resident fast path: one channel chunk (C <= 32, even), K = 97..100 (ark's default 10x10
-    // SOM; the last block's 4 nodes sit in one accumulator register -> RU = 1)
-    const int nv_last = L.k - 16 * (L.nb - 1), ru = (nv_last + 3) / 4;
-    const bool fast_ok = vec2 && L.nch == 1 && n >= 64 && L.nb == 7 && ru == 1 &&
-                         tile_offsets_fit<T>(ldx);
+    const bool fast_ok = filter_fast_path<T>(x, n, c, ldx, L);
     if (fast_ok && L.cpl == 6)       // C = 18..24 (BASELINE.json configs 2/3: C = 22)
-        launch_fast<T, 6, 7, 1>(x, n, c, ldx, ws, L, labels, st);
+        launch_fast<T, 6, 7, 1>(x, n, c, ldx, ws, L, labels, stats, st);
     else if (fast_ok && L.cpl == 8)  // C = 26..32
-        launch_fast<T, 8, 7, 1>(x, n, c, ldx, ws, L, labels, st);
+        launch_fast<T, 8, 7, 1>(x, n, c, ldx, ws, L, labels, stats, st);
     else if (fast_ok && L.cpl == 4)  // C = 10..16
-        launch_fast<T, 4, 7, 1>(x, n, c, ldx, ws, L, labels, st);
+        launch_fast<T, 4, 7, 1>(x, n, c, ldx, ws, L, labels, stats, st);
     else if (fast_ok && L.cpl == 2)  // C <= 8 (config 1)
-        launch_fast<T, 2, 7, 1>(x, n, c, ldx, ws, L, labels, st);
+        launch_fast<T, 2, 7, 1>(x, n, c, ldx, ws, L, labels, stats, st);
     else if (L.nch == 1)
         vec2 ? launch_filter<T, 1, 0, 0, true>(x, n, c, ldx, ws, L, labels, st)
              : launch_filter<T, 1, 0, 0, false>(x, n, c, ldx, ws, L, labels, st);
@@ -662,8 +722,10 @@ void launch_filter_any(const T *x, int64_t n, int c, int64_t ldx, char *ws, cons
 }
 
 template void launch_filter_any<float>(const float *, int64_t, int, int64_t, char *, const Layout &, int32_t *,
-                                       hipStream_t);
+                                       double *, hipStream_t);
 template void launch_filter_any<double>(const double *, int64_t, int, int64_t, char *, const Layout &, int32_t *,
-                                        hipStream_t);
+                                        double *, hipStream_t);
+template bool filter_fast_path<float>(const float *, int64_t, int, int64_t, const Layout &);
+template bool filter_fast_path<double>(const double *, int64_t, int, int64_t, const Layout &);
 
 }  // namespace pxsom_bmu

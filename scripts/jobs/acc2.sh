@@ -1,0 +1,3 @@
+bash scripts/jobs/ubench6.sh | tail -12
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-online | grep -o '"value": [0-9.]*\|"phases_ms".*"frac": [0-9.]*'

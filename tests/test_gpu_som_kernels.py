@@ -201,6 +201,45 @@ def test_train_online_ties_bit_exact(gpu, oracle, c, xdim, ydim):
     np.testing.assert_array_equal(wd.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("n,c,k,dtype,stride", [
+    (16_384, 22, 100, np.float32, 1),    # fused route: filter + exact accumulate (config 2 mini-batch)
+    (16_391, 22, 100, np.float32, 64),   # strided mini-batch view x[t::64], ragged last group
+    (5_003, 22, 100, np.float64, 1),     # fp64 table
+    (4_097, 16, 98, np.float32, 3),      # 4 channels per lane
+    (3_001, 30, 100, np.float64, 1),     # 8 channels per lane
+    (2_000, 6, 100, np.float32, 1),      # 2 channels per lane
+    (2_000, 40, 400, np.float32, 1),     # unfused route (generic filter + cluster sums)
+    (50, 22, 100, np.float32, 1),        # unfused: fewer than 64 rows
+])
+def test_batch_accumulate_matches_oracle(gpu, oracle, n, c, k, dtype, stride):
+    """One mini-batch step's accumulation half: labels bit-exact, counts exact, sums to 1e-12.
+    Rows are duplicated / quantised / NaN-poisoned so that listed rows (exact kernel) take part."""
+    rs = np.random.RandomState(77)
+    big = synth.make_fov_numpy(n * stride, c, seed=31, dtype=dtype)
+    big[::17] = np.round(big[::17] * 2) / 2          # coarse rows: near-ties
+    big[5 * stride] = np.nan                         # one NaN row inside the view
+    w = _codebook(big[::stride], k, seed=5)
+    w[7] = w[3]                                      # duplicate node
+    w[11] = (w[12] + w[13]) / 2
+    xd_big = torch.from_numpy(big).to(gpu)
+    xv = xd_big[::stride]
+    wd = torch.from_numpy(w).to(gpu)
+    labels = torch.empty(n, dtype=torch.int32, device=gpu)
+    stats = torch.full((k * (c + 1),), 123.0, dtype=torch.float64, device=gpu)   # must be cleared
+    ws = sd.AssignWorkspace(n, c, k, gpu)
+    sd.batch_accumulate(xv, wd, labels, stats, ws)
+    xh = np.ascontiguousarray(big[::stride]).astype(np.float64)
+    want_l, _ = oracle.map_data_to_nodes(w, xh)
+    np.testing.assert_array_equal(labels.cpu().numpy(), want_l)
+    ws_, wc_ = oracle.cluster_sums(np.nan_to_num(xh), want_l, k)
+    got = stats.cpu().numpy()
+    np.testing.assert_array_equal(got[k * c:], wc_.astype(np.float64))
+    np.testing.assert_allclose(got[:k * c].reshape(k, c), ws_, rtol=1e-12, atol=1e-12)
+    # a second call on the same buffers gives the same answer (statistics are cleared, not added to)
+    sd.batch_accumulate(xv, wd, labels, stats, ws)
+    np.testing.assert_allclose(stats.cpu().numpy(), got, rtol=1e-12, atol=1e-12)
+
+
 def test_batch_update_matches_oracle(gpu, oracle):
     rs = np.random.RandomState(17)
     for (xdim, ydim, c) in [(10, 10, 22), (20, 20, 40), (3, 2, 4)]:
