@@ -22,6 +22,8 @@ _STATUS = {0: "PXSOM_OK", -1: "PXSOM_ERR_INVALID_ARG", -2: "PXSOM_ERR_UNSUPPORTE
 # every symbol include/pxsom.h declares: (restype, argtypes)
 _vp, _i32, _i64, _f64, _sz = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double,
                               ctypes.c_size_t)
+ABI_VERSION = 2  # include/pxsom.h PXSOM_ABI_VERSION
+
 SYMBOLS = {
     "pxsom_abi_version": (_i32, []),
     "pxsom_last_error": (ctypes.c_char_p, []),
@@ -36,7 +38,8 @@ SYMBOLS = {
     "pxsom_cluster_sums": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _i32, _vp, _vp, _vp]),
     "pxsom_train_online": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _i32, _i32, _i32, _f64, _f64,
                                   _f64, _f64, _vp, _vp]),
-    "pxsom_batch_accumulate": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "pxsom_batch_accumulate": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _sz, _i32, _vp]),
+    "pxsom_batch_update_prepare": (_i32, [_vp, _i32, _i32, _i32, _vp, _f64, _f64, _vp, _sz, _vp]),
     "pxsom_gaussian_blur_hwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "pxsom_rownorm_workspace_bytes": (_sz, [_i64]),
     "pxsom_rowsum_filter_normalize": (_i32, [_vp, _i64, _i32, _f64, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -69,8 +72,8 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the ABI lost a symbol
             fn.restype = res
             fn.argtypes = args
-        if L.pxsom_abi_version() != 1:
-            raise ImportError(f"libpxsom.so ABI {L.pxsom_abi_version()} != 1")
+        if L.pxsom_abi_version() != ABI_VERSION:
+            raise ImportError(f"libpxsom.so ABI {L.pxsom_abi_version()} != {ABI_VERSION}")
         _lib = L
     return _lib
 

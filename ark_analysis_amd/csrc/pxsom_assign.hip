@@ -35,81 +35,86 @@ __device__ long long g_phase_ticks[32];
     do {                                                        \
         if (threadIdx.x == 0 && blockIdx.x == 0) g_phase_ticks[i] = clock64(); \
     } while (0)
+#define PXSOM_PHASE_ANY(i)                                  \
+    do {                                                    \
+        if (threadIdx.x == 0) g_phase_ticks[i] = clock64(); \
+    } while (0)
 #else
 #define PXSOM_PHASE(i) \
     do {               \
     } while (0)
+#define PXSOM_PHASE_ANY(i) \
+    do {                   \
+    } while (0)
 #endif
 
 // ------------------------------------------------------------------------------------------------
-// 1. prep: one workgroup of 256 threads.
+// 1. prep: one workgroup of NT threads.  prep_body works on a codebook that is already in `wl` (LDS when
+//    it fits, else HBM); the callers differ in how it got there.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict__ w, int k, int c,
-                                                       AssignHdr *hdr, half8 *wfrag, f32x4 *bias,
-                                                       int nb, int nch, int cpl, int idx_bits,
-                                                       int node_bits, int stage, double *zero_ptr,
-                                                       int zero_count)
+template <int NT>
+__device__ __forceinline__ void prep_body(const double *wl, int k, int c, AssignHdr *hdr, half8 *wfrag,
+                                          f32x4 *bias, int nb, int nch, int cpl, int idx_bits, int node_bits)
 {
-    PXSOM_PHASE(0);
-    // fused batch accumulation: the statistics buffer is cleared here instead of by a memset node
-    for (int e = threadIdx.x; e < zero_count; e += 256) zero_ptr[e] = 0.0;
     __shared__ double s_norm2[PXSOM_MAX_NODES];
-    __shared__ double s_red[8];
+    __shared__ unsigned long long s_key[PXSOM_MAX_NODES];  // hash of the row's bit patterns (duplicate test)
+    __shared__ double s_red[2 * (NT / 64)];
     __shared__ int s_bad;
-    extern __shared__ __attribute__((aligned(16))) char prep_smem[];
     const int tid = threadIdx.x;
     if (tid == 0) s_bad = 0;
-    // small codebooks are staged in LDS with one coalesced sweep (8 loads in flight per thread); every
-    // later read is an LDS read
-    const double *wl = w;
-    if (stage) {
-        double *sw = reinterpret_cast<double *>(prep_smem);
-        for (int e0 = tid; e0 < k * c; e0 += 8 * 256) {
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = w[e0 + u * 256 < k * c ? e0 + u * 256 : 0];
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-                if (e0 + u * 256 < k * c) sw[e0 + u * 256] = v[u];
-        }
-        wl = sw;
-    }
     __syncthreads();
-    PXSOM_PHASE(1);
 
     // per-node squared norm (binary64), max |w| and max norm.  `parts` adjacent lanes share a node
     // (interleaved channels, butterfly sum: every node is summed in the same order, so bit-identical
     // rows get bit-identical norms -- the duplicate test below relies on it).
-    const int parts = k <= 64 ? 4 : (k <= 128 ? 2 : 1);
+    const int parts = 4 * k <= NT ? 4 : (2 * k <= NT ? 2 : 1);
     const int pshift = parts == 4 ? 2 : (parts == 2 ? 1 : 0);
     double mymax = 0.0, mynorm = 0.0;
     bool bad = false;
-    for (int p = tid; p < (k << pshift); p += 256) {
+    for (int p = tid; p < (k << pshift); p += NT) {
         const int node = p >> pshift, part = p & (parts - 1);
         double sum = 0.0;
+        unsigned long long key = 0;
         for (int j = part; j < c; j += parts) {
             const double v = wl[(size_t)node * c + j];
             bad |= !(fabs(v) <= DBL_MAX);  // NaN / Inf in the codebook
             sum += v * v;
             mymax = fmax(mymax, fabs(v));
+            const unsigned long long hb = (unsigned long long)__double_as_longlong(v) * 0x9E3779B97F4A7C15ull +
+                                          (unsigned long long)(j + 1) * 0xC2B2AE3D27D4EB4Full;
+            key ^= hb ^ (hb >> 29);
         }
-        if (parts >= 2) sum += __shfl_xor(sum, 1);
-        if (parts == 4) sum += __shfl_xor(sum, 2);
-        if (part == 0) s_norm2[node] = sum;
+        if (parts >= 2) {
+            sum += __shfl_xor(sum, 1);
+            key ^= __shfl_xor(key, 1);
+        }
+        if (parts == 4) {
+            sum += __shfl_xor(sum, 2);
+            key ^= __shfl_xor(key, 2);
+        }
+        if (part == 0) {
+            s_norm2[node] = sum;
+            s_key[node] = key;
+        }
         mynorm = fmax(mynorm, sum);
     }
     if (bad) s_bad = 1;
     // both maxima: DPP wave reduction (max(a, b) = -min(-a, -b)), then 4 partials through LDS
     mymax = -pxsom::wave_min_f64(-mymax);
     mynorm = mynorm == mynorm ? -pxsom::wave_min_f64(-mynorm) : mynorm;
+    constexpr int NW = NT / 64;
     if ((tid & 63) == 0) {
         s_red[tid >> 6] = mymax;
-        s_red[4 + (tid >> 6)] = mynorm;
+        s_red[NW + (tid >> 6)] = mynorm;
     }
     __syncthreads();
-    PXSOM_PHASE(2);
-    const double maxabs = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
-    const double wn2max = fmax(fmax(s_red[4], s_red[5]), fmax(s_red[6], s_red[7]));
+    PXSOM_PHASE_ANY(2);
+    double maxabs = s_red[0], wn2max = s_red[NW];
+#pragma unroll
+    for (int i = 1; i < NW; i++) {
+        maxabs = fmax(maxabs, s_red[i]);
+        wn2max = fmax(wn2max, s_red[NW + i]);
+    }
     // scale = 2^e with maxabs*scale in [128, 256): fp16 keeps 11 significant bits there and the
     // low halves of the split stay normal down to |x| ~ 1e-4 * maxabs.
     int e = 0;
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict_
         if (e < -100) e = -100;
     }
     const double scale = ldexp(1.0, e);
-    PXSOM_PHASE(3);
+    PXSOM_PHASE_ANY(3);
     if (tid == 0) {
         const bool badw = s_bad != 0 || !(wn2max * scale * scale <= 1.0e30);
         hdr->amb_count = 0;
@@ -148,8 +153,8 @@ __global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict_
     // A-fragments: wfrag[(b*nsteps + s)*64 + lane], lane = (q<<4 | m): node 16b+m,
     // slot i of lane group q in chunk h <-> channel h*4*cpl + q*cpl + i (i < cpl); s = 2h: hi, 2h+1: lo
     const int nsteps = 2 * nch;
-    PXSOM_PHASE(4);
-    for (int f = tid; f < nb * nch * 64; f += 256) {
+    PXSOM_PHASE_ANY(4);
+    for (int f = tid; f < nb * nch * 64; f += NT) {
         const int lane = f & 63, h = (f >> 6) % nch, b = (f >> 6) / nch;
         const int m = lane & 15, q = lane >> 4;
         const int node = node_of_row(b, m, nb);
@@ -172,71 +177,80 @@ __global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict_
     // update and are bit-identical, which would otherwise send every row they win to the exact path.
     // (s_dup reuses s_red's storage class: one flag per node.)
     __shared__ unsigned char s_dup[PXSOM_MAX_NODES];
-    PXSOM_PHASE(5);
-    for (int node = tid; node < k; node += 256) s_dup[node] = 0;
+    PXSOM_PHASE_ANY(5);
+    for (int node = tid; node < k; node += NT) s_dup[node] = 0;
     __syncthreads();
+    // rows compared 4 channels per trip (the 8 reads of a trip pipeline), leaving at the first trip that
+    // differs.  Near-duplicates are the common case in early batch-training steps: gain = 1 makes every
+    // node with the same window the same mean up to the last bit, and their norms often round equal.
     auto same_rows = [&](int prev, int node) {
-        if (s_norm2[prev] != s_norm2[node]) return false;
-        for (int j = 0; j < c; j++)
-            if (wl[(size_t)prev * c + j] != wl[(size_t)node * c + j]) return false;
+        if (s_key[prev] != s_key[node]) return false;
+        const double *a = wl + (size_t)prev * c, *b = wl + (size_t)node * c;
+        int j = 0;
+        for (; j + 3 < c; j += 4) {
+            const bool eq = (a[j] == b[j]) & (a[j + 1] == b[j + 1]) & (a[j + 2] == b[j + 2]) & (a[j + 3] == b[j + 3]);
+            if (!eq) return false;
+        }
+        for (; j < c; j++)
+            if (a[j] != b[j]) return false;
         return true;
     };
     if (k <= 256) {
-        // all pairs on the norms (equal rows have equal norms), the range of earlier nodes split over
-        // 256/k threads per node; full channel comparison only on a norm match
+        // all pairs on the row keys (equal rows have equal keys; norms are useless here: near-duplicates
+        // often round to the same norm), the range of earlier nodes split over NT/k threads per node;
+        // full channel comparison only on a key match
         __shared__ int s_first[256];
-        for (int node = tid; node < k; node += 256) s_first[node] = 0x7fffffff;
+        for (int node = tid; node < k; node += NT) s_first[node] = 0x7fffffff;
         __syncthreads();
         int sp = 1;
-        while (sp * 2 * k <= 256) sp *= 2;
+        while (sp * 2 * k <= NT) sp *= 2;
         const int len = (k + sp - 1) / sp;
-        for (int p = tid; p < k * sp; p += 256) {
+        for (int p = tid; p < k * sp; p += NT) {
             const int node = p / sp, part = p - node * sp;
             const int lo = part * len, hi = min(node, lo + len);
-            const double n2 = s_norm2[node];
+            const unsigned long long n2 = s_key[node];
             int hit = 0x7fffffff;
 #pragma unroll 8
-            for (int prev = lo; prev < hi; prev++) hit = min(hit, s_norm2[prev] == n2 ? prev : 0x7fffffff);
+            for (int prev = lo; prev < hi; prev++) hit = min(hit, s_key[prev] == n2 ? prev : 0x7fffffff);
             if (hit != 0x7fffffff) atomicMin(&s_first[node], hit);
         }
         __syncthreads();
-        for (int node = tid; node < k; node += 256) {
+        for (int node = tid; node < k; node += NT) {
             const int first = s_first[node];
             if (first >= node) continue;
             bool dup = same_rows(first, node);
-            for (int prev = first + 1; prev < node && !dup; prev++) dup = same_rows(prev, node);  // norm collision
+#ifdef PXSOM_PHASE_TIMING
+            atomicAdd((unsigned long long *)&g_phase_ticks[24], 1ull);
+            if (!dup) atomicAdd((unsigned long long *)&g_phase_ticks[25], 1ull);
+#endif
+            for (int prev = first + 1; prev < node && !dup; prev++) dup = same_rows(prev, node);  // key collision
             if (dup) s_dup[node] = 1;
         }
     } else
-    // hash table keyed by the norm's bit pattern (equal rows have equal norms): slot <- smallest node
-    // index hashing there; a node is a duplicate iff an earlier node with identical channels exists.
+    // hash table keyed by the row key: slot <- smallest node index hashing there; a node is a duplicate
+    // iff an earlier node with identical channels exists.
     {
         __shared__ int s_tab[1024];
-        for (int i = tid; i < 1024; i += 256) s_tab[i] = 0x7fffffff;
+        for (int i = tid; i < 1024; i += NT) s_tab[i] = 0x7fffffff;
         __syncthreads();
         auto slot_of = [&](int node) {
-            const unsigned long long b = (unsigned long long)__double_as_longlong(s_norm2[node]);
+            const unsigned long long b = s_key[node];
             return (int)((b ^ (b >> 17) ^ (b >> 41)) & 1023ull);
         };
-        for (int node = tid; node < k; node += 256) atomicMin(&s_tab[slot_of(node)], node);
+        for (int node = tid; node < k; node += NT) atomicMin(&s_tab[slot_of(node)], node);
         __syncthreads();
-        for (int node = tid; node < k; node += 256) {
+        for (int node = tid; node < k; node += NT) {
             const int first = s_tab[slot_of(node)];
             if (first >= node) continue;
-            auto same_as = [&](int prev) {
-                if (s_norm2[prev] != s_norm2[node]) return false;
-                for (int j = 0; j < c; j++)
-                    if (wl[(size_t)prev * c + j] != wl[(size_t)node * c + j]) return false;
-                return true;
-            };
+            auto same_as = [&](int prev) { return same_rows(prev, node); };
             bool dup = same_as(first);
             if (!dup) {  // slot shared with a different earlier node: scan the norms (no early exit, so
                          // the LDS reads pipeline), full comparison only on a norm match
-                const double n2 = s_norm2[node];
+                const unsigned long long n2 = s_key[node];
                 int hit = -1;
 #pragma unroll 8
                 for (int prev = 0; prev < node; prev++)
-                    if (s_norm2[prev] == n2 && prev != first && hit < 0) hit = prev;
+                    if (s_key[prev] == n2 && prev != first && hit < 0) hit = prev;
                 if (hit >= 0) {
                     for (int prev = hit; prev < node && !dup; prev++) dup = same_as(prev);
                 }
@@ -245,9 +259,9 @@ __global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict_
         }
     }
     __syncthreads();
-    PXSOM_PHASE(6);
+    PXSOM_PHASE_ANY(6);
     // bias[b*64 + lane][r] for accumulator row (lane>>4)*4 + r <-> node_of_row(b, 4q + r)
-    for (int f = tid; f < nb * 64; f += 256) {
+    for (int f = tid; f < nb * 64; f += NT) {
         const int lane = f & 63, b = f >> 6, q = lane >> 4;
         f32x4 bv;
         for (int r = 0; r < 4; r++) {
@@ -256,8 +270,40 @@ __global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict_
         }
         bias[f] = bv;
     }
-    PXSOM_PHASE(7);
+    PXSOM_PHASE_ANY(7);
 }
+
+__global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict__ w, int k, int c,
+                                                       AssignHdr *hdr, half8 *wfrag, f32x4 *bias,
+                                                       int nb, int nch, int cpl, int idx_bits,
+                                                       int node_bits, int stage, double *zero_ptr,
+                                                       int zero_count)
+{
+    PXSOM_PHASE_ANY(0);
+    // fused batch accumulation: the statistics buffer is cleared here instead of by a memset node
+    for (int e = threadIdx.x; e < zero_count; e += 256) zero_ptr[e] = 0.0;
+    extern __shared__ __attribute__((aligned(16))) char prep_smem[];
+    const int tid = threadIdx.x;
+    // small codebooks are staged in LDS with one coalesced sweep (8 loads in flight per thread); every
+    // later read is an LDS read
+    const double *wl = w;
+    if (stage) {
+        double *sw = reinterpret_cast<double *>(prep_smem);
+        for (int e0 = tid; e0 < k * c; e0 += 8 * 256) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = w[e0 + u * 256 < k * c ? e0 + u * 256 : 0];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (e0 + u * 256 < k * c) sw[e0 + u * 256] = v[u];
+        }
+        wl = sw;
+    }
+    __syncthreads();
+    PXSOM_PHASE_ANY(1);
+    prep_body<256>(wl, k, c, hdr, wfrag, bias, nb, nch, cpl, idx_bits, node_bits);
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // 3. exact path: one wave per listed row; lane <-> nodes lane, lane+64, ...
@@ -456,15 +502,18 @@ __global__ __launch_bounds__(256) void bmu_dist_kernel(const T *__restrict__ x, 
 
 template <typename T>
 int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int k, int32_t *labels,
-                 double *dist, char *ws, const Layout &L, hipStream_t st, double *stats = nullptr)
+                 double *dist, char *ws, const Layout &L, hipStream_t st, double *stats = nullptr,
+                 bool prepared = false)
 {
-    const size_t stage_bytes = (size_t)k * c * sizeof(double);
-    const int stage = stage_bytes <= 40 * 1024;
-    hipLaunchKernelGGL(bmu_prep_kernel, dim3(1), dim3(256), stage ? stage_bytes : 0, st, w, k, c,
-                       reinterpret_cast<AssignHdr *>(ws),
-                       reinterpret_cast<half8 *>(ws + L.off_wfrag), reinterpret_cast<f32x4 *>(ws + L.off_bias),
-                       L.nb, L.nch, L.cpl, L.idx_bits, L.node_bits, stage, stats, stats ? k * (c + 1) : 0);
-    PXSOM_LAUNCH_CHECK("bmu_prep_kernel");
+    if (!prepared) {  // prepared: pxsom_batch_update_prepare already did this for w (and cleared stats)
+        const size_t stage_bytes = (size_t)k * c * sizeof(double);
+        const int stage = stage_bytes <= 40 * 1024;
+        hipLaunchKernelGGL(bmu_prep_kernel, dim3(1), dim3(256), stage ? stage_bytes : 0, st, w, k, c,
+                           reinterpret_cast<AssignHdr *>(ws),
+                           reinterpret_cast<half8 *>(ws + L.off_wfrag), reinterpret_cast<f32x4 *>(ws + L.off_bias),
+                           L.nb, L.nch, L.cpl, L.idx_bits, L.node_bits, stage, stats, stats ? k * (c + 1) : 0);
+        PXSOM_LAUNCH_CHECK("bmu_prep_kernel");
+    }
 
     const int cus = pxsom::device_cu_count();
     pxsom::Prof *prof = pxsom::current_prof();
@@ -534,7 +583,7 @@ PXSOM_EXPORT int pxsom_assign(const void *x_dev, int64_t n, int c, int64_t ldx, 
 
 int pxsom_bmu::assign_accumulate(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev,
                                  int k, int32_t *labels_dev, double *stats_dev, void *workspace_dev,
-                                 size_t workspace_bytes, hipStream_t st, bool *fused)
+                                 size_t workspace_bytes, hipStream_t st, bool prepared, bool *fused)
 {
     *fused = false;
     if (n < 64 || n > 0x7fffffffLL || c < 1 || c > PXSOM_MAX_CHANNELS || k < 1 || k > PXSOM_MAX_NODES || ldx < c ||
@@ -547,14 +596,48 @@ int pxsom_bmu::assign_accumulate(const void *x_dev, int64_t n, int c, int64_t ld
         const float *x = reinterpret_cast<const float *>(x_dev);
         if (!filter_fast_path<float>(x, n, c, ldx, L)) return PXSOM_OK;
         *fused = true;
-        return assign_typed<float>(x, n, c, ldx, w_dev, k, labels_dev, nullptr, ws, L, st, stats_dev);
+        return assign_typed<float>(x, n, c, ldx, w_dev, k, labels_dev, nullptr, ws, L, st, stats_dev, prepared);
     }
     if (dtype == PXSOM_F64) {
         const double *x = reinterpret_cast<const double *>(x_dev);
         if (!filter_fast_path<double>(x, n, c, ldx, L)) return PXSOM_OK;
         *fused = true;
-        return assign_typed<double>(x, n, c, ldx, w_dev, k, labels_dev, nullptr, ws, L, st, stats_dev);
+        return assign_typed<double>(x, n, c, ldx, w_dev, k, labels_dev, nullptr, ws, L, st, stats_dev, prepared);
     }
+    return PXSOM_OK;
+}
+
+// pxsom_assign on a workspace that pxsom_batch_update_prepare prepared for w_dev (no prep launch)
+int pxsom_bmu::assign_prepared(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev,
+                               int k, int32_t *labels_dev, void *workspace_dev, size_t workspace_bytes,
+                               hipStream_t st)
+{
+    const Layout L = make_layout(n, c, k);
+    if (!workspace_dev || workspace_bytes < L.total)
+        return pxsom::fail(PXSOM_ERR_WORKSPACE, "pxsom_batch_accumulate: workspace %zu < %zu bytes", workspace_bytes,
+                           L.total);
+    char *ws = reinterpret_cast<char *>(workspace_dev);
+    if (dtype == PXSOM_F32)
+        return assign_typed<float>(reinterpret_cast<const float *>(x_dev), n, c, ldx, w_dev, k, labels_dev, nullptr,
+                                   ws, L, st, nullptr, true);
+    return assign_typed<double>(reinterpret_cast<const double *>(x_dev), n, c, ldx, w_dev, k, labels_dev, nullptr, ws,
+                                L, st, nullptr, true);
+}
+
+// prep alone, optionally clearing the batch statistics (pxsom_batch_update_prepare)
+int pxsom_bmu::prepare_only(const double *w_dev, int c, int k, void *workspace_dev, size_t workspace_bytes,
+                            double *zero_stats, hipStream_t st)
+{
+    const Layout L = make_layout(0, c, k);
+    if (workspace_bytes < L.total) return pxsom::fail(PXSOM_ERR_WORKSPACE, "prepare: workspace too small");
+    char *ws = reinterpret_cast<char *>(workspace_dev);
+    const size_t stage_bytes = (size_t)k * c * sizeof(double);
+    const int stage = stage_bytes <= 40 * 1024;
+    hipLaunchKernelGGL(bmu_prep_kernel, dim3(1), dim3(256), stage ? stage_bytes : 0, st, w_dev, k, c,
+                       reinterpret_cast<AssignHdr *>(ws), reinterpret_cast<half8 *>(ws + L.off_wfrag),
+                       reinterpret_cast<f32x4 *>(ws + L.off_bias), L.nb, L.nch, L.cpl, L.idx_bits, L.node_bits, stage,
+                       zero_stats, zero_stats ? k * (c + 1) : 0);
+    PXSOM_LAUNCH_CHECK("bmu_prep_kernel");
     return PXSOM_OK;
 }
 

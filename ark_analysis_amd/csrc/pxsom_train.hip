@@ -524,39 +524,58 @@ __global__ __launch_bounds__(256) void som_online_split_kernel(const T *__restri
 // batch update: one workgroup per node k, thread <-> channel.  Only the Chebyshev window of k is
 // visited, in ascending node order b (the oracle's summation order: skipping the nodes it skips).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void batch_update_kernel(double *w, int xdim, int ydim, int c,
+__global__ __launch_bounds__(256) void batch_update_kernel(double *w, int xdim, int ydim, int c,
                                                            const double *__restrict__ sums,
                                                            const double *__restrict__ counts,
-                                                           double thr, double alpha)
+                                                           double thr, double alpha, int stage)
 {
-    const int k = blockIdx.x, j = threadIdx.x;
-    if (j >= c) return;
+    extern __shared__ __attribute__((aligned(16))) char upd_smem[];
+    const int k = blockIdx.x, tid = threadIdx.x;
     const int kx = k / ydim, ky = k % ydim;
     // nodes b with max(|dx|, |dy|) <= thr  <=>  |dx|, |dy| <= floor(thr)   (integer distances)
-    int r = thr < 0.0 ? -1 : (thr > 1.0e6 ? 1000000 : (int)floor(thr));
+    const int r = thr < 0.0 ? -1 : (thr > 1.0e6 ? 1000000 : (int)floor(thr));
     const int x0 = kx - r < 0 ? 0 : kx - r, x1 = kx + r > xdim - 1 ? xdim - 1 : kx + r;
     const int y0 = ky - r < 0 ? 0 : ky - r, y1 = ky + r > ydim - 1 ? ydim - 1 : ky + r;
+    // The window rows x0..x1 are contiguous in node order: stage their statistics in LDS with every
+    // thread of the workgroup loading (8 in flight each) -- a loop of dependent L2 round trips per window
+    // node costs 5-10 us at radius 6 -- then sum from LDS in the oracle's order.
+    const int b_lo = x0 * ydim, b_hi = (x1 + 1) * ydim;  // node range [b_lo, b_hi)
+    const double *ls = sums, *lc = counts;
+    int boff = 0;
+    if (stage) {
+        double *ss = reinterpret_cast<double *>(upd_smem);  // [(b_hi - b_lo) * c] sums, then counts
+        const int ne = (b_hi - b_lo) * c, nc = b_hi - b_lo;
+        const double *gs = sums + (size_t)b_lo * c, *gc = counts + b_lo;
+        for (int e0 = tid; e0 < ne + nc; e0 += 8 * 256) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int e = e0 + u * 256;
+                v[u] = e < ne ? gs[e] : (e < ne + nc ? gc[e - ne] : 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (e0 + u * 256 < ne + nc) ss[e0 + u * 256] = v[u];
+        }
+        __syncthreads();
+        ls = ss;
+        lc = ss + ne;
+        boff = b_lo;
+    }
+    const int j = tid;
+    if (j >= c) return;
+    const double wv = w[(size_t)k * c + j];
     double num = 0.0, den = 0.0;
     for (int bx = x0; bx <= x1; bx++) {
-        // the loads of a window row are independent: issue them 4 at a time, accumulate in node order
-        int by = y0;
-        for (; by + 3 <= y1; by += 4) {
-            const int b = bx * ydim + by;
-            const double c0 = counts[b], c1 = counts[b + 1], c2 = counts[b + 2], c3 = counts[b + 3];
-            const double s0 = sums[(size_t)b * c + j], s1 = sums[(size_t)(b + 1) * c + j],
-                         s2 = sums[(size_t)(b + 2) * c + j], s3 = sums[(size_t)(b + 3) * c + j];
-            den += c0; den += c1; den += c2; den += c3;
-            num += s0; num += s1; num += s2; num += s3;
-        }
-        for (; by <= y1; by++) {
-            const int b = bx * ydim + by;
-            den += counts[b];
-            num += sums[(size_t)b * c + j];
+#pragma unroll 4
+        for (int by = y0; by <= y1; by++) {
+            const int b = bx * ydim + by - boff;
+            den += lc[b];
+            num += ls[(size_t)b * c + j];
         }
     }
     if (den > 0.0) {
         const double gain = 1.0 - pow(1.0 - alpha, den);
-        const double wv = w[(size_t)k * c + j];
         w[(size_t)k * c + j] = wv + gain * (num / den - wv);
     }
 }
@@ -805,8 +824,11 @@ PXSOM_EXPORT int pxsom_batch_update(double *w_dev, int xdim, int ydim, int c, co
     if (!w_dev || !sums_dev || !counts_dev) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_batch_update: null pointer");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int K = xdim * ydim;
-    hipLaunchKernelGGL(batch_update_kernel, dim3(K), dim3(128), 0, st, w_dev, xdim, ydim, c, sums_dev, counts_dev,
-                       thr, alpha);
+    // statistics of the widest window (the whole grid) staged in LDS when they fit
+    const size_t stage_bytes = (size_t)K * (c + 1) * sizeof(double);
+    const int stage = stage_bytes <= 60 * 1024;
+    hipLaunchKernelGGL(batch_update_kernel, dim3(K), dim3(256), stage ? stage_bytes : 0, st, w_dev, xdim, ydim, c,
+                       sums_dev, counts_dev, thr, alpha, stage);
     PXSOM_LAUNCH_CHECK("batch_update_kernel");
     return PXSOM_OK;
 }
@@ -814,24 +836,32 @@ PXSOM_EXPORT int pxsom_batch_update(double *w_dev, int xdim, int ydim, int c, co
 // One mini-batch step's accumulation half: zero the statistics, BMU of every row, per-BMU sums.
 // stats_dev = [k*c sums | k counts], all binary64 (counts are exact integers below 2^53), so the
 // multi-GPU all-reduce is a single sum over one buffer.
+// flags & PXSOM_ACC_PREPARED: pxsom_batch_update_prepare already prepared the workspace for w_dev and
+// cleared stats_dev (no prep launch, no memset).
 PXSOM_EXPORT int pxsom_batch_accumulate(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype,
                                         const double *w_dev, int k, int32_t *labels_dev, double *stats_dev,
-                                        void *workspace_dev, size_t workspace_bytes, void *stream)
+                                        void *workspace_dev, size_t workspace_bytes, int flags, void *stream)
 {
     if (!stats_dev || k < 1 || k > PXSOM_MAX_NODES || c < 1 || c > PXSOM_MAX_CHANNELS)
         return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_batch_accumulate: bad statistics buffer / shape");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bool prepared = (flags & PXSOM_ACC_PREPARED) != 0;
     // fused route (register-resident filter shapes): prep clears the statistics, the filter adds the rows
-    // it is sure of, the exact kernel the rest -- 3 launches, one pass over x
+    // it is sure of, the exact kernel the rest -- 3 launches (2 when prepared), one pass over x
     bool fused = false;
     int rc = pxsom_bmu::assign_accumulate(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, stats_dev, workspace_dev,
-                                          workspace_bytes, st, &fused);
+                                          workspace_bytes, st, prepared, &fused);
     if (fused) return rc;
-    PXSOM_HIP_TRY(hipMemsetAsync(stats_dev, 0, (size_t)k * (c + 1) * sizeof(double), st));
+    if (!prepared) PXSOM_HIP_TRY(hipMemsetAsync(stats_dev, 0, (size_t)k * (c + 1) * sizeof(double), st));
     if (n == 0) return PXSOM_OK;
     rc = check_matrix("pxsom_batch_accumulate", x_dev, n, c, ldx, dtype);
     if (rc) return rc;
-    rc = pxsom_assign(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, nullptr, workspace_dev, workspace_bytes, stream);
+    if (prepared) {
+        if (!w_dev || !labels_dev) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_batch_accumulate: null pointer");
+        rc = pxsom_bmu::assign_prepared(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, workspace_dev, workspace_bytes, st);
+    } else {
+        rc = pxsom_assign(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, nullptr, workspace_dev, workspace_bytes, stream);
+    }
     if (rc) return rc;
     double *sums = stats_dev;
     int64_t *counts = reinterpret_cast<int64_t *>(stats_dev + (size_t)k * c);
@@ -840,4 +870,26 @@ PXSOM_EXPORT int pxsom_batch_accumulate(const void *x_dev, int64_t n, int c, int
                                                counts, st);
     return cluster_sums_typed<double, true>(reinterpret_cast<const double *>(x_dev), n, c, ldx, labels_dev, k, sums,
                                             counts, st);
+}
+
+// The update half of a mini-batch step plus everything the NEXT pxsom_batch_accumulate needs before its
+// filter kernel: codebook update from the (all-reduced) statistics, then one prep launch that also clears
+// the statistics.  (A single-workgroup fusion of the two was measured slower: its window sums are LDS-
+// bandwidth bound on one CU, 9-14 us at radius 6; so was a last-workgroup-runs-prep variant.)
+PXSOM_EXPORT int pxsom_batch_update_prepare(double *w_dev, int xdim, int ydim, int c, double *stats_dev,
+                                            double thr, double alpha, void *workspace_dev,
+                                            size_t workspace_bytes, void *stream)
+{
+    if (xdim < 1 || ydim < 1 || (int64_t)xdim * ydim > PXSOM_MAX_NODES || c < 1 || c > PXSOM_MAX_CHANNELS)
+        return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "pxsom_batch_update_prepare: shape %dx%d x %d", xdim, ydim, c);
+    if (!w_dev || !stats_dev || !workspace_dev)
+        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_batch_update_prepare: null pointer");
+    const int k = xdim * ydim;
+    if (workspace_bytes < pxsom_assign_workspace_bytes(0, c, k))
+        return pxsom::fail(PXSOM_ERR_WORKSPACE, "pxsom_batch_update_prepare: workspace %zu bytes too small",
+                           workspace_bytes);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int rc = pxsom_batch_update(w_dev, xdim, ydim, c, stats_dev, stats_dev + (size_t)k * c, thr, alpha, stream);
+    if (rc) return rc;
+    return pxsom_bmu::prepare_only(w_dev, c, k, workspace_dev, workspace_bytes, stats_dev, st);
 }

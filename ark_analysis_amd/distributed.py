@@ -12,7 +12,8 @@ rows i with i % batch_steps == g % batch_steps:
     labels = BMU(rows, W)                       (exact rule, pxsom_assign)
     S[b] += x_i, n[b] += 1                      (pxsom_cluster_sums)      -> all-reduce(S, n)
     thr = r0 - (r0-r1) g/G (0.5 once < 1);  alpha = a0 - (a0-a1) g/G
-    W_k += (1 - (1-alpha)^den_k) (num_k/den_k - W_k)                      (pxsom_batch_update)
+    W_k += (1 - (1-alpha)^den_k) (num_k/den_k - W_k)                      (pxsom_batch_update_prepare:
+                                                  also clears S, n and prepares the next step's BMU search)
 Oracle of record: oracle/pxsom_oracle.c (orc_som_batch).
 """
 from typing import Optional, Sequence, Tuple
@@ -41,16 +42,32 @@ class HipKernels:
         from . import som_device
         self._sd = som_device
         self._ws = None
+        self._prepared_for = None
 
-    def accumulate(self, x: torch.Tensor, w: torch.Tensor, labels: torch.Tensor, stats: torch.Tensor) -> None:
-        """zero(stats); labels = BMU(x, w); stats[label] += [x, 1]  (stats = [K*C sums | K counts] f64)."""
+    def accumulate(self, x: torch.Tensor, w: torch.Tensor, labels: torch.Tensor, stats: torch.Tensor,
+                   chained: bool = False) -> None:
+        """zero(stats); labels = BMU(x, w); stats[label] += [x, 1]  (stats = [K*C sums | K counts] f64).
+        ``chained``: the caller guarantees that neither ``w`` nor ``stats`` changed since this object's
+        last ``update_prepare`` (then its prep + memset are skipped)."""
         n, c = x.shape
         if self._ws is None or not self._ws.fits(n, c, w.shape[0]):
             self._ws = self._sd.AssignWorkspace(n, c, w.shape[0], x.device)
-        self._sd.batch_accumulate(x, w, labels, stats, self._ws)
+            self._prepared_for = None
+        # the previous step's update_prepare left the workspace prepared for exactly this codebook
+        prepared = chained and self._prepared_for == (w.data_ptr(), stats.data_ptr())
+        self._prepared_for = None
+        self._sd.batch_accumulate(x, w, labels, stats, self._ws, prepared=prepared)
 
     def batch_update(self, w, xdim, ydim, sums, counts, thr, alpha):
         return self._sd.batch_update(w, xdim, ydim, sums, counts, thr, alpha)
+
+    def update_prepare(self, w, xdim, ydim, stats, thr, alpha) -> None:
+        """Codebook update + statistics cleared + workspace prepared for the next accumulate (one launch)."""
+        if self._ws is None:
+            self._sd.batch_update(w, xdim, ydim, stats[: w.numel()].view_as(w), stats[w.numel():], thr, alpha)
+            return
+        self._sd.batch_update_prepare(w, xdim, ydim, stats, thr, alpha, self._ws)
+        self._prepared_for = (w.data_ptr(), stats.data_ptr())
 
 
 def _world(group) -> int:
@@ -80,24 +97,33 @@ class BatchSOMTrainer:
         self.counts = self.stats[self.k * self.c:]
         self.label_buf = None
 
-    def step(self, x_local: torch.Tensor, w: torch.Tensor, g: int, total_steps: int) -> None:
-        """One mini-batch step g on this rank's shard; collective when world_size > 1."""
+    def step(self, x_local: torch.Tensor, w: torch.Tensor, g: int, total_steps: int,
+             chained: bool = False) -> None:
+        """One mini-batch step g on this rank's shard; collective when world_size > 1.
+        ``chained``: this call directly follows step g-1 of the same ``train`` (nothing touched ``w``
+        in between), so the BMU search may reuse what the previous update prepared."""
         m = self.batch_steps
         view = x_local[(g % m)::m]
         nrows = view.shape[0]
         if self.label_buf is None or self.label_buf.numel() < nrows:
             self.label_buf = torch.empty(max(nrows, 1), dtype=torch.int32, device=x_local.device)
-        self.kernels.accumulate(view, w, self.label_buf, self.stats)
+        if chained and hasattr(self.kernels, "update_prepare"):
+            self.kernels.accumulate(view, w, self.label_buf, self.stats, chained=True)
+        else:
+            self.kernels.accumulate(view, w, self.label_buf, self.stats)
         if _world(self.group) > 1:
             dist.all_reduce(self.stats, op=dist.ReduceOp.SUM, group=self.group)
         thr, alpha = batch_schedule(g, total_steps, self.alpha_range, self.radius_range)
-        self.kernels.batch_update(w, self.xdim, self.ydim, self.sums, self.counts, thr, alpha)
+        if hasattr(self.kernels, "update_prepare"):
+            self.kernels.update_prepare(w, self.xdim, self.ydim, self.stats, thr, alpha)
+        else:
+            self.kernels.batch_update(w, self.xdim, self.ydim, self.sums, self.counts, thr, alpha)
 
     def train(self, x_local: torch.Tensor, w: torch.Tensor, num_passes: int = 1) -> torch.Tensor:
         """Runs num_passes passes in place on ``w`` [K, C] f64 (identical on every rank)."""
         total = int(num_passes) * self.batch_steps
         for g in range(total):
-            self.step(x_local, w, g, total)
+            self.step(x_local, w, g, total, chained=g > 0)
         return w
 
 

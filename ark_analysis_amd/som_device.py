@@ -91,9 +91,13 @@ def cluster_sums(x: torch.Tensor, labels: torch.Tensor, k: int,
     return sums, counts
 
 
+ACC_PREPARED = 1  # include/pxsom.h PXSOM_ACC_PREPARED
+
+
 def batch_accumulate(x: torch.Tensor, w: torch.Tensor, labels: torch.Tensor, stats: torch.Tensor,
-                     workspace: AssignWorkspace) -> None:
-    """Zero ``stats`` ([K*C sums | K counts], float64), label every row of ``x`` and accumulate."""
+                     workspace: AssignWorkspace, prepared: bool = False) -> None:
+    """Zero ``stats`` ([K*C sums | K counts], float64), label every row of ``x`` and accumulate.
+    ``prepared``: ``batch_update_prepare`` already prepared ``workspace`` for ``w`` and cleared ``stats``."""
     n, c, ldx, dt = _matrix_args(x)
     w = _codebook(w)
     k = w.shape[0]
@@ -106,8 +110,25 @@ def batch_accumulate(x: torch.Tensor, w: torch.Tensor, labels: torch.Tensor, sta
     rc = _capi.lib().pxsom_batch_accumulate(x.data_ptr(), n, c, ldx, dt, w.data_ptr(), k,
                                             labels.data_ptr(), stats.data_ptr(),
                                             workspace.buf.data_ptr(), workspace.bytes,
-                                            _capi.stream_ptr())
+                                            ACC_PREPARED if prepared else 0, _capi.stream_ptr())
     _capi.check(rc, "pxsom_batch_accumulate")
+
+
+def batch_update_prepare(w: torch.Tensor, xdim: int, ydim: int, stats: torch.Tensor, thr: float,
+                         alpha: float, workspace: AssignWorkspace) -> None:
+    """Batch-rule codebook update from ``stats`` ([K*C sums | K counts], all-reduced), in place on ``w``;
+    then ``stats`` is cleared and ``workspace`` prepared for the new codebook (next accumulate:
+    ``prepared=True``)."""
+    w = _codebook(w)
+    k, c = w.shape
+    if k != xdim * ydim:
+        raise ValueError(f"codebook has {k} nodes, grid is {xdim}x{ydim}")
+    if stats.dtype != torch.float64 or stats.numel() != k * (c + 1) or not stats.is_contiguous():
+        raise ValueError("stats must be a contiguous float64 vector of K*(C+1) entries")
+    rc = _capi.lib().pxsom_batch_update_prepare(w.data_ptr(), int(xdim), int(ydim), c, stats.data_ptr(),
+                                                float(thr), float(alpha), workspace.buf.data_ptr(),
+                                                workspace.bytes, _capi.stream_ptr())
+    _capi.check(rc, "pxsom_batch_update_prepare")
 
 
 def train_online(x: torch.Tensor, w: torch.Tensor, xdim: int, ydim: int, rlen: int,

@@ -1,0 +1,30 @@
+import sys, os
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from ark_analysis_amd import som_device as sd, synth
+from tests import oracle_binding as ob
+gpu = torch.device("cuda:0")
+for (n, c, k, dtype, stride) in [(2250, 16, 100, np.float64, 4), (2250, 16, 100, np.float64, 1), (2250, 22, 100, np.float64, 4),
+                                 (2250, 16, 100, np.float32, 4), (9000, 16, 100, np.float64, 4), (2250, 16, 100, np.float64, 2)]:
+    big = synth.make_fov_numpy(n * stride, c, seed=41, dtype=dtype)
+    rs = np.random.RandomState(8)
+    w = np.ascontiguousarray(big[rs.choice(n * stride, k, replace=False)].astype(np.float64))
+    xd = torch.from_numpy(big).to(gpu)
+    for off in range(min(stride, 2)):
+        xv = xd[off::stride]
+        xh = np.ascontiguousarray(big[off::stride]).astype(np.float64)
+        nn = xv.shape[0]
+        wd = torch.from_numpy(w).to(gpu)
+        want_l, _ = ob.map_data_to_nodes(w, xh)
+        ws_, wc_ = ob.cluster_sums(xh, want_l, k)
+        lab_a, _ = sd.assign(xv, wd)
+        labels = torch.empty(nn, dtype=torch.int32, device=gpu)
+        stats = torch.empty(k * (c + 1), dtype=torch.float64, device=gpu)
+        ws = sd.AssignWorkspace(nn, c, k, gpu)
+        sd.batch_accumulate(xv, wd, labels, stats, ws)
+        got = stats.cpu().numpy()
+        print(n, c, dtype.__name__, "stride", stride, "off", off,
+              "assign bad", int((lab_a.cpu().numpy() != want_l).sum()),
+              "acc labels bad", int((labels.cpu().numpy() != want_l).sum()),
+              "count diff", float(np.abs(got[k * c:] - wc_).sum()),
+              "sum maxdiff %.3e" % np.abs(got[:k * c].reshape(k, c) - ws_).max(), flush=True)

@@ -256,6 +256,54 @@ def test_batch_update_matches_oracle(gpu, oracle):
             np.testing.assert_allclose(wd.cpu().numpy(), want, rtol=1e-12, atol=0)
 
 
+@pytest.mark.parametrize("xdim,ydim,c,dtype", [(10, 10, 22, np.float32), (10, 10, 16, np.float64),
+                                               (7, 9, 12, np.float32), (20, 20, 40, np.float32)])
+def test_batch_update_prepare_matches_oracle_and_chains(gpu, oracle, xdim, ydim, c, dtype):
+    """update_prepare == oracle batch update; statistics cleared; an accumulate on the prepared
+    workspace equals an unprepared one (labels bit-exact, statistics to 1e-12)."""
+    from ark_analysis_amd.distributed import BatchSOMTrainer
+    k, n = xdim * ydim, 9_000
+    rs = np.random.RandomState(5)
+    x = synth.make_fov_numpy(n, c, seed=41, dtype=dtype)
+    w = _codebook(x, k, seed=8)
+    sums = rs.uniform(size=(k, c)) * 40
+    counts = rs.randint(0, 90, size=k).astype(np.float64)
+    counts[::9] = 0
+    xd = torch.from_numpy(x).to(gpu)
+    ws = sd.AssignWorkspace(n, c, k, gpu)
+    for thr, alpha in [(6.0, 0.05), (1.4, 0.02), (0.5, 0.01)]:
+        want_w = oracle.batch_update(w, xdim, ydim, sums, counts.astype(np.int64), thr, alpha)
+        wd = torch.from_numpy(w.copy()).to(gpu)
+        stats = torch.from_numpy(np.concatenate([sums.reshape(-1), counts])).to(gpu)
+        sd.batch_update_prepare(wd, xdim, ydim, stats, thr, alpha, ws)
+        np.testing.assert_allclose(wd.cpu().numpy(), want_w, rtol=1e-12, atol=0)
+        assert float(stats.abs().max()) == 0.0
+        labels = torch.empty(n, dtype=torch.int32, device=gpu)
+        sd.batch_accumulate(xd, wd, labels, stats, ws, prepared=True)
+        labels2 = torch.empty(n, dtype=torch.int32, device=gpu)
+        stats2 = torch.empty_like(stats)
+        sd.batch_accumulate(xd, wd, labels2, stats2, sd.AssignWorkspace(n, c, k, gpu))
+        assert torch.equal(labels, labels2)
+        want_l, _ = oracle.map_data_to_nodes(wd.cpu().numpy(), x.astype(np.float64))
+        np.testing.assert_array_equal(labels.cpu().numpy(), want_l)
+        np.testing.assert_allclose(stats.cpu().numpy(), stats2.cpu().numpy(), rtol=1e-12, atol=1e-12)
+    if dtype != np.float32:
+        # binary64 rows: the per-cluster sums are atomics in arbitrary order (1e-16 relative noise), which
+        # the degenerate early steps of a 4-step pass amplify (BMU flips between near-identical nodes);
+        # fp32 rows sum exactly in binary64, so only they give a reproducible whole-pass comparison
+        return
+    # a trainer reused after its codebook was reset must not reuse stale prepared state
+    tr = BatchSOMTrainer(xdim, ydim, c, gpu, batch_steps=4)
+    w0 = torch.from_numpy(w.copy()).to(gpu)
+    wa = tr.train(xd, w0.clone(), num_passes=1).clone()
+    wb = w0.clone()
+    tr.train(xd, wb, num_passes=1)
+    np.testing.assert_allclose(wb.cpu().numpy(), wa.cpu().numpy(), rtol=1e-12, atol=0)
+    want_b = oracle.som_batch(x.astype(np.float64), w, xdim, ydim, 1, (0.05, 0.01),
+                              default_radius_range(xdim, ydim), 4)
+    np.testing.assert_allclose(wa.cpu().numpy(), want_b, rtol=1e-9, atol=0)
+
+
 def test_assign_full_size_sampled_against_oracle(gpu, oracle):
     """BASELINE config 2 size on one GPU (10 x 1024^2 x 22 fp32, K=100): rows are independent, so
     the oracle on a random sample of rows must agree exactly; plus idempotence and range."""
