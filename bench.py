@@ -5,8 +5,10 @@
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 One "step" = one pass of the hot path over one batch of synthetic input, resident in HBM before
-the clock starts:  batch-mode SOM training (1 pass over the 10 % training subset, `--batch-steps`
-mini-batch steps, statistics all-reduced over RCCL when N > 1)  +  BMU assignment of every pixel.
+the clock starts ("normalised pixel matrix resident" -> "labels + codebook + mean table
+resident"):  batch-mode SOM training (1 pass over the 10 % training subset, `--batch-steps` mini-batch
+steps, statistics all-reduced over RCCL when N > 1)  +  BMU assignment of every pixel  +  the per-cluster
+mean-expression table over all pixels (sums/counts all-reduced once when N > 1).
 Workload at N = 1: BASELINE.json configs[1] (10 FOVs 1024x1024x22 fp32, 10x10 SOM); weak scaling:
 every rank holds its own `--fovs-per-gpu` FOVs.  Rank 0 prints ONE JSON line.
 
@@ -32,7 +34,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from ark_analysis_amd import _capi, som_device, synth  # noqa: E402
-from ark_analysis_amd.distributed import BatchSOMTrainer, broadcast_codebook  # noqa: E402
+from ark_analysis_amd.distributed import (BatchSOMTrainer, allreduce_cluster_tables,  # noqa: E402
+                                          broadcast_codebook)
 from ark_analysis_amd.flowsom import default_radius_range  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -88,11 +91,24 @@ def main():
     labels = torch.empty(n_all, dtype=torch.int32, device=dev)
     ws_all = som_device.AssignWorkspace(n_all, C, K, dev)
     trainer = BatchSOMTrainer(XDIM, YDIM, C, dev, batch_steps=args.batch_steps)
+    k8_sums = torch.empty((K, C), dtype=torch.float64, device=dev)
+    k8_counts = torch.empty(K, dtype=torch.int64, device=dev)
+    means = torch.empty((K, C), dtype=torch.float64, device=dev)
+
+    def mean_table():
+        """K8: per-cluster channel means over every pixel of every rank."""
+        k8_sums.zero_()
+        k8_counts.zero_()
+        som_device.cluster_sums(x_all, labels, K, sums=k8_sums, counts=k8_counts)
+        if use_dist:
+            allreduce_cluster_tables(k8_sums, k8_counts)
+        torch.div(k8_sums, k8_counts.clamp(min=1).to(torch.float64).unsqueeze(1), out=means)
 
     def step():
         w.copy_(w0)
         trainer.train(x_train, w, num_passes=1)
         som_device.assign(x_all, w, labels=labels, workspace=ws_all)
+        mean_table()
 
     def fence():
         torch.cuda.synchronize()
@@ -106,6 +122,8 @@ def main():
     timer = _capi.KernelTimer(min_rows=n_all)
     ev_train = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 for _ in range(args.steps)]
+    ev_k8 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+             for _ in range(args.steps)]
     with timer:
         t0 = time.perf_counter()
         for i in range(args.steps):
@@ -114,6 +132,9 @@ def main():
             trainer.train(x_train, w, num_passes=1)
             ev_train[i][1].record()
             som_device.assign(x_all, w, labels=labels, workspace=ws_all)
+            ev_k8[i][0].record()
+            mean_table()
+            ev_k8[i][1].record()
         fence()
         t1 = time.perf_counter()
         kern_ms, kern_launches = timer.collect()
@@ -122,6 +143,7 @@ def main():
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed_s = float(elapsed.item())
     train_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_train]))
+    k8_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_k8]))
     exact_rows = som_device.last_exact_rows(ws_all)
 
     if rank != 0:
@@ -151,10 +173,12 @@ def main():
                                f"(BASELINE.json configs[1] at N=1)",
                    "fovs_per_gpu": F, "pixels_per_gpu": n_all, "channels": C, "som_nodes": K,
                    "train_mode": "batch", "batch_steps": args.batch_steps, "train_fraction": 0.1,
-                   "num_passes": 1, "parallelism": f"fov-shard x{world}"},
+                   "num_passes": 1, "step": "train + assign + per-cluster mean table",
+                   "parallelism": f"fov-shard x{world}"},
         "phases_ms": {"train_batch": round(train_ms, 4),
                       "assign_filter_kernel": round(kern_avg_ms, 4),
-                      "assign_exact_rows": exact_rows},
+                      "assign_exact_rows": exact_rows,
+                      "mean_table": round(k8_ms, 4)},
         "roofline": {"kernel": "bmu_filter_kernel", "bound": "hbm", "achieved": round(achieved, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": traffic, "bytes_per_pixel": BYTES_PER_PIXEL_ASSIGN,
@@ -179,7 +203,10 @@ def main():
             tt = time.perf_counter()
             lab_cpu, _ = ob.map_data_to_nodes(oracle_w, xs, column_major_copy=True)
             t_assign = time.perf_counter() - tt
-            cpu_s = t_train + t_assign * (n_all / n_s)
+            tt = time.perf_counter()
+            ob.cluster_sums(xs, lab_cpu, K)
+            t_means = time.perf_counter() - tt
+            cpu_s = t_train + (t_assign + t_means) * (n_all / n_s)
             # free full-size check: GPU labels for the same codebook on the same sample
             wd = torch.from_numpy(oracle_w).to(dev)
             lab_gpu, _ = som_device.assign(x_all[:n_s], wd)
@@ -188,8 +215,8 @@ def main():
                 "value": round(n_all / cpu_s / 1e6, 4), "unit": "Mpx/s", "cores": 1,
                 "host_cores": os.cpu_count(), "kind": "port",
                 "sample": f"oracle online FlowSOM training on the full {n_train}-row training subset "
-                          f"({t_train:.2f} s) + reference-shaped BMU search on {n_s} of {n_all} pixels "
-                          f"({t_assign:.2f} s, scaled linearly); fp64, 1 thread",
+                          f"({t_train:.2f} s) + reference-shaped BMU search ({t_assign:.2f} s) and per-cluster "
+                          f"sums ({t_means:.2f} s) on {n_s} of {n_all} pixels, scaled linearly; fp64, 1 thread",
                 "gpu_labels_equal_on_sample": labels_equal}
         if not args.no_online:
             if order is None:
