@@ -13,6 +13,7 @@ from . import _build
 
 PXSOM_F32 = 0
 PXSOM_F64 = 1
+PXSOM_F16 = 2
 MAX_CHANNELS = 128
 MAX_NODES = 1024
 
@@ -102,7 +103,9 @@ def dtype_code(t: torch.Tensor) -> int:
         return PXSOM_F32
     if t.dtype == torch.float64:
         return PXSOM_F64
-    raise TypeError(f"pixel matrix must be float32 or float64, got {t.dtype}")
+    if t.dtype == torch.float16:
+        return PXSOM_F16
+    raise TypeError(f"pixel matrix must be float16, float32 or float64, got {t.dtype}")
 
 
 def glibc_rand(seed: int, count: int):

@@ -560,8 +560,7 @@ PXSOM_EXPORT int pxsom_assign(const void *x_dev, int64_t n, int c, int64_t ldx, 
     if (k < 1 || k > PXSOM_MAX_NODES)
         return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "pxsom_assign: k=%d outside [1, %d]", k, PXSOM_MAX_NODES);
     if (ldx < c) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_assign: ldx=%lld < c=%d", (long long)ldx, c);
-    if (dtype != PXSOM_F32 && dtype != PXSOM_F64)
-        return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "pxsom_assign: dtype %d", dtype);
+    if (!pxsom::dtype_ok(dtype)) return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "pxsom_assign: dtype %d", dtype);
     if (!w_dev || (n > 0 && (!x_dev || !labels_dev)))
         return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_assign: null pointer");
     const Layout L = make_layout(n, c, k);
@@ -574,11 +573,7 @@ PXSOM_EXPORT int pxsom_assign(const void *x_dev, int64_t n, int c, int64_t ldx, 
         PXSOM_HIP_TRY(hipMemsetAsync(ws, 0, kHdrBytes, st));
         return PXSOM_OK;
     }
-    if (dtype == PXSOM_F32)
-        return assign_typed<float>(reinterpret_cast<const float *>(x_dev), n, c, ldx, w_dev, k, labels_dev,
-                                   dist_dev, ws, L, st);
-    return assign_typed<double>(reinterpret_cast<const double *>(x_dev), n, c, ldx, w_dev, k, labels_dev,
-                                dist_dev, ws, L, st);
+    PXSOM_DISPATCH_DTYPE(dtype, x_dev, xp, assign_typed<T>(xp, n, c, ldx, w_dev, k, labels_dev, dist_dev, ws, L, st));
 }
 
 int pxsom_bmu::assign_accumulate(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev,
@@ -592,19 +587,12 @@ int pxsom_bmu::assign_accumulate(const void *x_dev, int64_t n, int c, int64_t ld
     const Layout L = make_layout(n, c, k);
     if (workspace_bytes < L.total) return PXSOM_OK;
     char *ws = reinterpret_cast<char *>(workspace_dev);
-    if (dtype == PXSOM_F32) {
-        const float *x = reinterpret_cast<const float *>(x_dev);
-        if (!filter_fast_path<float>(x, n, c, ldx, L)) return PXSOM_OK;
-        *fused = true;
-        return assign_typed<float>(x, n, c, ldx, w_dev, k, labels_dev, nullptr, ws, L, st, stats_dev, prepared);
-    }
-    if (dtype == PXSOM_F64) {
-        const double *x = reinterpret_cast<const double *>(x_dev);
-        if (!filter_fast_path<double>(x, n, c, ldx, L)) return PXSOM_OK;
-        *fused = true;
-        return assign_typed<double>(x, n, c, ldx, w_dev, k, labels_dev, nullptr, ws, L, st, stats_dev, prepared);
-    }
-    return PXSOM_OK;
+    if (!pxsom::dtype_ok(dtype)) return PXSOM_OK;
+    PXSOM_DISPATCH_DTYPE(dtype, x_dev, xp,
+                         (filter_fast_path<T>(xp, n, c, ldx, L)
+                              ? (*fused = true, assign_typed<T>(xp, n, c, ldx, w_dev, k, labels_dev, nullptr, ws, L, st,
+                                                                stats_dev, prepared))
+                              : PXSOM_OK));
 }
 
 // pxsom_assign on a workspace that pxsom_batch_update_prepare prepared for w_dev (no prep launch)
@@ -617,11 +605,8 @@ int pxsom_bmu::assign_prepared(const void *x_dev, int64_t n, int c, int64_t ldx,
         return pxsom::fail(PXSOM_ERR_WORKSPACE, "pxsom_batch_accumulate: workspace %zu < %zu bytes", workspace_bytes,
                            L.total);
     char *ws = reinterpret_cast<char *>(workspace_dev);
-    if (dtype == PXSOM_F32)
-        return assign_typed<float>(reinterpret_cast<const float *>(x_dev), n, c, ldx, w_dev, k, labels_dev, nullptr,
-                                   ws, L, st, nullptr, true);
-    return assign_typed<double>(reinterpret_cast<const double *>(x_dev), n, c, ldx, w_dev, k, labels_dev, nullptr, ws,
-                                L, st, nullptr, true);
+    PXSOM_DISPATCH_DTYPE(dtype, x_dev, xp,
+                         assign_typed<T>(xp, n, c, ldx, w_dev, k, labels_dev, nullptr, ws, L, st, nullptr, true));
 }
 
 // prep alone, optionally clearing the batch statistics (pxsom_batch_update_prepare)

@@ -34,6 +34,13 @@ template <>
 struct Pair<double> {
     typedef double2 type;
 };
+struct half_pair {
+    _Float16 x, y;
+};
+template <>
+struct Pair<_Float16> {
+    typedef half_pair type;
+};
 
 __device__ __forceinline__ float pack_idx(float v, unsigned idx, unsigned mask)
 {
@@ -406,7 +413,12 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
             const int soff = (int)(t * tile_bytes);
 #pragma unroll
             for (int p = 0; p < NP; p++) {
-                if constexpr (sizeof(T) == 4) {
+                if constexpr (sizeof(T) == 2) {
+                    const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)loff[p], soff, 0);
+                    const half2_t h = __builtin_bit_cast(half2_t, v);
+                    raw[t][p].x = h[0];
+                    raw[t][p].y = h[1];
+                } else if constexpr (sizeof(T) == 4) {
                     const uint2v v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)loff[p], soff, 0);
                     raw[t][p].x = __uint_as_float(v[0]);
                     raw[t][p].y = __uint_as_float(v[1]);
@@ -725,6 +737,9 @@ template void launch_filter_any<float>(const float *, int64_t, int, int64_t, cha
                                        double *, hipStream_t);
 template void launch_filter_any<double>(const double *, int64_t, int, int64_t, char *, const Layout &, int32_t *,
                                         double *, hipStream_t);
+template void launch_filter_any<_Float16>(const _Float16 *, int64_t, int, int64_t, char *, const Layout &, int32_t *,
+                                          double *, hipStream_t);
+template bool filter_fast_path<_Float16>(const _Float16 *, int64_t, int, int64_t, const Layout &);
 template bool filter_fast_path<float>(const float *, int64_t, int, int64_t, const Layout &);
 template bool filter_fast_path<double>(const double *, int64_t, int, int64_t, const Layout &);
 

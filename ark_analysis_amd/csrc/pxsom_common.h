@@ -36,6 +36,26 @@ inline int hip_fail(hipError_t e, const char *what)
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+inline bool dtype_ok(int dtype) { return dtype == PXSOM_F32 || dtype == PXSOM_F64 || dtype == PXSOM_F16; }
+
+// `return CALL<T>(static_cast<const T *>(ptr), ...)` for the pixel-matrix dtype (validated by the caller)
+#define PXSOM_DISPATCH_DTYPE(dtype, ptr, XP, CALL)                      \
+    do {                                                                \
+        if ((dtype) == PXSOM_F32) {                                     \
+            typedef float T;                                            \
+            const T *XP = reinterpret_cast<const T *>(ptr);             \
+            return CALL;                                                \
+        }                                                               \
+        if ((dtype) == PXSOM_F16) {                                     \
+            typedef _Float16 T;                                         \
+            const T *XP = reinterpret_cast<const T *>(ptr);             \
+            return CALL;                                                \
+        }                                                               \
+        typedef double T;                                               \
+        const T *XP = reinterpret_cast<const T *>(ptr);                 \
+        return CALL;                                                    \
+    } while (0)
+
 // number of CUs of the current device (256 on MI355X); cached per process
 int device_cu_count();
 

@@ -833,7 +833,7 @@ int check_matrix(const char *fn, const void *x, int64_t n, int c, int64_t ldx, i
     if (c < 1 || c > PXSOM_MAX_CHANNELS)
         return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "%s: c=%d outside [1, %d]", fn, c, PXSOM_MAX_CHANNELS);
     if (ldx < c) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "%s: ldx=%lld < c=%d", fn, (long long)ldx, c);
-    if (dtype != PXSOM_F32 && dtype != PXSOM_F64) return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "%s: dtype %d", fn, dtype);
+    if (!pxsom::dtype_ok(dtype)) return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "%s: dtype %d", fn, dtype);
     if (n > 0 && !x) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "%s: null matrix", fn);
     return PXSOM_OK;
 }
@@ -853,11 +853,8 @@ PXSOM_EXPORT int pxsom_train_online(const void *x_dev, int64_t n, int c, int64_t
     if (n == 0 || rlen == 0) return PXSOM_OK;
     if (!order_dev) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_train_online: null order");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == PXSOM_F32)
-        return train_online_typed<float>(reinterpret_cast<const float *>(x_dev), n, c, ldx, w_dev, xdim, ydim, rlen,
-                                         a0, a1, r0, r1, order_dev, st);
-    return train_online_typed<double>(reinterpret_cast<const double *>(x_dev), n, c, ldx, w_dev, xdim, ydim, rlen,
-                                      a0, a1, r0, r1, order_dev, st);
+    PXSOM_DISPATCH_DTYPE(dtype, x_dev, xp,
+                         train_online_typed<T>(xp, n, c, ldx, w_dev, xdim, ydim, rlen, a0, a1, r0, r1, order_dev, st));
 }
 
 PXSOM_EXPORT int pxsom_cluster_sums(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype,
@@ -872,11 +869,7 @@ PXSOM_EXPORT int pxsom_cluster_sums(const void *x_dev, int64_t n, int c, int64_t
         return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_cluster_sums: null pointer");
     if (n == 0) return PXSOM_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == PXSOM_F32)
-        return cluster_sums_typed<float>(reinterpret_cast<const float *>(x_dev), n, c, ldx, labels_dev, k, sums_dev,
-                                         counts_dev, st);
-    return cluster_sums_typed<double>(reinterpret_cast<const double *>(x_dev), n, c, ldx, labels_dev, k, sums_dev,
-                                      counts_dev, st);
+    PXSOM_DISPATCH_DTYPE(dtype, x_dev, xp, cluster_sums_typed<T>(xp, n, c, ldx, labels_dev, k, sums_dev, counts_dev, st));
 }
 
 PXSOM_EXPORT int pxsom_batch_update(double *w_dev, int xdim, int ydim, int c, const double *sums_dev,
@@ -928,11 +921,7 @@ PXSOM_EXPORT int pxsom_batch_accumulate(const void *x_dev, int64_t n, int c, int
     if (rc) return rc;
     double *sums = stats_dev;
     int64_t *counts = reinterpret_cast<int64_t *>(stats_dev + (size_t)k * c);
-    if (dtype == PXSOM_F32)
-        return cluster_sums_typed<float, true>(reinterpret_cast<const float *>(x_dev), n, c, ldx, labels_dev, k, sums,
-                                               counts, st);
-    return cluster_sums_typed<double, true>(reinterpret_cast<const double *>(x_dev), n, c, ldx, labels_dev, k, sums,
-                                            counts, st);
+    PXSOM_DISPATCH_DTYPE(dtype, x_dev, xp, (cluster_sums_typed<T, true>(xp, n, c, ldx, labels_dev, k, sums, counts, st)));
 }
 
 // The update half of a mini-batch step plus everything the NEXT pxsom_batch_accumulate needs before its

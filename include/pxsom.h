@@ -45,7 +45,9 @@ typedef enum pxsom_status {
 
 typedef enum pxsom_dtype {
     PXSOM_F32 = 0, /* IEEE binary32 pixel matrix (BASELINE.json configs 2-4) */
-    PXSOM_F64 = 1  /* IEEE binary64 pixel matrix (what the reference's feather tables hold) */
+    PXSOM_F64 = 1, /* IEEE binary64 pixel matrix (what the reference's feather tables hold) */
+    PXSOM_F16 = 2  /* IEEE binary16 pixel matrix (BASELINE.json config 5); every value is used as the exact
+                      real number it encodes -- results equal those for the same values held in binary64 */
 } pxsom_dtype;
 
 /* Limits of the gfx950 kernels in this build. */

@@ -6,11 +6,13 @@ from ark_analysis_amd import _capi, som_device, synth
 from ark_analysis_amd.distributed import BatchSOMTrainer
 
 dev = torch.device("cuda:0")
-for name, n, c, xd, yd in [("cfg4 cell SOM 1e6 x 100, K=100", 1_000_000, 100, 10, 10),
-                           ("cfg5 shape 4x1024^2 x 40, K=400", 4 * 1024 * 1024, 40, 20, 20),
-                           ("cfg1 shape 512^2 x 8, K=100", 512 * 512, 8, 10, 10)]:
+for name, n, c, xd, yd, dt in [("cfg4 cell SOM 1e6 x 100, K=100", 1_000_000, 100, 10, 10, torch.float32),
+                               ("cfg5 shape 2048^2 x 40 fp32, K=400", 4 * 1024 * 1024, 40, 20, 20, torch.float32),
+                               ("cfg5 2048^2 x 40 fp16, K=400", 4 * 1024 * 1024, 40, 20, 20, torch.float16),
+                               ("cfg1 shape 512^2 x 8, K=100", 512 * 512, 8, 10, 10, torch.float32)]:
     k = xd * yd
-    x = synth.make_fov_torch(n, c, seed=3, device=dev)
+    x = synth.make_fov_torch(n, c, seed=3, device=dev).to(dt)
+    esz = x.element_size()
     w = x[torch.randperm(n, device=dev)[:k]].double().contiguous()
     BatchSOMTrainer(xd, yd, c, dev, batch_steps=16).train(x[::10].contiguous(), w, 1)
     ws = som_device.AssignWorkspace(n, c, k, dev)
@@ -27,5 +29,5 @@ for name, n, c, xd, yd in [("cfg4 cell SOM 1e6 x 100, K=100", 1_000_000, 100, 10
         wall = (time.perf_counter() - t0) / 5
         ms, cnt = t.collect()
     print(json.dumps({"shape": name, "filter_ms": round(ms / cnt, 3), "assign_wall_ms": round(wall * 1e3, 3),
-                      "Mpx_per_s": round(n / wall / 1e6, 1), "GBps_algorithmic": round((c * 4 + 4) * n / (ms / cnt) / 1e6, 1),
+                      "Mpx_per_s": round(n / wall / 1e6, 1), "GBps_algorithmic": round((c * esz + 4) * n / (ms / cnt) / 1e6, 1),
                       "exact_rows": som_device.last_exact_rows(ws)}))

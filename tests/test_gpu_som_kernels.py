@@ -45,6 +45,9 @@ def _gpu_assign(gpu, x, w, want_dists=False):
     (64, 3, 4, np.float32),
     (1, 22, 100, np.float32),
     (5, 22, 1, np.float32),
+    (30_000, 40, 400, np.float16),    # config 5: fp16 pixel matrix, 20x20 SOM
+    (20_001, 22, 100, np.float16),    # fp16 rows on the register-resident path
+    (2_000, 7, 30, np.float16),       # fp16, odd channel count
 ])
 def test_assign_matches_oracle(gpu, oracle, n, c, k, dtype):
     x = synth.make_fov_numpy(max(n, 2 * k), c, seed=11, dtype=dtype)[:n]
@@ -144,7 +147,8 @@ def test_assign_strided_rows_and_dists(gpu, oracle):
 
 def test_cluster_sums_matches_oracle(gpu, oracle):
     for (n, c, k, dtype) in [(100_000, 22, 100, np.float32), (30_000, 40, 400, np.float64),
-                             (999, 5, 7, np.float32)]:
+                             (999, 5, 7, np.float32), (50_001, 22, 100, np.float32),
+                             (20_000, 40, 400, np.float16)]:
         x = synth.make_fov_numpy(n, c, seed=14, dtype=dtype)
         labels = np.random.RandomState(1).randint(0, k + 1, size=n).astype(np.int32)  # 0 = skipped
         s, cnt = sd.cluster_sums(torch.from_numpy(x).to(gpu), torch.from_numpy(labels).to(gpu), k)
@@ -167,6 +171,7 @@ def test_cluster_sums_matches_oracle(gpu, oracle):
     (1_500, 37, 10, 12, 1, np.float32),   # 2 lanes per node, 20 channels per lane
     (1_000, 45, 10, 10, 1, np.float32),   # thread <-> node form (c > 40)
     (1_000, 70, 12, 12, 1, np.float64),   # thread <-> node form, codebook in LDS
+    (2_000, 22, 10, 10, 1, np.float16),   # fp16 rows
 ])
 def test_train_online_bit_exact(gpu, oracle, n, c, xdim, ydim, rlen, dtype):
     k = xdim * ydim
@@ -209,6 +214,8 @@ def test_train_online_ties_bit_exact(gpu, oracle, c, xdim, ydim):
     (3_001, 30, 100, np.float64, 1),     # 8 channels per lane
     (2_000, 6, 100, np.float32, 1),      # 2 channels per lane
     (2_000, 40, 400, np.float32, 1),     # unfused route (generic filter + cluster sums)
+    (4_000, 40, 400, np.float16, 1),     # config 5 dtype, unfused route
+    (6_001, 22, 100, np.float16, 2),     # fp16 rows on the fused route
     (50, 22, 100, np.float32, 1),        # unfused: fewer than 64 rows
 ])
 def test_batch_accumulate_matches_oracle(gpu, oracle, n, c, k, dtype, stride):
