@@ -1,0 +1,202 @@
+"""Per-FOV feather tables on disk -- the wire format between the Pixie stages -- and the machinery the
+pipeline functions share for walking them.
+
+Reference contract (read for behaviour, not structure): one ``<fov>.feather`` (Arrow IPC, written
+uncompressed) per field of view inside ``<base_dir>/<data_dir>``; a stage that rewrites the tables
+writes into ``<data_dir>_temp`` and swaps the directories when every FOV is done, so an interrupted
+run restarts from the FOVs that are still missing in ``_temp``
+(/root/reference/src/ark/phenotyping/pixel_som_clustering.py:114-134, :288-289;
+pixel_cluster_utils.py:419-478).
+
+What is different here, on purpose (SURVEY.md section 8 f, rank 1): with the BMU search at HBM speed the
+stage is I/O bound, so
+
+* the *next* tables are read by a background thread while the current one is on the GPU
+  (:class:`TablePrefetcher`), and finished tables are written by another thread (:class:`TableWriter`);
+* "which FOVs still lack column X" looks at the Arrow schema in the file footer instead of loading a
+  whole table (:meth:`FovTableDir.column_names`).
+"""
+import os
+import queue
+import shutil
+import threading
+from typing import Iterable, Iterator, List, Optional, Sequence, Tuple
+
+import pandas as pd
+import pyarrow as pa
+from pyarrow.lib import ArrowInvalid
+
+from .host_utils import natsorted
+
+#: what a damaged table raises when opened (the reference catches exactly these)
+UNREADABLE = (ArrowInvalid, OSError, IOError)
+
+SUFFIX = ".feather"
+#: bookkeeping columns that are never SOM features
+POSITION_COLUMNS = ("fov", "row_index", "column_index")
+OPTIONAL_COLUMNS = ("label", "pixel_som_cluster", "pixel_meta_cluster", "pixel_meta_cluster_rename")
+
+
+def read_dataframe(path) -> pd.DataFrame:
+    """What ``feather.read_dataframe`` does: a Feather V2 file *is* an Arrow IPC file."""
+    with pa.OSFile(str(path), "rb") as src:
+        return pa.ipc.open_file(src).read_all().to_pandas()
+
+
+def write_dataframe(df: pd.DataFrame, path, compression="uncompressed") -> None:
+    """What ``feather.write_dataframe(df, path, compression=...)`` does (64 Ki-row record batches)."""
+    body = pa.Table.from_pandas(df, preserve_index=None)
+    options = pa.ipc.IpcWriteOptions(compression=None if compression in (None, "uncompressed") else compression)
+    with pa.OSFile(str(path), "wb") as sink, pa.ipc.new_file(sink, body.schema, options=options) as out:
+        out.write_table(body, max_chunksize=1 << 16)
+
+
+def unify_label_column(table: pd.DataFrame) -> pd.DataFrame:
+    """Tables written by newer pipeline versions call the segmentation id ``segmentation_label``."""
+    if "segmentation_label" in table.columns:
+        table.rename(columns={"segmentation_label": "label"}, inplace=True)
+    return table
+
+
+def feature_columns(table: pd.DataFrame) -> pd.Index:
+    """Columns left once position, label and cluster columns are removed (order preserved)."""
+    skip = set(POSITION_COLUMNS) | set(OPTIONAL_COLUMNS)
+    return table.columns[[c not in skip for c in table.columns]]
+
+
+class FovTableDir:
+    """A directory of ``<fov>.feather`` tables plus its ``_temp`` staging twin."""
+
+    def __init__(self, root):
+        self.root = str(root)
+        self.staging = self.root + "_temp"
+
+    # ---- naming -----------------------------------------------------------------------------
+    @staticmethod
+    def _tables_in(folder) -> List[str]:
+        found = [name for name in os.listdir(folder)
+                 if SUFFIX in name and not name.startswith(".")
+                 and not os.path.isdir(os.path.join(folder, name))]
+        return natsorted(found)
+
+    def files(self) -> List[str]:
+        return self._tables_in(self.root)
+
+    def fovs(self) -> List[str]:
+        return [os.path.splitext(name)[0] for name in self.files()]
+
+    def path(self, fov: str, staged: bool = False) -> str:
+        return os.path.join(self.staging if staged else self.root, fov + SUFFIX)
+
+    # ---- reading ----------------------------------------------------------------------------
+    def load(self, fov: str) -> pd.DataFrame:
+        return read_dataframe(self.path(fov))
+
+    def column_names(self, fov: str) -> List[str]:
+        """Column names from the Arrow footer only (no data pages are touched)."""
+        with pa.OSFile(self.path(fov), "rb") as src:
+            return list(pa.ipc.open_file(src).schema.names)
+
+    def first_readable(self) -> Optional[pd.DataFrame]:
+        """The first table that opens; damaged files are passed over.  ``None`` if none opens."""
+        for name in self.files():
+            try:
+                return read_dataframe(os.path.join(self.root, name))
+            except UNREADABLE:
+                continue
+        return None
+
+    # ---- restartable rewrite ----------------------------------------------------------------
+    def pending(self, column: str) -> List[str]:
+        """FOVs a stage that adds ``column`` still has to process.
+
+        No staging directory yet: every FOV if the first readable table lacks ``column`` (the staging
+        directory is created as a side effect, like the reference's helper does), nobody otherwise.
+        Staging directory present (an earlier run was interrupted): the FOVs not yet staged."""
+        if os.path.exists(self.staging):
+            done = set(self._tables_in(self.staging))
+            return [os.path.splitext(name)[0] for name in set(self.files()) - done]
+        probe = self.first_readable()
+        if column in probe.columns.values:
+            return []
+        os.mkdir(self.staging)
+        return self.fovs()
+
+    def open_staging(self) -> None:
+        os.mkdir(self.staging)
+
+    def commit(self, on_rm_error=None) -> None:
+        """Replace the directory by its staging twin."""
+        shutil.rmtree(self.root, onerror=on_rm_error)
+        shutil.move(self.staging, self.root)
+
+
+class TablePrefetcher:
+    """Iterates ``(fov, table-or-None)`` over ``fovs``, reading up to ``depth`` tables ahead on a
+    background thread.  ``None`` stands for a table that could not be opened."""
+
+    _END = object()
+
+    def __init__(self, tables: FovTableDir, fovs: Sequence[str], depth: int = 2):
+        self._tables = tables
+        self._fovs = list(fovs)
+        self._slots: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
+        self._worker = threading.Thread(target=self._fill, name="fov-prefetch", daemon=True)
+        self._worker.start()
+
+    def _fill(self) -> None:
+        for fov in self._fovs:
+            try:
+                item = (fov, self._tables.load(fov))
+            except UNREADABLE:
+                item = (fov, None)
+            except BaseException as err:  # surfaced in the consumer thread
+                self._slots.put((fov, err))
+                break
+            self._slots.put(item)
+        self._slots.put(self._END)
+
+    def __iter__(self) -> Iterator[Tuple[str, Optional[pd.DataFrame]]]:
+        while True:
+            item = self._slots.get()
+            if item is self._END:
+                return
+            if isinstance(item[1], BaseException):
+                raise item[1]
+            yield item
+
+
+class TableWriter:
+    """Writes tables on a background thread (one at a time, in submission order); ``close()`` waits
+    and re-raises the first failure."""
+
+    def __init__(self, depth: int = 2):
+        self._jobs: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
+        self._error: Optional[BaseException] = None
+        self._worker = threading.Thread(target=self._drain, name="fov-write", daemon=True)
+        self._worker.start()
+
+    def _drain(self) -> None:
+        while True:
+            job = self._jobs.get()
+            if job is None:
+                return
+            if self._error is None:
+                try:
+                    write_dataframe(job[0], job[1], compression="uncompressed")
+                except BaseException as err:
+                    self._error = err
+
+    def submit(self, table: pd.DataFrame, path: str) -> None:
+        self._jobs.put((table, path))
+
+    def close(self) -> None:
+        self._jobs.put(None)
+        self._worker.join()
+        if self._error is not None:
+            raise self._error
+
+
+def batches(items: Sequence, size: int) -> Iterable[Sequence]:
+    for start in range(0, len(items), size):
+        yield items[start:start + size]

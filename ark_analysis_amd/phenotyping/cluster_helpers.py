@@ -1,227 +1,193 @@
-"""SOM cluster objects -- drop-in for ``ark.phenotyping.cluster_helpers``
-(/root/reference/src/ark/phenotyping/cluster_helpers.py:52-416).
+"""SOM cluster objects -- the classes ``ark.phenotyping.cluster_helpers`` exposes for the Pixie SOM steps
+(/root/reference/src/ark/phenotyping/cluster_helpers.py:52-416), re-implemented over the gfx950 kernels.
 
-Same classes, constructor signatures, attributes, warning strings and on-disk formats as the
-reference; ``pyFlowSOM.som`` / ``pyFlowSOM.map_data_to_nodes`` are replaced by the gfx950
-implementations in :mod:`ark_analysis_amd.flowsom`.  Objects hold only host state (pandas /
-numpy), so they pickle like the reference's; device buffers are created per call.
+Public surface kept so notebooks and the reference's tests run unchanged: class names, constructor
+arguments and defaults, the attributes callers read (``weights``, ``weights_path``, ``columns``,
+``norm_data``, ``train_data``, ``cell_data``, ``fovs``, ``som_clusters_seen``), the warning texts and the
+on-disk weights format (feather, one row per node, row k <-> label k + 1).  ``pyFlowSOM.som`` /
+``pyFlowSOM.map_data_to_nodes`` are :func:`ark_analysis_amd.flowsom.som` /
+:func:`~ark_analysis_amd.flowsom.map_data_to_nodes`.
 
-Differences, all deliberate and documented in DESIGN.md:
-* feather I/O goes through ``pyarrow.feather`` (the ``feather-format`` package is that re-export).
-* training tables are concatenated in natural-sorted FOV order (the reference takes
-  ``os.listdir`` order, cluster_helpers.py:211-215).
-* assignment batches are sliced positionally (the reference's label slice ``.loc[i:i+B-1]``,
-  :154-156, selects the same rows for the RangeIndex every reader produces).
+Objects hold host state only (pandas / numpy) and therefore pickle; device buffers live for one call.
+
+Deliberate differences:
+* training tables are concatenated in natural-sorted FOV order -- the reference takes ``os.listdir``
+  order (:211-215), which is file-system dependent, and the presentation order is an input of the SOM;
+* rows are handed to the BMU search in positional blocks (the reference slices by index label,
+  :154-156, which selects the same rows for the RangeIndex every table reader produces).
 """
 import os
 import pathlib
 import warnings
 from abc import ABC, abstractmethod
-from typing import List
+from typing import Iterator, List, Optional, Tuple
 
 import numpy as np
 import pandas as pd
-import pyarrow as pa
 
 from .. import flowsom
-from ..host_utils import list_files, validate_paths, verify_in_list
+from ..fov_tables import FovTableDir, read_dataframe, write_dataframe  # noqa: F401  (re-exported)
+from ..host_utils import validate_paths, verify_in_list
 
 
-def read_dataframe(path) -> pd.DataFrame:
-    """feather.read_dataframe: a Feather V2 file is an Arrow IPC file.  A corrupted file raises
-    pyarrow.lib.ArrowInvalid / OSError, which the pipeline functions catch like the reference."""
-    with pa.OSFile(str(path), "rb") as f:
-        return pa.ipc.open_file(f).read_all().to_pandas()
+def _row_blocks(n_rows: int, block: int) -> Iterator[Tuple[int, int]]:
+    """[start, stop) bounds of consecutive blocks of at most ``block`` rows."""
+    start = 0
+    while start < n_rows:
+        yield start, min(start + block, n_rows)
+        start += block
 
 
-def write_dataframe(df: pd.DataFrame, path, compression="uncompressed") -> None:
-    """feather.write_dataframe(df, path, compression='uncompressed')."""
-    table = pa.Table.from_pandas(df, preserve_index=None)
-    codec = None if compression in (None, "uncompressed") else compression
-    opts = pa.ipc.IpcWriteOptions(compression=codec)
-    with pa.OSFile(str(path), "wb") as f:
-        with pa.ipc.new_file(f, table.schema, options=opts) as w:
-            w.write_table(table, max_chunksize=65536)
+def _as_f64_matrix(frame: pd.DataFrame) -> np.ndarray:
+    return np.ascontiguousarray(frame.to_numpy(dtype=np.float64))
 
 
 class PixieSOMCluster(ABC):
+    """What pixel and cell SOMs share: the grid, the schedule, the codebook file and the two kernel
+    calls (reference base class: cluster_helpers.py:52-163)."""
+
+    #: words of the "already trained" / "retraining" warnings; the subclasses fill them in
+    _subject = ("SOM", "columns")
+
     @abstractmethod
     def __init__(self, weights_path: pathlib.Path, columns: List[str], num_passes: int = 1,
                  xdim: int = 10, ydim: int = 10, lr_start: float = 0.05, lr_end: float = 0.01,
                  seed=42):
-        """Generic SOM runner (reference: cluster_helpers.py:52-87)."""
         self.weights_path = weights_path
-        self.weights = None if not os.path.exists(weights_path) else read_dataframe(weights_path)
         self.columns = columns
+        self.xdim, self.ydim = xdim, ydim
+        self.lr_start, self.lr_end = lr_start, lr_end
         self.num_passes = num_passes
-        self.xdim = xdim
-        self.ydim = ydim
-        self.lr_start = lr_start
-        self.lr_end = lr_end
         self.seed = seed
+        # a codebook written by an earlier session is picked up again
+        self.weights: Optional[pd.DataFrame] = read_dataframe(weights_path) \
+            if os.path.exists(weights_path) else None
 
     @abstractmethod
     def normalize_data(self) -> pd.DataFrame:
-        """Normalisation of the input data (implemented by the subclasses)."""
+        """Scaling of the input columns; each subclass has its own rule."""
+
+    # ---- training ---------------------------------------------------------------------------
+    def _needs_training(self, overwrite: bool) -> bool:
+        """The reference's three-way decision with its three warnings (:250-268, :374-393)."""
+        kind, what = self._subject
+        if overwrite:
+            warnings.warn("Overwrite flag set, retraining SOM")
+            return True
+        if self.weights is None:
+            return True
+        if set(self.weights.columns.values) == set(self.columns):
+            warnings.warn("%s SOM already trained on specified %s" % (kind, what))
+            return False
+        warnings.warn("New %s specified, retraining" % what)
+        return True
 
     def train_som(self, data: pd.DataFrame):
-        """Trains the SOM on ``data`` and saves the weights (reference: cluster_helpers.py:98-116)."""
-        som_weights = flowsom.som(
-            data=data.values.astype(np.float64), xdim=self.xdim, ydim=self.ydim,
-            rlen=self.num_passes, alpha_range=(self.lr_start, self.lr_end), seed=self.seed
-        )
-        # ensure dimensions of weights are flattened
-        som_weights = np.reshape(som_weights, (self.xdim * self.ydim, som_weights.shape[-1]))
-        self.weights = pd.DataFrame(som_weights, columns=data.columns.values)
-        write_dataframe(self.weights, self.weights_path, compression='uncompressed')
+        """Fit the xdim x ydim codebook on the rows of ``data`` (FlowSOM online rule, ``num_passes``
+        passes, learning rate ``lr_start`` -> ``lr_end``) and store it next to ``weights_path``."""
+        codebook = flowsom.som(data=_as_f64_matrix(data), xdim=self.xdim, ydim=self.ydim,
+                               rlen=self.num_passes, alpha_range=(self.lr_start, self.lr_end),
+                               seed=self.seed)
+        nodes = self.xdim * self.ydim
+        self.weights = pd.DataFrame(np.asarray(codebook).reshape(nodes, -1), columns=data.columns.values)
+        write_dataframe(self.weights, self.weights_path, compression="uncompressed")
 
+    # ---- assignment -------------------------------------------------------------------------
     def generate_som_clusters(self, external_data: pd.DataFrame,
                               num_parallel_obs: int = 1000000) -> np.ndarray:
-        """BMU label (1-based) of every row (reference: cluster_helpers.py:118-163)."""
+        """1-based best-matching-unit label of every row of ``external_data`` (first minimum wins),
+        searched in blocks of ``num_parallel_obs`` rows."""
         if num_parallel_obs <= 0:
             raise ValueError("num_parallel_obs specified needs to be greater than 0")
 
-        # subset on just the weights columns prior to SOM cluster mapping
-        weights_cols = self.weights.columns.values
-        verify_in_list(
-            weights_cols=weights_cols,
-            external_data_cols=external_data.columns.values
-        )
+        trained_on = self.weights.columns.values
+        verify_in_list(weights_cols=trained_on, external_data_cols=external_data.columns.values)
 
-        cluster_labels = []
-        weights = self.weights.values.astype(np.float64)
-        # NOTE: indexing by weights_cols also orders the columns like self.weights
-        data = external_data[list(weights_cols)]
-        for i in np.arange(0, external_data.shape[0], num_parallel_obs):
-            cluster_labels.append(flowsom.map_data_to_nodes(
-                weights, data.iloc[i:i + num_parallel_obs].values.astype(np.float64)
-            )[0])
-
-        # if no pixels in the image, return empty array
-        if not cluster_labels:
-            return np.empty(0)
-        return np.concatenate(cluster_labels)
+        codebook = _as_f64_matrix(self.weights)
+        features = external_data[list(trained_on)]  # also puts the columns in codebook order
+        found = [flowsom.map_data_to_nodes(codebook, _as_f64_matrix(features.iloc[lo:hi]))[0]
+                 for lo, hi in _row_blocks(len(external_data), num_parallel_obs)]
+        # an image without retained pixels gives an empty (float) vector, like the reference
+        return np.concatenate(found) if found else np.empty(0)
 
 
 class PixelSOMCluster(PixieSOMCluster):
+    """Pixel SOM: trains on the sub-sampled tables of ``pixel_subset_folder``, values divided by the
+    per-channel 99.9 % row of ``norm_vals_path`` (reference: cluster_helpers.py:166-301)."""
+
+    _subject = ("Pixel", "markers")
+
     def __init__(self, pixel_subset_folder: pathlib.Path, norm_vals_path: pathlib.Path,
                  weights_path: pathlib.Path, fovs: List[str], columns: List[str],
                  num_passes: int = 1, xdim: int = 10, ydim: int = 10,
                  lr_start: float = 0.05, lr_end: float = 0.01, seed=42):
-        """Pixel SOM cluster object (reference: cluster_helpers.py:166-221)."""
-        super().__init__(
-            weights_path, columns, num_passes, xdim, ydim, lr_start, lr_end, seed
-        )
-
-        # path validation
+        super().__init__(weights_path, columns, num_passes, xdim, ydim, lr_start, lr_end, seed)
         validate_paths([norm_vals_path, pixel_subset_folder])
 
-        # load the normalization values in
-        self.norm_data = read_dataframe(norm_vals_path)
-
-        # define the fovs used
         self.fovs = fovs
-
-        # list all the files in pixel_subset_folder and load them to train_data
-        fov_files = list_files(pixel_subset_folder, substrs='.feather')
-        self.train_data = pd.concat(
-            [read_dataframe(os.path.join(pixel_subset_folder, fov)) for fov in fov_files
-             if os.path.splitext(fov)[0] in fovs]
-        )
-
-        # we can just normalize train_data now since that's what we'll be training on
-        self.train_data = self.normalize_data(self.train_data)
-
-        # define each SOM cluster seen
+        self.norm_data = read_dataframe(norm_vals_path)
         self.som_clusters_seen = set()
 
-    def normalize_data(self, external_data: pd.DataFrame) -> pd.DataFrame:
-        """``external_data[norm cols] / norm_data`` (reference: cluster_helpers.py:223-248)."""
-        verify_in_list(
-            norm_data_cols=self.norm_data.columns.values,
-            external_data_cols=external_data.columns.values
-        )
+        wanted = set(fovs)
+        subset = FovTableDir(pixel_subset_folder)
+        parts = [subset.load(fov) for fov in subset.fovs() if fov in wanted]
+        # the training matrix is only ever used normalised
+        self.train_data = self.normalize_data(pd.concat(parts))
 
-        norm_data_cols = self.norm_data.columns.values
-        external_data_norm = external_data.copy()
-        external_data_norm[norm_data_cols] = external_data_norm[norm_data_cols].div(
-            self.norm_data.iloc[0], axis=1
-        )
-        return external_data_norm
+    def normalize_data(self, external_data: pd.DataFrame) -> pd.DataFrame:
+        """Copy of ``external_data`` with every channel of ``norm_data`` divided by its norm value."""
+        channels = self.norm_data.columns.values
+        verify_in_list(norm_data_cols=channels, external_data_cols=external_data.columns.values)
+
+        scaled = external_data.copy()
+        divisors = self.norm_data.iloc[0].to_numpy(dtype=np.float64)
+        scaled[channels] = scaled[channels].to_numpy() / divisors   # IEEE division per element
+        return scaled
 
     def train_som(self, overwrite=False):
-        """Trains the SOM using ``train_data`` (reference: cluster_helpers.py:250-268)."""
-        if overwrite:
-            warnings.warn('Overwrite flag set, retraining SOM')
-        elif self.weights is not None:
-            if set(self.weights.columns.values) == set(self.columns):
-                warnings.warn('Pixel SOM already trained on specified markers')
-                return
-            warnings.warn('New markers specified, retraining')
+        if self._needs_training(overwrite):
+            super().train_som(self.train_data[self.columns])
 
-        super().train_som(self.train_data[self.columns])
-
-    def assign_som_clusters(self, external_data: pd.DataFrame,
-                            normalize_data: bool = True,
+    def assign_som_clusters(self, external_data: pd.DataFrame, normalize_data: bool = True,
                             num_parallel_pixels: int = 1000000) -> pd.DataFrame:
-        """Assigns SOM clusters to a dataset (reference: cluster_helpers.py:270-301)."""
-        external_data_norm = self.normalize_data(external_data) if normalize_data \
-            else external_data.copy()
-        som_labels = super().generate_som_clusters(
-            external_data_norm, num_parallel_obs=num_parallel_pixels
-        )
-
-        external_data_norm['pixel_som_cluster'] = som_labels
-        self.som_clusters_seen.update(list(np.unique(som_labels)))
-        return external_data_norm
+        """``external_data`` (normalised unless told otherwise) plus a ``pixel_som_cluster`` column;
+        the labels met are remembered in ``som_clusters_seen``."""
+        table = self.normalize_data(external_data) if normalize_data else external_data.copy()
+        labels = self.generate_som_clusters(table, num_parallel_obs=num_parallel_pixels)
+        table["pixel_som_cluster"] = labels
+        self.som_clusters_seen.update(np.unique(labels).tolist())
+        return table
 
 
 class CellSOMCluster(PixieSOMCluster):
+    """Cell SOM over a cell x feature table held in memory; features are scaled by their own 99.9 %
+    quantile of non-zero values (reference: cluster_helpers.py:304-416)."""
+
+    _subject = ("Cell", "columns")
+
     def __init__(self, cell_data: pd.DataFrame, weights_path: pathlib.Path,
                  fovs: List[str], columns: List[str], num_passes: int = 1,
                  xdim: int = 10, ydim: int = 10, lr_start: float = 0.05, lr_end: float = 0.01,
                  seed=42, normalize=True):
-        """Cell SOM cluster object (reference: cluster_helpers.py:304-353)."""
-        super().__init__(
-            weights_path, columns, num_passes, xdim, ydim, lr_start, lr_end, seed
-        )
-
-        self.cell_data = cell_data
+        super().__init__(weights_path, columns, num_passes, xdim, ydim, lr_start, lr_end, seed)
         self.fovs = fovs
-
-        # subset cell_data on just the FOVs specified
-        self.cell_data = self.cell_data[
-            self.cell_data['fov'].isin(self.fovs)
-        ].reset_index(drop=True)
-
-        # since cell_data is the only dataset, we can just normalize it immediately
+        in_cohort = cell_data["fov"].isin(fovs)
+        self.cell_data = cell_data[in_cohort].reset_index(drop=True)
         if normalize:
             self.normalize_data()
 
     def normalize_data(self):
-        """99.9 % normalisation of the count columns, zeros ignored
-        (reference: cluster_helpers.py:355-372)."""
-        cell_data_sub = self.cell_data[self.columns].copy()
-        cell_norm_vals = cell_data_sub.replace(0, np.nan).quantile(q=0.999, axis=0)
-        cell_data_sub = cell_data_sub.div(cell_norm_vals)
-        self.cell_data[self.columns] = cell_data_sub
+        """In place: each training column divided by the 0.999 quantile of its non-zero entries."""
+        block = self.cell_data[self.columns]
+        caps = block.where(block != 0).quantile(q=0.999, axis=0)   # zeros -> NaN -> ignored
+        self.cell_data[self.columns] = block.div(caps)
 
     def train_som(self, overwrite=False):
-        """Trains the SOM using ``cell_data`` (reference: cluster_helpers.py:374-393)."""
-        if overwrite:
-            warnings.warn('Overwrite flag set, retraining SOM')
-        elif self.weights is not None:
-            if set(self.weights.columns.values) == set(self.columns):
-                warnings.warn('Cell SOM already trained on specified columns')
-                return
-            warnings.warn('New columns specified, retraining')
-
-        super().train_som(self.cell_data[self.columns])
+        if self._needs_training(overwrite):
+            super().train_som(self.cell_data[self.columns])
 
     def assign_som_clusters(self, num_parallel_cells=1000000) -> pd.DataFrame:
-        """Assigns SOM clusters to ``cell_data`` (reference: cluster_helpers.py:395-416)."""
-        som_labels = super().generate_som_clusters(
-            self.cell_data[self.columns], num_parallel_obs=num_parallel_cells
-        )
-        self.cell_data['cell_som_cluster'] = som_labels
+        """Adds ``cell_som_cluster`` to ``cell_data`` and returns the table."""
+        self.cell_data["cell_som_cluster"] = self.generate_som_clusters(
+            self.cell_data[self.columns], num_parallel_obs=num_parallel_cells)
         return self.cell_data

@@ -1,148 +1,116 @@
-"""Hot-path pieces of ``ark.phenotyping.pixel_cluster_utils``
-(/root/reference/src/ark/phenotyping/pixel_cluster_utils.py): row normalisation, the
-per-cluster channel-average table and the restart helper.  The per-cluster reduction runs on
-the GPU (pxsom_cluster_sums); the TIFF-bound helpers of the reference module are out of scope
-(SURVEY.md section 2, row 5)."""
+"""The parts of ``ark.phenotyping.pixel_cluster_utils`` that sit on the Pixie SOM path
+(/root/reference/src/ark/phenotyping/pixel_cluster_utils.py): row normalisation (:109-142), the
+per-cluster mean-expression table (:294-416) and the restart helper (:419-478).  Same names, arguments,
+error / warning texts and results; the TIFF-bound helpers of that module are out of scope (SURVEY.md
+section 8).  The per-cluster reduction is one accumulating device pass per FOV (pxsom_cluster_sums:
+binary64 sums, int64 counts) instead of a pandas groupby per FOV plus a groupby over the concatenation.
+"""
 import os
 import random
 import warnings
 
 import numpy as np
 import pandas as pd
-from pyarrow.lib import ArrowInvalid
 
 from .. import flowsom
-from ..host_utils import list_files, remove_file_extensions, validate_paths, verify_in_list
-from .cluster_helpers import read_dataframe
+from ..fov_tables import UNREADABLE, FovTableDir
+from ..host_utils import validate_paths, verify_in_list
 
 
 def normalize_rows(pixel_data, channels, include_seg_label=True):
-    """Divide each row by its channel sum (reference: pixel_cluster_utils.py:109-142)."""
-    pixel_data_sub = pixel_data[channels]
-    pixel_data_sub = pixel_data_sub.div(pixel_data_sub.sum(axis=1), axis=0)
+    """Each pixel's channel values divided by their sum; position (and label) columns carried along."""
+    values = pixel_data[channels]
+    out = values.div(values.sum(axis=1), axis=0)
+    carried = ["fov", "row_index", "column_index"] + (["label"] if include_seg_label else [])
+    out[carried] = pixel_data.loc[out.index.values, carried]
+    return out
 
-    meta_cols = ['fov', 'row_index', 'column_index']
-    if include_seg_label:
-        meta_cols.append('label')
 
-    pixel_data_sub[meta_cols] = pixel_data.loc[pixel_data_sub.index.values, meta_cols]
-    return pixel_data_sub
+class _ClusterTotals:
+    """Running per-cluster channel sums and pixel counts over FOV tables; cluster ids are whatever the
+    label column holds (SOM labels 1..K, or meta-cluster ids), so totals are kept per id."""
+
+    def __init__(self, channels):
+        self.channels = list(channels)
+        self._sum = {}
+        self._n = {}
+
+    def add_table(self, table: pd.DataFrame, cluster_col: str) -> None:
+        ids = table[cluster_col].to_numpy()
+        if ids.size == 0:
+            return
+        distinct, dense = np.unique(ids, return_inverse=True)
+        # the kernel wants labels 1..len(distinct)
+        sums, counts = flowsom.cluster_sums(table[self.channels].to_numpy(),
+                                            (dense + 1).astype(np.int32), len(distinct))
+        for row, cid in enumerate(distinct):
+            if cid in self._sum:
+                self._sum[cid] = self._sum[cid] + sums[row]
+                self._n[cid] += int(counts[row])
+            else:
+                self._sum[cid] = np.array(sums[row], dtype=np.float64)
+                self._n[cid] = int(counts[row])
+
+    def __len__(self):
+        return len(self._sum)
+
+    def frame(self, cluster_col: str) -> pd.DataFrame:
+        """[cluster id | channel sums ... | count], ascending cluster id."""
+        order = sorted(self._sum)
+        out = pd.DataFrame(np.stack([self._sum[cid] for cid in order]), columns=self.channels)
+        out.insert(0, cluster_col, order)
+        out["count"] = [self._n[cid] for cid in order]
+        return out
 
 
 def compute_pixel_cluster_channel_avg(fovs, channels, base_dir, pixel_cluster_col,
                                       num_pixel_clusters,
                                       pixel_data_dir='pixel_mat_data',
                                       num_fovs_subset=100, seed=42, keep_count=False):
-    """Average channel values per pixel SOM / meta cluster
-    (reference: pixel_cluster_utils.py:294-416).
+    """Mean channel expression of every pixel SOM / meta cluster over (a random subset of) the FOVs.
 
-    The per-FOV ``groupby(cluster)[channels].sum()`` / ``.size()`` and the sum over FOVs are one
-    accumulating device reduction (binary64 sums, int64 counts); everything else -- validation,
-    FOV sub-sampling with ``random.seed(seed)``, the error and warning texts, sorting and the
-    ``count`` column -- follows the reference line by line.
-    """
-    verify_in_list(
-        provided_cluster_col=[pixel_cluster_col],
-        valid_cluster_cols=['pixel_som_cluster', 'pixel_meta_cluster']
-    )
-
+    ``num_pixel_clusters``: how many clusters the table must contain (``None``: do not check);
+    ``num_fovs_subset``: how many FOVs to draw (``random.seed(seed)``; all of them if fewer exist);
+    ``keep_count``: keep the per-cluster pixel count column."""
+    verify_in_list(provided_cluster_col=[pixel_cluster_col],
+                   valid_cluster_cols=['pixel_som_cluster', 'pixel_meta_cluster'])
     if num_pixel_clusters is not None and num_pixel_clusters <= 0:
         raise ValueError("If set, number of pixel clusters desired must be a positive integer")
-
     if num_fovs_subset <= 0:
         raise ValueError("Number of fovs to subset must be a positive integer")
 
-    if len(fovs) < num_fovs_subset:
-        warnings.warn(
-            'Provided num_fovs_subset=%d but only %d FOVs in dataset, '
-            'subsetting just the %d FOVs' %
-            (num_fovs_subset, len(fovs), len(fovs))
-        )
-
+    available = len(fovs)
+    if available < num_fovs_subset:
+        warnings.warn('Provided num_fovs_subset=%d but only %d FOVs in dataset, subsetting just the %d FOVs'
+                      % (num_fovs_subset, available, available))
     random.seed(seed)
-    fovs_sub = random.sample(fovs, num_fovs_subset) if num_fovs_subset < len(fovs) else fovs
+    chosen = fovs if num_fovs_subset >= available else random.sample(fovs, num_fovs_subset)
 
-    channels = list(channels)
-    sums = {}     # cluster id -> float64 [C]
-    counts = {}   # cluster id -> int
-    for fov in fovs_sub:
+    tables = FovTableDir(os.path.join(base_dir, pixel_data_dir))
+    totals = _ClusterTotals(channels)
+    for fov in chosen:
         try:
-            fov_pixel_data = read_dataframe(
-                os.path.join(base_dir, pixel_data_dir, fov + '.feather')
-            )
-        except (ArrowInvalid, OSError, IOError):
+            totals.add_table(tables.load(fov), pixel_cluster_col)
+        except UNREADABLE:
             print("The data for FOV %s has been corrupted, skipping" % fov)
-            continue
 
-        labels = fov_pixel_data[pixel_cluster_col].values
-        if labels.size == 0:
-            continue
-        ids, inv = np.unique(labels, return_inverse=True)   # dense 1..len(ids) for the kernel
-        fsum, fcnt = flowsom.cluster_sums(fov_pixel_data[channels].values,
-                                          (inv + 1).astype(np.int32), len(ids))
-        for pos, cid in enumerate(ids):
-            if cid in sums:
-                sums[cid] = sums[cid] + fsum[pos]
-                counts[cid] += int(fcnt[pos])
-            else:
-                sums[cid] = fsum[pos].copy()
-                counts[cid] = int(fcnt[pos])
+    if len(totals) == 0:
+        raise ValueError("No objects to concatenate")   # what pd.concat([]) says in the reference
+    table = totals.frame(pixel_cluster_col)
+    if num_pixel_clusters is not None and len(table) < num_pixel_clusters:
+        raise ValueError('Averaged data contains just %d clusters out of %d. '
+                         'Average expression file not written. '
+                         'Consider increasing your num_fovs_subset value.' % (len(table), num_pixel_clusters))
 
-    if not sums:
-        # mirrors pd.concat([]) in the reference
-        raise ValueError("No objects to concatenate")
-
-    cluster_ids = sorted(sums)
-    sum_count_totals = pd.DataFrame(np.stack([sums[cid] for cid in cluster_ids]), columns=channels)
-    sum_count_totals.insert(0, pixel_cluster_col, cluster_ids)
-    sum_count_totals['count'] = [counts[cid] for cid in cluster_ids]
-
-    if num_pixel_clusters is not None and sum_count_totals.shape[0] < num_pixel_clusters:
-        raise ValueError(
-            'Averaged data contains just %d clusters out of %d. '
-            'Average expression file not written. '
-            'Consider increasing your num_fovs_subset value.' %
-            (sum_count_totals.shape[0], num_pixel_clusters)
-        )
-
-    sum_count_totals[channels] = sum_count_totals[channels].div(sum_count_totals['count'], axis=0)
-    sum_count_totals[pixel_cluster_col] = sum_count_totals[pixel_cluster_col].astype(int)
-    sum_count_totals = sum_count_totals.sort_values(by=pixel_cluster_col)
-
-    if not keep_count:
-        sum_count_totals = sum_count_totals.drop('count', axis=1)
-
-    return sum_count_totals
+    table[totals.channels] = table[totals.channels].div(table['count'], axis=0)
+    table[pixel_cluster_col] = table[pixel_cluster_col].astype(int)
+    table = table.sort_values(by=pixel_cluster_col)
+    return table if keep_count else table.drop('count', axis=1)
 
 
 def find_fovs_missing_col(base_dir, data_dir, missing_col):
-    """FOV names in ``data_dir`` without ``missing_col`` (reference: pixel_cluster_utils.py:419-478)."""
-    data_path = os.path.join(base_dir, data_dir)
-    temp_path = os.path.join(base_dir, data_dir + '_temp')
-
-    validate_paths(data_path)
-
-    if not os.path.exists(temp_path):
-        fov_files = list_files(data_path, substrs='.feather')
-
-        # read in a sample FOV, skipping potentially corrupted files
-        i = 0
-        fov_data = None
-        while i < len(fov_files):
-            try:
-                fov_data = read_dataframe(os.path.join(data_path, fov_files[i]))
-            except (ArrowInvalid, OSError, IOError):
-                i += 1
-                continue
-            break
-
-        if missing_col not in fov_data.columns.values:
-            os.mkdir(temp_path)
-            return remove_file_extensions(fov_files)
-        else:
-            return []
-    else:
-        data_files = set(list_files(data_path, substrs='.feather'))
-        temp_files = set(list_files(temp_path, substrs='.feather'))
-        leftover_files = list(data_files.difference(temp_files))
-        return remove_file_extensions(leftover_files)
+    """FOVs of ``base_dir/data_dir`` a stage adding ``missing_col`` still has to process; creates
+    ``<data_dir>_temp`` when it starts a fresh run (see :meth:`FovTableDir.pending`)."""
+    root = os.path.join(base_dir, data_dir)
+    validate_paths(root)
+    return FovTableDir(root).pending(missing_col)

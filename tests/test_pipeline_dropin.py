@@ -201,6 +201,63 @@ def test_reference_cluster_pixels_behaviour(som_backend, tmp_path, capsys, multi
     np.testing.assert_array_equal(res[CHANS].values, g["normed_fov0"])
 
 
+def test_cluster_pixels_restarts_from_staged_tables(som_backend, tmp_path, capsys):
+    """An interrupted run left <data_dir>_temp behind with one FOV done: only the others are processed,
+    the staged table is kept as it is, and the directories are swapped at the end
+    (reference behaviour: pixel_cluster_utils.py:419-478 + pixel_som_clustering.py:231-251)."""
+    import shutil
+    from ark_analysis_amd.fov_tables import FovTableDir
+    g = np.load(os.path.join(GOLD, "g7_pixel_pipeline.npz"))
+    td = str(tmp_path)
+    _build_pixel_dirs(td, g)
+    obj = pixel_som_clustering.train_pixel_som(FOVS, CHANS, td)
+    # a complete run elsewhere provides the table an interrupted run would have staged
+    shutil.copytree(os.path.join(td, "pixel_mat_data"), os.path.join(td, "full"))
+    pixel_som_clustering.cluster_pixels(FOVS, td, obj, data_dir="full")
+    os.mkdir(os.path.join(td, "pixel_mat_data_temp"))
+    shutil.copy(os.path.join(td, "full", "fov1.feather"), os.path.join(td, "pixel_mat_data_temp", "fov1.feather"))
+    assert sorted(FovTableDir(os.path.join(td, "pixel_mat_data")).pending("pixel_som_cluster")) == ["fov0", "fov2"]
+    capsys.readouterr()
+    pixel_som_clustering.cluster_pixels(FOVS, td, obj)
+    out = capsys.readouterr().out
+    assert "Restarting SOM label assignment from fov " in out and "2 fovs left to process\n" in out
+    assert out.endswith("Processed 2 fovs\n")
+    assert not os.path.exists(os.path.join(td, "pixel_mat_data_temp"))
+    for fov in FOVS:
+        res = read_dataframe(os.path.join(td, "pixel_mat_data", fov + ".feather"))
+        np.testing.assert_array_equal(res["pixel_som_cluster"].values, g["labels_" + fov])
+        np.testing.assert_array_equal(res[CHANS].values, g["normed_" + fov])
+
+
+def test_fov_table_helpers(tmp_path):
+    """Footer-only column listing, natural ordering, prefetcher / writer round trip, damaged files."""
+    from ark_analysis_amd.fov_tables import FovTableDir, TablePrefetcher, TableWriter
+    root = tmp_path / "tabs"
+    root.mkdir()
+    names = ["fov10", "fov2", "fov1"]
+    frames = {n: pd.DataFrame({"a": np.arange(5.0) + i, "segmentation_label": np.arange(5)})
+              for i, n in enumerate(names)}
+    w = TableWriter()
+    for n, df in frames.items():
+        w.submit(df, str(root / (n + ".feather")))
+    w.close()
+    (root / "fov3.feather").write_text("not an arrow file")
+    (root / ".hidden.feather").write_text("x")
+    tabs = FovTableDir(str(root))
+    assert tabs.fovs() == ["fov1", "fov2", "fov3", "fov10"]
+    assert tabs.column_names("fov2") == ["a", "segmentation_label"]
+    got = list(TablePrefetcher(tabs, tabs.fovs(), depth=1))
+    assert [f for f, _ in got] == tabs.fovs()
+    assert got[2][1] is None                                  # damaged table
+    for fov, table in got:
+        if table is not None:
+            pd.testing.assert_frame_equal(table, frames[fov])
+    with pytest.raises(OSError):
+        bad = TableWriter()
+        bad.submit(frames["fov1"], str(tmp_path / "no_such_dir" / "x.feather"))
+        bad.close()
+
+
 def test_reference_generate_som_avg_files(som_backend, tmp_path, capsys):
     g = np.load(os.path.join(GOLD, "g7_pixel_pipeline.npz"))
     td = str(tmp_path)
