@@ -37,15 +37,21 @@ POSITION_COLUMNS = ("fov", "row_index", "column_index")
 OPTIONAL_COLUMNS = ("label", "pixel_som_cluster", "pixel_meta_cluster", "pixel_meta_cluster_rename")
 
 
+def read_table(path) -> pa.Table:
+    """The file's Arrow table (column chunks as stored; nothing is converted)."""
+    with pa.OSFile(str(path), "rb") as src:
+        return pa.ipc.open_file(src).read_all()
+
+
 def read_dataframe(path) -> pd.DataFrame:
     """What ``feather.read_dataframe`` does: a Feather V2 file *is* an Arrow IPC file."""
-    with pa.OSFile(str(path), "rb") as src:
-        return pa.ipc.open_file(src).read_all().to_pandas()
+    return read_table(path).to_pandas()
 
 
-def write_dataframe(df: pd.DataFrame, path, compression="uncompressed") -> None:
-    """What ``feather.write_dataframe(df, path, compression=...)`` does (64 Ki-row record batches)."""
-    body = pa.Table.from_pandas(df, preserve_index=None)
+def write_dataframe(df, path, compression="uncompressed") -> None:
+    """What ``feather.write_dataframe(df, path, compression=...)`` does (64 Ki-row record batches).
+    ``df`` may also be an Arrow table that already carries pandas metadata."""
+    body = df if isinstance(df, pa.Table) else pa.Table.from_pandas(df, preserve_index=None)
     options = pa.ipc.IpcWriteOptions(compression=None if compression in (None, "uncompressed") else compression)
     with pa.OSFile(str(path), "wb") as sink, pa.ipc.new_file(sink, body.schema, options=options) as out:
         out.write_table(body, max_chunksize=1 << 16)
@@ -92,6 +98,9 @@ class FovTableDir:
     def load(self, fov: str) -> pd.DataFrame:
         return read_dataframe(self.path(fov))
 
+    def load_arrow(self, fov: str) -> pa.Table:
+        return read_table(self.path(fov))
+
     def column_names(self, fov: str) -> List[str]:
         """Column names from the Arrow footer only (no data pages are touched)."""
         with pa.OSFile(self.path(fov), "rb") as src:
@@ -133,13 +142,15 @@ class FovTableDir:
 
 class TablePrefetcher:
     """Iterates ``(fov, table-or-None)`` over ``fovs``, reading up to ``depth`` tables ahead on a
-    background thread.  ``None`` stands for a table that could not be opened."""
+    background thread (as DataFrames, or as Arrow tables with ``as_arrow``).  ``None`` stands for a table
+    that could not be opened."""
 
     _END = object()
 
-    def __init__(self, tables: FovTableDir, fovs: Sequence[str], depth: int = 2):
+    def __init__(self, tables: FovTableDir, fovs: Sequence[str], depth: int = 2, as_arrow: bool = False):
         self._tables = tables
         self._fovs = list(fovs)
+        self._read = tables.load_arrow if as_arrow else tables.load
         self._slots: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
         self._worker = threading.Thread(target=self._fill, name="fov-prefetch", daemon=True)
         self._worker.start()
@@ -147,7 +158,7 @@ class TablePrefetcher:
     def _fill(self) -> None:
         for fov in self._fovs:
             try:
-                item = (fov, self._tables.load(fov))
+                item = (fov, self._read(fov))
             except UNREADABLE:
                 item = (fov, None)
             except BaseException as err:  # surfaced in the consumer thread
@@ -187,7 +198,7 @@ class TableWriter:
                 except BaseException as err:
                     self._error = err
 
-    def submit(self, table: pd.DataFrame, path: str) -> None:
+    def submit(self, table, path: str) -> None:
         self._jobs.put((table, path))
 
     def close(self) -> None:

@@ -16,7 +16,7 @@ worker copies.
 import os
 from typing import Any, Callable, Tuple
 
-from .. import fov_tables
+from .. import arrow_assign, flowsom, fov_tables
 from ..fov_tables import FovTableDir, TablePrefetcher, TableWriter
 from ..host_utils import validate_paths, verify_in_list, verify_same_elements
 from . import cluster_helpers, pixel_cluster_utils
@@ -49,9 +49,18 @@ def train_pixel_som(fovs, channels, base_dir,
     return som
 
 
+_DEVICE_BMU = flowsom.map_data_to_nodes   # the real device entry point (tests may swap the attribute)
+
+
 def _label_table(som, table, relabel: bool, block: int):
     """One FOV table -> the same table with normalised channels and ``pixel_som_cluster``.
-    ``relabel``: the table was produced by an earlier run (already normalised, old labels present)."""
+    ``relabel``: the table was produced by an earlier run (already normalised, old labels present).
+    Arrow tables take the pandas-free device path when it covers them (and the device entry point has
+    not been replaced); everything else goes through ``PixelSOMCluster.assign_som_clusters``."""
+    if not hasattr(table, "iloc"):   # an Arrow table
+        if flowsom.map_data_to_nodes is _DEVICE_BMU and arrow_assign.applicable(som, table, not relabel):
+            return arrow_assign.label_table(som, table, normalize=not relabel)
+        table = table.to_pandas()
     if relabel:
         table = table.drop(columns="pixel_som_cluster", errors="ignore")
     return som.assign_som_clusters(table, normalize_data=not relabel, num_parallel_pixels=block)
@@ -118,7 +127,7 @@ def cluster_pixels(fovs, base_dir, pixel_pysom, data_dir='pixel_mat_data',
     done = 0
     writer = TableWriter()
     try:
-        feed = iter(TablePrefetcher(tables, todo))
+        feed = iter(TablePrefetcher(tables, todo, as_arrow=True))
         for names in fov_tables.batches(todo, group):
             spoiled = []
             for _ in names:

@@ -229,6 +229,42 @@ def test_cluster_pixels_restarts_from_staged_tables(som_backend, tmp_path, capsy
         np.testing.assert_array_equal(res[CHANS].values, g["normed_" + fov])
 
 
+@pytest.mark.gpu
+def test_arrow_fast_path_equals_dataframe_path(gpu, tmp_path):
+    """cluster_pixels' pandas-free labelling writes exactly the table the DataFrame path writes
+    (values, dtypes, column order, index), for first labelling and for re-labelling."""
+    from ark_analysis_amd import arrow_assign, fov_tables
+    g = np.load(os.path.join(GOLD, "g7_pixel_pipeline.npz"))
+    td = str(tmp_path)
+    _build_pixel_dirs(td, g)
+    obj = pixel_som_clustering.train_pixel_som(FOVS, CHANS, td)
+    for fov in FOVS:
+        src = os.path.join(td, "pixel_mat_data", fov + ".feather")
+        arrow_in = fov_tables.read_table(src)
+        assert arrow_assign.applicable(obj, arrow_in, True)
+        obj.som_clusters_seen = set()
+        fast = arrow_assign.label_table(obj, arrow_in, normalize=True)
+        seen_fast = set(obj.som_clusters_seen)
+        obj.som_clusters_seen = set()
+        slow = obj.assign_som_clusters(fov_tables.read_dataframe(src))
+        assert seen_fast == {int(v) for v in obj.som_clusters_seen}
+        fov_tables.write_dataframe(fast, os.path.join(td, "fast.feather"))
+        fov_tables.write_dataframe(slow, os.path.join(td, "slow.feather"))
+        a, b = read_dataframe(os.path.join(td, "fast.feather")), read_dataframe(os.path.join(td, "slow.feather"))
+        pd.testing.assert_frame_equal(a, b, check_exact=True)
+        np.testing.assert_array_equal(a["pixel_som_cluster"].values, g["labels_" + fov])
+        np.testing.assert_array_equal(a[CHANS].values, g["normed_" + fov])
+        # re-labelling an already labelled, already normalised table
+        again = arrow_assign.label_table(obj, fov_tables.read_table(os.path.join(td, "fast.feather")), normalize=False)
+        fov_tables.write_dataframe(again, os.path.join(td, "again.feather"))
+        pd.testing.assert_frame_equal(read_dataframe(os.path.join(td, "again.feather")), a, check_exact=True)
+    # tables the fast path does not cover fall back (float32 channel)
+    odd = fov_tables.read_table(os.path.join(td, "pixel_mat_data", "fov0.feather"))
+    import pyarrow as pa
+    odd = odd.set_column(0, CHANS[0], odd.column(CHANS[0]).cast(pa.float32()))
+    assert not arrow_assign.applicable(obj, odd, True)
+
+
 def test_fov_table_helpers(tmp_path):
     """Footer-only column listing, natural ordering, prefetcher / writer round trip, damaged files."""
     from ark_analysis_amd.fov_tables import FovTableDir, TablePrefetcher, TableWriter
