@@ -872,6 +872,34 @@ PXSOM_EXPORT int pxsom_cluster_sums(const void *x_dev, int64_t n, int c, int64_t
     PXSOM_DISPATCH_DTYPE(dtype, x_dev, xp, cluster_sums_typed<T>(xp, n, c, ldx, labels_dev, k, sums_dev, counts_dev, st));
 }
 
+// cell x pixel-cluster counts (create_c2pc_data's groupby + pivot): plain global int64 atomics.  The bins
+// of one cell are nb consecutive words and neighbouring pixels mostly belong to the same cell, so the
+// atomics of a wave land in a few cache lines; the kernel is bound by reading the two label vectors.
+__global__ __launch_bounds__(256) void pair_histogram_kernel(const int32_t *__restrict__ a,
+                                                             const int32_t *__restrict__ b, int64_t n,
+                                                             int64_t na, int nb, unsigned long long *hist)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int32_t ai = a[i], bi = b[i];
+        if (ai >= 0 && ai < na && bi >= 0 && bi < nb) atomicAdd(&hist[(int64_t)ai * nb + bi], 1ull);
+    }
+}
+
+PXSOM_EXPORT int pxsom_pair_histogram(const int32_t *a_dev, const int32_t *b_dev, int64_t n, int64_t na, int nb,
+                                      int64_t *hist_dev, void *stream)
+{
+    if (n < 0 || na < 1 || nb < 1) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_pair_histogram: bad sizes");
+    if (!hist_dev || (n > 0 && (!a_dev || !b_dev)))
+        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_pair_histogram: null pointer");
+    if (n == 0) return PXSOM_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t grid = std::min<int64_t>((n + 255) / 256, (int64_t)pxsom::device_cu_count() * 16);
+    hipLaunchKernelGGL(pair_histogram_kernel, dim3((unsigned)grid), dim3(256), 0, st, a_dev, b_dev, n, na, nb,
+                       reinterpret_cast<unsigned long long *>(hist_dev));
+    PXSOM_LAUNCH_CHECK("pair_histogram_kernel");
+    return PXSOM_OK;
+}
+
 PXSOM_EXPORT int pxsom_batch_update(double *w_dev, int xdim, int ydim, int c, const double *sums_dev,
                                     const double *counts_dev, double thr, double alpha, void *stream)
 {

@@ -118,3 +118,14 @@ def cluster_sums(data, labels, k: int):
     lab = torch.from_numpy(np.ascontiguousarray(labels, dtype=np.int32)).to(dev)
     sums, counts = som_device.cluster_sums(x, lab, int(k))
     return sums.cpu().numpy(), counts.cpu().numpy()
+
+
+def pair_histogram(a, b, na: int, nb: int) -> np.ndarray:
+    """[na, nb] int64 counts of the pairs (a_i, b_i) -- the device form of
+    ``groupby([label, cluster]).size()`` + ``pivot`` (create_c2pc_data, cell_cluster_utils.py:128-141)."""
+    import torch
+    from . import _capi, som_device
+    dev = _capi.require_gpu()
+    ad = torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+    bd = torch.from_numpy(np.ascontiguousarray(b, dtype=np.int32)).to(dev)
+    return som_device.pair_histogram(ad, bd, int(na), int(nb)).cpu().numpy()

@@ -233,3 +233,18 @@ def quantile_nonzero(x: torch.Tensor, q: float, keep_mode: int = 0) -> torch.Ten
 
 def to_numpy(t: torch.Tensor) -> np.ndarray:
     return t.detach().cpu().numpy()
+
+
+def pair_histogram(a: torch.Tensor, b: torch.Tensor, na: int, nb: int,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``out[a_i, b_i] += 1`` over two int32 HBM vectors (pairs outside [0, na) x [0, nb) are ignored);
+    ``out`` [na, nb] int64 (zeros if not given)."""
+    if a.dtype != torch.int32 or b.dtype != torch.int32 or a.numel() != b.numel() or not a.is_cuda:
+        raise ValueError("a and b must be int32 HBM vectors of the same length")
+    a, b = a.contiguous(), b.contiguous()
+    if out is None:
+        out = torch.zeros((int(na), int(nb)), dtype=torch.int64, device=a.device)
+    rc = _capi.lib().pxsom_pair_histogram(a.data_ptr(), b.data_ptr(), a.numel(), int(na), int(nb),
+                                          out.data_ptr(), _capi.stream_ptr())
+    _capi.check(rc, "pxsom_pair_histogram")
+    return out

@@ -103,6 +103,13 @@ int pxsom_cluster_sums(const void *x_dev, int64_t n, int c, int64_t ldx, int dty
                        const int32_t *labels_dev, int k, double *sums_dev, int64_t *counts_dev,
                        void *stream);
 
+/* ---- cell x pixel-cluster counts: the counting step of create_c2pc_data --------------------------
+ * reference: cell_cluster_utils.py:128-141 (groupby(['label', pixel_cluster_col]).size() + pivot per
+ * FOV).  hist[a_i * nb + b_i] += 1 for every i with 0 <= a_i < na and 0 <= b_i < nb (other pairs are
+ * ignored); hist_dev [na, nb] int64 is accumulated into, the caller clears it.  Exact integer counts. */
+int pxsom_pair_histogram(const int32_t *a_dev, const int32_t *b_dev, int64_t n, int64_t na, int nb,
+                         int64_t *hist_dev, void *stream);
+
 /* ---- exact online SOM training: replaces pyFlowSOM.som -------------------------------------
  * reference: cluster_helpers.py:106-109 (PixieSOMCluster.train_som), FlowSOM C_SOM semantics:
  * n*rlen strictly sequential steps; step t presents row order_dev[t]; Euclidean BMU (first

@@ -31,7 +31,7 @@ def gpu():
 
 @pytest.fixture(params=[pytest.param("oracle"), pytest.param("hip", marks=pytest.mark.gpu)])
 def som_backend(request, monkeypatch):
-    """Runs a host-logic test twice: on CPU with the three device entry points of
+    """Runs a host-logic test twice: on CPU with the device entry points of
     ark_analysis_amd.flowsom swapped for the oracle (test infrastructure; `-m "not gpu"`), and on
     the GPU box with the real HIP path (`-m gpu`)."""
     if request.param == "hip":
@@ -62,4 +62,5 @@ def som_backend(request, monkeypatch):
     monkeypatch.setattr(flowsom, "som", som)
     monkeypatch.setattr(flowsom, "map_data_to_nodes", map_data_to_nodes)
     monkeypatch.setattr(flowsom, "cluster_sums", cluster_sums)
+    monkeypatch.setattr(flowsom, "pair_histogram", ob.pair_histogram)
     return "oracle"

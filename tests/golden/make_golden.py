@@ -215,11 +215,75 @@ def g7_end_to_end():
          stdout=np.array(buf.getvalue()))
 
 
+def g8_c2pc():
+    """The reference's create_c2pc_data (cell x pixel-cluster count matrix + its cell_size-normalised
+    twin) on three small FOV tables: clusters that never fall inside a listed cell (dropped with a
+    warning), a float-typed cluster column, cells without pixels, background label 0, a FOV of the cell
+    table that is not requested."""
+    import warnings
+    from ark.phenotyping import cell_cluster_utils
+    rs = np.random.RandomState(21)
+    fovs = ["fov0", "fov1", "fov2"]
+    arrays = {}
+    with tempfile.TemporaryDirectory() as td:
+        pix = os.path.join(td, "pixel_mat_data")
+        os.mkdir(pix)
+        for i, fov in enumerate(fovs):
+            n = 900
+            df = pd.DataFrame({"chan0": rs.rand(n)})
+            df["fov"] = fov
+            df["row_index"] = np.repeat(np.arange(30), 30)
+            df["column_index"] = np.tile(np.arange(30), 30)
+            lab = rs.randint(0, 26, size=n)
+            som = rs.randint(1, 13, size=n)
+            meta = rs.randint(1, 7, size=n)
+            meta[lab > 0] = np.where(meta[lab > 0] == 6, 5, meta[lab > 0])   # cluster 6 only on background
+            som[(som == 12) & (lab != 25)] = 11                              # cluster 12 only in cell 25
+            df["segmentation_label" if i == 1 else "label"] = lab
+            df["pixel_som_cluster"] = som
+            df["pixel_meta_cluster_rename"] = meta.astype(np.float64) if i == 2 else meta
+            feather.write_dataframe(df, os.path.join(pix, fov + ".feather"))
+            arrays["lab_" + fov], arrays["som_" + fov], arrays["meta_" + fov] = lab, som, meta
+        rows = []
+        for fov in fovs + ["fov9"]:
+            for lab in range(1, 25):             # cell 25 is not in the cell table, cells 1..24 are
+                rows.append((fov, lab, int(rs.randint(20, 200)), rs.rand()))
+        rows.append(("fov0", 40, 77, 0.5))       # a cell without pixels
+        cell = pd.DataFrame(rows, columns=["fov", "label", "cell_size", "extra"])
+        # FOVs interleaved, labels ascending within a FOV (as ark's own cell tables are).  NB: the reference
+        # pairs count rows (in set-iteration order of the labels) with cell rows (in table order)
+        # positionally, cell_cluster_utils.py:152-166 -- for a table not sorted by label it attaches
+        # counts to the wrong cells; the fixture stays inside the well-defined case.
+        cell = cell.sample(frac=1.0, random_state=3).sort_values("label", kind="stable").reset_index(drop=True)
+        cell_path = os.path.join(td, "cell_table.csv")
+        cell.to_csv(cell_path, index=False)
+        arrays["cell_fov"] = cell["fov"].values.astype("U8")
+        arrays["cell_label"] = cell["label"].values.astype(np.int64)
+        arrays["cell_size"] = cell["cell_size"].values.astype(np.int64)
+        arrays["cell_extra"] = cell["extra"].values
+        for col in ("pixel_som_cluster", "pixel_meta_cluster_rename"):
+            with warnings.catch_warnings(record=True) as wl:
+                warnings.simplefilter("always")
+                counts, normed = cell_cluster_utils.create_c2pc_data(fovs, pix, cell_path, col)
+            arrays[col + "_warnings"] = np.array([str(w.message) for w in wl
+                                                  if not str(w.message).startswith("pyarrow.feather")], dtype="U300")
+            for tag, frame in (("counts", counts), ("normed", normed)):
+                arrays[f"{col}_{tag}_columns"] = np.array(list(frame.columns), dtype="U64")
+                arrays[f"{col}_{tag}_dtypes"] = np.array([str(t) for t in frame.dtypes], dtype="U16")
+                arrays[f"{col}_{tag}_fov"] = frame["fov"].values.astype("U8")
+                arrays[f"{col}_{tag}_values"] = frame.drop(columns="fov").values.astype(np.float64)
+    save("g8_c2pc", **arrays)
+
+
 if __name__ == "__main__":
     ob.build()
+    if len(sys.argv) > 1 and sys.argv[1] == "g8":
+        g8_c2pc()
+        sys.exit(0)
     g1_normalize()
     g2_g5_preprocess()
     g3_quantiles()
     g4_cluster_avg()
     g6_som()
     g7_end_to_end()
+    g8_c2pc()

@@ -43,6 +43,8 @@ def lib():
         L.orc_cluster_sums.restype = None
         L.orc_cluster_sums.argtypes = [c_dp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                        ctypes.c_int, c_i32p, ctypes.c_int, c_dp, c_i64p]
+        L.orc_pair_histogram.restype = None
+        L.orc_pair_histogram.argtypes = [c_i32p, c_i32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, c_i64p]
         L.orc_batch_update.restype = None
         L.orc_batch_update.argtypes = [c_dp, ctypes.c_int, ctypes.c_int, c_dp, c_dp, c_i64p,
                                        ctypes.c_double, ctypes.c_double]
@@ -130,6 +132,15 @@ def cluster_sums(data, labels, K, row0=0, stride=1, count=None):
     lib().orc_cluster_sums(_dp(data), row0, stride, count, px, labels.ctypes.data_as(c_i32p), K,
                            _dp(sums), counts.ctypes.data_as(c_i64p))
     return sums, counts
+
+
+def pair_histogram(a, b, na, nb):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    b = np.ascontiguousarray(b, dtype=np.int32)
+    hist = np.zeros((int(na), int(nb)), dtype=np.int64)
+    lib().orc_pair_histogram(a.ctypes.data_as(c_i32p), b.ctypes.data_as(c_i32p), a.size, int(na), int(nb),
+                             hist.ctypes.data_as(c_i64p))
+    return hist
 
 
 def cluster_means(sums, counts):

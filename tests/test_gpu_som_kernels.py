@@ -247,6 +247,15 @@ def test_batch_accumulate_matches_oracle(gpu, oracle, n, c, k, dtype, stride):
     np.testing.assert_allclose(stats.cpu().numpy(), got, rtol=1e-12, atol=1e-12)
 
 
+def test_pair_histogram_matches_oracle(gpu, oracle):
+    rs = np.random.RandomState(9)
+    for n, na, nb in [(1_000_003, 5_000, 100), (50_000, 7, 3), (10, 1, 1), (0, 4, 4)]:
+        a = rs.randint(-2, na + 3, size=n).astype(np.int32)      # some pairs fall outside and are ignored
+        b = rs.randint(-1, nb + 2, size=n).astype(np.int32)
+        got = sd.pair_histogram(torch.from_numpy(a).to(gpu), torch.from_numpy(b).to(gpu), na, nb)
+        np.testing.assert_array_equal(got.cpu().numpy(), oracle.pair_histogram(a, b, na, nb))
+
+
 def test_batch_update_matches_oracle(gpu, oracle):
     rs = np.random.RandomState(17)
     for (xdim, ydim, c) in [(10, 10, 22), (20, 20, 40), (3, 2, 4)]:

@@ -265,6 +265,43 @@ def test_arrow_fast_path_equals_dataframe_path(gpu, tmp_path):
     assert not arrow_assign.applicable(obj, odd, True)
 
 
+@pytest.mark.parametrize("cluster_col", ["pixel_som_cluster", "pixel_meta_cluster_rename"])
+def test_create_c2pc_data_matches_reference_run(som_backend, tmp_path, cluster_col):
+    """cell x pixel-cluster counts and their cell_size-normalised twin against the reference's own
+    create_c2pc_data on the same tables (tests/golden/g8_c2pc.npz)."""
+    from ark_analysis_amd.phenotyping import cell_cluster_utils
+    g = np.load(os.path.join(GOLD, "g8_c2pc.npz"))
+    fovs = ["fov0", "fov1", "fov2"]
+    pix = tmp_path / "pixel_mat_data"
+    pix.mkdir()
+    for i, fov in enumerate(fovs):
+        n = len(g["lab_" + fov])
+        df = pd.DataFrame({"chan0": np.zeros(n)})
+        df["fov"] = fov
+        df["segmentation_label" if i == 1 else "label"] = g["lab_" + fov]
+        df["pixel_som_cluster"] = g["som_" + fov]
+        meta = g["meta_" + fov]
+        df["pixel_meta_cluster_rename"] = meta.astype(np.float64) if i == 2 else meta
+        write_dataframe(df, str(pix / (fov + ".feather")))
+    cell = pd.DataFrame({"fov": g["cell_fov"], "label": g["cell_label"], "cell_size": g["cell_size"],
+                         "extra": g["cell_extra"]})
+    cell_path = str(tmp_path / "cell_table.csv")
+    cell.to_csv(cell_path, index=False)
+    with warnings.catch_warnings(record=True) as wl:
+        warnings.simplefilter("always")
+        counts, normed = cell_cluster_utils.create_c2pc_data(fovs, str(pix), cell_path, cluster_col)
+    assert [str(w.message) for w in wl if "Pixel clusters" in str(w.message)] == list(g[cluster_col + "_warnings"])
+    for tag, frame in (("counts", counts), ("normed", normed)):
+        assert list(frame.columns) == list(g[f"{cluster_col}_{tag}_columns"])
+        assert [str(t) for t in frame.dtypes] == list(g[f"{cluster_col}_{tag}_dtypes"])
+        assert list(frame["fov"]) == list(g[f"{cluster_col}_{tag}_fov"])
+        assert list(frame.index) == list(range(len(frame)))
+        np.testing.assert_array_equal(frame.drop(columns="fov").values.astype(np.float64),
+                                      g[f"{cluster_col}_{tag}_values"])
+    with pytest.raises(ValueError):
+        cell_cluster_utils.create_c2pc_data(fovs, str(pix), cell_path, "pixel_meta_cluster")
+
+
 def test_fov_table_helpers(tmp_path):
     """Footer-only column listing, natural ordering, prefetcher / writer round trip, damaged files."""
     from ark_analysis_amd.fov_tables import FovTableDir, TablePrefetcher, TableWriter
