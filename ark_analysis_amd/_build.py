@@ -3,6 +3,8 @@
 The shared object sits next to this file so that it travels with the source tree (gpurun
 snapshots, no site-packages install).  hipcc cross-compiles without a GPU.
 """
+import fcntl
+import hashlib
 import os
 import shutil
 import subprocess
@@ -26,46 +28,71 @@ def _hipcc() -> str:
     return exe
 
 
+HEADERS = ["pxsom_common.h", "pxsom_assign.h", "pxsom_wave.h"]
+STAMP_PATH = SO_PATH + ".srchash"
+
+
+def _source_digest() -> str:
+    """sha256 over every input of the build (sources, headers, flags).  Content, not mtimes: a tree copied
+    to another box (gpurun snapshot, rsync) keeps its prebuilt library valid whatever the copy did to the
+    timestamps."""
+    h = hashlib.sha256()
+    files = [os.path.join(_PKG, "csrc", f) for f in SOURCES + HEADERS] + [os.path.join(_ROOT, "include", "pxsom.h")]
+    for path in files:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    h.update(repr((HIPCC_FLAGS, sorted(EXTRA_FLAGS.items()))).encode())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
-    if not os.path.exists(SO_PATH):
+    if not (os.path.exists(SO_PATH) and os.path.exists(STAMP_PATH)):
         return True
-    so_m = os.path.getmtime(SO_PATH)
-    deps = [os.path.join(_PKG, "csrc", s) for s in SOURCES if os.path.exists(os.path.join(_PKG, "csrc", s))]
-    deps += [os.path.join(_PKG, "csrc", "pxsom_common.h"), os.path.join(_PKG, "csrc", "pxsom_assign.h"),
-             os.path.join(_ROOT, "include", "pxsom.h")]
-    return any(os.path.getmtime(d) > so_m for d in deps)
+    with open(STAMP_PATH) as f:
+        return f.read().strip() != _source_digest()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 and link libpxsom.so.  Returns its path."""
+    """Compile every HIP source for gfx950 and link libpxsom.so.  Returns its path.
+    Safe to call from several processes at once (one rank per GPU): an exclusive file lock lets one of
+    them build while the others wait and then find the library up to date."""
     if not force and not needs_build():
         return SO_PATH
+    with open(os.path.join(_PKG, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():
+                return SO_PATH
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose: bool) -> str:
     hipcc = _hipcc()
     objdir = os.path.join(_PKG, "csrc", "_obj")
     os.makedirs(objdir, exist_ok=True)
-    objs = []
-    procs = []
+    jobs = []
     for src in SOURCES:
-        sp = os.path.join(_PKG, "csrc", src)
-        if not os.path.exists(sp):
-            continue
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         cmd = [hipcc, *HIPCC_FLAGS, *EXTRA_FLAGS.get(src, []), "-I", os.path.join(_ROOT, "include"), "-I",
-               os.path.join(_PKG, "csrc"), "-c", sp, "-o", obj]
+               os.path.join(_PKG, "csrc"), "-c", os.path.join(_PKG, "csrc", src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(obj)
-    for src, p in procs:
-        out, _ = p.communicate()
-        if p.returncode != 0:
+        jobs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, _, proc in jobs:   # the translation units compile side by side
+        out, _ = proc.communicate()
+        if proc.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode(errors='replace')}")
         if verbose and out:
             print(out.decode(errors="replace"))
     tmp = SO_PATH + ".tmp"
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", tmp]
-    subprocess.check_call(cmd)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[o for _, o, _ in jobs], "-o", tmp])
     os.replace(tmp, SO_PATH)
+    with open(STAMP_PATH + ".tmp", "w") as f:
+        f.write(_source_digest() + "\n")
+    os.replace(STAMP_PATH + ".tmp", STAMP_PATH)
     return SO_PATH
 
 
