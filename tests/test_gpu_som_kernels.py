@@ -60,6 +60,31 @@ def test_assign_matches_oracle(gpu, oracle, n, c, k, dtype):
     assert got.min() >= 1 and got.max() <= k
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_assign_random_shapes_against_oracle(gpu, oracle, seed):
+    """Seeded sweep over shapes / dtypes / degeneracies nobody hand-picked: every label must equal the
+    oracle's (first strict minimum), whatever path (fast / generic filter, exact) the shape takes."""
+    rs = np.random.RandomState(1000 + seed)
+    n = int(rs.choice([1, 2, 63, 64, 65, 257, 1000, 4097, 20_000]))
+    c = int(rs.choice([1, 2, 3, 8, 15, 22, 32, 33, 40, 64, 100, 128]))
+    k = int(rs.choice([1, 2, 16, 17, 97, 100, 128, 200, 400, 1024]))
+    dtype = [np.float16, np.float32, np.float64][seed % 3]
+    scale = float(rs.choice([1e-3, 1.0, 50.0])) if dtype != np.float16 else 1.0
+    x = (rs.gamma(0.7, 0.4, size=(n, c)) * scale).astype(dtype)
+    x[rs.uniform(size=x.shape) < 0.15] = 0
+    w = x[rs.randint(0, n, size=k)].astype(np.float64)              # nodes are data rows: exact zero distances
+    w += (rs.uniform(size=(k, 1)) < 0.5) * 1e-3 * scale * rs.standard_normal((k, c))
+    if k > 3:
+        w[k // 2] = w[0]                                                # duplicate node: the lower index must win
+        w[k - 1] = np.nextafter(w[1], np.inf)                           # one-ulp neighbour
+    if n > 10:
+        x[3] = x[7]
+        x[5] = 0
+    got, _ = _gpu_assign(gpu, x, w)
+    want, _ = oracle.map_data_to_nodes(w, x.astype(np.float64))
+    np.testing.assert_array_equal(got, want)
+
+
 def test_assign_empty(gpu):
     x = torch.empty((0, 22), dtype=torch.float32, device=gpu)
     w = torch.rand((100, 22), dtype=torch.float64, device=gpu)
