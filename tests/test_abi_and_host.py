@@ -45,6 +45,41 @@ def test_argument_validation_without_gpu():
     assert rc == -1
     with pytest.raises(_capi.PxsomError):
         _capi.check(rc, "pxsom_cluster_sums")
+    # dtype codes: 0 / 1 / 2 (fp32 / fp64 / fp16) are accepted, anything else is not
+    assert lib.pxsom_cluster_sums(None, 0, 22, 22, 2, None, 100, None, None, None) == -1   # null tables, dtype ok
+    assert lib.pxsom_cluster_sums(None, 0, 22, 22, 3, None, 100, None, None, None) == -2
+    rc = lib.pxsom_batch_update_prepare(None, 10, 10, 22, None, 1.0, 0.05, None, 0, None)
+    assert rc == -1 and b"null" in lib.pxsom_last_error()
+    rc = lib.pxsom_batch_update_prepare(None, 40, 40, 22, None, 1.0, 0.05, None, 0, None)
+    assert rc == -2
+    rc = lib.pxsom_batch_accumulate(None, 10, 22, 22, 0, None, 100, None, None, None, 0, 0, None)
+    assert rc == -1
+    rc = lib.pxsom_pair_histogram(None, None, 10, 0, 5, None, None)
+    assert rc == -1 and b"sizes" in lib.pxsom_last_error()
+    assert lib.pxsom_pair_histogram(None, None, 10, 5, 5, None, None) == -1
+
+
+def test_pipeline_stays_loud_without_gpu(tmp_path):
+    """cluster_pixels on a CPU box must raise (no silent CPU route through the Arrow fast path either)."""
+    if torch.cuda.is_available():
+        pytest.skip("CPU-box behaviour")
+    import pandas as pd
+    from ark_analysis_amd import flowsom
+    from ark_analysis_amd.fov_tables import write_dataframe
+    from ark_analysis_amd.phenotyping import cluster_helpers, pixel_som_clustering
+    chans = ["a", "b"]
+    for d in ("pixel_mat_data", "pixel_mat_subsetted"):
+        (tmp_path / d).mkdir()
+        df = pd.DataFrame(np.random.rand(50, 2), columns=chans)
+        df["fov"], df["row_index"], df["column_index"] = "fov0", 0, 0
+        write_dataframe(df, str(tmp_path / d / "fov0.feather"))
+    write_dataframe(pd.DataFrame(np.ones((1, 2)), columns=chans), str(tmp_path / "norm.feather"))
+    write_dataframe(pd.DataFrame(np.random.rand(4, 2), columns=chans), str(tmp_path / "w.feather"))
+    som = cluster_helpers.PixelSOMCluster(str(tmp_path / "pixel_mat_subsetted"), str(tmp_path / "norm.feather"),
+                                          str(tmp_path / "w.feather"), ["fov0"], chans, xdim=2, ydim=2)
+    assert som.weights is not None and flowsom.map_data_to_nodes is not None
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        pixel_som_clustering.cluster_pixels(["fov0"], str(tmp_path), som)
 
 
 def test_glibc_rand_host_helper_matches_libc():
