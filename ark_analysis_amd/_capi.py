@@ -40,11 +40,13 @@ SYMBOLS = {
     "pxsom_train_online": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _i32, _i32, _i32, _f64, _f64,
                                   _f64, _f64, _vp, _vp]),
     "pxsom_batch_accumulate": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _sz, _i32, _vp]),
+    "pxsom_quantile_f32": (_i32, [_vp, _i64, _i32, _i64, _f64, _i32, _vp, _vp, _sz, _vp]),
+    "pxsom_scaled_rowsum_f32": (_i32, [_vp, _i64, _i32, _i64, _vp, _vp, _vp]),
     "pxsom_pair_histogram": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
     "pxsom_batch_update_prepare": (_i32, [_vp, _i32, _i32, _i32, _vp, _f64, _f64, _vp, _sz, _vp]),
-    "pxsom_gaussian_blur_hwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "pxsom_gaussian_blur_hwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
     "pxsom_rownorm_workspace_bytes": (_sz, [_i64]),
-    "pxsom_rowsum_filter_normalize": (_i32, [_vp, _i64, _i32, _f64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pxsom_rowsum_filter_normalize": (_i32, [_vp, _i64, _i32, _f64, _vp, _vp, _vp, _vp, _sz, _i32, _vp]),
     "pxsom_normalize_columns": (_i32, [_vp, _i64, _i32, _i64, _vp, _vp, _i64, _vp]),
     "pxsom_quantile_workspace_bytes": (_sz, [_i64, _i32]),
     "pxsom_quantile_nonzero": (_i32, [_vp, _i64, _i32, _i64, _f64, _i32, _vp, _vp, _sz, _vp]),

@@ -47,7 +47,9 @@ __device__ __forceinline__ int reflect_idx(int i, int len)
 //   tmp = in[0]*w[0];  for d = r .. 1:  tmp += (in[-d] + in[+d]) * w[d]
 // AXIS 0: along image rows (stride W*C), AXIS 1: along image columns (stride C).
 // Thread <-> one output element; consecutive threads walk (x, c), so every tap is a coalesced read.
-template <int AXIS>
+// R32: the image holds float32 values (widened): scipy then computes each line in binary64 but stores the pass's
+// result as float32, so each pass rounds its output to float32.
+template <int AXIS, bool R32>
 __global__ __launch_bounds__(256) void blur_pass_kernel(const double *__restrict__ in, double *__restrict__ out,
                                                         int H, int W, int C, Taps taps)
 {
@@ -67,28 +69,41 @@ __global__ __launch_bounds__(256) void blur_pass_kernel(const double *__restrict
             const int hi = interior ? pos + d : reflect_idx(pos + d, len);
             tmp += (in[base + (int64_t)lo * stride] + in[base + (int64_t)hi * stride]) * taps.w[d];
         }
-        out[e] = tmp;
+        out[e] = R32 ? (double)(float)tmp : tmp;
     }
 }
 
 // ---- row filter + normalise + compaction ---------------------------------------------------------
 // pass A: keep flag per row and per-workgroup kept counts; pass B: exclusive scan of the counts (one
 // workgroup); pass C: rows rewritten as x / rowsum at their compacted position, in pixel order.
-__device__ __forceinline__ bool row_keep(const double *__restrict__ row, int c, double thresh, double &s)
+// f32: the matrix holds float32 values (widened) and pandas works on a float32 frame: sum and division in
+// binary32.
+__device__ __forceinline__ bool row_keep(const double *__restrict__ row, int c, double thresh, double &s, int f32)
 {
-    double acc = 0.0;  // left-to-right, as pandas' DataFrame.sum(axis=1) adds the columns
     bool any = false;
-    for (int j = 0; j < c; j++) {
-        const double v = row[j];
-        acc += v;
-        any |= (v != 0.0);
+    if (f32) {
+        float acc = 0.f;
+        for (int j = 0; j < c; j++) {
+            const float v = (float)row[j];
+            acc += v;
+            any |= (v != 0.f);
+        }
+        s = (double)acc;
+    } else {
+        double acc = 0.0;  // left-to-right, as pandas' DataFrame.sum(axis=1) adds the columns
+        for (int j = 0; j < c; j++) {
+            const double v = row[j];
+            acc += v;
+            any |= (v != 0.0);
+        }
+        s = acc;
     }
-    s = acc;
-    return (acc > thresh) && any;
+    return (s > thresh) && any;
 }
 
 __global__ __launch_bounds__(256) void rowfilter_count_kernel(const double *__restrict__ x, int64_t n, int c,
-                                                              double thresh, unsigned *__restrict__ block_counts)
+                                                              double thresh, unsigned *__restrict__ block_counts,
+                                                              int f32)
 {
     __shared__ unsigned s_cnt;
     if (threadIdx.x == 0) s_cnt = 0;
@@ -97,7 +112,7 @@ __global__ __launch_bounds__(256) void rowfilter_count_kernel(const double *__re
     bool keep = false;
     if (row < n) {
         double s;
-        keep = row_keep(x + row * c, c, thresh, s);
+        keep = row_keep(x + row * c, c, thresh, s, f32);
     }
     const unsigned long long m = __ballot(keep);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(&s_cnt, (unsigned)__popcll(m));
@@ -136,14 +151,14 @@ __global__ __launch_bounds__(1024) void block_scan_kernel(unsigned *__restrict__
 __global__ __launch_bounds__(256) void rowfilter_write_kernel(const double *__restrict__ x, int64_t n, int c,
                                                               double thresh, const unsigned *__restrict__ block_off,
                                                               double *__restrict__ out_rows,
-                                                              int64_t *__restrict__ out_index)
+                                                              int64_t *__restrict__ out_index, int f32)
 {
     __shared__ unsigned s_wave[4];
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     bool keep = false;
     double s = 0.0;
-    if (row < n) keep = row_keep(x + row * c, c, thresh, s);
+    if (row < n) keep = row_keep(x + row * c, c, thresh, s, f32);
     const unsigned long long m = __ballot(keep);
     if (lane == 0) s_wave[wv] = (unsigned)__popcll(m);
     __syncthreads();
@@ -153,7 +168,10 @@ __global__ __launch_bounds__(256) void rowfilter_write_kernel(const double *__re
         const int64_t dst = (int64_t)off + __popcll(m & ((1ull << lane) - 1ull));
         const double *src = x + row * c;
         double *d = out_rows + dst * c;
-        for (int j = 0; j < c; j++) d[j] = src[j] / s;
+        if (f32)
+            for (int j = 0; j < c; j++) d[j] = (double)((float)src[j] / (float)s);
+        else
+            for (int j = 0; j < c; j++) d[j] = src[j] / s;
         out_index[dst] = row;
     }
 }
@@ -182,7 +200,11 @@ __device__ __forceinline__ double key_f64(unsigned long long k)
     const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
     return __longlong_as_double((long long)b);
 }
-__device__ __forceinline__ bool q_keep(double v, int keep_mode) { return keep_mode == 0 ? (v != 0.0 && v == v) : (v > 0.0); }
+// keep_mode 0: != 0 and not NaN (pandas replace(0, nan)); 1: > 0 (img[img > 0]); 2: everything but NaN
+__device__ __forceinline__ bool q_keep(double v, int keep_mode)
+{
+    return keep_mode == 0 ? (v != 0.0 && v == v) : (keep_mode == 1 ? v > 0.0 : v == v);
+}
 
 struct QState {              // per column, in the workspace
     unsigned long long prefix;   // key bits fixed so far (high bits)
@@ -194,7 +216,8 @@ struct QState {              // per column, in the workspace
 
 // pass (shift = 56, 48, ..., 0): histogram of byte (key >> shift) over kept values whose higher bits equal
 // prefix.  hist [c][256] u64 in the workspace (zeroed before every pass).
-__global__ __launch_bounds__(256) void q_hist_kernel(const double *__restrict__ x, int64_t n, int c, int64_t ldx,
+template <typename T>
+__global__ __launch_bounds__(256) void q_hist_kernel(const T *__restrict__ x, int64_t n, int c, int64_t ldx,
                                                      int keep_mode, int shift, const QState *__restrict__ st,
                                                      unsigned long long *__restrict__ hist, int first_pass)
 {
@@ -205,7 +228,7 @@ __global__ __launch_bounds__(256) void q_hist_kernel(const double *__restrict__ 
     const unsigned long long prefix = first_pass ? 0ull : st[col].prefix;
     const unsigned long long himask = shift >= 56 ? 0ull : (~0ull << (shift + 8));
     for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < n; row += (int64_t)gridDim.x * 256) {
-        const double v = x[row * ldx + col];
+        const double v = (double)x[row * ldx + col];   // binary32 values are exact in binary64
         if (!q_keep(v, keep_mode)) continue;
         const unsigned long long k = f64_key(v);
         if ((k & himask) != (prefix & himask)) continue;
@@ -217,7 +240,10 @@ __global__ __launch_bounds__(256) void q_hist_kernel(const double *__restrict__ 
 
 // one thread per column: locate the bucket holding `rank`, narrow the prefix.  On the first pass also
 // derive m and the target rank lo = floor(q*(m-1)).
-__global__ void q_select_kernel(QState *st, unsigned long long *hist, int c, int shift, double q, int first_pass)
+// arith32: the virtual index is formed in binary32 -- what numpy does for a float32 array
+// (q is cast to the array's dtype, then (n-1)*q, floor and the fraction are all float32).
+__global__ void q_select_kernel(QState *st, unsigned long long *hist, int c, int shift, double q, int first_pass,
+                                int arith32)
 {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= c) return;
@@ -228,7 +254,7 @@ __global__ void q_select_kernel(QState *st, unsigned long long *hist, int c, int
         for (int b = 0; b < 256; b++) m += h[b];
         s.m = m;
         s.prefix = 0;
-        double vi = q * (double)(m > 0 ? m - 1 : 0);
+        const double vi = arith32 ? (double)((float)(m > 0 ? m - 1 : 0) * (float)q) : q * (double)(m > 0 ? m - 1 : 0);
         unsigned long long lo = (unsigned long long)floor(vi);
         if (m > 0 && lo > m - 1) lo = m - 1;
         s.rank = lo;
@@ -250,7 +276,8 @@ __global__ void q_select_kernel(QState *st, unsigned long long *hist, int c, int
 
 // after the last pass prefix == key of the order statistic lo.  One more sweep: count keys <= lo_key and
 // find the smallest key above it (the next order statistic unless lo_key is repeated).
-__global__ __launch_bounds__(256) void q_next_kernel(const double *__restrict__ x, int64_t n, int c, int64_t ldx,
+template <typename T>
+__global__ __launch_bounds__(256) void q_next_kernel(const T *__restrict__ x, int64_t n, int c, int64_t ldx,
                                                      int keep_mode, QState *st)
 {
     __shared__ unsigned long long s_min;
@@ -265,7 +292,7 @@ __global__ __launch_bounds__(256) void q_next_kernel(const double *__restrict__ 
     unsigned long long mymin = ~0ull;
     unsigned mycnt = 0;
     for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < n; row += (int64_t)gridDim.x * 256) {
-        const double v = x[row * ldx + col];
+        const double v = (double)x[row * ldx + col];
         if (!q_keep(v, keep_mode)) continue;
         const unsigned long long k = f64_key(v);
         if (k <= lo_key) mycnt++;
@@ -281,13 +308,25 @@ __global__ __launch_bounds__(256) void q_next_kernel(const double *__restrict__ 
 }
 
 // numpy's linear interpolation (_lerp): a + (b-a)*g for g < 0.5, b - (b-a)*(1-g) otherwise.
-__global__ void q_finish_kernel(const QState *st, int c, double q, double *out)
+__global__ void q_finish_kernel(const QState *st, int c, double q, double *out, int arith32)
 {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= c) return;
     const QState s = st[col];
     if (s.m == 0) {
         out[col] = __longlong_as_double(0x7ff8000000000000ll);  // NaN, like pandas for an all-zero column
+        return;
+    }
+    if (arith32) {  // numpy on a float32 array: index, fraction and interpolation in binary32
+        const float vi = (float)(s.m - 1) * (float)q;
+        unsigned long long lo = (unsigned long long)floorf(vi);
+        if (lo > s.m - 1) lo = s.m - 1;
+        const unsigned long long hi = lo + 1 > s.m - 1 ? s.m - 1 : lo + 1;
+        const float g = vi - (float)lo;
+        const float a = (float)key_f64(s.prefix);
+        const float b = (hi == lo || s.count_le > hi) ? a : (float)key_f64(s.hi_key);
+        const float diff = b - a;
+        out[col] = (double)(g >= 0.5f ? b - diff * (1.0f - g) : a + diff * g);
         return;
     }
     const double vi = q * (double)(s.m - 1);
@@ -321,7 +360,7 @@ __global__ void q_init_kernel(QState *st, int c)
 }  // namespace
 
 PXSOM_EXPORT int pxsom_gaussian_blur_hwc(double *img_dev, double *tmp_dev, int h, int w, int c,
-                                         const double *weights_host, int radius, void *stream)
+                                         const double *weights_host, int radius, int f32_semantics, void *stream)
 {
     if (!img_dev || !tmp_dev || !weights_host || h < 1 || w < 1 || c < 1)
         return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_gaussian_blur_hwc: bad arguments");
@@ -334,10 +373,14 @@ PXSOM_EXPORT int pxsom_gaussian_blur_hwc(double *img_dev, double *tmp_dev, int h
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int64_t total = (int64_t)h * w * c;
     const int grid = (int)std::min<int64_t>((total + 255) / 256, (int64_t)pxsom::device_cu_count() * 16);
-    hipLaunchKernelGGL(blur_pass_kernel<0>, dim3(grid), dim3(256), 0, st, img_dev, tmp_dev, h, w, c, taps);
-    PXSOM_LAUNCH_CHECK("blur_pass_kernel<0>");
-    hipLaunchKernelGGL(blur_pass_kernel<1>, dim3(grid), dim3(256), 0, st, tmp_dev, img_dev, h, w, c, taps);
-    PXSOM_LAUNCH_CHECK("blur_pass_kernel<1>");
+    if (f32_semantics) {
+        hipLaunchKernelGGL((blur_pass_kernel<0, true>), dim3(grid), dim3(256), 0, st, img_dev, tmp_dev, h, w, c, taps);
+        hipLaunchKernelGGL((blur_pass_kernel<1, true>), dim3(grid), dim3(256), 0, st, tmp_dev, img_dev, h, w, c, taps);
+    } else {
+        hipLaunchKernelGGL((blur_pass_kernel<0, false>), dim3(grid), dim3(256), 0, st, img_dev, tmp_dev, h, w, c, taps);
+        hipLaunchKernelGGL((blur_pass_kernel<1, false>), dim3(grid), dim3(256), 0, st, tmp_dev, img_dev, h, w, c, taps);
+    }
+    PXSOM_LAUNCH_CHECK("blur_pass_kernel");
     return PXSOM_OK;
 }
 
@@ -349,7 +392,8 @@ PXSOM_EXPORT size_t pxsom_rownorm_workspace_bytes(int64_t n)
 
 PXSOM_EXPORT int pxsom_rowsum_filter_normalize(const double *x_dev, int64_t n, int c, double thresh,
                                                double *out_rows_dev, int64_t *out_index_dev, int64_t *out_count_dev,
-                                               void *workspace_dev, size_t workspace_bytes, void *stream)
+                                               void *workspace_dev, size_t workspace_bytes, int f32_semantics,
+                                               void *stream)
 {
     if (n < 0 || n > 0x7fffffffLL || c < 1 || !out_count_dev || (n > 0 && (!x_dev || !out_rows_dev || !out_index_dev)))
         return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_rowsum_filter_normalize: bad arguments");
@@ -362,12 +406,13 @@ PXSOM_EXPORT int pxsom_rowsum_filter_normalize(const double *x_dev, int64_t n, i
     }
     unsigned *counts = reinterpret_cast<unsigned *>(workspace_dev);
     const int64_t nblocks = (n + 255) / 256;
-    hipLaunchKernelGGL(rowfilter_count_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, x_dev, n, c, thresh, counts);
+    hipLaunchKernelGGL(rowfilter_count_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, x_dev, n, c, thresh, counts,
+                       f32_semantics);
     PXSOM_LAUNCH_CHECK("rowfilter_count_kernel");
     hipLaunchKernelGGL(block_scan_kernel, dim3(1), dim3(1024), 0, st, counts, nblocks, out_count_dev);
     PXSOM_LAUNCH_CHECK("block_scan_kernel");
     hipLaunchKernelGGL(rowfilter_write_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, x_dev, n, c, thresh, counts,
-                       out_rows_dev, out_index_dev);
+                       out_rows_dev, out_index_dev, f32_semantics);
     PXSOM_LAUNCH_CHECK("rowfilter_write_kernel");
     return PXSOM_OK;
 }
@@ -392,14 +437,16 @@ PXSOM_EXPORT size_t pxsom_quantile_workspace_bytes(int64_t n, int c)
     return pxsom::align_up((size_t)c * sizeof(QState), 256) + (size_t)c * 256 * sizeof(unsigned long long);
 }
 
-PXSOM_EXPORT int pxsom_quantile_nonzero(const double *x_dev, int64_t n, int c, int64_t ldx, double q, int keep_mode,
-                                        double *out_dev, void *workspace_dev, size_t workspace_bytes, void *stream)
+namespace {
+template <typename T>
+int quantile_typed(const char *fn, const T *x_dev, int64_t n, int c, int64_t ldx, double q, int keep_mode,
+                   double *out_dev, void *workspace_dev, size_t workspace_bytes, int arith32, hipStream_t st)
 {
-    if (n < 0 || c < 1 || c > 65535 || ldx < c || !(q >= 0.0 && q <= 1.0) || !out_dev || (n > 0 && !x_dev))
-        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_quantile_nonzero: bad arguments");
+    if (n < 0 || c < 1 || c > 65535 || ldx < c || !(q >= 0.0 && q <= 1.0) || !out_dev || (n > 0 && !x_dev) ||
+        keep_mode < 0 || keep_mode > 2)
+        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "%s: bad arguments", fn);
     if (!workspace_dev || workspace_bytes < pxsom_quantile_workspace_bytes(n, c))
-        return pxsom::fail(PXSOM_ERR_WORKSPACE, "pxsom_quantile_nonzero: workspace too small");
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+        return pxsom::fail(PXSOM_ERR_WORKSPACE, "%s: workspace too small", fn);
     QState *qs = reinterpret_cast<QState *>(workspace_dev);
     unsigned long long *hist =
         reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(workspace_dev) + pxsom::align_up((size_t)c * sizeof(QState), 256));
@@ -409,12 +456,78 @@ PXSOM_EXPORT int pxsom_quantile_nonzero(const double *x_dev, int64_t n, int c, i
     int rgrid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)pxsom::device_cu_count() * 2);
     if (rgrid < 1) rgrid = 1;
     for (int shift = 56, first = 1; shift >= 0; shift -= 8, first = 0) {
-        hipLaunchKernelGGL(q_hist_kernel, dim3(rgrid, c), dim3(256), 0, st, x_dev, n, c, ldx, keep_mode, shift, qs, hist,
-                           first);
-        hipLaunchKernelGGL(q_select_kernel, dim3(cgrid), dim3(64), 0, st, qs, hist, c, shift, q, first);
+        hipLaunchKernelGGL(q_hist_kernel<T>, dim3(rgrid, c), dim3(256), 0, st, x_dev, n, c, ldx, keep_mode, shift, qs,
+                           hist, first);
+        hipLaunchKernelGGL(q_select_kernel, dim3(cgrid), dim3(64), 0, st, qs, hist, c, shift, q, first, arith32);
     }
-    hipLaunchKernelGGL(q_next_kernel, dim3(rgrid, c), dim3(256), 0, st, x_dev, n, c, ldx, keep_mode, qs);
-    hipLaunchKernelGGL(q_finish_kernel, dim3(cgrid), dim3(64), 0, st, qs, c, q, out_dev);
-    PXSOM_LAUNCH_CHECK("pxsom_quantile_nonzero");
+    hipLaunchKernelGGL(q_next_kernel<T>, dim3(rgrid, c), dim3(256), 0, st, x_dev, n, c, ldx, keep_mode, qs);
+    hipLaunchKernelGGL(q_finish_kernel, dim3(cgrid), dim3(64), 0, st, qs, c, q, out_dev, arith32);
+    PXSOM_LAUNCH_CHECK(fn);
+    return PXSOM_OK;
+}
+}  // namespace
+
+PXSOM_EXPORT int pxsom_quantile_nonzero(const double *x_dev, int64_t n, int c, int64_t ldx, double q, int keep_mode,
+                                        double *out_dev, void *workspace_dev, size_t workspace_bytes, void *stream)
+{
+    return quantile_typed<double>("pxsom_quantile_nonzero", x_dev, n, c, ldx, q, keep_mode, out_dev, workspace_dev,
+                                  workspace_bytes, 0, reinterpret_cast<hipStream_t>(stream));
+}
+
+// float32 columns with numpy's float32 arithmetic (np.quantile on a float32 image: the TIFF-side percentiles
+// of calculate_channel_percentiles / calculate_pixel_intensity_percentile).  out_dev holds the float32
+// results widened to binary64.
+PXSOM_EXPORT int pxsom_quantile_f32(const float *x_dev, int64_t n, int c, int64_t ldx, double q, int keep_mode,
+                                    double *out_dev, void *workspace_dev, size_t workspace_bytes, void *stream)
+{
+    return quantile_typed<float>("pxsom_quantile_f32", x_dev, n, c, ldx, q, keep_mode, out_dev, workspace_dev,
+                                 workspace_bytes, 1, reinterpret_cast<hipStream_t>(stream));
+}
+
+// out[i] = sum_j img[i, j] / norm[j] in float32, added up the way numpy adds a contiguous float32 axis of at
+// most 128 elements (np.sum(img / norm_vect, axis=-1), pixel_cluster_utils.py:96-101): fewer than 8 terms
+// left to right; otherwise eight running sums over blocks of 8, combined ((0+1)+(2+3))+((4+5)+(6+7)), then the
+// remaining terms one by one.
+namespace {
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void scaled_rowsum_f32_kernel(const float *__restrict__ img, int64_t n, int c,
+                                                                int64_t ldx, const float *__restrict__ norm,
+                                                                float *__restrict__ out)
+{
+    for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < n; row += (int64_t)gridDim.x * 256) {
+        const float *p = img + row * ldx;
+        float res;
+        if (c < 8) {
+            res = 0.f;
+            for (int j = 0; j < c; j++) res += p[j] / norm[j];
+        } else {
+            float r[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) r[j] = p[j] / norm[j];
+            int i = 8;
+            for (; i < c - (c % 8); i += 8) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) r[j] += p[i + j] / norm[i + j];
+            }
+            res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+            for (; i < c; i++) res += p[i] / norm[i];
+        }
+        out[row] = res;
+    }
+}
+#pragma clang fp contract(fast)
+}  // namespace
+
+PXSOM_EXPORT int pxsom_scaled_rowsum_f32(const float *img_dev, int64_t n, int c, int64_t ldx, const float *norm_dev,
+                                         float *out_dev, void *stream)
+{
+    if (n < 0 || c < 1 || c > 128 || ldx < c || !norm_dev || (n > 0 && (!img_dev || !out_dev)))
+        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_scaled_rowsum_f32: bad arguments (c <= 128)");
+    if (n == 0) return PXSOM_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t grid = std::min<int64_t>((n + 255) / 256, (int64_t)pxsom::device_cu_count() * 16);
+    hipLaunchKernelGGL(scaled_rowsum_f32_kernel, dim3((unsigned)grid), dim3(256), 0, st, img_dev, n, c, ldx, norm_dev,
+                       out_dev);
+    PXSOM_LAUNCH_CHECK("scaled_rowsum_f32_kernel");
     return PXSOM_OK;
 }

@@ -129,3 +129,33 @@ def pair_histogram(a, b, na: int, nb: int) -> np.ndarray:
     ad = torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
     bd = torch.from_numpy(np.ascontiguousarray(b, dtype=np.int32)).to(dev)
     return som_device.pair_histogram(ad, bd, int(na), int(nb)).cpu().numpy()
+
+
+def positive_quantile_f32(image, q: float):
+    """``np.quantile(image[image > 0], q)`` for a float32 image (NaN if nothing is positive): the per-channel
+    percentile of calculate_channel_percentiles (pixel_cluster_utils.py:41-51)."""
+    import torch
+    from . import _capi, som_device
+    dev = _capi.require_gpu()
+    image = np.asarray(image)
+    if image.dtype == np.float32:
+        flat = torch.from_numpy(np.ascontiguousarray(image).reshape(-1, 1)).to(dev)
+        return som_device.quantile_f32(flat, q, keep_mode=1).cpu().numpy()[0]
+    # integer / float64 images: numpy interpolates those in binary64
+    flat = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float64).reshape(-1, 1)).to(dev)
+    return som_device.quantile_nonzero(flat, q, keep_mode=1).cpu().numpy()[0]
+
+
+def total_intensity_quantile_f32(image_hwc, norm, q: float):
+    """``np.quantile(np.sum(image / norm, axis=-1), q)`` for a float32 [H, W, C] image and float32 [C]
+    divisors: the per-FOV percentile of calculate_pixel_intensity_percentile (:96-103)."""
+    import torch
+    from . import _capi, som_device
+    dev = _capi.require_gpu()
+    if np.asarray(image_hwc).dtype != np.float32 or np.asarray(norm).dtype != np.float32:
+        raise TypeError("total_intensity_quantile_f32 reproduces numpy's float32 arithmetic: it needs float32 "
+                        "images (MIBI / MPLEX exports) and the float32 channel percentiles computed from them")
+    img = np.ascontiguousarray(image_hwc, dtype=np.float32)
+    pixels = torch.from_numpy(img.reshape(-1, img.shape[-1])).to(dev)
+    sums = som_device.scaled_rowsum_f32(pixels, torch.from_numpy(np.ascontiguousarray(norm, dtype=np.float32)).to(dev))
+    return som_device.quantile_f32(sums.reshape(-1, 1), q, keep_mode=2).cpu().numpy()[0]

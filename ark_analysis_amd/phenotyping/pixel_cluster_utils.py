@@ -1,6 +1,7 @@
 """The parts of ``ark.phenotyping.pixel_cluster_utils`` that sit on the Pixie SOM path
 (/root/reference/src/ark/phenotyping/pixel_cluster_utils.py): row normalisation (:109-142), the
-per-cluster mean-expression table (:294-416) and the restart helper (:419-478).  Same names, arguments,
+per-cluster mean-expression table (:294-416), the restart helper (:419-478) and the TIFF-side percentiles
+that feed ``create_pixel_matrix`` (:16-106, :145-181; numpy's float32 arithmetic reproduced on the device).  Same names, arguments,
 error / warning texts and results; the TIFF-bound helpers of that module are out of scope (SURVEY.md
 section 8).  The per-cluster reduction is one accumulating device pass per FOV (pxsom_cluster_sums:
 binary64 sums, int64 counts) instead of a pandas groupby per FOV plus a groupby over the concatenation.
@@ -12,9 +13,51 @@ import warnings
 import numpy as np
 import pandas as pd
 
-from .. import flowsom
+from .. import flowsom, image_io
 from ..fov_tables import UNREADABLE, FovTableDir
-from ..host_utils import validate_paths, verify_in_list
+from ..host_utils import natsort_key, validate_paths, verify_in_list
+
+
+def calculate_channel_percentiles(tiff_dir, fovs, channels, img_sub_folder, percentile):
+    """One normalisation value per channel: the ``percentile`` quantile of the positive pixels of each
+    FOV's channel image, averaged over the FOVs that have any (reference: pixel_cluster_utils.py:16-58).
+    Returns a one-row DataFrame, columns naturally sorted."""
+    per_channel = []
+    for channel in channels:
+        found = []
+        for fov in fovs:
+            value = flowsom.positive_quantile_f32(image_io.read_channel(tiff_dir, fov, channel, img_sub_folder),
+                                                  percentile)
+            if not np.isnan(value):     # a channel image without positive pixels contributes nothing
+                found.append(value)
+        per_channel.append(np.mean(found))
+    table = pd.DataFrame(np.expand_dims(per_channel, axis=0), columns=channels)
+    return table[sorted(table.columns, key=natsort_key)]
+
+
+def calculate_pixel_intensity_percentile(tiff_dir, fovs, channels, img_sub_folder, channel_percentiles,
+                                         percentile=0.05):
+    """Mean over FOVs of the ``percentile`` quantile of the per-pixel total signal, each channel first
+    divided by its normalisation value (reference: pixel_cluster_utils.py:61-106)."""
+    divisors = channel_percentiles.iloc[0].values
+    per_fov = [flowsom.total_intensity_quantile_f32(image_io.read_channels(tiff_dir, fov, channels, img_sub_folder),
+                                                    divisors, percentile)
+               for fov in fovs]
+    return np.mean(per_fov)
+
+
+def check_for_modified_channels(tiff_dir, test_fov, img_sub_folder, channels):
+    """Warn when a selected channel also exists in a post-processed variant (``_smoothed``,
+    ``_nuc_include``, ``_nuc_exclude``) the user may have meant (reference: pixel_cluster_utils.py:145-181)."""
+    present = set(image_io.channel_names(tiff_dir, test_fov, img_sub_folder))
+    for channel in channels:
+        for suffix in ('_smoothed', '_nuc_include', '_nuc_exclude'):
+            variant = channel + suffix
+            if variant in present:
+                warnings.warn('You selected {} as the channel to analyze, but there were potential'
+                              ' modified channels found: {}. Make sure you selected the correct '
+                              'version of the channel for inclusion in '
+                              'clustering'.format(channel, variant))
 
 
 def normalize_rows(pixel_data, channels, include_seg_label=True):

@@ -19,11 +19,16 @@ def create_fov_pixel_data(fov, channels, img_data, seg_labels, pixel_thresh_val,
     dev = _capi.require_gpu()
     channels.sort(key=natsort_key)                       # in place, like the reference (:44)
     h, w = img_data.shape[0], img_data.shape[1]
+    # float32 images (what preprocess_fov passes for float32 TIFFs) keep float32 semantics end to end: scipy
+    # stores each blur pass as float32, pandas sums and divides the float32 frame in binary32
+    f32 = np.asarray(img_data).dtype == np.float32
     img = torch.from_numpy(np.ascontiguousarray(img_data[:, :, :len(channels)], dtype=np.float64)).to(dev)
-    som_device.gaussian_blur_hwc(img, float(blur_factor))
-    rows, kept = som_device.rowsum_filter_normalize(img.view(h * w, len(channels)), float(pixel_thresh_val))
+    som_device.gaussian_blur_hwc(img, float(blur_factor), f32_semantics=f32)
+    rows, kept = som_device.rowsum_filter_normalize(img.view(h * w, len(channels)), float(pixel_thresh_val),
+                                                    f32_semantics=f32)
     kept_h = kept.cpu().numpy()
-    pixel_mat = pd.DataFrame(rows.cpu().numpy(), columns=channels)
+    values = rows.cpu().numpy()
+    pixel_mat = pd.DataFrame(values.astype(np.float32) if f32 else values, columns=channels)
     pixel_mat['fov'] = fov
     pixel_mat['row_index'] = (kept_h // w).astype(np.int64)
     pixel_mat['column_index'] = (kept_h % w).astype(np.int64)

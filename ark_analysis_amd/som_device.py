@@ -172,8 +172,11 @@ def gaussian_kernel1d(sigma: float, truncate: float = 4.0):
     return np.ascontiguousarray(phi_x[::-1], dtype=np.float64), radius
 
 
-def gaussian_blur_hwc(img: torch.Tensor, sigma: float, tmp: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """In-place per-channel Gaussian blur of an [H, W, C] float64 HBM image (scipy semantics)."""
+def gaussian_blur_hwc(img: torch.Tensor, sigma: float, tmp: Optional[torch.Tensor] = None,
+                      f32_semantics: bool = False) -> torch.Tensor:
+    """In-place per-channel Gaussian blur of an [H, W, C] float64 HBM image (scipy semantics).
+    ``f32_semantics``: the values are widened float32 and every pass is stored as float32, as scipy does
+    for a float32 image."""
     if img.dtype != torch.float64 or not img.is_cuda or not img.is_contiguous() or img.dim() != 3:
         raise ValueError("image must be a contiguous float64 [H, W, C] HBM tensor")
     h, w, c = img.shape
@@ -181,13 +184,15 @@ def gaussian_blur_hwc(img: torch.Tensor, sigma: float, tmp: Optional[torch.Tenso
         tmp = torch.empty_like(img)
     weights, radius = gaussian_kernel1d(sigma)
     rc = _capi.lib().pxsom_gaussian_blur_hwc(img.data_ptr(), tmp.data_ptr(), h, w, c,
-                                             weights.ctypes.data, radius, _capi.stream_ptr())
+                                             weights.ctypes.data, radius, int(bool(f32_semantics)),
+                                             _capi.stream_ptr())
     _capi.check(rc, "pxsom_gaussian_blur_hwc")
     return img
 
 
-def rowsum_filter_normalize(x: torch.Tensor, thresh: float):
-    """(rows [m, C] f64 = x_i / rowsum_i for kept pixels, flat pixel index [m] i64), compacted in order."""
+def rowsum_filter_normalize(x: torch.Tensor, thresh: float, f32_semantics: bool = False):
+    """(rows [m, C] f64 = x_i / rowsum_i for kept pixels, flat pixel index [m] i64), compacted in order.
+    ``f32_semantics``: widened float32 values, row sum and division in binary32 (a float32 pandas frame)."""
     if x.dtype != torch.float64 or not x.is_cuda or not x.is_contiguous() or x.dim() != 2:
         raise ValueError("matrix must be a contiguous float64 [N, C] HBM tensor")
     n, c = x.shape
@@ -198,7 +203,7 @@ def rowsum_filter_normalize(x: torch.Tensor, thresh: float):
     ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=x.device)
     rc = _capi.lib().pxsom_rowsum_filter_normalize(x.data_ptr(), n, c, float(thresh), out.data_ptr(),
                                                    idx.data_ptr(), cnt.data_ptr(), ws.data_ptr(), wsb,
-                                                   _capi.stream_ptr())
+                                                   int(bool(f32_semantics)), _capi.stream_ptr())
     _capi.check(rc, "pxsom_rowsum_filter_normalize")
     m = int(cnt.item())
     return out[:m], idx[:m]
@@ -247,4 +252,33 @@ def pair_histogram(a: torch.Tensor, b: torch.Tensor, na: int, nb: int,
     rc = _capi.lib().pxsom_pair_histogram(a.data_ptr(), b.data_ptr(), a.numel(), int(na), int(nb),
                                           out.data_ptr(), _capi.stream_ptr())
     _capi.check(rc, "pxsom_pair_histogram")
+    return out
+
+
+def quantile_f32(x: torch.Tensor, q: float, keep_mode: int = 1) -> torch.Tensor:
+    """``np.quantile`` of the kept values of every float32 column, in numpy's float32 arithmetic
+    (keep_mode 1: > 0, 2: every non-NaN value) -> [C] float32."""
+    if x.dtype != torch.float32 or not x.is_cuda or x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("matrix must be a float32 [N, C] HBM tensor with contiguous rows")
+    n, c = x.shape
+    out = torch.empty(c, dtype=torch.float64, device=x.device)
+    wsb = _capi.lib().pxsom_quantile_workspace_bytes(n, c)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+    rc = _capi.lib().pxsom_quantile_f32(x.data_ptr(), n, c, x.stride(0) if n > 1 else c, float(q), int(keep_mode),
+                                        out.data_ptr(), ws.data_ptr(), wsb, _capi.stream_ptr())
+    _capi.check(rc, "pxsom_quantile_f32")
+    return out.to(torch.float32)
+
+
+def scaled_rowsum_f32(img: torch.Tensor, norm: torch.Tensor) -> torch.Tensor:
+    """``np.sum(img / norm, axis=-1)`` for float32 [N, C] pixels and float32 [C] divisors, in numpy's
+    summation order -> [N] float32."""
+    if img.dtype != torch.float32 or norm.dtype != torch.float32 or not img.is_cuda or img.dim() != 2 \
+            or img.stride(1) != 1:
+        raise ValueError("img must be a float32 [N, C] HBM tensor with contiguous rows, norm float32 [C]")
+    n, c = img.shape
+    out = torch.empty(n, dtype=torch.float32, device=img.device)
+    rc = _capi.lib().pxsom_scaled_rowsum_f32(img.data_ptr(), n, c, img.stride(0) if n > 1 else c,
+                                             norm.contiguous().data_ptr(), out.data_ptr(), _capi.stream_ptr())
+    _capi.check(rc, "pxsom_scaled_rowsum_f32")
     return out

@@ -151,7 +151,11 @@ int pxsom_batch_update_prepare(double *w_dev, int xdim, int ydim, int c, double 
  * (numpy exp / sum on the host: part of the reference numerics), radius = int(4*sigma + 0.5).
  * img_dev [h, w, c] binary64 interleaved, blurred in place; tmp_dev: same-size scratch. */
 int pxsom_gaussian_blur_hwc(double *img_dev, double *tmp_dev, int h, int w, int c,
-                            const double *weights_host, int radius, void *stream);
+                            const double *weights_host, int radius, int f32_semantics, void *stream);
+/* f32_semantics (here and below): the matrix holds float32 values widened to binary64 -- what the
+ * pipeline feeds create_fov_pixel_data for float32 TIFFs (pixie_preprocessing.py:152-159).  scipy then
+ * stores every blur pass as float32 and pandas sums / divides the float32 frame in binary32; with the flag
+ * the kernels round in exactly those places, so the results are the reference's float32 values (widened). */
 
 /* reference: pixie_preprocessing.py:67-75 + pixel_cluster_utils.normalize_rows (:126-130):
  * keep pixel i iff rowsum_i > thresh and any(x_ij != 0); out row = x_i / rowsum_i (left-to-right
@@ -162,7 +166,7 @@ size_t pxsom_rownorm_workspace_bytes(int64_t n);
 int pxsom_rowsum_filter_normalize(const double *x_dev, int64_t n, int c, double thresh,
                                   double *out_rows_dev, int64_t *out_index_dev,
                                   int64_t *out_count_dev, void *workspace_dev,
-                                  size_t workspace_bytes, void *stream);
+                                  size_t workspace_bytes, int f32_semantics, void *stream);
 
 /* reference: PixelSOMCluster.normalize_data (cluster_helpers.py:242-246): x[:, j] / norm[j] in
  * binary64 (in place allowed: out_dev may equal x_dev). */
@@ -171,13 +175,28 @@ int pxsom_normalize_columns(const double *x_dev, int64_t n, int c, int64_t ldx,
 
 /* reference: df.replace(0, nan).quantile(q) per column (pixie_preprocessing.py:406-408,
  * cluster_helpers.py:366) / np.quantile(img[img > 0], q) (pixel_cluster_utils.py:47-51):
- * type-7 (linear) quantile of the kept values (keep_mode 0: != 0 and not NaN, 1: > 0) of each column.
+ * type-7 (linear) quantile of the kept values (keep_mode 0: != 0 and not NaN, 1: > 0, 2: not NaN) of each
+ * column.
  * out_dev [c] binary64 (NaN for a column with no kept value).  Exact: MSB-first radix select on the
  * binary64 bit patterns, then numpy's interpolation formula.  Note pandas' effective q is (q*100)/100. */
 size_t pxsom_quantile_workspace_bytes(int64_t n, int c);
 int pxsom_quantile_nonzero(const double *x_dev, int64_t n, int c, int64_t ldx, double q,
                            int keep_mode, double *out_dev, void *workspace_dev,
                            size_t workspace_bytes, void *stream);
+
+/* reference: np.quantile(img[img > 0], percentile) on a float32 image (calculate_channel_percentiles,
+ * pixel_cluster_utils.py:41-51) and np.quantile(summed_data, 0.05) (calculate_pixel_intensity_percentile,
+ * :96-103).  Same radix select on float32 columns; index, fraction and interpolation in binary32 exactly as
+ * numpy forms them for a float32 array.  keep_mode 2 keeps every non-NaN value.  out_dev [c] binary64
+ * holding the float32 results. */
+int pxsom_quantile_f32(const float *x_dev, int64_t n, int c, int64_t ldx, double q, int keep_mode,
+                       double *out_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
+
+/* reference: np.sum(img_data / norm_vect, axis=-1) of calculate_pixel_intensity_percentile
+ * (pixel_cluster_utils.py:96-101): per pixel the float32 sum over channels of img/norm, added in numpy's
+ * order for a contiguous float32 axis (c <= 128).  img_dev [n, c] float32, out_dev [n] float32. */
+int pxsom_scaled_rowsum_f32(const float *img_dev, int64_t n, int c, int64_t ldx, const float *norm_dev,
+                            float *out_dev, void *stream);
 
 #ifdef __cplusplus
 }

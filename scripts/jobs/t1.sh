@@ -1,1 +1,1 @@
-timeout 600 python -m pytest tests/test_gpu_som_kernels.py -m gpu -x -q -k "random_shapes" 2>&1 | grep -v "^$" | tail -25
+timeout 600 python -m pytest tests/test_gpu_preprocessing.py tests/test_pipeline_dropin.py -m gpu -x -q 2>&1 | grep -v "^$" | tail -25

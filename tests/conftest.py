@@ -63,4 +63,15 @@ def som_backend(request, monkeypatch):
     monkeypatch.setattr(flowsom, "map_data_to_nodes", map_data_to_nodes)
     monkeypatch.setattr(flowsom, "cluster_sums", cluster_sums)
     monkeypatch.setattr(flowsom, "pair_histogram", ob.pair_histogram)
+
+    # the TIFF-side percentiles ARE numpy calls in the reference (pixel_cluster_utils.py:41-51, :96-103)
+    def positive_quantile_f32(image, q):
+        kept = np.asarray(image)[np.asarray(image) > 0]
+        return np.quantile(kept, q) if kept.size else np.float32("nan")
+
+    def total_intensity_quantile_f32(image_hwc, norm, q):
+        return np.quantile(np.sum(image_hwc / np.asarray(norm).reshape([1, 1, -1]), axis=-1), q)
+
+    monkeypatch.setattr(flowsom, "positive_quantile_f32", positive_quantile_f32)
+    monkeypatch.setattr(flowsom, "total_intensity_quantile_f32", total_intensity_quantile_f32)
     return "oracle"

@@ -74,6 +74,17 @@ def g2_g5_preprocess():
         kept = (full["row_index"].values * w + full["column_index"].values).astype(np.int64)
         save("g2_fovpixel_" + tag, img=img, blurred=blurred, thresh=np.float64(thresh),
              kept_index=kept, rows=full[chans].values, subset_len=np.int64(len(sub)))
+        # the dtype the pipeline really feeds (preprocess_fov: float32 TIFF / float32 norm values): scipy and
+        # pandas then stay in float32
+        img32 = img.astype(np.float32)
+        blurred32 = np.stack([ndimage.gaussian_filter(img32[:, :, i], sigma=2) for i in range(c)], axis=-1)
+        np.random.seed(7)
+        full32, sub32 = pixie_preprocessing.create_fov_pixel_data(
+            "fov0", list(chans), img32.copy(), None, pixel_thresh_val=np.float32(thresh))
+        assert blurred32.dtype == np.float32 and full32[chans].values.dtype == np.float32
+        kept32 = (full32["row_index"].values * w + full32["column_index"].values).astype(np.int64)
+        save("g2_fovpixel_" + tag + "_f32", img=img32, blurred=blurred32, thresh=np.float32(thresh),
+             kept_index=kept32, rows=full32[chans].values, subset_index=sub32.index.values.astype(np.int64))
 
 
 def g3_quantiles():
@@ -279,6 +290,9 @@ if __name__ == "__main__":
     ob.build()
     if len(sys.argv) > 1 and sys.argv[1] == "g8":
         g8_c2pc()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g2":
+        g2_g5_preprocess()
         sys.exit(0)
     g1_normalize()
     g2_g5_preprocess()

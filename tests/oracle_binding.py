@@ -55,6 +55,9 @@ def lib():
         L.orc_gaussian_blur_hwc.restype = ctypes.c_int
         L.orc_gaussian_blur_hwc.argtypes = [c_dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_dp,
                                             ctypes.c_int]
+        L.orc_gaussian_blur_hwc_ex.restype = ctypes.c_int
+        L.orc_gaussian_blur_hwc_ex.argtypes = [c_dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_dp, ctypes.c_int,
+                                               ctypes.c_int]
         L.orc_rowsum_filter_normalize.restype = ctypes.c_int64
         L.orc_rowsum_filter_normalize.argtypes = [c_dp, ctypes.c_int64, ctypes.c_int,
                                                   ctypes.c_double, ctypes.c_int, c_dp, c_i64p]
@@ -187,12 +190,12 @@ def gaussian_weights(sigma, truncate=4.0):
     return phi_x, radius
 
 
-def gaussian_blur_hwc(img, sigma, truncate=4.0):
+def gaussian_blur_hwc(img, sigma, truncate=4.0, f32=False):
     img = _f64(img).copy()
     H, W, C = img.shape
     w, r = gaussian_weights(sigma, truncate)
     w = _f64(w[::-1])  # scipy hands correlate1d the reversed kernel (symmetric: same values)
-    rc = lib().orc_gaussian_blur_hwc(_dp(img), H, W, C, _dp(w), r)
+    rc = lib().orc_gaussian_blur_hwc_ex(_dp(img), H, W, C, _dp(w), r, int(bool(f32)))
     assert rc == 0
     return img
 

@@ -24,6 +24,30 @@ def test_gaussian_blur_matches_scipy_fixture_and_oracle(gpu, oracle, tag):
     np.testing.assert_array_equal(got, oracle.gaussian_blur_hwc(g["img"], 2.0))   # same op order: bit-equal
 
 
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_float32_create_fov_pixel_data_matches_reference(gpu, oracle, tag):
+    """float32 image in -> the reference's float32 tables out (blur passes stored as float32, binary32 row
+    sums and divisions), through the kernels and through the create_fov_pixel_data mirror."""
+    from ark_analysis_amd.phenotyping import pixie_preprocessing
+    g = np.load(os.path.join(GOLD, f"g2_fovpixel_{tag}_f32.npz"))
+    h, w, c = g["img"].shape
+    img = torch.from_numpy(g["img"].astype(np.float64)).to(gpu)
+    sd.gaussian_blur_hwc(img, 2.0, f32_semantics=True)
+    np.testing.assert_array_equal(img.cpu().numpy().astype(np.float32), g["blurred"])
+    np.testing.assert_array_equal(img.cpu().numpy(), oracle.gaussian_blur_hwc(g["img"], 2.0, f32=True))
+    rows, kept = sd.rowsum_filter_normalize(img.view(h * w, c), float(g["thresh"]), f32_semantics=True)
+    np.testing.assert_array_equal(kept.cpu().numpy(), g["kept_index"])
+    np.testing.assert_array_equal(rows.cpu().numpy().astype(np.float32), g["rows"])
+    chans = ["chan%d" % i for i in range(c)]
+    np.random.seed(7)
+    full, sub = pixie_preprocessing.create_fov_pixel_data("fov0", list(chans), g["img"].copy(), None,
+                                                          pixel_thresh_val=g["thresh"])
+    assert full[chans].values.dtype == np.float32
+    np.testing.assert_array_equal(full[chans].values, g["rows"])
+    np.testing.assert_array_equal((full["row_index"].values * w + full["column_index"].values), g["kept_index"])
+    np.testing.assert_array_equal(sub.index.values, g["subset_index"])          # same seeded sample
+
+
 def test_gaussian_blur_small_and_odd_shapes(gpu, oracle):
     rs = np.random.RandomState(0)
     for (h, w, c, sigma) in [(1, 1, 1, 2.0), (3, 50, 2, 2.0), (40, 5, 3, 1.0), (9, 9, 4, 3.0), (64, 64, 22, 2.0)]:
@@ -111,3 +135,45 @@ def test_quantile_many_columns_against_pandas(gpu):
             assert got2[j] == np.quantile(pos, 0.05)
         else:
             assert np.isnan(got2[j])
+
+
+def test_float32_quantiles_match_numpy_bit_for_bit(gpu):
+    """np.quantile on float32 data (index, fraction and interpolation in binary32): the TIFF-side
+    percentiles of calculate_channel_percentiles / calculate_pixel_intensity_percentile."""
+    from ark_analysis_amd import flowsom
+    rs = np.random.RandomState(3)
+    for trial in range(40):
+        n = int(rs.choice([1, 2, 3, 17, 1000, 4097, 65536, 300_001]))
+        img = rs.gamma(0.6, 2.0, size=n).astype(np.float32)
+        img[rs.uniform(size=n) < 0.3] = 0
+        if trial % 7 == 0:
+            img = np.round(img)                               # many repeated values
+        q = float(rs.choice([0.99, 0.999, 0.05, 0.5, 0.123456]))
+        kept = img[img > 0]
+        got = flowsom.positive_quantile_f32(img, q)
+        if kept.size == 0:
+            assert np.isnan(got)
+        else:
+            want = np.quantile(kept, q)
+            assert want.dtype == np.float32 and got.dtype == np.float32
+            assert got == want, (n, q, got, want)
+    # integer images interpolate in binary64
+    img16 = rs.randint(0, 4000, size=5000).astype(np.uint16)
+    assert flowsom.positive_quantile_f32(img16, 0.99) == np.quantile(img16[img16 > 0], 0.99)
+
+
+@pytest.mark.parametrize("c", [1, 5, 8, 9, 22, 23, 40, 128])
+def test_total_intensity_quantile_matches_numpy(gpu, c):
+    """np.quantile(np.sum(img / norm, axis=-1), 0.05) incl. numpy's float32 summation order."""
+    from ark_analysis_amd import flowsom, som_device as sd
+    rs = np.random.RandomState(c)
+    img = rs.gamma(0.5, 1.5, size=(61, 47, c)).astype(np.float32)
+    img[rs.uniform(size=img.shape) < 0.4] = 0
+    norm = rs.uniform(0.5, 3.0, size=c).astype(np.float32)
+    want_sum = np.sum(img / norm.reshape([1, 1, c]), axis=-1)
+    got_sum = sd.scaled_rowsum_f32(torch.from_numpy(img.reshape(-1, c)).to(gpu), torch.from_numpy(norm).to(gpu))
+    np.testing.assert_array_equal(got_sum.cpu().numpy().reshape(61, 47), want_sum)
+    for q in (0.05, 0.5):
+        assert flowsom.total_intensity_quantile_f32(img, norm, q) == np.quantile(want_sum, q)
+    with pytest.raises(TypeError):
+        flowsom.total_intensity_quantile_f32(img.astype(np.float64), norm, 0.05)

@@ -302,6 +302,46 @@ def test_create_c2pc_data_matches_reference_run(som_backend, tmp_path, cluster_c
         cell_cluster_utils.create_c2pc_data(fovs, str(pix), cell_path, "pixel_meta_cluster")
 
 
+def test_tiff_side_percentiles(som_backend, tmp_path):
+    """calculate_channel_percentiles / calculate_pixel_intensity_percentile / check_for_modified_channels on
+    a small TIFF cohort, against the reference's arithmetic written out with numpy
+    (pixel_cluster_utils.py:16-106, :145-181)."""
+    from ark_analysis_amd import image_io
+    rs = np.random.RandomState(5)
+    fovs, chans = ["fov0", "fov1", "fov10"], ["chan10", "chan2", "chan1"]
+    images = {}
+    for fov in fovs:
+        os.makedirs(tmp_path / fov / "TIFs")
+        for ch in chans + ["chan2_smoothed"]:
+            img = rs.gamma(0.5, 2.0, size=(40, 30)).astype(np.float32)
+            img[rs.uniform(size=img.shape) < 0.35] = 0
+            if fov == "fov1" and ch == "chan1":
+                img[:] = 0                                      # no positive pixel: skipped in the mean
+            images[fov, ch] = img
+            image_io.write_channel(str(tmp_path / fov / "TIFs" / (ch + ".tiff")), img)
+    assert image_io.channel_names(str(tmp_path), "fov0", "TIFs") == ["chan1", "chan2", "chan2_smoothed", "chan10"]
+    np.testing.assert_array_equal(image_io.read_channel(str(tmp_path), "fov10", "chan2", "TIFs"), images["fov10", "chan2"])
+
+    got = pixel_cluster_utils.calculate_channel_percentiles(str(tmp_path), fovs, chans, "TIFs", 0.99)
+    want = {}
+    for ch in chans:
+        vals = [np.quantile(images[f, ch][images[f, ch] > 0], 0.99) for f in fovs if (images[f, ch] > 0).any()]
+        want[ch] = np.mean(vals)
+    assert list(got.columns) == ["chan1", "chan2", "chan10"] and got.shape == (1, 3)
+    for ch in chans:
+        assert got[ch].dtype == np.float32 and got[ch].values[0] == want[ch]
+
+    thresh = pixel_cluster_utils.calculate_pixel_intensity_percentile(str(tmp_path), fovs, list(got.columns), "TIFs", got)
+    per_fov = []
+    for f in fovs:
+        stack = np.stack([images[f, ch] for ch in got.columns], axis=-1)
+        per_fov.append(np.quantile(np.sum(stack / got.iloc[0].values.reshape([1, 1, 3]), axis=-1), 0.05))
+    assert thresh == np.mean(per_fov)
+
+    with pytest.warns(UserWarning, match="chan2_smoothed"):
+        pixel_cluster_utils.check_for_modified_channels(str(tmp_path), "fov0", "TIFs", ["chan2", "chan1"])
+
+
 def test_fov_table_helpers(tmp_path):
     """Footer-only column listing, natural ordering, prefetcher / writer round trip, damaged files."""
     from ark_analysis_amd.fov_tables import FovTableDir, TablePrefetcher, TableWriter
