@@ -159,3 +159,31 @@ def total_intensity_quantile_f32(image_hwc, norm, q: float):
     pixels = torch.from_numpy(img.reshape(-1, img.shape[-1])).to(dev)
     sums = som_device.scaled_rowsum_f32(pixels, torch.from_numpy(np.ascontiguousarray(norm, dtype=np.float32)).to(dev))
     return som_device.quantile_f32(sums.reshape(-1, 1), q, keep_mode=2).cpu().numpy()[0]
+
+
+def fov_pixel_rows(img_hwc, sigma: float, thresh: float):
+    """The numeric core of ``create_fov_pixel_data`` (pixie_preprocessing.py:45-75): per-channel Gaussian blur,
+    keep pixels whose channel sum exceeds ``thresh`` and that are not all zero, divide the kept pixels by
+    their channel sum.  Returns ``(rows [m, C], flat pixel index [m])``; a float32 image keeps the reference's
+    float32 arithmetic (rows come back float32), anything else is processed in binary64."""
+    import torch
+    from . import _capi, som_device
+    dev = _capi.require_gpu()
+    img_hwc = np.asarray(img_hwc)
+    f32 = img_hwc.dtype == np.float32
+    h, w, c = img_hwc.shape
+    img = torch.from_numpy(np.ascontiguousarray(img_hwc, dtype=np.float64)).to(dev)
+    som_device.gaussian_blur_hwc(img, float(sigma), f32_semantics=f32)
+    rows, kept = som_device.rowsum_filter_normalize(img.view(h * w, c), float(thresh), f32_semantics=f32)
+    values = rows.cpu().numpy()
+    return (values.astype(np.float32) if f32 else values), kept.cpu().numpy()
+
+
+def nonzero_quantiles(matrix, q: float) -> np.ndarray:
+    """Per column: linear-interpolation quantile of the non-zero, non-NaN entries in binary64 (NaN for a
+    column without any) -- ``DataFrame.replace(0, nan).quantile(q)`` up to pandas' casts, which callers add."""
+    import torch
+    from . import _capi, som_device
+    dev = _capi.require_gpu()
+    m = torch.from_numpy(np.ascontiguousarray(matrix, dtype=np.float64)).to(dev)
+    return som_device.quantile_nonzero(m, float(q), keep_mode=0).cpu().numpy()

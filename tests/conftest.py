@@ -72,6 +72,20 @@ def som_backend(request, monkeypatch):
     def total_intensity_quantile_f32(image_hwc, norm, q):
         return np.quantile(np.sum(image_hwc / np.asarray(norm).reshape([1, 1, -1]), axis=-1), q)
 
+    def fov_pixel_rows(img_hwc, sigma, thresh):
+        img_hwc = np.asarray(img_hwc)
+        f32 = img_hwc.dtype == np.float32
+        h, w, c = img_hwc.shape
+        blurred = ob.gaussian_blur_hwc(img_hwc, float(sigma), f32=f32)
+        rows, kept = ob.rowsum_filter_normalize(blurred.reshape(h * w, c), float(thresh), sum_mode=2 if f32 else 0)
+        return (rows.astype(np.float32) if f32 else rows), kept
+
+    def nonzero_quantiles(matrix, q):
+        m = np.asarray(matrix, dtype=np.float64)
+        return np.array([ob.quantile_nonzero(np.ascontiguousarray(m[:, j]), q, 0) for j in range(m.shape[1])])
+
+    monkeypatch.setattr(flowsom, "fov_pixel_rows", fov_pixel_rows)
+    monkeypatch.setattr(flowsom, "nonzero_quantiles", nonzero_quantiles)
     monkeypatch.setattr(flowsom, "positive_quantile_f32", positive_quantile_f32)
     monkeypatch.setattr(flowsom, "total_intensity_quantile_f32", total_intensity_quantile_f32)
     return "oracle"

@@ -1,5 +1,8 @@
-"""Shim (unused by the hot path)."""
+"""Stand-in for skimage.io (test infrastructure for tests/golden/make_golden.py only): imread via Pillow."""
+import numpy as np
+from PIL import Image
 
 
-def imread(*a, **k):
-    raise NotImplementedError("skimage shim")
+def imread(path, *a, **k):
+    with Image.open(path) as im:
+        return np.array(im)

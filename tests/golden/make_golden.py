@@ -286,18 +286,56 @@ def g8_c2pc():
     save("g8_c2pc", **arrays)
 
 
+def g9_create_pixel_matrix():
+    """The reference's own create_pixel_matrix on a small float32 TIFF cohort (with segmentation masks),
+    through the alpineer / skimage stand-ins of tests/golden/_shims (Pillow readers): pre-row-norm channel
+    values, pixel threshold, per-FOV tables (full + seeded subset), post-row-norm 99.9 % values, stdout."""
+    from PIL import Image
+    rs = np.random.RandomState(31)
+    fovs, chans = ["fov0", "fov1", "fov2"], ["chan0", "chan1", "chan2", "chan10"]
+    arrays = {}
+    with tempfile.TemporaryDirectory() as td:
+        tiff_dir, seg_dir = os.path.join(td, "tiffs"), os.path.join(td, "seg")
+        os.makedirs(os.path.join(td, "pixel_output_dir"))
+        os.mkdir(seg_dir)
+        for fov in fovs:
+            os.makedirs(os.path.join(tiff_dir, fov, "TIFs"))
+            for ch in chans:
+                img = rs.gamma(0.5, 2.0, size=(28, 24)).astype(np.float32)
+                img[rs.uniform(size=img.shape) < 0.4] = 0
+                Image.fromarray(img).save(os.path.join(tiff_dir, fov, "TIFs", ch + ".tiff"), format="TIFF")
+                arrays[f"img_{fov}_{ch}"] = img
+            seg = rs.randint(0, 9, size=(28, 24)).astype(np.int32)
+            Image.fromarray(seg).save(os.path.join(seg_dir, fov + "_whole_cell.tiff"), format="TIFF")
+            arrays["seg_" + fov] = seg
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            pixie_preprocessing.create_pixel_matrix(list(fovs), list(chans), td, tiff_dir, seg_dir,
+                                                    subset_proportion=0.25, seed=42)
+        arrays["stdout"] = np.array(buf.getvalue())
+        pre = feather.read_dataframe(os.path.join(td, "pixel_output_dir", "channel_norm_pre_rownorm.feather"))
+        arrays["pre_columns"] = np.array(list(pre.columns), dtype="U16")
+        arrays["pre_values"] = pre.values[0]
+        th = feather.read_dataframe(os.path.join(td, "pixel_output_dir", "pixel_thresh.feather"))
+        arrays["thresh"] = th["pixel_thresh_val"].values
+        post = feather.read_dataframe(os.path.join(td, "channel_norm_post_rownorm.feather"))
+        arrays["post_columns"] = np.array(list(post.columns), dtype="U16")
+        arrays["post_values"] = post.values[0]
+        arrays["data_dir_listing"] = np.array(sorted(os.listdir(os.path.join(td, "pixel_mat_data"))), dtype="U32")
+        for fov in fovs:
+            for kind in ("pixel_mat_data", "pixel_mat_subsetted"):
+                t = feather.read_dataframe(os.path.join(td, kind, fov + ".feather"))
+                tag = f"{kind}_{fov}"
+                arrays[tag + "_columns"] = np.array(list(t.columns), dtype="U16")
+                arrays[tag + "_dtypes"] = np.array([str(d) for d in t.dtypes], dtype="U16")
+                arrays[tag + "_channels"] = t[sorted(chans, key=lambda c: int(c[4:]))].values
+                arrays[tag + "_meta"] = t[["row_index", "column_index", "label"]].values.astype(np.int64)
+    save("g9_create_pixel_matrix", **arrays)
+
+
 if __name__ == "__main__":
     ob.build()
-    if len(sys.argv) > 1 and sys.argv[1] == "g8":
-        g8_c2pc()
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "g2":
-        g2_g5_preprocess()
-        sys.exit(0)
-    g1_normalize()
-    g2_g5_preprocess()
-    g3_quantiles()
-    g4_cluster_avg()
-    g6_som()
-    g7_end_to_end()
-    g8_c2pc()
+    steps = {"g1": g1_normalize, "g2": g2_g5_preprocess, "g3": g3_quantiles, "g4": g4_cluster_avg, "g6": g6_som,
+             "g7": g7_end_to_end, "g8": g8_c2pc, "g9": g9_create_pixel_matrix}
+    for name in (sys.argv[1:] or list(steps)):
+        steps[name]()

@@ -342,6 +342,62 @@ def test_tiff_side_percentiles(som_backend, tmp_path):
         pixel_cluster_utils.check_for_modified_channels(str(tmp_path), "fov0", "TIFs", ["chan2", "chan1"])
 
 
+def _write_g9_cohort(g, td):
+    from ark_analysis_amd import image_io
+    fovs, chans = ["fov0", "fov1", "fov2"], ["chan0", "chan1", "chan2", "chan10"]
+    tiff_dir, seg_dir = os.path.join(td, "tiffs"), os.path.join(td, "seg")
+    os.makedirs(os.path.join(td, "pixel_output_dir"))
+    os.mkdir(seg_dir)
+    for fov in fovs:
+        os.makedirs(os.path.join(tiff_dir, fov, "TIFs"))
+        for ch in chans:
+            image_io.write_channel(os.path.join(tiff_dir, fov, "TIFs", ch + ".tiff"), g[f"img_{fov}_{ch}"])
+        image_io.write_channel(os.path.join(seg_dir, fov + "_whole_cell.tiff"), g["seg_" + fov])
+    return fovs, chans, tiff_dir, seg_dir
+
+
+def test_create_pixel_matrix_matches_reference_run(som_backend, tmp_path, capsys):
+    """TIFF cohort -> pixel tables + the three normalisation files, against the reference's own
+    create_pixel_matrix on the same TIFFs (tests/golden/g9_create_pixel_matrix.npz): every value, dtype,
+    column order, the seeded sub-sample and the printed progress."""
+    from ark_analysis_amd.phenotyping import pixie_preprocessing
+    g = np.load(os.path.join(GOLD, "g9_create_pixel_matrix.npz"))
+    td = str(tmp_path)
+    fovs, chans, tiff_dir, seg_dir = _write_g9_cohort(g, td)
+    pixie_preprocessing.create_pixel_matrix(list(fovs), list(chans), td, tiff_dir, seg_dir,
+                                            subset_proportion=0.25, seed=42)
+    assert capsys.readouterr().out == str(g["stdout"])
+    pre = read_dataframe(os.path.join(td, "pixel_output_dir", "channel_norm_pre_rownorm.feather"))
+    assert list(pre.columns) == list(g["pre_columns"]) and pre.values.dtype == g["pre_values"].dtype
+    np.testing.assert_array_equal(pre.values[0], g["pre_values"])
+    th = read_dataframe(os.path.join(td, "pixel_output_dir", "pixel_thresh.feather"))["pixel_thresh_val"].values
+    assert th.dtype == g["thresh"].dtype
+    np.testing.assert_array_equal(th, g["thresh"])
+    post = read_dataframe(os.path.join(td, "channel_norm_post_rownorm.feather"))
+    assert list(post.columns) == list(g["post_columns"]) and post.values.dtype == g["post_values"].dtype
+    np.testing.assert_array_equal(post.values[0], g["post_values"])
+    assert sorted(os.listdir(os.path.join(td, "pixel_mat_data"))) == list(g["data_dir_listing"])
+    for fov in fovs:
+        for kind in ("pixel_mat_data", "pixel_mat_subsetted"):
+            t = read_dataframe(os.path.join(td, kind, fov + ".feather"))
+            tag = f"{kind}_{fov}"
+            assert list(t.columns) == list(g[tag + "_columns"])
+            assert [str(d) for d in t.dtypes] == list(g[tag + "_dtypes"])
+            np.testing.assert_array_equal(t[["chan0", "chan1", "chan2", "chan10"]].values, g[tag + "_channels"])
+            np.testing.assert_array_equal(t[["row_index", "column_index", "label"]].values.astype(np.int64),
+                                          g[tag + "_meta"])
+    # nothing left to do on a second call; a changed channel list resets the cohort
+    pixie_preprocessing.create_pixel_matrix(list(fovs), list(chans), td, tiff_dir, seg_dir, subset_proportion=0.25)
+    assert capsys.readouterr().out == "There are no more FOVs to preprocess, skipping\n"
+    pixie_preprocessing.create_pixel_matrix(list(fovs), chans[:3], td, tiff_dir, seg_dir, subset_proportion=0.25)
+    out = capsys.readouterr().out
+    assert out.startswith("New channels provided: overwriting whole cohort\n") and out.endswith("Processed 3 fovs\n")
+    t = read_dataframe(os.path.join(td, "pixel_mat_data", "fov1.feather"))
+    assert list(t.columns)[:3] == chans[:3] and "chan10" not in t.columns
+    with pytest.raises(ValueError, match="Invalid subset percentage"):
+        pixie_preprocessing.create_pixel_matrix(list(fovs), list(chans), td, tiff_dir, seg_dir, subset_proportion=1.5)
+
+
 def test_fov_table_helpers(tmp_path):
     """Footer-only column listing, natural ordering, prefetcher / writer round trip, damaged files."""
     from ark_analysis_amd.fov_tables import FovTableDir, TablePrefetcher, TableWriter
