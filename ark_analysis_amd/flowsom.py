@@ -132,18 +132,22 @@ def pair_histogram(a, b, na: int, nb: int) -> np.ndarray:
 
 
 def positive_quantile_f32(image, q: float):
-    """``np.quantile(image[image > 0], q)`` for a float32 image (NaN if nothing is positive): the per-channel
-    percentile of calculate_channel_percentiles (pixel_cluster_utils.py:41-51)."""
+    """``np.quantile(plane[plane > 0], q)`` of every channel plane of an ``[H, W]`` or ``[H, W, C]`` image
+    (NaN where nothing is positive): the per-channel percentile of calculate_channel_percentiles
+    (pixel_cluster_utils.py:41-51).  Scalar for a single plane, ``[C]`` otherwise.  float32 images use
+    numpy's float32 arithmetic, integer / float64 images binary64 (as numpy does)."""
     import torch
     from . import _capi, som_device
     dev = _capi.require_gpu()
     image = np.asarray(image)
+    planes = image.reshape(-1, 1) if image.ndim <= 2 else image.reshape(-1, image.shape[-1])
     if image.dtype == np.float32:
-        flat = torch.from_numpy(np.ascontiguousarray(image).reshape(-1, 1)).to(dev)
-        return som_device.quantile_f32(flat, q, keep_mode=1).cpu().numpy()[0]
-    # integer / float64 images: numpy interpolates those in binary64
-    flat = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float64).reshape(-1, 1)).to(dev)
-    return som_device.quantile_nonzero(flat, q, keep_mode=1).cpu().numpy()[0]
+        got = som_device.quantile_f32(torch.from_numpy(np.ascontiguousarray(planes)).to(dev), q, keep_mode=1)
+    else:
+        got = som_device.quantile_nonzero(torch.from_numpy(np.ascontiguousarray(planes, dtype=np.float64)).to(dev),
+                                          q, keep_mode=1)
+    got = got.cpu().numpy()
+    return got[0] if image.ndim <= 2 else got
 
 
 def total_intensity_quantile_f32(image_hwc, norm, q: float):

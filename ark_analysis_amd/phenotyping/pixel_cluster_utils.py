@@ -22,14 +22,13 @@ def calculate_channel_percentiles(tiff_dir, fovs, channels, img_sub_folder, perc
     """One normalisation value per channel: the ``percentile`` quantile of the positive pixels of each
     FOV's channel image, averaged over the FOVs that have any (reference: pixel_cluster_utils.py:16-58).
     Returns a one-row DataFrame, columns naturally sorted."""
+    # one device call per FOV covers all its channels (the reference walks channel by channel; the values it
+    # averages -- and their order, FOV by FOV -- are the same)
+    by_fov = [flowsom.positive_quantile_f32(image_io.read_channels(tiff_dir, fov, channels, img_sub_folder), percentile)
+              for fov in fovs]
     per_channel = []
-    for channel in channels:
-        found = []
-        for fov in fovs:
-            value = flowsom.positive_quantile_f32(image_io.read_channel(tiff_dir, fov, channel, img_sub_folder),
-                                                  percentile)
-            if not np.isnan(value):     # a channel image without positive pixels contributes nothing
-                found.append(value)
+    for j in range(len(channels)):
+        found = [values[j] for values in by_fov if not np.isnan(values[j])]   # no positive pixel: not counted
         per_channel.append(np.mean(found))
     table = pd.DataFrame(np.expand_dims(per_channel, axis=0), columns=channels)
     return table[sorted(table.columns, key=natsort_key)]

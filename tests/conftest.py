@@ -66,8 +66,14 @@ def som_backend(request, monkeypatch):
 
     # the TIFF-side percentiles ARE numpy calls in the reference (pixel_cluster_utils.py:41-51, :96-103)
     def positive_quantile_f32(image, q):
-        kept = np.asarray(image)[np.asarray(image) > 0]
-        return np.quantile(kept, q) if kept.size else np.float32("nan")
+        image = np.asarray(image)
+
+        def one(plane):
+            kept = plane[plane > 0]
+            return np.quantile(kept, q) if kept.size else np.float32("nan")
+        if image.ndim == 2:
+            return one(image)
+        return np.array([one(image[:, :, j]) for j in range(image.shape[2])])
 
     def total_intensity_quantile_f32(image_hwc, norm, q):
         return np.quantile(np.sum(image_hwc / np.asarray(norm).reshape([1, 1, -1]), axis=-1), q)
