@@ -1,2 +1,4 @@
-python scripts/debug/k8_cost.py 2>&1 | tail -3
-timeout 600 python -m pytest tests/test_gpu_som_kernels.py -m gpu -x -q -k "cluster_sums or full_size or accumulate" 2>&1 | tail -2
+for i in 1 2; do
+PXSOM_SUMS_SORTED=1 python scripts/debug/k8_cost.py 2>&1 | tail -2 | head -1
+PXSOM_SUMS_SORTED=0 python scripts/debug/k8_cost.py 2>&1 | tail -2 | head -1
+done
