@@ -1,1 +1,1 @@
-timeout 600 python -m pytest tests/test_pipeline_dropin.py tests/test_gpu_preprocessing.py -m gpu -x -q 2>&1 | grep -E "^E|FAILED|Error" | head -20
+timeout 600 python -m pytest tests/test_gpu_som_kernels.py -m gpu -x -q -k "cell_som_shape" 2>&1 | grep -v "^$" | tail -15

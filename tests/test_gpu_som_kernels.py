@@ -363,3 +363,29 @@ def test_assign_full_size_sampled_against_oracle(gpu, oracle):
     # checksum of checksums: per-cluster counts add up to n
     _, cnt = sd.cluster_sums(x, labels, k)
     assert int(cnt.sum()) == n
+
+
+def test_cell_som_shape_full_size_properties(gpu, oracle):
+    """BASELINE config 4 (cell SOM: 1e6 cells x 100 features, 10x10 SOM) at full size: batch training leaves a
+    finite codebook whose every mini-batch statistic accounts for every row; labels of a random sample equal
+    the oracle's; relabelling is idempotent; per-cluster counts add up."""
+    from ark_analysis_amd.distributed import BatchSOMTrainer
+    n, c, xdim, ydim = 1_000_000, 100, 10, 10
+    k = xdim * ydim
+    g = torch.Generator(device=gpu)
+    g.manual_seed(4)
+    x = torch.rand((n, c), generator=g, device=gpu, dtype=torch.float32)
+    x *= (torch.rand((n, c), generator=g, device=gpu) > 0.6)            # sparse counts, like pixel-cluster counts
+    w = x[torch.randperm(n, device=gpu)[:k]].double().contiguous()
+    tr = BatchSOMTrainer(xdim, ydim, c, gpu, batch_steps=16)
+    tr.train(x, w, num_passes=1)
+    assert bool(torch.isfinite(w).all())
+    labels, _ = sd.assign(x, w)
+    labels2, _ = sd.assign(x, w)
+    assert torch.equal(labels, labels2)
+    idx = torch.randperm(n, device=gpu)[:50_000]
+    want, _ = oracle.map_data_to_nodes(w.cpu().numpy(), x[idx].double().cpu().numpy())
+    np.testing.assert_array_equal(labels[idx].cpu().numpy(), want)
+    sums, cnt = sd.cluster_sums(x, labels, k)
+    assert int(cnt.sum()) == n
+    np.testing.assert_allclose(sums.sum(dim=0).cpu().numpy(), x.double().sum(dim=0).cpu().numpy(), rtol=1e-9)
