@@ -72,7 +72,11 @@ __host__ __device__ inline int node_of_row(int b, int m, int nb)
 // [k*c sums | k counts] for every row it does not list
 template <typename T>
 void launch_filter_any(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L,
-                       int32_t *labels, double *stats, hipStream_t st);
+                       int32_t *labels, double *stats, const double *w, hipStream_t st);
+// the accumulating variant (pxsom_assign_filter_acc.hip): also settles its listed rows itself
+template <typename T>
+void launch_filter_fast_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels,
+                            double *stats, const double *w, hipStream_t st);
 template <typename T>
 bool filter_fast_path(const T *x, int64_t n, int c, int64_t ldx, const Layout &L);
 

@@ -518,10 +518,11 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
     const int cus = pxsom::device_cu_count();
     pxsom::Prof *prof = pxsom::current_prof();
     pxsom::prof_mark(prof, st, true, n);
-    launch_filter_any<T>(x, n, c, ldx, ws, L, labels, stats, st);
+    launch_filter_any<T>(x, n, c, ldx, ws, L, labels, stats, w, st);
     pxsom::prof_mark(prof, st, false, n);
     PXSOM_LAUNCH_CHECK("bmu_filter_kernel");
 
+    if (stats) return PXSOM_OK;   // the accumulating filter settled its listed rows itself
     const size_t wt_bytes = (size_t)k * c * sizeof(double);
     const int use_lds = wt_bytes <= 64 * 1024;
     // listed rows are a small fraction of n; the kernel grid-strides over the list anyway

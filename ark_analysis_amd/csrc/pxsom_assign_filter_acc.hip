@@ -1,0 +1,56 @@
+// pxsom_assign_filter_acc.hip -- the batch-rule variant of the register-resident BMU filter (ACC = true in
+// pxsom_assign_filter_fast.h): labels + per-BMU sums / counts of a mini-batch in ONE launch, listed rows
+// settled inline in binary64.  Compiled WITHOUT -ffinite-math-only: the inline exact path relies on IEEE
+// NaN comparisons (a NaN row must end up with label 0).
+#include <algorithm>
+
+#include "pxsom_assign_filter_fast.h"
+
+namespace pxsom_bmu {
+namespace {
+
+template <typename T, int CPL>
+void launch_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels, double *stats,
+                const double *w, hipStream_t st)
+{
+    auto kern = bmu_filter_fast<T, CPL, 7, 1, 0, true>;
+    const size_t lds = ((size_t)L.k * c + L.k + (size_t)L.k * c) * sizeof(double);   // table + transposed codebook
+    static int bpc = 0;
+    if (bpc == 0) {
+        int nbk = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, kern, 256, lds) != hipSuccess || nbk < 1) nbk = 2;
+        bpc = nbk > 8 ? 8 : nbk;
+    }
+    const int64_t ngroups = (n + 63) / 64;
+    int grid = (int)std::min<int64_t>((ngroups + 3) / 4, (int64_t)pxsom::device_cu_count() * bpc);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, x, n, c, ldx,
+                       reinterpret_cast<const half8 *>(ws + L.off_wfrag),
+                       reinterpret_cast<const f32x4 *>(ws + L.off_bias), reinterpret_cast<AssignHdr *>(ws),
+                       reinterpret_cast<unsigned *>(ws + L.off_list), labels, L.k, stats, w);
+}
+
+}  // namespace
+
+template <typename T>
+void launch_filter_fast_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels,
+                            double *stats, const double *w, hipStream_t st)
+{
+    if (L.cpl == 6)
+        launch_acc<T, 6>(x, n, c, ldx, ws, L, labels, stats, w, st);
+    else if (L.cpl == 8)
+        launch_acc<T, 8>(x, n, c, ldx, ws, L, labels, stats, w, st);
+    else if (L.cpl == 4)
+        launch_acc<T, 4>(x, n, c, ldx, ws, L, labels, stats, w, st);
+    else
+        launch_acc<T, 2>(x, n, c, ldx, ws, L, labels, stats, w, st);
+}
+
+template void launch_filter_fast_acc<float>(const float *, int64_t, int, int64_t, char *, const Layout &, int32_t *,
+                                            double *, const double *, hipStream_t);
+template void launch_filter_fast_acc<double>(const double *, int64_t, int, int64_t, char *, const Layout &, int32_t *,
+                                             double *, const double *, hipStream_t);
+template void launch_filter_fast_acc<_Float16>(const _Float16 *, int64_t, int, int64_t, char *, const Layout &,
+                                               int32_t *, double *, const double *, hipStream_t);
+
+}  // namespace pxsom_bmu

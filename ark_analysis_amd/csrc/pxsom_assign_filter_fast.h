@@ -1,0 +1,452 @@
+// pxsom_assign_filter_fast.h -- the register-resident BMU filter kernel (bmu_filter_fast) and the helpers it
+// shares with the generic filter.  Included by two translation units:
+//   pxsom_assign_filter.hip      -ffinite-math-only, the plain filter (ACC = false): the roofline kernel
+//   pxsom_assign_filter_acc.hip  default FP semantics, the batch-rule variant (ACC = true), which also
+//                                resolves its listed rows itself in binary64 and must see NaNs as NaNs
+#pragma once
+#include <cfloat>
+#include <cmath>
+
+#include "pxsom_assign.h"
+#include "pxsom_wave.h"
+
+namespace pxsom_bmu {
+namespace {
+
+template <typename T>
+struct Pair;
+template <>
+struct Pair<float> {
+    typedef float2 type;
+};
+template <>
+struct Pair<double> {
+    typedef double2 type;
+};
+struct half_pair {
+    _Float16 x, y;
+};
+template <>
+struct Pair<_Float16> {
+    typedef half_pair type;
+};
+
+__device__ __forceinline__ float pack_idx(float v, unsigned idx, unsigned mask)
+{
+    return __uint_as_float((__float_as_uint(v) & ~mask) | idx);
+}
+
+// {own, partner} of a value across lanes l <-> l^16 / l^32, in lane-dependent order: only ever fed
+// to symmetric functions (max/min/add), so no select is needed.  VALU only, no LDS crossbar.
+struct F2 {
+    float a, b;
+};
+__device__ __forceinline__ F2 xchg16(float v)
+{
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return {__uint_as_float(r[0]), __uint_as_float(r[1])};
+}
+__device__ __forceinline__ F2 xchg32(float v)
+{
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return {__uint_as_float(r[0]), __uint_as_float(r[1])};
+}
+
+// running top-2 (m1 >= m2) absorbs two values per update:
+//   m1' = max3(m1, a, b);   m2' = max(med3(m1, a, b), m2)
+__device__ __forceinline__ void top2_pair(float &m1, float &m2, float a, float b)
+{
+    const float tm = __builtin_amdgcn_fmed3f(m1, a, b);
+    m1 = fmaxf(fmaxf(m1, a), b);
+    m2 = fmaxf(tm, m2);
+}
+
+__device__ __forceinline__ void consume(float &m1, float &m2, const f32x4 &acc, int b, unsigned idx_mask)
+{
+    const float p0 = pack_idx(acc[0], (unsigned)(b * 4 + 0), idx_mask);
+    const float p1 = pack_idx(acc[1], (unsigned)(b * 4 + 1), idx_mask);
+    const float p2 = pack_idx(acc[2], (unsigned)(b * 4 + 2), idx_mask);
+    const float p3 = pack_idx(acc[3], (unsigned)(b * 4 + 3), idx_mask);
+    top2_pair(m1, m2, p0, p1);
+    top2_pair(m1, m2, p2, p3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fast path: one 32-slot channel chunk (C <= 32, even), K <= 128, rows 2-element aligned, n >= 64.
+// Codebook fragments and bias stay in registers for the whole launch.
+//   * addressing: SGPR row base + per-lane 32-bit offsets (3 VGPRs); the last, partial 64-row group
+//     is shifted back to rows [n-64, n) instead of being clamped (identical labels are rewritten).
+//   * conversion: hi = f16(x*s), lo = f16(x*s - hi) as v_fma_mix ops; |X|^2 from v_dot2_f32_f16.
+//   * last node block: only its first RU accumulator registers hold real nodes (node_of_row).
+// MODE (scripts/assign_microbench.py only): 1 = stream without MFMA/top-2, 2 = cache-hot loads.
+// ------------------------------------------------------------------------------------------------
+// One listed row settled by a whole wave (ACC variant): lanes <-> nodes lane and lane + 64 (K <= 128 on this
+// path), the row's channels broadcast with v_readlane, distances exactly as bmu_exact_kernel / the oracle
+// form them.  The winner becomes the row's label and the row is added to the workgroup's table.
+#pragma clang fp contract(off)
+template <typename T>
+__device__ __forceinline__ void exact_row_accumulate(const T *__restrict__ x, int64_t row, int c, int64_t ldx,
+                                                     const double *wt, int k, int32_t *__restrict__ labels,
+                                                     double *ls, int lane)
+{
+    const double xa = (double)x[row * ldx + (lane < c ? lane : 0)];   // c <= 32 here: lane j holds channel j
+    const unsigned xlo = (unsigned)__double_as_longlong(xa), xhi = (unsigned)(__double_as_longlong(xa) >> 32);
+    const int n0 = lane, n1 = lane + 64;
+    const int c0 = n0 < k ? n0 : k - 1, c1 = n1 < k ? n1 : k - 1;
+    double d0 = 0.0, d1 = 0.0;
+    for (int j = 0; j < c; j++) {
+        const double xj = __longlong_as_double(((long long)__builtin_amdgcn_readlane(xhi, j) << 32) |
+                                               (unsigned)__builtin_amdgcn_readlane(xlo, j));
+        const double t0 = xj - wt[(size_t)j * k + c0], t1 = xj - wt[(size_t)j * k + c1];
+        d0 += t0 * t0;
+        d1 += t1 * t1;
+    }
+    double best = DBL_MAX;
+    int bestk = 0x7fffffff;
+    const double s0 = sqrt(d0), s1 = sqrt(d1);
+    if (n0 < k && s0 < best) {
+        best = s0;
+        bestk = n0;
+    }
+    if (n1 < k && s1 < best) {
+        best = s1;
+        bestk = n1;
+    }
+    const double smin = pxsom::wave_min_f64(best);
+    const int win = (int)pxsom::wave_min_u32(best == smin ? (unsigned)bestk : 0xffffffffu);
+    if (lane == 0) labels[row] = win == 0x7fffffff ? 0 : win + 1;   // no finite distance (NaN row): label 0
+    if (win != 0x7fffffff) {
+        if (lane < c)
+            __hip_atomic_fetch_add(ls + (size_t)win * c + lane, xa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0)
+            __hip_atomic_fetch_add(ls + (size_t)k * c + win, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+#pragma clang fp contract(fast)
+
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+
+// SGB_VALU > 0 forces a 1-MFMA : SGB_VALU-VALU cadence with sched_group_barrier.  Measured (bench.py,
+// filter kernel): 0 -> 0.237 ms, 3 -> 0.252, 5 -> 0.249, 8 -> 0.247: the compiler's own order wins.
+#ifndef SGB_VALU
+#define SGB_VALU 0
+#endif
+// ACC (batch-rule accumulation fused in, pxsom_batch_accumulate): every row the filter is sure of adds
+// itself to a per-workgroup binary64 table [K*c sums | K counts] in LDS (ds_add_f64), flushed once with
+// global atomics into `stats`.  Rows it is NOT sure of are settled on the spot by the wave that met them,
+// exactly as the exact kernel would (binary64, j ascending, no contraction, sqrt, first strict minimum)
+// against a transposed binary64 copy of the codebook in LDS, and added to the table too -- so a
+// mini-batch step needs no exact-kernel launch.  One pass over x, one launch.
+template <typename T, int CPL, int NB, int RU, int MODE, bool ACC>
+__global__ __launch_bounds__(256, 2) void bmu_filter_fast(
+    const T *__restrict__ x, int64_t n, int c, int64_t ldx, const half8 *__restrict__ wfrag,
+    const f32x4 *__restrict__ bias, AssignHdr *hdr, unsigned *__restrict__ amb_list,
+    int32_t *__restrict__ labels, int k, double *__restrict__ stats, const double *__restrict__ wcodes)
+{
+    extern __shared__ __attribute__((aligned(16))) char acc_smem[];
+    double *ls = reinterpret_cast<double *>(acc_smem);  // [k*c + k]
+    double *wt = ls + (size_t)k * c + k;                 // [c][k] transposed codebook (ACC only)
+    if constexpr (ACC) {
+        for (int e = threadIdx.x; e < k * c + k; e += 256) ls[e] = 0.0;
+        for (int e0 = threadIdx.x; e0 < k * c; e0 += 8 * 256) {   // 8 L2 loads in flight per thread
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = wcodes[e0 + u * 256 < k * c ? e0 + u * 256 : 0];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int e = e0 + u * 256;
+                if (e < k * c) {
+                    const int node = e / c, j = e - node * c;
+                    wt[(size_t)j * k + node] = v[u];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    constexpr int NP = CPL / 2;  // pair loads per lane per tile
+    // scores carry (b*4 + r) in their low 7 mantissa bits (inline constants <= 27: one v_and_or_b32 each);
+    // OR-ing (q << 5) in yields a 7-bit id (q, b, r) that is mapped to the node once per group
+    constexpr unsigned idx_mask = 127u;
+    constexpr unsigned node_mask = 127u;
+    static_assert(NB <= 8, "7-bit packed node index");
+    const float scale = hdr->scale, wn_max = hdr->wn_max, tol_rel = hdr->tol_rel,
+                tol_abs = hdr->tol_abs, x_limit = hdr->x_limit;
+    const bool force_exact = hdr->force_exact != 0;
+
+    const int lane = threadIdx.x & 63;
+    const int pix = lane & 15, q = lane >> 4;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t ngroups = (n + 63) / 64;
+
+    half8 wreg[NB][2];
+    f32x4 breg[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        wreg[b][0] = wfrag[(b * 2 + 0) * 64 + lane];
+        wreg[b][1] = wfrag[(b * 2 + 1) * 64 + lane];
+        breg[b] = bias[b * 64 + lane];
+    }
+
+    // byte offset of this lane's pair p inside a 16-row tile (channel slots past c re-read the
+    // row's last valid pair: their codebook slots are zero)
+    unsigned loff[NP];
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        int ch = q * CPL + 2 * p;
+        if (ch > c - 2) ch = c - 2;
+        loff[p] = (unsigned)((pix * ldx + ch) * (int64_t)sizeof(T));
+    }
+    const int64_t tile_bytes = 16 * ldx * (int64_t)sizeof(T);
+
+    typedef typename Pair<T>::type P2;
+    P2 raw[kTilesPerIter][NP];
+    P2 keep[ACC ? kTilesPerIter : 1][NP];  // ACC: the group's rows outlive the prefetch of the next
+    // Buffer loads: the 64-row group is a descriptor of its own (base = x + row0*ldx*sizeof(T), built
+    // from wave-uniform values on the scalar unit), the tile offset rides in soffset and the lane offset in
+    // voffset -- no per-load VALU address arithmetic.
+    auto load_group = [&](int64_t g) {
+        if constexpr (MODE >= 2) g = wave;
+        int64_t row0 = g * 64;
+        if (row0 > n - 64) row0 = n - 64;
+        const char *gb = reinterpret_cast<const char *>(x) + row0 * ldx * (int64_t)sizeof(T);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char *>(gb), (short)0, (int)(64 * ldx * (int64_t)sizeof(T)), 0x00020000);
+#pragma unroll
+        for (int t = 0; t < kTilesPerIter; t++) {
+            const int soff = (int)(t * tile_bytes);
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+                if constexpr (sizeof(T) == 2) {
+                    const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)loff[p], soff, 0);
+                    const half2_t h = __builtin_bit_cast(half2_t, v);
+                    raw[t][p].x = h[0];
+                    raw[t][p].y = h[1];
+                } else if constexpr (sizeof(T) == 4) {
+                    const uint2v v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)loff[p], soff, 0);
+                    raw[t][p].x = __uint_as_float(v[0]);
+                    raw[t][p].y = __uint_as_float(v[1]);
+                } else {
+                    typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+                    const uint4v v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)loff[p], soff, 0);
+                    raw[t][p].x = __longlong_as_double(((long long)v[1] << 32) | v[0]);
+                    raw[t][p].y = __longlong_as_double(((long long)v[3] << 32) | v[2]);
+                }
+            }
+        }
+    };
+
+    int64_t g = wave;
+    if (g < ngroups) load_group(g);
+    for (; g < ngroups; g += nwaves) {
+        half8 bh[kTilesPerIter], bl[kTilesPerIter];
+        float ss[kTilesPerIter];
+#pragma unroll
+        for (int t = 0; t < kTilesPerIter; t++) {
+            float acc2 = 0.f;
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                half2_t h2 = {(_Float16)0, (_Float16)0}, l2 = {(_Float16)0, (_Float16)0};
+                if (p < NP) {
+                    const float x0 = (float)raw[t][p < NP ? p : 0].x, x1 = (float)raw[t][p < NP ? p : 0].y;
+                    h2[0] = (_Float16)(x0 * scale);
+                    h2[1] = (_Float16)(x1 * scale);
+                    l2[0] = (_Float16)fmaf(x0, scale, -(float)h2[0]);
+                    l2[1] = (_Float16)fmaf(x1, scale, -(float)h2[1]);
+                    acc2 = __builtin_amdgcn_fdot2(h2, h2, acc2, false);
+                }
+                bh[t][2 * p] = h2[0];
+                bh[t][2 * p + 1] = h2[1];
+                bl[t][2 * p] = l2[0];
+                bl[t][2 * p + 1] = l2[1];
+            }
+            ss[t] = acc2;
+        }
+        if constexpr (ACC) {
+#pragma unroll
+            for (int t = 0; t < kTilesPerIter; t++)
+#pragma unroll
+                for (int p = 0; p < NP; p++) keep[t][p] = raw[t][p];
+        }
+        {
+            int64_t gnext = g + nwaves;
+            if (gnext > ngroups - 1) gnext = ngroups - 1;  // harmless re-read on the last trip
+            load_group(gnext);
+        }
+
+        float my_m1 = 0.f;
+        bool my_amb = false;
+        if constexpr (MODE == 1) {
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < kTilesPerIter; t++) acc += ss[t];
+            my_m1 = __uint_as_float(__float_as_uint(acc) & node_mask);
+        } else {
+            float tm1[kTilesPerIter], tm2[kTilesPerIter];
+#pragma unroll
+            for (int t0 = 0; t0 < kTilesPerIter; t0 += 2) {
+                float m1[2] = {kNegBig, kNegBig}, m2[2] = {kNegBig, kNegBig};
+#pragma unroll
+                for (int b = 0; b < NB; b++) {
+                    f32x4 acc[2];
+                    // Wh*Xh + Wh*Xl + Wl*Xh, the two tiles' chains interleaved
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+                        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b][0], bh[t0 + u], breg[b], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+                        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b][0], bl[t0 + u], acc[u], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+                        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b][1], bh[t0 + u], acc[u], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        if (b < NB - 1 || RU == 4) {
+                            top2_pair(m1[u], m2[u], pack_idx(acc[u][0], (unsigned)(b * 4 + 0), idx_mask),
+                                      pack_idx(acc[u][1], (unsigned)(b * 4 + 1), idx_mask));
+                            top2_pair(m1[u], m2[u], pack_idx(acc[u][2], (unsigned)(b * 4 + 2), idx_mask),
+                                      pack_idx(acc[u][3], (unsigned)(b * 4 + 3), idx_mask));
+                        } else {
+                            // last block: only registers 0..RU-1 hold real nodes
+                            const float p0 = pack_idx(acc[u][0], (unsigned)(b * 4 + 0), idx_mask);
+                            if (RU == 1) {
+                                m2[u] = __builtin_amdgcn_fmed3f(m1[u], m2[u], p0);
+                                m1[u] = fmaxf(m1[u], p0);
+                            } else {
+                                const float p1 = pack_idx(acc[u][1], (unsigned)(b * 4 + 1), idx_mask);
+                                top2_pair(m1[u], m2[u], p0, p1);
+                                if (RU == 3) {
+                                    const float p2 = pack_idx(acc[u][2], (unsigned)(b * 4 + 2), idx_mask);
+                                    m2[u] = __builtin_amdgcn_fmed3f(m1[u], m2[u], p2);
+                                    m1[u] = fmaxf(m1[u], p2);
+                                }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    // (b*4 + r) -> id (q << 5 | b*4 + r): one OR
+                    tm1[t0 + u] = __uint_as_float(__float_as_uint(m1[u]) | ((unsigned)q << 5));
+                    tm2[t0 + u] = m2[u];
+                }
+            }
+            // Transposing merge of the 4 lane groups (rows of 16 lanes) that share a pixel.
+            //   v_permlane16_swap(A, B): odd rows of A <-> even rows of B.  With A = tile 2i's value and
+            //   B = tile 2i+1's, even rows end up holding {own, partner} of tile 2i and odd rows those of
+            //   tile 2i+1 -- in some order, which the symmetric max/min/add below do not care about.
+            //   v_permlane32_swap(A, B): lanes 32-63 of A <-> lanes 0-31 of B, applied to the (0,1) and
+            //   (2,3) partial results.  Afterwards lane row q holds tile q's fully merged result, i.e.
+            //   lane (q, pix) owns row row0 + 16 q + pix = row0 + lane.  9 swaps per 64 rows.
+            auto merge = [&](float x1, float y1, float x2, float y2, float xs, float ys, bool wide, float &o1,
+                             float &o2, float &os) {
+                uint2v r1, r2, rs;
+                if (wide) {
+                    r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x1), __float_as_uint(y1), false, false);
+                    r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x2), __float_as_uint(y2), false, false);
+                    rs = __builtin_amdgcn_permlane32_swap(__float_as_uint(xs), __float_as_uint(ys), false, false);
+                } else {
+                    r1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(x1), __float_as_uint(y1), false, false);
+                    r2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(x2), __float_as_uint(y2), false, false);
+                    rs = __builtin_amdgcn_permlane16_swap(__float_as_uint(xs), __float_as_uint(ys), false, false);
+                }
+                const float a = __uint_as_float(r1[0]), b = __uint_as_float(r1[1]);
+                o1 = fmaxf(a, b);
+                o2 = fmaxf(fmaxf(fminf(a, b), __uint_as_float(r2[0])), __uint_as_float(r2[1]));
+                os = __uint_as_float(rs[0]) + __uint_as_float(rs[1]);
+            };
+            float p1, p2, ps, q1, q2, qs, a1, a2, s2;
+            merge(tm1[0], tm1[1], tm2[0], tm2[1], ss[0], ss[1], false, p1, p2, ps);
+            merge(tm1[2], tm1[3], tm2[2], tm2[3], ss[2], ss[3], false, q1, q2, qs);
+            merge(p1, q1, p2, q2, ps, qs, true, a1, a2, s2);
+            {
+                // |Xh| <= |X| (1 + 2^-11): folded into the 1.001 factor with the sqrt's ulp
+                const float xn = __builtin_amdgcn_sqrtf(s2) * 1.001f;
+                const float tol = tol_rel * (xn * wn_max + 0.5f * wn_max * wn_max) + tol_abs * (xn + wn_max);
+                unsigned sbits = __float_as_uint(s2);
+                asm("" : "+v"(sbits));  // opaque copy: keeps the exponent test under finite-math
+                const unsigned nonfinite = (unsigned)((sbits & 0x7f800000u) == 0x7f800000u);
+                const unsigned amb = (unsigned)!((a1 - a2) > tol) | (unsigned)!(xn < x_limit) | nonfinite |
+                                     (unsigned)force_exact;
+                my_amb = amb != 0u;
+                my_m1 = a1;
+            }
+        }
+        // Both waves of a SIMD run this same stream, so MFMA bursts and VALU stretches would line up
+        // and the two pipes would take turns instead of overlapping (measured: VALU-active + MFMA-busy
+        // ~= 100 % of the runtime).  Ask the scheduler for a fine interleave inside each wave:
+        // every MFMA is followed by VALU work that does not depend on it.
+        if constexpr (MODE != 1 && SGB_VALU > 0) {
+#pragma unroll
+            for (int i = 0; i < kTilesPerIter * NB * 3; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, SGB_VALU, 0);  // VALU
+            }
+        }
+        // lane (q, pix) owns row row0 + q*16 + pix == row0 + lane
+        int64_t row0 = g * 64;
+        if (row0 > n - 64) row0 = n - 64;
+        const int64_t row = row0 + lane;
+        // rows of a shifted last group that the previous group already covered are not listed again
+        // (a row listed twice would be accumulated twice by the exact kernel)
+        my_amb = my_amb && row >= g * 64;
+        {
+            // id (q, b, r) -> node: 16 b + 4 q + r, the last block's 4x4 (q, r) grid transposed (node_of_row)
+            const unsigned id = __float_as_uint(my_m1) & node_mask;
+            const unsigned wq = id >> 5, wb = (id >> 2) & 7u, wr = id & 3u;
+            const unsigned real = wb == (unsigned)(NB - 1) ? 16u * wb + 4u * wr + wq : 16u * wb + 4u * wq + wr;
+            labels[row] = (int)real + 1;
+            if constexpr (ACC) {
+                // lane (q, pix) holds channels q*CPL.. of rows (t, pix), t = 0..3; their labels sit in
+                // lanes (t, pix).  Skipped: listed rows, rows a previous group already added.
+                const unsigned mine = real | ((my_amb || row < g * 64) ? 0x80000000u : 0u);
+#pragma unroll
+                for (int t = 0; t < kTilesPerIter; t++) {
+                    const unsigned v = (unsigned)__shfl((int)mine, t * 16 + pix);
+                    if (!(v >> 31)) {
+                        double *dst = ls + (size_t)v * c + q * CPL;
+#pragma unroll
+                        for (int p = 0; p < NP; p++) {
+                            if (q * CPL + 2 * p <= c - 2) {  // clamped slots re-read the last pair: not theirs
+                                __hip_atomic_fetch_add(dst + 2 * p, (double)keep[t][p].x, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                                __hip_atomic_fetch_add(dst + 2 * p + 1, (double)keep[t][p].y, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                        }
+                        if (q == 0)
+                            __hip_atomic_fetch_add(ls + (size_t)k * c + v, 1.0, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+        }
+        unsigned long long mask = __ballot(my_amb);
+        if (mask) {
+            if constexpr (ACC) {
+                if (lane == 0) atomicAdd(&hdr->amb_count, (unsigned)__popcll(mask));   // statistics only
+                while (mask) {
+                    const int src = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    exact_row_accumulate<T>(x, row0 + src, c, ldx, wt, k, labels, ls, lane);
+                }
+            } else {
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(&hdr->amb_count, (unsigned)__popcll(mask));
+                base = __shfl(base, 0);
+                if (my_amb) amb_list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned)row;
+            }
+        }
+    }
+    if constexpr (ACC) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < k * c + k; e += 256) {
+            const double v = ls[e];
+            if (v != 0.0) __hip_atomic_fetch_add(stats + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+}  // namespace
+}  // namespace pxsom_bmu
