@@ -28,7 +28,7 @@ def _hipcc() -> str:
     return exe
 
 
-HEADERS = ["pxsom_common.h", "pxsom_assign.h", "pxsom_wave.h", "pxsom_assign_filter_fast.h"]
+HEADERS = ["pxsom_common.h", "pxsom_assign.h", "pxsom_wave.h", "pxsom_assign_filter_fast.h", "pxsom_prep.h"]
 STAMP_PATH = SO_PATH + ".srchash"
 
 

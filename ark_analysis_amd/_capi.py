@@ -43,7 +43,7 @@ SYMBOLS = {
     "pxsom_quantile_f32": (_i32, [_vp, _i64, _i32, _i64, _f64, _i32, _vp, _vp, _sz, _vp]),
     "pxsom_scaled_rowsum_f32": (_i32, [_vp, _i64, _i32, _i64, _vp, _vp, _vp]),
     "pxsom_pair_histogram": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
-    "pxsom_batch_update_prepare": (_i32, [_vp, _i32, _i32, _i32, _vp, _f64, _f64, _vp, _sz, _vp]),
+    "pxsom_batch_update_prepare": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _f64, _f64, _vp, _sz, _vp]),
     "pxsom_gaussian_blur_hwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
     "pxsom_rownorm_workspace_bytes": (_sz, [_i64]),
     "pxsom_rowsum_filter_normalize": (_i32, [_vp, _i64, _i32, _f64, _vp, _vp, _vp, _vp, _sz, _i32, _vp]),

@@ -84,7 +84,7 @@ bool filter_fast_path(const T *x, int64_t n, int c, int64_t ldx, const Layout &L
 // is outside the fused path, nothing was done, the caller runs assign + cluster sums separately.
 int assign_accumulate(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev, int k,
                       int32_t *labels_dev, double *stats_dev, void *workspace_dev, size_t workspace_bytes,
-                      hipStream_t st, bool prepared, bool *fused);
+                      hipStream_t st, bool *fused);
 int assign_prepared(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev, int k,
                     int32_t *labels_dev, void *workspace_dev, size_t workspace_bytes, hipStream_t st);
 int prepare_only(const double *w_dev, int c, int k, void *workspace_dev, size_t workspace_bytes,

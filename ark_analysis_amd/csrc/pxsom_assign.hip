@@ -21,257 +21,12 @@
 #include <cmath>
 
 #include "pxsom_assign.h"
+#include "pxsom_prep.h"
 #include "pxsom_wave.h"
 
 using namespace pxsom_bmu;
 
 namespace {
-
-// scripts/ubench/assign_phase_timing.hip includes this file with PXSOM_PHASE_TIMING defined: s_memtime at
-// phase boundaries of the single-workgroup prep kernel and of workgroup 0 of the exact kernel
-#ifdef PXSOM_PHASE_TIMING
-__device__ long long g_phase_ticks[32];
-#define PXSOM_PHASE(i)                                          \
-    do {                                                        \
-        if (threadIdx.x == 0 && blockIdx.x == 0) g_phase_ticks[i] = clock64(); \
-    } while (0)
-#define PXSOM_PHASE_ANY(i)                                  \
-    do {                                                    \
-        if (threadIdx.x == 0) g_phase_ticks[i] = clock64(); \
-    } while (0)
-#else
-#define PXSOM_PHASE(i) \
-    do {               \
-    } while (0)
-#define PXSOM_PHASE_ANY(i) \
-    do {                   \
-    } while (0)
-#endif
-
-// ------------------------------------------------------------------------------------------------
-// 1. prep: one workgroup of NT threads.  prep_body works on a codebook that is already in `wl` (LDS when
-//    it fits, else HBM); the callers differ in how it got there.
-// ------------------------------------------------------------------------------------------------
-template <int NT>
-__device__ __forceinline__ void prep_body(const double *wl, int k, int c, AssignHdr *hdr, half8 *wfrag,
-                                          f32x4 *bias, int nb, int nch, int cpl, int idx_bits, int node_bits)
-{
-    __shared__ double s_norm2[PXSOM_MAX_NODES];
-    __shared__ unsigned long long s_key[PXSOM_MAX_NODES];  // hash of the row's bit patterns (duplicate test)
-    __shared__ double s_red[2 * (NT / 64)];
-    __shared__ int s_bad;
-    const int tid = threadIdx.x;
-    if (tid == 0) s_bad = 0;
-    __syncthreads();
-
-    // per-node squared norm (binary64), max |w| and max norm.  `parts` adjacent lanes share a node
-    // (interleaved channels, butterfly sum: every node is summed in the same order, so bit-identical
-    // rows get bit-identical norms -- the duplicate test below relies on it).
-    const int parts = 4 * k <= NT ? 4 : (2 * k <= NT ? 2 : 1);
-    const int pshift = parts == 4 ? 2 : (parts == 2 ? 1 : 0);
-    double mymax = 0.0, mynorm = 0.0;
-    bool bad = false;
-    for (int p = tid; p < (k << pshift); p += NT) {
-        const int node = p >> pshift, part = p & (parts - 1);
-        double sum = 0.0;
-        unsigned long long key = 0;
-        for (int j = part; j < c; j += parts) {
-            const double v = wl[(size_t)node * c + j];
-            bad |= !(fabs(v) <= DBL_MAX);  // NaN / Inf in the codebook
-            sum += v * v;
-            mymax = fmax(mymax, fabs(v));
-            const unsigned long long hb = (unsigned long long)__double_as_longlong(v) * 0x9E3779B97F4A7C15ull +
-                                          (unsigned long long)(j + 1) * 0xC2B2AE3D27D4EB4Full;
-            key ^= hb ^ (hb >> 29);
-        }
-        if (parts >= 2) {
-            sum += __shfl_xor(sum, 1);
-            key ^= __shfl_xor(key, 1);
-        }
-        if (parts == 4) {
-            sum += __shfl_xor(sum, 2);
-            key ^= __shfl_xor(key, 2);
-        }
-        if (part == 0) {
-            s_norm2[node] = sum;
-            s_key[node] = key;
-        }
-        mynorm = fmax(mynorm, sum);
-    }
-    if (bad) s_bad = 1;
-    // both maxima: DPP wave reduction (max(a, b) = -min(-a, -b)), then 4 partials through LDS
-    mymax = -pxsom::wave_min_f64(-mymax);
-    mynorm = mynorm == mynorm ? -pxsom::wave_min_f64(-mynorm) : mynorm;
-    constexpr int NW = NT / 64;
-    if ((tid & 63) == 0) {
-        s_red[tid >> 6] = mymax;
-        s_red[NW + (tid >> 6)] = mynorm;
-    }
-    __syncthreads();
-    PXSOM_PHASE_ANY(2);
-    double maxabs = s_red[0], wn2max = s_red[NW];
-#pragma unroll
-    for (int i = 1; i < NW; i++) {
-        maxabs = fmax(maxabs, s_red[i]);
-        wn2max = fmax(wn2max, s_red[NW + i]);
-    }
-    // scale = 2^e with maxabs*scale in [128, 256): fp16 keeps 11 significant bits there and the
-    // low halves of the split stay normal down to |x| ~ 1e-4 * maxabs.
-    int e = 0;
-    if (maxabs > 0.0 && maxabs <= DBL_MAX) {
-        int ex;
-        frexp(maxabs, &ex);  // maxabs = m * 2^ex, m in [0.5, 1)
-        e = 8 - ex;
-        if (e > 100) e = 100;
-        if (e < -100) e = -100;
-    }
-    const double scale = ldexp(1.0, e);
-    PXSOM_PHASE_ANY(3);
-    if (tid == 0) {
-        const bool badw = s_bad != 0 || !(wn2max * scale * scale <= 1.0e30);
-        hdr->amb_count = 0;
-        hdr->scale = (float)scale;
-        // rounded up by a hair; an infinite wn_max makes every row take the exact path
-        hdr->wn_max = badw ? 0.f : (float)(sqrt(wn2max) * scale * (1.0 + 1e-6));
-        hdr->force_exact = badw ? 1 : 0;  // NaN/Inf/huge codebook: every row takes the exact path
-        // coefficient of the rigorous |filter - exact| bound, see DESIGN.md "K7 error bound":
-        //   index packing 2^-(23-idx_bits) (idx_bits low mantissa bits replaced), fp32 accumulation
-        //   (3C+2)*2^-24, split residual 2^-19,
-        //   f64->f32 input rounding 2^-23;  tol = 2 * 1.25 * E
-        const double coef = ldexp(1.0, -(23 - idx_bits)) +
-                            (3.0 * c + 2.0) * ldexp(1.0, -24) + ldexp(1.0, -19) + ldexp(1.0, -23);
-        hdr->tol_rel = (float)(2.5 * coef);
-        hdr->tol_abs = (float)(2.5 * ldexp(1.0, -24) * sqrt((double)c));  // fp16 subnormal floor
-        hdr->x_limit = 60000.0f;
-        hdr->nb = nb;
-        hdr->nch = nch;
-        hdr->cpl = cpl;
-        hdr->idx_bits = idx_bits;
-        hdr->node_bits = node_bits;
-    }
-
-    // A-fragments: wfrag[(b*nsteps + s)*64 + lane], lane = (q<<4 | m): node 16b+m,
-    // slot i of lane group q in chunk h <-> channel h*4*cpl + q*cpl + i (i < cpl); s = 2h: hi, 2h+1: lo
-    const int nsteps = 2 * nch;
-    PXSOM_PHASE_ANY(4);
-    for (int f = tid; f < nb * nch * 64; f += NT) {
-        const int lane = f & 63, h = (f >> 6) % nch, b = (f >> 6) / nch;
-        const int m = lane & 15, q = lane >> 4;
-        const int node = node_of_row(b, m, nb);
-        half8 fhi, flo;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int ch = h * 4 * cpl + q * cpl + i;
-            float W = 0.f;
-            if (i < cpl && ch < c && node < k) W = (float)(wl[(size_t)node * c + ch] * scale);
-            const _Float16 hi = (_Float16)W;
-            fhi[i] = hi;
-            flo[i] = (_Float16)(W - (float)hi);
-        }
-        wfrag[(size_t)(b * nsteps + 2 * h) * 64 + lane] = fhi;
-        wfrag[(size_t)(b * nsteps + 2 * h + 1) * 64 + lane] = flo;
-    }
-    // Exact duplicates of an EARLIER node can never be the answer (their distance is identical and the
-    // reference keeps the first minimum), so they are masked out of the filter.  This matters in batch
-    // training: while the neighbourhood radius still spans the grid, all central nodes receive the same
-    // update and are bit-identical, which would otherwise send every row they win to the exact path.
-    // (s_dup reuses s_red's storage class: one flag per node.)
-    __shared__ unsigned char s_dup[PXSOM_MAX_NODES];
-    PXSOM_PHASE_ANY(5);
-    for (int node = tid; node < k; node += NT) s_dup[node] = 0;
-    __syncthreads();
-    // rows compared 4 channels per trip (the 8 reads of a trip pipeline), leaving at the first trip that
-    // differs.  Near-duplicates are the common case in early batch-training steps: gain = 1 makes every
-    // node with the same window the same mean up to the last bit, and their norms often round equal.
-    auto same_rows = [&](int prev, int node) {
-        if (s_key[prev] != s_key[node]) return false;
-        const double *a = wl + (size_t)prev * c, *b = wl + (size_t)node * c;
-        int j = 0;
-        for (; j + 3 < c; j += 4) {
-            const bool eq = (a[j] == b[j]) & (a[j + 1] == b[j + 1]) & (a[j + 2] == b[j + 2]) & (a[j + 3] == b[j + 3]);
-            if (!eq) return false;
-        }
-        for (; j < c; j++)
-            if (a[j] != b[j]) return false;
-        return true;
-    };
-    if (k <= 256) {
-        // all pairs on the row keys (equal rows have equal keys; norms are useless here: near-duplicates
-        // often round to the same norm), the range of earlier nodes split over NT/k threads per node;
-        // full channel comparison only on a key match
-        __shared__ int s_first[256];
-        for (int node = tid; node < k; node += NT) s_first[node] = 0x7fffffff;
-        __syncthreads();
-        int sp = 1;
-        while (sp * 2 * k <= NT) sp *= 2;
-        const int len = (k + sp - 1) / sp;
-        for (int p = tid; p < k * sp; p += NT) {
-            const int node = p / sp, part = p - node * sp;
-            const int lo = part * len, hi = min(node, lo + len);
-            const unsigned long long n2 = s_key[node];
-            int hit = 0x7fffffff;
-#pragma unroll 8
-            for (int prev = lo; prev < hi; prev++) hit = min(hit, s_key[prev] == n2 ? prev : 0x7fffffff);
-            if (hit != 0x7fffffff) atomicMin(&s_first[node], hit);
-        }
-        __syncthreads();
-        for (int node = tid; node < k; node += NT) {
-            const int first = s_first[node];
-            if (first >= node) continue;
-            bool dup = same_rows(first, node);
-#ifdef PXSOM_PHASE_TIMING
-            atomicAdd((unsigned long long *)&g_phase_ticks[24], 1ull);
-            if (!dup) atomicAdd((unsigned long long *)&g_phase_ticks[25], 1ull);
-#endif
-            for (int prev = first + 1; prev < node && !dup; prev++) dup = same_rows(prev, node);  // key collision
-            if (dup) s_dup[node] = 1;
-        }
-    } else
-    // hash table keyed by the row key: slot <- smallest node index hashing there; a node is a duplicate
-    // iff an earlier node with identical channels exists.
-    {
-        __shared__ int s_tab[1024];
-        for (int i = tid; i < 1024; i += NT) s_tab[i] = 0x7fffffff;
-        __syncthreads();
-        auto slot_of = [&](int node) {
-            const unsigned long long b = s_key[node];
-            return (int)((b ^ (b >> 17) ^ (b >> 41)) & 1023ull);
-        };
-        for (int node = tid; node < k; node += NT) atomicMin(&s_tab[slot_of(node)], node);
-        __syncthreads();
-        for (int node = tid; node < k; node += NT) {
-            const int first = s_tab[slot_of(node)];
-            if (first >= node) continue;
-            auto same_as = [&](int prev) { return same_rows(prev, node); };
-            bool dup = same_as(first);
-            if (!dup) {  // slot shared with a different earlier node: scan the norms (no early exit, so
-                         // the LDS reads pipeline), full comparison only on a norm match
-                const unsigned long long n2 = s_key[node];
-                int hit = -1;
-#pragma unroll 8
-                for (int prev = 0; prev < node; prev++)
-                    if (s_key[prev] == n2 && prev != first && hit < 0) hit = prev;
-                if (hit >= 0) {
-                    for (int prev = hit; prev < node && !dup; prev++) dup = same_as(prev);
-                }
-            }
-            if (dup) s_dup[node] = 1;
-        }
-    }
-    __syncthreads();
-    PXSOM_PHASE_ANY(6);
-    // bias[b*64 + lane][r] for accumulator row (lane>>4)*4 + r <-> node_of_row(b, 4q + r)
-    for (int f = tid; f < nb * 64; f += NT) {
-        const int lane = f & 63, b = f >> 6, q = lane >> 4;
-        f32x4 bv;
-        for (int r = 0; r < 4; r++) {
-            const int node = node_of_row(b, q * 4 + r, nb);
-            bv[r] = (node < k && !s_dup[node]) ? (float)(-0.5 * s_norm2[node] * scale * scale) : kNegBig;
-        }
-        bias[f] = bv;
-    }
-    PXSOM_PHASE_ANY(7);
-}
 
 __global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict__ w, int k, int c,
                                                        AssignHdr *hdr, half8 *wfrag, f32x4 *bias,
@@ -505,7 +260,8 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
                  double *dist, char *ws, const Layout &L, hipStream_t st, double *stats = nullptr,
                  bool prepared = false)
 {
-    if (!prepared) {  // prepared: pxsom_batch_update_prepare already did this for w (and cleared stats)
+    if (!prepared && !stats) {  // prepared: pxsom_batch_update_prepare did this; stats: the accumulating filter
+                                 // prepares the codebook inside its own launch
         const size_t stage_bytes = (size_t)k * c * sizeof(double);
         const int stage = stage_bytes <= 40 * 1024;
         hipLaunchKernelGGL(bmu_prep_kernel, dim3(1), dim3(256), stage ? stage_bytes : 0, st, w, k, c,
@@ -579,7 +335,7 @@ PXSOM_EXPORT int pxsom_assign(const void *x_dev, int64_t n, int c, int64_t ldx, 
 
 int pxsom_bmu::assign_accumulate(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev,
                                  int k, int32_t *labels_dev, double *stats_dev, void *workspace_dev,
-                                 size_t workspace_bytes, hipStream_t st, bool prepared, bool *fused)
+                                 size_t workspace_bytes, hipStream_t st, bool *fused)
 {
     *fused = false;
     if (n < 64 || n > 0x7fffffffLL || c < 1 || c > PXSOM_MAX_CHANNELS || k < 1 || k > PXSOM_MAX_NODES || ldx < c ||
@@ -592,7 +348,7 @@ int pxsom_bmu::assign_accumulate(const void *x_dev, int64_t n, int c, int64_t ld
     PXSOM_DISPATCH_DTYPE(dtype, x_dev, xp,
                          (filter_fast_path<T>(xp, n, c, ldx, L)
                               ? (*fused = true, assign_typed<T>(xp, n, c, ldx, w_dev, k, labels_dev, nullptr, ws, L, st,
-                                                                stats_dev, prepared))
+                                                                stats_dev, false))
                               : PXSOM_OK));
 }
 

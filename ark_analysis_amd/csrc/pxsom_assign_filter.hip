@@ -292,7 +292,7 @@ void launch_fast(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layo
                        reinterpret_cast<const half8 *>(ws + L.off_wfrag),
                        reinterpret_cast<const f32x4 *>(ws + L.off_bias), reinterpret_cast<AssignHdr *>(ws),
                        reinterpret_cast<unsigned *>(ws + L.off_list), labels, L.k, (double *)nullptr,
-                       (const double *)nullptr);
+                       (const double *)nullptr, 0, 0);
 }
 
 template <typename T, int NCH, int CPL, int NB, bool VEC2>

@@ -14,11 +14,15 @@ void launch_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layou
                 const double *w, hipStream_t st)
 {
     auto kern = bmu_filter_fast<T, CPL, 7, 1, 0, true>;
-    const size_t lds = ((size_t)L.k * c + L.k + (size_t)L.k * c) * sizeof(double);   // table + transposed codebook
+    // table | transposed codebook | row-major codebook | fragments | bias | header copy
+    const size_t lds = ((size_t)L.k * c + L.k + 2 * (size_t)L.k * c) * sizeof(double) +
+                       (size_t)7 * 2 * 64 * sizeof(half8) + (size_t)7 * 64 * sizeof(f32x4) + kHdrBytes;
     static int bpc = 0;
     if (bpc == 0) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  128 * 1024);
         int nbk = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, kern, 256, lds) != hipSuccess || nbk < 1) nbk = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, kern, 256, lds) != hipSuccess || nbk < 1) nbk = 1;
         bpc = nbk > 8 ? 8 : nbk;
     }
     const int64_t ngroups = (n + 63) / 64;
@@ -27,7 +31,7 @@ void launch_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layou
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, x, n, c, ldx,
                        reinterpret_cast<const half8 *>(ws + L.off_wfrag),
                        reinterpret_cast<const f32x4 *>(ws + L.off_bias), reinterpret_cast<AssignHdr *>(ws),
-                       reinterpret_cast<unsigned *>(ws + L.off_list), labels, L.k, stats, w);
+                       reinterpret_cast<unsigned *>(ws + L.off_list), labels, L.k, stats, w, L.idx_bits, L.node_bits);
 }
 
 }  // namespace

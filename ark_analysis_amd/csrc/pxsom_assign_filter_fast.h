@@ -8,6 +8,7 @@
 #include <cmath>
 
 #include "pxsom_assign.h"
+#include "pxsom_prep.h"
 #include "pxsom_wave.h"
 
 namespace pxsom_bmu {
@@ -142,12 +143,20 @@ template <typename T, int CPL, int NB, int RU, int MODE, bool ACC>
 __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
     const T *__restrict__ x, int64_t n, int c, int64_t ldx, const half8 *__restrict__ wfrag,
     const f32x4 *__restrict__ bias, AssignHdr *hdr, unsigned *__restrict__ amb_list,
-    int32_t *__restrict__ labels, int k, double *__restrict__ stats, const double *__restrict__ wcodes)
+    int32_t *__restrict__ labels, int k, double *__restrict__ stats, const double *__restrict__ wcodes,
+    int idx_bits, int node_bits)
 {
     extern __shared__ __attribute__((aligned(16))) char acc_smem[];
     double *ls = reinterpret_cast<double *>(acc_smem);  // [k*c + k]
     double *wt = ls + (size_t)k * c + k;                 // [c][k] transposed codebook (ACC only)
     if constexpr (ACC) {
+        // Every workgroup prepares the codebook for itself (no prep launch in front of a mini-batch step):
+        // row-major copy in LDS -> prep_body -> fragments / bias / constants in LDS, read below exactly as
+        // the plain filter reads them from the workspace.
+        double *wrow = wt + (size_t)k * c;                                           // [k][c]
+        half8 *frag_l = reinterpret_cast<half8 *>(wrow + (size_t)k * c);             // [NB][2][64]
+        f32x4 *bias_l = reinterpret_cast<f32x4 *>(frag_l + NB * 2 * 64);             // [NB][64]
+        AssignHdr *hdr_l = reinterpret_cast<AssignHdr *>(bias_l + NB * 64);
         for (int e = threadIdx.x; e < k * c + k; e += 256) ls[e] = 0.0;
         for (int e0 = threadIdx.x; e0 < k * c; e0 += 8 * 256) {   // 8 L2 loads in flight per thread
             double v[8];
@@ -158,11 +167,17 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
                 const int e = e0 + u * 256;
                 if (e < k * c) {
                     const int node = e / c, j = e - node * c;
+                    wrow[e] = v[u];
                     wt[(size_t)j * k + node] = v[u];
                 }
             }
         }
         __syncthreads();
+        prep_body<256>(wrow, k, c, hdr_l, frag_l, bias_l, NB, 1, CPL, idx_bits, node_bits);
+        __syncthreads();
+        wfrag = frag_l;
+        bias = bias_l;
+        hdr = hdr_l;
     }
     constexpr int NP = CPL / 2;  // pair loads per lane per tile
     // scores carry (b*4 + r) in their low 7 mantissa bits (inline constants <= 27: one v_and_or_b32 each);
@@ -425,7 +440,6 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
         unsigned long long mask = __ballot(my_amb);
         if (mask) {
             if constexpr (ACC) {
-                if (lane == 0) atomicAdd(&hdr->amb_count, (unsigned)__popcll(mask));   // statistics only
                 while (mask) {
                     const int src = __builtin_ctzll(mask);
                     mask &= mask - 1;

@@ -527,10 +527,16 @@ __global__ __launch_bounds__(256) void som_online_split_kernel(const T *__restri
 __global__ __launch_bounds__(256) void batch_update_kernel(double *w, int xdim, int ydim, int c,
                                                            const double *__restrict__ sums,
                                                            const double *__restrict__ counts,
-                                                           double thr, double alpha, int stage)
+                                                           double thr, double alpha, int stage,
+                                                           double *__restrict__ zero_out, int zero_count)
 {
     extern __shared__ __attribute__((aligned(16))) char upd_smem[];
     const int k = blockIdx.x, tid = threadIdx.x;
+    // the OTHER statistics buffer (the next accumulate's target) is cleared here, a slice per workgroup
+    if (zero_count > 0) {
+        const int per = (zero_count + gridDim.x - 1) / gridDim.x;
+        for (int e = k * per + tid; e < min((k + 1) * per, zero_count); e += 256) zero_out[e] = 0.0;
+    }
     const int kx = k / ydim, ky = k % ydim;
     // nodes b with max(|dx|, |dy|) <= thr  <=>  |dx|, |dy| <= floor(thr)   (integer distances)
     const int r = thr < 0.0 ? -1 : (thr > 1.0e6 ? 1000000 : (int)floor(thr));
@@ -912,16 +918,23 @@ PXSOM_EXPORT int pxsom_batch_update(double *w_dev, int xdim, int ydim, int c, co
     const size_t stage_bytes = (size_t)K * (c + 1) * sizeof(double);
     const int stage = stage_bytes <= 60 * 1024;
     hipLaunchKernelGGL(batch_update_kernel, dim3(K), dim3(256), stage ? stage_bytes : 0, st, w_dev, xdim, ydim, c,
-                       sums_dev, counts_dev, thr, alpha, stage);
+                       sums_dev, counts_dev, thr, alpha, stage, (double *)nullptr, 0);
     PXSOM_LAUNCH_CHECK("batch_update_kernel");
     return PXSOM_OK;
+}
+
+// codebooks the accumulating filter prepares for itself inside its own launch (register-resident shapes)
+static bool self_preparing_shape(int c, int k)
+{
+    const pxsom_bmu::Layout L = pxsom_bmu::make_layout(0, c, k);
+    return c % 2 == 0 && L.nch == 1 && L.nb == 7 && (k - 16 * (L.nb - 1) + 3) / 4 == 1;
 }
 
 // One mini-batch step's accumulation half: zero the statistics, BMU of every row, per-BMU sums.
 // stats_dev = [k*c sums | k counts], all binary64 (counts are exact integers below 2^53), so the
 // multi-GPU all-reduce is a single sum over one buffer.
-// flags & PXSOM_ACC_PREPARED: pxsom_batch_update_prepare already prepared the workspace for w_dev and
-// cleared stats_dev (no prep launch, no memset).
+// flags & PXSOM_ACC_PREPARED: pxsom_batch_update_prepare already cleared stats_dev (and prepared the workspace
+// for w_dev where the shape needs one).
 PXSOM_EXPORT int pxsom_batch_accumulate(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype,
                                         const double *w_dev, int k, int32_t *labels_dev, double *stats_dev,
                                         void *workspace_dev, size_t workspace_bytes, int flags, void *stream)
@@ -929,18 +942,19 @@ PXSOM_EXPORT int pxsom_batch_accumulate(const void *x_dev, int64_t n, int c, int
     if (!stats_dev || k < 1 || k > PXSOM_MAX_NODES || c < 1 || c > PXSOM_MAX_CHANNELS)
         return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_batch_accumulate: bad statistics buffer / shape");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const bool prepared = (flags & PXSOM_ACC_PREPARED) != 0;
-    // fused route (register-resident filter shapes): prep clears the statistics, the filter adds the rows
-    // it is sure of, the exact kernel the rest -- 3 launches (2 when prepared), one pass over x
+    const bool cleared = (flags & PXSOM_ACC_PREPARED) != 0;
+    if (!cleared) PXSOM_HIP_TRY(hipMemsetAsync(stats_dev, 0, (size_t)k * (c + 1) * sizeof(double), st));
+    // fused route (register-resident filter shapes): ONE launch prepares the codebook, labels every row,
+    // settles the listed rows and accumulates -- one pass over x
     bool fused = false;
     int rc = pxsom_bmu::assign_accumulate(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, stats_dev, workspace_dev,
-                                          workspace_bytes, st, prepared, &fused);
+                                          workspace_bytes, st, &fused);
     if (fused) return rc;
-    if (!prepared) PXSOM_HIP_TRY(hipMemsetAsync(stats_dev, 0, (size_t)k * (c + 1) * sizeof(double), st));
     if (n == 0) return PXSOM_OK;
     rc = check_matrix("pxsom_batch_accumulate", x_dev, n, c, ldx, dtype);
     if (rc) return rc;
-    if (prepared) {
+    // a workspace prepared by update_prepare exists only for shapes that are not self-preparing
+    if (cleared && !self_preparing_shape(c, k)) {
         if (!w_dev || !labels_dev) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_batch_accumulate: null pointer");
         rc = pxsom_bmu::assign_prepared(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, workspace_dev, workspace_bytes, st);
     } else {
@@ -952,24 +966,35 @@ PXSOM_EXPORT int pxsom_batch_accumulate(const void *x_dev, int64_t n, int c, int
     PXSOM_DISPATCH_DTYPE(dtype, x_dev, xp, (cluster_sums_typed<T, true>(xp, n, c, ldx, labels_dev, k, sums, counts, st)));
 }
 
-// The update half of a mini-batch step plus everything the NEXT pxsom_batch_accumulate needs before its
-// filter kernel: codebook update from the (all-reduced) statistics, then one prep launch that also clears
-// the statistics.  (A single-workgroup fusion of the two was measured slower: its window sums are LDS-
-// bandwidth bound on one CU, 9-14 us at radius 6; so was a last-workgroup-runs-prep variant.)
+// The update half of a mini-batch step plus what the NEXT pxsom_batch_accumulate(PXSOM_ACC_PREPARED) relies on:
+// codebook update from the (all-reduced) statistics in stats_dev; stats_next_dev -- the buffer the next
+// accumulate will fill -- cleared by the same launch (pass the other one of two alternating buffers; with
+// stats_next_dev == stats_dev or NULL the buffer is cleared by a separate fill); and, for codebook shapes the
+// accumulating filter does not prepare itself, the workspace prepared for the new codebook.
+// (A single-workgroup fusion of update and prep was measured slower: its window sums are LDS-bandwidth bound
+// on one CU, 9-14 us at radius 6; so was a last-workgroup-runs-prep variant.)
 PXSOM_EXPORT int pxsom_batch_update_prepare(double *w_dev, int xdim, int ydim, int c, double *stats_dev,
-                                            double thr, double alpha, void *workspace_dev,
-                                            size_t workspace_bytes, void *stream)
+                                            double *stats_next_dev, double thr, double alpha,
+                                            void *workspace_dev, size_t workspace_bytes, void *stream)
 {
     if (xdim < 1 || ydim < 1 || (int64_t)xdim * ydim > PXSOM_MAX_NODES || c < 1 || c > PXSOM_MAX_CHANNELS)
         return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "pxsom_batch_update_prepare: shape %dx%d x %d", xdim, ydim, c);
-    if (!w_dev || !stats_dev || !workspace_dev)
-        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_batch_update_prepare: null pointer");
+    if (!w_dev || !stats_dev) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_batch_update_prepare: null pointer");
     const int k = xdim * ydim;
-    if (workspace_bytes < pxsom_assign_workspace_bytes(0, c, k))
+    const bool needs_ws = !self_preparing_shape(c, k);
+    if (needs_ws && (!workspace_dev || workspace_bytes < pxsom_assign_workspace_bytes(0, c, k)))
         return pxsom::fail(PXSOM_ERR_WORKSPACE, "pxsom_batch_update_prepare: workspace %zu bytes too small",
                            workspace_bytes);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    int rc = pxsom_batch_update(w_dev, xdim, ydim, c, stats_dev, stats_dev + (size_t)k * c, thr, alpha, stream);
-    if (rc) return rc;
-    return pxsom_bmu::prepare_only(w_dev, c, k, workspace_dev, workspace_bytes, stats_dev, st);
+    const int nstats = k * (c + 1);
+    const bool other = stats_next_dev && stats_next_dev != stats_dev;
+    const size_t stage_bytes = (size_t)nstats * sizeof(double);
+    const int stage = stage_bytes <= 60 * 1024;
+    hipLaunchKernelGGL(batch_update_kernel, dim3(k), dim3(256), stage ? stage_bytes : 0, st, w_dev, xdim, ydim, c,
+                       stats_dev, stats_dev + (size_t)k * c, thr, alpha, stage, other ? stats_next_dev : nullptr,
+                       other ? nstats : 0);
+    PXSOM_LAUNCH_CHECK("batch_update_kernel");
+    if (!other) PXSOM_HIP_TRY(hipMemsetAsync(stats_dev, 0, stage_bytes, st));
+    if (!needs_ws) return PXSOM_OK;
+    return pxsom_bmu::prepare_only(w_dev, c, k, workspace_dev, workspace_bytes, nullptr, st);
 }

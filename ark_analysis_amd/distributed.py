@@ -61,13 +61,12 @@ class HipKernels:
     def batch_update(self, w, xdim, ydim, sums, counts, thr, alpha):
         return self._sd.batch_update(w, xdim, ydim, sums, counts, thr, alpha)
 
-    def update_prepare(self, w, xdim, ydim, stats, thr, alpha) -> None:
-        """Codebook update + statistics cleared + workspace prepared for the next accumulate (one launch)."""
-        if self._ws is None:
-            self._sd.batch_update(w, xdim, ydim, stats[: w.numel()].view_as(w), stats[w.numel():], thr, alpha)
-            return
-        self._sd.batch_update_prepare(w, xdim, ydim, stats, thr, alpha, self._ws)
-        self._prepared_for = (w.data_ptr(), stats.data_ptr())
+    def update_prepare(self, w, xdim, ydim, stats, thr, alpha, stats_next=None) -> None:
+        """Codebook update from ``stats``; the same launch clears ``stats_next`` (the buffer of the next
+        accumulate) and, where the shape needs one, a prep launch readies the workspace."""
+        self._sd.batch_update_prepare(w, xdim, ydim, stats, thr, alpha, self._ws, stats_next=stats_next)
+        cleared = stats_next if stats_next is not None else stats
+        self._prepared_for = (w.data_ptr(), cleared.data_ptr())
 
 
 def _world(group) -> int:
@@ -90,12 +89,21 @@ class BatchSOMTrainer:
             default_radius_range(xdim, ydim)
         self.group = group
         self.kernels = kernels if kernels is not None else HipKernels()
-        # statistics: [K*C sums | K counts], all float64 (counts are exact integers): one memset, one
-        # all-reduce, no conversions
-        self.stats = torch.zeros(self.k * self.c + self.k, dtype=torch.float64, device=device)
-        self.sums = self.stats[: self.k * self.c].view(self.k, self.c)
-        self.counts = self.stats[self.k * self.c:]
+        # statistics: [K*C sums | K counts], all float64 (counts are exact integers): one all-reduce, no
+        # conversions.  Two buffers alternate between steps, so the update launch of step g can clear the
+        # buffer step g+1 accumulates into while other workgroups still read step g's.
+        self._stats_pair = [torch.zeros(self.k * self.c + self.k, dtype=torch.float64, device=device)
+                            for _ in range(2)]
+        self.stats = self._stats_pair[0]
         self.label_buf = None
+
+    @property
+    def sums(self) -> torch.Tensor:
+        return self.stats[: self.k * self.c].view(self.k, self.c)
+
+    @property
+    def counts(self) -> torch.Tensor:
+        return self.stats[self.k * self.c:]
 
     def step(self, x_local: torch.Tensor, w: torch.Tensor, g: int, total_steps: int,
              chained: bool = False) -> None:
@@ -107,6 +115,7 @@ class BatchSOMTrainer:
         nrows = view.shape[0]
         if self.label_buf is None or self.label_buf.numel() < nrows:
             self.label_buf = torch.empty(max(nrows, 1), dtype=torch.int32, device=x_local.device)
+        self.stats, stats_next = self._stats_pair[g % 2], self._stats_pair[(g + 1) % 2]
         if chained and hasattr(self.kernels, "update_prepare"):
             self.kernels.accumulate(view, w, self.label_buf, self.stats, chained=True)
         else:
@@ -115,7 +124,7 @@ class BatchSOMTrainer:
             dist.all_reduce(self.stats, op=dist.ReduceOp.SUM, group=self.group)
         thr, alpha = batch_schedule(g, total_steps, self.alpha_range, self.radius_range)
         if hasattr(self.kernels, "update_prepare"):
-            self.kernels.update_prepare(w, self.xdim, self.ydim, self.stats, thr, alpha)
+            self.kernels.update_prepare(w, self.xdim, self.ydim, self.stats, thr, alpha, stats_next)
         else:
             self.kernels.batch_update(w, self.xdim, self.ydim, self.sums, self.counts, thr, alpha)
 

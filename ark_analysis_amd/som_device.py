@@ -115,19 +115,27 @@ def batch_accumulate(x: torch.Tensor, w: torch.Tensor, labels: torch.Tensor, sta
 
 
 def batch_update_prepare(w: torch.Tensor, xdim: int, ydim: int, stats: torch.Tensor, thr: float,
-                         alpha: float, workspace: AssignWorkspace) -> None:
-    """Batch-rule codebook update from ``stats`` ([K*C sums | K counts], all-reduced), in place on ``w``;
-    then ``stats`` is cleared and ``workspace`` prepared for the new codebook (next accumulate:
-    ``prepared=True``)."""
+                         alpha: float, workspace: Optional[AssignWorkspace],
+                         stats_next: Optional[torch.Tensor] = None) -> None:
+    """Batch-rule codebook update from ``stats`` ([K*C sums | K counts], all-reduced), in place on ``w``.
+    ``stats_next`` -- the buffer the next accumulate fills (alternate two) -- is cleared by the same launch
+    (``None``: ``stats`` itself is cleared afterwards); ``workspace`` is prepared for the new codebook where
+    the shape needs that.  Next accumulate: ``prepared=True``."""
     w = _codebook(w)
     k, c = w.shape
     if k != xdim * ydim:
         raise ValueError(f"codebook has {k} nodes, grid is {xdim}x{ydim}")
     if stats.dtype != torch.float64 or stats.numel() != k * (c + 1) or not stats.is_contiguous():
         raise ValueError("stats must be a contiguous float64 vector of K*(C+1) entries")
+    if stats_next is not None and (stats_next.dtype != torch.float64 or stats_next.numel() != stats.numel()
+                                   or not stats_next.is_contiguous()):
+        raise ValueError("stats_next must look like stats")
     rc = _capi.lib().pxsom_batch_update_prepare(w.data_ptr(), int(xdim), int(ydim), c, stats.data_ptr(),
-                                                float(thr), float(alpha), workspace.buf.data_ptr(),
-                                                workspace.bytes, _capi.stream_ptr())
+                                                stats_next.data_ptr() if stats_next is not None else None,
+                                                float(thr), float(alpha),
+                                                workspace.buf.data_ptr() if workspace is not None else None,
+                                                workspace.bytes if workspace is not None else 0,
+                                                _capi.stream_ptr())
     _capi.check(rc, "pxsom_batch_update_prepare")
 
 

@@ -130,19 +130,22 @@ int pxsom_train_online(const void *x_dev, int64_t n, int c, int64_t ldx, int dty
  *               returns them); stats[b, :] += x_i, stats_count[b] += 1 for b = label_i - 1.
  *   update:     num[k] = sum_{b: cheb(k,b) <= thr} sums[b], den[k] = sum_{b: ...} counts[b]
  *               den[k] > 0:  w[k] += (1 - (1-alpha)^den[k]) * (num[k]/den[k] - w[k])
- *   update_prepare: the same update with sums/counts = the two halves of stats_dev, then stats_dev is
- *               cleared and workspace_dev is prepared for the new codebook, so that the next
- *               pxsom_batch_accumulate(..., PXSOM_ACC_PREPARED, ...) starts with its filter kernel
- *               (update + one prep launch that also clears the statistics).
+ *   update_prepare: the same update with sums/counts = the two halves of stats_dev; the same launch clears
+ *               stats_next_dev, the buffer the next accumulate will fill (alternate two buffers; NULL or
+ *               == stats_dev: cleared by a separate fill), so the next
+ *               pxsom_batch_accumulate(..., PXSOM_ACC_PREPARED, ...) is a single launch for the
+ *               register-resident shapes (the accumulating filter prepares the codebook itself); other
+ *               shapes get workspace_dev prepared for the new codebook here (may be NULL otherwise).
  * Oracle of record: oracle/pxsom_oracle.c orc_cluster_sums / orc_batch_update. */
-#define PXSOM_ACC_PREPARED 1 /* flags: workspace prepared for w_dev and stats_dev cleared by update_prepare */
+#define PXSOM_ACC_PREPARED 1 /* flags: stats_dev was cleared (and the workspace prepared) by update_prepare */
 int pxsom_batch_accumulate(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype,
                            const double *w_dev, int k, int32_t *labels_dev, double *stats_dev,
                            void *workspace_dev, size_t workspace_bytes, int flags, void *stream);
 int pxsom_batch_update(double *w_dev, int xdim, int ydim, int c, const double *sums_dev,
                        const double *counts_dev, double thr, double alpha, void *stream);
-int pxsom_batch_update_prepare(double *w_dev, int xdim, int ydim, int c, double *stats_dev, double thr,
-                               double alpha, void *workspace_dev, size_t workspace_bytes, void *stream);
+int pxsom_batch_update_prepare(double *w_dev, int xdim, int ydim, int c, double *stats_dev,
+                               double *stats_next_dev, double thr, double alpha, void *workspace_dev,
+                               size_t workspace_bytes, void *stream);
 
 /* ---- pre-processing (create_fov_pixel_data and the 99.9 % values) -----------------------------
  * reference: pixie_preprocessing.py:47-49 -> scipy.ndimage.gaussian_filter(plane, sigma) per channel:

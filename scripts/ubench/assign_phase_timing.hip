@@ -26,7 +26,7 @@ int main()
     hipMemcpy(dw, w.data(), w.size() * 8, hipMemcpyHostToDevice);
     for (int rep = 0; rep < 3; rep++) {
         bool fused = false;
-        int rc = pxsom_bmu::assign_accumulate(dx, n, c, c, PXSOM_F32, dw, K, dl, dstats, ws, wsb, 0, false, &fused);
+        int rc = pxsom_bmu::assign_accumulate(dx, n, c, c, PXSOM_F32, dw, K, dl, dstats, ws, wsb, 0, &fused);
         hipDeviceSynchronize();
         long long t[32];
         hipMemcpyFromSymbol(t, HIP_SYMBOL(g_phase_ticks), sizeof(t));

@@ -48,9 +48,9 @@ def test_argument_validation_without_gpu():
     # dtype codes: 0 / 1 / 2 (fp32 / fp64 / fp16) are accepted, anything else is not
     assert lib.pxsom_cluster_sums(None, 0, 22, 22, 2, None, 100, None, None, None) == -1   # null tables, dtype ok
     assert lib.pxsom_cluster_sums(None, 0, 22, 22, 3, None, 100, None, None, None) == -2
-    rc = lib.pxsom_batch_update_prepare(None, 10, 10, 22, None, 1.0, 0.05, None, 0, None)
+    rc = lib.pxsom_batch_update_prepare(None, 10, 10, 22, None, None, 1.0, 0.05, None, 0, None)
     assert rc == -1 and b"null" in lib.pxsom_last_error()
-    rc = lib.pxsom_batch_update_prepare(None, 40, 40, 22, None, 1.0, 0.05, None, 0, None)
+    rc = lib.pxsom_batch_update_prepare(None, 40, 40, 22, None, None, 1.0, 0.05, None, 0, None)
     assert rc == -2
     rc = lib.pxsom_batch_accumulate(None, 10, 22, 22, 0, None, 100, None, None, None, 0, 0, None)
     assert rc == -1

@@ -316,6 +316,13 @@ def test_batch_update_prepare_matches_oracle_and_chains(gpu, oracle, xdim, ydim,
         want_w = oracle.batch_update(w, xdim, ydim, sums, counts.astype(np.int64), thr, alpha)
         wd = torch.from_numpy(w.copy()).to(gpu)
         stats = torch.from_numpy(np.concatenate([sums.reshape(-1), counts])).to(gpu)
+        # two alternating buffers: the launch clears the OTHER one and leaves the one it read alone
+        other = torch.full_like(stats, 7.0)
+        wd2 = torch.from_numpy(w.copy()).to(gpu)
+        sd.batch_update_prepare(wd2, xdim, ydim, stats, thr, alpha, ws, stats_next=other)
+        np.testing.assert_allclose(wd2.cpu().numpy(), want_w, rtol=1e-12, atol=0)
+        assert float(other.abs().max()) == 0.0 and float(stats.abs().max()) > 0.0
+        # single buffer: cleared after the update
         sd.batch_update_prepare(wd, xdim, ydim, stats, thr, alpha, ws)
         np.testing.assert_allclose(wd.cpu().numpy(), want_w, rtol=1e-12, atol=0)
         assert float(stats.abs().max()) == 0.0
