@@ -102,7 +102,7 @@ __device__ __forceinline__ void exact_rows_loop(const T *__restrict__ x, int c, 
                                                 const double *__restrict__ w, const double *wt, int k,
                                                 unsigned count, const unsigned *__restrict__ amb_list,
                                                 int32_t *__restrict__ labels, int use_lds,
-                                                double *__restrict__ stats, unsigned wave, unsigned nwaves,
+                                                unsigned wave, unsigned nwaves,
                                                 int lane, ExactRows<T, RB> &cur)
 {
     for (unsigned e0 = wave * RB; e0 < count; e0 += nwaves * RB) {
@@ -159,21 +159,6 @@ __device__ __forceinline__ void exact_rows_loop(const T *__restrict__ x, int c, 
             const unsigned cand = best[u] == smin ? (unsigned)bestk[u] : 0xffffffffu;
             const int win = (int)pxsom::wave_min_u32(cand);  // 0x7fffffff: no finite distance (NaN row)
             if (lane == 0) labels[cur.rows[u]] = win == 0x7fffffff ? 0 : win + 1;
-            // fused batch accumulation: the filter left this row's contribution to us
-            if (stats && e0 + u < count && win != 0x7fffffff) {
-                double *dst = stats + (size_t)win * c;
-                if (lane < c)
-                    __hip_atomic_fetch_add(dst + lane,
-                                           __longlong_as_double(((long long)cur.x_hi[u][0] << 32) | cur.x_lo[u][0]),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (lane + 64 < c)
-                    __hip_atomic_fetch_add(dst + lane + 64,
-                                           __longlong_as_double(((long long)cur.x_hi[u][1] << 32) | cur.x_lo[u][1]),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (lane == 0)
-                    __hip_atomic_fetch_add(stats + (size_t)k * c + win, 1.0, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-            }
         }
         PXSOM_PHASE(12);
         if (en < count) cur = nxt;
@@ -185,8 +170,7 @@ __global__ __launch_bounds__(256) void bmu_exact_kernel(const T *__restrict__ x,
                                                         const double *__restrict__ w, int k,
                                                         const AssignHdr *hdr,
                                                         const unsigned *__restrict__ amb_list,
-                                                        int32_t *__restrict__ labels, int use_lds,
-                                                        double *__restrict__ stats)
+                                                        int32_t *__restrict__ labels, int use_lds)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double *wt = reinterpret_cast<double *>(smem_raw);  // [c][k] transposed codebook
@@ -224,9 +208,9 @@ __global__ __launch_bounds__(256) void bmu_exact_kernel(const T *__restrict__ x,
     }
     PXSOM_PHASE(10);
     if (wide)
-        exact_rows_loop<T, 4>(x, c, ldx, w, wt, k, count, amb_list, labels, use_lds, stats, wave, nwaves, lane, cur4);
+        exact_rows_loop<T, 4>(x, c, ldx, w, wt, k, count, amb_list, labels, use_lds, wave, nwaves, lane, cur4);
     else
-        exact_rows_loop<T, 1>(x, c, ldx, w, wt, k, count, amb_list, labels, use_lds, stats, wave, nwaves, lane, cur1);
+        exact_rows_loop<T, 1>(x, c, ldx, w, wt, k, count, amb_list, labels, use_lds, wave, nwaves, lane, cur1);
 }
 
 // distance of every row to its labelled node (only when the caller asks for dists)
@@ -267,7 +251,7 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
         hipLaunchKernelGGL(bmu_prep_kernel, dim3(1), dim3(256), stage ? stage_bytes : 0, st, w, k, c,
                            reinterpret_cast<AssignHdr *>(ws),
                            reinterpret_cast<half8 *>(ws + L.off_wfrag), reinterpret_cast<f32x4 *>(ws + L.off_bias),
-                           L.nb, L.nch, L.cpl, L.idx_bits, L.node_bits, stage, stats, stats ? k * (c + 1) : 0);
+                           L.nb, L.nch, L.cpl, L.idx_bits, L.node_bits, stage, (double *)nullptr, 0);
         PXSOM_LAUNCH_CHECK("bmu_prep_kernel");
     }
 
@@ -286,7 +270,7 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
     if (egrid < 1) egrid = 1;
     hipLaunchKernelGGL(bmu_exact_kernel<T>, dim3(egrid), dim3(256), use_lds ? wt_bytes : 0, st, x, c, ldx, w,
                        k, reinterpret_cast<const AssignHdr *>(ws),
-                       reinterpret_cast<const unsigned *>(ws + L.off_list), labels, use_lds, stats);
+                       reinterpret_cast<const unsigned *>(ws + L.off_list), labels, use_lds);
     PXSOM_LAUNCH_CHECK("bmu_exact_kernel");
 
     if (dist) {
