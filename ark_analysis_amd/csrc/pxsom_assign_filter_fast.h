@@ -95,9 +95,28 @@ __device__ __forceinline__ void exact_row_accumulate(const T *__restrict__ x, in
     const int n0 = lane, n1 = lane + 64;
     const int c0 = n0 < k ? n0 : k - 1, c1 = n1 < k ? n1 : k - 1;
     double d0 = 0.0, d1 = 0.0;
-    for (int j = 0; j < c; j++) {
-        const double xj = __longlong_as_double(((long long)__builtin_amdgcn_readlane(xhi, j) << 32) |
-                                               (unsigned)__builtin_amdgcn_readlane(xlo, j));
+    auto channel = [&](int j) {   // the row's channel j, from the lane that holds it
+        return __longlong_as_double(((long long)__builtin_amdgcn_readlane(xhi, j) << 32) |
+                                    (unsigned)__builtin_amdgcn_readlane(xlo, j));
+    };
+    int j = 0;
+    for (; j + 4 <= c; j += 4) {   // the 8 LDS reads of a trip are issued together; sums stay in j order
+        double wa[4], wb[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            wa[u] = wt[(size_t)(j + u) * k + c0];
+            wb[u] = wt[(size_t)(j + u) * k + c1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const double xj = channel(j + u);
+            const double t0 = xj - wa[u], t1 = xj - wb[u];
+            d0 += t0 * t0;
+            d1 += t1 * t1;
+        }
+    }
+    for (; j < c; j++) {
+        const double xj = channel(j);
         const double t0 = xj - wt[(size_t)j * k + c0], t1 = xj - wt[(size_t)j * k + c1];
         d0 += t0 * t0;
         d1 += t1 * t1;
