@@ -582,7 +582,9 @@ __global__ __launch_bounds__(256) void batch_update_kernel(double *w, int xdim, 
     }
     if (den > 0.0) {
         const double gain = 1.0 - pow(1.0 - alpha, den);
-        w[(size_t)k * c + j] = wv + gain * (num / den - wv);
+        // gain == 1 exactly (wide windows): the node is the window mean itself, so nodes sharing a window are
+        // bit-identical (and masked as duplicates by prep) instead of one ulp apart (orc_batch_update)
+        w[(size_t)k * c + j] = gain == 1.0 ? num / den : wv + gain * (num / den - wv);
     }
 }
 
