@@ -9,8 +9,7 @@ mini-batch step (9.2 KB at K=100, C=22 -- latency-bound, xGMI bandwidth is irrel
 
 One pass = ``batch_steps`` mini-batch steps; step g (of G = rlen*batch_steps) uses the local
 rows i with i % batch_steps == g % batch_steps:
-    labels = BMU(rows, W)                       (exact rule, pxsom_assign)
-    S[b] += x_i, n[b] += 1                      (pxsom_cluster_sums)      -> all-reduce(S, n)
+    labels = BMU(rows, W); S[b] += x_i, n[b] += 1     (pxsom_batch_accumulate: one launch)  -> all-reduce(S, n)
     thr = r0 - (r0-r1) g/G (0.5 once < 1);  alpha = a0 - (a0-a1) g/G
     W_k += (1 - (1-alpha)^den_k) (num_k/den_k - W_k)                      (pxsom_batch_update_prepare:
                                                   also clears S, n and prepares the next step's BMU search)
@@ -47,13 +46,13 @@ class HipKernels:
     def accumulate(self, x: torch.Tensor, w: torch.Tensor, labels: torch.Tensor, stats: torch.Tensor,
                    chained: bool = False) -> None:
         """zero(stats); labels = BMU(x, w); stats[label] += [x, 1]  (stats = [K*C sums | K counts] f64).
-        ``chained``: the caller guarantees that neither ``w`` nor ``stats`` changed since this object's
-        last ``update_prepare`` (then its prep + memset are skipped)."""
+        ``chained``: the caller guarantees that neither ``w`` nor ``stats`` changed since this object's last
+        ``update_prepare`` cleared ``stats`` (then no memset / prep launch precedes the filter)."""
         n, c = x.shape
         if self._ws is None or not self._ws.fits(n, c, w.shape[0]):
             self._ws = self._sd.AssignWorkspace(n, c, w.shape[0], x.device)
             self._prepared_for = None
-        # the previous step's update_prepare left the workspace prepared for exactly this codebook
+        # the previous step's update_prepare cleared exactly this buffer for exactly this codebook
         prepared = chained and self._prepared_for == (w.data_ptr(), stats.data_ptr())
         self._prepared_for = None
         self._sd.batch_accumulate(x, w, labels, stats, self._ws, prepared=prepared)

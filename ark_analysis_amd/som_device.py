@@ -97,7 +97,8 @@ ACC_PREPARED = 1  # include/pxsom.h PXSOM_ACC_PREPARED
 def batch_accumulate(x: torch.Tensor, w: torch.Tensor, labels: torch.Tensor, stats: torch.Tensor,
                      workspace: AssignWorkspace, prepared: bool = False) -> None:
     """Zero ``stats`` ([K*C sums | K counts], float64), label every row of ``x`` and accumulate.
-    ``prepared``: ``batch_update_prepare`` already prepared ``workspace`` for ``w`` and cleared ``stats``."""
+    ``prepared``: ``batch_update_prepare`` already cleared ``stats`` (and, for shapes the accumulating filter
+    does not prepare itself, readied ``workspace`` for ``w``): no memset, no prep launch."""
     n, c, ldx, dt = _matrix_args(x)
     w = _codebook(w)
     k = w.shape[0]
