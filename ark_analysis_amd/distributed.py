@@ -5,7 +5,7 @@ The reference has no analogue (its training is pyFlowSOM's sequential loop,
 /root/reference/src/ark/phenotyping/cluster_helpers.py:106-109, "replicas only" in DESIGN.md).
 This is the throughput-mode rule BASELINE.json's north_star asks for: pixels never leave their
 GPU; the only exchange is one all-reduce of the [K, C+1] binary64 statistics per
-mini-batch step (9.2 KB at K=100, C=22 -- latency-bound, xGMI bandwidth is irrelevant).
+mini-batch step (18.4 KB at K=100, C=22 -- latency-bound, xGMI bandwidth is irrelevant).
 
 One pass = ``batch_steps`` mini-batch steps; step g (of G = rlen*batch_steps) uses the local
 rows i with i % batch_steps == g % batch_steps:
