@@ -29,7 +29,7 @@ struct AssignHdr {
 
 struct Layout {
     int k, nb, nch, cpl, nsteps, idx_bits, node_bits;
-    size_t off_wfrag, off_bias, off_list, total;
+    size_t off_wfrag, off_bias, off_wt, off_list, total;
 };
 
 inline Layout make_layout(int64_t n, int c, int k)
@@ -52,7 +52,11 @@ inline Layout make_layout(int64_t n, int c, int k)
     L.node_bits = L.idx_bits;
     L.off_wfrag = kHdrBytes;
     L.off_bias = L.off_wfrag + (size_t)L.nb * L.nsteps * 64 * sizeof(half8);
-    L.off_list = pxsom::align_up(L.off_bias + (size_t)L.nb * 64 * sizeof(f32x4), 256);
+    // transposed binary64 codebook [c][k] for the exact kernel when the codebook is too big for its LDS
+    // (config 5: 400 x 40 = 128 KB); smaller codebooks do not use the region (kept tiny)
+    L.off_wt = pxsom::align_up(L.off_bias + (size_t)L.nb * 64 * sizeof(f32x4), 256);
+    const size_t wt_bytes = (size_t)k * c * sizeof(double);
+    L.off_list = pxsom::align_up(L.off_wt + (wt_bytes > 64 * 1024 ? wt_bytes : 0), 256);
     L.total = L.off_list + (size_t)(n > 0 ? n : 1) * sizeof(unsigned);
     return L;
 }

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict_
                                                        AssignHdr *hdr, half8 *wfrag, f32x4 *bias,
                                                        int nb, int nch, int cpl, int idx_bits,
                                                        int node_bits, int stage, double *zero_ptr,
-                                                       int zero_count)
+                                                       int zero_count, double *wt_out)
 {
     PXSOM_PHASE_ANY(0);
     // fused batch accumulation: the statistics buffer is cleared here instead of by a memset node
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict_
     }
     __syncthreads();
     PXSOM_PHASE_ANY(1);
-    prep_body<256>(wl, k, c, hdr, wfrag, bias, nb, nch, cpl, idx_bits, node_bits);
+    prep_body<256>(wl, k, c, hdr, wfrag, bias, nb, nch, cpl, idx_bits, node_bits, wt_out);
 }
 
 
@@ -124,8 +124,10 @@ __device__ __forceinline__ void exact_rows_loop(const T *__restrict__ x, int c, 
             for (int u = 0; u < RB; u++) d0[u] = d1[u] = 0.0;
 #pragma unroll 2
             for (int j = 0; j < c; j++) {
-                const double w0 = use_lds ? wt[(size_t)j * k + c0] : w[(size_t)c0 * c + j];
-                const double w1 = use_lds ? wt[(size_t)j * k + c1] : w[(size_t)c1 * c + j];
+                // LDS copy, or (big codebooks) the transposed copy prep left in the workspace: either way lanes
+                // read consecutive nodes of channel j
+                const double w0 = wt[(size_t)j * k + c0];
+                const double w1 = wt[(size_t)j * k + c1];
                 const int h = j >> 6, jj = j & 63;
 #pragma unroll
                 for (int u = 0; u < RB; u++) {
@@ -170,10 +172,12 @@ __global__ __launch_bounds__(256) void bmu_exact_kernel(const T *__restrict__ x,
                                                         const double *__restrict__ w, int k,
                                                         const AssignHdr *hdr,
                                                         const unsigned *__restrict__ amb_list,
-                                                        int32_t *__restrict__ labels, int use_lds)
+                                                        int32_t *__restrict__ labels, int use_lds,
+                                                        const double *__restrict__ wt_global)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double *wt = reinterpret_cast<double *>(smem_raw);  // [c][k] transposed codebook
+    // [c][k] transposed codebook: staged in LDS, or (too big for LDS) the copy prep wrote to the workspace
+    const double *wt = use_lds ? reinterpret_cast<const double *>(smem_raw) : wt_global;
     PXSOM_PHASE(8);
     const unsigned count = hdr->amb_count;
     const int lane = threadIdx.x & 63;
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(256) void bmu_exact_kernel(const T *__restrict__ x,
                 const int e = e0 + u * 256;
                 if (e < k * c) {
                     const int node = e / c, j = e - node * c;
-                    wt[(size_t)j * k + node] = v[u];
+                    reinterpret_cast<double *>(smem_raw)[(size_t)j * k + node] = v[u];
                 }
             }
         }
@@ -251,7 +255,8 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
         hipLaunchKernelGGL(bmu_prep_kernel, dim3(1), dim3(256), stage ? stage_bytes : 0, st, w, k, c,
                            reinterpret_cast<AssignHdr *>(ws),
                            reinterpret_cast<half8 *>(ws + L.off_wfrag), reinterpret_cast<f32x4 *>(ws + L.off_bias),
-                           L.nb, L.nch, L.cpl, L.idx_bits, L.node_bits, stage, (double *)nullptr, 0);
+                           L.nb, L.nch, L.cpl, L.idx_bits, L.node_bits, stage, (double *)nullptr, 0,
+                           L.off_list > L.off_wt ? reinterpret_cast<double *>(ws + L.off_wt) : nullptr);
         PXSOM_LAUNCH_CHECK("bmu_prep_kernel");
     }
 
@@ -270,7 +275,8 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
     if (egrid < 1) egrid = 1;
     hipLaunchKernelGGL(bmu_exact_kernel<T>, dim3(egrid), dim3(256), use_lds ? wt_bytes : 0, st, x, c, ldx, w,
                        k, reinterpret_cast<const AssignHdr *>(ws),
-                       reinterpret_cast<const unsigned *>(ws + L.off_list), labels, use_lds);
+                       reinterpret_cast<const unsigned *>(ws + L.off_list), labels, use_lds,
+                       reinterpret_cast<const double *>(ws + L.off_wt));
     PXSOM_LAUNCH_CHECK("bmu_exact_kernel");
 
     if (dist) {
@@ -362,7 +368,8 @@ int pxsom_bmu::prepare_only(const double *w_dev, int c, int k, void *workspace_d
     hipLaunchKernelGGL(bmu_prep_kernel, dim3(1), dim3(256), stage ? stage_bytes : 0, st, w_dev, k, c,
                        reinterpret_cast<AssignHdr *>(ws), reinterpret_cast<half8 *>(ws + L.off_wfrag),
                        reinterpret_cast<f32x4 *>(ws + L.off_bias), L.nb, L.nch, L.cpl, L.idx_bits, L.node_bits, stage,
-                       zero_stats, zero_stats ? k * (c + 1) : 0);
+                       zero_stats, zero_stats ? k * (c + 1) : 0,
+                       L.off_list > L.off_wt ? reinterpret_cast<double *>(ws + L.off_wt) : nullptr);
     PXSOM_LAUNCH_CHECK("bmu_prep_kernel");
     return PXSOM_OK;
 }

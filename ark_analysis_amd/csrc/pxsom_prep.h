@@ -40,8 +40,16 @@ __device__ long long g_phase_ticks[32];
 // ------------------------------------------------------------------------------------------------
 template <int NT>
 __device__ __forceinline__ void prep_body(const double *wl, int k, int c, AssignHdr *hdr, half8 *wfrag,
-                                          f32x4 *bias, int nb, int nch, int cpl, int idx_bits, int node_bits)
+                                          f32x4 *bias, int nb, int nch, int cpl, int idx_bits, int node_bits,
+                                          double *wt_out = nullptr)
 {
+    // big codebooks: a transposed copy [c][k] for the exact kernel (coalesced reads, lanes <-> nodes)
+    if (wt_out) {
+        for (int e = threadIdx.x; e < k * c; e += NT) {
+            const int node = e / c, j = e - node * c;
+            wt_out[(size_t)j * k + node] = wl[e];
+        }
+    }
     __shared__ double s_norm2[PXSOM_MAX_NODES];
     __shared__ unsigned long long s_key[PXSOM_MAX_NODES];  // hash of the row's bit patterns (duplicate test)
     __shared__ double s_red[2 * (NT / 64)];
