@@ -182,6 +182,45 @@ def test_cluster_sums_matches_oracle(gpu, oracle):
         np.testing.assert_allclose(s.cpu().numpy(), ws, rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize("n,c,k,dtype,mode", [
+    (300_001, 22, 100, np.float32, "uniform"),   # 2 rows per instruction, 8 tables per CU
+    (300_001, 22, 100, np.float32, "runs"),      # equal neighbouring labels: the row-by-row path
+    (200_000, 22, 100, np.float32, "one"),       # every row in one cluster
+    (100_003, 13, 50, np.float32, "uniform"),    # 4 rows per instruction
+    (100_003, 21, 100, np.float32, "runs"),      # 3 rows per instruction (label registers of 60 rows)
+    (100_003, 33, 64, np.float32, "uniform"),    # 1 row per instruction
+    (100_003, 64, 100, np.float16, "uniform"),   # 2 tables per CU
+    (100_003, 22, 100, np.float64, "uniform"),
+    (32_768, 16, 8, np.float32, "skew"),
+])
+def test_cluster_sums_wave_private_tables(gpu, oracle, n, c, k, dtype, mode):
+    """Shapes served by the wave-private-table kernel (13 <= c <= 64, n >= 32768).  The values are multiples
+    of 2^-8 below 4, so every partial sum is exact in binary64 and the order of the additions cannot show:
+    bit-equal to the oracle."""
+    rs = np.random.RandomState(n % 1000 + c)
+    x = (rs.randint(0, 1024, size=(n, c)) / 256.0).astype(dtype)
+    if mode == "uniform":
+        labels = rs.randint(0, k + 2, size=n)          # 0 and k + 1 are skipped
+    elif mode == "runs":
+        labels = np.arange(n) // 3 % k + 1
+    elif mode == "one":
+        labels = np.full(n, 7)
+    else:
+        labels = np.where(rs.rand(n) < 0.7, 1, rs.randint(1, k + 1, size=n))
+    labels = labels.astype(np.int32)
+    xd = torch.from_numpy(x).to(gpu)
+    s, cnt = sd.cluster_sums(xd, torch.from_numpy(labels).to(gpu), k)
+    inside = np.where((labels >= 1) & (labels <= k), labels, 0)
+    ws, wc = oracle.cluster_sums(x.astype(np.float64), inside, k)
+    np.testing.assert_array_equal(cnt.cpu().numpy(), wc)
+    np.testing.assert_array_equal(s.cpu().numpy(), ws)
+    # a column window of a wider matrix (ldx > c) accumulating on top of the first result
+    wide = torch.from_numpy(np.concatenate([x, x], axis=1)).to(gpu)
+    s2, cnt2 = sd.cluster_sums(wide[:, c:], torch.from_numpy(labels).to(gpu), k, sums=s, counts=cnt)
+    np.testing.assert_array_equal(cnt2.cpu().numpy(), 2 * wc)
+    np.testing.assert_array_equal(s2.cpu().numpy(), 2 * ws)
+
+
 @pytest.mark.parametrize("n,c,xdim,ydim,rlen,dtype", [
     (20_000, 22, 10, 10, 1, np.float32),
     (5_000, 22, 10, 10, 2, np.float64),
