@@ -131,21 +131,36 @@ def pair_histogram(a, b, na: int, nb: int) -> np.ndarray:
     return som_device.pair_histogram(ad, bd, int(na), int(nb)).cpu().numpy()
 
 
+def _image_to_device(image, dev, dtype=None):
+    """Host image ``[H, W]`` / ``[H, W, C]`` -> contiguous device tensor of the same shape (converted to the
+    torch ``dtype`` on the device when given).  A stack whose storage is channel-planar (what
+    ``image_io.read_channels`` returns: a ``[C, H, W]`` buffer viewed as ``[H, W, C]``) is uploaded as it lies
+    and interleaved on the device -- on the host that transpose costs more than decoding the TIFFs."""
+    import torch
+    arr = np.asarray(image)
+    if arr.ndim == 3 and not arr.flags.c_contiguous and arr.transpose(2, 0, 1).flags.c_contiguous:
+        t = torch.from_numpy(arr.transpose(2, 0, 1)).to(dev).permute(1, 2, 0)
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
 def positive_quantile_f32(image, q: float):
     """``np.quantile(plane[plane > 0], q)`` of every channel plane of an ``[H, W]`` or ``[H, W, C]`` image
     (NaN where nothing is positive): the per-channel percentile of calculate_channel_percentiles
     (pixel_cluster_utils.py:41-51).  Scalar for a single plane, ``[C]`` otherwise.  float32 images use
     numpy's float32 arithmetic, integer / float64 images binary64 (as numpy does)."""
-    import torch
     from . import _capi, som_device
     dev = _capi.require_gpu()
     image = np.asarray(image)
-    planes = image.reshape(-1, 1) if image.ndim <= 2 else image.reshape(-1, image.shape[-1])
+    columns = 1 if image.ndim <= 2 else image.shape[-1]
     if image.dtype == np.float32:
-        got = som_device.quantile_f32(torch.from_numpy(np.ascontiguousarray(planes)).to(dev), q, keep_mode=1)
+        got = som_device.quantile_f32(_image_to_device(image, dev).view(-1, columns), q, keep_mode=1)
     else:
-        got = som_device.quantile_nonzero(torch.from_numpy(np.ascontiguousarray(planes, dtype=np.float64)).to(dev),
-                                          q, keep_mode=1)
+        host = image if image.dtype == np.float64 else image.astype(np.float64)   # keeps a planar layout
+        got = som_device.quantile_nonzero(_image_to_device(host, dev).view(-1, columns), q, keep_mode=1)
     got = got.cpu().numpy()
     return got[0] if image.ndim <= 2 else got
 
@@ -156,31 +171,38 @@ def total_intensity_quantile_f32(image_hwc, norm, q: float):
     import torch
     from . import _capi, som_device
     dev = _capi.require_gpu()
-    if np.asarray(image_hwc).dtype != np.float32 or np.asarray(norm).dtype != np.float32:
+    image_hwc = np.asarray(image_hwc)
+    if image_hwc.dtype != np.float32 or np.asarray(norm).dtype != np.float32:
         raise TypeError("total_intensity_quantile_f32 reproduces numpy's float32 arithmetic: it needs float32 "
                         "images (MIBI / MPLEX exports) and the float32 channel percentiles computed from them")
-    img = np.ascontiguousarray(image_hwc, dtype=np.float32)
-    pixels = torch.from_numpy(img.reshape(-1, img.shape[-1])).to(dev)
+    pixels = _image_to_device(image_hwc, dev).view(-1, image_hwc.shape[-1])
     sums = som_device.scaled_rowsum_f32(pixels, torch.from_numpy(np.ascontiguousarray(norm, dtype=np.float32)).to(dev))
     return som_device.quantile_f32(sums.reshape(-1, 1), q, keep_mode=2).cpu().numpy()[0]
 
 
-def fov_pixel_rows(img_hwc, sigma: float, thresh: float):
+def fov_pixel_rows(img_hwc, sigma: float, thresh: float, nonzero_q=None):
     """The numeric core of ``create_fov_pixel_data`` (pixie_preprocessing.py:45-75): per-channel Gaussian blur,
     keep pixels whose channel sum exceeds ``thresh`` and that are not all zero, divide the kept pixels by
     their channel sum.  Returns ``(rows [m, C], flat pixel index [m])``; a float32 image keeps the reference's
-    float32 arithmetic (rows come back float32), anything else is processed in binary64."""
+    float32 arithmetic (rows come back float32), anything else is processed in binary64.
+    ``nonzero_q``: also return :func:`nonzero_quantiles` of the rows at that q, taken while they are still
+    in HBM (a third element)."""
     import torch
     from . import _capi, som_device
     dev = _capi.require_gpu()
     img_hwc = np.asarray(img_hwc)
     f32 = img_hwc.dtype == np.float32
     h, w, c = img_hwc.shape
-    img = torch.from_numpy(np.ascontiguousarray(img_hwc, dtype=np.float64)).to(dev)
+    if img_hwc.dtype not in (np.float32, np.float64):
+        img_hwc = img_hwc.astype(np.float64)
+    img = _image_to_device(img_hwc, dev, torch.float64)     # the kernels work on binary64 storage
     som_device.gaussian_blur_hwc(img, float(sigma), f32_semantics=f32)
     rows, kept = som_device.rowsum_filter_normalize(img.view(h * w, c), float(thresh), f32_semantics=f32)
-    values = rows.cpu().numpy()
-    return (values.astype(np.float32) if f32 else values), kept.cpu().numpy()
+    values = (rows.to(torch.float32) if f32 else rows).cpu().numpy()
+    if nonzero_q is None:
+        return values, kept.cpu().numpy()
+    quantiles = som_device.quantile_nonzero(rows, float(nonzero_q), keep_mode=0).cpu().numpy()
+    return values, kept.cpu().numpy(), quantiles
 
 
 def nonzero_quantiles(matrix, q: float) -> np.ndarray:

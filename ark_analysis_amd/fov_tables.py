@@ -194,12 +194,20 @@ class TableWriter:
                 return
             if self._error is None:
                 try:
-                    write_dataframe(job[0], job[1], compression="uncompressed")
+                    if callable(job):
+                        job()
+                    else:
+                        write_dataframe(job[0], job[1], compression="uncompressed")
                 except BaseException as err:
                     self._error = err
 
     def submit(self, table, path: str) -> None:
         self._jobs.put((table, path))
+
+    def submit_call(self, fn) -> None:
+        """Run ``fn()`` on the writer thread after everything submitted before it (e.g. a progress record
+        that must not reach the disk before the tables it describes)."""
+        self._jobs.put(fn)
 
     def close(self) -> None:
         self._jobs.put(None)

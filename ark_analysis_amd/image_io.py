@@ -39,11 +39,69 @@ def read_channel(tiff_dir, fov: str, channel: str, img_sub_folder: Optional[str]
         return np.array(im)
 
 
+_DECODERS = None
+
+
+def _decoder_pool():
+    """Shared thread pool for TIFF decoding (Pillow releases the GIL while it reads and decodes)."""
+    global _DECODERS
+    if _DECODERS is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _DECODERS = ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4), thread_name_prefix="pxsom-tiff")
+    return _DECODERS
+
+
 def read_channels(tiff_dir, fov: str, channels: Sequence[str], img_sub_folder: Optional[str] = None) -> np.ndarray:
     """``[H, W, len(channels)]`` stack in the dtype of the first channel (the loader the reference uses
-    allocates the stack with the dtype of a test image)."""
-    planes = [read_channel(tiff_dir, fov, ch, img_sub_folder) for ch in channels]
-    return np.stack(planes, axis=-1).astype(planes[0].dtype, copy=False)
+    allocates the stack with the dtype of a test image).  The channel files are decoded side by side into
+    one channel-planar buffer and the result is that buffer VIEWED as ``[H, W, C]``: interleaving 22 planes
+    on the host costs several times the decode, so it is left to the device (``flowsom`` uploads planar
+    storage as it lies and permutes there); for numpy the view behaves like any other array."""
+    channels = list(channels)
+    first = read_channel(tiff_dir, fov, channels[0], img_sub_folder)
+    planar = np.empty((len(channels),) + first.shape, dtype=first.dtype)
+    planar[0] = first
+
+    def fill(j):
+        planar[j] = read_channel(tiff_dir, fov, channels[j], img_sub_folder)
+
+    list(_decoder_pool().map(fill, range(1, len(channels))))
+    return planar.transpose(1, 2, 0)
+
+
+def iter_stacks(tiff_dir, fovs: Sequence[str], channels: Sequence[str], img_sub_folder: Optional[str] = None,
+                cache: Optional[dict] = None, fill: bool = True):
+    """Yields ``(fov, stack)`` for every FOV, reading one FOV ahead on a background thread.  ``cache``
+    (fov -> stack) is consulted first and, with ``fill``, filled while it stays under
+    ``cache['__max_bytes__']``: the passes create_pixel_matrix makes over the same TIFFs (two percentile passes, then the tables) decode them once
+    when the cohort fits the budget."""
+    from concurrent.futures import ThreadPoolExecutor
+    fovs = list(fovs)
+
+    def load(fov):
+        if cache is not None and fov in cache:
+            return cache[fov]
+        stack = read_channels(tiff_dir, fov, channels, img_sub_folder)
+        if cache is not None and fill:
+            used = cache.get("__bytes__", 0)
+            if used + stack.nbytes <= cache.get("__max_bytes__", 0):
+                cache[fov] = stack
+                cache["__bytes__"] = used + stack.nbytes
+        return stack
+
+    with ThreadPoolExecutor(max_workers=1, thread_name_prefix="pxsom-fov") as ahead:
+        pending = ahead.submit(load, fovs[0]) if fovs else None
+        for i, fov in enumerate(fovs):
+            stack = pending.result()
+            pending = ahead.submit(load, fovs[i + 1]) if i + 1 < len(fovs) else None
+            yield fov, stack
+
+
+def stack_cache(max_bytes: Optional[int] = None) -> dict:
+    """A cache for :func:`iter_stacks`; default budget 8 GiB of host memory (``PXSOM_STACK_CACHE_GB``)."""
+    if max_bytes is None:
+        max_bytes = int(float(os.environ.get("PXSOM_STACK_CACHE_GB", "8")) * (1 << 30))
+    return {"__max_bytes__": int(max_bytes), "__bytes__": 0}
 
 
 def write_channel(path, image: np.ndarray) -> None:

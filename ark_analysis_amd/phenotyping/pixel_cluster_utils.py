@@ -18,14 +18,15 @@ from ..fov_tables import UNREADABLE, FovTableDir
 from ..host_utils import natsort_key, validate_paths, verify_in_list
 
 
-def calculate_channel_percentiles(tiff_dir, fovs, channels, img_sub_folder, percentile):
+def calculate_channel_percentiles(tiff_dir, fovs, channels, img_sub_folder, percentile, stacks=None):
     """One normalisation value per channel: the ``percentile`` quantile of the positive pixels of each
     FOV's channel image, averaged over the FOVs that have any (reference: pixel_cluster_utils.py:16-58).
-    Returns a one-row DataFrame, columns naturally sorted."""
+    Returns a one-row DataFrame, columns naturally sorted.  ``stacks``: an ``image_io.stack_cache()`` shared
+    with the other passes over the same TIFFs."""
     # one device call per FOV covers all its channels (the reference walks channel by channel; the values it
-    # averages -- and their order, FOV by FOV -- are the same)
-    by_fov = [flowsom.positive_quantile_f32(image_io.read_channels(tiff_dir, fov, channels, img_sub_folder), percentile)
-              for fov in fovs]
+    # averages -- and their order, FOV by FOV -- are the same); the next FOV is decoded meanwhile
+    by_fov = [flowsom.positive_quantile_f32(stack, percentile)
+              for _, stack in image_io.iter_stacks(tiff_dir, fovs, channels, img_sub_folder, cache=stacks)]
     per_channel = []
     for j in range(len(channels)):
         found = [values[j] for values in by_fov if not np.isnan(values[j])]   # no positive pixel: not counted
@@ -35,13 +36,12 @@ def calculate_channel_percentiles(tiff_dir, fovs, channels, img_sub_folder, perc
 
 
 def calculate_pixel_intensity_percentile(tiff_dir, fovs, channels, img_sub_folder, channel_percentiles,
-                                         percentile=0.05):
+                                         percentile=0.05, stacks=None):
     """Mean over FOVs of the ``percentile`` quantile of the per-pixel total signal, each channel first
     divided by its normalisation value (reference: pixel_cluster_utils.py:61-106)."""
     divisors = channel_percentiles.iloc[0].values
-    per_fov = [flowsom.total_intensity_quantile_f32(image_io.read_channels(tiff_dir, fov, channels, img_sub_folder),
-                                                    divisors, percentile)
-               for fov in fovs]
+    per_fov = [flowsom.total_intensity_quantile_f32(stack, divisors, percentile)
+               for _, stack in image_io.iter_stacks(tiff_dir, fovs, channels, img_sub_folder, cache=stacks)]
     return np.mean(per_fov)
 
 

@@ -12,20 +12,22 @@ import numpy as np
 import pandas as pd
 
 from .. import flowsom, image_io
-from ..fov_tables import FovTableDir, read_dataframe, write_dataframe
+from ..fov_tables import FovTableDir, TableWriter, read_dataframe, write_dataframe
 from ..host_utils import natsort_key, validate_paths, verify_in_list
 from . import pixel_cluster_utils
 
 
-def create_fov_pixel_data(fov, channels, img_data, seg_labels, pixel_thresh_val,
-                          blur_factor=2, subset_proportion=0.1):
-    """Preprocess pixel data for one fov; returns ``(pixel_mat, pixel_mat_subset)`` DataFrames with
-    the reference's columns (channels, fov, row_index, column_index[, label])."""
+def _fov_tables(fov, channels, img_data, seg_labels, pixel_thresh_val, blur_factor, subset_proportion,
+                nonzero_q=None):
+    """create_fov_pixel_data plus, on request, the non-zero quantile of every channel of the full table at
+    ``nonzero_q`` (taken on the device while the rows are there; same numbers as quantiling the table)."""
     channels.sort(key=natsort_key)                       # in place, like the reference (:44)
     w = img_data.shape[1]
     # float32 images (what preprocess_fov passes for float32 TIFFs) keep float32 semantics end to end: scipy
     # stores each blur pass as float32, pandas sums and divides the float32 frame in binary32
-    values, kept_h = flowsom.fov_pixel_rows(np.asarray(img_data)[:, :, :len(channels)], blur_factor, pixel_thresh_val)
+    got = flowsom.fov_pixel_rows(np.asarray(img_data)[:, :, :len(channels)], blur_factor, pixel_thresh_val,
+                                 **({} if nonzero_q is None else {"nonzero_q": nonzero_q}))
+    values, kept_h = got[0], got[1]
     pixel_mat = pd.DataFrame(values, columns=channels)
     pixel_mat['fov'] = fov
     pixel_mat['row_index'] = (kept_h // w).astype(np.int64)
@@ -34,7 +36,16 @@ def create_fov_pixel_data(fov, channels, img_data, seg_labels, pixel_thresh_val,
         pixel_mat['label'] = np.asarray(seg_labels).flatten()[kept_h]
     # subset the pixel matrix for training (global numpy RNG state, as the reference: :78)
     pixel_mat_subset = pixel_mat.sample(frac=subset_proportion)
-    return pixel_mat, pixel_mat_subset
+    return pixel_mat, pixel_mat_subset, (got[2] if nonzero_q is not None else None)
+
+
+def create_fov_pixel_data(fov, channels, img_data, seg_labels, pixel_thresh_val,
+                          blur_factor=2, subset_proportion=0.1):
+    """Preprocess pixel data for one fov; returns ``(pixel_mat, pixel_mat_subset)`` DataFrames with
+    the reference's columns (channels, fov, row_index, column_index[, label])."""
+    full, subset, _ = _fov_tables(fov, channels, img_data, seg_labels, pixel_thresh_val, blur_factor,
+                                  subset_proportion)
+    return full, subset
 
 
 # ---- cohort level: TIFF folders -> per-FOV pixel tables + normalisation files ----------------------------
@@ -51,34 +62,38 @@ def _read_segmentation(seg_dir, fov, seg_suffix):
 
 def preprocess_fov(base_dir, tiff_dir, data_dir, subset_dir, seg_dir, seg_suffix,
                    img_sub_folder, is_mibitiff, channels, blur_factor,
-                   subset_proportion, pixel_thresh_val, seed, channel_norm_df, fov):
+                   subset_proportion, pixel_thresh_val, seed, channel_norm_df, fov, stack=None,
+                   post_rownorm_q=None, writer=None):
     """One FOV from TIFFs to tables: load the channel images, divide by the pre-row-norm channel values,
     run :func:`create_fov_pixel_data` (seeded), write ``<data_dir>/<fov>.feather`` and
-    ``<subset_dir>/<fov>.feather``; returns the full table (the caller needs its 99.9 % values)."""
+    ``<subset_dir>/<fov>.feather``; returns the full table (the caller needs its 99.9 % values).
+    Extensions used by :func:`create_pixel_matrix`: ``stack`` -- the FOV's channel stack when the caller has
+    already read it; ``post_rownorm_q`` -- return ``(table, per-channel non-zero quantile Series)``, the
+    quantile taken on the device; ``writer`` -- a ``TableWriter`` that takes over the two writes."""
     if is_mibitiff:
         raise NotImplementedError("multi-page MIBItiff input is not built; export single-channel TIFFs")
     verify_in_list(provided_chans=channels,
                    pixel_mat_chans=image_io.channel_names(tiff_dir, fov, img_sub_folder))
     labels = _read_segmentation(seg_dir, fov, seg_suffix) if seg_dir is not None else None
 
-    stack = image_io.read_channels(tiff_dir, fov, channels, img_sub_folder).astype(np.float32)
+    if stack is None:
+        stack = image_io.read_channels(tiff_dir, fov, channels, img_sub_folder)
+    stack = stack.astype(np.float32, copy=False)
     stack = stack / np.array(channel_norm_df.iloc[0].values).reshape([1, 1, -1])   # float32 / float32 stays float32
 
     np.random.seed(seed)
-    full, subset = create_fov_pixel_data(fov=fov, channels=channels, img_data=stack, seg_labels=labels,
-                                         pixel_thresh_val=pixel_thresh_val, blur_factor=blur_factor,
-                                         subset_proportion=subset_proportion)
-    write_dataframe(full, os.path.join(base_dir, data_dir, fov + ".feather"), compression='uncompressed')
-    write_dataframe(subset, os.path.join(base_dir, subset_dir, fov + ".feather"), compression='uncompressed')
-    return full
-
-
-def _nonzero_quantile_row(table, feature_cols, q, fov):
-    """``table[feature_cols].replace(0, nan).quantile(q)`` as a Series named ``fov`` (index ``channel``).
-    Binary64 with pandas' effective q, also for float32 tables: on the frames ``create_fov_pixel_data``
-    builds (one block per channel after ``normalize_rows``) pandas returns the binary64 percentile uncast."""
-    got = flowsom.nonzero_quantiles(table[feature_cols].to_numpy(dtype=np.float64), (q * 100) / 100)
-    return pd.Series(got, index=pd.Index(feature_cols, name="channel"), name=fov)
+    q = None if post_rownorm_q is None else (post_rownorm_q * 100) / 100      # pandas' effective q
+    full, subset, quantiles = _fov_tables(fov, channels, stack, labels, pixel_thresh_val, blur_factor,
+                                          subset_proportion, nonzero_q=q)
+    for table, folder in ((full, data_dir), (subset, subset_dir)):
+        path = os.path.join(base_dir, folder, fov + ".feather")
+        if writer is None:
+            write_dataframe(table, path, compression='uncompressed')
+        else:
+            writer.submit(table, path)
+    if post_rownorm_q is None:
+        return full
+    return full, pd.Series(quantiles, index=pd.Index(list(channels), name="channel"), name=fov)
 
 
 def create_pixel_matrix(fovs, channels, base_dir, tiff_dir, seg_dir,
@@ -134,12 +149,15 @@ def create_pixel_matrix(fovs, channels, base_dir, tiff_dir, seg_dir,
     pixel_cluster_utils.check_for_modified_channels(tiff_dir=tiff_dir, test_fov=fovs[0],
                                                     img_sub_folder=img_sub_folder, channels=channels)
 
+    # up to three passes read the same TIFFs (two percentile passes, then the tables): decoded stacks are kept
+    # on the host between them while they fit the cache budget, and each pass reads one FOV ahead
+    stacks = image_io.stack_cache()
     if os.path.exists(pre_norm_file):
         pre_norm = read_dataframe(pre_norm_file)
     else:
         pre_norm = pixel_cluster_utils.calculate_channel_percentiles(
             tiff_dir=tiff_dir, fovs=fovs, channels=channels, img_sub_folder=img_sub_folder,
-            percentile=channel_percentile_pre_rownorm)
+            percentile=channel_percentile_pre_rownorm, stacks=stacks)
         write_dataframe(pre_norm, pre_norm_file, compression='uncompressed')
 
     if os.path.exists(thresh_file):
@@ -147,26 +165,36 @@ def create_pixel_matrix(fovs, channels, base_dir, tiff_dir, seg_dir,
     else:
         pixel_thresh_val = pixel_cluster_utils.calculate_pixel_intensity_percentile(
             tiff_dir=tiff_dir, fovs=fovs, channels=channels, img_sub_folder=img_sub_folder,
-            channel_percentiles=pre_norm)
+            channel_percentiles=pre_norm, stacks=stacks)
         write_dataframe(pd.DataFrame({'pixel_thresh_val': [pixel_thresh_val]}), thresh_file,
                         compression='uncompressed')
 
-    not_features = ['fov', 'row_index', 'column_index'] + (['label'] if seg_dir else [])
+    # tables (and, behind them, the per-FOV record) are written by a background thread while the next FOV
+    # is on the GPU; the record never reaches the disk before the tables it vouches for
+    writer = TableWriter(depth=4)
     group = batch_size if multiprocess else 1
     done = 0
-    for start in range(0, len(todo), group):
-        names = todo[start:start + group]
-        for fov in names:
-            table = preprocess_fov(base_dir, tiff_dir, data_dir, subset_dir, seg_dir, seg_suffix, img_sub_folder,
-                                   is_mibitiff, channels, blur_factor, subset_proportion, pixel_thresh_val, seed,
-                                   pre_norm, fov)
-            features = [c for c in table.columns if c not in not_features]
-            row = _nonzero_quantile_row(table, features, channel_percentile_post_rownorm, fov)
-            per_fov = per_fov.merge(row, how="outer", left_index=True, right_index=True)
-            per_fov.to_csv(per_fov_file)   # after every FOV: an interrupted run keeps what it has
-        done += len(names)
-        if multiprocess or done % 10 == 0 or done == len(todo):
-            print("Processed %d fovs" % done)
+    ahead = image_io.iter_stacks(tiff_dir, todo, channels, img_sub_folder, cache=stacks, fill=False)
+    try:
+        for start in range(0, len(todo), group):
+            names = todo[start:start + group]
+            for fov in names:
+                stack = next(ahead)[1]
+                stacks.pop(fov, None)     # last use of this FOV's stack
+                _, row = preprocess_fov(base_dir, tiff_dir, data_dir, subset_dir, seg_dir, seg_suffix,
+                                        img_sub_folder, is_mibitiff, channels, blur_factor, subset_proportion,
+                                        pixel_thresh_val, seed, pre_norm, fov, stack=stack,
+                                        post_rownorm_q=channel_percentile_post_rownorm, writer=writer)
+                if fov in per_fov.columns:            # re-done after an interrupted run
+                    per_fov = per_fov.drop(columns=[fov])
+                per_fov = per_fov.merge(row, how="outer", left_index=True, right_index=True)
+                # after every FOV: an interrupted run keeps what it has
+                writer.submit_call(lambda snapshot=per_fov.copy(): snapshot.to_csv(per_fov_file))
+            done += len(names)
+            if multiprocess or done % 10 == 0 or done == len(todo):
+                print("Processed %d fovs" % done)
+    finally:
+        writer.close()
 
     # cohort value per channel = mean of the per-FOV values; channels in natural order
     cohort = pd.DataFrame(per_fov.mean(axis=1))

@@ -38,6 +38,8 @@ for fov in fovs:
     image_io.write_channel(os.path.join(seg_dir, fov + "_whole_cell.tiff"),
                            rs.randint(0, 2000, size=(args.side, args.side)).astype(np.int32))
 
+from ark_analysis_amd import flowsom  # noqa: E402
+flowsom.positive_quantile_f32(np.ones((8, 8), dtype=np.float32), 0.5)   # library load / HIP init outside the timings
 t0 = time.perf_counter()
 pre = pixel_cluster_utils.calculate_channel_percentiles(tiff_dir, fovs, chans, "TIFs", 0.99)
 t1 = time.perf_counter()

@@ -78,17 +78,18 @@ def som_backend(request, monkeypatch):
     def total_intensity_quantile_f32(image_hwc, norm, q):
         return np.quantile(np.sum(image_hwc / np.asarray(norm).reshape([1, 1, -1]), axis=-1), q)
 
-    def fov_pixel_rows(img_hwc, sigma, thresh):
-        img_hwc = np.asarray(img_hwc)
+    def nonzero_quantiles(matrix, q):
+        m = np.asarray(matrix, dtype=np.float64)
+        return np.array([ob.quantile_nonzero(np.ascontiguousarray(m[:, j]), q, 0) for j in range(m.shape[1])])
+
+    def fov_pixel_rows(img_hwc, sigma, thresh, nonzero_q=None):
+        img_hwc = np.ascontiguousarray(img_hwc)
         f32 = img_hwc.dtype == np.float32
         h, w, c = img_hwc.shape
         blurred = ob.gaussian_blur_hwc(img_hwc, float(sigma), f32=f32)
         rows, kept = ob.rowsum_filter_normalize(blurred.reshape(h * w, c), float(thresh), sum_mode=2 if f32 else 0)
-        return (rows.astype(np.float32) if f32 else rows), kept
-
-    def nonzero_quantiles(matrix, q):
-        m = np.asarray(matrix, dtype=np.float64)
-        return np.array([ob.quantile_nonzero(np.ascontiguousarray(m[:, j]), q, 0) for j in range(m.shape[1])])
+        rows = rows.astype(np.float32) if f32 else rows
+        return (rows, kept) if nonzero_q is None else (rows, kept, nonzero_quantiles(rows, nonzero_q))
 
     monkeypatch.setattr(flowsom, "fov_pixel_rows", fov_pixel_rows)
     monkeypatch.setattr(flowsom, "nonzero_quantiles", nonzero_quantiles)

@@ -398,6 +398,73 @@ def test_create_pixel_matrix_matches_reference_run(som_backend, tmp_path, capsys
         pixie_preprocessing.create_pixel_matrix(list(fovs), list(chans), td, tiff_dir, seg_dir, subset_proportion=1.5)
 
 
+def test_channel_stacks_planar_view_prefetch_and_cache(tmp_path):
+    """read_channels: same values / dtype / shape as stacking the planes, stored channel-planar; iter_stacks:
+    every FOV once and in order, second pass served from the cache while it is under budget."""
+    from ark_analysis_amd import image_io
+    rs = np.random.RandomState(5)
+    fovs, chans = ["fov%d" % i for i in range(4)], ["chan%d" % i for i in range(5)]
+    planes = {}
+    for fov in fovs:
+        os.makedirs(os.path.join(str(tmp_path), fov, "TIFs"))
+        for ch in chans:
+            planes[fov, ch] = rs.gamma(0.5, 2.0, size=(17, 23)).astype(np.float32)
+            image_io.write_channel(os.path.join(str(tmp_path), fov, "TIFs", ch + ".tiff"), planes[fov, ch])
+    stack = image_io.read_channels(str(tmp_path), "fov2", chans, "TIFs")
+    want = np.stack([planes["fov2", ch] for ch in chans], axis=-1)
+    assert stack.shape == (17, 23, 5) and stack.dtype == np.float32
+    np.testing.assert_array_equal(stack, want)
+    assert stack.transpose(2, 0, 1).flags.c_contiguous           # what flowsom uploads as it lies
+    np.testing.assert_array_equal(stack / np.float32(3), want / np.float32(3))
+    cache = image_io.stack_cache(max_bytes=2 * stack.nbytes)      # room for two FOVs
+    first = [(fov, s.copy()) for fov, s in image_io.iter_stacks(str(tmp_path), fovs, chans, "TIFs", cache=cache)]
+    assert [fov for fov, _ in first] == fovs and sorted(k for k in cache if not k.startswith("__")) == fovs[:2]
+    os.remove(os.path.join(str(tmp_path), "fov0", "TIFs", "chan0.tiff"))     # cached: not read again
+    second = list(image_io.iter_stacks(str(tmp_path), fovs[:2] + fovs[3:], chans, "TIFs", cache=cache, fill=False))
+    assert [fov for fov, _ in second] == ["fov0", "fov1", "fov3"]
+    for (_, a), (_, b) in zip(second, [first[0], first[1], first[3]]):
+        np.testing.assert_array_equal(a, b)
+    with pytest.raises(FileNotFoundError):
+        list(image_io.iter_stacks(str(tmp_path), ["fov0"], chans, "TIFs"))
+
+
+def test_create_pixel_matrix_resumes_after_interruption(som_backend, tmp_path, capsys):
+    """Tables of one FOV missing although its 99.9 % values are on record (a run killed between the two):
+    only that FOV is redone and the cohort file comes out as in an uninterrupted run."""
+    from ark_analysis_amd.phenotyping import pixie_preprocessing
+    g = np.load(os.path.join(GOLD, "g9_create_pixel_matrix.npz"))
+    td = str(tmp_path)
+    fovs, chans, tiff_dir, seg_dir = _write_g9_cohort(g, td)
+    kept = {}
+    real_remove = os.remove
+
+    def keep_record(path):            # hold on to the per-FOV record the function deletes at the end
+        if path.endswith("channel_norm_post_rownorm_perfov.csv"):
+            kept["csv"] = open(path).read()
+        real_remove(path)
+    os.remove = keep_record
+    try:
+        pixie_preprocessing.create_pixel_matrix(list(fovs), list(chans), td, tiff_dir, seg_dir,
+                                                subset_proportion=0.25, seed=42)
+    finally:
+        os.remove = real_remove
+    capsys.readouterr()
+    real_remove(os.path.join(td, "pixel_mat_data", "fov1.feather"))
+    real_remove(os.path.join(td, "channel_norm_post_rownorm.feather"))
+    with open(os.path.join(td, "pixel_mat_data", "channel_norm_post_rownorm_perfov.csv"), "w") as f:
+        f.write(kept["csv"])
+    pixie_preprocessing.create_pixel_matrix(list(fovs), list(chans), td, tiff_dir, seg_dir,
+                                            subset_proportion=0.25, seed=42)
+    assert "Restarting preprocessing from FOV fov1, 1 fovs left to process" in capsys.readouterr().out
+    post = read_dataframe(os.path.join(td, "channel_norm_post_rownorm.feather"))
+    assert list(post.columns) == list(g["post_columns"])
+    # the cohort value is a mean over the per-FOV columns in the order they were recorded (set order in the
+    # reference, pixie_preprocessing.py:315-327 and :442): a resumed run may differ in the last place
+    np.testing.assert_allclose(post.values[0], g["post_values"], rtol=1e-15, atol=0)
+    t = read_dataframe(os.path.join(td, "pixel_mat_data", "fov1.feather"))
+    np.testing.assert_array_equal(t[["chan0", "chan1", "chan2", "chan10"]].values, g["pixel_mat_data_fov1_channels"])
+
+
 def test_fov_table_helpers(tmp_path):
     """Footer-only column listing, natural ordering, prefetcher / writer round trip, damaged files."""
     from ark_analysis_amd.fov_tables import FovTableDir, TablePrefetcher, TableWriter
