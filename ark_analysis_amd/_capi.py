@@ -23,7 +23,7 @@ _STATUS = {0: "PXSOM_OK", -1: "PXSOM_ERR_INVALID_ARG", -2: "PXSOM_ERR_UNSUPPORTE
 # every symbol include/pxsom.h declares: (restype, argtypes)
 _vp, _i32, _i64, _f64, _sz = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double,
                               ctypes.c_size_t)
-ABI_VERSION = 2  # include/pxsom.h PXSOM_ABI_VERSION
+ABI_VERSION = 3  # include/pxsom.h PXSOM_ABI_VERSION
 
 SYMBOLS = {
     "pxsom_abi_version": (_i32, []),
@@ -42,6 +42,8 @@ SYMBOLS = {
     "pxsom_batch_accumulate": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _sz, _i32, _vp]),
     "pxsom_quantile_f32": (_i32, [_vp, _i64, _i32, _i64, _f64, _i32, _vp, _vp, _sz, _vp]),
     "pxsom_scaled_rowsum_f32": (_i32, [_vp, _i64, _i32, _i64, _vp, _vp, _vp]),
+    "pxsom_cluster_mask_workspace_bytes": (_sz, [_i32, _i32]),
+    "pxsom_cluster_mask": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "pxsom_pair_histogram": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
     "pxsom_batch_update_prepare": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _f64, _f64, _vp, _sz, _vp]),
     "pxsom_gaussian_blur_hwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),

@@ -531,3 +531,82 @@ PXSOM_EXPORT int pxsom_scaled_rowsum_f32(const float *img_dev, int64_t n, int c,
     PXSOM_LAUNCH_CHECK("scaled_rowsum_f32_kernel");
     return PXSOM_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// pixel cluster mask (generate_pixel_cluster_mask): winner[pos] = highest row index listing that pixel
+// (numpy's sequential fancy assignment keeps the last), then mask[pos] = lut[label[winner]]
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void mask_winner_kernel(const int64_t *__restrict__ row_index,
+                                                          const int64_t *__restrict__ column_index,
+                                                          const int64_t *__restrict__ labels, int64_t n,
+                                                          const int32_t *__restrict__ lut, int64_t lut_size, int h,
+                                                          int w, long long *winner, int32_t *status)
+{
+    int bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = row_index[i], c = column_index[i], lb = labels[i];
+        const int64_t pos = r * w + c;  // numpy indexes the flattened image with this number
+        if (pos < 0 || pos >= (int64_t)h * w) {
+            bad |= PXSOM_MASK_BAD_PIXEL;
+            continue;
+        }
+        if (lb < 0 || lb >= lut_size || lut[lb] == PXSOM_LUT_UNMAPPED) bad |= PXSOM_MASK_BAD_LABEL;
+        atomicMax(&winner[pos], (long long)i);
+    }
+    if (bad) atomicOr(status, bad);
+}
+
+__global__ __launch_bounds__(256) void mask_resolve_kernel(const int64_t *__restrict__ labels,
+                                                           const int32_t *__restrict__ lut, int64_t lut_size,
+                                                           int64_t pixels, const long long *__restrict__ winner,
+                                                           int16_t *mask)
+{
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < pixels; p += (int64_t)gridDim.x * 256) {
+        const long long i = winner[p];
+        int32_t id = 0;
+        if (i >= 0) {
+            const int64_t lb = labels[i];
+            id = (lb >= 0 && lb < lut_size) ? lut[lb] : 0;
+        }
+        mask[p] = (int16_t)id;
+    }
+}
+
+}  // namespace
+
+PXSOM_EXPORT size_t pxsom_cluster_mask_workspace_bytes(int h, int w)
+{
+    return h > 0 && w > 0 ? (size_t)h * (size_t)w * sizeof(long long) : 0;
+}
+
+PXSOM_EXPORT int pxsom_cluster_mask(const int64_t *row_index_dev, const int64_t *column_index_dev,
+                                    const int64_t *labels_dev, int64_t n, const int32_t *lut_dev, int64_t lut_size,
+                                    int h, int w, int16_t *mask_dev, int32_t *status_dev, void *workspace_dev,
+                                    size_t workspace_bytes, void *stream)
+{
+    if (n < 0 || h < 1 || w < 1 || lut_size < 0)
+        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_cluster_mask: bad sizes (n=%lld, %dx%d)", (long long)n, h, w);
+    if (!mask_dev || !status_dev || !workspace_dev || (lut_size > 0 && !lut_dev) ||
+        (n > 0 && (!row_index_dev || !column_index_dev || !labels_dev)))
+        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_cluster_mask: null pointer");
+    const size_t need = pxsom_cluster_mask_workspace_bytes(h, w);
+    if (workspace_bytes < need)
+        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_cluster_mask: workspace %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t pixels = (int64_t)h * w;
+    PXSOM_HIP_TRY(hipMemsetAsync(workspace_dev, 0xFF, need, st));  // every winner = -1
+    PXSOM_HIP_TRY(hipMemsetAsync(status_dev, 0, sizeof(int32_t), st));
+    const int64_t cap = (int64_t)pxsom::device_cu_count() * 16;
+    long long *winner = reinterpret_cast<long long *>(workspace_dev);
+    if (n > 0) {
+        hipLaunchKernelGGL(mask_winner_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, cap)), dim3(256), 0, st,
+                           row_index_dev, column_index_dev, labels_dev, n, lut_dev, lut_size, h, w, winner, status_dev);
+        PXSOM_LAUNCH_CHECK("mask_winner_kernel");
+    }
+    hipLaunchKernelGGL(mask_resolve_kernel, dim3((unsigned)std::min<int64_t>((pixels + 255) / 256, cap)), dim3(256), 0,
+                       st, labels_dev, lut_dev, lut_size, pixels, winner, mask_dev);
+    PXSOM_LAUNCH_CHECK("mask_resolve_kernel");
+    return PXSOM_OK;
+}

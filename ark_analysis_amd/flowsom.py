@@ -213,3 +213,34 @@ def nonzero_quantiles(matrix, q: float) -> np.ndarray:
     dev = _capi.require_gpu()
     m = torch.from_numpy(np.ascontiguousarray(matrix, dtype=np.float64)).to(dev)
     return som_device.quantile_nonzero(m, float(q), keep_mode=0).cpu().numpy()
+
+
+def pixel_cluster_mask(row_index, column_index, labels, id_mapping: dict, shape) -> np.ndarray:
+    """The relabel + scatter of ``generate_pixel_cluster_mask`` (utils/data_utils.py:532-553): an int16
+    ``shape`` image of zeros with ``id_mapping[label]`` written at every listed pixel.  Raises ``KeyError``
+    for a label the mapping lacks and ``IndexError`` for a pixel outside the image, as the reference's dict
+    lookup and numpy assignment do."""
+    import torch
+    from . import _capi, som_device
+    dev = _capi.require_gpu()
+    labels = np.ascontiguousarray(labels, dtype=np.int64)
+    keys = np.fromiter(id_mapping.keys(), dtype=np.int64, count=len(id_mapping))
+    size = int(keys.max()) + 1 if keys.size and keys.max() >= 0 else 0
+    lut = np.full(size, som_device.LUT_UNMAPPED, dtype=np.int64)
+    for key, value in id_mapping.items():         # negative or fractional keys can never equal a label here
+        if float(key).is_integer() and 0 <= int(key) < size:
+            lut[int(key)] = int(value)
+    # ids are narrowed to int16 the way numpy narrows them on assignment; only the marker stays out of range
+    narrowed = np.where(lut == som_device.LUT_UNMAPPED, lut, lut.astype(np.int16)).astype(np.int32)
+
+    def up(a, dtype):
+        host = np.ascontiguousarray(a, dtype=dtype)
+        return torch.from_numpy(host if host.flags.writeable else host.copy()).to(dev)   # Arrow columns are read-only
+    mask, status = som_device.cluster_mask(up(row_index, np.int64), up(column_index, np.int64), up(labels, np.int64),
+                                           up(narrowed, np.int32), int(shape[0]), int(shape[1]))
+    if status & som_device.MASK_BAD_PIXEL:
+        raise IndexError("pixel coordinates outside the %d x %d image" % (shape[0], shape[1]))
+    if status & som_device.MASK_BAD_LABEL:
+        missing = sorted(set(np.unique(labels).tolist()) - set(int(k) for k in id_mapping))
+        raise KeyError(missing[0] if missing else "cluster label without a cluster_id")
+    return mask.cpu().numpy()

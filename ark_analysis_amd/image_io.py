@@ -32,6 +32,13 @@ def _channel_file(folder: str, channel: str) -> str:
     raise FileNotFoundError("The file/path, %s.tiff, could not be found in %s" % (channel, folder))
 
 
+def read_image(path) -> np.ndarray:
+    """Any single image file as an array in its own dtype."""
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.array(im)
+
+
 def read_channel(tiff_dir, fov: str, channel: str, img_sub_folder: Optional[str] = None) -> np.ndarray:
     """One channel image ``[H, W]`` in the file's dtype."""
     from PIL import Image

@@ -291,3 +291,31 @@ def scaled_rowsum_f32(img: torch.Tensor, norm: torch.Tensor) -> torch.Tensor:
                                              norm.contiguous().data_ptr(), out.data_ptr(), _capi.stream_ptr())
     _capi.check(rc, "pxsom_scaled_rowsum_f32")
     return out
+
+
+MASK_BAD_LABEL, MASK_BAD_PIXEL = 1, 2   # include/pxsom.h PXSOM_MASK_*
+LUT_UNMAPPED = -2 ** 31                 # PXSOM_LUT_UNMAPPED
+
+
+def cluster_mask(row_index: torch.Tensor, column_index: torch.Tensor, labels: torch.Tensor, lut: torch.Tensor,
+                 h: int, w: int):
+    """``mask.ravel()[row_index * w + column_index] = lut[labels]`` on an int16 ``[h, w]`` image of zeros
+    (last row wins for a pixel listed twice).  int64 HBM vectors, int32 LUT.  Returns ``(mask, status)``:
+    status 0, or MASK_BAD_LABEL / MASK_BAD_PIXEL bits (synchronises to read it)."""
+    for name, t in (("row_index", row_index), ("column_index", column_index), ("labels", labels)):
+        if t.dtype != torch.int64 or not t.is_cuda or t.dim() != 1 or not t.is_contiguous():
+            raise ValueError(f"{name} must be a contiguous int64 HBM vector")
+    if not (row_index.numel() == column_index.numel() == labels.numel()):
+        raise ValueError("row_index, column_index and labels must have one entry per table row")
+    if lut.dtype != torch.int32 or not lut.is_cuda or not lut.is_contiguous():
+        raise ValueError("lut must be a contiguous int32 HBM vector")
+    dev = labels.device
+    mask = torch.empty((int(h), int(w)), dtype=torch.int16, device=dev)
+    status = torch.empty(1, dtype=torch.int32, device=dev)
+    wsb = _capi.lib().pxsom_cluster_mask_workspace_bytes(int(h), int(w))
+    ws = torch.empty(max(wsb, 8), dtype=torch.uint8, device=dev)
+    rc = _capi.lib().pxsom_cluster_mask(row_index.data_ptr(), column_index.data_ptr(), labels.data_ptr(),
+                                        labels.numel(), lut.data_ptr(), lut.numel(), int(h), int(w),
+                                        mask.data_ptr(), status.data_ptr(), ws.data_ptr(), wsb, _capi.stream_ptr())
+    _capi.check(rc, "pxsom_cluster_mask")
+    return mask, int(status.item())

@@ -1,0 +1,39 @@
+"""The one function of ``ark.utils.data_utils`` that sits directly behind the pixel labels
+(/root/reference/src/ark/utils/data_utils.py:476-555; SURVEY.md section 8 f, rank 4): a FOV's pixel table with
+SOM / meta cluster labels -> an ``[H, W]`` int16 image of cluster ids.  The relabel (label -> cluster_id) and
+the scatter run on the device; path checks, the mapping table and the table read stay on the host."""
+import os
+
+import numpy as np
+
+from .. import flowsom, image_io
+from ..fov_tables import read_table
+from ..host_utils import validate_paths, verify_in_list
+
+
+def generate_pixel_cluster_mask(fov, base_dir, tiff_dir, chan_file_path,
+                                pixel_data_dir, cluster_mapping,
+                                pixel_cluster_col='pixel_meta_cluster'):
+    """For a fov, create a mask labeling each pixel with its SOM or meta cluster id.
+
+    ``chan_file_path`` (relative to ``tiff_dir``) names a sample channel image that fixes the mask's size;
+    ``cluster_mapping`` is the DataFrame that maps ``pixel_cluster_col`` values to ``cluster_id``.  Pixels the
+    table does not list stay 0."""
+    table_dir = os.path.join(base_dir, pixel_data_dir)
+    validate_paths([tiff_dir, os.path.join(tiff_dir, chan_file_path), table_dir])
+    verify_in_list(provided_cluster_col=[pixel_cluster_col],
+                   valid_cluster_cols=['pixel_som_cluster', 'pixel_meta_cluster'])
+    verify_in_list(provided_fov_file=[fov + '.feather'], consensus_fov_files=os.listdir(table_dir))
+
+    sample = np.squeeze(image_io.read_image(os.path.join(tiff_dir, chan_file_path)))
+    table = read_table(os.path.join(table_dir, fov + '.feather'))
+
+    def column(name):
+        return table.column(name).to_numpy()
+    labels = column(pixel_cluster_col).astype(int)        # "ensure integer display and not float"
+
+    # later rows of the mapping win for a repeated key, as in dict(zip(...))
+    pairs = cluster_mapping.drop_duplicates()[[pixel_cluster_col, 'cluster_id']]
+    id_mapping = dict(zip(pairs[pixel_cluster_col], pairs['cluster_id']))
+    return flowsom.pixel_cluster_mask(column('row_index'), column('column_index'), labels, id_mapping,
+                                      (sample.shape[0], sample.shape[1]))

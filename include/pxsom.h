@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PXSOM_ABI_VERSION 2
+#define PXSOM_ABI_VERSION 3
 
 typedef enum pxsom_status {
     PXSOM_OK = 0,
@@ -200,6 +200,24 @@ int pxsom_quantile_f32(const float *x_dev, int64_t n, int c, int64_t ldx, double
  * order for a contiguous float32 axis (c <= 128).  img_dev [n, c] float32, out_dev [n] float32. */
 int pxsom_scaled_rowsum_f32(const float *img_dev, int64_t n, int c, int64_t ldx, const float *norm_dev,
                             float *out_dev, void *stream);
+
+/* ---- pixel cluster mask: the relabel + scatter of generate_pixel_cluster_mask ------------------------
+ * reference: utils/data_utils.py:532-553 -- coordinates = row_index * W + column_index;
+ * cluster_labels = [id_mapping[label] for label in ...]; img.ravel()[coordinates] = cluster_labels on an
+ * int16 image of zeros.  lut_dev [lut_size] int32 holds id_mapping densely (PXSOM_LUT_UNMAPPED where the
+ * mapping has no entry).  mask_dev [h, w] int16 is overwritten (0 where the table has no pixel; ids are
+ * narrowed to int16 the way numpy's assignment does).  A pixel listed more than once keeps the id of its
+ * LAST row, like the sequential numpy assignment.  status_dev [1] int32 comes back 0, or with
+ * PXSOM_MASK_BAD_LABEL (a label outside the LUT or unmapped: the reference raises KeyError) and / or
+ * PXSOM_MASK_BAD_PIXEL (a coordinate outside the image: IndexError) set; the mask is then unspecified.
+ * workspace: pxsom_cluster_mask_workspace_bytes(h, w) (one int64 per pixel: index of the winning row). */
+#define PXSOM_LUT_UNMAPPED (-2147483647 - 1)
+#define PXSOM_MASK_BAD_LABEL 1
+#define PXSOM_MASK_BAD_PIXEL 2
+size_t pxsom_cluster_mask_workspace_bytes(int h, int w);
+int pxsom_cluster_mask(const int64_t *row_index_dev, const int64_t *column_index_dev, const int64_t *labels_dev,
+                       int64_t n, const int32_t *lut_dev, int64_t lut_size, int h, int w, int16_t *mask_dev,
+                       int32_t *status_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

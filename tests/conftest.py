@@ -91,6 +91,16 @@ def som_backend(request, monkeypatch):
         rows = rows.astype(np.float32) if f32 else rows
         return (rows, kept) if nonzero_q is None else (rows, kept, nonzero_quantiles(rows, nonzero_q))
 
+    # generate_pixel_cluster_mask's relabel + scatter is plain numpy in the reference (utils/data_utils.py:532-553)
+    def pixel_cluster_mask(row_index, column_index, labels, id_mapping, shape):
+        img = np.zeros((int(shape[0]), int(shape[1])), dtype='int16')
+        flat = img.ravel()
+        ids = np.asarray([id_mapping[label] for label in np.asarray(labels).tolist()], dtype=np.int64)
+        # the reference pins numpy < 1.24, where assigning a list of Python ints narrows silently
+        flat[np.asarray(row_index) * img.shape[1] + np.asarray(column_index)] = ids.astype(np.int16)
+        return flat.reshape(img.shape)
+
+    monkeypatch.setattr(flowsom, "pixel_cluster_mask", pixel_cluster_mask)
     monkeypatch.setattr(flowsom, "fov_pixel_rows", fov_pixel_rows)
     monkeypatch.setattr(flowsom, "nonzero_quantiles", nonzero_quantiles)
     monkeypatch.setattr(flowsom, "positive_quantile_f32", positive_quantile_f32)

@@ -333,9 +333,46 @@ def g9_create_pixel_matrix():
     save("g9_create_pixel_matrix", **arrays)
 
 
+def g10_pixel_cluster_mask():
+    """The reference's generate_pixel_cluster_mask (utils/data_utils.py:476-555) on one small FOV table: SOM
+    and meta cluster columns (the meta column float-typed, as after a CSV round trip), a mapping table with
+    repeated rows and cluster ids that are neither dense nor monotone, pixels missing from the table (mask
+    stays 0 there)."""
+    from ark.utils import data_utils
+    from PIL import Image
+    rs = np.random.RandomState(10)
+    h, w, k = 37, 41, 12
+    keep = np.sort(rs.choice(h * w, size=1100, replace=False))
+    som = rs.randint(1, k + 1, size=keep.size)
+    som_to_meta = rs.randint(1, 5, size=k + 1)
+    meta_to_id = {1: 7, 2: 300, 3: 2, 4: 41}
+    table = pd.DataFrame({"chan0": rs.rand(keep.size), "fov": "fov0", "row_index": keep // w, "column_index": keep % w,
+                          "pixel_som_cluster": som, "pixel_meta_cluster": som_to_meta[som].astype(np.float64)})
+    mapping = pd.DataFrame({"pixel_som_cluster": np.arange(1, k + 1), "pixel_meta_cluster": som_to_meta[1:]})
+    mapping["cluster_id"] = [meta_to_id[m] for m in mapping["pixel_meta_cluster"]]
+    mapping = pd.concat([mapping, mapping.iloc[:4]], ignore_index=True)           # repeated rows
+    som_mapping = mapping.copy()
+    som_mapping["cluster_id"] = [(5 * c) % 23 + 1 for c in som_mapping["pixel_som_cluster"]]
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        os.makedirs(os.path.join(td, "tiffs", "fov0"))
+        os.makedirs(os.path.join(td, "pixel_mat_data"))
+        Image.fromarray(rs.rand(h, w).astype(np.float32)).save(os.path.join(td, "tiffs", "fov0", "chan0.tiff"))
+        feather.write_dataframe(table, os.path.join(td, "pixel_mat_data", "fov0.feather"))
+        for col, mp in (("pixel_meta_cluster", mapping), ("pixel_som_cluster", som_mapping)):
+            mask = data_utils.generate_pixel_cluster_mask("fov0", td, os.path.join(td, "tiffs"),
+                                                          os.path.join("fov0", "chan0.tiff"), "pixel_mat_data",
+                                                          mp, pixel_cluster_col=col)
+            out["mask_" + col] = mask
+            out["mapping_" + col] = mp[[col, "cluster_id"]].values.astype(np.int64)
+    save("g10_pixel_cluster_mask", shape=np.array([h, w]), row_index=table["row_index"].values,
+         column_index=table["column_index"].values, pixel_som_cluster=table["pixel_som_cluster"].values,
+         pixel_meta_cluster=table["pixel_meta_cluster"].values, **out)
+
+
 if __name__ == "__main__":
     ob.build()
     steps = {"g1": g1_normalize, "g2": g2_g5_preprocess, "g3": g3_quantiles, "g4": g4_cluster_avg, "g6": g6_som,
-             "g7": g7_end_to_end, "g8": g8_c2pc, "g9": g9_create_pixel_matrix}
+             "g7": g7_end_to_end, "g8": g8_c2pc, "g9": g9_create_pixel_matrix, "g10": g10_pixel_cluster_mask}
     for name in (sys.argv[1:] or list(steps)):
         steps[name]()

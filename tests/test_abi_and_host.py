@@ -25,7 +25,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/pxsom.h but not exported"
     assert set(declared) == set(_capi.SYMBOLS), "ctypes prototype table and header disagree"
-    assert lib.pxsom_abi_version() == _capi.ABI_VERSION == 2
+    assert lib.pxsom_abi_version() == _capi.ABI_VERSION == 3
 
 
 def test_argument_validation_without_gpu():
@@ -57,6 +57,12 @@ def test_argument_validation_without_gpu():
     rc = lib.pxsom_pair_histogram(None, None, 10, 0, 5, None, None)
     assert rc == -1 and b"sizes" in lib.pxsom_last_error()
     assert lib.pxsom_pair_histogram(None, None, 10, 5, 5, None, None) == -1
+    assert lib.pxsom_cluster_mask_workspace_bytes(1024, 1024) == 8 * 1024 * 1024
+    assert lib.pxsom_cluster_mask_workspace_bytes(0, 1024) == 0
+    rc = lib.pxsom_cluster_mask(None, None, None, 10, None, 5, 0, 64, None, None, None, 0, None)
+    assert rc == -1 and b"sizes" in lib.pxsom_last_error()
+    rc = lib.pxsom_cluster_mask(None, None, None, 10, None, 5, 64, 64, None, None, None, 0, None)
+    assert rc == -1 and b"null" in lib.pxsom_last_error()
 
 
 def test_pipeline_stays_loud_without_gpu(tmp_path):

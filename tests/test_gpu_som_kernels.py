@@ -182,6 +182,40 @@ def test_cluster_sums_matches_oracle(gpu, oracle):
         np.testing.assert_allclose(s.cpu().numpy(), ws, rtol=1e-12, atol=1e-12)
 
 
+def test_cluster_mask_kernel_against_numpy(gpu):
+    """pxsom_cluster_mask on a 1024 x 1024 image: unique pixels, repeated pixels (last row wins), unmapped
+    labels and stray coordinates reported through the status word."""
+    rs = np.random.RandomState(21)
+    h, w, k = 1024, 1024, 300
+    pos = rs.permutation(h * w)[:900_000]
+    pos = np.concatenate([pos, pos[:50_000]])                  # 50 000 pixels listed twice
+    labels = rs.randint(0, k, size=pos.size)
+    lut = rs.randint(-40_000, 40_000, size=k).astype(np.int32)
+    narrowed = lut.astype(np.int16).astype(np.int32)
+
+    def dev(a, dt):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(gpu)
+    mask, status = sd.cluster_mask(dev(pos // w, np.int64), dev(pos % w, np.int64), dev(labels, np.int64),
+                                   dev(narrowed, np.int32), h, w)
+    want = np.zeros(h * w, dtype=np.int16)
+    want[pos] = lut[labels].astype(np.int16)                   # numpy assigns in order: the last row stays
+    assert status == 0
+    np.testing.assert_array_equal(mask.cpu().numpy().ravel(), want)
+    holes = narrowed.copy()
+    holes[7] = sd.LUT_UNMAPPED
+    assert sd.cluster_mask(dev(pos // w, np.int64), dev(pos % w, np.int64), dev(labels, np.int64),
+                           dev(holes, np.int32), h, w)[1] == sd.MASK_BAD_LABEL
+    assert sd.cluster_mask(dev(pos // w, np.int64), dev(pos % w, np.int64), dev(labels + 1, np.int64),
+                           dev(narrowed, np.int32), h, w)[1] == sd.MASK_BAD_LABEL          # label k: past the LUT
+    rows = pos // w
+    rows[5] = h
+    assert sd.cluster_mask(dev(rows, np.int64), dev(pos % w, np.int64), dev(labels, np.int64),
+                           dev(narrowed, np.int32), h, w)[1] == sd.MASK_BAD_PIXEL
+    empty = torch.empty(0, dtype=torch.int64, device=gpu)
+    mask, status = sd.cluster_mask(empty, empty, empty, dev(narrowed, np.int32), 5, 7)
+    assert status == 0 and not mask.any() and mask.shape == (5, 7)
+
+
 @pytest.mark.parametrize("n,c,k,dtype,mode", [
     (300_001, 22, 100, np.float32, "uniform"),   # 2 rows per instruction, 8 tables per CU
     (300_001, 22, 100, np.float32, "runs"),      # equal neighbouring labels: the row-by-row path

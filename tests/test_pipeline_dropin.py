@@ -465,6 +465,52 @@ def test_create_pixel_matrix_resumes_after_interruption(som_backend, tmp_path, c
     np.testing.assert_array_equal(t[["chan0", "chan1", "chan2", "chan10"]].values, g["pixel_mat_data_fov1_channels"])
 
 
+def test_generate_pixel_cluster_mask_matches_reference_run(som_backend, tmp_path):
+    """Pixel table + mapping -> int16 cluster-id image, against the reference's own function on the same
+    inputs (tests/golden/g10_pixel_cluster_mask.npz): SOM and meta columns, float-typed labels, repeated
+    mapping rows, ids beyond int8, unlisted pixels left 0; then the error cases."""
+    from ark_analysis_amd import image_io
+    from ark_analysis_amd.utils import data_utils
+    g = np.load(os.path.join(GOLD, "g10_pixel_cluster_mask.npz"))
+    td = str(tmp_path)
+    h, w = (int(v) for v in g["shape"])
+    os.makedirs(os.path.join(td, "tiffs", "fov0"))
+    os.makedirs(os.path.join(td, "pixel_mat_data"))
+    image_io.write_channel(os.path.join(td, "tiffs", "fov0", "chan0.tiff"), np.zeros((h, w), dtype=np.float32))
+    table = pd.DataFrame({"chan0": 0.5, "fov": "fov0", "row_index": g["row_index"], "column_index": g["column_index"],
+                          "pixel_som_cluster": g["pixel_som_cluster"], "pixel_meta_cluster": g["pixel_meta_cluster"]})
+    write_dataframe(table, os.path.join(td, "pixel_mat_data", "fov0.feather"))
+    args = ("fov0", td, os.path.join(td, "tiffs"), os.path.join("fov0", "chan0.tiff"), "pixel_mat_data")
+    for col in ("pixel_meta_cluster", "pixel_som_cluster"):
+        pairs = g["mapping_" + col]
+        mapping = pd.DataFrame({col: pairs[:, 0], "cluster_id": pairs[:, 1], "other": 1.5})
+        mask = data_utils.generate_pixel_cluster_mask(*args, mapping, pixel_cluster_col=col)
+        assert mask.dtype == np.int16 and mask.shape == (h, w)
+        np.testing.assert_array_equal(mask, g["mask_" + col])
+    # a pixel listed twice keeps its last row; ids wrap into int16 like numpy's assignment
+    twice = pd.concat([table, table.iloc[:3].assign(pixel_som_cluster=2)], ignore_index=True)
+    write_dataframe(twice, os.path.join(td, "pixel_mat_data", "fov0.feather"))
+    mapping = pd.DataFrame({"pixel_som_cluster": np.arange(1, 13), "cluster_id": np.arange(1, 13) * 7000})
+    mask = data_utils.generate_pixel_cluster_mask(*args, mapping, pixel_cluster_col="pixel_som_cluster")
+    want = np.zeros(h * w, dtype=np.int16)
+    want[twice["row_index"].values * w + twice["column_index"].values] = \
+        (twice["pixel_som_cluster"].values * 7000).astype(np.int16)
+    np.testing.assert_array_equal(mask, want.reshape(h, w))
+    with pytest.raises(KeyError):            # a label the mapping does not know
+        data_utils.generate_pixel_cluster_mask(*args, mapping.iloc[:5], pixel_cluster_col="pixel_som_cluster")
+    with pytest.raises(ValueError):          # not a cluster column
+        data_utils.generate_pixel_cluster_mask(*args, mapping, pixel_cluster_col="fov")
+    with pytest.raises(ValueError):          # unknown FOV
+        data_utils.generate_pixel_cluster_mask("fov9", *args[1:], mapping, pixel_cluster_col="pixel_som_cluster")
+    with pytest.raises(FileNotFoundError):
+        data_utils.generate_pixel_cluster_mask("fov0", td, os.path.join(td, "tiffs"), "fov0/none.tiff",
+                                               "pixel_mat_data", mapping, pixel_cluster_col="pixel_som_cluster")
+    outside = table.assign(row_index=table["row_index"] + h)
+    write_dataframe(outside, os.path.join(td, "pixel_mat_data", "fov0.feather"))
+    with pytest.raises(IndexError):
+        data_utils.generate_pixel_cluster_mask(*args, mapping, pixel_cluster_col="pixel_som_cluster")
+
+
 def test_fov_table_helpers(tmp_path):
     """Footer-only column listing, natural ordering, prefetcher / writer round trip, damaged files."""
     from ark_analysis_amd.fov_tables import FovTableDir, TablePrefetcher, TableWriter
