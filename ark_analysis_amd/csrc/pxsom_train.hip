@@ -19,6 +19,7 @@
 
 namespace {
 
+using pxsom::dpp_f64;
 using pxsom::readlane_f64;
 using pxsom::shr1_f64;
 using pxsom::wave_min_f64;
@@ -271,12 +272,16 @@ __global__ __launch_bounds__(MAXT) void som_online_kernel(const T *__restrict__ 
 // exact online SOM, split form: L adjacent lanes share one node, each owning CH consecutive channels
 // (K * L <= 256 threads: the Pixie default 10x10 x <= 24 markers runs as 4 waves, one per SIMD, 12
 // channels per lane).  binary64 issue (~6.75 cycles per wave instruction) bounds the thread<->node
-// form; splitting the channels cuts the per-wave instruction count while keeping the oracle's
-// arithmetic: the squared distance is still accumulated strictly left to right -- lane q continues
-// the partial sum of lane q-1 (row_shr:1 DPP), so after L phases lane L-1 of the group holds the
-// oracle's value bit for bit.  The codebook update is element-wise and splits trivially.
-// The wave minimum runs on the upper 32 bits of d2 (one v_min_u32 DPP per stage); only when the
-// smallest key is shared does the binary64 / sqrt comparison of the thread<->node form run.
+// form; splitting the channels cuts the per-wave instruction count.  The codebook update is
+// element-wise and splits trivially.  The winner search runs in two tiers, both bit-faithful:
+//  * every step: squared distances by a pairwise tree + butterfly (short dependency chain), wave minimum
+//    on their upper 32 bits (one v_min_u32 DPP per stage).  The tree sum is within a few ulp of the
+//    oracle's left-to-right sum, so it decides the step only when no other node's key is within one key
+//    step (2^-21 relative) of the leader's -- then the oracle's winner is necessarily the same node;
+//  * otherwise (near ties, duplicates, non-finite rows; block-uniform branch): the oracle's own
+//    arithmetic -- lane q continues the strictly left-to-right partial sum of lane q-1 (row_shr:1 DPP),
+//    so after L phases lane L-1 holds the oracle's value bit for bit -- a second exchange, and the
+//    key / sqrt comparison of the thread<->node form.
 // ------------------------------------------------------------------------------------------------
 // scripts/ubench/online_step_timing.hip includes this file with PXSOM_STEP_TIMING defined: s_memtime
 // deltas per step segment, accumulated by wave 0 (changes the schedule slightly; diagnosis only)
@@ -310,7 +315,8 @@ __global__ __launch_bounds__(256) void som_online_split_kernel(const T *__restri
     const int lane = tid & 63, wv = tid >> 6, nwv = bd >> 6;
     double *xs = reinterpret_cast<double *>(smem_raw);        // [2][chunk][CMAX] (pad slots stay 0)
     double *dall = xs + (size_t)2 * chunk * CMAX;             // [2][NS] squared distance of every node
-    double *red = dall + 2 * NS;                              // [4] change partials
+    double *dexact = dall + 2 * NS;                           // [NS] FlowSOM-order distances of a close call
+    double *red = dexact + NS;                                // [4] change partials
     int64_t *ordl = reinterpret_cast<int64_t *>(red + 4);     // [chunk] rows presented in the next chunk
     double *alpha_ring = reinterpret_cast<double *>(ordl + chunk);  // [2][chunk] (+ CMAX doubles of slack:
                                                                     //  the one-step-ahead reads may overrun)
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(256) void som_online_split_kernel(const T *__restri
     };
 
     for (int e = tid; e < 2 * chunk * CMAX; e += bd) xs[e] = 0.0;
-    for (int e = tid; e < 2 * NS; e += bd) dall[e] = INFINITY;
+    for (int e = tid; e < 3 * NS; e += bd) dall[e] = INFINITY;  // dall and dexact
     fetch_order(0);
     publish_order();
     __syncthreads();
@@ -441,49 +447,78 @@ __global__ __launch_bounds__(256) void som_online_split_kernel(const T *__restri
                 for (int j = 0; j < CH; j++) xcur[j] = xr[j];
                 alpha_cur = alpha_ring[buf * chunk + s + 1];
             }
-            // FlowSOM eucl() before its sqrt: xdist = 0; xdist += tmp_j^2, j ascending over the node's
-            // channels (0 + sq_0 == sq_0 exactly).  Lane q is correct after phase q.
-            double acc = sq[0];
+            // Squared distance, fast form: pairwise tree over the lane's channels, butterfly over the node's
+            // L lanes.  It differs from FlowSOM's left-to-right sum by a few ulp at most (< 2^-47 relative),
+            // so it may only decide a step whose runner-up is far away; see the key test below.
+            double tsum[CH];
 #pragma unroll
-            for (int j = 1; j < CH; j++) acc += sq[j];
+            for (int j = 0; j < CH; j++) tsum[j] = sq[j];
 #pragma unroll
-            for (int p = 1; p < L; p++) {
-                double t = shr1_f64(acc);
+            for (int stride = 1; stride < CH; stride *= 2)
 #pragma unroll
-                for (int j = 0; j < CH; j++) t += sq[j];
-                acc = q == 0 ? acc : t;
-            }
+                for (int j = 0; j + stride < CH; j += 2 * stride) tsum[j] += tsum[j + stride];
+            double dfast = tsum[0];
+            dfast += dpp_f64(dfast, 0);
+            if (L == 4) dfast += dpp_f64(dfast, 1);
             PXSOM_TICK(1);
             // all-to-all through LDS: one write, one barrier, one 16-byte read per lane; every wave then
             // finds the minimum of all K distances itself (no second exchange of per-wave winners)
-            if (owner) dall[par * NS + node] = acc == acc ? acc : INFINITY;
+            if (owner) dall[par * NS + node] = dfast == dfast ? dfast : INFINITY;
             __syncthreads();
             PXSOM_TICK(2);
-            const d2_t dd = *reinterpret_cast<const d2_t *>(dall + par * NS + 2 * lane);
+            const d2_t df = *reinterpret_cast<const d2_t *>(dall + par * NS + 2 * lane);
             par ^= 1;
-            // the oracle compares sqrt(d2) with a strict '<' in node order.  sqrt is monotone: a node
-            // whose d2 is the only one with the smallest upper 32 bits (gap >= 2^-21 relative) wins
-            // outright; keys shared by several nodes are settled on the sqrt values themselves.
-            const unsigned key0 = (unsigned)(__double_as_longlong(dd[0]) >> 32);
-            const unsigned key1 = (unsigned)(__double_as_longlong(dd[1]) >> 32);
-            const unsigned kmin = wave_min_u32(min(key0, key1));
-            unsigned long long cand0 = __ballot(key0 == kmin), cand1 = __ballot(key1 == kmin);
+            // keys = upper 32 bits of d2 (sign, exponent, 20 mantissa bits).  Exactly one key within
+            // {kmin, kmin + 1}: every other node is at least one whole key step (>= 2^-21 relative) above the
+            // leader -- far more than the fast sum can be off -- so the leader is FlowSOM's winner as well.
+            const unsigned fk0 = (unsigned)(__double_as_longlong(df[0]) >> 32);
+            const unsigned fk1 = (unsigned)(__double_as_longlong(df[1]) >> 32);
+            const unsigned fkmin = wave_min_u32(min(fk0, fk1));
+            const unsigned long long near0 = __ballot(fk0 <= fkmin + 1u), near1 = __ballot(fk1 <= fkmin + 1u);
             int nearest;
-            if (__popcll(cand0) + __popcll(cand1) == 1) {
-                nearest = cand0 ? __builtin_amdgcn_readlane(pk0, (int)__ffsll((long long)cand0) - 1)
-                                : __builtin_amdgcn_readlane(pk1, (int)__ffsll((long long)cand1) - 1);
+            if (__popcll(near0) + __popcll(near1) == 1 && fkmin < 0x7ff00000u) {
+                nearest = near0 ? __builtin_amdgcn_readlane(pk0, (int)__ffsll((long long)near0) - 1)
+                                : __builtin_amdgcn_readlane(pk1, (int)__ffsll((long long)near1) - 1);
             } else {
-                const double s0 = key0 == kmin ? sqrt(dd[0]) : INFINITY;
-                const double s1 = key1 == kmin ? sqrt(dd[1]) : INFINITY;
-                const double sl = fmin(s0, s1);
-                const double smin = wave_min_f64(sl);
-                const unsigned long long cl = __ballot(sl == smin);
-                const int first = (int)__ffsll((long long)cl) - 1;  // lanes ascend in node order
-                const int p0 = __builtin_amdgcn_readlane(pk0, first), p1 = __builtin_amdgcn_readlane(pk1, first);
-                const bool zero_first = (__ballot(s0 == smin) >> first) & 1ull;
-                nearest = zero_first ? p0 : p1;
-                // no finite distance anywhere (NaN row, overflow): FlowSOM's loop never replaces node 0
-                if (!(smin < INFINITY)) nearest = 0;
+                // close call (or no finite distance): redo the step with FlowSOM's own arithmetic.
+                // eucl() before its sqrt: xdist = 0; xdist += tmp_j^2, j ascending over the node's channels
+                // (0 + sq_0 == sq_0 exactly); lane q continues the partial sum of lane q - 1.
+                double acc = sq[0];
+#pragma unroll
+                for (int j = 1; j < CH; j++) acc += sq[j];
+#pragma unroll
+                for (int p = 1; p < L; p++) {
+                    double t = shr1_f64(acc);
+#pragma unroll
+                    for (int j = 0; j < CH; j++) t += sq[j];
+                    acc = q == 0 ? acc : t;
+                }
+                if (owner) dexact[node] = acc == acc ? acc : INFINITY;
+                __syncthreads();  // block-uniform branch: every wave read the same distances
+                const d2_t dd = *reinterpret_cast<const d2_t *>(dexact + 2 * lane);
+                // the oracle compares sqrt(d2) with a strict '<' in node order.  sqrt is monotone: a node
+                // whose d2 is the only one with the smallest key wins outright; keys shared by several nodes
+                // are settled on the sqrt values themselves.
+                const unsigned key0 = (unsigned)(__double_as_longlong(dd[0]) >> 32);
+                const unsigned key1 = (unsigned)(__double_as_longlong(dd[1]) >> 32);
+                const unsigned kmin = wave_min_u32(min(key0, key1));
+                unsigned long long cand0 = __ballot(key0 == kmin), cand1 = __ballot(key1 == kmin);
+                if (__popcll(cand0) + __popcll(cand1) == 1) {
+                    nearest = cand0 ? __builtin_amdgcn_readlane(pk0, (int)__ffsll((long long)cand0) - 1)
+                                    : __builtin_amdgcn_readlane(pk1, (int)__ffsll((long long)cand1) - 1);
+                } else {
+                    const double s0 = key0 == kmin ? sqrt(dd[0]) : INFINITY;
+                    const double s1 = key1 == kmin ? sqrt(dd[1]) : INFINITY;
+                    const double sl = fmin(s0, s1);
+                    const double smin = wave_min_f64(sl);
+                    const unsigned long long cl = __ballot(sl == smin);
+                    const int first = (int)__ffsll((long long)cl) - 1;  // lanes ascend in node order
+                    const int p0 = __builtin_amdgcn_readlane(pk0, first), p1 = __builtin_amdgcn_readlane(pk1, first);
+                    const bool zero_first = (__ballot(s0 == smin) >> first) & 1ull;
+                    nearest = zero_first ? p0 : p1;
+                    // no finite distance anywhere (NaN row, overflow): FlowSOM's loop never replaces node 0
+                    if (!(smin < INFINITY)) nearest = 0;
+                }
             }
             PXSOM_TICK(4);
             if (threshold < 1.0) threshold = 0.5;
@@ -771,7 +806,7 @@ int launch_online_split(const T *x, int64_t n, int c, int64_t ldx, double *w, in
     const int bd = ((K * L + 63) / 64) * 64;
     int chunk = 64;
     while ((chunk * c + bd - 1) / bd > 16) chunk >>= 1;  // gather registers per thread
-    const size_t lds = (size_t)2 * chunk * CH * L * 8 + (2 * 128 + 4) * 8 + (size_t)chunk * 8 +
+    const size_t lds = (size_t)2 * chunk * CH * L * 8 + (3 * 128 + 4) * 8 + (size_t)chunk * 8 +
                        (size_t)2 * chunk * 8 + (size_t)(CH * L + 2) * 8;
     auto kern = som_online_split_kernel<T, CH, L>;
     hipLaunchKernelGGL(kern, dim3(1), dim3(bd), lds, st, x, n, c, ldx, w, xdim, ydim, rlen, a0, a1, r0, r1,

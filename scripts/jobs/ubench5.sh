@@ -1,2 +1,2 @@
 C=ark_analysis_amd/csrc
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -Iinclude -I$C scripts/ubench/online_step_timing.hip $C/pxsom_api.hip $C/pxsom_assign.hip $C/pxsom_assign_filter.hip -o /tmp/ost 2>&1 | grep -E "error" ; /tmp/ost
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -Iinclude -I$C scripts/ubench/online_step_timing.hip $C/pxsom_api.hip $C/pxsom_assign.hip $C/pxsom_assign_filter.hip $C/pxsom_assign_filter_acc.hip -o /tmp/ost 2>&1 | grep -E "error" ; /tmp/ost

@@ -304,6 +304,28 @@ def test_train_online_ties_bit_exact(gpu, oracle, c, xdim, ydim):
     np.testing.assert_array_equal(wd.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("c,xdim,ydim", [(22, 10, 10), (20, 8, 8)])
+def test_train_online_near_ties_take_the_exact_path(gpu, oracle, c, xdim, ydim):
+    """Pairs of initial nodes a few ulp apart: their distances differ, but by far less than the key step the
+    fast (tree-summed) minimum may decide, and in an order a reassociated sum could flip -- the winner has to
+    come from the left-to-right sums.  Bit-equal codebook after two epochs."""
+    k = xdim * ydim
+    n = 3_000
+    x = synth.make_fov_numpy(n, c, seed=19, dtype=np.float32)
+    rs = np.random.RandomState(62)
+    w0 = np.ascontiguousarray(x[rs.choice(n, size=k, replace=False)].astype(np.float64))
+    for a in range(0, k - 1, 2):                       # node a+1 = node a nudged by 1..3 ulp per channel
+        w0[a + 1] = w0[a]
+        for _ in range(3):
+            w0[a + 1] = np.where(rs.rand(c) < 0.5, np.nextafter(w0[a + 1], 2.0), w0[a + 1])
+    order = rs.randint(0, n, size=2 * n).astype(np.int64)
+    ar, rr = (0.05, 0.01), (0.4, 0.0)                  # threshold 0.5 throughout: only the winner moves
+    want = oracle.som_online(x.astype(np.float64), w0, xdim, ydim, 2, ar, rr, order)
+    wd = torch.from_numpy(w0.copy()).to(gpu)
+    sd.train_online(torch.from_numpy(x).to(gpu), wd, xdim, ydim, 2, ar, rr, torch.from_numpy(order).to(gpu))
+    np.testing.assert_array_equal(wd.cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("n,c,k,dtype,stride", [
     (16_384, 22, 100, np.float32, 1),    # fused route: filter + exact accumulate (config 2 mini-batch)
     (16_391, 22, 100, np.float32, 64),   # strided mini-batch view x[t::64], ragged last group
