@@ -16,7 +16,8 @@ SOURCES = ["pxsom_api.hip", "pxsom_assign.hip", "pxsom_assign_filter.hip", "pxso
            "pxsom_pre.hip"]
 # per-file extra flags: the filter works on provably finite scores (see the file header)
 EXTRA_FLAGS = {"pxsom_assign_filter.hip": ["-ffinite-math-only"] + (
-    ["-DSGB_VALU=" + os.environ["PXSOM_SGB_VALU"]] if "PXSOM_SGB_VALU" in os.environ else [])}
+    ["-DSGB_VALU=" + os.environ["PXSOM_SGB_VALU"]] if "PXSOM_SGB_VALU" in os.environ else []) + (
+    ["-DPXSOM_STREAM_TP=" + os.environ["PXSOM_STREAM_TP"]] if "PXSOM_STREAM_TP" in os.environ else [])}
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
                "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
 

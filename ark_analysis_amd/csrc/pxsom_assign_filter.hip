@@ -22,6 +22,9 @@
 #include "pxsom_assign.h"
 #include "pxsom_assign_filter_fast.h"
 
+#ifndef PXSOM_STREAM_TP
+#define PXSOM_STREAM_TP 0
+#endif
 namespace pxsom_bmu {
 namespace {
 
@@ -300,7 +303,10 @@ void launch_filter(const T *x, int64_t n, int c, int64_t ldx, char *ws, const La
                    hipStream_t st)
 {
     constexpr bool PF = (NCH == 1);
-    constexpr int TP = (NB > 0) ? 2 : 1;
+    // streamed codebook (NB == 0): every fragment read from L1 / L2 serves TP tiles.  Measured (filter, ms):
+    // C = 40, K = 400, 4.2 M rows: TP 1 / 2 / 4 = 1.27 / 0.83 / 0.75; C = 100, K = 100, 1 M rows: 0.244 / 0.188 /
+    // 0.257 (four channel chunks x four tiles of fragments no longer fit the register file)
+    constexpr int TP = (NB > 0) ? 2 : (PXSOM_STREAM_TP > 0 ? PXSOM_STREAM_TP : (NCH <= 2 ? 4 : 2));
     auto kern = bmu_filter_kernel<T, NCH, CPL, NB, VEC2, PF, TP>;
     // persistent grid: exactly as many workgroups as are resident (VGPR-limited), capped by the work
     static int blocks_per_cu = 0;
