@@ -36,7 +36,9 @@ namespace {
 //
 // Loads never branch: rows past n are clamped to row n-1 (their results are discarded) and
 // channel slots past c re-read the row's last valid pair (their codebook slots are zero).
-template <typename T, int NCH_T, int CPL_T, int NB_T, bool VEC2, bool PREFETCH, int TP>
+// LDSW (streamed codebook only): fragments + bias are copied into LDS once per workgroup and read from there
+// (ds_read_b128) instead of from L1 / L2 for every tile set.
+template <typename T, int NCH_T, int CPL_T, int NB_T, bool VEC2, bool PREFETCH, int TP, bool LDSW>
 __global__ __launch_bounds__(256, 2) void bmu_filter_kernel(
     const T *__restrict__ x, int64_t n, int c, int64_t ldx, const half8 *__restrict__ wfrag,
     const f32x4 *__restrict__ bias, AssignHdr *hdr, unsigned *__restrict__ amb_list,
@@ -68,6 +70,23 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_kernel(
             for (int s = 0; s < NFR; s++) wreg[b][s] = wfrag[(b * NFR + s) * 64 + lane];
             breg[b] = bias[b * 64 + lane];
         }
+    }
+
+    extern __shared__ __attribute__((aligned(16))) char filt_smem[];
+    half8 *lfrag = reinterpret_cast<half8 *>(filt_smem);
+    f32x4 *lbias = reinterpret_cast<f32x4 *>(lfrag + (size_t)nb * NFR * 64);
+    if constexpr (LDSW && NB_T == 0) {
+        const int nf = nb * NFR * 64;
+        for (int i0 = threadIdx.x; i0 < nf; i0 += 4 * 256) {   // 4 x 16 B in flight per thread
+            half8 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = wfrag[i0 + u * 256 < nf ? i0 + u * 256 : 0];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (i0 + u * 256 < nf) lfrag[i0 + u * 256] = v[u];
+        }
+        for (int i = threadIdx.x; i < nb * 64; i += 256) lbias[i] = bias[i];
+        __syncthreads();
     }
 
     // per-lane element offsets inside a row (clamped into the row): slot (h, i)
@@ -234,13 +253,21 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_kernel(
             } else {
                 for (int b = 0; b < nb; b++) {
                     f32x4 acc[TP];
-                    const f32x4 bv = bias[b * 64 + lane];
+                    f32x4 bv;
+                    if constexpr (LDSW) bv = lbias[b * 64 + lane];
+                    else bv = bias[b * 64 + lane];
 #pragma unroll
                     for (int u = 0; u < TP; u++) acc[u] = bv;
 #pragma unroll
                     for (int h = 0; h < NCH; h++) {
-                        const half8 wh = wfrag[(b * NFR + 2 * h) * 64 + lane];
-                        const half8 wl = wfrag[(b * NFR + 2 * h + 1) * 64 + lane];
+                        half8 wh, wl;
+                        if constexpr (LDSW) {
+                            wh = lfrag[(b * NFR + 2 * h) * 64 + lane];
+                            wl = lfrag[(b * NFR + 2 * h + 1) * 64 + lane];
+                        } else {
+                            wh = wfrag[(b * NFR + 2 * h) * 64 + lane];
+                            wl = wfrag[(b * NFR + 2 * h + 1) * 64 + lane];
+                        }
 #pragma unroll
                         for (int u = 0; u < TP; u++) {
                             const int sl = PREFETCH ? t0 + u : u;
@@ -298,30 +325,48 @@ void launch_fast(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layo
                        (const double *)nullptr, 0, 0);
 }
 
+template <typename T, int NCH, int CPL, int NB, bool VEC2, bool LDSW>
+void launch_filter_variant(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels,
+                           hipStream_t st, size_t lds)
+{
+    constexpr bool PF = (NCH == 1);
+    // streamed codebook (NB == 0): every fragment read serves TP tiles.  Measured (filter, ms, fragments from
+    // L1 / L2): C = 40, K = 400, 4.2 M rows: TP 1 / 2 / 4 = 1.27 / 0.83 / 0.75; C = 100, K = 100, 1 M rows:
+    // 0.244 / 0.188 / 0.257 (four channel chunks x four tiles of fragments no longer fit the register file)
+    constexpr int TP = (NB > 0) ? 2 : (PXSOM_STREAM_TP > 0 ? PXSOM_STREAM_TP : (NCH <= 2 ? 4 : 2));
+    auto kern = bmu_filter_kernel<T, NCH, CPL, NB, VEC2, PF, TP, LDSW>;
+    // persistent grid: exactly as many workgroups as are resident (VGPR- and LDS-limited), capped by the work
+    static int by_regs = 0;
+    if (by_regs == 0) {
+        if (LDSW)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        int nbk = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, kern, 256, 0) != hipSuccess || nbk < 1) nbk = 2;
+        by_regs = nbk > 8 ? 8 : nbk;
+    }
+    int blocks_per_cu = by_regs;
+    if (lds > 0) blocks_per_cu = std::max(1, std::min<int>(by_regs, (int)((160 * 1024) / lds)));
+    const int64_t ngroups = (n + 63) / 64;
+    int grid = (int)std::min<int64_t>((ngroups + 3) / 4, (int64_t)pxsom::device_cu_count() * blocks_per_cu);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, x, n, c, ldx,
+                       reinterpret_cast<const half8 *>(ws + L.off_wfrag),
+                       reinterpret_cast<const f32x4 *>(ws + L.off_bias), reinterpret_cast<AssignHdr *>(ws),
+                       reinterpret_cast<unsigned *>(ws + L.off_list), labels);
+}
+
 template <typename T, int NCH, int CPL, int NB, bool VEC2>
 void launch_filter(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels,
                    hipStream_t st)
 {
-    constexpr bool PF = (NCH == 1);
-    // streamed codebook (NB == 0): every fragment read from L1 / L2 serves TP tiles.  Measured (filter, ms):
-    // C = 40, K = 400, 4.2 M rows: TP 1 / 2 / 4 = 1.27 / 0.83 / 0.75; C = 100, K = 100, 1 M rows: 0.244 / 0.188 /
-    // 0.257 (four channel chunks x four tiles of fragments no longer fit the register file)
-    constexpr int TP = (NB > 0) ? 2 : (PXSOM_STREAM_TP > 0 ? PXSOM_STREAM_TP : (NCH <= 2 ? 4 : 2));
-    auto kern = bmu_filter_kernel<T, NCH, CPL, NB, VEC2, PF, TP>;
-    // persistent grid: exactly as many workgroups as are resident (VGPR-limited), capped by the work
-    static int blocks_per_cu = 0;
-    if (blocks_per_cu == 0) {
-        int nbk = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, kern, 256, 0) != hipSuccess || nbk < 1) nbk = 2;
-        blocks_per_cu = nbk > 8 ? 8 : nbk;
-    }
-    const int64_t ngroups = (n + 63) / 64;
-    int grid = (int)std::min<int64_t>((ngroups + 3) / 4, (int64_t)pxsom::device_cu_count() * blocks_per_cu);
-    if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, x, n, c, ldx,
-                       reinterpret_cast<const half8 *>(ws + L.off_wfrag),
-                       reinterpret_cast<const f32x4 *>(ws + L.off_bias), reinterpret_cast<AssignHdr *>(ws),
-                       reinterpret_cast<unsigned *>(ws + L.off_list), labels);
+    // fragments + bias of the whole codebook in LDS when they fit beside nothing else (150 KB): 2 * NCH + 1
+    // KB per node block
+    const size_t lds = (size_t)L.nb * (2 * NCH + 1) * 1024;
+    if (NB == 0 && lds <= 150 * 1024)
+        launch_filter_variant<T, NCH, CPL, NB, VEC2, true>(x, n, c, ldx, ws, L, labels, st, lds);
+    else
+        launch_filter_variant<T, NCH, CPL, NB, VEC2, false>(x, n, c, ldx, ws, L, labels, st, 0);
 }
 
 }  // namespace
