@@ -44,11 +44,10 @@ inline Layout make_layout(int64_t n, int c, int k)
     if (cpl > 8) cpl = 8;
     L.cpl = cpl;
     L.nsteps = 2 * L.nch;  // stored fragments per node block: {Wh, Wl} per chunk
-    // bits of the per-lane register index b*4 + r packed into the scores' low mantissa bits (the fast
-    // kernel packs a 7-bit (q, b, r) id): the only perturbation the top-2 logic adds
-    L.idx_bits = 4;
-    while ((1 << L.idx_bits) < L.nb * 4) L.idx_bits++;
-    if (L.idx_bits < 7 && L.nb <= 8) L.idx_bits = 7;
+    // low mantissa bits of the scores that the top-2 logic replaces by an index -- its only perturbation, and a
+    // term of the tolerance prep derives: the register-resident kernel (one chunk, 7 node blocks) packs a 7-bit
+    // (q, b, r) id, the streamed kernel only the 2-bit accumulator register index r
+    L.idx_bits = (L.nch == 1 && L.nb <= 8) ? 7 : 2;
     L.node_bits = L.idx_bits;
     L.off_wfrag = kHdrBytes;
     L.off_bias = L.off_wfrag + (size_t)L.nb * L.nsteps * 64 * sizeof(half8);

@@ -49,7 +49,10 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_kernel(
     constexpr int CPLMAX = CPL_T > 0 ? CPL_T : 8;
     const int cpl = CPL_T > 0 ? CPL_T : hdr->cpl;
     const int nb = NB_T > 0 ? NB_T : hdr->nb;
-    const unsigned idx_mask = NB_T > 0 ? 63u : ((1u << hdr->idx_bits) - 1u);
+    // only the accumulator register index r (2 bits) rides in the scores' low mantissa bits; the node block of the
+    // running maximum is tracked beside it (2 VALU ops per block and tile).  With the whole (b, r) index packed,
+    // K = 400 replaced 7 mantissa bits and the packing term was 60 % of the tolerance: 2.5x more rows listed.
+    constexpr unsigned idx_mask = 3u;
     const float scale = hdr->scale, wn_max = hdr->wn_max, tol_rel = hdr->tol_rel,
                 tol_abs = hdr->tol_abs, x_limit = hdr->x_limit;
     const bool force_exact = hdr->force_exact != 0;
@@ -147,13 +150,12 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_kernel(
     };
 
     // finish one tile: node index into the winner, merge the 4 lane groups of a pixel, decide
-    auto finish = [&](float m1, float m2, float s2, int &out_node, bool &out_amb, int t) {
+    auto finish = [&](float m1, float m2, float s2, int bsel, int &out_node, bool &out_amb, int t) {
         // the node index travels beside the score through the merge (no second packing: the only
-        // perturbation of the scores is the idx_bits-wide register index)
+        // perturbation of the scores is the 2-bit register index)
         int node;
         {
-            const unsigned idx = __float_as_uint(m1) & idx_mask;
-            const unsigned bb = idx >> 2, r = idx & 3u;
+            const unsigned bb = (unsigned)bsel, r = __float_as_uint(m1) & idx_mask;
             node = (int)((int)bb == nb - 1 ? (bb << 4) | (r << 2) | (unsigned)q : (bb << 4) | ((unsigned)q << 2) | r);
         }
         // xchg(v) returns (value of the lower lane, value of the upper lane) in BOTH partner lanes, so the
@@ -219,8 +221,19 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_kernel(
                 }
             }
             float m1[TP], m2[TP];
+            int bsel[TP];
 #pragma unroll
-            for (int u = 0; u < TP; u++) m1[u] = m2[u] = kNegBig;
+            for (int u = 0; u < TP; u++) {
+                m1[u] = m2[u] = kNegBig;
+                bsel[u] = 0;
+            }
+            // block b's four scores into the running top-2; remember b when the maximum moved (an equal later
+            // score leaves it where it was: the earlier block)
+            auto absorb = [&](int u, const f32x4 &a, int b) {
+                const float before = m1[u];
+                consume(m1[u], m2[u], a, 0, idx_mask);
+                bsel[u] = m1[u] != before ? b : bsel[u];
+            };
 
             if constexpr (NB_T > 0) {
 #pragma unroll
@@ -248,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_kernel(
                         }
                     }
 #pragma unroll
-                    for (int u = 0; u < TP; u++) consume(m1[u], m2[u], acc[u], b, idx_mask);
+                    for (int u = 0; u < TP; u++) absorb(u, acc[u], b);
                 }
             } else {
                 for (int b = 0; b < nb; b++) {
@@ -277,12 +290,12 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_kernel(
                         }
                     }
 #pragma unroll
-                    for (int u = 0; u < TP; u++) consume(m1[u], m2[u], acc[u], b, idx_mask);
+                    for (int u = 0; u < TP; u++) absorb(u, acc[u], b);
                 }
             }
 #pragma unroll
             for (int u = 0; u < TP; u++)
-                finish(m1[u], m2[u], ss[PREFETCH ? t0 + u : u], my_node, my_amb, t0 + u);
+                finish(m1[u], m2[u], ss[PREFETCH ? t0 + u : u], bsel[u], my_node, my_amb, t0 + u);
         }
         // lane (q, pix) now owns row g*64 + q*16 + pix == g*64 + lane
         const int64_t row = g * 64 + lane;
