@@ -122,21 +122,33 @@ __device__ __forceinline__ void exact_rows_loop(const T *__restrict__ x, int c, 
             double d0[RB], d1[RB];
 #pragma unroll
             for (int u = 0; u < RB; u++) d0[u] = d1[u] = 0.0;
-#pragma unroll 2
-            for (int j = 0; j < c; j++) {
-                // LDS copy, or (big codebooks) the transposed copy prep left in the workspace: either way lanes
-                // read consecutive nodes of channel j
-                const double w0 = wt[(size_t)j * k + c0];
-                const double w1 = wt[(size_t)j * k + c1];
-                const int h = j >> 6, jj = j & 63;
+            // LDS copy, or (big codebooks) the transposed copy prep left in the workspace: either way lanes read
+            // consecutive nodes of channel j.  Eight channels' codebook values are requested together: one at a
+            // time, a short list (a training mini-batch: one row per wave) pays the L2 latency per channel.
+            constexpr int JB = 8;
+            for (int j0 = 0; j0 < c; j0 += JB) {
+                double w0[JB], w1[JB];
 #pragma unroll
-                for (int u = 0; u < RB; u++) {
-                    const unsigned lo = __builtin_amdgcn_readlane(h ? cur.x_lo[u][1] : cur.x_lo[u][0], jj);
-                    const unsigned hi = __builtin_amdgcn_readlane(h ? cur.x_hi[u][1] : cur.x_hi[u][0], jj);
-                    const double xj = __longlong_as_double(((long long)hi << 32) | lo);
-                    const double t0 = xj - w0, t1 = xj - w1;
-                    d0[u] += t0 * t0;
-                    d1[u] += t1 * t1;
+                for (int i = 0; i < JB; i++) {
+                    const int j = j0 + i < c ? j0 + i : c - 1;
+                    w0[i] = wt[(size_t)j * k + c0];
+                    w1[i] = wt[(size_t)j * k + c1];
+                }
+#pragma unroll
+                for (int i = 0; i < JB; i++) {
+                    const int j = j0 + i;
+                    if (j < c) {   // uniform
+                        const int h = j >> 6, jj = j & 63;
+#pragma unroll
+                        for (int u = 0; u < RB; u++) {
+                            const unsigned lo = __builtin_amdgcn_readlane(h ? cur.x_lo[u][1] : cur.x_lo[u][0], jj);
+                            const unsigned hi = __builtin_amdgcn_readlane(h ? cur.x_hi[u][1] : cur.x_hi[u][0], jj);
+                            const double xj = __longlong_as_double(((long long)hi << 32) | lo);
+                            const double t0 = xj - w0[i], t1 = xj - w1[i];
+                            d0[u] += t0 * t0;
+                            d1[u] += t1 * t1;
+                        }
+                    }
                 }
             }
 #pragma unroll
@@ -243,6 +255,20 @@ __global__ __launch_bounds__(256) void bmu_dist_kernel(const T *__restrict__ x, 
 }
 #pragma clang fp contract(fast)
 
+// The prep kernel (one workgroup) stages the codebook in LDS whenever it fits beside its own tables: from
+// global memory its dependent reads cost the L2 latency each (55 us at K = 400, C = 40).
+static int prep_stage(size_t stage_bytes)
+{
+    constexpr size_t kPrepStageMax = 132 * 1024;
+    static bool raised = false;
+    if (!raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bmu_prep_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPrepStageMax);
+        raised = true;
+    }
+    return stage_bytes <= kPrepStageMax;
+}
+
 template <typename T>
 int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int k, int32_t *labels,
                  double *dist, char *ws, const Layout &L, hipStream_t st, double *stats = nullptr,
@@ -251,7 +277,7 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
     if (!prepared && !stats) {  // prepared: pxsom_batch_update_prepare did this; stats: the accumulating filter
                                  // prepares the codebook inside its own launch
         const size_t stage_bytes = (size_t)k * c * sizeof(double);
-        const int stage = stage_bytes <= 40 * 1024;
+        const int stage = prep_stage(stage_bytes);
         hipLaunchKernelGGL(bmu_prep_kernel, dim3(1), dim3(256), stage ? stage_bytes : 0, st, w, k, c,
                            reinterpret_cast<AssignHdr *>(ws),
                            reinterpret_cast<half8 *>(ws + L.off_wfrag), reinterpret_cast<f32x4 *>(ws + L.off_bias),
@@ -364,7 +390,7 @@ int pxsom_bmu::prepare_only(const double *w_dev, int c, int k, void *workspace_d
     if (workspace_bytes < L.total) return pxsom::fail(PXSOM_ERR_WORKSPACE, "prepare: workspace too small");
     char *ws = reinterpret_cast<char *>(workspace_dev);
     const size_t stage_bytes = (size_t)k * c * sizeof(double);
-    const int stage = stage_bytes <= 40 * 1024;
+    const int stage = prep_stage(stage_bytes);
     hipLaunchKernelGGL(bmu_prep_kernel, dim3(1), dim3(256), stage ? stage_bytes : 0, st, w_dev, k, c,
                        reinterpret_cast<AssignHdr *>(ws), reinterpret_cast<half8 *>(ws + L.off_wfrag),
                        reinterpret_cast<f32x4 *>(ws + L.off_bias), L.nb, L.nch, L.cpl, L.idx_bits, L.node_bits, stage,

@@ -189,11 +189,12 @@ __device__ __forceinline__ void prep_body(const double *wl, int k, int c, Assign
             if (a[j] != b[j]) return false;
         return true;
     };
-    if (k <= 256) {
+    if (k <= PXSOM_MAX_NODES) {
         // all pairs on the row keys (equal rows have equal keys; norms are useless here: near-duplicates
         // often round to the same norm), the range of earlier nodes split over NT/k threads per node;
-        // full channel comparison only on a key match
-        __shared__ int s_first[256];
+        // full channel comparison only on a key match.  (Also for k > 256, where each thread scans for several
+        // nodes: the hash table below took 60 us at k = 400 -- slot collisions fall back to scans one by one.)
+        __shared__ int s_first[PXSOM_MAX_NODES];
         for (int node = tid; node < k; node += NT) s_first[node] = 0x7fffffff;
         __syncthreads();
         int sp = 1;
