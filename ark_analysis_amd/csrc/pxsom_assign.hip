@@ -97,7 +97,10 @@ struct ExactRows {
     }
 };
 
-template <typename T, int RB>
+// NS node slots per sweep (lane <-> nodes base + lane + 64 s), JB channels of codebook values requested
+// together.  Long lists (RB = 4) are throughput-bound: NS = 2, JB = 8.  A short list is one row per wave and pure
+// latency; against a big codebook read from L2 its sweeps collapse into one with NS = 8 (512 nodes), JB = 4.
+template <typename T, int RB, int NS, int JB>
 __device__ __forceinline__ void exact_rows_loop(const T *__restrict__ x, int c, int64_t ldx,
                                                 const double *__restrict__ w, const double *wt, int k,
                                                 unsigned count, const unsigned *__restrict__ amb_list,
@@ -116,23 +119,26 @@ __device__ __forceinline__ void exact_rows_loop(const T *__restrict__ x, int c, 
             best[u] = DBL_MAX;
             bestk[u] = 0x7fffffff;
         }
-        for (int base = 0; base < k; base += 128) {
-            const int n0 = base + lane, n1 = base + 64 + lane;
-            const int c0 = n0 < k ? n0 : k - 1, c1 = n1 < k ? n1 : k - 1;
-            double d0[RB], d1[RB];
+        for (int base = 0; base < k; base += 64 * NS) {
+            int cn[NS];   // clamped node of each slot
+            double d[NS][RB];
 #pragma unroll
-            for (int u = 0; u < RB; u++) d0[u] = d1[u] = 0.0;
+            for (int s = 0; s < NS; s++) {
+                const int nd = base + 64 * s + lane;
+                cn[s] = nd < k ? nd : k - 1;
+#pragma unroll
+                for (int u = 0; u < RB; u++) d[s][u] = 0.0;
+            }
             // LDS copy, or (big codebooks) the transposed copy prep left in the workspace: either way lanes read
-            // consecutive nodes of channel j.  Eight channels' codebook values are requested together: one at a
-            // time, a short list (a training mini-batch: one row per wave) pays the L2 latency per channel.
-            constexpr int JB = 8;
+            // consecutive nodes of channel j.  JB channels' values of every slot are requested together: one at
+            // a time, a short list (a training mini-batch: one row per wave) pays the L2 latency per channel.
             for (int j0 = 0; j0 < c; j0 += JB) {
-                double w0[JB], w1[JB];
+                double wv[NS][JB];
 #pragma unroll
                 for (int i = 0; i < JB; i++) {
                     const int j = j0 + i < c ? j0 + i : c - 1;
-                    w0[i] = wt[(size_t)j * k + c0];
-                    w1[i] = wt[(size_t)j * k + c1];
+#pragma unroll
+                    for (int s = 0; s < NS; s++) wv[s][i] = wt[(size_t)j * k + cn[s]];
                 }
 #pragma unroll
                 for (int i = 0; i < JB; i++) {
@@ -144,23 +150,25 @@ __device__ __forceinline__ void exact_rows_loop(const T *__restrict__ x, int c, 
                             const unsigned lo = __builtin_amdgcn_readlane(h ? cur.x_lo[u][1] : cur.x_lo[u][0], jj);
                             const unsigned hi = __builtin_amdgcn_readlane(h ? cur.x_hi[u][1] : cur.x_hi[u][0], jj);
                             const double xj = __longlong_as_double(((long long)hi << 32) | lo);
-                            const double t0 = xj - w0[i], t1 = xj - w1[i];
-                            d0[u] += t0 * t0;
-                            d1[u] += t1 * t1;
+#pragma unroll
+                            for (int s = 0; s < NS; s++) {
+                                const double t = xj - wv[s][i];
+                                d[s][u] += t * t;
+                            }
                         }
                     }
                 }
             }
 #pragma unroll
-            for (int u = 0; u < RB; u++) {
-                const double s0 = sqrt(d0[u]), s1 = sqrt(d1[u]);
-                if (n0 < k && s0 < best[u]) {
-                    best[u] = s0;
-                    bestk[u] = n0;
-                }
-                if (n1 < k && s1 < best[u]) {
-                    best[u] = s1;
-                    bestk[u] = n1;
+            for (int s = 0; s < NS; s++) {   // ascending node order within the lane: first strict minimum
+                const int nd = base + 64 * s + lane;
+#pragma unroll
+                for (int u = 0; u < RB; u++) {
+                    const double sd = sqrt(d[s][u]);
+                    if (nd < k && sd < best[u]) {
+                        best[u] = sd;
+                        bestk[u] = nd;
+                    }
                 }
             }
         }
@@ -224,9 +232,11 @@ __global__ __launch_bounds__(256) void bmu_exact_kernel(const T *__restrict__ x,
     }
     PXSOM_PHASE(10);
     if (wide)
-        exact_rows_loop<T, 4>(x, c, ldx, w, wt, k, count, amb_list, labels, use_lds, wave, nwaves, lane, cur4);
+        exact_rows_loop<T, 4, 2, 8>(x, c, ldx, w, wt, k, count, amb_list, labels, use_lds, wave, nwaves, lane, cur4);
+    else if (!use_lds && k > 128)
+        exact_rows_loop<T, 1, 8, 4>(x, c, ldx, w, wt, k, count, amb_list, labels, use_lds, wave, nwaves, lane, cur1);
     else
-        exact_rows_loop<T, 1>(x, c, ldx, w, wt, k, count, amb_list, labels, use_lds, wave, nwaves, lane, cur1);
+        exact_rows_loop<T, 1, 2, 8>(x, c, ldx, w, wt, k, count, amb_list, labels, use_lds, wave, nwaves, lane, cur1);
 }
 
 // distance of every row to its labelled node (only when the caller asks for dists)
@@ -296,8 +306,10 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
     if (stats) return PXSOM_OK;   // the accumulating filter settled its listed rows itself
     const size_t wt_bytes = (size_t)k * c * sizeof(double);
     const int use_lds = wt_bytes <= 64 * 1024;
-    // listed rows are a small fraction of n; the kernel grid-strides over the list anyway
-    int egrid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)cus * 4);
+    // listed rows are a small fraction of n and the kernel grid-strides over the list, but a mini-batch of a
+    // few thousand rows can list hundreds in early training steps: enough workgroups that those still take one
+    // or two rounds (workgroups without rows leave at once)
+    int egrid = (int)std::min<int64_t>((n + 31) / 32, (int64_t)cus * 4);
     if (egrid < 1) egrid = 1;
     hipLaunchKernelGGL(bmu_exact_kernel<T>, dim3(egrid), dim3(256), use_lds ? wt_bytes : 0, st, x, c, ldx, w,
                        k, reinterpret_cast<const AssignHdr *>(ws),
