@@ -41,9 +41,8 @@ __global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict_
     const int tid = threadIdx.x;
     // small codebooks are staged in LDS with one coalesced sweep (8 loads in flight per thread); every
     // later read is an LDS read
-    const double *wl = w;
+    double *sw = reinterpret_cast<double *>(prep_smem);
     if (stage) {
-        double *sw = reinterpret_cast<double *>(prep_smem);
         for (int e0 = tid; e0 < k * c; e0 += 8 * 256) {
             double v[8];
 #pragma unroll
@@ -52,11 +51,13 @@ __global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict_
             for (int u = 0; u < 8; u++)
                 if (e0 + u * 256 < k * c) sw[e0 + u * 256] = v[u];
         }
-        wl = sw;
     }
     __syncthreads();
     PXSOM_PHASE_ANY(1);
-    prep_body<256>(wl, k, c, hdr, wfrag, bias, nb, nch, cpl, idx_bits, node_bits, wt_out);
+    // two calls, not one with a selected pointer: each inlined copy then knows its address space (ds_read for
+    // the staged codebook instead of flat loads)
+    if (stage) prep_body<256>(sw, k, c, hdr, wfrag, bias, nb, nch, cpl, idx_bits, node_bits, wt_out);
+    else prep_body<256>(w, k, c, hdr, wfrag, bias, nb, nch, cpl, idx_bits, node_bits, wt_out);
 }
 
 

@@ -44,10 +44,20 @@ __device__ __forceinline__ void prep_body(const double *wl, int k, int c, Assign
                                           double *wt_out = nullptr)
 {
     // big codebooks: a transposed copy [c][k] for the exact kernel (coalesced reads, lanes <-> nodes)
+    // Written in ITS order (consecutive threads <-> consecutive nodes of a channel: coalesced stores, strided
+    // reads of the staged codebook), the (channel, node) pair advanced without a division per element.
     if (wt_out) {
+        int j = (int)threadIdx.x / k, node = (int)threadIdx.x - j * k;
+        const int dj = NT / k, dn = NT % k;
+#pragma unroll 4
         for (int e = threadIdx.x; e < k * c; e += NT) {
-            const int node = e / c, j = e - node * c;
-            wt_out[(size_t)j * k + node] = wl[e];
+            wt_out[e] = wl[(size_t)node * c + j];
+            j += dj;
+            node += dn;
+            if (node >= k) {
+                node -= k;
+                j++;
+            }
         }
     }
     __shared__ double s_norm2[PXSOM_MAX_NODES];

@@ -6,10 +6,10 @@
 #include <cstdlib>
 #include <vector>
 
-int main()
+int main(int argc, char **argv)
 {
     const int64_t n = 16384;
-    const int c = 22, K = 100;
+    const int c = argc > 1 ? atoi(argv[1]) : 22, K = argc > 2 ? atoi(argv[2]) : 100;
     std::vector<float> x((size_t)n * c);
     srand(1);
     for (auto &v : x) v = (float)rand() / RAND_MAX;
@@ -26,7 +26,8 @@ int main()
     hipMemcpy(dw, w.data(), w.size() * 8, hipMemcpyHostToDevice);
     for (int rep = 0; rep < 3; rep++) {
         bool fused = false;
-        int rc = pxsom_bmu::assign_accumulate(dx, n, c, c, PXSOM_F32, dw, K, dl, dstats, ws, wsb, 0, &fused);
+        int rc = argc > 1 ? pxsom_assign(dx, n, c, c, PXSOM_F32, dw, K, dl, nullptr, ws, wsb, nullptr)
+                          : pxsom_bmu::assign_accumulate(dx, n, c, c, PXSOM_F32, dw, K, dl, dstats, ws, wsb, 0, &fused);
         hipDeviceSynchronize();
         long long t[32];
         hipMemcpyFromSymbol(t, HIP_SYMBOL(g_phase_ticks), sizeof(t));
