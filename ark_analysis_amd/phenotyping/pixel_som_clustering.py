@@ -125,7 +125,7 @@ def cluster_pixels(fovs, base_dir, pixel_pysom, data_dir='pixel_mat_data',
     # progress is reported per group: batch_size FOVs when multiprocess, else every 10th FOV + the last
     group = batch_size if multiprocess else 1
     done = 0
-    writer = TableWriter()
+    writer = TableWriter(depth=4, workers=3)      # FOV tables are independent: written side by side
     try:
         feed = iter(TablePrefetcher(tables, todo, as_arrow=True))
         for names in fov_tables.batches(todo, group):
