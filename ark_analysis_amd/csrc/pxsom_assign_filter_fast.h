@@ -177,6 +177,9 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
         f32x4 *bias_l = reinterpret_cast<f32x4 *>(frag_l + NB * 2 * 64);             // [NB][64]
         AssignHdr *hdr_l = reinterpret_cast<AssignHdr *>(bias_l + NB * 64);
         for (int e = threadIdx.x; e < k * c + k; e += 256) ls[e] = 0.0;
+        // element e = tid + 256 u  <->  (node, channel), advanced without a division per element
+        int node = (int)threadIdx.x / c, j = (int)threadIdx.x - node * c;
+        const int dnode = 256 / c, dj = 256 % c;
         for (int e0 = threadIdx.x; e0 < k * c; e0 += 8 * 256) {   // 8 L2 loads in flight per thread
             double v[8];
 #pragma unroll
@@ -185,9 +188,14 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
             for (int u = 0; u < 8; u++) {
                 const int e = e0 + u * 256;
                 if (e < k * c) {
-                    const int node = e / c, j = e - node * c;
                     wrow[e] = v[u];
-                    wt[(size_t)j * k + node] = v[u];
+                    wt[j * k + node] = v[u];
+                }
+                node += dnode;
+                j += dj;
+                if (j >= c) {
+                    j -= c;
+                    node++;
                 }
             }
         }
