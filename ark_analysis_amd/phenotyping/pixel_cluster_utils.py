@@ -14,7 +14,7 @@ import numpy as np
 import pandas as pd
 
 from .. import flowsom, image_io
-from ..fov_tables import UNREADABLE, FovTableDir
+from ..fov_tables import FovTableDir, TablePrefetcher
 from ..host_utils import natsort_key, validate_paths, verify_in_list
 
 
@@ -68,6 +68,9 @@ def normalize_rows(pixel_data, channels, include_seg_label=True):
     return out
 
 
+_DEVICE_SUMS = flowsom.cluster_sums   # the real device entry point (tests may swap the attribute)
+
+
 class _ClusterTotals:
     """Running per-cluster channel sums and pixel counts over FOV tables; cluster ids are whatever the
     label column holds (SOM labels 1..K, or meta-cluster ids), so totals are kept per id."""
@@ -85,6 +88,9 @@ class _ClusterTotals:
         # the kernel wants labels 1..len(distinct)
         sums, counts = flowsom.cluster_sums(table[self.channels].to_numpy(),
                                             (dense + 1).astype(np.int32), len(distinct))
+        self._merge(distinct, sums, counts)
+
+    def _merge(self, distinct, sums, counts) -> None:
         for row, cid in enumerate(distinct):
             if cid in self._sum:
                 self._sum[cid] = self._sum[cid] + sums[row]
@@ -92,6 +98,36 @@ class _ClusterTotals:
             else:
                 self._sum[cid] = np.array(sums[row], dtype=np.float64)
                 self._n[cid] = int(counts[row])
+
+    def add_arrow(self, table, cluster_col: str) -> None:
+        """The same totals from the Arrow table the file reader produced, without pandas: channel chunks ->
+        ``[C, n]`` in HBM -> transpose -> ``pxsom_cluster_sums`` with the distinct ids found on the device.
+        Tables it does not cover (nulls, other column types) take :meth:`add_table`."""
+        import pyarrow as pa
+        import torch
+        from .. import _capi, som_device
+        ids_col = table.column(cluster_col) if cluster_col in table.column_names else None
+        plain = (ids_col is not None and ids_col.null_count == 0 and table.num_rows > 0
+                 and (pa.types.is_integer(ids_col.type) or pa.types.is_floating(ids_col.type))
+                 and all(ch in table.column_names and table.column(ch).type == pa.float64()
+                         and table.column(ch).null_count == 0 for ch in self.channels))
+        if not plain:
+            return self.add_table(table.to_pandas(), cluster_col)
+        dev = _capi.require_gpu()
+        n, c = table.num_rows, len(self.channels)
+        planar = torch.empty((c, n), dtype=torch.float64, device=dev)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", UserWarning)   # torch: "array is not writable" (only read)
+            for j, name in enumerate(self.channels):
+                at = 0
+                for chunk in table.column(name).chunks:
+                    host = chunk.to_numpy(zero_copy_only=True)
+                    planar[j, at:at + len(host)].copy_(torch.from_numpy(host), non_blocking=True)
+                    at += len(host)
+            ids = torch.from_numpy(ids_col.to_numpy()).to(dev)
+        distinct, dense = torch.unique(ids, return_inverse=True)
+        sums, counts = som_device.cluster_sums(planar.t().contiguous(), (dense + 1).to(torch.int32), int(distinct.numel()))
+        self._merge(distinct.cpu().numpy(), sums.cpu().numpy(), counts.cpu().numpy())
 
     def __len__(self):
         return len(self._sum)
@@ -130,11 +166,16 @@ def compute_pixel_cluster_channel_avg(fovs, channels, base_dir, pixel_cluster_co
 
     tables = FovTableDir(os.path.join(base_dir, pixel_data_dir))
     totals = _ClusterTotals(channels)
-    for fov in chosen:
-        try:
-            totals.add_table(tables.load(fov), pixel_cluster_col)
-        except UNREADABLE:
+    # tables are read one ahead on a background thread; with the device entry point in place (tests may swap
+    # it) they stay Arrow tables and never become DataFrames
+    on_device = flowsom.cluster_sums is _DEVICE_SUMS
+    for fov, table in TablePrefetcher(tables, chosen, as_arrow=on_device):
+        if table is None:
             print("The data for FOV %s has been corrupted, skipping" % fov)
+        elif on_device:
+            totals.add_arrow(table, pixel_cluster_col)
+        else:
+            totals.add_table(table, pixel_cluster_col)
 
     if len(totals) == 0:
         raise ValueError("No objects to concatenate")   # what pd.concat([]) says in the reference

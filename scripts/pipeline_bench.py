@@ -72,6 +72,23 @@ t0 = time.perf_counter()
 pixel_som_clustering.cluster_pixels(fovs, root, som)
 t_pipe = time.perf_counter() - t0
 px = n * args.fovs
+# the per-SOM-cluster mean table over the labelled tables (generate_som_avg_files' work): device path, then
+# the DataFrame path the reference shape implies (same kernel underneath)
+from ark_analysis_amd.phenotyping import pixel_cluster_utils  # noqa: E402
+chans = list(som.weights.columns)
+t0 = time.perf_counter()
+avg = pixel_cluster_utils.compute_pixel_cluster_channel_avg(fovs, chans, root, "pixel_som_cluster", None, "pixel_mat_data",
+                                                            num_fovs_subset=len(fovs), keep_count=True)
+t_avg = time.perf_counter() - t0
+device_sums = pixel_cluster_utils._DEVICE_SUMS
+pixel_cluster_utils._DEVICE_SUMS = None           # forces the DataFrame route
+t0 = time.perf_counter()
+avg_df = pixel_cluster_utils.compute_pixel_cluster_channel_avg(fovs, chans, root, "pixel_som_cluster", None,
+                                                               "pixel_mat_data", num_fovs_subset=len(fovs), keep_count=True)
+t_avg_df = time.perf_counter() - t0
+pixel_cluster_utils._DEVICE_SUMS = device_sums
+assert np.array_equal(avg["count"].values, avg_df["count"].values)
+assert np.allclose(avg[chans].values, avg_df[chans].values, rtol=1e-13, atol=0)
 print(json.dumps({
     "workload": f"{args.fovs} FOV tables {args.side}^2 x {args.channels} float64 + 4 meta columns, "
                 f"{bytes_per_table / 1e6:.0f} MB each, scratch {root}",
@@ -80,5 +97,6 @@ print(json.dumps({
                             "write": round(t_write, 3), "sum": round(t_read + t_label + t_write, 3)},
     "cluster_pixels_s": round(t_pipe, 3),
     "cluster_pixels_Mpx_per_s": round(px / t_pipe / 1e6, 2),
+    "cluster_channel_avg_s": round(t_avg, 3), "cluster_channel_avg_dataframe_route_s": round(t_avg_df, 3),
     "generated_in_s": round(t_gen, 1)}))
 shutil.rmtree(root)

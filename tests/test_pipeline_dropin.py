@@ -265,6 +265,43 @@ def test_arrow_fast_path_equals_dataframe_path(gpu, tmp_path):
     assert not arrow_assign.applicable(obj, odd, True)
 
 
+@pytest.mark.gpu
+def test_cluster_channel_avg_arrow_route_equals_dataframe_route(gpu, tmp_path, capsys):
+    """compute_pixel_cluster_channel_avg straight from the Arrow tables == through DataFrames: integer and
+    float-typed cluster ids, ids that are not 1..K, a float32 channel (falls back per table), a damaged file."""
+    from ark_analysis_amd import fov_tables
+    rs = np.random.RandomState(12)
+    td = str(tmp_path)
+    os.mkdir(os.path.join(td, "pixel_mat_data"))
+    chans = ["chan%d" % i for i in range(5)]
+    fovs = ["fov%d" % i for i in range(4)]
+    for i, fov in enumerate(fovs):
+        n = 3000 + 17 * i
+        df = pd.DataFrame(rs.rand(n, 5), columns=chans)
+        df["fov"] = fov
+        df["pixel_som_cluster"] = rs.choice([2, 3, 5, 8, 13, 40], size=n)
+        df["pixel_meta_cluster"] = rs.choice([1.0, 2.0, 7.0], size=n)          # float-typed ids
+        if i == 2:
+            df["chan1"] = df["chan1"].astype(np.float32)                        # not covered: per-table fallback
+        fov_tables.write_dataframe(df, os.path.join(td, "pixel_mat_data", fov + ".feather"))
+    with open(os.path.join(td, "pixel_mat_data", "fov3.feather"), "r+b") as f:  # damaged table
+        f.truncate(1000)
+    for col in ("pixel_som_cluster", "pixel_meta_cluster"):
+        fast = pixel_cluster_utils.compute_pixel_cluster_channel_avg(fovs, chans, td, col, None, keep_count=True)
+        out_fast = capsys.readouterr().out
+        real = pixel_cluster_utils._DEVICE_SUMS
+        pixel_cluster_utils._DEVICE_SUMS = None            # DataFrame route (same kernel underneath)
+        try:
+            slow = pixel_cluster_utils.compute_pixel_cluster_channel_avg(fovs, chans, td, col, None, keep_count=True)
+        finally:
+            pixel_cluster_utils._DEVICE_SUMS = real
+        assert out_fast == capsys.readouterr().out == "The data for FOV fov3 has been corrupted, skipping\n"
+        assert list(fast.columns) == list(slow.columns) and [str(d) for d in fast.dtypes] == [str(d) for d in slow.dtypes]
+        np.testing.assert_array_equal(fast[col].values, slow[col].values)
+        np.testing.assert_array_equal(fast["count"].values, slow["count"].values)
+        np.testing.assert_allclose(fast[chans].values, slow[chans].values, rtol=1e-13, atol=0)
+
+
 @pytest.mark.parametrize("cluster_col", ["pixel_som_cluster", "pixel_meta_cluster_rename"])
 def test_create_c2pc_data_matches_reference_run(som_backend, tmp_path, cluster_col):
     """cell x pixel-cluster counts and their cell_size-normalised twin against the reference's own
