@@ -300,7 +300,7 @@ __device__ long long g_step_ticks[8];
 #endif
 
 template <typename T, int CH, int L>
-__global__ __launch_bounds__(256) void som_online_split_kernel(const T *__restrict__ x, int64_t n, int c,
+__global__ __launch_bounds__(CH * L > 40 ? 512 : 256) void som_online_split_kernel(const T *__restrict__ x, int64_t n, int c,
                                                                int64_t ldx, double *w, int xdim, int ydim,
                                                                int rlen, double a0, double a1, double r0,
                                                                double r1, const int64_t *__restrict__ order,
@@ -316,8 +316,8 @@ __global__ __launch_bounds__(256) void som_online_split_kernel(const T *__restri
     double *xs = reinterpret_cast<double *>(smem_raw);        // [2][chunk][CMAX] (pad slots stay 0)
     double *dall = xs + (size_t)2 * chunk * CMAX;             // [2][NS] squared distance of every node
     double *dexact = dall + 2 * NS;                           // [NS] FlowSOM-order distances of a close call
-    double *red = dexact + NS;                                // [4] change partials
-    int64_t *ordl = reinterpret_cast<int64_t *>(red + 4);     // [chunk] rows presented in the next chunk
+    double *red = dexact + NS;                                // [8] change partials (one per wave)
+    int64_t *ordl = reinterpret_cast<int64_t *>(red + 8);     // [chunk] rows presented in the next chunk
     double *alpha_ring = reinterpret_cast<double *>(ordl + chunk);  // [2][chunk] (+ CMAX doubles of slack:
                                                                     //  the one-step-ahead reads may overrun)
 
@@ -806,9 +806,12 @@ int launch_online_split(const T *x, int64_t n, int c, int64_t ldx, double *w, in
     const int bd = ((K * L + 63) / 64) * 64;
     int chunk = 64;
     while ((chunk * c + bd - 1) / bd > 16) chunk >>= 1;  // gather registers per thread
-    const size_t lds = (size_t)2 * chunk * CH * L * 8 + (3 * 128 + 4) * 8 + (size_t)chunk * 8 +
+    const size_t lds = (size_t)2 * chunk * CH * L * 8 + (3 * 128 + 8) * 8 + (size_t)chunk * 8 +
                        (size_t)2 * chunk * 8 + (size_t)(CH * L + 2) * 8;
     auto kern = som_online_split_kernel<T, CH, L>;
+    if (lds > 48 * 1024)
+        PXSOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(1), dim3(bd), lds, st, x, n, c, ldx, w, xdim, ydim, rlen, a0, a1, r0, r1,
                        order, chunk);
     PXSOM_LAUNCH_CHECK("som_online_split_kernel");
@@ -835,6 +838,13 @@ int train_online_typed(const T *x, int64_t n, int c, int64_t ldx, double *w, int
         if (c <= 24) PXSOM_ONLINE_SPLIT(12, 2);
         PXSOM_ONLINE_SPLIT(20, 2);
     }
+    // wide rows (cell SOM: ~100 cluster-count features) on maps up to 128 nodes: 4 lanes per node in a
+    // 512-thread workgroup (two waves per SIMD)
+    if (xdim * ydim <= 128 && c <= 104) {
+        if (c <= 64) PXSOM_ONLINE_SPLIT(16, 4);
+        if (c <= 80) PXSOM_ONLINE_SPLIT(20, 4);
+        PXSOM_ONLINE_SPLIT(26, 4);
+    }
 #undef PXSOM_ONLINE_SPLIT
     // <= 256 nodes: 4 waves at most, the whole register file is available per thread
     if (xdim * ydim <= 256) {
@@ -843,9 +853,17 @@ int train_online_typed(const T *x, int64_t n, int c, int64_t ldx, double *w, int
         if (c <= 24) PXSOM_ONLINE(24, 256);
         if (c <= 40) PXSOM_ONLINE(40, 256);
         if (c <= 64) PXSOM_ONLINE(64, 256);
+        if (c <= 104) PXSOM_ONLINE(104, 256);   // cell SOM: ~100 cluster-count features (one wave per SIMD: 512 registers)
         PXSOM_ONLINE(0, 256);
     }
-    PXSOM_ONLINE(0, 1024);  // > 256 nodes: 128 VGPRs per thread, codebook stays in LDS
+    // <= 512 nodes (config 5's 20 x 20 map): two waves per SIMD, 256 registers per thread
+    if (xdim * ydim <= 512) {
+        if (c <= 8) PXSOM_ONLINE(8, 512);
+        if (c <= 16) PXSOM_ONLINE(16, 512);
+        if (c <= 24) PXSOM_ONLINE(24, 512);
+        if (c <= 40) PXSOM_ONLINE(40, 512);
+    }
+    PXSOM_ONLINE(0, 1024);  // more nodes or wider rows: 128 VGPRs per thread, codebook stays in LDS
 #undef PXSOM_ONLINE
 }
 

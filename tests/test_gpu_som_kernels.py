@@ -267,8 +267,13 @@ def test_cluster_sums_wave_private_tables(gpu, oracle, n, c, k, dtype, mode):
     (2_000, 5, 10, 10, 1, np.float64),    # 2 lanes per node, 4 channels per lane
     (2_000, 14, 11, 11, 1, np.float32),   # 2 lanes per node, 8 channels per lane
     (1_500, 37, 10, 12, 1, np.float32),   # 2 lanes per node, 20 channels per lane
-    (1_000, 45, 10, 10, 1, np.float32),   # thread <-> node form (c > 40)
-    (1_000, 70, 12, 12, 1, np.float64),   # thread <-> node form, codebook in LDS
+    (1_000, 45, 10, 10, 1, np.float32),   # wide rows: 4 lanes per node in 512 threads, 16 channels per lane
+    (1_000, 70, 9, 11, 2, np.float64),    # ... 20 channels per lane
+    (1_500, 100, 10, 10, 1, np.float32),  # ... 26 channels per lane: the cell SOM of config 4
+    (800, 104, 8, 16, 1, np.float64),     # ... all 104 slots used, 128 nodes
+    (1_000, 70, 12, 12, 1, np.float64),   # thread <-> node form (more than 128 nodes), 104 registers per node
+    (600, 100, 16, 16, 1, np.float32),    # thread <-> node form, 256 nodes
+    (500, 110, 10, 10, 1, np.float32),    # thread <-> node form, codebook in LDS (c > 104)
     (2_000, 22, 10, 10, 1, np.float16),   # fp16 rows
 ])
 def test_train_online_bit_exact(gpu, oracle, n, c, xdim, ydim, rlen, dtype):
@@ -286,7 +291,7 @@ def test_train_online_bit_exact(gpu, oracle, n, c, xdim, ydim, rlen, dtype):
     np.testing.assert_array_equal(got, want)
 
 
-@pytest.mark.parametrize("c,xdim,ydim", [(22, 10, 10), (6, 7, 9), (12, 5, 5), (30, 16, 16)])
+@pytest.mark.parametrize("c,xdim,ydim", [(22, 10, 10), (6, 7, 9), (12, 5, 5), (30, 16, 16), (100, 10, 10), (50, 8, 8)])
 def test_train_online_ties_bit_exact(gpu, oracle, c, xdim, ydim):
     """Coarsely quantised rows and duplicated initial nodes: equal and near-equal distances are the
     rule, so the first-strict-minimum path (sqrt comparison, lowest node wins) is what is tested."""
