@@ -14,9 +14,10 @@ void launch_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layou
                 const double *w, hipStream_t st)
 {
     auto kern = bmu_filter_fast<T, CPL, 7, 1, 0, true>;
-    // table | transposed codebook | row-major codebook | fragments | bias | header copy
+    // table | transposed codebook | row-major codebook | fragments | bias | header copy | listed-row queue
     const size_t lds = ((size_t)L.k * c + L.k + 2 * (size_t)L.k * c) * sizeof(double) +
-                       (size_t)7 * 2 * 64 * sizeof(half8) + (size_t)7 * 64 * sizeof(f32x4) + kHdrBytes;
+                       (size_t)7 * 2 * 64 * sizeof(half8) + (size_t)7 * 64 * sizeof(f32x4) + kHdrBytes +
+                       256 * sizeof(int64_t) + 16;   // + queue of listed rows and its counter
     static int bpc = 0;
     if (bpc == 0) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -26,7 +27,7 @@ void launch_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layou
         bpc = nbk > 8 ? 8 : nbk;
     }
     const int64_t ngroups = (n + 63) / 64;
-    int grid = (int)std::min<int64_t>((ngroups + 3) / 4, (int64_t)pxsom::device_cu_count() * bpc);
+    int grid = (int)std::min<int64_t>(ngroups, (int64_t)pxsom::device_cu_count() * bpc);   // see the group dealing
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, x, n, c, ldx,
                        reinterpret_cast<const half8 *>(ws + L.off_wfrag),

@@ -168,6 +168,11 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
     extern __shared__ __attribute__((aligned(16))) char acc_smem[];
     double *ls = reinterpret_cast<double *>(acc_smem);  // [k*c + k]
     double *wt = ls + (size_t)k * c + k;                 // [c][k] transposed codebook (ACC only)
+    // ACC: rows the filter is not sure of wait in a per-workgroup queue and are settled after the group loop by
+    // whichever wave is free (a mini-batch lists 0..6 rows per wave early in training: the slowest wave set the pace)
+    constexpr unsigned kAmbQueue = 256;
+    int64_t *amb_q = nullptr;
+    unsigned *amb_n = nullptr;
     if constexpr (ACC) {
         // Every workgroup prepares the codebook for itself (no prep launch in front of a mini-batch step):
         // row-major copy in LDS -> prep_body -> fragments / bias / constants in LDS, read below exactly as
@@ -176,6 +181,9 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
         half8 *frag_l = reinterpret_cast<half8 *>(wrow + (size_t)k * c);             // [NB][2][64]
         f32x4 *bias_l = reinterpret_cast<f32x4 *>(frag_l + NB * 2 * 64);             // [NB][64]
         AssignHdr *hdr_l = reinterpret_cast<AssignHdr *>(bias_l + NB * 64);
+        amb_q = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(hdr_l) + kHdrBytes);   // [kAmbQueue]
+        amb_n = reinterpret_cast<unsigned *>(amb_q + kAmbQueue);
+        if (threadIdx.x == 0) *amb_n = 0u;
         for (int e = threadIdx.x; e < k * c + k; e += 256) ls[e] = 0.0;
         // element e = tid + 256 u  <->  (node, channel), advanced without a division per element
         int node = (int)threadIdx.x / c, j = (int)threadIdx.x - node * c;
@@ -218,7 +226,10 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
 
     const int lane = threadIdx.x & 63;
     const int pix = lane & 15, q = lane >> 4;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // ACC: groups are dealt workgroup-major (wave 0 of every workgroup first), so a mini-batch of a few hundred
+    // groups spreads over all CUs -- and so do the rows its workgroups have to settle exactly
+    const int wv_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t wave = ACC ? (int64_t)wv_in_block * gridDim.x + blockIdx.x : (int64_t)blockIdx.x * 4 + wv_in_block;
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     const int64_t ngroups = (n + 63) / 64;
 
@@ -467,9 +478,16 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
         unsigned long long mask = __ballot(my_amb);
         if (mask) {
             if constexpr (ACC) {
-                while (mask) {
-                    const int src = __builtin_ctzll(mask);
-                    mask &= mask - 1;
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(amb_n, (unsigned)__popcll(mask));
+                base = __shfl(base, 0);
+                const unsigned pos = base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+                if (my_amb && pos < kAmbQueue) amb_q[pos] = row;
+                // queue full (a launch over many groups): the rows that did not fit are settled on the spot
+                unsigned long long late = __ballot(my_amb && pos >= kAmbQueue);
+                while (late) {
+                    const int src = __builtin_ctzll(late);
+                    late &= late - 1;
                     exact_row_accumulate<T>(x, row0 + src, c, ldx, wt, k, labels, ls, lane);
                 }
             } else {
@@ -481,6 +499,10 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
         }
     }
     if constexpr (ACC) {
+        __syncthreads();   // every wave is through its groups: the queue is complete
+        const unsigned queued = *amb_n < kAmbQueue ? *amb_n : kAmbQueue;   // rows past the end were settled at once
+        for (unsigned i = threadIdx.x >> 6; i < queued; i += 4)
+            exact_row_accumulate<T>(x, amb_q[i], c, ldx, wt, k, labels, ls, lane);
         __syncthreads();
         for (int e = threadIdx.x; e < k * c + k; e += 256) {
             const double v = ls[e];
