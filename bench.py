@@ -198,14 +198,22 @@ def main():
             tt = time.perf_counter()
             oracle_w = ob.som_online(xt, w0h, XDIM, YDIM, 1, (0.05, 0.01), rr, order)
             t_train = time.perf_counter() - tt
-            n_s = 1_000_000
-            xs = x_all[:n_s].cpu().numpy().astype(np.float64)
-            tt = time.perf_counter()
-            lab_cpu, _ = ob.map_data_to_nodes(oracle_w, xs, column_major_copy=True)
-            t_assign = time.perf_counter() - tt
-            tt = time.perf_counter()
-            ob.cluster_sums(xs, lab_cpu, K)
-            t_means = time.perf_counter() - tt
+            # the reference labels one FOV table per call (cluster_pixels): so does this leg, FOV by FOV, over
+            # 8 of the FOVs (~10 s of host work together with the training leg)
+            f_s = min(F, 8)
+            n_s = f_s * P
+            t_assign = t_means = 0.0
+            lab_parts = []
+            for f in range(f_s):
+                xs = x_all[f * P:(f + 1) * P].cpu().numpy().astype(np.float64)
+                tt = time.perf_counter()
+                lab_f, _ = ob.map_data_to_nodes(oracle_w, xs, column_major_copy=True)
+                t_assign += time.perf_counter() - tt
+                tt = time.perf_counter()
+                ob.cluster_sums(xs, lab_f, K)
+                t_means += time.perf_counter() - tt
+                lab_parts.append(lab_f)
+            lab_cpu = np.concatenate(lab_parts)
             cpu_s = t_train + (t_assign + t_means) * (n_all / n_s)
             # free full-size check: GPU labels for the same codebook on the same sample
             wd = torch.from_numpy(oracle_w).to(dev)
@@ -216,7 +224,7 @@ def main():
                 "host_cores": os.cpu_count(), "kind": "port",
                 "sample": f"oracle online FlowSOM training on the full {n_train}-row training subset "
                           f"({t_train:.2f} s) + reference-shaped BMU search ({t_assign:.2f} s) and per-cluster "
-                          f"sums ({t_means:.2f} s) on {n_s} of {n_all} pixels, scaled linearly; fp64, 1 thread",
+                          f"sums ({t_means:.2f} s) on {n_s} of {n_all} pixels (one FOV per call, as cluster_pixels does), scaled linearly; fp64, 1 thread",
                 "gpu_labels_equal_on_sample": labels_equal}
         if not args.no_online:
             if order is None:
