@@ -15,6 +15,7 @@
 
 #include "pxsom_assign.h"
 #include "pxsom_common.h"
+#include "pxsom_sums.h"
 #include "pxsom_wave.h"
 
 namespace {
@@ -1006,12 +1007,20 @@ __global__ __launch_bounds__(256) void cluster_sums_private_kernel(const T *__re
                     *w0 = a + v0;
                     *w1 = b + v1;
                 } else {
+                    // one row at a time.  The fences keep the predicated updates apart: to the compiler they are
+                    // mutually exclusive branches of one thread, which it may fold into a single update
 #pragma unroll
-                    for (int s = 0; s < RPI; s++)
+                    for (int s = 0; s < RPI; s++) {
                         if (slot == s) *w0 += v0;
+                        __builtin_amdgcn_wave_barrier();
+                        asm volatile("" ::: "memory");
+                    }
 #pragma unroll
-                    for (int s = 0; s < RPI; s++)
+                    for (int s = 0; s < RPI; s++) {
                         if (slot == s) *w1 += v1;
+                        __builtin_amdgcn_wave_barrier();
+                        asm volatile("" ::: "memory");
+                    }
                 }
             }
 #pragma unroll
@@ -1086,6 +1095,13 @@ int cluster_sums_typed(const T *x, int64_t n, int c, int64_t ldx, const int32_t 
         const int64_t waves = (int64_t)pxsom::device_cu_count() * per_cu * (nwv ? nwv : 1);
         const bool addressable = ((n + waves - 1) / waves + 1024) * ldx * (int64_t)sizeof(T) < (1ll << 31);
         if (nwv && addressable) {
+            // two channels per lane where the rows allow pair loads (pxsom_sums.hip): 2.5x fewer instructions per row
+            if constexpr (sizeof(T) <= 4) {
+                if (pxsom::launch_sums_pairs<T>(x, n, c, ldx, labels, k, sums, counts, COUNT_F64, st, nwv, per_cu)) {
+                    PXSOM_LAUNCH_CHECK("cluster_sums_pairs_kernel");
+                    return PXSOM_OK;
+                }
+            }
             switch (64 / c) {
                 case 1: return launch_sums_private<T, 1, COUNT_F64>(x, n, c, ldx, labels, k, sums, counts, st, nwv, per_cu);
                 case 2: return launch_sums_private<T, 2, COUNT_F64>(x, n, c, ldx, labels, k, sums, counts, st, nwv, per_cu);

@@ -225,10 +225,15 @@ def test_cluster_mask_kernel_against_numpy(gpu):
     (100_003, 33, 64, np.float32, "uniform"),    # 1 row per instruction
     (100_003, 64, 100, np.float16, "uniform"),   # 2 tables per CU
     (100_003, 22, 100, np.float64, "uniform"),
-    (32_768, 16, 8, np.float32, "skew"),
+    (32_768, 16, 8, np.float32, "skew"),          # channel pairs per lane: 8 rows per instruction
+    (100_003, 40, 100, np.float32, "runs"),       # ... 3 rows per instruction
+    (100_003, 32, 100, np.float32, "uniform"),    # ... 4
+    (150_001, 22, 100, np.float16, "runs"),       # ... 5, fp16 pairs
+    (100_003, 14, 30, np.float32, "skew"),        # ... 8 (capped), idle lanes
 ])
 def test_cluster_sums_wave_private_tables(gpu, oracle, n, c, k, dtype, mode):
-    """Shapes served by the wave-private-table kernel (13 <= c <= 64, n >= 32768).  The values are multiples
+    """Shapes served by the wave-private-table kernels (13 <= c <= 64, n >= 32768; fp32 / fp16 rows with an even
+    channel count take the channel-pair form of pxsom_sums.hip, the rest one channel per lane).  The values are multiples
     of 2^-8 below 4, so every partial sum is exact in binary64 and the order of the additions cannot show:
     bit-equal to the oracle."""
     rs = np.random.RandomState(n % 1000 + c)
