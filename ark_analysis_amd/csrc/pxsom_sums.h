@@ -7,8 +7,8 @@
 
 namespace pxsom {
 
-// sums[label - 1, :] += x[i, :], counts[label - 1] += 1 for float / _Float16 rows with an even channel count,
-// even leading dimension and an 8- / 4-byte aligned base (channel PAIRS are loaded).  counts_f64: the counts
+// sums[label - 1, :] += x[i, :], counts[label - 1] += 1 for rows with an even channel count, an even leading
+// dimension and a pair-aligned base (channel PAIRS are loaded: 4 / 8 / 16 bytes for fp16 / fp32 / fp64).  counts_f64: the counts
 // buffer holds binary64 (the batch rule's statistics) instead of int64.  nwv tables per workgroup.
 // Returns false without launching when the shape is outside this kernel.
 template <typename T>

@@ -48,6 +48,16 @@ struct PairBits<_Float16> {
     }
 };
 
+template <>
+struct PairBits<double> {
+    typedef unsigned type __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ type load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+    {
+        return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    }
+    static __device__ __forceinline__ d2 widen(type v) { return __builtin_bit_cast(d2, v); }
+};
+
 template <typename T, int RPI, bool COUNT_F64>
 __global__ __launch_bounds__(256) void cluster_sums_pairs_kernel(const T *__restrict__ x, int64_t n, int c,
                                                                  int64_t ldx, const int32_t *__restrict__ labels,
@@ -56,7 +66,7 @@ __global__ __launch_bounds__(256) void cluster_sums_pairs_kernel(const T *__rest
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     typedef typename PairBits<T>::type bits_t;
-    constexpr int U = 32;                   // groups per tile == loads in flight per lane
+    constexpr int U = sizeof(T) == 8 ? 16 : 32;   // groups per tile == loads in flight per lane
     constexpr int TR = RPI * U;             // rows per tile
     constexpr int RL = 64 / RPI * RPI;      // rows per label register (whole groups)
     constexpr int NL = (TR + RL - 1) / RL;  // label registers per tile
@@ -200,7 +210,7 @@ bool launch_pairs(const T *x, int64_t n, int c, int64_t ldx, const int32_t *labe
     const size_t tbytes = ((size_t)(k + 1) * c + 128) * 8;
     const size_t lds = tbytes * nwv + (size_t)k * 4;
     if (lds > 159 * 1024) return false;
-    constexpr int TR = RPI * 32;
+    constexpr int TR = RPI * (sizeof(T) == 8 ? 16 : 32);
     const int64_t max_waves = (int64_t)device_cu_count() * blocks_per_cu * nwv;
     int64_t rows_per_wave = (n + max_waves - 1) / max_waves;
     if (rows_per_wave < 4 * TR) rows_per_wave = 4 * TR;
@@ -247,5 +257,7 @@ template bool launch_sums_pairs<float>(const float *, int64_t, int, int64_t, con
                                        hipStream_t, int, int);
 template bool launch_sums_pairs<_Float16>(const _Float16 *, int64_t, int, int64_t, const int32_t *, int, double *, void *,
                                           bool, hipStream_t, int, int);
+template bool launch_sums_pairs<double>(const double *, int64_t, int, int64_t, const int32_t *, int, double *, void *, bool,
+                                        hipStream_t, int, int);
 
 }  // namespace pxsom

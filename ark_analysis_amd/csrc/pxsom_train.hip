@@ -1096,11 +1096,9 @@ int cluster_sums_typed(const T *x, int64_t n, int c, int64_t ldx, const int32_t 
         const bool addressable = ((n + waves - 1) / waves + 1024) * ldx * (int64_t)sizeof(T) < (1ll << 31);
         if (nwv && addressable) {
             // two channels per lane where the rows allow pair loads (pxsom_sums.hip): 2.5x fewer instructions per row
-            if constexpr (sizeof(T) <= 4) {
-                if (pxsom::launch_sums_pairs<T>(x, n, c, ldx, labels, k, sums, counts, COUNT_F64, st, nwv, per_cu)) {
-                    PXSOM_LAUNCH_CHECK("cluster_sums_pairs_kernel");
-                    return PXSOM_OK;
-                }
+            if (pxsom::launch_sums_pairs<T>(x, n, c, ldx, labels, k, sums, counts, COUNT_F64, st, nwv, per_cu)) {
+                PXSOM_LAUNCH_CHECK("cluster_sums_pairs_kernel");
+                return PXSOM_OK;
             }
             switch (64 / c) {
                 case 1: return launch_sums_private<T, 1, COUNT_F64>(x, n, c, ldx, labels, k, sums, counts, st, nwv, per_cu);
