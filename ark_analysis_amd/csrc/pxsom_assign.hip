@@ -28,7 +28,10 @@ using namespace pxsom_bmu;
 
 namespace {
 
-__global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict__ w, int k, int c,
+// NT threads in ONE workgroup: 256, or 1024 for codebooks of more than 128 nodes (every phase is a loop over
+// nodes or fragments: four times the threads, a quarter of the trips)
+template <int NT>
+__global__ __launch_bounds__(NT) void bmu_prep_kernel(const double *__restrict__ w, int k, int c,
                                                        AssignHdr *hdr, half8 *wfrag, f32x4 *bias,
                                                        int nb, int nch, int cpl, int idx_bits,
                                                        int node_bits, int stage, double *zero_ptr,
@@ -36,28 +39,28 @@ __global__ __launch_bounds__(256) void bmu_prep_kernel(const double *__restrict_
 {
     PXSOM_PHASE_ANY(0);
     // fused batch accumulation: the statistics buffer is cleared here instead of by a memset node
-    for (int e = threadIdx.x; e < zero_count; e += 256) zero_ptr[e] = 0.0;
+    for (int e = threadIdx.x; e < zero_count; e += NT) zero_ptr[e] = 0.0;
     extern __shared__ __attribute__((aligned(16))) char prep_smem[];
     const int tid = threadIdx.x;
     // small codebooks are staged in LDS with one coalesced sweep (8 loads in flight per thread); every
     // later read is an LDS read
     double *sw = reinterpret_cast<double *>(prep_smem);
     if (stage) {
-        for (int e0 = tid; e0 < k * c; e0 += 8 * 256) {
+        for (int e0 = tid; e0 < k * c; e0 += 8 * NT) {
             double v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = w[e0 + u * 256 < k * c ? e0 + u * 256 : 0];
+            for (int u = 0; u < 8; u++) v[u] = w[e0 + u * NT < k * c ? e0 + u * NT : 0];
 #pragma unroll
             for (int u = 0; u < 8; u++)
-                if (e0 + u * 256 < k * c) sw[e0 + u * 256] = v[u];
+                if (e0 + u * NT < k * c) sw[e0 + u * NT] = v[u];
         }
     }
     __syncthreads();
     PXSOM_PHASE_ANY(1);
     // two calls, not one with a selected pointer: each inlined copy then knows its address space (ds_read for
     // the staged codebook instead of flat loads)
-    if (stage) prep_body<256>(sw, k, c, hdr, wfrag, bias, nb, nch, cpl, idx_bits, node_bits, wt_out);
-    else prep_body<256>(w, k, c, hdr, wfrag, bias, nb, nch, cpl, idx_bits, node_bits, wt_out);
+    if (stage) prep_body<NT>(sw, k, c, hdr, wfrag, bias, nb, nch, cpl, idx_bits, node_bits, wt_out);
+    else prep_body<NT>(w, k, c, hdr, wfrag, bias, nb, nch, cpl, idx_bits, node_bits, wt_out);
 }
 
 
@@ -268,12 +271,17 @@ __global__ __launch_bounds__(256) void bmu_dist_kernel(const T *__restrict__ x, 
 
 // The prep kernel (one workgroup) stages the codebook in LDS whenever it fits beside its own tables: from
 // global memory its dependent reads cost the L2 latency each (55 us at K = 400, C = 40).
+// 1024 threads once the codebook has more than 128 nodes or 4096 entries
+static bool prep_wide(int k, int c) { return k > 128 || k * c > 4096; }
+
 static int prep_stage(size_t stage_bytes)
 {
     constexpr size_t kPrepStageMax = 132 * 1024;
     static bool raised = false;
     if (!raised) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bmu_prep_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bmu_prep_kernel<256>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPrepStageMax);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bmu_prep_kernel<1024>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPrepStageMax);
         raised = true;
     }
@@ -289,7 +297,8 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
                                  // prepares the codebook inside its own launch
         const size_t stage_bytes = (size_t)k * c * sizeof(double);
         const int stage = prep_stage(stage_bytes);
-        hipLaunchKernelGGL(bmu_prep_kernel, dim3(1), dim3(256), stage ? stage_bytes : 0, st, w, k, c,
+        hipLaunchKernelGGL(prep_wide(k, c) ? bmu_prep_kernel<1024> : bmu_prep_kernel<256>, dim3(1), dim3(prep_wide(k, c) ? 1024 : 256),
+                           stage ? stage_bytes : 0, st, w, k, c,
                            reinterpret_cast<AssignHdr *>(ws),
                            reinterpret_cast<half8 *>(ws + L.off_wfrag), reinterpret_cast<f32x4 *>(ws + L.off_bias),
                            L.nb, L.nch, L.cpl, L.idx_bits, L.node_bits, stage, (double *)nullptr, 0,
@@ -404,7 +413,8 @@ int pxsom_bmu::prepare_only(const double *w_dev, int c, int k, void *workspace_d
     char *ws = reinterpret_cast<char *>(workspace_dev);
     const size_t stage_bytes = (size_t)k * c * sizeof(double);
     const int stage = prep_stage(stage_bytes);
-    hipLaunchKernelGGL(bmu_prep_kernel, dim3(1), dim3(256), stage ? stage_bytes : 0, st, w_dev, k, c,
+    hipLaunchKernelGGL(prep_wide(k, c) ? bmu_prep_kernel<1024> : bmu_prep_kernel<256>, dim3(1), dim3(prep_wide(k, c) ? 1024 : 256),
+                       stage ? stage_bytes : 0, st, w_dev, k, c,
                        reinterpret_cast<AssignHdr *>(ws), reinterpret_cast<half8 *>(ws + L.off_wfrag),
                        reinterpret_cast<f32x4 *>(ws + L.off_bias), L.nb, L.nch, L.cpl, L.idx_bits, L.node_bits, stage,
                        zero_stats, zero_stats ? k * (c + 1) : 0,
