@@ -23,7 +23,7 @@ _STATUS = {0: "PXSOM_OK", -1: "PXSOM_ERR_INVALID_ARG", -2: "PXSOM_ERR_UNSUPPORTE
 # every symbol include/pxsom.h declares: (restype, argtypes)
 _vp, _i32, _i64, _f64, _sz = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double,
                               ctypes.c_size_t)
-ABI_VERSION = 3  # include/pxsom.h PXSOM_ABI_VERSION
+ABI_VERSION = 4  # include/pxsom.h PXSOM_ABI_VERSION
 
 SYMBOLS = {
     "pxsom_abi_version": (_i32, []),
@@ -53,6 +53,10 @@ SYMBOLS = {
     "pxsom_quantile_workspace_bytes": (_sz, [_i64, _i32]),
     "pxsom_quantile_nonzero": (_i32, [_vp, _i64, _i32, _i64, _f64, _i32, _vp, _vp, _sz, _vp]),
     "pxsom_batch_update": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _f64, _f64, _vp]),
+    "pxsom_batch_train_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
+    "pxsom_batch_train_steps": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
+                                       _f64, _f64, _f64, _f64, _vp, _sz, _i32, _vp]),
+    "pxsom_batch_train_finish": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f64, _f64, _f64, _f64, _vp, _vp]),
 }
 
 _lib = None

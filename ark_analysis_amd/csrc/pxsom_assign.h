@@ -27,6 +27,17 @@ struct AssignHdr {
     int force_exact;      // codebook not representable by the filter: list every row
 };
 
+// the pending update a fused mini-batch step applies at its head, and its housekeeping (pxsom_batch_step.hip)
+struct StepArgs {
+    const double *w_in;        // [k, c] codebook the pending update applies to (W_{g-1}, or W_0 when has_update == 0)
+    double *w_out;             // [k, c] receives W_g (workgroup 0); may be NULL
+    const double *stats_prev;  // [k*c sums | k counts] of step g-1, all-reduced
+    double *stats_zero;        // buffer cleared for step g+1 (NULL: none)
+    int zero_count;
+    int has_update;
+    double thr, alpha;         // schedule of the pending update (step g-1)
+};
+
 struct Layout {
     int k, nb, nch, cpl, nsteps, idx_bits, node_bits;
     size_t off_wfrag, off_bias, off_wt, off_list, total;
@@ -82,6 +93,12 @@ void launch_filter_fast_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws,
                             double *stats, const double *w, hipStream_t st);
 template <typename T>
 bool filter_fast_path(const T *x, int64_t n, int c, int64_t ldx, const Layout &L);
+// fused mini-batch step (pxsom_batch_step.hip): which shapes it covers, and its launch
+template <typename T>
+bool step_fused_shape(const T *x, int64_t n, int c, int64_t ldx, int xdim, int ydim);
+template <typename T>
+int launch_batch_step(const T *x, int64_t n, int c, int64_t ldx, double *stats, const StepArgs &sa,
+                      int tiles_per_wave, hipStream_t st);
 
 // pxsom_assign with the batch rule's accumulation fused in (pxsom_assign.hip).  *fused = false: the shape
 // is outside the fused path, nothing was done, the caller runs assign + cluster sums separately.

@@ -1,0 +1,653 @@
+// pxsom_batch_step.hip -- the fused mini-batch step of the batch SOM rule (K6b), one launch per step.
+//
+// Batch rule (no pyFlowSOM analogue; oracle of record oracle/pxsom_oracle.c orc_som_batch; the reference call it
+// stands in for is PixieSOMCluster.train_som, /root/reference/src/ark/phenotyping/cluster_helpers.py:98-116):
+//     step g:  W_g = update(W_{g-1}, stats_{g-1});  b_i = BMU(x_i, W_g);  stats_g[b_i] += [x_i, 1]
+// A step is latency-bound (16 K rows x 88 B against ~2 us of HBM latency), so the kernel is built around the
+// length of its dependency chain, not around bandwidth:
+//   * every workgroup (512 threads) applies the pending update and prepares the codebook for itself -- no update
+//     launch, no prep launch, no second pass over a workspace.  Update: separable window sums in registers
+//     (orc_batch_update's order, bit for bit), new node values stay in the registers of the thread that formed
+//     them: thread <-> (node, lane group q) holds exactly the channels of one MFMA A-fragment element, so norms,
+//     the duplicate key, the fp16 hi/lo split and the fragment store need no further LDS round trip;
+//   * the rows of the step are requested before any of that (they do not depend on the codebook);
+//   * BMU search: fp16-split MFMA filter (the K7 scheme: v_mfma_f32_16x16x32_f16, nodes on the M axis, running
+//     top-2 with the node id in the low mantissa bits, rigorous tolerance) on 16-row tiles, TPW tiles per wave;
+//     rows it is sure of go straight into the workgroup's binary64 table in LDS (ds_add_f64); rows it is not sure
+//     of are queued IN LDS with their values and settled afterwards in the oracle's own arithmetic (binary64,
+//     j ascending, no contraction, sqrt, first strict minimum) by whichever wave is free;
+//   * one staggered flush of the table with device-scope atomics; the statistics buffer of the NEXT step is
+//     cleared here (three buffers rotate), W_g is written to the twin codebook buffer by workgroup 0.
+// Shapes: 10 x 10 grid, even c <= 32, rows 2-element aligned (the Pixie pixel SOM; BASELINE.json configs 2, 3).
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+
+#include "pxsom_assign_filter_fast.h"
+
+namespace pxsom_bmu {
+namespace {
+
+constexpr int kXD = 10, kYD = 10, kK = 100, kNB = 7;
+constexpr int kStepThreads = 512, kStepWaves = 8;
+constexpr int kQueueRows = 96;       // listed rows a workgroup keeps in LDS; further ones are settled on the spot
+
+struct StepHdr {
+    float scale, wn_max, tol_rel, tol_abs, x_limit;
+    int force_exact;
+    int bad;          // NaN / Inf met in the codebook
+    unsigned q_n;     // rows in the queue
+};
+
+// LDS carve-up (bytes from the start of the dynamic segment)
+struct StepLds {
+    size_t ls, wt, tl, norm2, key, red, ovf, frag, bias, biasv, hdr, total;
+};
+__host__ __device__ inline StepLds step_lds(int c)
+{
+    StepLds L;
+    size_t o = 0;
+    L.ls = o;    o += ((size_t)kK * c + kK) * 8;          // table [K*c sums | K counts]
+    L.wt = o;    o += (size_t)c * kK * 8;                 // codebook, transposed [c][K]
+    L.tl = o;    o += (size_t)kK * (c + 1) * 8;           // window-sum scratch; later the queue of listed rows
+    L.norm2 = o; o += (size_t)kK * 8;
+    L.key = o;   o += (size_t)kK * 8;
+    L.red = o;   o += 2 * kStepWaves * 8;
+    L.ovf = o;   o += (size_t)kStepWaves * 32 * 8;        // one row per wave (queue overflow)
+    L.frag = o;  o += (size_t)kNB * 2 * 64 * 16;          // [NB][hi, lo][64] half8
+    L.bias = o;  o += (size_t)kNB * 64 * 16;              // [NB][64] f32x4
+    L.biasv = o; o += (size_t)kK * 4;                     // per-node bias value
+    L.hdr = o;   o += 64;
+    L.total = o;
+    return L;
+}
+
+#pragma clang fp contract(off)
+// One listed row settled by a whole wave: lanes <-> nodes lane and lane + 64, the row's values read from LDS
+// (one address for the wave: a broadcast), distances exactly as the oracle forms them.
+__device__ __forceinline__ void exact_row_from_lds(const double *xr, int c, const double *wt, double *ls, int lane)
+{
+    const int n0 = lane, n1 = lane + 64;
+    const int c1 = n1 < kK ? n1 : kK - 1;
+    double d0 = 0.0, d1 = 0.0;
+    int j = 0;
+    for (; j + 4 <= c; j += 4) {   // the LDS reads of a trip are issued together; sums stay in j order
+        double xa[4], wa[4], wb[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            xa[u] = xr[j + u];
+            wa[u] = wt[(size_t)(j + u) * kK + n0];
+            wb[u] = wt[(size_t)(j + u) * kK + c1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const double t0 = xa[u] - wa[u], t1 = xa[u] - wb[u];
+            d0 += t0 * t0;
+            d1 += t1 * t1;
+        }
+    }
+    for (; j < c; j++) {
+        const double xj = xr[j];
+        const double t0 = xj - wt[(size_t)j * kK + n0], t1 = xj - wt[(size_t)j * kK + c1];
+        d0 += t0 * t0;
+        d1 += t1 * t1;
+    }
+    double best = DBL_MAX;
+    int bestk = 0x7fffffff;
+    const double s0 = sqrt(d0), s1 = sqrt(d1);
+    if (s0 < best) {
+        best = s0;
+        bestk = n0;
+    }
+    if (n1 < kK && s1 < best) {
+        best = s1;
+        bestk = n1;
+    }
+    const double smin = pxsom::wave_min_f64(best);
+    const int win = (int)pxsom::wave_min_u32(best == smin ? (unsigned)bestk : 0xffffffffu);
+    if (win != 0x7fffffff) {   // 0x7fffffff: no finite distance (NaN row): label 0, not accumulated
+        if (lane < c)
+            __hip_atomic_fetch_add(ls + (size_t)win * c + lane, xr[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0)
+            __hip_atomic_fetch_add(ls + (size_t)kK * c + win, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+#pragma clang fp contract(fast)
+
+template <typename T, int CPL, int TPW>
+__global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__restrict__ x, int64_t n, int c, int64_t ldx,
+                                                                  double *__restrict__ stats, StepArgs sa)
+{
+    extern __shared__ __attribute__((aligned(16))) char step_smem[];
+    const StepLds L = step_lds(c);
+    double *ls = reinterpret_cast<double *>(step_smem + L.ls);
+    double *wt = reinterpret_cast<double *>(step_smem + L.wt);
+    double *tl = reinterpret_cast<double *>(step_smem + L.tl);
+    double *norm2 = reinterpret_cast<double *>(step_smem + L.norm2);
+    unsigned long long *key = reinterpret_cast<unsigned long long *>(step_smem + L.key);
+    double *red = reinterpret_cast<double *>(step_smem + L.red);
+    double *ovf = reinterpret_cast<double *>(step_smem + L.ovf);
+    half8 *frag_l = reinterpret_cast<half8 *>(step_smem + L.frag);
+    f32x4 *bias_l = reinterpret_cast<f32x4 *>(step_smem + L.bias);
+    float *biasv = reinterpret_cast<float *>(step_smem + L.biasv);
+    StepHdr *hdr = reinterpret_cast<StepHdr *>(step_smem + L.hdr);
+
+    constexpr int NP = CPL / 2;
+    typedef typename Pair<T>::type P2;
+    PXSOM_PHASE(8);
+#ifdef PXSOM_PHASE_TIMING
+    const long long t_start = clock64();
+#endif
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pix = lane & 15, q = lane >> 4;
+    constexpr int kRowsPerWave = 16 * TPW, kRowsPerWg = kStepWaves * kRowsPerWave;
+
+    // ---- P0: everything that does not depend on the codebook is requested first --------------------------
+    // rows of this wave's tiles (rows past the end re-read the last row and are ignored afterwards)
+    P2 raw[TPW][NP];
+    auto load_rows = [&](int64_t blk) {
+#pragma unroll
+        for (int t = 0; t < TPW; t++) {
+            int64_t row = blk * kRowsPerWg + (int64_t)wv * kRowsPerWave + t * 16 + pix;
+            if (row > n - 1) row = n - 1;
+            const T *rp = x + row * ldx;
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+                int ch = q * CPL + 2 * p;
+                if (ch > c - 2) ch = c - 2;   // slots past c re-read the last valid pair: their codebook slots are zero
+                if constexpr (sizeof(T) == 2) {
+                    const half2_t h = *reinterpret_cast<const half2_t *>(rp + ch);
+                    raw[t][p].x = h[0];
+                    raw[t][p].y = h[1];
+                } else {
+                    raw[t][p] = *reinterpret_cast<const P2 *>(rp + ch);
+                }
+            }
+        }
+    };
+    const int64_t nblocks = (n + kRowsPerWg - 1) / kRowsPerWg;
+    int64_t blk = blockIdx.x;
+
+    // thread <-> (node, lane group nq): the channels nq*CPL .. nq*CPL + CPL - 1 of one node
+    const int node = tid >> 2, nq = tid & 3;
+    const bool has_node = node < kK;
+    double wv_[CPL];   // this thread's node values: old, then new
+    const int NC = c + 1;
+    // Order of the requests matters: vmcnt retires loads in issue order, so what is needed first is asked for
+    // first -- the statistics (pass 1), then the old node values (P3), the step's rows (HBM, slowest) last.
+    if (sa.has_update) {
+        // pass 1 of the separable window sums: thread <-> (grid row gx, column cc); column c carries the counts
+        double S[kYD];
+        const bool p1 = tid < kXD * NC;
+        const int gx = p1 ? tid / NC : 0, cc = p1 ? tid - gx * NC : 0;
+#pragma unroll
+        for (int y = 0; y < kYD; y++)   // branch-free: idle threads re-read a valid word
+            S[y] = sa.stats_prev[cc < c ? (size_t)(gx * kYD + y) * c + cc : (size_t)kK * c + gx * kYD + y];
+#pragma unroll
+        for (int i = 0; i < CPL; i++) {
+            const int ch = nq * CPL + i;
+            wv_[i] = sa.w_in[(has_node && ch < c) ? (size_t)node * c + ch : 0];
+        }
+        if (blk < nblocks) load_rows(blk);
+        PXSOM_PHASE(9);
+        // (while those are in flight) clear the table and this workgroup's slice of the next buffer
+        for (int e = tid; e < kK * c + kK; e += kStepThreads) ls[e] = 0.0;
+        if (tid == 0) {
+            hdr->q_n = 0u;
+            hdr->bad = 0;
+        }
+        if (sa.stats_zero) {
+            const int per = (sa.zero_count + (int)gridDim.x - 1) / (int)gridDim.x;
+            const int z1 = min(((int)blockIdx.x + 1) * per, sa.zero_count);
+            for (int e = (int)blockIdx.x * per + tid; e < z1; e += kStepThreads) sa.stats_zero[e] = 0.0;
+        }
+        const double thr = sa.thr;
+        const int r = thr < 0.0 ? -1 : (thr > 1.0e6 ? 1000000 : (int)floor(thr));
+        double md[kXD > kYD ? kXD : kYD];
+#pragma unroll
+        for (int d = 0; d < (kXD > kYD ? kXD : kYD); d++) md[d] = d <= r ? 1.0 : 0.0;
+        if (p1) {
+#pragma unroll
+            for (int yp = 0; yp < kYD; yp++) {
+                double t = 0.0;
+#pragma unroll
+                for (int y = 0; y < kYD; y++) t = __builtin_fma(md[y > yp ? y - yp : yp - y], S[y], t);
+                tl[(size_t)(yp * kXD + gx) * NC + cc] = t;
+            }
+        }
+        PXSOM_PHASE(10);
+        __syncthreads();
+        // pass 2: thread <-> (y', cc), in place
+        if (tid < kYD * NC) {
+            const int yp = tid / NC, c2 = tid - yp * NC;
+            double *col = tl + (size_t)(yp * kXD) * NC + c2;
+            double Tx[kXD];
+#pragma unroll
+            for (int gx2 = 0; gx2 < kXD; gx2++) Tx[gx2] = col[(size_t)gx2 * NC];
+#pragma unroll
+            for (int xp = 0; xp < kXD; xp++) {
+                double t = 0.0;
+#pragma unroll
+                for (int gx2 = 0; gx2 < kXD; gx2++) t = __builtin_fma(md[gx2 > xp ? gx2 - xp : xp - gx2], Tx[gx2], t);
+                col[(size_t)xp * NC] = t;
+            }
+        }
+        PXSOM_PHASE(11);
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int i = 0; i < CPL; i++) {
+            const int ch = nq * CPL + i;
+            wv_[i] = sa.w_in[(has_node && ch < c) ? (size_t)node * c + ch : 0];
+        }
+        if (blk < nblocks) load_rows(blk);
+        PXSOM_PHASE(9);
+        for (int e = tid; e < kK * c + kK; e += kStepThreads) ls[e] = 0.0;
+        if (tid == 0) {
+            hdr->q_n = 0u;
+            hdr->bad = 0;
+        }
+        if (sa.stats_zero) {
+            const int per = (sa.zero_count + (int)gridDim.x - 1) / (int)gridDim.x;
+            const int z1 = min(((int)blockIdx.x + 1) * per, sa.zero_count);
+            for (int e = (int)blockIdx.x * per + tid; e < z1; e += kStepThreads) sa.stats_zero[e] = 0.0;
+        }
+        __syncthreads();
+    }
+
+    // ---- P3: new node values in registers; norms, duplicate key, maxima -----------------------------------
+    double nrm = 0.0, mymax = 0.0;
+    unsigned long long kkey = 0;
+    {
+        bool bad = false;
+        if (has_node) {
+#pragma clang fp contract(off)
+            double den = 0.0, gain = -1.0;
+            const int xp = node / kYD, yp = node - xp * kYD;
+            const double *nrow = tl + (size_t)(yp * kXD + xp) * NC;
+            if (sa.has_update) {
+                den = nrow[c];
+                // gain == 1 exactly (wide windows): the node is the window mean itself (orc_batch_update)
+                if (den > 0.0) gain = 1.0 - pow(1.0 - sa.alpha, den);
+            }
+#pragma unroll
+            for (int i = 0; i < CPL; i++) {
+                const int ch = nq * CPL + i;
+                if (ch < c) {
+                    double v = wv_[i];
+                    if (gain >= 0.0) {   // (idle channel slots hold whatever word 0 held: never used)
+                        const double num = nrow[ch];
+                        v = gain == 1.0 ? num / den : v + gain * (num / den - v);
+                    }
+                    wv_[i] = v;
+                    wt[(size_t)ch * kK + node] = v;
+                    if (blockIdx.x == 0 && sa.w_out && (sa.has_update || sa.w_out != sa.w_in)) sa.w_out[(size_t)node * c + ch] = v;
+                    bad |= !(fabs(v) <= DBL_MAX);
+                    nrm += v * v;
+                    mymax = fmax(mymax, fabs(v));
+                    const unsigned long long hb = (unsigned long long)__double_as_longlong(v) * 0x9E3779B97F4A7C15ull +
+                                                  (unsigned long long)(ch + 1) * 0xC2B2AE3D27D4EB4Full;
+                    kkey ^= hb ^ (hb >> 29);
+                }
+            }
+        }
+        // the 4 lanes of a node are adjacent: butterfly over the quad (same order for every node, so bit-identical
+        // rows get bit-identical norms and keys)
+        nrm += __shfl_xor(nrm, 1);
+        kkey ^= __shfl_xor(kkey, 1);
+        nrm += __shfl_xor(nrm, 2);
+        kkey ^= __shfl_xor(kkey, 2);
+        if (has_node && nq == 0) {
+            norm2[node] = nrm;
+            key[node] = kkey;
+        }
+        if (bad) hdr->bad = 1;   // NaN / Inf in the codebook: every row takes the exact path
+        const double wmax = -pxsom::wave_min_f64(-mymax);
+        const double nmax = -pxsom::wave_min_f64(-((has_node && nrm == nrm) ? nrm : 0.0));
+        if (lane == 0) {
+            red[wv] = wmax;
+            red[kStepWaves + wv] = nmax;
+        }
+    }
+    PXSOM_PHASE(12);
+    __syncthreads();
+
+    // ---- P4: scale, fragments, duplicate table ---------------------------------------------------------------
+    double scale;
+    {
+        double maxabs = red[0], wn2max = red[kStepWaves];
+#pragma unroll
+        for (int i = 1; i < kStepWaves; i++) {
+            maxabs = fmax(maxabs, red[i]);
+            wn2max = fmax(wn2max, red[kStepWaves + i]);
+        }
+        // scale = 2^e with maxabs*scale in [128, 256) (pxsom_prep.h)
+        int e = 0;
+        if (maxabs > 0.0 && maxabs <= DBL_MAX) {
+            int ex;
+            frexp(maxabs, &ex);
+            e = 8 - ex;
+            if (e > 100) e = 100;
+            if (e < -100) e = -100;
+        }
+        scale = ldexp(1.0, e);
+        if (tid == 0) {
+            const bool badw = hdr->bad != 0 || !(wn2max * scale * scale <= 1.0e30);
+            hdr->scale = (float)scale;
+            hdr->wn_max = badw ? 0.f : (float)(sqrt(wn2max) * scale * (1.0 + 1e-6));
+            hdr->force_exact = badw ? 1 : 0;
+            // coefficient of the rigorous |filter - exact| bound (DESIGN.md "K7 error bound"; 7 index bits)
+            const double coef = ldexp(1.0, -(23 - 7)) + (3.0 * c + 2.0) * ldexp(1.0, -24) + ldexp(1.0, -19) + ldexp(1.0, -23);
+            hdr->tol_rel = (float)(2.5 * coef);
+            hdr->tol_abs = (float)(2.5 * ldexp(1.0, -24) * sqrt((double)c));
+            hdr->x_limit = 60000.0f;
+        }
+        if (has_node) {
+            // A-fragment element of (node, nq): lane (nq << 4 | m) of node block b; the last block's (q, r) grid is
+            // transposed (node_of_row): node 96 + t sits in row m = 4 t
+            const int b = node < 96 ? node >> 4 : 6, m = node < 96 ? node & 15 : 4 * (node - 96);
+            half8 fhi, flo;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                float W = 0.f;
+                if (i < CPL && nq * CPL + i < c) W = (float)(wv_[i < CPL ? i : 0] * scale);
+                const _Float16 hi = (_Float16)W;
+                fhi[i] = hi;
+                flo[i] = (_Float16)(W - (float)hi);
+            }
+            const int lf = (nq << 4) | m;
+            frag_l[(b * 2 + 0) * 64 + lf] = fhi;
+            frag_l[(b * 2 + 1) * 64 + lf] = flo;
+        } else if (tid < 4 * kK + 48) {
+            // the 12 rows of the last block that hold no node
+            const int i = (tid - 4 * kK) >> 2, m = (i / 3) * 4 + (i % 3) + 1;
+            const half8 z = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
+            frag_l[(6 * 2 + 0) * 64 + ((nq << 4) | m)] = z;
+            frag_l[(6 * 2 + 1) * 64 + ((nq << 4) | m)] = z;
+        }
+    }
+    PXSOM_PHASE(13);
+    __syncthreads();
+
+    // ---- P5: exact duplicates of an EARLIER node are masked out of the filter (pxsom_prep.h).  The node's 4 lanes
+    // scan the earlier nodes' keys together (lane nq takes prev = nq, nq + 4, ...; no early exit, so the LDS reads
+    // pipeline), the smallest match is then compared channel by channel.
+    if (has_node) {
+        auto same_as = [&](int prev) {   // all channels equal, decided by the node's 4 lanes together
+            bool eq = true;
+#pragma unroll
+            for (int i = 0; i < CPL; i++) {
+                const int ch = nq * CPL + i;
+                if (ch < c) eq &= wt[(size_t)ch * kK + prev] == wv_[i];
+            }
+            int e = eq ? 1 : 0;
+            e &= __shfl_xor(e, 1);
+            e &= __shfl_xor(e, 2);
+            return e != 0;
+        };
+        int hit = 0x7fffffff;
+#pragma unroll 5
+        for (int prev = nq; prev < kK; prev += 4) hit = min(hit, (prev < node && key[prev] == kkey) ? prev : 0x7fffffff);
+        hit = min(hit, __shfl_xor(hit, 1));
+        hit = min(hit, __shfl_xor(hit, 2));
+        bool dup = false;
+        if (hit != 0x7fffffff) {
+            dup = same_as(hit);
+            for (int prev = hit + 1; prev < node && !dup; prev++)   // a key collision: keep looking
+                if (key[prev] == kkey) dup = same_as(prev);
+        }
+        if (nq == 0) biasv[node] = dup ? kNegBig : (float)(-0.5 * nrm * scale * scale);
+    }
+    PXSOM_PHASE(14);
+    __syncthreads();
+    // ---- P6: bias fragments ---------------------------------------------------------------------------------
+    if (tid < kNB * 64) {
+        const int lf = tid & 63, b = tid >> 6, qf = lf >> 4;
+        f32x4 bv;
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const int nd = node_of_row(b, qf * 4 + rr, kNB);
+            bv[rr] = nd < kK ? biasv[nd] : kNegBig;
+        }
+        bias_l[tid] = bv;
+    }
+    PXSOM_PHASE(15);
+    __syncthreads();
+
+    // ---- P7: BMU search of this workgroup's rows -------------------------------------------------------------
+    const float fscale = hdr->scale, wn_max = hdr->wn_max, tol_rel = hdr->tol_rel, tol_abs = hdr->tol_abs,
+                x_limit = hdr->x_limit;
+    const bool force_exact = hdr->force_exact != 0;
+    double *qrows = tl;   // the window-sum scratch is free now: [kQueueRows][c]
+    constexpr unsigned idx_mask = 127u;
+    for (; blk < nblocks; blk += gridDim.x) {
+        half8 bh[TPW], bl[TPW];
+        float ss[TPW];
+#pragma unroll
+        for (int t = 0; t < TPW; t++) {
+            float acc2 = 0.f;
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                half2_t h2 = {(_Float16)0, (_Float16)0}, l2 = {(_Float16)0, (_Float16)0};
+                if (p < NP) {
+                    const float x0 = (float)raw[t][p < NP ? p : 0].x, x1 = (float)raw[t][p < NP ? p : 0].y;
+                    h2[0] = (_Float16)(x0 * fscale);
+                    h2[1] = (_Float16)(x1 * fscale);
+                    l2[0] = (_Float16)fmaf(x0, fscale, -(float)h2[0]);
+                    l2[1] = (_Float16)fmaf(x1, fscale, -(float)h2[1]);
+                    acc2 = __builtin_amdgcn_fdot2(h2, h2, acc2, false);
+                }
+                bh[t][2 * p] = h2[0];
+                bh[t][2 * p + 1] = h2[1];
+                bl[t][2 * p] = l2[0];
+                bl[t][2 * p + 1] = l2[1];
+            }
+            ss[t] = acc2;
+        }
+        float m1[TPW], m2[TPW];
+#pragma unroll
+        for (int t = 0; t < TPW; t++) m1[t] = m2[t] = kNegBig;
+#pragma unroll
+        for (int b = 0; b < kNB; b++) {
+            const half8 wa0 = frag_l[(b * 2 + 0) * 64 + lane], wa1 = frag_l[(b * 2 + 1) * 64 + lane];
+            const f32x4 bb = bias_l[b * 64 + lane];
+            f32x4 acc[TPW];
+            // Wh*Xh + Wh*Xl + Wl*Xh, the tiles' chains interleaved
+#pragma unroll
+            for (int t = 0; t < TPW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa0, bh[t], bb, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < TPW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa0, bl[t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < TPW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa1, bh[t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < TPW; t++) {
+                if (b < kNB - 1) {
+                    top2_pair(m1[t], m2[t], pack_idx(acc[t][0], (unsigned)(b * 4 + 0), idx_mask),
+                              pack_idx(acc[t][1], (unsigned)(b * 4 + 1), idx_mask));
+                    top2_pair(m1[t], m2[t], pack_idx(acc[t][2], (unsigned)(b * 4 + 2), idx_mask),
+                              pack_idx(acc[t][3], (unsigned)(b * 4 + 3), idx_mask));
+                } else {   // last block: only accumulator register 0 holds real nodes (K = 100)
+                    const float p0 = pack_idx(acc[t][0], (unsigned)(b * 4 + 0), idx_mask);
+                    m2[t] = __builtin_amdgcn_fmed3f(m1[t], m2[t], p0);
+                    m1[t] = fmaxf(m1[t], p0);
+                }
+            }
+        }
+        // the next block's rows (usually none: one block per workgroup) -- the current values are kept
+        P2 cur[TPW][NP];
+#pragma unroll
+        for (int t = 0; t < TPW; t++)
+#pragma unroll
+            for (int p = 0; p < NP; p++) cur[t][p] = raw[t][p];
+        if (blk + gridDim.x < nblocks) load_rows(blk + gridDim.x);
+#pragma unroll
+        for (int t = 0; t < TPW; t++) {
+            // merge of the 4 lane groups that share a pixel: afterwards all four hold the pixel's top-2
+            float a1 = __uint_as_float(__float_as_uint(m1[t]) | ((unsigned)q << 5)), a2 = m2[t], s2 = ss[t];
+            {
+                const F2 e1 = xchg16(a1), e2 = xchg16(a2), es = xchg16(s2);
+                a1 = fmaxf(e1.a, e1.b);
+                a2 = fmaxf(fmaxf(fminf(e1.a, e1.b), e2.a), e2.b);
+                s2 = es.a + es.b;
+            }
+            {
+                const F2 e1 = xchg32(a1), e2 = xchg32(a2), es = xchg32(s2);
+                a1 = fmaxf(e1.a, e1.b);
+                a2 = fmaxf(fmaxf(fminf(e1.a, e1.b), e2.a), e2.b);
+                s2 = es.a + es.b;
+            }
+            // |Xh| <= |X| (1 + 2^-11): folded into the 1.001 factor with the sqrt's ulp
+            const float xn = __builtin_amdgcn_sqrtf(s2) * 1.001f;
+            const float tol = tol_rel * (xn * wn_max + 0.5f * wn_max * wn_max) + tol_abs * (xn + wn_max);
+            const unsigned nonfinite = (unsigned)((__float_as_uint(s2) & 0x7f800000u) == 0x7f800000u);
+            const int64_t row = blk * kRowsPerWg + (int64_t)wv * kRowsPerWave + t * 16 + pix;
+            const bool valid = row < n;
+            const bool amb = valid && ((!((a1 - a2) > tol)) || !(xn < x_limit) || nonfinite != 0u || force_exact);
+            // id (q, b, r) -> node: 16 b + 4 q + r, the last block's 4x4 (q, r) grid transposed (node_of_row)
+            const unsigned id = __float_as_uint(a1) & idx_mask;
+            const unsigned wq = id >> 5, wb = (id >> 2) & 7u, wr = id & 3u;
+            const unsigned real = wb == (unsigned)(kNB - 1) ? 16u * wb + 4u * wr + wq : 16u * wb + 4u * wq + wr;
+            if (valid && !amb) {
+                double *dst = ls + (size_t)real * c + q * CPL;
+#pragma unroll
+                for (int p = 0; p < NP; p++) {
+                    if (q * CPL + 2 * p <= c - 2) {   // clamped slots re-read the last pair: not theirs
+                        __hip_atomic_fetch_add(dst + 2 * p, (double)cur[t][p].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(dst + 2 * p + 1, (double)cur[t][p].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                if (q == 0)
+                    __hip_atomic_fetch_add(ls + (size_t)kK * c + real, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            // listed rows: values into the queue (all four lanes of a pixel agree on amb and on the slot)
+            const unsigned mask16 = (unsigned)(__ballot(amb) & 0xffffull);
+            if (mask16) {
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(&hdr->q_n, (unsigned)__popc(mask16));
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                const unsigned pos = base + (unsigned)__popc(mask16 & ((1u << pix) - 1u));
+                if (amb && pos < (unsigned)kQueueRows) {
+#pragma unroll
+                    for (int p = 0; p < NP; p++) {
+                        if (q * CPL + 2 * p <= c - 2) {
+                            qrows[(size_t)pos * c + q * CPL + 2 * p] = (double)cur[t][p].x;
+                            qrows[(size_t)pos * c + q * CPL + 2 * p + 1] = (double)cur[t][p].y;
+                        }
+                    }
+                }
+                // queue full: the rows that did not fit are settled on the spot, one at a time, through this wave's slot
+                unsigned late = (unsigned)(__ballot(amb && pos >= (unsigned)kQueueRows) & 0xffffull);
+                while (late) {
+                    const int src = __builtin_ctz(late);
+                    late &= late - 1u;
+                    double *slot = ovf + (size_t)wv * 32;
+                    if (pix == src) {
+#pragma unroll
+                        for (int p = 0; p < NP; p++) {
+                            if (q * CPL + 2 * p <= c - 2) {
+                                slot[q * CPL + 2 * p] = (double)cur[t][p].x;
+                                slot[q * CPL + 2 * p + 1] = (double)cur[t][p].y;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    exact_row_from_lds(slot, c, wt, ls, lane);
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        PXSOM_PHASE(16);
+        __syncthreads();   // every wave is through its tiles: the queue is complete
+        const unsigned queued = hdr->q_n < (unsigned)kQueueRows ? hdr->q_n : (unsigned)kQueueRows;
+        for (unsigned i = wv; i < queued; i += kStepWaves) exact_row_from_lds(qrows + (size_t)i * c, c, wt, ls, lane);
+        __syncthreads();
+        if (blk + gridDim.x < nblocks && tid == 0) hdr->q_n = 0u;
+        PXSOM_PHASE(17);
+#ifdef PXSOM_PHASE_TIMING
+        if (tid == 0 && blockIdx.x == 0) g_phase_ticks[21] = (long long)queued;
+#endif
+        if (blk + gridDim.x < nblocks) __syncthreads();
+    }
+    // ---- P9: flush.  Every workgroup starts at a different offset, so that the workgroups of a launch (which all
+    // get here at about the same time) do not queue up on the same few addresses.
+    {
+        const int total = kK * c + kK, span = (total + kStepThreads - 1) / kStepThreads * kStepThreads;
+        int e = tid + (int)((blockIdx.x * 7u) % (unsigned)(span / kStepThreads)) * kStepThreads;
+        for (int it = 0; it < span; it += kStepThreads) {
+            if (e >= span) e -= span;
+            if (e < total) {
+                const double v = ls[e];
+                if (v != 0.0) __hip_atomic_fetch_add(stats + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            e += kStepThreads;
+        }
+    }
+    PXSOM_PHASE(18);
+#ifdef PXSOM_PHASE_TIMING
+    __builtin_amdgcn_s_waitcnt(0);
+    PXSOM_PHASE(19);
+    if (tid == 0) {
+        atomicMin((unsigned long long *)&g_phase_ticks[28], (unsigned long long)t_start);
+        atomicMax((unsigned long long *)&g_phase_ticks[29], (unsigned long long)clock64());
+    }
+#endif
+}
+
+template <typename T, int CPL>
+int launch_step(const T *x, int64_t n, int c, int64_t ldx, double *stats, const StepArgs &sa, int tiles_per_wave,
+                hipStream_t st)
+{
+    const size_t lds = step_lds(c).total;
+    auto k1 = batch_step_kernel<T, CPL, 1>;
+    auto k2 = batch_step_kernel<T, CPL, 2>;
+    static size_t attr_lds = 0;   // per process = per device (one process per GPU)
+    if (attr_lds < lds) {
+        for (const void *fn : {reinterpret_cast<const void *>(k1), reinterpret_cast<const void *>(k2)}) {
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess)
+                return pxsom::fail(PXSOM_ERR_HIP, "batch step kernel: cannot raise the LDS limit to %zu bytes: %s", lds,
+                                   hipGetErrorString(e));
+        }
+        attr_lds = lds;
+    }
+    const int tpw = tiles_per_wave == 1 ? 1 : 2;
+    const int64_t rows_per_wg = (int64_t)kStepWaves * 16 * tpw;
+    int grid = (int)std::min<int64_t>((n + rows_per_wg - 1) / rows_per_wg, (int64_t)pxsom::device_cu_count());
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(tpw == 1 ? k1 : k2, dim3(grid), dim3(kStepThreads), lds, st, x, n, c, ldx, stats, sa);
+    PXSOM_LAUNCH_CHECK("batch_step_kernel");
+    return PXSOM_OK;
+}
+
+}  // namespace
+
+// Shapes the fused step kernel covers: the Pixie pixel SOM's -- 10 x 10 grid, even c <= 32, pair-aligned rows.
+template <typename T>
+bool step_fused_shape(const T *x, int64_t n, int c, int64_t ldx, int xdim, int ydim)
+{
+    return xdim == kXD && ydim == kYD && n >= 1 && c >= 2 && c <= 32 && c % 2 == 0 && ldx % 2 == 0 &&
+           reinterpret_cast<uintptr_t>(x) % (2 * sizeof(T)) == 0;
+}
+
+template <typename T>
+int launch_batch_step(const T *x, int64_t n, int c, int64_t ldx, double *stats, const StepArgs &sa,
+                      int tiles_per_wave, hipStream_t st)
+{
+    const int cpl = make_layout(n, c, kK).cpl;
+    if (cpl == 6) return launch_step<T, 6>(x, n, c, ldx, stats, sa, tiles_per_wave, st);
+    if (cpl == 8) return launch_step<T, 8>(x, n, c, ldx, stats, sa, tiles_per_wave, st);
+    if (cpl == 4) return launch_step<T, 4>(x, n, c, ldx, stats, sa, tiles_per_wave, st);
+    return launch_step<T, 2>(x, n, c, ldx, stats, sa, tiles_per_wave, st);
+}
+
+#define PXSOM_INSTANTIATE_STEP(T)                                                                                   \
+    template bool step_fused_shape<T>(const T *, int64_t, int, int64_t, int, int);                                  \
+    template int launch_batch_step<T>(const T *, int64_t, int, int64_t, double *, const StepArgs &, int, hipStream_t);
+PXSOM_INSTANTIATE_STEP(float)
+PXSOM_INSTANTIATE_STEP(double)
+PXSOM_INSTANTIATE_STEP(_Float16)
+
+}  // namespace pxsom_bmu

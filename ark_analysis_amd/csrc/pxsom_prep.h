@@ -21,10 +21,14 @@ __device__ long long g_phase_ticks[32];
     do {                                                        \
         if (threadIdx.x == 0 && blockIdx.x == 0) g_phase_ticks[i] = clock64(); \
     } while (0)
+#ifdef PXSOM_PHASE_BLOCK0_ONLY
+#define PXSOM_PHASE_ANY(i) PXSOM_PHASE(i)
+#else
 #define PXSOM_PHASE_ANY(i)                                  \
     do {                                                    \
         if (threadIdx.x == 0) g_phase_ticks[i] = clock64(); \
     } while (0)
+#endif
 #else
 #define PXSOM_PHASE(i) \
     do {               \

@@ -558,7 +558,7 @@ __global__ __launch_bounds__(CH * L > 40 ? 512 : 256) void som_online_split_kern
 
 // ------------------------------------------------------------------------------------------------
 // batch update: one workgroup per node k, thread <-> channel.  Only the Chebyshev window of k is
-// visited, in ascending node order b (the oracle's summation order: skipping the nodes it skips).
+// visited, in the oracle's separable summation order (orc_batch_update: per grid row, then over the rows).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void batch_update_kernel(double *w, int xdim, int ydim, int c,
                                                            const double *__restrict__ sums,
@@ -607,14 +607,18 @@ __global__ __launch_bounds__(256) void batch_update_kernel(double *w, int xdim, 
     const int j = tid;
     if (j >= c) return;
     const double wv = w[(size_t)k * c + j];
+    // separable order of orc_batch_update: T[bx] = sum over the window's by (ascending), num = sum of T[bx]
     double num = 0.0, den = 0.0;
     for (int bx = x0; bx <= x1; bx++) {
+        double tn = 0.0, td = 0.0;
 #pragma unroll 4
         for (int by = y0; by <= y1; by++) {
             const int b = bx * ydim + by - boff;
-            den += lc[b];
-            num += ls[(size_t)b * c + j];
+            td += lc[b];
+            tn += ls[(size_t)b * c + j];
         }
+        den += td;
+        num += tn;
     }
     if (den > 0.0) {
         const double gain = 1.0 - pow(1.0 - alpha, den);
@@ -1289,4 +1293,133 @@ PXSOM_EXPORT int pxsom_batch_update_prepare(double *w_dev, int xdim, int ydim, i
     if (!other) PXSOM_HIP_TRY(hipMemsetAsync(stats_dev, 0, stage_bytes, st));
     if (!needs_ws) return PXSOM_OK;
     return pxsom_bmu::prepare_only(w_dev, c, k, workspace_dev, workspace_bytes, nullptr, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batch training pass driven from ONE call (pxsom_batch_train_steps): the host loop over the mini-batch steps
+// lives here, not in Python.  Register-resident shapes on a 10 x 10 grid take one launch per step (the fused
+// step kernel, pxsom_assign_filter_fast.h ACC == 2: pending update + prep + filter + table + flush); other
+// shapes run update / prep / filter / exact / cluster sums per step as before.  Both keep the same state:
+//   wbuf[g % 2]        W_g, the codebook step g searches with          (two buffers alternate)
+//   ring[g % 3]        statistics of step g; ring[(g+1) % 3] is cleared by step g
+// so a multi-rank caller runs one step per call and all-reduces ring[g % 3] in between.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+inline void batch_schedule(int g, int total, double a0, double a1, double r0, double r1, double *thr, double *alpha)
+{
+    double t = r0 - (r0 - r1) * (double)g / (double)total;
+    if (t < 1.0) t = 0.5;
+    *thr = t;
+    *alpha = a0 - (a0 - a1) * (double)g / (double)total;
+}
+
+inline int64_t step_rows(int64_t n, int m, int t) { return n > t ? (n - t + m - 1) / m : 0; }
+
+template <typename T>
+int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, double *wbuf, double *ring, int xdim,
+                      int ydim, int m, int g_begin, int g_end, int total, double a0, double a1, double r0, double r1,
+                      char *ws, size_t ws_bytes, int flags, hipStream_t st)
+{
+    const int k = xdim * ydim;
+    const size_t nstats = (size_t)k * (c + 1), nw = (size_t)k * c;
+    const int64_t rows_max = step_rows(n, m, 0);
+    const size_t assign_ws = pxsom_assign_workspace_bytes(rows_max, c, k);
+    int32_t *labels = reinterpret_cast<int32_t *>(ws + pxsom::align_up(assign_ws, 256));
+    static int tpw = 0;   // 16-row tiles per wave of the fused step (tuning hook)
+    if (tpw == 0) {
+        const char *e = getenv("PXSOM_STEP_TPW");
+        tpw = e ? atoi(e) : 2;
+        if (tpw != 1) tpw = 2;
+    }
+    for (int g = g_begin; g < g_end; g++) {
+        const int t = g % m;
+        const int64_t rows = step_rows(n, m, t);
+        const T *xv = x + (size_t)t * ldx;
+        const int64_t ldv = ldx * m;
+        double *w_prev = wbuf + (size_t)((g + 1) % 2) * nw, *w_cur = wbuf + (size_t)(g % 2) * nw;
+        double *s_prev = ring + (size_t)((g + 2) % 3) * nstats, *s_cur = ring + (size_t)(g % 3) * nstats,
+               *s_next = ring + (size_t)((g + 1) % 3) * nstats;
+        double thr = 0.0, alpha = 0.0;
+        if (g > 0) batch_schedule(g - 1, total, a0, a1, r0, r1, &thr, &alpha);
+        const bool fused = !(flags & PXSOM_TRAIN_UNFUSED) && pxsom_bmu::step_fused_shape<T>(xv, rows, c, ldv, xdim, ydim);
+        if (fused) {
+            pxsom_bmu::StepArgs sa;
+            sa.w_in = g > 0 ? w_prev : w_cur;
+            sa.w_out = w_cur;
+            sa.stats_prev = s_prev;
+            sa.stats_zero = s_next;
+            sa.zero_count = (int)nstats;
+            sa.has_update = g > 0 ? 1 : 0;
+            sa.thr = thr;
+            sa.alpha = alpha;
+            int rc = pxsom_bmu::launch_batch_step<T>(xv, rows, c, ldv, s_cur, sa, tpw, st);
+            if (rc) return rc;
+            continue;
+        }
+        if (g > 0) {
+            PXSOM_HIP_TRY(hipMemcpyAsync(w_cur, w_prev, nw * sizeof(double), hipMemcpyDeviceToDevice, st));
+            int rc = pxsom_batch_update(w_cur, xdim, ydim, c, s_prev, s_prev + nw, thr, alpha, st);
+            if (rc) return rc;
+        }
+        PXSOM_HIP_TRY(hipMemsetAsync(s_next, 0, nstats * sizeof(double), st));
+        int rc = pxsom_batch_accumulate(xv, rows, c, ldv, dtype, w_cur, k, labels, s_cur, ws, assign_ws, 0, st);
+        if (rc) return rc;
+    }
+    return PXSOM_OK;
+}
+
+}  // namespace
+
+PXSOM_EXPORT size_t pxsom_batch_train_workspace_bytes(int64_t n, int batch_steps, int c, int k)
+{
+    if (n < 0 || batch_steps < 1 || c < 1 || c > PXSOM_MAX_CHANNELS || k < 1 || k > PXSOM_MAX_NODES) return 0;
+    const int64_t rows_max = step_rows(n, batch_steps, 0);
+    return pxsom::align_up(pxsom_assign_workspace_bytes(rows_max, c, k), 256) +
+           pxsom::align_up((size_t)(rows_max > 0 ? rows_max : 1) * sizeof(int32_t), 256);
+}
+
+PXSOM_EXPORT int pxsom_batch_train_steps(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, double *wbuf_dev,
+                                         double *stats_ring_dev, int xdim, int ydim, int batch_steps, int g_begin,
+                                         int g_end, int total_steps, double a0, double a1, double r0, double r1,
+                                         void *workspace_dev, size_t workspace_bytes, int flags, void *stream)
+{
+    int rc = check_matrix("pxsom_batch_train_steps", x_dev, n, c, ldx, dtype);
+    if (rc) return rc;
+    if (xdim < 1 || ydim < 1 || (int64_t)xdim * ydim > PXSOM_MAX_NODES)
+        return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "pxsom_batch_train_steps: grid %dx%d outside [1, %d] nodes", xdim, ydim,
+                           PXSOM_MAX_NODES);
+    if (batch_steps < 1 || total_steps < 1 || g_begin < 0 || g_end < g_begin || g_end > total_steps)
+        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_batch_train_steps: steps [%d, %d) of %d, %d per pass", g_begin,
+                           g_end, total_steps, batch_steps);
+    if (!wbuf_dev || !stats_ring_dev) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_batch_train_steps: null pointer");
+    const size_t need = pxsom_batch_train_workspace_bytes(n, batch_steps, c, xdim * ydim);
+    if (!workspace_dev || workspace_bytes < need)
+        return pxsom::fail(PXSOM_ERR_WORKSPACE, "pxsom_batch_train_steps: workspace %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (g_begin == 0)   // the first step's statistics buffer; every later one is cleared by the step before it
+        PXSOM_HIP_TRY(hipMemsetAsync(stats_ring_dev, 0, (size_t)xdim * ydim * (c + 1) * sizeof(double), st));
+    PXSOM_DISPATCH_DTYPE(dtype, x_dev, xp,
+                         train_steps_typed<T>(xp, n, c, ldx, dtype, wbuf_dev, stats_ring_dev, xdim, ydim, batch_steps,
+                                              g_begin, g_end, total_steps, a0, a1, r0, r1,
+                                              reinterpret_cast<char *>(workspace_dev), workspace_bytes, flags, st));
+}
+
+PXSOM_EXPORT int pxsom_batch_train_finish(const double *wbuf_dev, const double *stats_ring_dev, int xdim, int ydim, int c,
+                                          int steps_done, int total_steps, double a0, double a1, double r0, double r1,
+                                          double *w_out_dev, void *stream)
+{
+    if (xdim < 1 || ydim < 1 || (int64_t)xdim * ydim > PXSOM_MAX_NODES || c < 1 || c > PXSOM_MAX_CHANNELS)
+        return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "pxsom_batch_train_finish: shape %dx%d x %d", xdim, ydim, c);
+    if (!wbuf_dev || !stats_ring_dev || !w_out_dev || steps_done < 1 || steps_done > total_steps)
+        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_batch_train_finish: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int k = xdim * ydim, g = steps_done - 1;
+    const size_t nw = (size_t)k * c, nstats = (size_t)k * (c + 1);
+    const double *w_last = wbuf_dev + (size_t)(g % 2) * nw, *s_last = stats_ring_dev + (size_t)(g % 3) * nstats;
+    if (w_out_dev != w_last)
+        PXSOM_HIP_TRY(hipMemcpyAsync(w_out_dev, w_last, nw * sizeof(double), hipMemcpyDeviceToDevice, st));
+    double thr, alpha;
+    batch_schedule(g, total_steps, a0, a1, r0, r1, &thr, &alpha);
+    return pxsom_batch_update(w_out_dev, xdim, ydim, c, s_last, s_last + nw, thr, alpha, stream);
 }

@@ -9,10 +9,11 @@ mini-batch step (18.4 KB at K=100, C=22 -- latency-bound, xGMI bandwidth is irre
 
 One pass = ``batch_steps`` mini-batch steps; step g (of G = rlen*batch_steps) uses the local
 rows i with i % batch_steps == g % batch_steps:
-    labels = BMU(rows, W); S[b] += x_i, n[b] += 1     (pxsom_batch_accumulate: one launch)  -> all-reduce(S, n)
+    labels = BMU(rows, W); S[b] += x_i, n[b] += 1          -> all-reduce(S, n)
     thr = r0 - (r0-r1) g/G (0.5 once < 1);  alpha = a0 - (a0-a1) g/G
-    W_k += (1 - (1-alpha)^den_k) (num_k/den_k - W_k)                      (pxsom_batch_update_prepare:
-                                                  also clears S, n and prepares the next step's BMU search)
+    W_k += (1 - (1-alpha)^den_k) (num_k/den_k - W_k)
+pxsom_batch_train_steps runs the step loop inside the library: for the register-resident shapes a step is ONE
+launch (the update of step g-1 and the codebook preparation sit at the head of step g's BMU search).
 Oracle of record: oracle/pxsom_oracle.c (orc_som_batch).
 """
 from typing import Optional, Sequence, Tuple
@@ -35,37 +36,37 @@ def batch_schedule(g: int, total_steps: int, alpha_range: Sequence[float],
 
 
 class HipKernels:
-    """The product kernel set: libpxsom.so through the C ABI (no other implementation ships)."""
+    """The product kernel set: libpxsom.so through the C ABI (no other implementation ships).
 
-    def __init__(self):
+    Interface the trainer drives (tests/test_distributed_gloo.py holds an oracle-backed stand-in with the same
+    four methods, for the host logic on CPU):
+        begin(x, w, xdim, ydim, batch_steps)      state for this matrix; W_0 = w
+        steps(x, g0, g1, total, alpha, radius)    mini-batch steps [g0, g1), launched back to back
+        ring(g)                                   statistics of step g: what the ranks all-reduce after it
+        finish(steps_done, total, alpha, radius, w)   last pending update; w receives the result
+    """
+
+    def __init__(self, unfused: bool = False):
         from . import som_device
         self._sd = som_device
-        self._ws = None
-        self._prepared_for = None
+        self._state = None
+        self.unfused = bool(unfused)
 
-    def accumulate(self, x: torch.Tensor, w: torch.Tensor, labels: torch.Tensor, stats: torch.Tensor,
-                   chained: bool = False) -> None:
-        """zero(stats); labels = BMU(x, w); stats[label] += [x, 1]  (stats = [K*C sums | K counts] f64).
-        ``chained``: the caller guarantees that neither ``w`` nor ``stats`` changed since this object's last
-        ``update_prepare`` cleared ``stats`` (then no memset / prep launch precedes the filter)."""
+    def begin(self, x: torch.Tensor, w: torch.Tensor, xdim: int, ydim: int, batch_steps: int) -> None:
         n, c = x.shape
-        if self._ws is None or not self._ws.fits(n, c, w.shape[0]):
-            self._ws = self._sd.AssignWorkspace(n, c, w.shape[0], x.device)
-            self._prepared_for = None
-        # the previous step's update_prepare cleared exactly this buffer for exactly this codebook
-        prepared = chained and self._prepared_for == (w.data_ptr(), stats.data_ptr())
-        self._prepared_for = None
-        self._sd.batch_accumulate(x, w, labels, stats, self._ws, prepared=prepared)
+        st = self._state
+        if st is None or not st.fits(n, c, xdim, ydim, batch_steps) or st.wbuf.device != x.device:
+            st = self._state = self._sd.BatchTrainState(n, c, xdim, ydim, batch_steps, x.device)
+        st.wbuf[0].copy_(w)
 
-    def batch_update(self, w, xdim, ydim, sums, counts, thr, alpha):
-        return self._sd.batch_update(w, xdim, ydim, sums, counts, thr, alpha)
+    def steps(self, x, g0: int, g1: int, total: int, alpha_range, radius_range) -> None:
+        self._sd.batch_train_steps(x, self._state, g0, g1, total, alpha_range, radius_range, unfused=self.unfused)
 
-    def update_prepare(self, w, xdim, ydim, stats, thr, alpha, stats_next=None) -> None:
-        """Codebook update from ``stats``; the same launch clears ``stats_next`` (the buffer of the next
-        accumulate) and, where the shape needs one, a prep launch readies the workspace."""
-        self._sd.batch_update_prepare(w, xdim, ydim, stats, thr, alpha, self._ws, stats_next=stats_next)
-        cleared = stats_next if stats_next is not None else stats
-        self._prepared_for = (w.data_ptr(), cleared.data_ptr())
+    def ring(self, g: int) -> torch.Tensor:
+        return self._state.ring[g % 3]
+
+    def finish(self, steps_done: int, total: int, alpha_range, radius_range, w: torch.Tensor) -> None:
+        self._sd.batch_train_finish(self._state, steps_done, total, alpha_range, radius_range, w)
 
 
 def _world(group) -> int:
@@ -73,7 +74,9 @@ def _world(group) -> int:
 
 
 class BatchSOMTrainer:
-    """Holds the per-rank buffers of the batch rule so repeated passes allocate nothing."""
+    """Batch-rule SOM training on this rank's rows; collective when world_size > 1.  One process: the whole
+    run is ONE library call (the step loop lives in libpxsom); several ranks: one call per step with the
+    packed statistics all-reduced in between."""
 
     def __init__(self, xdim: int, ydim: int, channels: int, device, batch_steps: int = 64,
                  alpha_range: Sequence[float] = (0.05, 0.01),
@@ -88,50 +91,24 @@ class BatchSOMTrainer:
             default_radius_range(xdim, ydim)
         self.group = group
         self.kernels = kernels if kernels is not None else HipKernels()
-        # statistics: [K*C sums | K counts], all float64 (counts are exact integers): one all-reduce, no
-        # conversions.  Two buffers alternate between steps, so the update launch of step g can clear the
-        # buffer step g+1 accumulates into while other workgroups still read step g's.
-        self._stats_pair = [torch.zeros(self.k * self.c + self.k, dtype=torch.float64, device=device)
-                            for _ in range(2)]
-        self.stats = self._stats_pair[0]
-        self.label_buf = None
-
-    @property
-    def sums(self) -> torch.Tensor:
-        return self.stats[: self.k * self.c].view(self.k, self.c)
-
-    @property
-    def counts(self) -> torch.Tensor:
-        return self.stats[self.k * self.c:]
-
-    def step(self, x_local: torch.Tensor, w: torch.Tensor, g: int, total_steps: int,
-             chained: bool = False) -> None:
-        """One mini-batch step g on this rank's shard; collective when world_size > 1.
-        ``chained``: this call directly follows step g-1 of the same ``train`` (nothing touched ``w``
-        in between), so the BMU search may reuse what the previous update prepared."""
-        m = self.batch_steps
-        view = x_local[(g % m)::m]
-        nrows = view.shape[0]
-        if self.label_buf is None or self.label_buf.numel() < nrows:
-            self.label_buf = torch.empty(max(nrows, 1), dtype=torch.int32, device=x_local.device)
-        self.stats, stats_next = self._stats_pair[g % 2], self._stats_pair[(g + 1) % 2]
-        if chained and hasattr(self.kernels, "update_prepare"):
-            self.kernels.accumulate(view, w, self.label_buf, self.stats, chained=True)
-        else:
-            self.kernels.accumulate(view, w, self.label_buf, self.stats)
-        if _world(self.group) > 1:
-            dist.all_reduce(self.stats, op=dist.ReduceOp.SUM, group=self.group)
-        thr, alpha = batch_schedule(g, total_steps, self.alpha_range, self.radius_range)
-        if hasattr(self.kernels, "update_prepare"):
-            self.kernels.update_prepare(w, self.xdim, self.ydim, self.stats, thr, alpha, stats_next)
-        else:
-            self.kernels.batch_update(w, self.xdim, self.ydim, self.sums, self.counts, thr, alpha)
 
     def train(self, x_local: torch.Tensor, w: torch.Tensor, num_passes: int = 1) -> torch.Tensor:
         """Runs num_passes passes in place on ``w`` [K, C] f64 (identical on every rank)."""
         total = int(num_passes) * self.batch_steps
-        for g in range(total):
-            self.step(x_local, w, g, total, chained=g > 0)
+        if total < 1:
+            return w
+        if x_local.shape[1] != self.c or tuple(w.shape) != (self.k, self.c):
+            raise ValueError(f"matrix [{tuple(x_local.shape)}] / codebook [{tuple(w.shape)}] do not match "
+                             f"the trainer's {self.k} nodes x {self.c} channels")
+        kern = self.kernels
+        kern.begin(x_local, w, self.xdim, self.ydim, self.batch_steps)
+        if _world(self.group) > 1:
+            for g in range(total):
+                kern.steps(x_local, g, g + 1, total, self.alpha_range, self.radius_range)
+                dist.all_reduce(kern.ring(g), op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            kern.steps(x_local, 0, total, total, self.alpha_range, self.radius_range)
+        kern.finish(total, total, self.alpha_range, self.radius_range, w)
         return w
 
 

@@ -91,6 +91,55 @@ def cluster_sums(x: torch.Tensor, labels: torch.Tensor, k: int,
     return sums, counts
 
 
+TRAIN_UNFUSED = 1  # include/pxsom.h PXSOM_TRAIN_UNFUSED
+
+
+class BatchTrainState:
+    """Caller-owned state of ``pxsom_batch_train_steps``: the codebook twin buffer ``wbuf`` [2, K, C], the
+    rotating statistics ``ring`` [3, K*(C+1)] (float64; ``ring[g % 3]`` is what a multi-rank job all-reduces
+    after step g) and the scratch workspace for ``n`` training rows in ``batch_steps`` mini-batches."""
+
+    def __init__(self, n: int, c: int, xdim: int, ydim: int, batch_steps: int, device):
+        self.n, self.c, self.xdim, self.ydim = int(n), int(c), int(xdim), int(ydim)
+        self.k, self.batch_steps = self.xdim * self.ydim, int(batch_steps)
+        self.ws_bytes = _capi.lib().pxsom_batch_train_workspace_bytes(self.n, self.batch_steps, self.c, self.k)
+        if self.ws_bytes == 0:
+            raise _capi.PxsomError(f"unsupported batch-training shape n={n} c={c} k={self.k}")
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
+        self.wbuf = torch.empty((2, self.k, self.c), dtype=torch.float64, device=device)
+        self.ring = torch.zeros((3, self.k * (self.c + 1)), dtype=torch.float64, device=device)
+
+    def fits(self, n: int, c: int, xdim: int, ydim: int, batch_steps: int) -> bool:
+        return (c == self.c and xdim == self.xdim and ydim == self.ydim and batch_steps == self.batch_steps
+                and n <= self.n)
+
+
+def batch_train_steps(x: torch.Tensor, state: BatchTrainState, g_begin: int, g_end: int, total_steps: int,
+                      alpha_range, radius_range, unfused: bool = False) -> None:
+    """Mini-batch steps [g_begin, g_end) of a batch training run, launched back to back by the library
+    (``state.wbuf[0]`` holds W_0 before step 0; see include/pxsom.h)."""
+    n, c, ldx, dt = _matrix_args(x)
+    if not state.fits(n, c, state.xdim, state.ydim, state.batch_steps):
+        raise ValueError("batch-training state does not fit this matrix")
+    rc = _capi.lib().pxsom_batch_train_steps(
+        x.data_ptr(), n, c, ldx, dt, state.wbuf.data_ptr(), state.ring.data_ptr(), state.xdim, state.ydim,
+        state.batch_steps, int(g_begin), int(g_end), int(total_steps), float(alpha_range[0]), float(alpha_range[1]),
+        float(radius_range[0]), float(radius_range[1]), state.ws.data_ptr(), state.ws_bytes,
+        TRAIN_UNFUSED if unfused else 0, _capi.stream_ptr())
+    _capi.check(rc, "pxsom_batch_train_steps")
+
+
+def batch_train_finish(state: BatchTrainState, steps_done: int, total_steps: int, alpha_range, radius_range,
+                       w_out: torch.Tensor) -> None:
+    """Applies the last pending update of a run: ``w_out`` [K, C] receives the codebook after ``steps_done`` steps."""
+    w_out = _codebook(w_out)
+    rc = _capi.lib().pxsom_batch_train_finish(
+        state.wbuf.data_ptr(), state.ring.data_ptr(), state.xdim, state.ydim, state.c, int(steps_done),
+        int(total_steps), float(alpha_range[0]), float(alpha_range[1]), float(radius_range[0]),
+        float(radius_range[1]), w_out.data_ptr(), _capi.stream_ptr())
+    _capi.check(rc, "pxsom_batch_train_finish")
+
+
 ACC_PREPARED = 1  # include/pxsom.h PXSOM_ACC_PREPARED
 
 

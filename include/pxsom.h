@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PXSOM_ABI_VERSION 3
+#define PXSOM_ABI_VERSION 4
 
 typedef enum pxsom_status {
     PXSOM_OK = 0,
@@ -129,6 +129,7 @@ int pxsom_train_online(const void *x_dev, int64_t n, int c, int64_t ldx, int dty
  *   accumulate: zero stats; labels = BMU(x rows, w) (pxsom_assign; labels_dev [n] int32 scratch that also
  *               returns them); stats[b, :] += x_i, stats_count[b] += 1 for b = label_i - 1.
  *   update:     num[k] = sum_{b: cheb(k,b) <= thr} sums[b], den[k] = sum_{b: ...} counts[b]
+ *               (summed in orc_batch_update's separable order: along y inside a grid row, then over the rows)
  *               den[k] > 0:  w[k] += (1 - (1-alpha)^den[k]) * (num[k]/den[k] - w[k])
  *   update_prepare: the same update with sums/counts = the two halves of stats_dev; the same launch clears
  *               stats_next_dev, the buffer the next accumulate will fill (alternate two buffers; NULL or
@@ -146,6 +147,31 @@ int pxsom_batch_update(double *w_dev, int xdim, int ydim, int c, const double *s
 int pxsom_batch_update_prepare(double *w_dev, int xdim, int ydim, int c, double *stats_dev,
                                double *stats_next_dev, double thr, double alpha, void *workspace_dev,
                                size_t workspace_bytes, void *stream);
+
+/* ---- batch SOM training, one call per run of steps ------------------------------------------------
+ * The host loop over the mini-batch steps of a pass, inside the library (no per-step Python / ctypes work).
+ * Step g of total_steps (= num_passes * batch_steps) uses the rows i = (g % batch_steps) + r * batch_steps of
+ * x_dev and the schedule thr/alpha(g) of orc_som_batch.  State, all caller-owned:
+ *   wbuf_dev        [2][k*c] binary64: W_g, the codebook step g searches with, lives in wbuf[g % 2].
+ *                   Before the first call the caller stores W_0 in wbuf[0].
+ *   stats_ring_dev  [3][k*(c+1)] binary64: step g leaves its [k*c sums | k counts] in ring[g % 3] and clears
+ *                   ring[(g+1) % 3]; the call with g_begin == 0 clears ring[0] first.
+ * A single process runs [0, total_steps) in one call.  A multi-rank job runs ONE step per call and sum-all-reduces
+ * ring[g % 3] across ranks before the next call (the only exchange of the rule).  After the last step (and its
+ * all-reduce) pxsom_batch_train_finish applies the last pending update: w_out_dev [k, c] receives W_total.
+ * Register-resident shapes (10 x 10 grid, even c <= 32, rows 2-element aligned) take ONE launch per step: the
+ * pending update of step g-1 and the codebook preparation run at the head of step g's BMU search in every
+ * workgroup; other shapes run update / prepare / search / exact / sums launches per step.  Same results either
+ * way (PXSOM_TRAIN_UNFUSED forces the second route).  Oracle of record: oracle/pxsom_oracle.c orc_som_batch. */
+#define PXSOM_TRAIN_UNFUSED 1
+size_t pxsom_batch_train_workspace_bytes(int64_t n, int batch_steps, int c, int k);
+int pxsom_batch_train_steps(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, double *wbuf_dev,
+                            double *stats_ring_dev, int xdim, int ydim, int batch_steps, int g_begin, int g_end,
+                            int total_steps, double a0, double a1, double r0, double r1, void *workspace_dev,
+                            size_t workspace_bytes, int flags, void *stream);
+int pxsom_batch_train_finish(const double *wbuf_dev, const double *stats_ring_dev, int xdim, int ydim, int c,
+                             int steps_done, int total_steps, double a0, double a1, double r0, double r1,
+                             double *w_out_dev, void *stream);
 
 /* ---- pre-processing (create_fov_pixel_data and the 99.9 % values) -----------------------------
  * reference: pixie_preprocessing.py:47-49 -> scipy.ndimage.gaussian_filter(plane, sigma) per channel:

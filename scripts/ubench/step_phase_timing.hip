@@ -1,0 +1,71 @@
+// Diagnosis: phase times (s_memtime, workgroup 0) inside the fused mini-batch step kernel
+// (pxsom_batch_step.hip) for config 2's mini-batch (16384 rows of a strided 1 M x 22 view).
+#define PXSOM_PHASE_TIMING 1
+#define PXSOM_PHASE_BLOCK0_ONLY 1
+#include "../../ark_analysis_amd/csrc/pxsom_batch_step.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+int main(int argc, char **argv)
+{
+    const int M = 64, c = 22, K = 100, tpw = argc > 1 ? atoi(argv[1]) : 2;
+    const int64_t n = 1048576;
+    std::vector<float> x((size_t)n * c);
+    srand(1);
+    std::vector<float> cen(32 * c);
+    for (auto &v : cen) v = (float)rand() / RAND_MAX;
+    for (int64_t i = 0; i < n; i++) {
+        const int z = rand() % 32;
+        for (int j = 0; j < c; j++) {
+            float v = cen[z * c + j] + 0.05f * ((float)rand() / RAND_MAX - 0.5f) * 3.4f;
+            x[(size_t)i * c + j] = (rand() % 10 == 0 || v < 0) ? 0.f : v;
+        }
+    }
+    std::vector<double> w((size_t)K * c);
+    for (int k = 0; k < K; k++)
+        for (int j = 0; j < c; j++) w[(size_t)k * c + j] = x[(size_t)(k * 9973) * c + j];
+    float *dx; double *dwbuf, *dring;
+    const size_t nw = (size_t)K * c, ns = (size_t)K * (c + 1);
+    hipMalloc(&dx, x.size() * 4); hipMalloc(&dwbuf, 2 * nw * 8); hipMalloc(&dring, 3 * ns * 8);
+    hipMemcpy(dx, x.data(), x.size() * 4, hipMemcpyHostToDevice);
+    using namespace pxsom_bmu;
+    for (int rep = 0; rep < 2; rep++) {
+        hipMemcpy(dwbuf, w.data(), nw * 8, hipMemcpyHostToDevice);
+        hipMemset(dring, 0, 3 * ns * 8);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0, 0);
+        for (int g = 0; g < M; g++) {
+            StepArgs sa;
+            sa.w_in = g > 0 ? dwbuf + ((g + 1) % 2) * nw : dwbuf; sa.w_out = dwbuf + (g % 2) * nw;
+            sa.stats_prev = dring + ((g + 2) % 3) * ns; sa.stats_zero = dring + ((g + 1) % 3) * ns;
+            sa.zero_count = (int)ns; sa.has_update = g > 0;
+            double thr = 6.0 - 6.0 * (g > 0 ? g - 1 : 0) / M; if (thr < 1) thr = 0.5;
+            sa.thr = thr; sa.alpha = 0.05 - 0.04 * (g > 0 ? g - 1 : 0) / M;
+            const int64_t rows = (n - g + M - 1) / M;
+            int rc = launch_batch_step<float>(dx + (size_t)g * c, rows, c, (int64_t)c * M, dring + (g % 3) * ns, sa, tpw, 0);
+            if (rc) { printf("rc %d %s\n", rc, pxsom_last_error()); return 1; }
+            if (rep == 1 && (g == 0 || g == 19 || g == 39 || g == 62)) {
+                hipDeviceSynchronize();
+                long long z[2] = {0x7fffffffffffffffLL, 0};
+                hipMemcpyToSymbol(HIP_SYMBOL(g_phase_ticks), z, sizeof(z), 28 * sizeof(long long));
+            }
+            if (rep == 1 && (g == 1 || g == 20 || g == 40 || g == 63)) {
+                hipDeviceSynchronize();
+                long long t[32];
+                hipMemcpyFromSymbol(t, HIP_SYMBOL(g_phase_ticks), sizeof(t));
+                auto us = [&](int a, int b) { return (t[b] - t[a]) / 2400.0; };   // s_memtime ticks at the 2.4 GHz shader clock (approx.)
+                printf("step %2d thr %.2f: rows+loads %.2f | pass1 %.2f pass2 %.2f | neww+norms %.2f | scale+frags %.2f | dups %.2f | bias %.2f | "
+                       "filter %.2f | exact(%lld) %.2f | flush-issue %.2f flush-done %.2f | total %.2f us\n",
+                       g, thr, us(8, 9), us(9, 10), us(10, 11), us(11, 12), us(12, 13), us(13, 14), us(14, 15), us(15, 16), t[21],
+                       us(16, 17), us(17, 18), us(18, 19), us(8, 19));
+                printf("         first workgroup start -> last workgroup end: %.2f us\n", us(28, 29));
+            }
+        }
+        hipEventRecord(e1, 0);
+        hipDeviceSynchronize();
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("rep %d: %d steps %.3f ms (%.2f us/step)\n", rep, M, ms, ms * 1e3 / M);
+    }
+    return 0;
+}

@@ -46,10 +46,10 @@ def lib():
         L.orc_pair_histogram.restype = None
         L.orc_pair_histogram.argtypes = [c_i32p, c_i32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, c_i64p]
         L.orc_batch_update.restype = None
-        L.orc_batch_update.argtypes = [c_dp, ctypes.c_int, ctypes.c_int, c_dp, c_dp, c_i64p,
+        L.orc_batch_update.argtypes = [c_dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_dp, c_i64p,
                                        ctypes.c_double, ctypes.c_double]
         L.orc_som_batch.restype = ctypes.c_int
-        L.orc_som_batch.argtypes = [c_dp, ctypes.c_int64, ctypes.c_int, c_dp, ctypes.c_int, c_dp,
+        L.orc_som_batch.argtypes = [c_dp, ctypes.c_int64, ctypes.c_int, c_dp, ctypes.c_int, ctypes.c_int,
                                     ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                     ctypes.c_double, ctypes.c_int, ctypes.c_int]
         L.orc_gaussian_blur_hwc.restype = ctypes.c_int
@@ -158,10 +158,10 @@ def cluster_means(sums, counts):
 def batch_update(codes, xdim, ydim, sums, counts, thr, alpha):
     codes = _f64(codes).copy()
     K, px = codes.shape
-    nh = nhbrdist(xdim, ydim)
+    assert K == xdim * ydim
     sums = _f64(sums)
     counts = np.ascontiguousarray(counts, dtype=np.int64)
-    lib().orc_batch_update(_dp(codes), K, px, _dp(nh), _dp(sums), counts.ctypes.data_as(c_i64p),
+    lib().orc_batch_update(_dp(codes), int(xdim), int(ydim), px, _dp(sums), counts.ctypes.data_as(c_i64p),
                            float(thr), float(alpha))
     return codes
 
@@ -170,9 +170,8 @@ def som_batch(data, codes, xdim, ydim, rlen, alpha_range, radius_range, M):
     data = _f64(data)
     codes = _f64(codes).copy()
     n, px = data.shape
-    K = xdim * ydim
-    nh = nhbrdist(xdim, ydim)
-    rc = lib().orc_som_batch(_dp(data), n, px, _dp(codes), K, _dp(nh), float(alpha_range[0]),
+    assert codes.shape[0] == xdim * ydim
+    rc = lib().orc_som_batch(_dp(data), n, px, _dp(codes), int(xdim), int(ydim), float(alpha_range[0]),
                              float(alpha_range[1]), float(radius_range[0]),
                              float(radius_range[1]), int(rlen), int(M))
     assert rc == 0

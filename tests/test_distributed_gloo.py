@@ -18,20 +18,40 @@ from ark_analysis_amd.distributed import (BatchSOMTrainer, allreduce_cluster_tab
 class OracleKernels:
     """Same interface as distributed.HipKernels, backed by oracle/pxsom_oracle.c (tests only)."""
 
-    def accumulate(self, x, w, labels, stats):
-        from tests import oracle_binding as ob
-        xn = np.ascontiguousarray(x.numpy(), dtype=np.float64)
+    def begin(self, x, w, xdim, ydim, batch_steps):
+        self.xdim, self.ydim, self.m = xdim, ydim, batch_steps
         k, c = w.shape
-        lab, _ = ob.map_data_to_nodes(w.numpy(), xn)
-        s, cnt = ob.cluster_sums(xn, lab, k)
-        labels[: len(lab)].copy_(torch.from_numpy(lab))
-        stats[: k * c].copy_(torch.from_numpy(s.reshape(-1)))
-        stats[k * c:].copy_(torch.from_numpy(cnt.astype(np.float64)))
+        self.w = [w.clone(), w.clone()]
+        self.rings = [torch.zeros(k * (c + 1), dtype=torch.float64) for _ in range(3)]
 
-    def batch_update(self, w, xdim, ydim, sums, counts, thr, alpha):
+    def ring(self, g):
+        return self.rings[g % 3]
+
+    def _update(self, w, g, total, alpha_range, radius_range):
         from tests import oracle_binding as ob
-        w.copy_(torch.from_numpy(ob.batch_update(w.numpy(), xdim, ydim, sums.numpy(),
-                                                 counts.numpy().astype(np.int64), thr, alpha)))
+        k, c = w.shape
+        thr, alpha = batch_schedule(g, total, alpha_range, radius_range)
+        st = self.rings[g % 3]
+        return torch.from_numpy(ob.batch_update(w.numpy(), self.xdim, self.ydim, st[: k * c].view(k, c).numpy(),
+                                                st[k * c:].numpy().astype(np.int64), thr, alpha))
+
+    def steps(self, x, g0, g1, total, alpha_range, radius_range):
+        from tests import oracle_binding as ob
+        for g in range(g0, g1):
+            if g > 0:
+                self.w[g % 2] = self._update(self.w[(g - 1) % 2], g - 1, total, alpha_range, radius_range)
+            w = self.w[g % 2]
+            k, c = w.shape
+            xn = np.ascontiguousarray(x[(g % self.m)::self.m].numpy(), dtype=np.float64)
+            lab, _ = ob.map_data_to_nodes(w.numpy(), xn)
+            s, cnt = ob.cluster_sums(xn, lab, k)
+            st = self.rings[g % 3]
+            st[: k * c].copy_(torch.from_numpy(s.reshape(-1)))
+            st[k * c:].copy_(torch.from_numpy(cnt.astype(np.float64)))
+
+    def finish(self, steps_done, total, alpha_range, radius_range, w):
+        g = steps_done - 1
+        w.copy_(self._update(self.w[g % 2], g, total, alpha_range, radius_range))
 
 
 def _free_port():
@@ -52,12 +72,12 @@ def _worker(rank, world, port, shards, w0, xdim, ydim, m, out_path):
     trainer = BatchSOMTrainer(xdim, ydim, x.shape[1], "cpu", batch_steps=m, kernels=OracleKernels())
     trainer.train(x, w, num_passes=2)
     # K8 across ranks: per-cluster tables of the final labels
-    labels = torch.empty(x.shape[0], dtype=torch.int32)
-    kc = xdim * ydim * x.shape[1]
-    stats = torch.zeros(kc + xdim * ydim, dtype=torch.float64)
-    trainer.kernels.accumulate(x, w, labels, stats)
-    sums = stats[:kc].view(xdim * ydim, x.shape[1]).clone()
-    counts = stats[kc:].to(torch.int64)
+    from tests import oracle_binding as ob
+    xn = np.ascontiguousarray(x.numpy(), dtype=np.float64)
+    lab, _ = ob.map_data_to_nodes(w.numpy(), xn)
+    s_np, cnt_np = ob.cluster_sums(xn, lab, xdim * ydim)
+    sums = torch.from_numpy(s_np).clone()
+    counts = torch.from_numpy(cnt_np.astype(np.int64))
     allreduce_cluster_tables(sums, counts)
     gathered = [torch.zeros_like(w) for _ in range(world)]
     dist.all_gather(gathered, w)

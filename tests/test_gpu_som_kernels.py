@@ -457,6 +457,88 @@ def test_batch_update_prepare_matches_oracle_and_chains(gpu, oracle, xdim, ydim,
     np.testing.assert_allclose(wa.cpu().numpy(), want_b, rtol=1e-9, atol=0)
 
 
+@pytest.mark.parametrize("c,dtype,n,m,passes", [(22, np.float32, 40_000, 8, 1), (22, np.float32, 9_001, 4, 2),
+                                                  (8, np.float32, 20_000, 16, 1), (16, np.float16, 30_000, 8, 1),
+                                                  (32, np.float32, 12_345, 5, 1), (22, np.float64, 10_000, 4, 1)])
+def test_batch_train_steps_fused_equals_unfused_and_oracle(gpu, oracle, c, dtype, n, m, passes):
+    """pxsom_batch_train_steps on a 10 x 10 grid: the one-launch-per-step route (pending update + prep at the
+    head of the BMU search) against the launch-per-phase route step by step (codebooks and statistics, bit for
+    bit for rows that sum exactly in binary64), against a run in one call, and against orc_som_batch."""
+    xdim = ydim = 10
+    k = 100
+    x = synth.make_fov_numpy(n, c, seed=77, dtype=np.float32).astype(dtype)
+    w0 = _codebook(x.astype(np.float64), k, seed=12)
+    w0[17] = w0[3]                       # a duplicate node from the start
+    xd = torch.from_numpy(x).to(gpu)
+    rr = default_radius_range(xdim, ydim)
+    total = m * passes
+    exact_rows = dtype != np.float64     # binary64 rows: atomic summation order leaves 1e-16 noise
+    states = [sd.BatchTrainState(n, c, xdim, ydim, m, gpu) for _ in range(2)]
+    for st in states:
+        st.wbuf[0].copy_(torch.from_numpy(w0))
+    for g in range(total):
+        sd.batch_train_steps(xd, states[0], g, g + 1, total, (0.05, 0.01), rr)                  # fused
+        sd.batch_train_steps(xd, states[1], g, g + 1, total, (0.05, 0.01), rr, unfused=True)
+        if not exact_rows:
+            # keep the two routes on the same trajectory: per-step parity is what is compared
+            states[1].wbuf.copy_(states[0].wbuf)
+            ra, rb = states[0].ring[g % 3].cpu().numpy(), states[1].ring[g % 3].cpu().numpy()
+            np.testing.assert_allclose(ra, rb, rtol=1e-12, atol=1e-12)
+            states[1].ring.copy_(states[0].ring)
+            continue
+        assert torch.equal(states[0].wbuf[g % 2], states[1].wbuf[g % 2]), f"codebook of step {g} differs"
+        assert torch.equal(states[0].ring[g % 3], states[1].ring[g % 3]), f"statistics of step {g} differ"
+        assert float(states[0].ring[(g + 1) % 3].abs().max()) == 0.0, "next statistics buffer not cleared"
+    wa = torch.empty((k, c), dtype=torch.float64, device=gpu)
+    wb = torch.empty_like(wa)
+    sd.batch_train_finish(states[0], total, total, (0.05, 0.01), rr, wa)
+    sd.batch_train_finish(states[1], total, total, (0.05, 0.01), rr, wb)
+    if not exact_rows:
+        np.testing.assert_allclose(wa.cpu().numpy(), wb.cpu().numpy(), rtol=1e-12, atol=0)
+        return
+    assert torch.equal(wa, wb)
+    # the whole run in ONE call (what a single process does)
+    st = sd.BatchTrainState(n, c, xdim, ydim, m, gpu)
+    st.wbuf[0].copy_(torch.from_numpy(w0))
+    sd.batch_train_steps(xd, st, 0, total, total, (0.05, 0.01), rr)
+    wc = torch.empty_like(wa)
+    sd.batch_train_finish(st, total, total, (0.05, 0.01), rr, wc)
+    assert torch.equal(wa, wc)
+    want = oracle.som_batch(x.astype(np.float64), w0, xdim, ydim, passes, (0.05, 0.01), rr, m)
+    np.testing.assert_allclose(wa.cpu().numpy(), want, rtol=1e-9, atol=0)
+
+
+def test_batch_train_steps_statistics_match_oracle_per_step(gpu, oracle):
+    """Every fused step's statistics == orc_cluster_sums of the oracle's BMUs for the codebook that step used,
+    and the codebook it derived == orc_batch_update of the previous one (ties / duplicate nodes included)."""
+    xdim = ydim = 10
+    k, c, n, m = 100, 22, 16_000, 8
+    x = synth.make_fov_numpy(n, c, seed=5, dtype=np.float32)
+    x[100:110] = x[100]                  # repeated rows
+    w0 = _codebook(x.astype(np.float64), k, seed=2)
+    w0[50] = w0[49]
+    xd = torch.from_numpy(x).to(gpu)
+    rr = default_radius_range(xdim, ydim)
+    st = sd.BatchTrainState(n, c, xdim, ydim, m, gpu)
+    st.wbuf[0].copy_(torch.from_numpy(w0))
+    from ark_analysis_amd.distributed import batch_schedule
+    w_prev = None
+    for g in range(m):
+        sd.batch_train_steps(xd, st, g, g + 1, m, (0.05, 0.01), rr)
+        w_g = st.wbuf[g % 2].cpu().numpy()
+        if g > 0:
+            thr, alpha = batch_schedule(g - 1, m, (0.05, 0.01), rr)
+            want_w = oracle.batch_update(w_prev, xdim, ydim, s_prev, cnt_prev, thr, alpha)
+            np.testing.assert_allclose(w_g, want_w, rtol=1e-12, atol=0)
+        rows = x[g::m].astype(np.float64)
+        lab, _ = oracle.map_data_to_nodes(w_g, rows)
+        s, cnt = oracle.cluster_sums(rows, lab, k)
+        ring = st.ring[g % 3].cpu().numpy()
+        np.testing.assert_array_equal(ring[k * c:], cnt.astype(np.float64))
+        np.testing.assert_array_equal(ring[: k * c].reshape(k, c), s)
+        w_prev, s_prev, cnt_prev = w_g, s, cnt
+
+
 def test_assign_full_size_sampled_against_oracle(gpu, oracle):
     """BASELINE config 2 size on one GPU (10 x 1024^2 x 22 fp32, K=100): rows are independent, so
     the oracle on a random sample of rows must agree exactly; plus idempotence and range."""
