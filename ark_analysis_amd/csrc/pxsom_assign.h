@@ -35,7 +35,8 @@ struct StepArgs {
     double *stats_zero;        // buffer cleared for step g+1 (NULL: none)
     int zero_count;
     int has_update;
-    double thr, alpha;         // schedule of the pending update (step g-1)
+    double thr, lg;            // schedule of the pending update (step g-1): window threshold, log(1 - alpha)
+    float tol_rel, tol_abs;    // filter tolerance coefficients (depend on c only: computed on the host)
 };
 
 struct Layout {

@@ -33,15 +33,13 @@ constexpr int kStepThreads = 512, kStepWaves = 8;
 constexpr int kQueueRows = 96;       // listed rows a workgroup keeps in LDS; further ones are settled on the spot
 
 struct StepHdr {
-    float scale, wn_max, tol_rel, tol_abs, x_limit;
-    int force_exact;
     int bad;          // NaN / Inf met in the codebook
     unsigned q_n;     // rows in the queue
 };
 
 // LDS carve-up (bytes from the start of the dynamic segment)
 struct StepLds {
-    size_t ls, wt, tl, norm2, key, red, ovf, frag, bias, biasv, hdr, total;
+    size_t ls, wt, tl, key, red, ovf, frag, bias, hdr, total;
 };
 __host__ __device__ inline StepLds step_lds(int c)
 {
@@ -50,13 +48,11 @@ __host__ __device__ inline StepLds step_lds(int c)
     L.ls = o;    o += ((size_t)kK * c + kK) * 8;          // table [K*c sums | K counts]
     L.wt = o;    o += (size_t)c * kK * 8;                 // codebook, transposed [c][K]
     L.tl = o;    o += (size_t)kK * (c + 1) * 8;           // window-sum scratch; later the queue of listed rows
-    L.norm2 = o; o += (size_t)kK * 8;
     L.key = o;   o += (size_t)kK * 8;
     L.red = o;   o += 2 * kStepWaves * 8;
     L.ovf = o;   o += (size_t)kStepWaves * 32 * 8;        // one row per wave (queue overflow)
     L.frag = o;  o += (size_t)kNB * 2 * 64 * 16;          // [NB][hi, lo][64] half8
     L.bias = o;  o += (size_t)kNB * 64 * 16;              // [NB][64] f32x4
-    L.biasv = o; o += (size_t)kK * 4;                     // per-node bias value
     L.hdr = o;   o += 64;
     L.total = o;
     return L;
@@ -123,13 +119,11 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
     double *ls = reinterpret_cast<double *>(step_smem + L.ls);
     double *wt = reinterpret_cast<double *>(step_smem + L.wt);
     double *tl = reinterpret_cast<double *>(step_smem + L.tl);
-    double *norm2 = reinterpret_cast<double *>(step_smem + L.norm2);
     unsigned long long *key = reinterpret_cast<unsigned long long *>(step_smem + L.key);
     double *red = reinterpret_cast<double *>(step_smem + L.red);
     double *ovf = reinterpret_cast<double *>(step_smem + L.ovf);
     half8 *frag_l = reinterpret_cast<half8 *>(step_smem + L.frag);
     f32x4 *bias_l = reinterpret_cast<f32x4 *>(step_smem + L.bias);
-    float *biasv = reinterpret_cast<float *>(step_smem + L.biasv);
     StepHdr *hdr = reinterpret_cast<StepHdr *>(step_smem + L.hdr);
 
     constexpr int NP = CPL / 2;
@@ -197,6 +191,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
             hdr->q_n = 0u;
             hdr->bad = 0;
         }
+        if (tid < 64) bias_l[6 * 64 + tid] = f32x4{kNegBig, kNegBig, kNegBig, kNegBig};   // rows of the last block without a node
         if (sa.stats_zero) {
             const int per = (sa.zero_count + (int)gridDim.x - 1) / (int)gridDim.x;
             const int z1 = min(((int)blockIdx.x + 1) * per, sa.zero_count);
@@ -248,6 +243,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
             hdr->q_n = 0u;
             hdr->bad = 0;
         }
+        if (tid < 64) bias_l[6 * 64 + tid] = f32x4{kNegBig, kNegBig, kNegBig, kNegBig};   // rows of the last block without a node
         if (sa.stats_zero) {
             const int per = (sa.zero_count + (int)gridDim.x - 1) / (int)gridDim.x;
             const int z1 = min(((int)blockIdx.x + 1) * per, sa.zero_count);
@@ -266,10 +262,15 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
             double den = 0.0, gain = -1.0;
             const int xp = node / kYD, yp = node - xp * kYD;
             const double *nrow = tl + (size_t)(yp * kXD + xp) * NC;
+            double inv = 0.0;
             if (sa.has_update) {
                 den = nrow[c];
-                // gain == 1 exactly (wide windows): the node is the window mean itself (orc_batch_update)
-                if (den > 0.0) gain = 1.0 - pow(1.0 - sa.alpha, den);
+                // gain = 1 - (1-alpha)^den = -expm1(den * log(1-alpha)); == 1 exactly for wide windows: the node is
+                // then the window mean itself (orc_batch_update)
+                if (den > 0.0) {
+                    gain = -expm1(den * sa.lg);
+                    inv = 1.0 / den;
+                }
             }
 #pragma unroll
             for (int i = 0; i < CPL; i++) {
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
                     double v = wv_[i];
                     if (gain >= 0.0) {   // (idle channel slots hold whatever word 0 held: never used)
                         const double num = nrow[ch];
-                        v = gain == 1.0 ? num / den : v + gain * (num / den - v);
+                        v = gain == 1.0 ? num * inv : v + gain * (num * inv - v);
                     }
                     wv_[i] = v;
                     wt[(size_t)ch * kK + node] = v;
@@ -286,9 +287,11 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
                     bad |= !(fabs(v) <= DBL_MAX);
                     nrm += v * v;
                     mymax = fmax(mymax, fabs(v));
-                    const unsigned long long hb = (unsigned long long)__double_as_longlong(v) * 0x9E3779B97F4A7C15ull +
-                                                  (unsigned long long)(ch + 1) * 0xC2B2AE3D27D4EB4Full;
-                    kkey ^= hb ^ (hb >> 29);
+                    // duplicate key: the bit pattern rotated by a channel-dependent amount, xor-ed up (no multiplies:
+                    // integer multiplies run at quarter rate; a key match is verified channel by channel anyway)
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+                    const int rot = (7 * ch + 1) & 63;
+                    kkey ^= (bits << rot) | (bits >> ((64 - rot) & 63));
                 }
             }
         }
@@ -298,10 +301,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
         kkey ^= __shfl_xor(kkey, 1);
         nrm += __shfl_xor(nrm, 2);
         kkey ^= __shfl_xor(kkey, 2);
-        if (has_node && nq == 0) {
-            norm2[node] = nrm;
-            key[node] = kkey;
-        }
+        if (has_node && nq == 0) key[node] = kkey;
         if (bad) hdr->bad = 1;   // NaN / Inf in the codebook: every row takes the exact path
         const double wmax = -pxsom::wave_min_f64(-mymax);
         const double nmax = -pxsom::wave_min_f64(-((has_node && nrm == nrm) ? nrm : 0.0));
@@ -313,8 +313,9 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
     PXSOM_PHASE(12);
     __syncthreads();
 
-    // ---- P4: scale, fragments, duplicate table ---------------------------------------------------------------
-    double scale;
+    // ---- P4: scale, fragments, duplicates, bias -- one phase: every thread knows its node's values, norm and key
+    float fscale, wn_max;
+    bool force_exact;
     {
         double maxabs = red[0], wn2max = red[kStepWaves];
 #pragma unroll
@@ -331,18 +332,12 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
             if (e > 100) e = 100;
             if (e < -100) e = -100;
         }
-        scale = ldexp(1.0, e);
-        if (tid == 0) {
-            const bool badw = hdr->bad != 0 || !(wn2max * scale * scale <= 1.0e30);
-            hdr->scale = (float)scale;
-            hdr->wn_max = badw ? 0.f : (float)(sqrt(wn2max) * scale * (1.0 + 1e-6));
-            hdr->force_exact = badw ? 1 : 0;
-            // coefficient of the rigorous |filter - exact| bound (DESIGN.md "K7 error bound"; 7 index bits)
-            const double coef = ldexp(1.0, -(23 - 7)) + (3.0 * c + 2.0) * ldexp(1.0, -24) + ldexp(1.0, -19) + ldexp(1.0, -23);
-            hdr->tol_rel = (float)(2.5 * coef);
-            hdr->tol_abs = (float)(2.5 * ldexp(1.0, -24) * sqrt((double)c));
-            hdr->x_limit = 60000.0f;
-        }
+        const double scale = ldexp(1.0, e);
+        const bool badw = hdr->bad != 0 || !(wn2max * scale * scale <= 1.0e30);
+        fscale = (float)scale;
+        // rounded up by a hair; NaN / Inf / huge codebook: every row takes the exact path
+        wn_max = badw ? 0.f : (float)(sqrt(wn2max) * scale * (1.0 + 1e-6));
+        force_exact = badw;
         if (has_node) {
             // A-fragment element of (node, nq): lane (nq << 4 | m) of node block b; the last block's (q, r) grid is
             // transposed (node_of_row): node 96 + t sits in row m = 4 t
@@ -359,8 +354,39 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
             const int lf = (nq << 4) | m;
             frag_l[(b * 2 + 0) * 64 + lf] = fhi;
             frag_l[(b * 2 + 1) * 64 + lf] = flo;
+            // Exact duplicates of an EARLIER node are masked out of the filter (pxsom_prep.h).  The node's 4 lanes scan
+            // the earlier nodes' keys together (lane nq takes prev = nq, nq + 4, ...; no early exit, so the LDS reads
+            // pipeline), the smallest match is then compared channel by channel.
+            auto same_as = [&](int prev) {   // all channels equal, decided by the node's 4 lanes together
+                bool eq = true;
+#pragma unroll
+                for (int i = 0; i < CPL; i++) {
+                    const int ch = nq * CPL + i;
+                    if (ch < c) eq &= wt[(size_t)ch * kK + prev] == wv_[i];
+                }
+                int ee = eq ? 1 : 0;
+                ee &= __shfl_xor(ee, 1);
+                ee &= __shfl_xor(ee, 2);
+                return ee != 0;
+            };
+            int hit = 0x7fffffff;
+#pragma unroll 5
+            for (int prev = nq; prev < kK; prev += 4) hit = min(hit, (prev < node && key[prev] == kkey) ? prev : 0x7fffffff);
+            hit = min(hit, __shfl_xor(hit, 1));
+            hit = min(hit, __shfl_xor(hit, 2));
+            bool dup = false;
+            if (hit != 0x7fffffff) {
+                dup = same_as(hit);
+                for (int prev = hit + 1; prev < node && !dup; prev++)   // a key collision: keep looking
+                    if (key[prev] == kkey) dup = same_as(prev);
+            }
+            // bias of accumulator row m = 4 qf + rr of block b, replicated over the 16 pixel lanes: this lane writes 4
+            const float bvv = dup ? kNegBig : (float)(-0.5 * nrm * scale * scale);
+            float *bf = reinterpret_cast<float *>(bias_l) + ((size_t)(b * 64 + (m >> 2) * 16 + nq * 4) * 4 + (m & 3));
+#pragma unroll
+            for (int u = 0; u < 4; u++) bf[u * 4] = bvv;
         } else if (tid < 4 * kK + 48) {
-            // the 12 rows of the last block that hold no node
+            // the 12 rows of the last block that hold no node (their bias was set to kNegBig at the start)
             const int i = (tid - 4 * kK) >> 2, m = (i / 3) * 4 + (i % 3) + 1;
             const half8 z = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
             frag_l[(6 * 2 + 0) * 64 + ((nq << 4) | m)] = z;
@@ -368,57 +394,12 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
         }
     }
     PXSOM_PHASE(13);
-    __syncthreads();
-
-    // ---- P5: exact duplicates of an EARLIER node are masked out of the filter (pxsom_prep.h).  The node's 4 lanes
-    // scan the earlier nodes' keys together (lane nq takes prev = nq, nq + 4, ...; no early exit, so the LDS reads
-    // pipeline), the smallest match is then compared channel by channel.
-    if (has_node) {
-        auto same_as = [&](int prev) {   // all channels equal, decided by the node's 4 lanes together
-            bool eq = true;
-#pragma unroll
-            for (int i = 0; i < CPL; i++) {
-                const int ch = nq * CPL + i;
-                if (ch < c) eq &= wt[(size_t)ch * kK + prev] == wv_[i];
-            }
-            int e = eq ? 1 : 0;
-            e &= __shfl_xor(e, 1);
-            e &= __shfl_xor(e, 2);
-            return e != 0;
-        };
-        int hit = 0x7fffffff;
-#pragma unroll 5
-        for (int prev = nq; prev < kK; prev += 4) hit = min(hit, (prev < node && key[prev] == kkey) ? prev : 0x7fffffff);
-        hit = min(hit, __shfl_xor(hit, 1));
-        hit = min(hit, __shfl_xor(hit, 2));
-        bool dup = false;
-        if (hit != 0x7fffffff) {
-            dup = same_as(hit);
-            for (int prev = hit + 1; prev < node && !dup; prev++)   // a key collision: keep looking
-                if (key[prev] == kkey) dup = same_as(prev);
-        }
-        if (nq == 0) biasv[node] = dup ? kNegBig : (float)(-0.5 * nrm * scale * scale);
-    }
     PXSOM_PHASE(14);
-    __syncthreads();
-    // ---- P6: bias fragments ---------------------------------------------------------------------------------
-    if (tid < kNB * 64) {
-        const int lf = tid & 63, b = tid >> 6, qf = lf >> 4;
-        f32x4 bv;
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-            const int nd = node_of_row(b, qf * 4 + rr, kNB);
-            bv[rr] = nd < kK ? biasv[nd] : kNegBig;
-        }
-        bias_l[tid] = bv;
-    }
     PXSOM_PHASE(15);
     __syncthreads();
 
     // ---- P7: BMU search of this workgroup's rows -------------------------------------------------------------
-    const float fscale = hdr->scale, wn_max = hdr->wn_max, tol_rel = hdr->tol_rel, tol_abs = hdr->tol_abs,
-                x_limit = hdr->x_limit;
-    const bool force_exact = hdr->force_exact != 0;
+    const float tol_rel = sa.tol_rel, tol_abs = sa.tol_abs, x_limit = 60000.0f;
     double *qrows = tl;   // the window-sum scratch is free now: [kQueueRows][c]
     constexpr unsigned idx_mask = 127u;
     for (; blk < nblocks; blk += gridDim.x) {

@@ -563,7 +563,7 @@ __global__ __launch_bounds__(CH * L > 40 ? 512 : 256) void som_online_split_kern
 __global__ __launch_bounds__(256) void batch_update_kernel(double *w, int xdim, int ydim, int c,
                                                            const double *__restrict__ sums,
                                                            const double *__restrict__ counts,
-                                                           double thr, double alpha, int stage,
+                                                           double thr, double lg, int stage,
                                                            double *__restrict__ zero_out, int zero_count)
 {
     extern __shared__ __attribute__((aligned(16))) char upd_smem[];
@@ -621,10 +621,11 @@ __global__ __launch_bounds__(256) void batch_update_kernel(double *w, int xdim, 
         num += tn;
     }
     if (den > 0.0) {
-        const double gain = 1.0 - pow(1.0 - alpha, den);
+        // 1 - (1-alpha)^den as -expm1(den * log(1-alpha)), the logarithm taken on the host (orc_batch_update)
+        const double gain = -expm1(den * lg), inv = 1.0 / den;
         // gain == 1 exactly (wide windows): the node is the window mean itself, so nodes sharing a window are
         // bit-identical (and masked as duplicates by prep) instead of one ulp apart (orc_batch_update)
-        w[(size_t)k * c + j] = gain == 1.0 ? num / den : wv + gain * (num / den - wv);
+        w[(size_t)k * c + j] = gain == 1.0 ? num * inv : wv + gain * (num * inv - wv);
     }
 }
 
@@ -1214,7 +1215,7 @@ PXSOM_EXPORT int pxsom_batch_update(double *w_dev, int xdim, int ydim, int c, co
     const size_t stage_bytes = (size_t)K * (c + 1) * sizeof(double);
     const int stage = stage_bytes <= 60 * 1024;
     hipLaunchKernelGGL(batch_update_kernel, dim3(K), dim3(256), stage ? stage_bytes : 0, st, w_dev, xdim, ydim, c,
-                       sums_dev, counts_dev, thr, alpha, stage, (double *)nullptr, 0);
+                       sums_dev, counts_dev, thr, log1p(-alpha), stage, (double *)nullptr, 0);
     PXSOM_LAUNCH_CHECK("batch_update_kernel");
     return PXSOM_OK;
 }
@@ -1287,7 +1288,7 @@ PXSOM_EXPORT int pxsom_batch_update_prepare(double *w_dev, int xdim, int ydim, i
     const size_t stage_bytes = (size_t)nstats * sizeof(double);
     const int stage = stage_bytes <= 60 * 1024;
     hipLaunchKernelGGL(batch_update_kernel, dim3(k), dim3(256), stage ? stage_bytes : 0, st, w_dev, xdim, ydim, c,
-                       stats_dev, stats_dev + (size_t)k * c, thr, alpha, stage, other ? stats_next_dev : nullptr,
+                       stats_dev, stats_dev + (size_t)k * c, thr, log1p(-alpha), stage, other ? stats_next_dev : nullptr,
                        other ? nstats : 0);
     PXSOM_LAUNCH_CHECK("batch_update_kernel");
     if (!other) PXSOM_HIP_TRY(hipMemsetAsync(stats_dev, 0, stage_bytes, st));
@@ -1352,7 +1353,12 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
             sa.zero_count = (int)nstats;
             sa.has_update = g > 0 ? 1 : 0;
             sa.thr = thr;
-            sa.alpha = alpha;
+            sa.lg = log1p(-alpha);
+            // coefficients of the filter's rigorous |score - exact| bound (DESIGN.md "K7 error bound"; 7 index bits
+            // packed into the scores): tol = 2 * 1.25 * E
+            sa.tol_rel = (float)(2.5 * (ldexp(1.0, -(23 - 7)) + (3.0 * c + 2.0) * ldexp(1.0, -24) + ldexp(1.0, -19) +
+                                        ldexp(1.0, -23)));
+            sa.tol_abs = (float)(2.5 * ldexp(1.0, -24) * sqrt((double)c));
             int rc = pxsom_bmu::launch_batch_step<T>(xv, rows, c, ldv, s_cur, sa, tpw, st);
             if (rc) return rc;
             continue;

@@ -112,6 +112,90 @@ class BatchSOMTrainer:
         return w
 
 
+# ---- rank context of the drop-in pipeline --------------------------------------------------------------------
+# Under ``torchrun`` (one process per GPU) the pipeline functions shard their FOV lists by rank; without a
+# process group everything below degenerates to rank 0 of 1 and costs nothing.
+
+def init_from_env() -> Tuple[int, int]:
+    """(rank, world).  Joins the job ``torch.distributed.run`` started (RANK / WORLD_SIZE / MASTER_* in the
+    environment) if no process group exists yet: backend "nccl" (= RCCL over xGMI) with a HIP device, else
+    "gloo".  A plain ``python`` process stays (0, 1)."""
+    import os
+    if not dist.is_available():
+        return 0, 1
+    if not dist.is_initialized():
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world <= 1 or "RANK" not in os.environ:
+            return 0, 1
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        rank = int(os.environ["RANK"])
+        if torch.cuda.is_available():
+            local = int(os.environ.get("LOCAL_RANK", str(rank % max(1, torch.cuda.device_count()))))
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    return dist.get_rank(), dist.get_world_size()
+
+
+def context() -> Tuple[int, int]:
+    """(rank, world) of the current process group; (0, 1) without one."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard(items, rank: Optional[int] = None, world: Optional[int] = None) -> list:
+    """This rank's share of ``items`` (round robin over a list every rank holds in the same order)."""
+    if rank is None or world is None:
+        rank, world = context()
+    return list(items)[rank::world]
+
+
+def barrier() -> None:
+    if context()[1] > 1:
+        dist.barrier()
+
+
+def _collective_device() -> torch.device:
+    """Where tensors handed to a collective must live: HBM for RCCL, host memory for gloo."""
+    if dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def broadcast_object(obj, src: int = 0):
+    """``obj`` of rank ``src`` on every rank (small host objects: codebooks, FOV lists)."""
+    if context()[1] <= 1:
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def allgather_objects(obj) -> list:
+    """[obj of rank 0, obj of rank 1, ...] on every rank."""
+    world = context()[1]
+    if world <= 1:
+        return [obj]
+    out = [None] * world
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def allreduce_sum_numpy(arr):
+    """Element-wise sum over ranks of a float64 / int64 numpy array (returned as a new array)."""
+    import numpy as np
+    if context()[1] <= 1:
+        return np.array(arr, copy=True)
+    t = torch.from_numpy(np.ascontiguousarray(arr)).to(_collective_device())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()
+
+
 def broadcast_codebook(w: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
     if _world(group) > 1:
         dist.broadcast(w, src=src, group=group)

@@ -90,6 +90,47 @@ def som(data, xdim: int = 10, ydim: int = 10, rlen: int = 10,
                            alpha_range, radius_range)
 
 
+def _batch_backend():
+    """(device, kernel set) batch-mode training runs on: HBM and the HIP kernels.  (The CPU test suite swaps this
+    for host memory and an oracle-backed stand-in to exercise the host logic; nothing else ever does.)"""
+    from . import _capi
+    from .distributed import HipKernels
+    return _capi.require_gpu(), HipKernels()
+
+
+def som_batch(data, xdim: int = 10, ydim: int = 10, rlen: int = 1,
+              alpha_range: Sequence[float] = (0.05, 0.01), radius_range=None, nodes=None, seed=None,
+              batch_steps: int = 64) -> np.ndarray:
+    """Throughput-mode SOM training (the batch rule of DESIGN.md "K6b"; oracle of record ``orc_som_batch``):
+    ``rlen`` passes of ``batch_steps`` mini-batch steps over ``data`` -- THIS RANK's rows when a process group
+    exists (the per-step statistics are all-reduced, every rank returns the same codebook), all rows otherwise.
+    Same arguments as :func:`som` otherwise.  Initial nodes: ``nodes`` if given, else
+    ``data[RandomState(seed).choice(n, K, replace=False)]`` of rank 0's rows (broadcast), the rule ``som`` uses.
+    Not the reference's algorithm: labels equal the batch oracle's, not those of an online pyFlowSOM run."""
+    import torch
+    from . import distributed
+    dev, kernels = _batch_backend()
+    rank, world = distributed.context()
+    arr = data if isinstance(data, torch.Tensor) else np.asarray(data)
+    n, c = int(arr.shape[0]), int(arr.shape[1])
+    k = xdim * ydim
+    if nodes is None:
+        if rank == 0:
+            if n < k:
+                raise ValueError(f"som needs at least as many rows ({n}) as nodes ({k})")
+            src = arr[np.random.RandomState(seed).choice(n, k, replace=False)]
+            nodes = src.cpu().numpy() if hasattr(src, "cpu") else np.asarray(src)
+        nodes = distributed.broadcast_object(nodes, 0)
+    if radius_range is None:
+        radius_range = default_radius_range(xdim, ydim)
+    x = _as_device_matrix(arr, dev)
+    w = torch.from_numpy(np.ascontiguousarray(nodes, dtype=np.float64).reshape(k, c)).to(dev)
+    trainer = distributed.BatchSOMTrainer(xdim, ydim, c, dev, batch_steps=batch_steps, alpha_range=alpha_range,
+                                          radius_range=radius_range, kernels=kernels)
+    trainer.train(x, w, num_passes=rlen)
+    return w.cpu().numpy()
+
+
 def map_data_to_nodes(nodes, newdata, distf: int = 2):
     """Drop-in for ``pyFlowSOM.map_data_to_nodes``: (labels 1-based, distances) of every row."""
     import torch

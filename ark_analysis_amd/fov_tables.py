@@ -124,8 +124,10 @@ class FovTableDir:
         Staging directory present (an earlier run was interrupted): the FOVs not yet staged."""
         if os.path.exists(self.staging):
             done = set(self._tables_in(self.staging))
-            return [os.path.splitext(name)[0] for name in set(self.files()) - done]
+            return [os.path.splitext(name)[0] for name in self.files() if name not in done]
         probe = self.first_readable()
+        if probe is None:
+            raise FileNotFoundError("no readable FOV table (*%s) in %s" % (SUFFIX, self.root))
         if column in probe.columns.values:
             return []
         os.mkdir(self.staging)
@@ -152,20 +154,35 @@ class TablePrefetcher:
         self._fovs = list(fovs)
         self._read = tables.load_arrow if as_arrow else tables.load
         self._slots: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
+        self._stop = threading.Event()
         self._worker = threading.Thread(target=self._fill, name="fov-prefetch", daemon=True)
         self._worker.start()
 
+    def _put(self, item) -> bool:
+        """Queue ``item`` unless the consumer has gone away (``close``): the reader then stops instead of
+        sitting in ``put`` for ever with the tables it has read."""
+        while not self._stop.is_set():
+            try:
+                self._slots.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
+
     def _fill(self) -> None:
         for fov in self._fovs:
+            if self._stop.is_set():
+                return
             try:
                 item = (fov, self._read(fov))
             except UNREADABLE:
                 item = (fov, None)
             except BaseException as err:  # surfaced in the consumer thread
-                self._slots.put((fov, err))
+                self._put((fov, err))
                 break
-            self._slots.put(item)
-        self._slots.put(self._END)
+            if not self._put(item):
+                return
+        self._put(self._END)
 
     def __iter__(self) -> Iterator[Tuple[str, Optional[pd.DataFrame]]]:
         while True:
@@ -175,6 +192,17 @@ class TablePrefetcher:
             if isinstance(item[1], BaseException):
                 raise item[1]
             yield item
+
+    def close(self) -> None:
+        """Stop reading ahead and drop what is queued (call from a ``finally``: a consumer that leaves early --
+        a GPU error, an exception in the caller -- must not leave the reader blocked holding tables)."""
+        self._stop.set()
+        try:
+            while True:
+                self._slots.get_nowait()
+        except queue.Empty:
+            pass
+        self._worker.join(timeout=5.0)
 
 
 class TableWriter:
@@ -206,7 +234,12 @@ class TableWriter:
                 except BaseException as err:
                     self._error = err
 
+    def _raise_if_failed(self) -> None:
+        if self._error is not None:   # stop the stage at the first failed write, not at close()
+            raise self._error
+
     def submit(self, table, path: str) -> None:
+        self._raise_if_failed()
         self._jobs.put((table, path))
 
     def submit_call(self, fn) -> None:
@@ -214,6 +247,7 @@ class TableWriter:
         that must not reach the disk before the tables it describes).  Single-worker writers only."""
         if not self._ordered:
             raise RuntimeError("submit_call needs a single-worker TableWriter (ordered writes)")
+        self._raise_if_failed()
         self._jobs.put(fn)
 
     def close(self) -> None:

@@ -16,9 +16,12 @@ _NOT_FEATURES = ('fov', 'label', 'cell_size')
 def train_cell_som(fovs, base_dir, cell_table_path, cell_som_cluster_cols,
                    cell_som_input_data, som_weights_name='cell_som_weights.feather',
                    xdim=10, ydim=10, lr_start=0.05, lr_end=0.01, num_passes=1, seed=42,
-                   overwrite=False, normalize=True):
+                   overwrite=False, normalize=True, *, train_mode="online", batch_steps=64):
     """Train the cell SOM on ``cell_som_cluster_cols`` of ``cell_som_input_data`` (rows of ``fovs``) and
-    store the codebook in ``base_dir/som_weights_name``; returns the ``CellSOMCluster``."""
+    store the codebook in ``base_dir/som_weights_name``; returns the ``CellSOMCluster``.
+    ``train_mode`` / ``batch_steps`` (keyword-only, beyond the reference): see ``train_pixel_som``."""
+    from .. import distributed
+    distributed.init_from_env()
     validate_paths([cell_table_path])
     verify_in_list(provided_cluster_cols=cell_som_cluster_cols,
                    som_input_cluster_cols=cell_som_input_data.columns.values)
@@ -26,8 +29,9 @@ def train_cell_som(fovs, base_dir, cell_table_path, cell_som_cluster_cols,
     som = cluster_helpers.CellSOMCluster(
         cell_som_input_data, os.path.join(base_dir, som_weights_name), fovs, cell_som_cluster_cols,
         num_passes=num_passes, xdim=xdim, ydim=ydim, lr_start=lr_start, lr_end=lr_end, seed=seed,
-        normalize=normalize)
-    print("Training SOM")
+        normalize=normalize, train_mode=train_mode, batch_steps=batch_steps)
+    if distributed.context()[0] == 0:
+        print("Training SOM")
     som.train_som(overwrite=overwrite)
     return som
 

@@ -10,6 +10,13 @@ on-disk weights format (feather, one row per node, row k <-> label k + 1).  ``py
 
 Objects hold host state only (pandas / numpy) and therefore pickle; device buffers live for one call.
 
+Beyond the reference (keyword-only, defaults = the reference's behaviour): ``train_mode="batch"`` with
+``batch_steps`` trains with the data-parallel batch rule (``flowsom.som_batch``) instead of the sequential
+online rule.  Under ``torchrun`` (``ark_analysis_amd.distributed.init_from_env``) a batch-mode object loads
+only its rank's share of the training tables, the per-step statistics are all-reduced over RCCL, and rank 0
+writes the codebook file; an online-mode object is trained by rank 0 alone and broadcast (the online rule is
+sequential: replicas only).
+
 Deliberate differences:
 * training tables are concatenated in natural-sorted FOV order -- the reference takes ``os.listdir``
   order (:211-215), which is file-system dependent, and the presentation order is an input of the SOM;
@@ -25,7 +32,7 @@ from typing import Iterator, List, Optional, Tuple
 import numpy as np
 import pandas as pd
 
-from .. import flowsom
+from .. import distributed, flowsom
 from ..fov_tables import FovTableDir, read_dataframe, write_dataframe  # noqa: F401  (re-exported)
 from ..host_utils import validate_paths, verify_in_list
 
@@ -52,7 +59,12 @@ class PixieSOMCluster(ABC):
     @abstractmethod
     def __init__(self, weights_path: pathlib.Path, columns: List[str], num_passes: int = 1,
                  xdim: int = 10, ydim: int = 10, lr_start: float = 0.05, lr_end: float = 0.01,
-                 seed=42):
+                 seed=42, *, train_mode: str = "online", batch_steps: int = 64):
+        if train_mode not in ("online", "batch"):
+            raise ValueError("train_mode must be 'online' (the reference's rule) or 'batch', got %r" % (train_mode,))
+        if int(batch_steps) < 1:
+            raise ValueError("batch_steps must be a positive integer")
+        self.train_mode, self.batch_steps = train_mode, int(batch_steps)
         self.weights_path = weights_path
         self.columns = columns
         self.xdim, self.ydim = xdim, ydim
@@ -83,14 +95,22 @@ class PixieSOMCluster(ABC):
         return True
 
     def train_som(self, data: pd.DataFrame):
-        """Fit the xdim x ydim codebook on the rows of ``data`` (FlowSOM online rule, ``num_passes``
-        passes, learning rate ``lr_start`` -> ``lr_end``) and store it next to ``weights_path``."""
-        codebook = flowsom.som(data=_as_f64_matrix(data), xdim=self.xdim, ydim=self.ydim,
-                               rlen=self.num_passes, alpha_range=(self.lr_start, self.lr_end),
-                               seed=self.seed)
+        """Fit the xdim x ydim codebook on the rows of ``data`` (``num_passes`` passes, learning rate
+        ``lr_start`` -> ``lr_end``; FlowSOM online rule, or the batch rule in ``train_mode="batch"``) and store it
+        at ``weights_path``.  With a process group: see the module docstring."""
+        rank, world = distributed.context()
+        args = dict(xdim=self.xdim, ydim=self.ydim, rlen=self.num_passes,
+                    alpha_range=(self.lr_start, self.lr_end), seed=self.seed)
+        if self.train_mode == "batch":
+            codebook = flowsom.som_batch(data=_as_f64_matrix(data), batch_steps=self.batch_steps, **args)
+        else:
+            codebook = flowsom.som(data=_as_f64_matrix(data), **args) if rank == 0 else None
+            codebook = distributed.broadcast_object(codebook, 0)
         nodes = self.xdim * self.ydim
         self.weights = pd.DataFrame(np.asarray(codebook).reshape(nodes, -1), columns=data.columns.values)
-        write_dataframe(self.weights, self.weights_path, compression="uncompressed")
+        if rank == 0:
+            write_dataframe(self.weights, self.weights_path, compression="uncompressed")
+        distributed.barrier()   # nobody goes on to read a half-written codebook file
 
     # ---- assignment -------------------------------------------------------------------------
     def generate_som_clusters(self, external_data: pd.DataFrame,
@@ -120,8 +140,10 @@ class PixelSOMCluster(PixieSOMCluster):
     def __init__(self, pixel_subset_folder: pathlib.Path, norm_vals_path: pathlib.Path,
                  weights_path: pathlib.Path, fovs: List[str], columns: List[str],
                  num_passes: int = 1, xdim: int = 10, ydim: int = 10,
-                 lr_start: float = 0.05, lr_end: float = 0.01, seed=42):
-        super().__init__(weights_path, columns, num_passes, xdim, ydim, lr_start, lr_end, seed)
+                 lr_start: float = 0.05, lr_end: float = 0.01, seed=42, *,
+                 train_mode: str = "online", batch_steps: int = 64):
+        super().__init__(weights_path, columns, num_passes, xdim, ydim, lr_start, lr_end, seed,
+                         train_mode=train_mode, batch_steps=batch_steps)
         validate_paths([norm_vals_path, pixel_subset_folder])
 
         self.fovs = fovs
@@ -130,7 +152,13 @@ class PixelSOMCluster(PixieSOMCluster):
 
         wanted = set(fovs)
         subset = FovTableDir(pixel_subset_folder)
-        parts = [subset.load(fov) for fov in subset.fovs() if fov in wanted]
+        mine = [fov for fov in subset.fovs() if fov in wanted]
+        if self.train_mode == "batch":
+            # data-parallel training: every rank holds its share of the FOVs (all of them without a process group)
+            mine = distributed.shard(mine) or mine[:0]
+        parts = [subset.load(fov) for fov in mine]
+        if not parts:   # more ranks than FOVs: an empty table with the right columns
+            parts = [subset.load(subset.fovs()[0]).iloc[:0]]
         # the training matrix is only ever used normalised
         self.train_data = self.normalize_data(pd.concat(parts))
 
@@ -168,8 +196,9 @@ class CellSOMCluster(PixieSOMCluster):
     def __init__(self, cell_data: pd.DataFrame, weights_path: pathlib.Path,
                  fovs: List[str], columns: List[str], num_passes: int = 1,
                  xdim: int = 10, ydim: int = 10, lr_start: float = 0.05, lr_end: float = 0.01,
-                 seed=42, normalize=True):
-        super().__init__(weights_path, columns, num_passes, xdim, ydim, lr_start, lr_end, seed)
+                 seed=42, normalize=True, *, train_mode: str = "online", batch_steps: int = 64):
+        super().__init__(weights_path, columns, num_passes, xdim, ydim, lr_start, lr_end, seed,
+                         train_mode=train_mode, batch_steps=batch_steps)
         self.fovs = fovs
         in_cohort = cell_data["fov"].isin(fovs)
         self.cell_data = cell_data[in_cohort].reset_index(drop=True)
@@ -184,10 +213,24 @@ class CellSOMCluster(PixieSOMCluster):
 
     def train_som(self, overwrite=False):
         if self._needs_training(overwrite):
-            super().train_som(self.cell_data[self.columns])
+            rows = self.cell_data[self.columns]
+            if self.train_mode == "batch":
+                rank, world = distributed.context()
+                rows = rows.iloc[rank::world]     # every rank holds the whole table: a strided share each
+            super().train_som(rows)
 
     def assign_som_clusters(self, num_parallel_cells=1000000) -> pd.DataFrame:
-        """Adds ``cell_som_cluster`` to ``cell_data`` and returns the table."""
-        self.cell_data["cell_som_cluster"] = self.generate_som_clusters(
-            self.cell_data[self.columns], num_parallel_obs=num_parallel_cells)
+        """Adds ``cell_som_cluster`` to ``cell_data`` and returns the table.  With a process group every rank
+        labels a contiguous block of the cells and the blocks are gathered."""
+        rank, world = distributed.context()
+        table = self.cell_data[self.columns]
+        if world > 1:
+            bounds = np.linspace(0, len(table), world + 1).astype(np.int64)
+            part = self.generate_som_clusters(table.iloc[bounds[rank]:bounds[rank + 1]],
+                                              num_parallel_obs=num_parallel_cells)
+            blocks = [b for b in distributed.allgather_objects(part) if len(b)]
+            labels = np.concatenate(blocks) if blocks else np.empty(0)
+        else:
+            labels = self.generate_som_clusters(table, num_parallel_obs=num_parallel_cells)
+        self.cell_data["cell_som_cluster"] = labels
         return self.cell_data

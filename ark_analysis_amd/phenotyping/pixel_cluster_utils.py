@@ -129,6 +129,23 @@ class _ClusterTotals:
         sums, counts = som_device.cluster_sums(planar.t().contiguous(), (dense + 1).to(torch.int32), int(distinct.numel()))
         self._merge(distinct.cpu().numpy(), sums.cpu().numpy(), counts.cpu().numpy())
 
+    def merge_ranks(self) -> None:
+        """Totals of every rank united on every rank (one gather of the small per-cluster tables; ids are
+        dictionary keys, so ranks that met different clusters merge cleanly).  Summation in rank order."""
+        from .. import distributed
+        if distributed.context()[1] <= 1:
+            return
+        parts = distributed.allgather_objects((self._sum, self._n))
+        self._sum, self._n = {}, {}
+        for sums, counts in parts:
+            for cid in sums:
+                if cid in self._sum:
+                    self._sum[cid] = self._sum[cid] + sums[cid]
+                    self._n[cid] += counts[cid]
+                else:
+                    self._sum[cid] = np.array(sums[cid], dtype=np.float64)
+                    self._n[cid] = int(counts[cid])
+
     def __len__(self):
         return len(self._sum)
 
@@ -167,15 +184,22 @@ def compute_pixel_cluster_channel_avg(fovs, channels, base_dir, pixel_cluster_co
     tables = FovTableDir(os.path.join(base_dir, pixel_data_dir))
     totals = _ClusterTotals(channels)
     # tables are read one ahead on a background thread; with the device entry point in place (tests may swap
-    # it) they stay Arrow tables and never become DataFrames
+    # it) they stay Arrow tables and never become DataFrames.  With a process group every rank takes its share
+    # of the chosen files (the same list everywhere: it comes from the seeded draw above).
+    from .. import distributed
     on_device = flowsom.cluster_sums is _DEVICE_SUMS
-    for fov, table in TablePrefetcher(tables, chosen, as_arrow=on_device):
-        if table is None:
-            print("The data for FOV %s has been corrupted, skipping" % fov)
-        elif on_device:
-            totals.add_arrow(table, pixel_cluster_col)
-        else:
-            totals.add_table(table, pixel_cluster_col)
+    feed = TablePrefetcher(tables, distributed.shard(chosen), as_arrow=on_device)
+    try:
+        for fov, table in feed:
+            if table is None:
+                print("The data for FOV %s has been corrupted, skipping" % fov)
+            elif on_device:
+                totals.add_arrow(table, pixel_cluster_col)
+            else:
+                totals.add_table(table, pixel_cluster_col)
+    finally:
+        feed.close()
+    totals.merge_ranks()
 
     if len(totals) == 0:
         raise ValueError("No objects to concatenate")   # what pd.concat([]) says in the reference

@@ -16,9 +16,9 @@ worker copies.
 import os
 from typing import Any, Callable, Tuple
 
-from .. import arrow_assign, flowsom, fov_tables
+from .. import arrow_assign, distributed, flowsom, fov_tables
 from ..fov_tables import FovTableDir, TablePrefetcher, TableWriter
-from ..host_utils import validate_paths, verify_in_list, verify_same_elements
+from ..host_utils import natsorted, validate_paths, verify_in_list, verify_same_elements
 from . import cluster_helpers, pixel_cluster_utils
 
 _CORRUPT = "The data for FOV %s has been corrupted, skipping"
@@ -29,9 +29,14 @@ def train_pixel_som(fovs, channels, base_dir,
                     norm_vals_name='post_rowsum_chan_norm.feather',
                     som_weights_name='pixel_som_weights.feather', xdim=10, ydim=10,
                     lr_start=0.05, lr_end=0.01, num_passes=1, seed=42,
-                    overwrite=False):
+                    overwrite=False, *, train_mode="online", batch_steps=64):
     """Train the pixel SOM on the sub-sampled tables of ``base_dir/subset_dir`` and store the codebook
-    in ``base_dir/som_weights_name``; returns the :class:`~.cluster_helpers.PixelSOMCluster`."""
+    in ``base_dir/som_weights_name``; returns the :class:`~.cluster_helpers.PixelSOMCluster`.
+
+    Beyond the reference (keyword-only): ``train_mode="batch"`` selects the data-parallel batch rule with
+    ``batch_steps`` mini-batch steps per pass (throughput mode; under ``torchrun`` the training tables are
+    sharded by rank and the per-step statistics all-reduced).  The default is the reference's online rule."""
+    distributed.init_from_env()
     subset_root = os.path.join(base_dir, subset_dir)
     norm_file = os.path.join(base_dir, norm_vals_name)
     validate_paths([subset_root, norm_file])   # the weights file may legitimately not exist yet
@@ -43,10 +48,17 @@ def train_pixel_som(fovs, channels, base_dir,
 
     som = cluster_helpers.PixelSOMCluster(
         subset_root, norm_file, os.path.join(base_dir, som_weights_name), fovs, channels,
-        num_passes=num_passes, xdim=xdim, ydim=ydim, lr_start=lr_start, lr_end=lr_end, seed=seed)
-    print("Training SOM")
+        num_passes=num_passes, xdim=xdim, ydim=ydim, lr_start=lr_start, lr_end=lr_end, seed=seed,
+        train_mode=train_mode, batch_steps=batch_steps)
+    _say("Training SOM")
     som.train_som(overwrite=overwrite)
     return som
+
+
+def _say(*args) -> None:
+    """The reference's progress lines, once per job: rank 0 prints, the other ranks stay silent."""
+    if distributed.context()[0] == 0:
+        print(*args)
 
 
 _DEVICE_BMU = flowsom.map_data_to_nodes   # the real device entry point (tests may swap the attribute)
@@ -82,7 +94,10 @@ def run_pixel_som_assignment(pixel_data_path, pixel_pysom_obj, overwrite, num_pa
 def _check_columns_against(som, tables: FovTableDir) -> None:
     """The first readable table must carry exactly the channels of the norm row and of the codebook,
     in the same order."""
-    probe = fov_tables.unify_label_column(tables.first_readable())
+    probe = tables.first_readable()
+    if probe is None:
+        raise FileNotFoundError("no readable FOV table in %s" % tables.root)
+    probe = fov_tables.unify_label_column(probe)
     channels = fov_tables.feature_columns(probe).values
     verify_same_elements(enforce_order=True, norm_vals_columns=som.norm_data.columns.values,
                          pixel_data_columns=channels)
@@ -105,33 +120,40 @@ def cluster_pixels(fovs, base_dir, pixel_pysom, data_dir='pixel_mat_data',
     verify_in_list(provided_fovs=fovs, subsetted_fovs=tables.fovs())
     _check_columns_against(pixel_pysom, tables)
 
+    rank, world = distributed.init_from_env()
     if overwrite:
-        print('Overwrite flag set, reassigning SOM cluster labels to all FOVs')
+        _say('Overwrite flag set, reassigning SOM cluster labels to all FOVs')
         pixel_pysom.som_clusters_seen = set()
-        tables.open_staging()
+        if rank == 0:
+            tables.open_staging()
         todo = tables.fovs()
     else:
-        todo = pixel_cluster_utils.find_fovs_missing_col(base_dir, data_dir, 'pixel_som_cluster')
-    todo = list(set(todo).intersection(fovs))
+        # (creates the staging directory on a fresh run: one rank decides, everybody uses its answer)
+        todo = pixel_cluster_utils.find_fovs_missing_col(base_dir, data_dir, 'pixel_som_cluster') if rank == 0 else None
+        todo = distributed.broadcast_object(todo, 0)
+    distributed.barrier()
+    todo = natsorted(set(todo).intersection(fovs))   # one order on every rank: FOVs are dealt round robin
 
     if not todo:
-        print("There are no more FOVs to assign SOM labels to, skipping")
+        _say("There are no more FOVs to assign SOM labels to, skipping")
         return
     if len(todo) < len(fovs):
-        print("Restarting SOM label assignment from fov %s, "
-              "%d fovs left to process" % (todo[0], len(todo)))
-    print("Mapping pixel data to SOM cluster labels")
+        _say("Restarting SOM label assignment from fov %s, "
+             "%d fovs left to process" % (todo[0], len(todo)))
+    _say("Mapping pixel data to SOM cluster labels")
 
     # progress is reported per group: batch_size FOVs when multiprocess, else every 10th FOV + the last
+    mine = distributed.shard(todo, rank, world)
     group = batch_size if multiprocess else 1
     done = 0
     writer = TableWriter(depth=4, workers=3)      # FOV tables are independent: written side by side
+    feed = TablePrefetcher(tables, mine, as_arrow=True)
     try:
-        feed = iter(TablePrefetcher(tables, todo, as_arrow=True))
-        for names in fov_tables.batches(todo, group):
+        rows = iter(feed)
+        for names in fov_tables.batches(mine, group):
             spoiled = []
             for _ in names:
-                fov, table = next(feed)
+                fov, table = next(rows)
                 if table is None:
                     spoiled.append(fov)
                     continue
@@ -140,12 +162,23 @@ def cluster_pixels(fovs, base_dir, pixel_pysom, data_dir='pixel_mat_data',
             for fov in spoiled:
                 print(_CORRUPT % fov)
             done += len(names) - len(spoiled)
-            if multiprocess or done % 10 == 0 or done == len(todo):
+            if world == 1 and (multiprocess or done % 10 == 0 or done == len(todo)):
                 print("Processed %d fovs" % done)
     finally:
+        feed.close()
         writer.close()
 
-    tables.commit(on_rm_error=_ignore_extended_attributes)
+    if world > 1:
+        # FOV files were dealt round robin: what the ranks saw is united, then one rank swaps the directories
+        seen = set()
+        for part in distributed.allgather_objects(sorted(pixel_pysom.som_clusters_seen)):
+            seen.update(part)
+        pixel_pysom.som_clusters_seen = seen
+        total = sum(distributed.allgather_objects(done))
+        _say("Processed %d fovs" % total)
+    if rank == 0:
+        tables.commit(on_rm_error=_ignore_extended_attributes)
+    distributed.barrier()
 
 
 def _ignore_extended_attributes(func: Callable, filename: str, exc_info: Tuple[Any, Any, Any]):
@@ -166,15 +199,20 @@ def generate_som_avg_files(fovs, channels, base_dir, pixel_pysom, data_dir='pixe
     if pixel_pysom.weights is None:
         raise ValueError("Using untrained pixel_pysom object, please invoke train_som first")
 
-    if os.path.exists(target):
+    rank, _ = distributed.init_from_env()
+    exists = distributed.broadcast_object(os.path.exists(target) if rank == 0 else None, 0)
+    if exists:
         if not overwrite:
-            print("Already generated SOM cluster channel average file, skipping")
+            _say("Already generated SOM cluster channel average file, skipping")
             return
-        print("Overwrite flag set, regenerating SOM cluster channel average file")
+        _say("Overwrite flag set, regenerating SOM cluster channel average file")
 
-    print("Computing average channel expression across pixel SOM clusters")
+    _say("Computing average channel expression across pixel SOM clusters")
     expected = len(pixel_pysom.som_clusters_seen) if require_all_som_clusters else None
+    # (with a process group the chosen FOV files are dealt to the ranks and the totals all-reduced)
     means = pixel_cluster_utils.compute_pixel_cluster_channel_avg(
         fovs, channels, base_dir, 'pixel_som_cluster', expected, data_dir,
         num_fovs_subset=num_fovs_subset, seed=seed, keep_count=True)
-    means.to_csv(target, index=False)
+    if rank == 0:
+        means.to_csv(target, index=False)
+    distributed.barrier()

@@ -130,7 +130,8 @@ int pxsom_train_online(const void *x_dev, int64_t n, int c, int64_t ldx, int dty
  *               returns them); stats[b, :] += x_i, stats_count[b] += 1 for b = label_i - 1.
  *   update:     num[k] = sum_{b: cheb(k,b) <= thr} sums[b], den[k] = sum_{b: ...} counts[b]
  *               (summed in orc_batch_update's separable order: along y inside a grid row, then over the rows)
- *               den[k] > 0:  w[k] += (1 - (1-alpha)^den[k]) * (num[k]/den[k] - w[k])
+ *               den[k] > 0:  w[k] += (1 - (1-alpha)^den[k]) * (num[k] * (1/den[k]) - w[k])
+ *               (the gain is formed as -expm1(den * log1p(-alpha)))
  *   update_prepare: the same update with sums/counts = the two halves of stats_dev; the same launch clears
  *               stats_next_dev, the buffer the next accumulate will fill (alternate two buffers; NULL or
  *               == stats_dev: cleared by a separate fill), so the next

@@ -41,7 +41,9 @@ int main(int argc, char **argv)
             sa.stats_prev = dring + ((g + 2) % 3) * ns; sa.stats_zero = dring + ((g + 1) % 3) * ns;
             sa.zero_count = (int)ns; sa.has_update = g > 0;
             double thr = 6.0 - 6.0 * (g > 0 ? g - 1 : 0) / M; if (thr < 1) thr = 0.5;
-            sa.thr = thr; sa.alpha = 0.05 - 0.04 * (g > 0 ? g - 1 : 0) / M;
+            sa.thr = thr; sa.lg = log1p(-(0.05 - 0.04 * (g > 0 ? g - 1 : 0) / M));
+            sa.tol_rel = (float)(2.5 * (ldexp(1.0, -16) + (3.0 * c + 2.0) * ldexp(1.0, -24) + ldexp(1.0, -19) + ldexp(1.0, -23)));
+            sa.tol_abs = (float)(2.5 * ldexp(1.0, -24) * sqrt((double)c));
             const int64_t rows = (n - g + M - 1) / M;
             int rc = launch_batch_step<float>(dx + (size_t)g * c, rows, c, (int64_t)c * M, dring + (g % 3) * ns, sa, tpw, 0);
             if (rc) { printf("rc %d %s\n", rc, pxsom_last_error()); return 1; }

@@ -6,6 +6,8 @@ so that the reference's *own Python* around the two pyFlowSOM calls can be execu
 generate end-to-end fixtures; the SOM arithmetic inside those fixtures is oracle-of-record =
 build restatement ("parity unpinned", see oracle/README.md).
 """
+import os
+
 import numpy as np
 
 
@@ -19,6 +21,9 @@ def som(data, xdim=10, ydim=10, rlen=10, alpha_range=(0.05, 0.01), radius_range=
     codes = data[init_idx].copy() if nodes is None else np.array(nodes, dtype=np.float64)
     if radius_range is None:
         radius_range = default_radius_range(xdim, ydim)
+    steps = os.environ.get("PXSOM_SHIM_BATCH_STEPS")
+    if steps:   # make_golden.py g7b: the same reference pipeline with the build's batch rule underneath
+        return ob.som_batch(data, codes, xdim, ydim, rlen, alpha_range, radius_range, int(steps))
     return ob.som_online(data, codes, xdim, ydim, rlen, alpha_range, radius_range, order)
 
 

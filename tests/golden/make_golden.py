@@ -158,9 +158,24 @@ def g6_som():
     save("g6_som_oracle", **out)
 
 
+def g7b_batch_mode():
+    """g7's pixel pipeline once more with the shim's som() running the build's BATCH rule (8 mini-batch steps):
+    the fixture of train_pixel_som(..., train_mode="batch", batch_steps=8)."""
+    os.environ["PXSOM_SHIM_BATCH_STEPS"] = "8"
+    try:
+        _g7_pixel("g7b_pixel_pipeline_batch")
+    finally:
+        del os.environ["PXSOM_SHIM_BATCH_STEPS"]
+
+
 def g7_end_to_end():
     """The reference's own train_pixel_som -> cluster_pixels -> generate_som_avg_files, with the
     pyFlowSOM shim (oracle) underneath: fixtures for the drop-in pipeline functions."""
+    _g7_pixel("g7_pixel_pipeline")
+    _g7_cell()
+
+
+def _g7_pixel(name):
     rs = np.random.RandomState(11)
     chans = ["chan%d" % i for i in range(4)]
     fovs = ["fov0", "fov1", "fov2"]
@@ -203,8 +218,10 @@ def g7_end_to_end():
         arrays["avg_means"] = avg[chans].values
         arrays["avg_count"] = avg["count"].values.astype(np.int64)
         arrays["clusters_seen"] = np.array(sorted(int(v) for v in obj.som_clusters_seen), dtype=np.int64)
-    save("g7_pixel_pipeline", **arrays)
+    save(name, **arrays)
 
+
+def _g7_cell():
     # cell path (reference: cell_som_clustering.py + CellSOMCluster 99.9 % normalisation)
     rs = np.random.RandomState(12)
     cols = ["pixel_meta_cluster_%d" % i for i in range(1, 9)]
@@ -372,7 +389,7 @@ def g10_pixel_cluster_mask():
 
 if __name__ == "__main__":
     ob.build()
-    steps = {"g1": g1_normalize, "g2": g2_g5_preprocess, "g3": g3_quantiles, "g4": g4_cluster_avg, "g6": g6_som,
+    steps = {"g1": g1_normalize, "g2": g2_g5_preprocess, "g3": g3_quantiles, "g4": g4_cluster_avg, "g6": g6_som, "g7b": g7b_batch_mode,
              "g7": g7_end_to_end, "g8": g8_c2pc, "g9": g9_create_pixel_matrix, "g10": g10_pixel_cluster_mask}
     for name in (sys.argv[1:] or list(steps)):
         steps[name]()

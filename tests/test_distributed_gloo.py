@@ -15,43 +15,7 @@ from ark_analysis_amd.distributed import (BatchSOMTrainer, allreduce_cluster_tab
                                           broadcast_codebook)
 
 
-class OracleKernels:
-    """Same interface as distributed.HipKernels, backed by oracle/pxsom_oracle.c (tests only)."""
-
-    def begin(self, x, w, xdim, ydim, batch_steps):
-        self.xdim, self.ydim, self.m = xdim, ydim, batch_steps
-        k, c = w.shape
-        self.w = [w.clone(), w.clone()]
-        self.rings = [torch.zeros(k * (c + 1), dtype=torch.float64) for _ in range(3)]
-
-    def ring(self, g):
-        return self.rings[g % 3]
-
-    def _update(self, w, g, total, alpha_range, radius_range):
-        from tests import oracle_binding as ob
-        k, c = w.shape
-        thr, alpha = batch_schedule(g, total, alpha_range, radius_range)
-        st = self.rings[g % 3]
-        return torch.from_numpy(ob.batch_update(w.numpy(), self.xdim, self.ydim, st[: k * c].view(k, c).numpy(),
-                                                st[k * c:].numpy().astype(np.int64), thr, alpha))
-
-    def steps(self, x, g0, g1, total, alpha_range, radius_range):
-        from tests import oracle_binding as ob
-        for g in range(g0, g1):
-            if g > 0:
-                self.w[g % 2] = self._update(self.w[(g - 1) % 2], g - 1, total, alpha_range, radius_range)
-            w = self.w[g % 2]
-            k, c = w.shape
-            xn = np.ascontiguousarray(x[(g % self.m)::self.m].numpy(), dtype=np.float64)
-            lab, _ = ob.map_data_to_nodes(w.numpy(), xn)
-            s, cnt = ob.cluster_sums(xn, lab, k)
-            st = self.rings[g % 3]
-            st[: k * c].copy_(torch.from_numpy(s.reshape(-1)))
-            st[k * c:].copy_(torch.from_numpy(cnt.astype(np.float64)))
-
-    def finish(self, steps_done, total, alpha_range, radius_range, w):
-        g = steps_done - 1
-        w.copy_(self._update(self.w[g % 2], g, total, alpha_range, radius_range))
+from tests.oracle_backend import OracleKernels  # noqa: E402
 
 
 def _free_port():

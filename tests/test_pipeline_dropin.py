@@ -58,6 +58,40 @@ def test_pixel_pipeline_matches_reference_run(som_backend, tmp_path, capsys):
     np.testing.assert_allclose(avg[CHANS].values, g["avg_means"], rtol=1e-12, atol=0)
 
 
+def test_pixel_pipeline_batch_mode_matches_fixture(som_backend, tmp_path, capsys):
+    """train_pixel_som(..., train_mode="batch", batch_steps=8) -> cluster_pixels -> generate_som_avg_files against
+    the reference's own pipeline run with the build's batch rule underneath (g7b; oracle of record orc_som_batch)."""
+    g = np.load(os.path.join(GOLD, "g7b_pixel_pipeline_batch.npz"))
+    td = str(tmp_path)
+    _build_pixel_dirs(td, g)
+    obj = pixel_som_clustering.train_pixel_som(FOVS, CHANS, td, num_passes=1, seed=42, train_mode="batch",
+                                               batch_steps=8)
+    assert obj.train_mode == "batch" and obj.batch_steps == 8
+    pixel_som_clustering.cluster_pixels(FOVS, td, obj)
+    pixel_som_clustering.generate_som_avg_files(FOVS, CHANS, td, obj, data_dir="pixel_mat_data")
+    assert capsys.readouterr().out == str(g["stdout"])
+    assert list(obj.weights.columns) == CHANS
+    # batch rule: 1e-9 (device expm1 / atomic summation order against libm / sequential sums)
+    np.testing.assert_allclose(obj.weights.values, g["weights"], rtol=1e-9, atol=0)
+    np.testing.assert_array_equal(read_dataframe(os.path.join(td, "pixel_som_weights.feather")).values,
+                                  obj.weights.values)
+    from tests import oracle_binding as ob
+    for fov in FOVS:
+        res = read_dataframe(os.path.join(td, "pixel_mat_data", fov + ".feather"))
+        np.testing.assert_array_equal(res[CHANS].values, g["normed_" + fov])
+        # labels: bit-exact for the codebook that was actually trained; against the fixture a last-bit difference
+        # of the codebook may flip a near-tie
+        want, _ = ob.map_data_to_nodes(obj.weights.values, res[CHANS].values)
+        np.testing.assert_array_equal(res["pixel_som_cluster"].values, want)
+        assert np.mean(res["pixel_som_cluster"].values != g["labels_" + fov]) < 2e-3
+    if som_backend == "oracle":
+        np.testing.assert_array_equal(obj.weights.values, g["weights"])
+    with pytest.raises(ValueError, match="train_mode"):
+        pixel_som_clustering.train_pixel_som(FOVS, CHANS, td, train_mode="minibatch")
+    with pytest.raises(ValueError, match="batch_steps"):
+        pixel_som_clustering.train_pixel_som(FOVS, CHANS, td, train_mode="batch", batch_steps=0)
+
+
 def test_cell_pipeline_matches_reference_run(som_backend, tmp_path, capsys):
     g = np.load(os.path.join(GOLD, "g7_cell_pipeline.npz"))
     cols = ["pixel_meta_cluster_%d" % i for i in range(1, 9)]
