@@ -1,29 +1,44 @@
 #!/usr/bin/env python
 """bench.py -- Pixie pixel-SOM train + assign throughput on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg3|cfg4|cfg5]
+    (N > 1 without RANK in the environment: re-executes itself under torch.distributed.run, one rank per GPU;
+     fails loudly when the box has fewer than N devices)
 
 One "step" = one pass of the hot path over one batch of synthetic input, resident in HBM before
 the clock starts ("normalised pixel matrix resident" -> "labels + codebook + mean table
-resident"):  batch-mode SOM training (1 pass over the 10 % training subset, `--batch-steps` mini-batch
-steps, statistics all-reduced over RCCL when N > 1)  +  BMU assignment of every pixel  +  the per-cluster
-mean-expression table over all pixels (sums/counts all-reduced once when N > 1).
-Workload at N = 1: BASELINE.json configs[1] (10 FOVs 1024x1024x22 fp32, 10x10 SOM); weak scaling:
-every rank holds its own `--fovs-per-gpu` FOVs.  Rank 0 prints ONE JSON line.
+resident"):  batch-mode SOM training (1 pass over the training subset, `--batch-steps` mini-batch
+steps, statistics all-reduced over RCCL when N > 1)  +  BMU assignment of every row  +  the per-cluster
+mean-expression table over all rows (sums/counts all-reduced once when N > 1).
+Workloads (`--config`; BASELINE.json configs):
+  cfg2  10 FOVs 1024x1024x22 fp32 per GPU, 10x10 SOM     (configs[1] at N = 1; the metric's configuration; default)
+  cfg3  25 FOVs 1024x1024x22 fp32 per GPU, 10x10 SOM     (configs[2]: 200 FOVs over 8 GPUs)
+  cfg4  1e6 cells x 100 features fp32 in total, 10x10 SOM, trained on every row (configs[3]; strong scaling)
+  cfg5  FOVs 2048x2048x40 fp16, 20x20 SOM                (configs[4]; `--fovs-per-gpu`, default 4)
+Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline     dominant kernel = bmu_filter_kernel over all pixels; achieved = 92 B/pixel
-               (22*4 read + 4 label written, DESIGN.md "K7") * pixels / its HIP-event duration.
-  cpu_baseline the oracle (port of the reference algorithm: online FlowSOM training on the same
-               training subset + reference-shaped BMU search) on ONE host core; bounded sample.
-  online_train the exact-online (reference-order) training kernel on the same subset, checked
-               against the oracle's codebook from the cpu_baseline leg (full-size parity).
+  roofline       dominant kernel = the BMU filter kernel over all rows; achieved = (C*s + 4) B/row (row read once +
+                 int32 label written, DESIGN.md "K7") * rows / its HIP-event duration; traffic = HBM bytes per launch
+                 from rocprofv3 PMC passes of this same script run inside the call (FETCH_SIZE x 2 + WRITE_SIZE, the
+                 gfx950 correction of MI355X_MICROARCH.md), or the recorded value if the profiler cannot run.
+  roofline_step  the whole step against the HBM roofline: SURVEY 8(d)'s B = C*s*(1 + f*p) + 4 bytes per row.
+  mfma_util      matrix-pipe busy cycles / (SIMDs x kernel cycles) of the filter kernel, same PMC run.
+  cpu_baseline   the oracle (port of the reference algorithm: online FlowSOM training on the same
+                 training subset + reference-shaped BMU search) on ONE host core; bounded sample.
+  batch_train    the timed training mode's codebook against orc_som_batch at FULL size (rtol 1e-9).
+  online_train   the exact-online (reference-order) training kernel on the same subset, checked
+                 against the oracle's codebook from the cpu_baseline leg (full-size parity).
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -39,10 +54,22 @@ from ark_analysis_amd.distributed import (BatchSOMTrainer, allreduce_cluster_tab
 from ark_analysis_amd.flowsom import default_radius_range  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PIXELS_PER_FOV = 1024 * 1024
-CHANNELS = 22
-XDIM = YDIM = 10
-BYTES_PER_PIXEL_ASSIGN = CHANNELS * 4 + 4   # algorithmic bytes of the assign kernel (fp32 in, i32 out)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 / bf16 MFMA peak (same guide)
+N_SIMDS = 1024                 # 256 CUs x 4
+N_XCDS = 8                     # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs
+
+CONFIGS = {
+    "cfg2": dict(kind="pixel", c=22, xdim=10, ydim=10, dtype="f32", unit_rows=1024 * 1024, units=10, frac=0.1,
+                 scaling="weak", desc="{u} FOVs 1024x1024x22ch fp32 per GPU, 10x10 SOM (BASELINE.json configs[1] at N=1)"),
+    "cfg3": dict(kind="pixel", c=22, xdim=10, ydim=10, dtype="f32", unit_rows=1024 * 1024, units=25, frac=0.1,
+                 scaling="weak", desc="{u} FOVs 1024x1024x22ch fp32 per GPU, 10x10 SOM (BASELINE.json configs[2]: 200 FOVs over 8 GPUs)"),
+    "cfg4": dict(kind="cell", c=100, xdim=10, ydim=10, dtype="f32", unit_rows=1_000_000, units=1, frac=1.0,
+                 scaling="strong", desc="1e6 cells x 100 pixel-cluster-count features fp32 in total, 10x10 SOM, trained on all rows "
+                                        "(BASELINE.json configs[3])"),
+    "cfg5": dict(kind="pixel", c=40, xdim=20, ydim=20, dtype="f16", unit_rows=2048 * 2048, units=4, frac=0.1,
+                 scaling="weak", desc="{u} FOVs 2048x2048x40ch fp16 per GPU, 20x20 SOM (BASELINE.json configs[4] shape; 62 per GPU at "
+                                      "full size)"),
+}
 
 
 def parse():
@@ -50,11 +77,84 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--fovs-per-gpu", type=int, default=10)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
+    ap.add_argument("--fovs-per-gpu", type=int, default=None)
     ap.add_argument("--batch-steps", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-online", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (traffic / mfma_util)")
+    ap.add_argument("--pmc-inner", action="store_true", help=argparse.SUPPRESS)   # the run rocprofv3 wraps
     return ap.parse_args()
+
+
+def respawn_under_torchrun(args):
+    """`--gpus N` from a plain shell: one rank per GPU through torch.distributed.run (the driver's own launch line)."""
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but this box exposes {have} HIP device(s); "
+                         f"refusing to run a smaller job under that name")
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def make_rows(cfg, n_units, rank, dev):
+    """This rank's rows in HBM: every rank owns different FOVs / cells."""
+    c = cfg["c"]
+    tdt = torch.float16 if cfg["dtype"] == "f16" else torch.float32
+    if cfg["kind"] == "cell":
+        # cells: pixel-cluster counts Poisson(3) / cell_size U(50, 500), 99.9 %-normalised per column
+        n = n_units
+        g = torch.Generator(device=dev)
+        g.manual_seed(2000 + rank)
+        x = torch.poisson(torch.full((n, c), 3.0, device=dev), generator=g)
+        x.div_(torch.empty((n, 1), device=dev).uniform_(50.0, 500.0, generator=g))
+        q = torch.quantile(x[: min(n, 1 << 20)].float(), 0.999, dim=0)
+        q[q == 0] = 1.0
+        return x.div_(q).to(tdt).contiguous()
+    p = cfg["unit_rows"]
+    x = torch.empty((n_units * p, c), dtype=tdt, device=dev)
+    for f in range(n_units):
+        x[f * p:(f + 1) * p] = synth.make_fov_torch(p, c, seed=1000 + rank * n_units + f, device=dev, dtype=tdt)
+    return x
+
+
+def pmc_passes(argv_inner, kernel_substr="bmu_filter"):
+    """rocprofv3 counter passes over a short run of this script (its own processes; kernel-trace + pmc only).
+    Returns {"FETCH_SIZE": v, ...} = per-dispatch means for the biggest launch of the filter kernel, or {}."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {}
+    out = {}
+    passes = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_MFMA", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"]]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counters in passes:
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            cmd = [exe, "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", td, "-o", "pmc", "--",
+                   sys.executable, os.path.abspath(__file__), *argv_inner]
+            try:
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240,
+                               check=True)
+            except Exception:
+                continue
+            rows = []
+            for f in glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True):
+                rows += [r for r in csv.DictReader(open(f)) if kernel_substr in r["Kernel_Name"]]
+            if not rows:
+                continue
+            big = max(int(r.get("Grid_Size", "0") or 0) for r in rows)     # the launch over all rows
+            for name in counters:
+                vals = [float(r["Counter_Value"]) for r in rows
+                        if r["Counter_Name"] == name and int(r.get("Grid_Size", "0") or 0) == big]
+                if vals:
+                    out[name] = sum(vals) / len(vals)
+    return out
 
 
 def main():
@@ -62,9 +162,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        respawn_under_torchrun(args)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     _capi.require_gpu()
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} has no device (LOCAL_RANK={local_rank}, {torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or "RANK" in os.environ     # launched by torch.distributed.run
@@ -74,13 +178,20 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
-    F, P, C, K = args.fovs_per_gpu, PIXELS_PER_FOV, CHANNELS, XDIM * YDIM
-    n_all = F * P
-    # ---- synthetic input, generated in HBM; every rank owns different FOVs
-    x_all = torch.empty((n_all, C), dtype=torch.float32, device=dev)
-    for f in range(F):
-        x_all[f * P:(f + 1) * P] = synth.make_fov_torch(P, C, seed=1000 + rank * F + f, device=dev)
-    x_train = x_all[::10].contiguous()            # 10 % training subset (every 10th retained pixel)
+    cfg = CONFIGS[args.config]
+    C, XD, YD = cfg["c"], cfg["xdim"], cfg["ydim"]
+    K = XD * YD
+    esize = 2 if cfg["dtype"] == "f16" else 4
+    if cfg["kind"] == "cell":
+        n_units = cfg["unit_rows"] // world            # strong scaling: the table is split over the ranks
+        units_label = n_units
+    else:
+        n_units = args.fovs_per_gpu if args.fovs_per_gpu else cfg["units"]
+        units_label = n_units
+    x_all = make_rows(cfg, n_units, rank, dev)
+    n_all = x_all.shape[0]
+    stride = int(round(1.0 / cfg["frac"]))
+    x_train = x_all if stride == 1 else x_all[::stride].contiguous()   # training subset (every 10th retained pixel)
     n_train = x_train.shape[0]
     g = torch.Generator(device="cpu")
     g.manual_seed(42)
@@ -90,13 +201,13 @@ def main():
     w = w0.clone()
     labels = torch.empty(n_all, dtype=torch.int32, device=dev)
     ws_all = som_device.AssignWorkspace(n_all, C, K, dev)
-    trainer = BatchSOMTrainer(XDIM, YDIM, C, dev, batch_steps=args.batch_steps)
+    trainer = BatchSOMTrainer(XD, YD, C, dev, batch_steps=args.batch_steps)
     k8_sums = torch.empty((K, C), dtype=torch.float64, device=dev)
     k8_counts = torch.empty(K, dtype=torch.int64, device=dev)
     means = torch.empty((K, C), dtype=torch.float64, device=dev)
 
     def mean_table():
-        """K8: per-cluster channel means over every pixel of every rank."""
+        """K8: per-cluster channel means over every row of every rank."""
         k8_sums.zero_()
         k8_counts.zero_()
         som_device.cluster_sums(x_all, labels, K, sums=k8_sums, counts=k8_counts)
@@ -146,61 +257,113 @@ def main():
     k8_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_k8]))
     exact_rows = som_device.last_exact_rows(ws_all)
 
-    if rank != 0:
+    if rank != 0 or args.pmc_inner:
         if use_dist:
             dist.barrier()
             dist.destroy_process_group()
         return
 
-    total_pixels = float(n_all) * world * args.steps
+    total_rows = float(n_all) * world * args.steps
     ms_per_step = elapsed_s * 1e3 / args.steps
-    value = total_pixels / elapsed_s / 1e6
+    value = total_rows / elapsed_s / 1e6
     kern_avg_ms = kern_ms / max(kern_launches, 1)
-    achieved = BYTES_PER_PIXEL_ASSIGN * n_all / (kern_avg_ms * 1e-3) / 1e9 if kern_launches else 0.0
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path):
-        try:
-            traffic = json.load(open(pmc_path)).get("bmu_filter_kernel_hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    bytes_assign = C * esize + 4                       # algorithmic bytes of the assign kernel per row
+    bytes_step = C * esize * (1.0 + cfg["frac"]) + 4   # B = C*s*(1 + f*p) + 4, p = 1 pass
+    achieved = bytes_assign * n_all / (kern_avg_ms * 1e-3) / 1e9 if kern_launches else 0.0
+    step_gbs = bytes_step * n_all / (ms_per_step * 1e-3) / 1e9     # per GPU: every rank moves its own rows
+    flops_assign = 2.0 * K * C                         # algorithmic flops per row (x . W^T)
+    achieved_tf = flops_assign * n_all / (kern_avg_ms * 1e-3) / 1e12 if kern_launches else 0.0
+    mfma_bound = K > 128                               # register-resident filter: HBM; streamed K=400 filter: matrix + VALU pipes
     out = {
         "metric": "M pixels/sec SOM train+assign, 22-ch 1024^2 FOVs, 100-node SOM",
         "value": round(value, 1), "unit": "Mpx/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{F} FOVs 1024x1024x22ch fp32 per GPU, 10x10 SOM "
-                               f"(BASELINE.json configs[1] at N=1)",
-                   "fovs_per_gpu": F, "pixels_per_gpu": n_all, "channels": C, "som_nodes": K,
-                   "train_mode": "batch", "batch_steps": args.batch_steps, "train_fraction": 0.1,
+        "scaling": cfg["scaling"], "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
+        "config": {"workload": cfg["desc"].format(u=units_label), "name": args.config,
+                   "rows_per_gpu": n_all, "channels": C, "som_nodes": K,
+                   "train_mode": "batch", "batch_steps": args.batch_steps, "train_fraction": cfg["frac"],
                    "num_passes": 1, "step": "train + assign + per-cluster mean table",
-                   "parallelism": f"fov-shard x{world}"},
+                   "parallelism": f"{'row' if cfg['kind'] == 'cell' else 'fov'}-shard x{world}",
+                   "rccl_ranks": world if use_dist else 0},
         "phases_ms": {"train_batch": round(train_ms, 4),
                       "assign_filter_kernel": round(kern_avg_ms, 4),
                       "assign_exact_rows": exact_rows,
                       "mean_table": round(k8_ms, 4)},
-        "roofline": {"kernel": "bmu_filter_kernel", "bound": "hbm", "achieved": round(achieved, 1),
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": traffic, "bytes_per_pixel": BYTES_PER_PIXEL_ASSIGN,
-                     "pixels_per_launch": n_all, "launches_timed": kern_launches},
+        "roofline": ({"kernel": "bmu_filter_kernel", "bound": "mfma", "achieved": round(achieved_tf, 1),
+                      "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved_tf / MFMA_F16_PEAK_TFLOPS, 4),
+                      "traffic": None, "flops_per_row": flops_assign, "hbm_frac": round(achieved / HBM_PEAK_GBS, 4),
+                      "rows_per_launch": n_all, "launches_timed": kern_launches,
+                      "note": "K = 400 nodes: 400 scores per row put the streamed filter on the matrix + VALU pipes, not on HBM"}
+                     if mfma_bound else
+                     {"kernel": "bmu_filter_kernel", "bound": "hbm", "achieved": round(achieved, 1),
+                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                      "traffic": None, "bytes_per_pixel": bytes_assign,
+                      "pixels_per_launch": n_all, "launches_timed": kern_launches}),
+        "roofline_step": {"bound": "hbm", "bytes_per_pixel": round(bytes_step, 2), "achieved": round(step_gbs, 1),
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_gbs / HBM_PEAK_GBS, 4),
+                          "note": "whole step per GPU: SURVEY 8(d) algorithmic bytes / ms_per_step"},
     }
 
-    if world == 1:
+    # ---- HBM traffic and matrix-pipe utilisation of the filter kernel: PMC passes of a short run of this script
+    pmc = {}
+    if world == 1 and not args.no_pmc:
+        inner = ["--config", args.config, "--steps", "2", "--warmup", "1", "--batch-steps", str(args.batch_steps),
+                 "--no-cpu-baseline", "--no-online", "--no-pmc", "--pmc-inner"]
+        if args.fovs_per_gpu:
+            inner += ["--fovs-per-gpu", str(args.fovs_per_gpu)]
+        pmc = pmc_passes(inner)
+    recorded = {}
+    rec_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(rec_path):
+        try:
+            recorded = json.load(open(rec_path))
+        except Exception:
+            recorded = {}
+    if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+        # rocprofv3 reports KiB; FETCH_SIZE counts 128-B requests at 64 B on gfx950 (MI355X_MICROARCH.md "HBM")
+        out["roofline"]["traffic"] = round((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0)
+        out["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes inside this run"
+    elif args.config == "cfg2" and not mfma_bound and recorded.get("bmu_filter_kernel_hbm_bytes_per_launch"):
+        out["roofline"]["traffic"] = recorded["bmu_filter_kernel_hbm_bytes_per_launch"]
+        out["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (recorded; no in-run PMC pass)"
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in pmc and pmc.get("GRBM_GUI_ACTIVE"):
+        kernel_cycles = pmc["GRBM_GUI_ACTIVE"] / N_XCDS     # cycles the kernel was resident (per XCD)
+        out["mfma_util"] = {"kernel": "bmu_filter_kernel",
+                            "value": round(pmc["SQ_VALU_MFMA_BUSY_CYCLES"] / (N_SIMDS * kernel_cycles), 4),
+                            "mfma_busy_cycles": pmc["SQ_VALU_MFMA_BUSY_CYCLES"], "kernel_cycles": round(kernel_cycles),
+                            "mfma_insts": pmc.get("SQ_INSTS_MFMA"), "valu_insts": pmc.get("SQ_INSTS_VALU"),
+                            "source": "rocprofv3 --pmc inside this run: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x "
+                                      "GRBM_GUI_ACTIVE / 8 XCDs)"}
+    elif recorded.get("bmu_filter_kernel_mfma_util") and args.config == "cfg2":
+        out["mfma_util"] = {"kernel": "bmu_filter_kernel", "value": recorded["bmu_filter_kernel_mfma_util"],
+                            "source": "profiles/pmc_traffic.json (recorded; no in-run PMC pass)"}
+
+    if world == 1 and args.config == "cfg2":
         oracle_w = None
         order = None
+        rr = default_radius_range(XD, YD)
         if not args.no_cpu_baseline:
             from tests import oracle_binding as ob
             xt = x_train.cpu().numpy().astype(np.float64)
             w0h = w0.cpu().numpy()
+            # the timed training mode at FULL size against its oracle (the bench's own codebook, last timed step)
+            tt = time.perf_counter()
+            want_b = ob.som_batch(xt, w0h, XD, YD, 1, (0.05, 0.01), rr, args.batch_steps)
+            t_b = time.perf_counter() - tt
+            got_b = w.cpu().numpy()
+            rel = float(np.max(np.abs(got_b - want_b) / np.maximum(np.abs(want_b), 1e-300)))
+            out["batch_train"] = {"rows": n_train, "steps": args.batch_steps,
+                                  "codebook_matches_oracle_rtol_1e-9": bool(np.allclose(got_b, want_b, rtol=1e-9, atol=0)),
+                                  "max_rel_err": rel, "oracle_s": round(t_b, 2)}
             rs = np.random.RandomState(7)
             order = rs.randint(0, n_train, size=n_train).astype(np.int64)
-            rr = default_radius_range(XDIM, YDIM)
             tt = time.perf_counter()
-            oracle_w = ob.som_online(xt, w0h, XDIM, YDIM, 1, (0.05, 0.01), rr, order)
+            oracle_w = ob.som_online(xt, w0h, XD, YD, 1, (0.05, 0.01), rr, order)
             t_train = time.perf_counter() - tt
             # the reference labels one FOV table per call (cluster_pixels): so does this leg, FOV by FOV, over
             # 8 of the FOVs (~10 s of host work together with the training leg)
-            f_s = min(F, 8)
+            P = cfg["unit_rows"]
+            f_s = min(n_units, 8)
             n_s = f_s * P
             t_assign = t_means = 0.0
             lab_parts = []
@@ -231,12 +394,11 @@ def main():
                 order = np.random.RandomState(7).randint(0, n_train, size=n_train).astype(np.int64)
             od = torch.from_numpy(order).to(dev)
             wo = w0.clone()
-            rr = default_radius_range(XDIM, YDIM)
-            som_device.train_online(x_train, wo, XDIM, YDIM, 1, (0.05, 0.01), rr, od)  # warm
+            som_device.train_online(x_train, wo, XD, YD, 1, (0.05, 0.01), rr, od)  # warm
             wo.copy_(w0)
             torch.cuda.synchronize()
             tt = time.perf_counter()
-            som_device.train_online(x_train, wo, XDIM, YDIM, 1, (0.05, 0.01), rr, od)
+            som_device.train_online(x_train, wo, XD, YD, 1, (0.05, 0.01), rr, od)
             torch.cuda.synchronize()
             t_on = time.perf_counter() - tt
             out["online_train"] = {"ms": round(t_on * 1e3, 2), "steps": n_train,

@@ -150,3 +150,19 @@ def test_host_utils_natsort_and_verifiers(tmp_path):
     with pytest.raises(ValueError):
         hu.verify_same_elements(enforce_order=True, a=["x", "y"], b=["y", "x"])
     assert hu.verify_same_elements(a=["x", "y"], b=["y", "x"])
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    """`bench.py --gpus N` from a plain shell spawns its own ranks -- and must not run a smaller job under that
+    name when the box has fewer devices (here: none)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("box has two devices")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert "--gpus 2" in r.stderr and "device" in r.stderr
