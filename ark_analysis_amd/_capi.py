@@ -42,6 +42,7 @@ SYMBOLS = {
     "pxsom_batch_accumulate": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _sz, _i32, _vp]),
     "pxsom_quantile_f32": (_i32, [_vp, _i64, _i32, _i64, _f64, _i32, _vp, _vp, _sz, _vp]),
     "pxsom_scaled_rowsum_f32": (_i32, [_vp, _i64, _i32, _i64, _vp, _vp, _vp]),
+    "pxsom_scaled_rowsum_f64": (_i32, [_vp, _i64, _i32, _i64, _vp, _vp, _vp]),
     "pxsom_cluster_mask_workspace_bytes": (_sz, [_i32, _i32]),
     "pxsom_cluster_mask": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "pxsom_pair_histogram": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),

@@ -490,18 +490,19 @@ PXSOM_EXPORT int pxsom_quantile_f32(const float *x_dev, int64_t n, int c, int64_
 // remaining terms one by one.
 namespace {
 #pragma clang fp contract(off)
-__global__ __launch_bounds__(256) void scaled_rowsum_f32_kernel(const float *__restrict__ img, int64_t n, int c,
-                                                                int64_t ldx, const float *__restrict__ norm,
-                                                                float *__restrict__ out)
+template <typename F>
+__global__ __launch_bounds__(256) void scaled_rowsum_kernel(const F *__restrict__ img, int64_t n, int c,
+                                                            int64_t ldx, const F *__restrict__ norm,
+                                                            F *__restrict__ out)
 {
     for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < n; row += (int64_t)gridDim.x * 256) {
-        const float *p = img + row * ldx;
-        float res;
+        const F *p = img + row * ldx;
+        F res;
         if (c < 8) {
-            res = 0.f;
+            res = (F)0;
             for (int j = 0; j < c; j++) res += p[j] / norm[j];
         } else {
-            float r[8];
+            F r[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) r[j] = p[j] / norm[j];
             int i = 8;
@@ -516,20 +517,33 @@ __global__ __launch_bounds__(256) void scaled_rowsum_f32_kernel(const float *__r
     }
 }
 #pragma clang fp contract(fast)
+
+template <typename F>
+int scaled_rowsum(const char *fn, const F *img_dev, int64_t n, int c, int64_t ldx, const F *norm_dev, F *out_dev,
+                  void *stream)
+{
+    if (n < 0 || c < 1 || c > 128 || ldx < c || !norm_dev || (n > 0 && (!img_dev || !out_dev)))
+        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "%s: bad arguments (c <= 128)", fn);
+    if (n == 0) return PXSOM_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t grid = std::min<int64_t>((n + 255) / 256, (int64_t)pxsom::device_cu_count() * 16);
+    hipLaunchKernelGGL(scaled_rowsum_kernel<F>, dim3((unsigned)grid), dim3(256), 0, st, img_dev, n, c, ldx, norm_dev,
+                       out_dev);
+    PXSOM_LAUNCH_CHECK("scaled_rowsum_kernel");
+    return PXSOM_OK;
+}
 }  // namespace
 
 PXSOM_EXPORT int pxsom_scaled_rowsum_f32(const float *img_dev, int64_t n, int c, int64_t ldx, const float *norm_dev,
                                          float *out_dev, void *stream)
 {
-    if (n < 0 || c < 1 || c > 128 || ldx < c || !norm_dev || (n > 0 && (!img_dev || !out_dev)))
-        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_scaled_rowsum_f32: bad arguments (c <= 128)");
-    if (n == 0) return PXSOM_OK;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int64_t grid = std::min<int64_t>((n + 255) / 256, (int64_t)pxsom::device_cu_count() * 16);
-    hipLaunchKernelGGL(scaled_rowsum_f32_kernel, dim3((unsigned)grid), dim3(256), 0, st, img_dev, n, c, ldx, norm_dev,
-                       out_dev);
-    PXSOM_LAUNCH_CHECK("scaled_rowsum_f32_kernel");
-    return PXSOM_OK;
+    return scaled_rowsum<float>("pxsom_scaled_rowsum_f32", img_dev, n, c, ldx, norm_dev, out_dev, stream);
+}
+
+PXSOM_EXPORT int pxsom_scaled_rowsum_f64(const double *img_dev, int64_t n, int c, int64_t ldx, const double *norm_dev,
+                                         double *out_dev, void *stream)
+{
+    return scaled_rowsum<double>("pxsom_scaled_rowsum_f64", img_dev, n, c, ldx, norm_dev, out_dev, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -207,18 +207,22 @@ def positive_quantile_f32(image, q: float):
 
 
 def total_intensity_quantile_f32(image_hwc, norm, q: float):
-    """``np.quantile(np.sum(image / norm, axis=-1), q)`` for a float32 [H, W, C] image and float32 [C]
-    divisors: the per-FOV percentile of calculate_pixel_intensity_percentile (:96-103)."""
+    """``np.quantile(np.sum(image / norm, axis=-1), q)`` for an [H, W, C] image and [C] divisors: the per-FOV
+    percentile of calculate_pixel_intensity_percentile (pixel_cluster_utils.py:96-103).  float32 image AND
+    float32 divisors (MIBI / MPLEX float exports): numpy's binary32 arithmetic throughout; anything else (uint16 /
+    int16 exports, float64 divisors): numpy promotes the division to binary64 and so does this."""
     import torch
     from . import _capi, som_device
     dev = _capi.require_gpu()
     image_hwc = np.asarray(image_hwc)
-    if image_hwc.dtype != np.float32 or np.asarray(norm).dtype != np.float32:
-        raise TypeError("total_intensity_quantile_f32 reproduces numpy's float32 arithmetic: it needs float32 "
-                        "images (MIBI / MPLEX exports) and the float32 channel percentiles computed from them")
-    pixels = _image_to_device(image_hwc, dev).view(-1, image_hwc.shape[-1])
-    sums = som_device.scaled_rowsum_f32(pixels, torch.from_numpy(np.ascontiguousarray(norm, dtype=np.float32)).to(dev))
-    return som_device.quantile_f32(sums.reshape(-1, 1), q, keep_mode=2).cpu().numpy()[0]
+    norm = np.asarray(norm)
+    if image_hwc.dtype == np.float32 and norm.dtype == np.float32:
+        pixels = _image_to_device(image_hwc, dev).view(-1, image_hwc.shape[-1])
+        sums = som_device.scaled_rowsum(pixels, torch.from_numpy(np.ascontiguousarray(norm)).to(dev))
+        return som_device.quantile_f32(sums.reshape(-1, 1), q, keep_mode=2).cpu().numpy()[0]
+    pixels = _image_to_device(image_hwc, dev, torch.float64).view(-1, image_hwc.shape[-1])   # exact widening
+    sums = som_device.scaled_rowsum(pixels, torch.from_numpy(np.ascontiguousarray(norm, dtype=np.float64)).to(dev))
+    return som_device.quantile_nonzero(sums.reshape(-1, 1), q, keep_mode=2).cpu().numpy()[0]
 
 
 def fov_pixel_rows(img_hwc, sigma: float, thresh: float, nonzero_q=None):

@@ -31,9 +31,13 @@ def compute_cell_som_cluster_cols_avg(cell_cluster_data, cell_som_cluster_cols,
 
 
 def _cluster_ids(values) -> np.ndarray:
-    """Cluster column as integers (numeric columns sometimes arrive as floats)."""
+    """The cluster column as the reference uses it (cell_cluster_utils.py:128-136): float columns become
+    integers ("can happen with numeric types"), everything else -- integer ids, or the free-text names the
+    meta-cluster remapping step assigns (``pixel_meta_cluster_rename``, e.g. 'CD4_T') -- is taken as it is."""
     arr = np.asarray(values)
-    return arr.astype(np.int64) if arr.dtype.kind == 'f' else arr.astype(np.int64, copy=False)
+    if arr.dtype.kind == 'f':
+        return arr.astype(np.int64)
+    return arr.astype(str) if arr.dtype.kind == 'O' else arr
 
 
 def create_c2pc_data(fovs, pixel_data_path, cell_table_path,
@@ -72,7 +76,8 @@ def create_c2pc_data(fovs, pixel_data_path, cell_table_path,
         seg = pixels['label'].to_numpy().astype(np.int64)
         clu = _cluster_ids(pixels[pixel_cluster_col].to_numpy())
         ids, dense = np.unique(clu, return_inverse=True)
-        met.update(int(v) for v in ids)
+        ids = ids.tolist()                               # python ints / strs: dictionary keys and column names
+        met.update(ids)
         hist = flowsom.pair_histogram(seg, dense, int(seg.max()) + 1 if seg.size else 1, len(ids))
         in_fov = np.flatnonzero((cells['fov'] == fov).to_numpy())
         cell_ids = cells['label'].to_numpy()[in_fov]
@@ -85,7 +90,7 @@ def create_c2pc_data(fovs, pixel_data_path, cell_table_path,
     column_of = {cid: pos for pos, cid in enumerate(order)}
     counts = np.zeros((len(cells), len(order)), dtype=np.float64)
     for rows, ids, block in per_fov.values():
-        counts[np.ix_(rows, [column_of[int(c)] for c in ids])] = block
+        counts[np.ix_(rows, [column_of[c] for c in ids])] = block
 
     count_cols = ['%s_%s' % (pixel_cluster_col, cid) for cid in order]
     out = pd.DataFrame(counts, columns=count_cols, index=cells.index)

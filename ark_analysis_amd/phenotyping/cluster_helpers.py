@@ -37,6 +37,11 @@ from ..fov_tables import FovTableDir, read_dataframe, write_dataframe  # noqa: F
 from ..host_utils import validate_paths, verify_in_list
 
 
+def _capi_limits() -> Tuple[int, int]:
+    """(max feature columns, max nodes) of the kernels: PXSOM_MAX_CHANNELS, PXSOM_MAX_NODES."""
+    return 128, 1024
+
+
 def _row_blocks(n_rows: int, block: int) -> Iterator[Tuple[int, int]]:
     """[start, stop) bounds of consecutive blocks of at most ``block`` rows."""
     start = 0
@@ -65,6 +70,13 @@ class PixieSOMCluster(ABC):
         if int(batch_steps) < 1:
             raise ValueError("batch_steps must be a positive integer")
         self.train_mode, self.batch_steps = train_mode, int(batch_steps)
+        # limits of the gfx950 kernels (include/pxsom.h): said here, where the user chose the shape, rather than as
+        # a kernel status code in the middle of a run
+        if len(columns) > _capi_limits()[0] or int(xdim) * int(ydim) > _capi_limits()[1]:
+            raise ValueError("this build's SOM kernels take at most %d feature columns and %d nodes; got %d columns "
+                             "on a %d x %d grid (e.g. a cell SOM over pixel_som_cluster counts of a 20 x 20 pixel "
+                             "SOM has 400 columns: cluster on pixel_meta_cluster_rename instead)"
+                             % (_capi_limits() + (len(columns), xdim, ydim)))
         self.weights_path = weights_path
         self.columns = columns
         self.xdim, self.ydim = xdim, ydim

@@ -328,18 +328,26 @@ def quantile_f32(x: torch.Tensor, q: float, keep_mode: int = 1) -> torch.Tensor:
     return out.to(torch.float32)
 
 
-def scaled_rowsum_f32(img: torch.Tensor, norm: torch.Tensor) -> torch.Tensor:
-    """``np.sum(img / norm, axis=-1)`` for float32 [N, C] pixels and float32 [C] divisors, in numpy's
-    summation order -> [N] float32."""
-    if img.dtype != torch.float32 or norm.dtype != torch.float32 or not img.is_cuda or img.dim() != 2 \
-            or img.stride(1) != 1:
-        raise ValueError("img must be a float32 [N, C] HBM tensor with contiguous rows, norm float32 [C]")
+def scaled_rowsum(img: torch.Tensor, norm: torch.Tensor) -> torch.Tensor:
+    """``np.sum(img / norm, axis=-1)`` for [N, C] pixels and [C] divisors of one floating type (float32: numpy's
+    binary32 arithmetic; float64: what numpy computes for every other image dtype), in numpy's summation
+    order -> [N] of that type."""
+    if img.dtype not in (torch.float32, torch.float64) or norm.dtype != img.dtype or not img.is_cuda \
+            or img.dim() != 2 or img.stride(1) != 1:
+        raise ValueError("img must be a float32 / float64 [N, C] HBM tensor with contiguous rows, norm [C] of the same type")
     n, c = img.shape
-    out = torch.empty(n, dtype=torch.float32, device=img.device)
-    rc = _capi.lib().pxsom_scaled_rowsum_f32(img.data_ptr(), n, c, img.stride(0) if n > 1 else c,
-                                             norm.contiguous().data_ptr(), out.data_ptr(), _capi.stream_ptr())
-    _capi.check(rc, "pxsom_scaled_rowsum_f32")
+    out = torch.empty(n, dtype=img.dtype, device=img.device)
+    fn = _capi.lib().pxsom_scaled_rowsum_f32 if img.dtype == torch.float32 else _capi.lib().pxsom_scaled_rowsum_f64
+    rc = fn(img.data_ptr(), n, c, img.stride(0) if n > 1 else c, norm.contiguous().data_ptr(), out.data_ptr(),
+            _capi.stream_ptr())
+    _capi.check(rc, "pxsom_scaled_rowsum")
     return out
+
+
+def scaled_rowsum_f32(img: torch.Tensor, norm: torch.Tensor) -> torch.Tensor:
+    if img.dtype != torch.float32 or norm.dtype != torch.float32:
+        raise ValueError("img must be a float32 [N, C] HBM tensor with contiguous rows, norm float32 [C]")
+    return scaled_rowsum(img, norm)
 
 
 MASK_BAD_LABEL, MASK_BAD_PIXEL = 1, 2   # include/pxsom.h PXSOM_MASK_*

@@ -227,6 +227,10 @@ int pxsom_quantile_f32(const float *x_dev, int64_t n, int c, int64_t ldx, double
  * order for a contiguous float32 axis (c <= 128).  img_dev [n, c] float32, out_dev [n] float32. */
 int pxsom_scaled_rowsum_f32(const float *img_dev, int64_t n, int c, int64_t ldx, const float *norm_dev,
                             float *out_dev, void *stream);
+/* The same sum in binary64: what numpy computes when the image is not float32 (uint16 / int16 exports: the
+ * division by the binary64 channel percentiles promotes to float64) -- same summation order. */
+int pxsom_scaled_rowsum_f64(const double *img_dev, int64_t n, int c, int64_t ldx, const double *norm_dev,
+                            double *out_dev, void *stream);
 
 /* ---- pixel cluster mask: the relabel + scatter of generate_pixel_cluster_mask ------------------------
  * reference: utils/data_utils.py:532-553 -- coordinates = row_index * W + column_index;

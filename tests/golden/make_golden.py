@@ -303,6 +303,49 @@ def g8_c2pc():
     save("g8_c2pc", **arrays)
 
 
+def g8s_c2pc_named():
+    """create_c2pc_data once more with the default column holding the free-text names the meta-cluster remapping
+    step assigns ('CD4_T', 'tumor 2', ...): the reference uses them as they are, in the pivot and in the column
+    names (cell_cluster_utils.py:128-146)."""
+    import warnings
+    from ark.phenotyping import cell_cluster_utils
+    rs = np.random.RandomState(22)
+    names = np.array(["CD4_T", "B cell", "tumor 2", "10", "2", "stroma", "only_background"])
+    fovs = ["fov0", "fov1"]
+    arrays = {"names": names.astype("U32")}
+    with tempfile.TemporaryDirectory() as td:
+        pix = os.path.join(td, "pixel_mat_data")
+        os.mkdir(pix)
+        for fov in fovs:
+            n = 600
+            df = pd.DataFrame({"chan0": rs.rand(n)})
+            df["fov"] = fov
+            lab = rs.randint(0, 16, size=n)
+            code = rs.randint(0, 6, size=n)
+            code[lab == 0] = 6                                   # one name occurs on background only
+            df["label"] = lab
+            df["pixel_som_cluster"] = rs.randint(1, 5, size=n)
+            df["pixel_meta_cluster_rename"] = names[code]
+            feather.write_dataframe(df, os.path.join(pix, fov + ".feather"))
+            arrays["lab_" + fov], arrays["code_" + fov] = lab, code
+        rows = [(fov, lab, int(rs.randint(20, 200))) for lab in range(1, 16) for fov in fovs]
+        cell = pd.DataFrame(rows, columns=["fov", "label", "cell_size"])
+        cell_path = os.path.join(td, "cell_table.csv")
+        cell.to_csv(cell_path, index=False)
+        arrays["cell_fov"] = cell["fov"].values.astype("U8")
+        arrays["cell_label"] = cell["label"].values.astype(np.int64)
+        arrays["cell_size"] = cell["cell_size"].values.astype(np.int64)
+        with warnings.catch_warnings(record=True) as wl:
+            warnings.simplefilter("always")
+            counts, normed = cell_cluster_utils.create_c2pc_data(fovs, pix, cell_path)
+        arrays["warnings"] = np.array([str(w.message) for w in wl if "Pixel clusters" in str(w.message)], dtype="U300")
+        for tag, frame in (("counts", counts), ("normed", normed)):
+            arrays[f"{tag}_columns"] = np.array(list(frame.columns), dtype="U64")
+            arrays[f"{tag}_fov"] = frame["fov"].values.astype("U8")
+            arrays[f"{tag}_values"] = frame.drop(columns="fov").values.astype(np.float64)
+    save("g8s_c2pc_named", **arrays)
+
+
 def g9_create_pixel_matrix():
     """The reference's own create_pixel_matrix on a small float32 TIFF cohort (with segmentation masks),
     through the alpineer / skimage stand-ins of tests/golden/_shims (Pillow readers): pre-row-norm channel
@@ -390,6 +433,6 @@ def g10_pixel_cluster_mask():
 if __name__ == "__main__":
     ob.build()
     steps = {"g1": g1_normalize, "g2": g2_g5_preprocess, "g3": g3_quantiles, "g4": g4_cluster_avg, "g6": g6_som, "g7b": g7b_batch_mode,
-             "g7": g7_end_to_end, "g8": g8_c2pc, "g9": g9_create_pixel_matrix, "g10": g10_pixel_cluster_mask}
+             "g7": g7_end_to_end, "g8": g8_c2pc, "g8s": g8s_c2pc_named, "g9": g9_create_pixel_matrix, "g10": g10_pixel_cluster_mask}
     for name in (sys.argv[1:] or list(steps)):
         steps[name]()

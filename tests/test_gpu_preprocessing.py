@@ -175,5 +175,15 @@ def test_total_intensity_quantile_matches_numpy(gpu, c):
     np.testing.assert_array_equal(got_sum.cpu().numpy().reshape(61, 47), want_sum)
     for q in (0.05, 0.5):
         assert flowsom.total_intensity_quantile_f32(img, norm, q) == np.quantile(want_sum, q)
-    with pytest.raises(TypeError):
-        flowsom.total_intensity_quantile_f32(img.astype(np.float64), norm, 0.05)
+    # every other dtype pairing: numpy promotes the division to binary64 (uint16 / int16 TIFF exports, float64
+    # channel percentiles) -- same summation order, binary64 quantile
+    for image, divisors in [(img.astype(np.float64), norm), (img, norm.astype(np.float64)),
+                            ((img * 500).astype(np.uint16), norm.astype(np.float64) * 500),
+                            ((img * 500).astype(np.int16), norm.astype(np.float64) * 500)]:
+        want64 = np.sum(image / divisors.reshape([1, 1, c]), axis=-1)
+        assert want64.dtype == np.float64
+        got64 = sd.scaled_rowsum(torch.from_numpy(image.reshape(-1, c).astype(np.float64)).to(gpu),
+                                 torch.from_numpy(divisors.astype(np.float64)).to(gpu))
+        np.testing.assert_array_equal(got64.cpu().numpy().reshape(61, 47), want64)
+        for q in (0.05, 0.5):
+            assert flowsom.total_intensity_quantile_f32(image, divisors, q) == np.quantile(want64, q)

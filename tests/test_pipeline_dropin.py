@@ -373,6 +373,35 @@ def test_create_c2pc_data_matches_reference_run(som_backend, tmp_path, cluster_c
         cell_cluster_utils.create_c2pc_data(fovs, str(pix), cell_path, "pixel_meta_cluster")
 
 
+def test_create_c2pc_data_with_named_clusters(som_backend, tmp_path):
+    """The default column, pixel_meta_cluster_rename, holds user-assigned names ('CD4_T', 'tumor 2', ...): used as
+    they are, like the reference does (tests/golden/g8s_c2pc_named.npz = the reference's own output)."""
+    from ark_analysis_amd.phenotyping import cell_cluster_utils
+    g = np.load(os.path.join(GOLD, "g8s_c2pc_named.npz"))
+    fovs = ["fov0", "fov1"]
+    pix = tmp_path / "pixel_mat_data"
+    pix.mkdir()
+    for fov in fovs:
+        n = len(g["lab_" + fov])
+        df = pd.DataFrame({"chan0": np.zeros(n)})
+        df["fov"] = fov
+        df["label"] = g["lab_" + fov]
+        df["pixel_som_cluster"] = 1
+        df["pixel_meta_cluster_rename"] = g["names"][g["code_" + fov]]
+        write_dataframe(df, str(pix / (fov + ".feather")))
+    cell = pd.DataFrame({"fov": g["cell_fov"], "label": g["cell_label"], "cell_size": g["cell_size"]})
+    cell_path = str(tmp_path / "cell_table.csv")
+    cell.to_csv(cell_path, index=False)
+    with warnings.catch_warnings(record=True) as wl:
+        warnings.simplefilter("always")
+        counts, normed = cell_cluster_utils.create_c2pc_data(fovs, str(pix), cell_path)
+    assert [str(w.message) for w in wl if "Pixel clusters" in str(w.message)] == list(g["warnings"])
+    for tag, frame in (("counts", counts), ("normed", normed)):
+        assert list(frame.columns) == list(g[f"{tag}_columns"])
+        assert list(frame["fov"]) == list(g[f"{tag}_fov"])
+        np.testing.assert_array_equal(frame.drop(columns="fov").values.astype(np.float64), g[f"{tag}_values"])
+
+
 def test_tiff_side_percentiles(som_backend, tmp_path):
     """calculate_channel_percentiles / calculate_pixel_intensity_percentile / check_for_modified_channels on
     a small TIFF cohort, against the reference's arithmetic written out with numpy
