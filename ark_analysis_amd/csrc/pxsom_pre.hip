@@ -624,3 +624,45 @@ PXSOM_EXPORT int pxsom_cluster_mask(const int64_t *row_index_dev, const int64_t 
     PXSOM_LAUNCH_CHECK("mask_resolve_kernel");
     return PXSOM_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// label -> label lookup (SOM cluster -> meta cluster): out[i] = lut[labels[i]], `fill` outside the table
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void relabel_kernel(const int32_t *__restrict__ labels, int64_t n,
+                                                      const int32_t *__restrict__ lut, int lut_size, int32_t fill,
+                                                      int32_t *__restrict__ out)
+{
+    extern __shared__ int32_t lut_s[];
+    for (int i = threadIdx.x; i < lut_size; i += 256) lut_s[i] = lut[i];
+    __syncthreads();
+    // 4 labels per thread and trip: 16-byte loads and stores when the vectors are aligned
+    const int64_t n4 = ((reinterpret_cast<uintptr_t>(labels) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 ? n / 4 : 0;
+    typedef int v4 __attribute__((ext_vector_type(4)));
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < n4; v += (int64_t)gridDim.x * 256) {
+        const v4 l = reinterpret_cast<const v4 *>(labels)[v];
+        v4 o;
+#pragma unroll
+        for (int u = 0; u < 4; u++) o[u] = (l[u] >= 0 && l[u] < lut_size) ? lut_s[l[u]] : fill;
+        reinterpret_cast<v4 *>(out)[v] = o;
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int l = labels[i];
+        out[i] = (l >= 0 && l < lut_size) ? lut_s[l] : fill;
+    }
+}
+}  // namespace
+
+PXSOM_EXPORT int pxsom_relabel(const int32_t *labels_dev, int64_t n, const int32_t *lut_dev, int lut_size, int32_t fill,
+                               int32_t *out_dev, void *stream)
+{
+    if (n < 0 || lut_size < 1 || lut_size > 16384 || !lut_dev || (n > 0 && (!labels_dev || !out_dev)))
+        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_relabel: bad arguments (lookup tables of 1..16384 entries)");
+    if (n == 0) return PXSOM_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t grid = std::min<int64_t>((n / 4 + 255) / 256 + 1, (int64_t)pxsom::device_cu_count() * 8);
+    hipLaunchKernelGGL(relabel_kernel, dim3((unsigned)grid), dim3(256), (size_t)lut_size * sizeof(int32_t), st, labels_dev, n,
+                       lut_dev, lut_size, fill, out_dev);
+    PXSOM_LAUNCH_CHECK("relabel_kernel");
+    return PXSOM_OK;
+}

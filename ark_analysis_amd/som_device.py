@@ -376,3 +376,16 @@ def cluster_mask(row_index: torch.Tensor, column_index: torch.Tensor, labels: to
                                         mask.data_ptr(), status.data_ptr(), ws.data_ptr(), wsb, _capi.stream_ptr())
     _capi.check(rc, "pxsom_cluster_mask")
     return mask, int(status.item())
+
+
+def relabel(labels: torch.Tensor, lut: torch.Tensor, fill: int = -1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``out[i] = lut[labels[i]]`` (``fill`` for labels outside the table): SOM cluster -> meta cluster for labels
+    that live in HBM.  int32 vectors; ``out`` may be ``labels``."""
+    if labels.dtype != torch.int32 or lut.dtype != torch.int32 or not labels.is_cuda or not labels.is_contiguous():
+        raise ValueError("labels and lut must be contiguous int32 HBM vectors")
+    if out is None:
+        out = torch.empty_like(labels)
+    rc = _capi.lib().pxsom_relabel(labels.data_ptr(), labels.numel(), lut.contiguous().data_ptr(), lut.numel(), int(fill),
+                                   out.data_ptr(), _capi.stream_ptr())
+    _capi.check(rc, "pxsom_relabel")
+    return out

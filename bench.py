@@ -338,6 +338,38 @@ def main():
         out["mfma_util"] = {"kernel": "bmu_filter_kernel", "value": recorded["bmu_filter_kernel_mfma_util"],
                             "source": "profiles/pmc_traffic.json (recorded; no in-run PMC pass)"}
 
+    if args.config == "cfg5":
+        # "+ consensus meta-cluster" (BASELINE.json configs[4]): Ward on the K x C mean table on the host (the
+        # reference's PixieConsensusCluster step), then the K-entry lookup over the labels in HBM.  Outside the timed
+        # step: reported beside it.
+        import pandas as pd
+        from ark_analysis_amd.phenotyping.cluster_helpers import PixieConsensusCluster
+        chans = ["chan%d" % j for j in range(C)]
+        avg = pd.DataFrame(means.cpu().numpy(), columns=chans)
+        avg.insert(0, "pixel_som_cluster", np.arange(1, K + 1))
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "pixel_channel_avg_som_cluster.csv")
+            avg.to_csv(path, index=False)
+            tt = time.perf_counter()
+            cc = PixieConsensusCluster("pixel", path, chans, max_k=20, cap=3)
+            cc.scale_data()
+            np.random.seed(42)
+            cc.run_consensus_clustering()
+            cc.generate_som_to_meta_map()
+            t_ward = time.perf_counter() - tt
+        lut = torch.from_numpy(cc.lookup_table().astype(np.int32)).to(dev)
+        meta = torch.empty_like(labels)
+        som_device.relabel(labels, lut, out=meta)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        som_device.relabel(labels, lut, out=meta)
+        e1.record()
+        torch.cuda.synchronize()
+        out["consensus"] = {"max_k": 20, "ward_host_ms": round(t_ward * 1e3, 2), "relabel_kernel_ms": round(e0.elapsed_time(e1), 4),
+                            "meta_clusters_found": int(torch.unique(meta).numel()),
+                            "note": "K x C table on the host (as the reference), K-entry lookup in HBM; not part of the timed step"}
+
     if world == 1 and args.config == "cfg2":
         oracle_w = None
         order = None

@@ -250,6 +250,13 @@ int pxsom_cluster_mask(const int64_t *row_index_dev, const int64_t *column_index
                        int64_t n, const int32_t *lut_dev, int64_t lut_size, int h, int w, int16_t *mask_dev,
                        int32_t *status_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
 
+/* ---- SOM cluster -> meta cluster: the per-pixel half of pixel_consensus_cluster -----------------------------
+ * reference: cluster_helpers.py:669-682 (PixieConsensusCluster.assign_consensus_labels: Series.map through the
+ * K-row mapping), applied per FOV table at pixel_meta_clustering.py:17-50.  out_dev[i] = lut_dev[labels_dev[i]] for
+ * labels inside [0, lut_size), `fill` otherwise (what the map turns into NaN); in place allowed. */
+int pxsom_relabel(const int32_t *labels_dev, int64_t n, const int32_t *lut_dev, int lut_size, int32_t fill,
+                  int32_t *out_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

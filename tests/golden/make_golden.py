@@ -133,6 +133,102 @@ def g4_cluster_avg():
          means_sub3=out3[chans].values, count_sub3=out3["count"].values.astype(np.int64), **arrays)
 
 
+def g5_meta_clustering():
+    """The reference's own meta-clustering step: PixieConsensusCluster (z-score, cap, Ward cut) on a seeded 100 x 6
+    table, then pixel_consensus_cluster -> generate_meta_avg_files -> apply_pixel_meta_cluster_remapping ->
+    generate_remap_avg_files on three small FOV tables (SURVEY.md section 8(c) "G5")."""
+    from ark.phenotyping import pixel_meta_clustering
+    rs = np.random.RandomState(5)
+    arrays = {}
+    cols = ["m%d" % i for i in range(6)]
+    with tempfile.TemporaryDirectory() as td:
+        table = pd.DataFrame(rs.gamma(1.2, 0.7, size=(100, 6)), columns=cols)
+        table.iloc[:, 3] *= 40.0                     # a column whose z-scores reach the cap
+        table.insert(0, "pixel_som_cluster", np.arange(1, 101))
+        table["count"] = rs.randint(10, 1000, size=100)
+        path = os.path.join(td, "avg.csv")
+        table.to_csv(path, index=False)
+        cc = cluster_helpers.PixieConsensusCluster("pixel", path, cols, max_k=20, cap=3)
+        cc.scale_data()
+        np.random.seed(42)
+        cc.run_consensus_clustering()
+        cc.generate_som_to_meta_map()
+        arrays.update(ward_table=table[cols].values, ward_scaled=cc.input_data[cols].values,
+                      ward_mapping=cc.mapping.values.astype(np.int64), ward_bestk=np.int64(cc.cc.bestK),
+                      ward_mk_shape=np.array(cc.cc.Mk.shape, dtype=np.int64))
+
+    chans = ["chan%d" % i for i in range(4)]
+    fovs = ["fov0", "fov1", "fov2"]
+    with tempfile.TemporaryDirectory() as td:
+        os.mkdir(os.path.join(td, "pixel_mat_data"))
+        centers = rs.rand(30, 4)
+        for fov in fovs:
+            n = 1200
+            som = rs.randint(1, 31, size=n)
+            x = np.abs(centers[som - 1] + 0.05 * rs.standard_normal((n, 4)))
+            df = pd.DataFrame(x, columns=chans)
+            df["fov"] = fov
+            df["row_index"] = np.repeat(np.arange(n // 40), 40)
+            df["column_index"] = np.tile(np.arange(40), n // 40)
+            df["label"] = rs.randint(0, 20, size=n)
+            df["pixel_som_cluster"] = som
+            feather.write_dataframe(df, os.path.join(td, "pixel_mat_data", fov + ".feather"))
+            arrays["data_" + fov], arrays["som_" + fov] = x, som.astype(np.int64)
+            arrays["meta_" + fov] = df[["row_index", "column_index", "label"]].values.astype(np.int64)
+        som_avg = pixel_cluster_utils.compute_pixel_cluster_channel_avg(
+            fovs, chans, td, "pixel_som_cluster", 30, "pixel_mat_data", keep_count=True)
+        som_avg.to_csv(os.path.join(td, "pixel_channel_avg_som_cluster.csv"), index=False)
+        arrays["som_avg"] = som_avg.values.astype(np.float64)
+        arrays["som_avg_columns"] = np.array(list(som_avg.columns), dtype="U32")
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            pcc = pixel_meta_clustering.pixel_consensus_cluster(fovs, chans, td, max_k=6, cap=3)
+            pixel_meta_clustering.generate_meta_avg_files(fovs, chans, td, pcc)
+        arrays["stdout_consensus"] = np.array(buf.getvalue())
+        arrays["mapping"] = pcc.mapping.values.astype(np.int64)
+        for fov in fovs:
+            res = feather.read_dataframe(os.path.join(td, "pixel_mat_data", fov + ".feather"))
+            arrays["columns_after_consensus"] = np.array(list(res.columns), dtype="U32")
+            arrays["metalab_" + fov] = res["pixel_meta_cluster"].values.astype(np.int64)
+        meta_avg = pd.read_csv(os.path.join(td, "pixel_channel_avg_meta_cluster.csv"))
+        som_avg2 = pd.read_csv(os.path.join(td, "pixel_channel_avg_som_cluster.csv"))
+        arrays.update(meta_avg=meta_avg.values.astype(np.float64), meta_avg_columns=np.array(list(meta_avg.columns), dtype="U32"),
+                      som_avg_after=som_avg2.values.astype(np.float64),
+                      som_avg_after_columns=np.array(list(som_avg2.columns), dtype="U32"))
+        # a manual remapping: meta clusters 5 and 6 merged into 5, everything named
+        remap = pcc.mapping.copy()
+        remap.loc[remap["pixel_meta_cluster"] == 6, "pixel_meta_cluster"] = 5
+        names = {1: "tumor", 2: "CD4 T", 3: "stroma_1", 4: "B", 5: "other"}
+        remap["pixel_meta_cluster_rename"] = remap["pixel_meta_cluster"].map(names)
+        remap.to_csv(os.path.join(td, "remap.csv"), index=False)
+        arrays["remap_som"] = remap["pixel_som_cluster"].values.astype(np.int64)
+        arrays["remap_meta"] = remap["pixel_meta_cluster"].values.astype(np.int64)
+        arrays["remap_name"] = remap["pixel_meta_cluster_rename"].values.astype("U16")
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            pixel_meta_clustering.apply_pixel_meta_cluster_remapping(fovs, chans, td, "pixel_mat_data", "remap.csv")
+            pixel_meta_clustering.generate_remap_avg_files(
+                fovs, chans, td, "pixel_mat_data", "remap.csv", "pixel_channel_avg_som_cluster.csv",
+                "pixel_channel_avg_meta_cluster.csv")
+        arrays["stdout_remap"] = np.array(buf.getvalue())
+        for fov in fovs:
+            res = feather.read_dataframe(os.path.join(td, "pixel_mat_data", fov + ".feather"))
+            arrays["columns_after_remap"] = np.array(list(res.columns), dtype="U32")
+            arrays["dtypes_after_remap"] = np.array([str(t) for t in res.dtypes], dtype="U16")
+            arrays["remapped_" + fov] = res["pixel_meta_cluster"].values.astype(np.int64)
+            arrays["renamed_" + fov] = res["pixel_meta_cluster_rename"].values.astype("U16")
+        meta_avg3 = pd.read_csv(os.path.join(td, "pixel_channel_avg_meta_cluster.csv"))
+        som_avg3 = pd.read_csv(os.path.join(td, "pixel_channel_avg_som_cluster.csv"))
+        num = [c for c in meta_avg3.columns if c != "pixel_meta_cluster_rename"]
+        arrays.update(meta_avg_remap=meta_avg3[num].values.astype(np.float64),
+                      meta_avg_remap_columns=np.array(list(meta_avg3.columns), dtype="U32"),
+                      meta_avg_remap_names=meta_avg3["pixel_meta_cluster_rename"].values.astype("U16"),
+                      som_avg_remap_columns=np.array(list(som_avg3.columns), dtype="U32"),
+                      som_avg_remap_meta=som_avg3["pixel_meta_cluster"].values.astype(np.int64),
+                      som_avg_remap_names=som_avg3["pixel_meta_cluster_rename"].values.astype("U16"))
+    save("g5_meta_clustering", **arrays)
+
+
 def g6_som():
     """Oracle-of-record SOM vectors (pyFlowSOM itself is absent: parity unpinned)."""
     from ark_analysis_amd.flowsom import default_radius_range
@@ -432,7 +528,7 @@ def g10_pixel_cluster_mask():
 
 if __name__ == "__main__":
     ob.build()
-    steps = {"g1": g1_normalize, "g2": g2_g5_preprocess, "g3": g3_quantiles, "g4": g4_cluster_avg, "g6": g6_som, "g7b": g7b_batch_mode,
+    steps = {"g1": g1_normalize, "g2": g2_g5_preprocess, "g3": g3_quantiles, "g4": g4_cluster_avg, "g5": g5_meta_clustering, "g6": g6_som, "g7b": g7b_batch_mode,
              "g7": g7_end_to_end, "g8": g8_c2pc, "g8s": g8s_c2pc_named, "g9": g9_create_pixel_matrix, "g10": g10_pixel_cluster_mask}
     for name in (sys.argv[1:] or list(steps)):
         steps[name]()

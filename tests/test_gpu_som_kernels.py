@@ -583,3 +583,18 @@ def test_cell_som_shape_full_size_properties(gpu, oracle):
     sums, cnt = sd.cluster_sums(x, labels, k)
     assert int(cnt.sum()) == n
     np.testing.assert_allclose(sums.sum(dim=0).cpu().numpy(), x.double().sum(dim=0).cpu().numpy(), rtol=1e-9)
+
+
+def test_relabel_matches_numpy(gpu):
+    rs = np.random.RandomState(4)
+    for n, k in [(1_000_003, 400), (37, 100), (0, 5), (4096, 1)]:
+        lut = rs.randint(1, 21, size=k + 1).astype(np.int32)
+        labels = rs.randint(-2, k + 4, size=n).astype(np.int32)
+        want = np.where((labels >= 0) & (labels <= k), lut[np.clip(labels, 0, k)], -7)
+        ld = torch.from_numpy(labels).to(gpu)
+        got = sd.relabel(ld, torch.from_numpy(lut).to(gpu), fill=-7)
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+        if n:
+            view = ld[1:]                                    # a misaligned view takes the scalar loop
+            got2 = sd.relabel(view.contiguous(), torch.from_numpy(lut).to(gpu), fill=-7)
+            np.testing.assert_array_equal(got2.cpu().numpy(), want[1:])
