@@ -27,18 +27,40 @@ def nhbrdist(xdim: int, ydim: int) -> np.ndarray:
                       np.abs(gy[:, None] - gy[None, :])).astype(np.float64)
 
 
-def default_radius_range(xdim: int, ydim: int) -> Tuple[float, float]:
+#: The details of pyFlowSOM.som this front end had to RECALL (the package is absent here: "parity unpinned"),
+#: each with the alternatives a real vector dump (scripts/dump_pyflowsom_vectors.py) would discriminate between.
+#: tests/test_pyflowsom_vectors.py sweeps them when tests/golden/g11_pyflowsom.npz exists.
+RECALLED = {
+    "radius_quantile": (0.67, "default radius_range = (quantile(nhbrdist, q), 0)"),
+    "order_stream": ("glibc_rand", "presentation order: 'glibc_rand' i = int(n * rand()/2^31) after srand(seed); "
+                                   "'numpy_randint' RandomState(seed) continued after the node choice; 'numpy_sample' "
+                                   "int(n * random_sample()) of that stream"),
+    "init_rule": ("numpy_choice", "initial nodes = data[RandomState(seed).choice(n, K, replace=False)]"),
+    "node_order": ("xy", "node k = x*ydim + y ('yx': k = y*xdim + x)"),
+}
+
+
+def default_radius_range(xdim: int, ydim: int, quantile: Optional[float] = None) -> Tuple[float, float]:
     """pyFlowSOM default: (quantile(nhbrdist, 0.67), 0) -- 6.0 for 10x10, 11.0 for 20x20."""
-    return float(np.quantile(nhbrdist(xdim, ydim), 0.67)), 0.0
+    q = RECALLED["radius_quantile"][0] if quantile is None else quantile
+    return float(np.quantile(nhbrdist(xdim, ydim), q)), 0.0
 
 
-def som_init_and_order(n: int, k: int, rlen: int, seed: Optional[int]):
-    """(indices of the K initial nodes, presentation order int64 [n*rlen]) for ``seed``."""
+def som_init_and_order(n: int, k: int, rlen: int, seed: Optional[int], order_stream: Optional[str] = None):
+    """(indices of the K initial nodes, presentation order int64 [n*rlen]) for ``seed``.
+    ``order_stream``: one of the alternatives listed in :data:`RECALLED` (default: the build's reading)."""
     from . import _capi
     if n < k:
         raise ValueError(f"som needs at least as many rows ({n}) as nodes ({k})")
     rs = np.random.RandomState(seed)
     init_idx = rs.choice(n, k, replace=False)
+    stream = RECALLED["order_stream"][0] if order_stream is None else order_stream
+    if stream == "numpy_randint":
+        return init_idx, rs.randint(0, n, size=n * rlen).astype(np.int64)
+    if stream == "numpy_sample":
+        return init_idx, (n * rs.random_sample(n * rlen)).astype(np.int64)
+    if stream != "glibc_rand":
+        raise ValueError("unknown order_stream %r" % (stream,))
     stream_seed = int(seed) if seed is not None else int(rs.randint(1, 2 ** 31 - 1))
     r = _capi.glibc_rand(stream_seed, n * rlen)
     order = (n * (r.astype(np.float64) / 2147483648.0)).astype(np.int64)

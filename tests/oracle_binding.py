@@ -89,8 +89,13 @@ def nhbrdist(xdim, ydim):
     return out
 
 
-def som_online(data, codes, xdim, ydim, rlen, alpha_range, radius_range, order):
-    """Returns trained codes [K, C] (copy).  ``order``: int64 [n*rlen]."""
+# named switches for the RECALLED details of pyFlowSOM (oracle/pxsom_oracle.c ORC_V_*): 0 = the build's reading
+V_COMPARE_SQUARED, V_NO_THRESHOLD_PIN, V_NO_EARLY_STOP, V_LAST_MINIMUM = 1, 2, 4, 8
+
+
+def som_online(data, codes, xdim, ydim, rlen, alpha_range, radius_range, order, variant=0, node_order="xy"):
+    """Returns trained codes [K, C] (copy).  ``order``: int64 [n*rlen].  ``variant`` / ``node_order``: the
+    recalled-detail switches (tests of real pyFlowSOM vectors sweep them)."""
     data = _f64(data)
     codes = _f64(codes).copy()
     n, px = data.shape
@@ -98,13 +103,34 @@ def som_online(data, codes, xdim, ydim, rlen, alpha_range, radius_range, order):
     assert codes.shape == (K, px)
     order = np.ascontiguousarray(order, dtype=np.int64)
     assert order.size == n * rlen and (n == 0 or (order.min() >= 0 and order.max() < n))
-    nh = nhbrdist(xdim, ydim)
-    steps = lib().orc_som_online(_dp(data), n, px, _dp(codes), K, _dp(nh),
-                                 float(alpha_range[0]), float(alpha_range[1]),
-                                 float(radius_range[0]), float(radius_range[1]), int(rlen),
-                                 order.ctypes.data_as(c_i64p))
+    nh = nhbrdist(xdim, ydim) if node_order == "xy" else _nhbrdist_yx(xdim, ydim)
+    fn = lib().orc_som_online_ex
+    fn.restype = ctypes.c_int64
+    fn.argtypes = [c_dp, ctypes.c_int64, ctypes.c_int, c_dp, ctypes.c_int, c_dp, ctypes.c_double, ctypes.c_double,
+                   ctypes.c_double, ctypes.c_double, ctypes.c_int, c_i64p, ctypes.c_int]
+    steps = fn(_dp(data), n, px, _dp(codes), K, _dp(nh), float(alpha_range[0]), float(alpha_range[1]),
+               float(radius_range[0]), float(radius_range[1]), int(rlen), order.ctypes.data_as(c_i64p), int(variant))
     assert steps >= 0
     return codes
+
+
+def _nhbrdist_yx(xdim, ydim):
+    """Chebyshev grid distances for the OTHER node numbering, k = y*xdim + x (switch of a recalled detail)."""
+    gy, gx = np.divmod(np.arange(xdim * ydim), xdim)
+    return np.ascontiguousarray(np.maximum(np.abs(gx[:, None] - gx[None, :]),
+                                           np.abs(gy[:, None] - gy[None, :])).astype(np.float64))
+
+
+def map_data_to_nodes_variant(codes, data, variant):
+    codes, data = _f64(codes), _f64(data)
+    n, px = data.shape
+    labels = np.empty(n, dtype=np.int32)
+    dists = np.empty(n, dtype=np.float64)
+    fn = lib().orc_map_data_to_nodes_ex
+    fn.restype = ctypes.c_int
+    fn.argtypes = [c_dp, ctypes.c_int, c_dp, ctypes.c_int64, ctypes.c_int, c_i32p, c_dp, ctypes.c_int]
+    assert fn(_dp(codes), codes.shape[0], _dp(data), n, px, labels.ctypes.data_as(c_i32p), _dp(dists), int(variant)) == 0
+    return labels, dists
 
 
 def map_data_to_nodes(codes, data, column_major_copy=False):
