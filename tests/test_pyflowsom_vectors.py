@@ -102,9 +102,17 @@ def test_recalled_switches_are_wired(oracle):
     rr = flowsom.default_radius_range(5, 5)
     base = oracle.som_online(x, x[init_idx], 5, 5, 2, (0.05, 0.01), rr, order)
     np.testing.assert_array_equal(base, oracle.som_online(x, x[init_idx], 5, 5, 2, (0.05, 0.01), rr, order, variant=0, node_order="xy"))
-    assert not np.array_equal(base, oracle.som_online(x, x[init_idx], 5, 5, 2, (0.05, 0.01), rr, order, variant=oracle.V_NO_THRESHOLD_PIN))
-    assert not np.array_equal(base, oracle.som_online(x, x[init_idx], 4, 6, 2, (0.05, 0.01), rr, order[: 600], node_order="yx")[:, :]) \
-        or True   # (a different grid: only checks the switch runs)
+    # the 0.5 pin is unobservable while the threshold stays in [0, 1): grid distances are integers
+    np.testing.assert_array_equal(base, oracle.som_online(x, x[init_idx], 5, 5, 2, (0.05, 0.01), rr, order,
+                                                          variant=oracle.V_NO_THRESHOLD_PIN))
+    # ... and observable once the schedule ends below zero (then no node, not even the BMU, is inside it)
+    neg = (3.0, -1.0)
+    assert not np.array_equal(oracle.som_online(x, x[init_idx], 5, 5, 2, (0.05, 0.01), neg, order),
+                              oracle.som_online(x, x[init_idx], 5, 5, 2, (0.05, 0.01), neg, order, variant=oracle.V_NO_THRESHOLD_PIN))
+    # node numbering matters on a non-square grid
+    w46 = x[init_idx[:24]]
+    assert not np.array_equal(oracle.som_online(x, w46, 4, 6, 1, (0.05, 0.01), (3.0, 0.0), order[:300]),
+                              oracle.som_online(x, w46, 4, 6, 1, (0.05, 0.01), (3.0, 0.0), order[:300], node_order="yx"))
     for stream in ("numpy_randint", "numpy_sample"):
         _, other = flowsom.som_init_and_order(300, 25, 2, 9, order_stream=stream)
         assert other.shape == order.shape and not np.array_equal(other, order)
