@@ -636,8 +636,8 @@ __global__ __launch_bounds__(256) void batch_update_kernel(double *w, int xdim, 
 // table in LDS (ds_add_f64), flushed once with global_atomic_add_f64.
 // Loads are flat-coalesced: lane e reads element e of the row range.
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool COUNT_F64>
-__global__ __launch_bounds__(256) void cluster_sums_kernel(const T *__restrict__ x, int64_t n, int c,
+template <typename T, bool COUNT_F64, int NT>
+__global__ __launch_bounds__(NT) void cluster_sums_kernel(const T *__restrict__ x, int64_t n, int c,
                                                            int64_t ldx, const int32_t *__restrict__ labels,
                                                            int k, double *sums, unsigned long long *counts,
                                                            int64_t rows_per_block, int use_lds)
@@ -647,8 +647,8 @@ __global__ __launch_bounds__(256) void cluster_sums_kernel(const T *__restrict__
     unsigned *lc = reinterpret_cast<unsigned *>(ls + (size_t)k * c);   // [k]
     const int tid = threadIdx.x;
     if (use_lds) {
-        for (int e = tid; e < k * c; e += 256) ls[e] = 0.0;
-        for (int e = tid; e < k; e += 256) lc[e] = 0u;
+        for (int e = tid; e < k * c; e += NT) ls[e] = 0.0;
+        for (int e = tid; e < k; e += NT) lc[e] = 0u;
         __syncthreads();
     }
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
@@ -657,23 +657,26 @@ __global__ __launch_bounds__(256) void cluster_sums_kernel(const T *__restrict__
     // contiguous fp32 rows (ldx == c): the row range is one flat array -- 16-byte loads, 4 per thread in
     // flight (a dword per lane keeps too few bytes in flight for HBM: measured 1.8 TB/s at 10 M rows)
     bool done = false;
-    if constexpr (sizeof(T) == 4) {
-        if (use_lds && ldx == c && r0 < r1 && ((reinterpret_cast<uintptr_t>(x) + (size_t)r0 * c * 4) & 15) == 0) {
-            typedef float f4 __attribute__((ext_vector_type(4)));
-            const float *xb = reinterpret_cast<const float *>(x) + r0 * c;
-            const int64_t total = (r1 - r0) * c, nvec = total / 4;
-            // (row, channel) of a thread's vector advance by 1024 elements per load: no division in the loop
-            int64_t vrow = (4 * (int64_t)tid) / c;
-            int vch = (int)(4 * (int64_t)tid - vrow * c);
-            const int drow = 1024 / c, dch = 1024 % c;
-            for (int64_t v0 = tid; v0 < nvec; v0 += 4 * 256) {
-                f4 val[4];
-                int lab[4][4], chn[4][4];
+    if constexpr (sizeof(T) <= 4) {
+        // contiguous fp32 / fp16 rows: VEC = 16 / sizeof(T) elements per load
+        constexpr int VEC = 16 / (int)sizeof(T);
+        if (use_lds && ldx == c && r0 < r1 && ((reinterpret_cast<uintptr_t>(x) + (size_t)r0 * c * sizeof(T)) & 15) == 0) {
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+            const T *xb = x + r0 * c;
+            const int64_t total = (r1 - r0) * c, nvec = total / VEC;
+            // (row, channel) of a thread's vector advance by NT*VEC elements per load: no division in the loop
+            int64_t vrow = ((int64_t)VEC * tid) / c;
+            int vch = (int)((int64_t)VEC * tid - vrow * c);
+            const int drow = (NT * VEC) / c, dch = (NT * VEC) % c;
+            for (int64_t v0 = tid; v0 < nvec; v0 += 4 * NT) {
+                T val[4][VEC];
+                int lab[4][VEC], chn[4][VEC];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    const int64_t v = v0 + u * 256;
+                    const int64_t v = v0 + u * NT;
                     const bool ok = v < nvec;
-                    val[u] = ok ? *reinterpret_cast<const f4 *>(xb + 4 * v) : f4{0.f, 0.f, 0.f, 0.f};
+                    const u4 raw = ok ? *reinterpret_cast<const u4 *>(xb + VEC * v) : u4{0u, 0u, 0u, 0u};
+                    __builtin_memcpy(val[u], &raw, 16);
                     int64_t row = vrow;
                     int ch = vch;
                     vrow += drow;
@@ -682,20 +685,22 @@ __global__ __launch_bounds__(256) void cluster_sums_kernel(const T *__restrict__
                         vch -= c;
                         vrow++;
                     }
+                    int lb = ok ? labels[r0 + row] - 1 : -1;
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
+                    for (int i = 0; i < VEC; i++) {
                         chn[u][i] = ch;
-                        lab[u][i] = ok ? labels[r0 + row] - 1 : -1;
+                        lab[u][i] = lb;
                         if (++ch == c) {
                             ch = 0;
                             row++;
+                            lb = (ok && r0 + row < r1) ? labels[r0 + row] - 1 : -1;
                         }
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++)
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
+                    for (int i = 0; i < VEC; i++) {
                         const int lb = lab[u][i];
                         if (lb >= 0 && lb < k) {
                             __hip_atomic_fetch_add(&ls[(size_t)lb * c + chn[u][i]], (double)val[u][i], __ATOMIC_RELAXED,
@@ -704,8 +709,8 @@ __global__ __launch_bounds__(256) void cluster_sums_kernel(const T *__restrict__
                         }
                     }
             }
-            // the (total % 4) trailing elements of the range
-            for (int64_t e = nvec * 4 + tid; e < total; e += 256) {
+            // the (total % VEC) trailing elements of the range
+            for (int64_t e = nvec * VEC + tid; e < total; e += NT) {
                 const int64_t row = e / c;
                 const int ch = (int)(e - row * c), lb = labels[r0 + row] - 1;
                 if (lb >= 0 && lb < k) {
@@ -723,14 +728,14 @@ __global__ __launch_bounds__(256) void cluster_sums_kernel(const T *__restrict__
         const int64_t total = (r1 - r0) * c;
         int64_t row = r0 + tid / c;
         int ch = tid % c;
-        const int drow = 256 / c, dch = 256 % c;
-        for (int64_t e = tid; e < total; e += 1024) {
+        const int drow = NT / c, dch = NT % c;
+        for (int64_t e = tid; e < total; e += 4 * NT) {
             int cc[4], lab[4];
             double v[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 cc[u] = ch;
-                const bool ok = e + 256 * u < total;
+                const bool ok = e + NT * u < total;
                 lab[u] = ok ? labels[row] - 1 : -1;
                 v[u] = ok ? (double)x[row * ldx + ch] : 0.0;
                 row += drow;
@@ -764,11 +769,11 @@ __global__ __launch_bounds__(256) void cluster_sums_kernel(const T *__restrict__
     }
     if (use_lds) {
         __syncthreads();
-        for (int e = tid; e < k * c; e += 256) {
+        for (int e = tid; e < k * c; e += NT) {
             const double v = ls[e];
             if (v != 0.0) __hip_atomic_fetch_add(&sums[e], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        for (int e = tid; e < k; e += 256)
+        for (int e = tid; e < k; e += NT)
             if (lc[e]) {
                 if constexpr (COUNT_F64)
                     __hip_atomic_fetch_add(reinterpret_cast<double *>(counts) + e, (double)lc[e], __ATOMIC_RELAXED,
@@ -1119,12 +1124,16 @@ int cluster_sums_typed(const T *x, int64_t n, int c, int64_t ldx, const int32_t 
     // small inputs: latency-bound per workgroup, so spread them wide (128 rows per workgroup)
     int64_t grid = std::min<int64_t>((n + 127) / 128, (int64_t)cus * (lds <= 32 * 1024 ? 4 : 1));
     if (grid < 1) grid = 1;
-    const int64_t rows_per_block = (n + grid - 1) / grid;
-    auto kern = cluster_sums_kernel<T, COUNT_F64>;
+    // (multiples of 16 rows keep every workgroup's range 16-byte aligned for the vector loads)
+    const int64_t rows_per_block = ((n + grid - 1) / grid + 15) / 16 * 16;
+    // one table per CU (K = 400 x C = 40: 128 KB): 16 waves share it, so that enough loads and LDS atomics are in
+    // flight; small tables keep 4-wave workgroups (several per CU)
+    const bool wide = use_lds && lds > 64 * 1024 && n >= 65536;
+    auto kern = wide ? cluster_sums_kernel<T, COUNT_F64, 1024> : cluster_sums_kernel<T, COUNT_F64, 256>;
     if (use_lds && lds > 48 * 1024)
         PXSOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), use_lds ? lds : 0, st, x, n, c, ldx, labels, k,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(wide ? 1024 : 256), use_lds ? lds : 0, st, x, n, c, ldx, labels, k,
                        sums, reinterpret_cast<unsigned long long *>(counts), rows_per_block, use_lds);
     PXSOM_LAUNCH_CHECK("cluster_sums_kernel");
     return PXSOM_OK;
@@ -1330,8 +1339,8 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
     static int tpw = 0;   // 16-row tiles per wave of the fused step (tuning hook)
     if (tpw == 0) {
         const char *e = getenv("PXSOM_STEP_TPW");
-        tpw = e ? atoi(e) : 2;
-        if (tpw != 1) tpw = 2;
+        tpw = e ? atoi(e) : 1;   // measured on config 2 (16 K-row steps): 1 tile per wave 0.93 ms / pass, 2 tiles 0.99
+        if (tpw != 2) tpw = 1;
     }
     for (int g = g_begin; g < g_end; g++) {
         const int t = g % m;

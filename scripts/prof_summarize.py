@@ -20,7 +20,7 @@ def short(name):
 
 def main():
     src, dst = sys.argv[1], sys.argv[2]
-    keep = sys.argv[3:] or ["bmu_", "som_online", "cluster_sums", "batch_update", "blur", "rownorm",
+    keep = sys.argv[3:] or ["bmu_", "som_online", "cluster_sums", "batch_update", "batch_step", "blur", "rownorm",
                             "quantile", "normalize"]
     lines = []
     for f in sorted(glob.glob(os.path.join(src, "**", "*kernel_stats.csv"), recursive=True)):

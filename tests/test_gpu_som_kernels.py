@@ -585,6 +585,40 @@ def test_cell_som_shape_full_size_properties(gpu, oracle):
     np.testing.assert_allclose(sums.sum(dim=0).cpu().numpy(), x.double().sum(dim=0).cpu().numpy(), rtol=1e-9)
 
 
+def test_config5_at_fov_size(gpu, oracle):
+    """BASELINE config 5's shape at FOV size on one GPU: one 2048 x 2048 x 40 fp16 FOV, 20 x 20 SOM.  Batch training
+    on the 10 % subset, labels of every pixel against the oracle on a 100 k-row sample (bit-exact), range /
+    idempotence / count properties over all rows, per-cluster sums against a binary64 scatter-add of the same
+    values, meta-cluster lookup."""
+    from ark_analysis_amd.distributed import BatchSOMTrainer
+    n, c, xdim, ydim = 2048 * 2048, 40, 20, 20
+    k = xdim * ydim
+    x = synth.make_fov_torch(n, c, seed=55, device=gpu, dtype=torch.float16)
+    sub = x[::10].contiguous()
+    g = torch.Generator(device="cpu")
+    g.manual_seed(3)
+    w = sub[torch.randperm(sub.shape[0], generator=g)[:k].to(gpu)].double().contiguous()
+    BatchSOMTrainer(xdim, ydim, c, gpu, batch_steps=16).train(sub, w, num_passes=1)
+    assert bool(torch.isfinite(w).all())
+    labels, _ = sd.assign(x, w)
+    exact_rows = sd.last_exact_rows(sd.assign.last_workspace)
+    labels2, _ = sd.assign(x, w)
+    assert torch.equal(labels, labels2)
+    assert int(labels.min()) >= 1 and int(labels.max()) <= k
+    assert exact_rows < n // 10, f"{exact_rows} of {n} rows took the exact path"
+    idx = torch.randperm(n, device=gpu)[:100_000]
+    want, _ = oracle.map_data_to_nodes(w.cpu().numpy(), x[idx].double().cpu().numpy())
+    np.testing.assert_array_equal(labels[idx].cpu().numpy(), want)
+    sums, counts = sd.cluster_sums(x, labels, k)
+    np.testing.assert_array_equal(counts.cpu().numpy(), torch.bincount(labels.long() - 1, minlength=k).cpu().numpy())
+    assert int(counts.sum()) == n
+    ref = torch.zeros((k, c), dtype=torch.float64, device=gpu).index_add_(0, labels.long() - 1, x.double())
+    np.testing.assert_allclose(sums.cpu().numpy(), ref.cpu().numpy(), rtol=1e-12, atol=1e-9)
+    lut = torch.from_numpy(np.concatenate([[0], np.random.RandomState(1).randint(1, 21, size=k)]).astype(np.int32)).to(gpu)
+    meta = sd.relabel(labels, lut)
+    assert torch.equal(meta, lut[labels.long()])
+
+
 def test_relabel_matches_numpy(gpu):
     rs = np.random.RandomState(4)
     for n, k in [(1_000_003, 400), (37, 100), (0, 5), (4096, 1)]:
