@@ -101,6 +101,10 @@ template <typename T>
 int launch_batch_step(const T *x, int64_t n, int c, int64_t ldx, double *stats, const StepArgs &sa,
                       int tiles_per_wave, hipStream_t st);
 
+// pending update + codebook preparation for the generic BMU search in one launch (pxsom_batch_step.hip); returns
+// false when the shape is not covered (then *rc is untouched and the caller takes the launch-per-phase route)
+bool launch_update_prepare(const StepArgs &sa, int xdim, int ydim, int c, char *ws, const Layout &L, hipStream_t st, int *rc);
+
 // pxsom_assign with the batch rule's accumulation fused in (pxsom_assign.hip).  *fused = false: the shape
 // is outside the fused path, nothing was done, the caller runs assign + cluster sums separately.
 int assign_accumulate(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev, int k,

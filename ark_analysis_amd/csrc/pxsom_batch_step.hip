@@ -28,6 +28,10 @@
 namespace pxsom_bmu {
 namespace {
 
+#ifdef PXSOM_PHASE_TIMING
+__device__ long long g_block_ticks[2 * 256];   // per workgroup: first and last instruction (s_memtime)
+#endif
+
 constexpr int kXD = 10, kYD = 10, kK = 100, kNB = 7;
 constexpr int kStepThreads = 512, kStepWaves = 8;
 constexpr int kQueueRows = 96;       // listed rows a workgroup keeps in LDS; further ones are settled on the spot
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
     typedef typename Pair<T>::type P2;
     PXSOM_PHASE(8);
 #ifdef PXSOM_PHASE_TIMING
-    const long long t_start = clock64();
+    const long long t_start = wall_clock64();   // s_memrealtime: 100 MHz, one counter for the whole chip
 #endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -571,10 +575,242 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
     __builtin_amdgcn_s_waitcnt(0);
     PXSOM_PHASE(19);
     if (tid == 0) {
-        atomicMin((unsigned long long *)&g_phase_ticks[28], (unsigned long long)t_start);
-        atomicMax((unsigned long long *)&g_phase_ticks[29], (unsigned long long)clock64());
+        g_block_ticks[blockIdx.x * 2] = t_start;
+        g_block_ticks[blockIdx.x * 2 + 1] = wall_clock64();
     }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// Codebooks too big for the all-in-one step kernel (K = 400 x C = 40: fragments + statistics table exceed one CU's
+// LDS; C = 100: the same): the pending update and the codebook preparation run ONCE, in one single-workgroup launch
+// (instead of copy + update + 2 clears + prep), and leave what the generic BMU search reads in the assign workspace:
+// fragments, bias, header, transposed binary64 copy.  Same arithmetic as the head of batch_step_kernel: separable
+// window sums in registers, node values / norms / duplicate keys in the registers of thread <-> (node, part),
+// duplicates by a key scan shared by the node's lanes.  1024 threads.
+// ------------------------------------------------------------------------------------------------
+constexpr int kUpdThreads = 1024, kUpdWaves = 16;
+
+template <int XD, int YD, int CPP>
+__global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs sa, int c, AssignHdr *hdr_g, half8 *wfrag,
+                                                                        f32x4 *bias_g, double *wt_out, int nb, int nch,
+                                                                        int cpl, int idx_bits, int parts_log2)
+{
+    constexpr int K = XD * YD;
+    extern __shared__ __attribute__((aligned(16))) char upd_smem[];
+    const int NC = c + 1;
+    double *tl = reinterpret_cast<double *>(upd_smem);                       // [K * NC] window sums; then W_new [K][c]
+    unsigned long long *key = reinterpret_cast<unsigned long long *>(tl + (size_t)K * NC);   // [K]
+    double *red = reinterpret_cast<double *>(key + K);                       // [2 * waves]
+    float *biasv = reinterpret_cast<float *>(red + 2 * kUpdWaves);           // [K]
+    int *flags = reinterpret_cast<int *>(biasv + K);                         // [0]: NaN / Inf met
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int parts = 1 << parts_log2;
+    const int node = tid >> parts_log2, part = tid & (parts - 1);
+    const bool has_node = node < K;
+    const int cpp = (c + parts - 1) / parts;          // channels per part (<= CPP)
+    const int ch0 = part * cpp;
+
+    // ---- requests, in the order they are needed: statistics, old node values
+    double S[YD], wv_[CPP];
+    const bool p1 = sa.has_update && tid < XD * NC;
+    const int gx = p1 ? tid / NC : 0, cc = p1 ? tid - gx * NC : 0;
+    if (sa.has_update) {
+#pragma unroll
+        for (int y = 0; y < YD; y++)
+            S[y] = sa.stats_prev[cc < c ? (size_t)(gx * YD + y) * c + cc : (size_t)K * c + gx * YD + y];
+    }
+#pragma unroll
+    for (int i = 0; i < CPP; i++) wv_[i] = sa.w_in[(has_node && i < cpp && ch0 + i < c) ? (size_t)node * c + ch0 + i : 0];
+    if (tid == 0) flags[0] = 0;
+    if (sa.stats_zero)
+        for (int e = tid; e < sa.zero_count; e += kUpdThreads) sa.stats_zero[e] = 0.0;
+    if (sa.has_update) {
+        const double thr = sa.thr;
+        const int r = thr < 0.0 ? -1 : (thr > 1.0e6 ? 1000000 : (int)floor(thr));
+        double md[XD > YD ? XD : YD];
+#pragma unroll
+        for (int d = 0; d < (XD > YD ? XD : YD); d++) md[d] = d <= r ? 1.0 : 0.0;
+        if (p1) {
+#pragma unroll
+            for (int yp = 0; yp < YD; yp++) {
+                double t = 0.0;
+#pragma unroll
+                for (int y = 0; y < YD; y++) t = __builtin_fma(md[y > yp ? y - yp : yp - y], S[y], t);
+                tl[(size_t)(yp * XD + gx) * NC + cc] = t;
+            }
+        }
+        __syncthreads();
+        if (tid < YD * NC) {
+            const int yp = tid / NC, c2 = tid - yp * NC;
+            double *col = tl + (size_t)(yp * XD) * NC + c2;
+            double Tx[XD];
+#pragma unroll
+            for (int gx2 = 0; gx2 < XD; gx2++) Tx[gx2] = col[(size_t)gx2 * NC];
+#pragma unroll
+            for (int xp = 0; xp < XD; xp++) {
+                double t = 0.0;
+#pragma unroll
+                for (int gx2 = 0; gx2 < XD; gx2++) t = __builtin_fma(md[gx2 > xp ? gx2 - xp : xp - gx2], Tx[gx2], t);
+                col[(size_t)xp * NC] = t;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- new node values (registers), norms, keys, maxima
+    double nrm = 0.0, mymax = 0.0;
+    unsigned long long kkey = 0;
+    bool bad = false;
+    if (has_node) {
+#pragma clang fp contract(off)
+        double den = 0.0, gain = -1.0, inv = 0.0;
+        const int xp = node / YD, yp = node - xp * YD;
+        const double *nrow = tl + (size_t)(yp * XD + xp) * NC;
+        if (sa.has_update) {
+            den = nrow[c];
+            if (den > 0.0) {
+                gain = -expm1(den * sa.lg);
+                inv = 1.0 / den;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CPP; i++) {
+            const int ch = ch0 + i;
+            if (i < cpp && ch < c) {
+                double v = wv_[i];
+                if (gain >= 0.0) {
+                    const double num = nrow[ch];
+                    v = gain == 1.0 ? num * inv : v + gain * (num * inv - v);
+                }
+                wv_[i] = v;
+                if (sa.w_out) sa.w_out[(size_t)node * c + ch] = v;
+                bad |= !(fabs(v) <= DBL_MAX);
+                nrm += v * v;
+                mymax = fmax(mymax, fabs(v));
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+                const int rot = (7 * ch + 1) & 63;
+                kkey ^= (bits << rot) | (bits >> ((64 - rot) & 63));
+            }
+        }
+    }
+    for (int m = 1; m < parts; m <<= 1) {   // the lanes of a node are adjacent: butterfly
+        nrm += __shfl_xor(nrm, m);
+        kkey ^= __shfl_xor(kkey, m);
+    }
+    if (has_node && part == 0) key[node] = kkey;
+    if (bad) flags[0] = 1;
+    {
+        const double wmax = -pxsom::wave_min_f64(-mymax);
+        const double nmax = -pxsom::wave_min_f64(-((has_node && nrm == nrm) ? nrm : 0.0));
+        if (lane == 0) {
+            red[wv] = wmax;
+            red[kUpdWaves + wv] = nmax;
+        }
+    }
+    __syncthreads();   // every read of the window sums is done: the region becomes W_new [K][c]
+    if (has_node) {
+#pragma unroll
+        for (int i = 0; i < CPP; i++)
+            if (i < cpp && ch0 + i < c) tl[(size_t)node * c + ch0 + i] = wv_[i];
+    }
+    double maxabs = red[0], wn2max = red[kUpdWaves];
+#pragma unroll
+    for (int i = 1; i < kUpdWaves; i++) {
+        maxabs = fmax(maxabs, red[i]);
+        wn2max = fmax(wn2max, red[kUpdWaves + i]);
+    }
+    int e = 0;
+    if (maxabs > 0.0 && maxabs <= DBL_MAX) {
+        int ex;
+        frexp(maxabs, &ex);
+        e = 8 - ex;
+        if (e > 100) e = 100;
+        if (e < -100) e = -100;
+    }
+    const double scale = ldexp(1.0, e);
+    __syncthreads();
+    const bool badw = flags[0] != 0 || !(wn2max * scale * scale <= 1.0e30);
+    if (tid == 0) {
+        hdr_g->amb_count = 0;
+        hdr_g->scale = (float)scale;
+        hdr_g->wn_max = badw ? 0.f : (float)(sqrt(wn2max) * scale * (1.0 + 1e-6));
+        hdr_g->force_exact = badw ? 1 : 0;
+        hdr_g->tol_rel = sa.tol_rel;
+        hdr_g->tol_abs = sa.tol_abs;
+        hdr_g->x_limit = 60000.0f;
+        hdr_g->nb = nb;
+        hdr_g->nch = nch;
+        hdr_g->cpl = cpl;
+        hdr_g->idx_bits = idx_bits;
+        hdr_g->node_bits = idx_bits;
+    }
+    // ---- exact duplicates of an earlier node: key scan shared by the node's lanes, then channel-by-channel
+    if (has_node) {
+        auto same_as = [&](int prev) {
+            bool eq = true;
+#pragma unroll
+            for (int i = 0; i < CPP; i++)
+                if (i < cpp && ch0 + i < c) eq &= tl[(size_t)prev * c + ch0 + i] == wv_[i];
+            int ee = eq ? 1 : 0;
+            for (int m = 1; m < parts; m <<= 1) ee &= __shfl_xor(ee, m);
+            return ee != 0;
+        };
+        int hit = 0x7fffffff;
+#pragma unroll 4
+        for (int prev = part; prev < K; prev += parts) hit = min(hit, (prev < node && key[prev] == kkey) ? prev : 0x7fffffff);
+        for (int m = 1; m < parts; m <<= 1) hit = min(hit, __shfl_xor(hit, m));
+        bool dup = false;
+        if (hit != 0x7fffffff) {
+            dup = same_as(hit);
+            for (int prev = hit + 1; prev < node && !dup; prev++)
+                if (key[prev] == kkey) dup = same_as(prev);
+        }
+        if (part == 0) biasv[node] = dup ? kNegBig : (float)(-0.5 * nrm * scale * scale);
+    }
+    __syncthreads();
+    // ---- what the generic BMU search reads: fragments, bias, transposed copy (pxsom_prep.h layouts)
+    const int nsteps = 2 * nch;
+    for (int f = tid; f < nb * nch * 64; f += kUpdThreads) {
+        const int fl = f & 63, h = (f >> 6) % nch, b = (f >> 6) / nch;
+        const int m = fl & 15, q = fl >> 4;
+        const int nd = node_of_row(b, m, nb);
+        half8 fhi, flo;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int ch = h * 4 * cpl + q * cpl + i;
+            float W = 0.f;
+            if (i < cpl && ch < c && nd < K) W = (float)(tl[(size_t)nd * c + ch] * scale);
+            const _Float16 hi = (_Float16)W;
+            fhi[i] = hi;
+            flo[i] = (_Float16)(W - (float)hi);
+        }
+        wfrag[(size_t)(b * nsteps + 2 * h) * 64 + fl] = fhi;
+        wfrag[(size_t)(b * nsteps + 2 * h + 1) * 64 + fl] = flo;
+    }
+    for (int f = tid; f < nb * 64; f += kUpdThreads) {
+        const int fl = f & 63, b = f >> 6, q = fl >> 4;
+        f32x4 bv;
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const int nd = node_of_row(b, q * 4 + rr, nb);
+            bv[rr] = nd < K ? biasv[nd] : kNegBig;
+        }
+        bias_g[f] = bv;
+    }
+    if (wt_out) {
+        int j = tid / K, nd = tid - j * K;
+        const int dj = kUpdThreads / K, dn = kUpdThreads % K;
+        for (int e2 = tid; e2 < K * c; e2 += kUpdThreads) {
+            wt_out[e2] = tl[(size_t)nd * c + j];
+            j += dj;
+            nd += dn;
+            if (nd >= K) {
+                nd -= K;
+                j++;
+            }
+        }
+    }
 }
 
 template <typename T, int CPL>
@@ -604,6 +840,38 @@ int launch_step(const T *x, int64_t n, int c, int64_t ldx, double *stats, const 
 }
 
 }  // namespace
+
+// The pending update + codebook preparation for the generic BMU search, one launch (false: shape not covered).
+bool launch_update_prepare(const StepArgs &sa, int xdim, int ydim, int c, char *ws, const Layout &L, hipStream_t st, int *rc)
+{
+    *rc = PXSOM_OK;
+    const int k = xdim * ydim;
+    if (!((xdim == 10 && ydim == 10) || (xdim == 20 && ydim == 20)) || k * 1 > kUpdThreads) return false;
+    int pl = 0;
+    while ((k << (pl + 1)) <= kUpdThreads && pl < 3) pl++;
+    const int parts = 1 << pl, cpp = (c + parts - 1) / parts;
+    if (cpp > 20 || xdim * (c + 1) > kUpdThreads) return false;
+    const size_t lds = ((size_t)k * (c + 1) + k + 2 * kUpdWaves) * 8 + (size_t)k * 4 + 64;
+    if (lds > 158 * 1024) return false;
+    auto kern = xdim == 10 ? batch_update_prep_kernel<10, 10, 20> : batch_update_prep_kernel<20, 20, 20>;
+    static size_t attr[2] = {0, 0};
+    size_t &have = attr[xdim == 10 ? 0 : 1];
+    if (have < lds) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            *rc = pxsom::fail(PXSOM_ERR_HIP, "batch update+prepare kernel: LDS limit %zu: %s", lds, hipGetErrorString(e));
+            return true;
+        }
+        have = lds;
+    }
+    double *wt_out = L.off_list > L.off_wt ? reinterpret_cast<double *>(ws + L.off_wt) : nullptr;
+    hipLaunchKernelGGL(kern, dim3(1), dim3(kUpdThreads), lds, st, sa, c, reinterpret_cast<AssignHdr *>(ws),
+                       reinterpret_cast<half8 *>(ws + L.off_wfrag), reinterpret_cast<f32x4 *>(ws + L.off_bias), wt_out, L.nb,
+                       L.nch, L.cpl, L.idx_bits, pl);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) *rc = pxsom::hip_fail(e, "batch_update_prep_kernel");
+    return true;
+}
 
 // Shapes the fused step kernel covers: the Pixie pixel SOM's -- 10 x 10 grid, even c <= 32, pair-aligned rows.
 template <typename T>

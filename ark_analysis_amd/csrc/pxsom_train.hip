@@ -1372,6 +1372,34 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
             if (rc) return rc;
             continue;
         }
+        // codebooks the all-in-one kernel cannot hold (K = 400, or C > 32): ONE launch applies the pending update and
+        // prepares the assign workspace for W_g (copy + update + clears + prep before), then search / exact / sums
+        if (!(flags & PXSOM_TRAIN_UNFUSED)) {
+            const pxsom_bmu::Layout L = pxsom_bmu::make_layout(rows, c, k);
+            pxsom_bmu::StepArgs sa;
+            sa.w_in = g > 0 ? w_prev : w_cur;
+            sa.w_out = g > 0 ? w_cur : nullptr;
+            sa.stats_prev = s_prev;
+            sa.stats_zero = s_next;
+            sa.zero_count = (int)nstats;
+            sa.has_update = g > 0 ? 1 : 0;
+            sa.thr = thr;
+            sa.lg = log1p(-alpha);
+            sa.tol_rel = (float)(2.5 * (ldexp(1.0, -(23 - L.idx_bits)) + (3.0 * c + 2.0) * ldexp(1.0, -24) + ldexp(1.0, -19) +
+                                        ldexp(1.0, -23)));
+            sa.tol_abs = (float)(2.5 * ldexp(1.0, -24) * sqrt((double)c));
+            int rc = PXSOM_OK;
+            if (pxsom_bmu::launch_update_prepare(sa, xdim, ydim, c, ws, L, st, &rc)) {
+                if (rc) return rc;
+                if (rows > 0) {
+                    rc = pxsom_bmu::assign_prepared(xv, rows, c, ldv, dtype, w_cur, k, labels, ws, assign_ws, st);
+                    if (rc) return rc;
+                    rc = cluster_sums_typed<T, true>(xv, rows, c, ldv, labels, k, s_cur, reinterpret_cast<int64_t *>(s_cur + nw), st);
+                    if (rc) return rc;
+                }
+                continue;
+            }
+        }
         if (g > 0) {
             PXSOM_HIP_TRY(hipMemcpyAsync(w_cur, w_prev, nw * sizeof(double), hipMemcpyDeviceToDevice, st));
             int rc = pxsom_batch_update(w_cur, xdim, ydim, c, s_prev, s_prev + nw, thr, alpha, st);

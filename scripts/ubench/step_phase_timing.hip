@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 
 int main(int argc, char **argv)
 {
@@ -47,11 +48,6 @@ int main(int argc, char **argv)
             const int64_t rows = (n - g + M - 1) / M;
             int rc = launch_batch_step<float>(dx + (size_t)g * c, rows, c, (int64_t)c * M, dring + (g % 3) * ns, sa, tpw, 0);
             if (rc) { printf("rc %d %s\n", rc, pxsom_last_error()); return 1; }
-            if (rep == 1 && (g == 0 || g == 19 || g == 39 || g == 62)) {
-                hipDeviceSynchronize();
-                long long z[2] = {0x7fffffffffffffffLL, 0};
-                hipMemcpyToSymbol(HIP_SYMBOL(g_phase_ticks), z, sizeof(z), 28 * sizeof(long long));
-            }
             if (rep == 1 && (g == 1 || g == 20 || g == 40 || g == 63)) {
                 hipDeviceSynchronize();
                 long long t[32];
@@ -61,7 +57,20 @@ int main(int argc, char **argv)
                        "filter %.2f | exact(%lld) %.2f | flush-issue %.2f flush-done %.2f | total %.2f us\n",
                        g, thr, us(8, 9), us(9, 10), us(10, 11), us(11, 12), us(12, 13), us(13, 14), us(14, 15), us(15, 16), t[21],
                        us(16, 17), us(17, 18), us(18, 19), us(8, 19));
-                printf("         first workgroup start -> last workgroup end: %.2f us\n", us(28, 29));
+                {
+                    long long bt[512];
+                    hipMemcpyFromSymbol(bt, HIP_SYMBOL(g_block_ticks), sizeof(bt));
+                    const int nwg = (int)((rows + (tpw == 1 ? 127 : 255)) / (tpw == 1 ? 128 : 256));
+                    long long s0 = bt[0], s1 = bt[0], e0 = bt[1], e1 = bt[1];
+                    double dsum = 0;
+                    for (int b = 0; b < nwg; b++) {
+                        s0 = std::min(s0, bt[2 * b]); s1 = std::max(s1, bt[2 * b]);
+                        e0 = std::min(e0, bt[2 * b + 1]); e1 = std::max(e1, bt[2 * b + 1]);
+                        dsum += (double)(bt[2 * b + 1] - bt[2 * b]);
+                    }
+                    printf("         %d workgroups: starts spread %.2f us, ends spread %.2f us, mean in-workgroup time %.2f us, first start -> last end %.2f us\n",
+                           nwg, (s1 - s0) / 100.0, (e1 - e0) / 100.0, dsum / nwg / 100.0, (e1 - s0) / 100.0);
+                }
             }
         }
         hipEventRecord(e1, 0);

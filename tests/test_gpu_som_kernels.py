@@ -457,15 +457,18 @@ def test_batch_update_prepare_matches_oracle_and_chains(gpu, oracle, xdim, ydim,
     np.testing.assert_allclose(wa.cpu().numpy(), want_b, rtol=1e-9, atol=0)
 
 
-@pytest.mark.parametrize("c,dtype,n,m,passes", [(22, np.float32, 40_000, 8, 1), (22, np.float32, 9_001, 4, 2),
-                                                  (8, np.float32, 20_000, 16, 1), (16, np.float16, 30_000, 8, 1),
-                                                  (32, np.float32, 12_345, 5, 1), (22, np.float64, 10_000, 4, 1)])
-def test_batch_train_steps_fused_equals_unfused_and_oracle(gpu, oracle, c, dtype, n, m, passes):
+@pytest.mark.parametrize("c,dtype,n,m,passes,grid", [
+    (22, np.float32, 40_000, 8, 1, 10), (22, np.float32, 9_001, 4, 2, 10), (8, np.float32, 20_000, 16, 1, 10),
+    (16, np.float16, 30_000, 8, 1, 10), (32, np.float32, 12_345, 5, 1, 10), (22, np.float64, 10_000, 4, 1, 10),
+    # codebooks beyond the all-in-one kernel: one update + prepare launch, then search / exact / sums
+    (100, np.float32, 30_000, 6, 1, 10), (40, np.float16, 40_000, 6, 1, 20), (40, np.float32, 21_000, 4, 2, 20),
+    (64, np.float32, 9_000, 3, 1, 10)])
+def test_batch_train_steps_fused_equals_unfused_and_oracle(gpu, oracle, c, dtype, n, m, passes, grid):
     """pxsom_batch_train_steps on a 10 x 10 grid: the one-launch-per-step route (pending update + prep at the
     head of the BMU search) against the launch-per-phase route step by step (codebooks and statistics, bit for
     bit for rows that sum exactly in binary64), against a run in one call, and against orc_som_batch."""
-    xdim = ydim = 10
-    k = 100
+    xdim = ydim = grid
+    k = xdim * ydim
     x = synth.make_fov_numpy(n, c, seed=77, dtype=np.float32).astype(dtype)
     w0 = _codebook(x.astype(np.float64), k, seed=12)
     w0[17] = w0[3]                       # a duplicate node from the start
