@@ -610,9 +610,15 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
     const bool has_node = node < K;
     const int cpp = (c + parts - 1) / parts;          // channels per part (<= CPP)
     const int ch0 = part * cpp;
+    PXSOM_PHASE(0);
 
-    // ---- requests, in the order they are needed: statistics, old node values
-    double S[YD], wv_[CPP];
+    // ---- requests, in the order they are needed: statistics, old node values.  Every global access of this kernel is
+    // coalesced (element e = tid + 1024 u of a row-major array): one workgroup issues all of them, and a wave-load
+    // whose lanes sit 8 c bytes apart costs a cache line per lane.
+    constexpr int kMaxE = (K * 128 + kUpdThreads - 1) / kUpdThreads;   // elements of W per thread (c <= 128)
+    double S[YD], wold[kMaxE < 16 ? kMaxE : 16];
+    constexpr int kE = kMaxE < 16 ? kMaxE : 16;
+    const int ne = (K * c + kUpdThreads - 1) / kUpdThreads;            // <= kE (checked by the host)
     const bool p1 = sa.has_update && tid < XD * NC;
     const int gx = p1 ? tid / NC : 0, cc = p1 ? tid - gx * NC : 0;
     if (sa.has_update) {
@@ -621,25 +627,25 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
             S[y] = sa.stats_prev[cc < c ? (size_t)(gx * YD + y) * c + cc : (size_t)K * c + gx * YD + y];
     }
 #pragma unroll
-    for (int i = 0; i < CPP; i++) wv_[i] = sa.w_in[(has_node && i < cpp && ch0 + i < c) ? (size_t)node * c + ch0 + i : 0];
+    for (int u = 0; u < kE; u++) wold[u] = sa.w_in[(u < ne && tid + kUpdThreads * u < K * c) ? tid + kUpdThreads * u : 0];
     if (tid == 0) flags[0] = 0;
     if (sa.stats_zero)
         for (int e = tid; e < sa.zero_count; e += kUpdThreads) sa.stats_zero[e] = 0.0;
+    PXSOM_PHASE(1);
     if (sa.has_update) {
         const double thr = sa.thr;
         const int r = thr < 0.0 ? -1 : (thr > 1.0e6 ? 1000000 : (int)floor(thr));
-        double md[XD > YD ? XD : YD];
-#pragma unroll
-        for (int d = 0; d < (XD > YD ? XD : YD); d++) md[d] = d <= r ? 1.0 : 0.0;
+        // window mask as a uniform select per term (|y - y'| <= r ? 1 : 0): no table of masks to keep in registers
         if (p1) {
 #pragma unroll
             for (int yp = 0; yp < YD; yp++) {
                 double t = 0.0;
 #pragma unroll
-                for (int y = 0; y < YD; y++) t = __builtin_fma(md[y > yp ? y - yp : yp - y], S[y], t);
+                for (int y = 0; y < YD; y++) t = __builtin_fma((y > yp ? y - yp : yp - y) <= r ? 1.0 : 0.0, S[y], t);
                 tl[(size_t)(yp * XD + gx) * NC + cc] = t;
             }
         }
+        PXSOM_PHASE(2);
         __syncthreads();
         if (tid < YD * NC) {
             const int yp = tid / NC, c2 = tid - yp * NC;
@@ -651,53 +657,84 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
             for (int xp = 0; xp < XD; xp++) {
                 double t = 0.0;
 #pragma unroll
-                for (int gx2 = 0; gx2 < XD; gx2++) t = __builtin_fma(md[gx2 > xp ? gx2 - xp : xp - gx2], Tx[gx2], t);
+                for (int gx2 = 0; gx2 < XD; gx2++) t = __builtin_fma((gx2 > xp ? gx2 - xp : xp - gx2) <= r ? 1.0 : 0.0, Tx[gx2], t);
                 col[(size_t)xp * NC] = t;
             }
         }
-    }
-    __syncthreads();
-
-    // ---- new node values (registers), norms, keys, maxima
-    double nrm = 0.0, mymax = 0.0;
-    unsigned long long kkey = 0;
-    bool bad = false;
-    if (has_node) {
+        PXSOM_PHASE(3);
+        __syncthreads();
+        // gain and 1/den of every node, once (key[] / biasv[] double as scratch until they get their own contents)
+        double *gain_l = reinterpret_cast<double *>(key);        // [K]
+        if (tid < K) {
+            const int xp = tid / YD, yp = tid - xp * YD;
+            const double den = tl[(size_t)(yp * XD + xp) * NC + c];
+            gain_l[tid] = den > 0.0 ? -expm1(den * sa.lg) : -1.0;
+            tl[(size_t)(yp * XD + xp) * NC + c] = den > 0.0 ? 1.0 / den : 0.0;     // the count column now holds 1/den
+        }
+        PXSOM_PHASE(4);
+        __syncthreads();
+        // new node values, element-wise (coalesced); kept in registers until every read of the window sums is done
+        {
 #pragma clang fp contract(off)
-        double den = 0.0, gain = -1.0, inv = 0.0;
-        const int xp = node / YD, yp = node - xp * YD;
-        const double *nrow = tl + (size_t)(yp * XD + xp) * NC;
-        if (sa.has_update) {
-            den = nrow[c];
-            if (den > 0.0) {
-                gain = -expm1(den * sa.lg);
-                inv = 1.0 / den;
+            int nd = tid / c, j = tid - nd * c;
+            const int dnd = kUpdThreads / c, dj = kUpdThreads % c;
+#pragma unroll
+            for (int u = 0; u < kE; u++) {
+                const int e = tid + kUpdThreads * u;
+                if (u < ne && e < K * c) {
+                    const int xp = nd / YD, yp = nd - xp * YD;
+                    const double *nrow = tl + (size_t)(yp * XD + xp) * NC;
+                    const double gain = gain_l[nd];
+                    double v = wold[u];
+                    if (gain >= 0.0) {
+                        const double mean = nrow[j] * nrow[c];
+                        v = gain == 1.0 ? mean : v + gain * (mean - v);
+                    }
+                    wold[u] = v;
+                    if (sa.w_out) sa.w_out[e] = v;
+                }
+                nd += dnd;
+                j += dj;
+                if (j >= c) {
+                    j -= c;
+                    nd++;
+                }
             }
         }
+        PXSOM_PHASE(5);
+        __syncthreads();
+    }
+    // the window-sum region becomes W_new [K][c]
 #pragma unroll
-        for (int i = 0; i < CPP; i++) {
-            const int ch = ch0 + i;
-            if (i < cpp && ch < c) {
-                double v = wv_[i];
-                if (gain >= 0.0) {
-                    const double num = nrow[ch];
-                    v = gain == 1.0 ? num * inv : v + gain * (num * inv - v);
-                }
-                wv_[i] = v;
-                if (sa.w_out) sa.w_out[(size_t)node * c + ch] = v;
-                bad |= !(fabs(v) <= DBL_MAX);
-                nrm += v * v;
-                mymax = fmax(mymax, fabs(v));
-                const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-                const int rot = (7 * ch + 1) & 63;
-                kkey ^= (bits << rot) | (bits >> ((64 - rot) & 63));
-            }
+    for (int u = 0; u < kE; u++)
+        if (u < ne && tid + kUpdThreads * u < K * c) tl[tid + kUpdThreads * u] = wold[u];
+    __syncthreads();
+
+    // ---- norms, keys, maxima: thread <-> (node, part) over the LDS copy
+    double nrm = 0.0, mymax = 0.0, wv_[CPP];
+    unsigned long long kkey = 0;
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < CPP; i++) {
+        const int ch = ch0 + i;
+        wv_[i] = 0.0;
+        if (has_node && i < cpp && ch < c) {
+            const double v = tl[(size_t)node * c + ch];
+            wv_[i] = v;
+            bad |= !(fabs(v) <= DBL_MAX);
+            nrm += v * v;
+            mymax = fmax(mymax, fabs(v));
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+            const int rot = (7 * ch + 1) & 63;
+            kkey ^= (bits << rot) | (bits >> ((64 - rot) & 63));
         }
     }
     for (int m = 1; m < parts; m <<= 1) {   // the lanes of a node are adjacent: butterfly
         nrm += __shfl_xor(nrm, m);
         kkey ^= __shfl_xor(kkey, m);
     }
+    PXSOM_PHASE(6);
+    __syncthreads();   // (key[] was scratch for the gains)
     if (has_node && part == 0) key[node] = kkey;
     if (bad) flags[0] = 1;
     {
@@ -708,12 +745,7 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
             red[kUpdWaves + wv] = nmax;
         }
     }
-    __syncthreads();   // every read of the window sums is done: the region becomes W_new [K][c]
-    if (has_node) {
-#pragma unroll
-        for (int i = 0; i < CPP; i++)
-            if (i < cpp && ch0 + i < c) tl[(size_t)node * c + ch0 + i] = wv_[i];
-    }
+    __syncthreads();
     double maxabs = red[0], wn2max = red[kUpdWaves];
 #pragma unroll
     for (int i = 1; i < kUpdWaves; i++) {
@@ -745,6 +777,7 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
         hdr_g->idx_bits = idx_bits;
         hdr_g->node_bits = idx_bits;
     }
+    PXSOM_PHASE(7);
     // ---- exact duplicates of an earlier node: key scan shared by the node's lanes, then channel-by-channel
     if (has_node) {
         auto same_as = [&](int prev) {
@@ -768,6 +801,7 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
         }
         if (part == 0) biasv[node] = dup ? kNegBig : (float)(-0.5 * nrm * scale * scale);
     }
+    PXSOM_PHASE(8);
     __syncthreads();
     // ---- what the generic BMU search reads: fragments, bias, transposed copy (pxsom_prep.h layouts)
     const int nsteps = 2 * nch;
@@ -798,6 +832,7 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
         }
         bias_g[f] = bv;
     }
+    PXSOM_PHASE(9);
     if (wt_out) {
         int j = tid / K, nd = tid - j * K;
         const int dj = kUpdThreads / K, dn = kUpdThreads % K;
@@ -811,6 +846,7 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
             }
         }
     }
+    PXSOM_PHASE(10);
 }
 
 template <typename T, int CPL>
@@ -850,7 +886,7 @@ bool launch_update_prepare(const StepArgs &sa, int xdim, int ydim, int c, char *
     int pl = 0;
     while ((k << (pl + 1)) <= kUpdThreads && pl < 3) pl++;
     const int parts = 1 << pl, cpp = (c + parts - 1) / parts;
-    if (cpp > 20 || xdim * (c + 1) > kUpdThreads) return false;
+    if (cpp > 20 || xdim * (c + 1) > kUpdThreads || (k * c + kUpdThreads - 1) / kUpdThreads > 16) return false;
     const size_t lds = ((size_t)k * (c + 1) + k + 2 * kUpdWaves) * 8 + (size_t)k * 4 + 64;
     if (lds > 158 * 1024) return false;
     auto kern = xdim == 10 ? batch_update_prep_kernel<10, 10, 20> : batch_update_prep_kernel<20, 20, 20>;

@@ -57,13 +57,14 @@ class HipKernels:
         st = self._state
         if st is None or not st.fits(n, c, xdim, ydim, batch_steps) or st.wbuf.device != x.device:
             st = self._state = self._sd.BatchTrainState(n, c, xdim, ydim, batch_steps, x.device)
+            self._rings = [st.ring[i] for i in range(3)]     # views made once: ring(g) sits in the per-step loop
         st.wbuf[0].copy_(w)
 
     def steps(self, x, g0: int, g1: int, total: int, alpha_range, radius_range) -> None:
         self._sd.batch_train_steps(x, self._state, g0, g1, total, alpha_range, radius_range, unfused=self.unfused)
 
     def ring(self, g: int) -> torch.Tensor:
-        return self._state.ring[g % 3]
+        return self._rings[g % 3]
 
     def finish(self, steps_done: int, total: int, alpha_range, radius_range, w: torch.Tensor) -> None:
         self._sd.batch_train_finish(self._state, steps_done, total, alpha_range, radius_range, w)
