@@ -401,6 +401,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
     PXSOM_PHASE(14);
     PXSOM_PHASE(15);
     __syncthreads();
+    PXSOM_PHASE(22);
 
     // ---- P7: BMU search of this workgroup's rows -------------------------------------------------------------
     const float tol_rel = sa.tol_rel, tol_abs = sa.tol_abs, x_limit = 60000.0f;
@@ -433,6 +434,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
         float m1[TPW], m2[TPW];
 #pragma unroll
         for (int t = 0; t < TPW; t++) m1[t] = m2[t] = kNegBig;
+        PXSOM_PHASE(23);
 #pragma unroll
         for (int b = 0; b < kNB; b++) {
             const half8 wa0 = frag_l[(b * 2 + 0) * 64 + lane], wa1 = frag_l[(b * 2 + 1) * 64 + lane];
@@ -459,6 +461,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
                 }
             }
         }
+        PXSOM_PHASE(24);
         // the next block's rows (usually none: one block per workgroup) -- the current values are kept
         P2 cur[TPW][NP];
 #pragma unroll

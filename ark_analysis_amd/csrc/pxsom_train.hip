@@ -1229,6 +1229,62 @@ PXSOM_EXPORT int pxsom_batch_update(double *w_dev, int xdim, int ydim, int c, co
     return PXSOM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// labels + per-cluster sums / counts in ONE pass over x (pxsom_assign_sums): for the register-resident shapes the
+// accumulating filter (labels, listed rows settled in binary64 inside the launch, per-workgroup binary64 tables) leaves
+// [k*c sums | k counts as binary64] in a scratch region behind the assign workspace; a small kernel adds them into the
+// caller's tables.  Other shapes: pxsom_assign, then pxsom_cluster_sums.
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void stats_to_tables_kernel(const double *__restrict__ stats, int k, int c, double *sums,
+                                                              long long *counts)
+{
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < k * c + k; e += gridDim.x * 256) {
+        if (e < k * c) sums[e] += stats[e];
+        else counts[e - k * c] += (long long)stats[e];
+    }
+}
+}  // namespace
+
+PXSOM_EXPORT size_t pxsom_assign_sums_workspace_bytes(int64_t n, int c, int k)
+{
+    const size_t a = pxsom_assign_workspace_bytes(n, c, k);
+    return a ? pxsom::align_up(a, 256) + pxsom::align_up((size_t)k * (c + 1) * sizeof(double), 256) : 0;
+}
+
+PXSOM_EXPORT int pxsom_assign_sums(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev, int k,
+                                   int32_t *labels_dev, double *sums_dev, int64_t *counts_dev, void *workspace_dev,
+                                   size_t workspace_bytes, void *stream)
+{
+    int rc = check_matrix("pxsom_assign_sums", x_dev, n, c, ldx, dtype);
+    if (rc) return rc;
+    if (k < 1 || k > PXSOM_MAX_NODES)
+        return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "pxsom_assign_sums: k=%d outside [1, %d]", k, PXSOM_MAX_NODES);
+    if (!w_dev || !sums_dev || !counts_dev || (n > 0 && !labels_dev))
+        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_assign_sums: null pointer");
+    const size_t need = pxsom_assign_sums_workspace_bytes(n, c, k);
+    if (!workspace_dev || workspace_bytes < need)
+        return pxsom::fail(PXSOM_ERR_WORKSPACE, "pxsom_assign_sums: workspace %zu < %zu bytes", workspace_bytes, need);
+    if (n == 0) return PXSOM_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t assign_ws = pxsom::align_up(pxsom_assign_workspace_bytes(n, c, k), 256);
+    double *scratch = reinterpret_cast<double *>(reinterpret_cast<char *>(workspace_dev) + assign_ws);
+    PXSOM_HIP_TRY(hipMemsetAsync(scratch, 0, (size_t)k * (c + 1) * sizeof(double), st));
+    bool fused = false;
+    rc = pxsom_bmu::assign_accumulate(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, scratch, workspace_dev, assign_ws, st,
+                                      &fused);
+    if (rc) return rc;
+    if (fused) {
+        hipLaunchKernelGGL(stats_to_tables_kernel, dim3((k * (c + 1) + 255) / 256), dim3(256), 0, st, scratch, k, c, sums_dev,
+                           reinterpret_cast<long long *>(counts_dev));
+        PXSOM_LAUNCH_CHECK("stats_to_tables_kernel");
+        return PXSOM_OK;
+    }
+    rc = pxsom_assign(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, nullptr, workspace_dev, assign_ws, stream);
+    if (rc) return rc;
+    return pxsom_cluster_sums(x_dev, n, c, ldx, dtype, labels_dev, k, sums_dev, counts_dev, stream);
+}
+
 // codebooks the accumulating filter prepares for itself inside its own launch (register-resident shapes)
 static bool self_preparing_shape(int c, int k)
 {

@@ -389,3 +389,39 @@ def relabel(labels: torch.Tensor, lut: torch.Tensor, fill: int = -1, out: Option
                                    out.data_ptr(), _capi.stream_ptr())
     _capi.check(rc, "pxsom_relabel")
     return out
+
+
+class AssignSumsWorkspace:
+    """Scratch for pxsom_assign_sums, reusable across calls of the same (n_max, c, k)."""
+
+    def __init__(self, n_max: int, c: int, k: int, device):
+        self.bytes = _capi.lib().pxsom_assign_sums_workspace_bytes(int(n_max), int(c), int(k))
+        if self.bytes == 0:
+            raise _capi.PxsomError(f"unsupported assign shape n={n_max} c={c} k={k}")
+        self.n_max, self.c, self.k = int(n_max), int(c), int(k)
+        self.buf = torch.empty(self.bytes, dtype=torch.uint8, device=device)
+
+    def fits(self, n: int, c: int, k: int) -> bool:
+        return c == self.c and k == self.k and n <= self.n_max
+
+
+def assign_sums(x: torch.Tensor, w: torch.Tensor, labels: Optional[torch.Tensor] = None,
+                sums: Optional[torch.Tensor] = None, counts: Optional[torch.Tensor] = None,
+                workspace: Optional[AssignSumsWorkspace] = None):
+    """BMU labels of every row AND the per-label channel sums [K, C] f64 / counts [K] i64 (added into ``sums`` /
+    ``counts``), reading ``x`` once where the shape allows.  Returns ``(labels, sums, counts)``."""
+    n, c, ldx, dt = _matrix_args(x)
+    w = _codebook(w)
+    k = w.shape[0]
+    if labels is None:
+        labels = torch.empty(n, dtype=torch.int32, device=x.device)
+    if sums is None:
+        sums = torch.zeros((k, c), dtype=torch.float64, device=x.device)
+    if counts is None:
+        counts = torch.zeros(k, dtype=torch.int64, device=x.device)
+    if workspace is None or not workspace.fits(n, c, k):
+        workspace = AssignSumsWorkspace(n, c, k, x.device)
+    rc = _capi.lib().pxsom_assign_sums(x.data_ptr(), n, c, ldx, dt, w.data_ptr(), k, labels.data_ptr(), sums.data_ptr(),
+                                       counts.data_ptr(), workspace.buf.data_ptr(), workspace.bytes, _capi.stream_ptr())
+    _capi.check(rc, "pxsom_assign_sums")
+    return labels, sums, counts

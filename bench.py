@@ -9,7 +9,8 @@ One "step" = one pass of the hot path over one batch of synthetic input, residen
 the clock starts ("normalised pixel matrix resident" -> "labels + codebook + mean table
 resident"):  batch-mode SOM training (1 pass over the training subset, `--batch-steps` mini-batch
 steps, statistics all-reduced over RCCL when N > 1)  +  BMU assignment of every row  +  the per-cluster
-mean-expression table over all rows (sums/counts all-reduced once when N > 1).
+mean-expression table over all rows (sums/counts all-reduced once when N > 1); `--one-pass` takes labels and table from
+one pass over x (pxsom_assign_sums) instead of two kernels.
 Workloads (`--config`; BASELINE.json configs):
   cfg2  10 FOVs 1024x1024x22 fp32 per GPU, 10x10 SOM     (configs[1] at N = 1; the metric's configuration; default)
   cfg3  25 FOVs 1024x1024x22 fp32 per GPU, 10x10 SOM     (configs[2]: 200 FOVs over 8 GPUs)
@@ -83,6 +84,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-online", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (traffic / mfma_util)")
+    ap.add_argument("--one-pass", action="store_true",
+                    help="labels and mean table from ONE pass over x (pxsom_assign_sums) instead of pxsom_assign + "
+                         "pxsom_cluster_sums; measured on config 2: 0.444 ms against 0.488 ms for the two kernels, the merged "
+                         "kernel bound by the LDS binary64 atomic rate (0.29 of the HBM roofline against 0.52 + 0.53)")
     ap.add_argument("--pmc-inner", action="store_true", help=argparse.SUPPRESS)   # the run rocprofv3 wraps
     return ap.parse_args()
 
@@ -200,17 +205,22 @@ def main():
     broadcast_codebook(w0, 0)
     w = w0.clone()
     labels = torch.empty(n_all, dtype=torch.int32, device=dev)
-    ws_all = som_device.AssignWorkspace(n_all, C, K, dev)
+    ws_all = som_device.AssignWorkspace(n_all, C, K, dev) if (not args.one_pass) else som_device.AssignSumsWorkspace(n_all, C, K, dev)
     trainer = BatchSOMTrainer(XD, YD, C, dev, batch_steps=args.batch_steps)
     k8_sums = torch.empty((K, C), dtype=torch.float64, device=dev)
     k8_counts = torch.empty(K, dtype=torch.int64, device=dev)
     means = torch.empty((K, C), dtype=torch.float64, device=dev)
 
-    def mean_table():
-        """K8: per-cluster channel means over every row of every rank."""
+    def assign_and_mean_table():
+        """K7 + K8: BMU label of every row and the per-cluster channel means over every row of every rank -- one
+        pass over x (pxsom_assign_sums) with --one-pass, else the BMU search followed by the K8 kernel."""
         k8_sums.zero_()
         k8_counts.zero_()
-        som_device.cluster_sums(x_all, labels, K, sums=k8_sums, counts=k8_counts)
+        if (not args.one_pass):
+            som_device.assign(x_all, w, labels=labels, workspace=ws_all)
+            som_device.cluster_sums(x_all, labels, K, sums=k8_sums, counts=k8_counts)
+        else:
+            som_device.assign_sums(x_all, w, labels=labels, sums=k8_sums, counts=k8_counts, workspace=ws_all)
         if use_dist:
             allreduce_cluster_tables(k8_sums, k8_counts)
         torch.div(k8_sums, k8_counts.clamp(min=1).to(torch.float64).unsqueeze(1), out=means)
@@ -218,8 +228,7 @@ def main():
     def step():
         w.copy_(w0)
         trainer.train(x_train, w, num_passes=1)
-        som_device.assign(x_all, w, labels=labels, workspace=ws_all)
-        mean_table()
+        assign_and_mean_table()
 
     def fence():
         torch.cuda.synchronize()
@@ -242,9 +251,8 @@ def main():
             ev_train[i][0].record()
             trainer.train(x_train, w, num_passes=1)
             ev_train[i][1].record()
-            som_device.assign(x_all, w, labels=labels, workspace=ws_all)
             ev_k8[i][0].record()
-            mean_table()
+            assign_and_mean_table()
             ev_k8[i][1].record()
         fence()
         t1 = time.perf_counter()
@@ -255,7 +263,8 @@ def main():
     elapsed_s = float(elapsed.item())
     train_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_train]))
     k8_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_k8]))
-    exact_rows = som_device.last_exact_rows(ws_all)
+    # (the one-pass kernel settles its listed rows inside the launch: no list to count afterwards)
+    exact_rows = som_device.last_exact_rows(ws_all) if (not args.one_pass) or cfg["c"] > 32 or K != 100 else None
 
     if rank != 0 or args.pmc_inner:
         if use_dist:
@@ -286,16 +295,19 @@ def main():
                    "parallelism": f"{'row' if cfg['kind'] == 'cell' else 'fov'}-shard x{world}",
                    "rccl_ranks": world if use_dist else 0},
         "phases_ms": {"train_batch": round(train_ms, 4),
+                      "assign_and_mean_table": round(k8_ms, 4),
                       "assign_filter_kernel": round(kern_avg_ms, 4),
                       "assign_exact_rows": exact_rows,
-                      "mean_table": round(k8_ms, 4)},
+                      "passes_over_x": 2 if (not args.one_pass) else 1},
         "roofline": ({"kernel": "bmu_filter_kernel", "bound": "mfma", "achieved": round(achieved_tf, 1),
                       "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved_tf / MFMA_F16_PEAK_TFLOPS, 4),
                       "traffic": None, "flops_per_row": flops_assign, "hbm_frac": round(achieved / HBM_PEAK_GBS, 4),
                       "rows_per_launch": n_all, "launches_timed": kern_launches,
                       "note": "K = 400 nodes: 400 scores per row put the streamed filter on the matrix + VALU pipes, not on HBM"}
                      if mfma_bound else
-                     {"kernel": "bmu_filter_kernel", "bound": "hbm", "achieved": round(achieved, 1),
+                     {"kernel": "bmu_filter_kernel" if (not args.one_pass) else
+                      "bmu_filter_fast<ACC> (labels + per-cluster table in one pass; replaces the filter and the K8 kernel)",
+                      "bound": "hbm", "achieved": round(achieved, 1),
                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                       "traffic": None, "bytes_per_pixel": bytes_assign,
                       "pixels_per_launch": n_all, "launches_timed": kern_launches}),
@@ -308,7 +320,7 @@ def main():
     pmc = {}
     if world == 1 and not args.no_pmc:
         inner = ["--config", args.config, "--steps", "2", "--warmup", "1", "--batch-steps", str(args.batch_steps),
-                 "--no-cpu-baseline", "--no-online", "--no-pmc", "--pmc-inner"]
+                 "--no-cpu-baseline", "--no-online", "--no-pmc", "--pmc-inner"] + (["--one-pass"] if args.one_pass else [])
         if args.fovs_per_gpu:
             inner += ["--fovs-per-gpu", str(args.fovs_per_gpu)]
         pmc = pmc_passes(inner)

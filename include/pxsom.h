@@ -103,6 +103,17 @@ int pxsom_cluster_sums(const void *x_dev, int64_t n, int c, int64_t ldx, int dty
                        const int32_t *labels_dev, int k, double *sums_dev, int64_t *counts_dev,
                        void *stream);
 
+/* ---- labels and per-cluster sums / counts in one pass over x ------------------------------------------
+ * pxsom_assign followed by pxsom_cluster_sums, reading the pixel matrix ONCE: what cluster_pixels + generate_som_avg_files
+ * compute together when the labelled rows are still in HBM (reference: cluster_helpers.py:150-157 +
+ * pixel_cluster_utils.py:369-404).  labels_dev as pxsom_assign; sums_dev / counts_dev are ADDED into, as pxsom_cluster_sums.
+ * Register-resident shapes (K = 97..100, even c <= 32, pair-aligned rows) take the fused launch; other shapes run the two
+ * kernels one after the other.  Workspace: pxsom_assign_sums_workspace_bytes(n, c, k). */
+size_t pxsom_assign_sums_workspace_bytes(int64_t n, int c, int k);
+int pxsom_assign_sums(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev, int k,
+                      int32_t *labels_dev, double *sums_dev, int64_t *counts_dev, void *workspace_dev,
+                      size_t workspace_bytes, void *stream);
+
 /* ---- cell x pixel-cluster counts: the counting step of create_c2pc_data --------------------------
  * reference: cell_cluster_utils.py:128-141 (groupby(['label', pixel_cluster_col]).size() + pivot per
  * FOV).  hist[a_i * nb + b_i] += 1 for every i with 0 <= a_i < na and 0 <= b_i < nb (other pairs are

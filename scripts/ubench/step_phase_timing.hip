@@ -57,6 +57,8 @@ int main(int argc, char **argv)
                        "filter %.2f | exact(%lld) %.2f | flush-issue %.2f flush-done %.2f | total %.2f us\n",
                        g, thr, us(8, 9), us(9, 10), us(10, 11), us(11, 12), us(12, 13), us(13, 14), us(14, 15), us(15, 16), t[21],
                        us(16, 17), us(17, 18), us(18, 19), us(8, 19));
+                printf("         filter: barrier %.2f | convert %.2f | mfma + top-2 %.2f | merge + table %.2f\n", us(15, 22), us(22, 23),
+                       us(23, 24), us(24, 16));
                 {
                     long long bt[512];
                     hipMemcpyFromSymbol(bt, HIP_SYMBOL(g_block_ticks), sizeof(bt));

@@ -635,3 +635,26 @@ def test_relabel_matches_numpy(gpu):
             view = ld[1:]                                    # a misaligned view takes the scalar loop
             got2 = sd.relabel(view.contiguous(), torch.from_numpy(lut).to(gpu), fill=-7)
             np.testing.assert_array_equal(got2.cpu().numpy(), want[1:])
+
+
+@pytest.mark.parametrize("n,c,k,dtype", [(300_000, 22, 100, np.float32), (50_001, 8, 100, np.float32), (70_000, 16, 100, np.float16),
+                                         (20_000, 22, 100, np.float64), (30_000, 40, 400, np.float16), (9_000, 7, 30, np.float32)])
+def test_assign_sums_one_pass_equals_two_passes(gpu, oracle, n, c, k, dtype):
+    """pxsom_assign_sums (labels + per-cluster tables, one pass over x where the shape allows) == pxsom_assign followed
+    by pxsom_cluster_sums: labels and counts bit for bit, sums bit for bit where rows sum exactly in binary64; labels
+    against the oracle; tables are added into."""
+    x = synth.make_fov_numpy(n, c, seed=91, dtype=np.float32).astype(dtype)
+    x[500:520] = x[500]
+    w = _codebook(x.astype(np.float64), k, seed=4)
+    w[k - 1] = w[2]
+    xd, wd = torch.from_numpy(x).to(gpu), torch.from_numpy(w).to(gpu)
+    l2, _ = sd.assign(xd, wd)
+    s2, c2 = sd.cluster_sums(xd, l2, k)
+    pre_s = torch.full((k, c), 0.5, dtype=torch.float64, device=gpu)
+    pre_c = torch.full((k,), 3, dtype=torch.int64, device=gpu)
+    l1, s1, c1 = sd.assign_sums(xd, wd, sums=pre_s.clone(), counts=pre_c.clone())
+    assert torch.equal(l1, l2)
+    assert torch.equal(c1, c2 + 3)
+    np.testing.assert_allclose((s1 - 0.5).cpu().numpy(), s2.cpu().numpy(), rtol=1e-12, atol=1e-9)
+    want, _ = oracle.map_data_to_nodes(w, x.astype(np.float64))
+    np.testing.assert_array_equal(l1.cpu().numpy(), want)
