@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 SO_PATH = os.path.join(_PKG, "libpxsom.so")
 SOURCES = ["pxsom_api.hip", "pxsom_assign.hip", "pxsom_assign_filter.hip", "pxsom_assign_filter_acc.hip", "pxsom_batch_step.hip", "pxsom_train.hip",
-           "pxsom_pre.hip", "pxsom_sums.hip"]
+           "pxsom_pre.hip", "pxsom_sums.hip", "pxsom_comm.hip"]
 # per-file extra flags: the filter works on provably finite scores (see the file header)
 EXTRA_FLAGS = {"pxsom_assign_filter.hip": ["-ffinite-math-only"] + (
     ["-DSGB_VALU=" + os.environ["PXSOM_SGB_VALU"]] if "PXSOM_SGB_VALU" in os.environ else []) + (
@@ -90,7 +90,7 @@ def _build_locked(verbose: bool) -> str:
         if verbose and out:
             print(out.decode(errors="replace"))
     tmp = SO_PATH + ".tmp"
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[o for _, o, _ in jobs], "-o", tmp])
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[o for _, o, _ in jobs], "-ldl", "-o", tmp])
     os.replace(tmp, SO_PATH)
     with open(STAMP_PATH + ".tmp", "w") as f:
         f.write(_source_digest() + "\n")

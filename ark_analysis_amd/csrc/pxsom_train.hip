@@ -1381,11 +1381,16 @@ inline void batch_schedule(int g, int total, double a0, double a1, double r0, do
 }
 
 inline int64_t step_rows(int64_t n, int m, int t) { return n > t ? (n - t + m - 1) / m : 0; }
+}  // namespace
+namespace pxsom {
+int comm_allreduce_sum_f64(pxsom_comm *c, double *buf, size_t count, hipStream_t st);   // pxsom_comm.hip
+}
+namespace {
 
 template <typename T>
 int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, double *wbuf, double *ring, int xdim,
                       int ydim, int m, int g_begin, int g_end, int total, double a0, double a1, double r0, double r1,
-                      char *ws, size_t ws_bytes, int flags, hipStream_t st)
+                      char *ws, size_t ws_bytes, int flags, pxsom_comm *comm, hipStream_t st)
 {
     const int k = xdim * ydim;
     const size_t nstats = (size_t)k * (c + 1), nw = (size_t)k * c;
@@ -1426,6 +1431,7 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
             sa.tol_abs = (float)(2.5 * ldexp(1.0, -24) * sqrt((double)c));
             int rc = pxsom_bmu::launch_batch_step<T>(xv, rows, c, ldv, s_cur, sa, tpw, st);
             if (rc) return rc;
+            if (comm && (rc = pxsom::comm_allreduce_sum_f64(comm, s_cur, nstats, st))) return rc;
             continue;
         }
         // codebooks the all-in-one kernel cannot hold (K = 400, or C > 32): ONE launch applies the pending update and
@@ -1453,6 +1459,7 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
                     rc = cluster_sums_typed<T, true>(xv, rows, c, ldv, labels, k, s_cur, reinterpret_cast<int64_t *>(s_cur + nw), st);
                     if (rc) return rc;
                 }
+                if (comm && (rc = pxsom::comm_allreduce_sum_f64(comm, s_cur, nstats, st))) return rc;
                 continue;
             }
         }
@@ -1464,6 +1471,7 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
         PXSOM_HIP_TRY(hipMemsetAsync(s_next, 0, nstats * sizeof(double), st));
         int rc = pxsom_batch_accumulate(xv, rows, c, ldv, dtype, w_cur, k, labels, s_cur, ws, assign_ws, 0, st);
         if (rc) return rc;
+        if (comm && (rc = pxsom::comm_allreduce_sum_f64(comm, s_cur, nstats, st))) return rc;
     }
     return PXSOM_OK;
 }
@@ -1483,6 +1491,17 @@ PXSOM_EXPORT int pxsom_batch_train_steps(const void *x_dev, int64_t n, int c, in
                                          int g_end, int total_steps, double a0, double a1, double r0, double r1,
                                          void *workspace_dev, size_t workspace_bytes, int flags, void *stream)
 {
+    return pxsom_batch_train_steps_sharded(x_dev, n, c, ldx, dtype, wbuf_dev, stats_ring_dev, xdim, ydim, batch_steps,
+                                           g_begin, g_end, total_steps, a0, a1, r0, r1, workspace_dev, workspace_bytes,
+                                           flags, nullptr, stream);
+}
+
+PXSOM_EXPORT int pxsom_batch_train_steps_sharded(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype,
+                                                 double *wbuf_dev, double *stats_ring_dev, int xdim, int ydim,
+                                                 int batch_steps, int g_begin, int g_end, int total_steps, double a0,
+                                                 double a1, double r0, double r1, void *workspace_dev,
+                                                 size_t workspace_bytes, int flags, pxsom_comm *comm, void *stream)
+{
     int rc = check_matrix("pxsom_batch_train_steps", x_dev, n, c, ldx, dtype);
     if (rc) return rc;
     if (xdim < 1 || ydim < 1 || (int64_t)xdim * ydim > PXSOM_MAX_NODES)
@@ -1501,7 +1520,7 @@ PXSOM_EXPORT int pxsom_batch_train_steps(const void *x_dev, int64_t n, int c, in
     PXSOM_DISPATCH_DTYPE(dtype, x_dev, xp,
                          train_steps_typed<T>(xp, n, c, ldx, dtype, wbuf_dev, stats_ring_dev, xdim, ydim, batch_steps,
                                               g_begin, g_end, total_steps, a0, a1, r0, r1,
-                                              reinterpret_cast<char *>(workspace_dev), workspace_bytes, flags, st));
+                                              reinterpret_cast<char *>(workspace_dev), workspace_bytes, flags, comm, st));
 }
 
 PXSOM_EXPORT int pxsom_batch_train_finish(const double *wbuf_dev, const double *stats_ring_dev, int xdim, int ydim, int c,

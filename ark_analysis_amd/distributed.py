@@ -60,8 +60,15 @@ class HipKernels:
             self._rings = [st.ring[i] for i in range(3)]     # views made once: ring(g) sits in the per-step loop
         st.wbuf[0].copy_(w)
 
-    def steps(self, x, g0: int, g1: int, total: int, alpha_range, radius_range) -> None:
-        self._sd.batch_train_steps(x, self._state, g0, g1, total, alpha_range, radius_range, unfused=self.unfused)
+    def steps(self, x, g0: int, g1: int, total: int, alpha_range, radius_range, comm=None) -> None:
+        self._sd.batch_train_steps(x, self._state, g0, g1, total, alpha_range, radius_range, unfused=self.unfused,
+                                   comm=comm)
+
+    def exchange(self, group=None):
+        """The in-library exchange over ``group`` (an RCCL communicator owned by libpxsom, made once per process
+        group): with it ``steps(..., comm=...)`` all-reduces every step's statistics itself.  None when the
+        group is not RCCL-backed (gloo) or PXSOM_NATIVE_EXCHANGE=0: the trainer then all-reduces ``ring(g)``."""
+        return native_exchange(group)
 
     def ring(self, g: int) -> torch.Tensor:
         return self._rings[g % 3]
@@ -104,13 +111,63 @@ class BatchSOMTrainer:
         kern = self.kernels
         kern.begin(x_local, w, self.xdim, self.ydim, self.batch_steps)
         if _world(self.group) > 1:
-            for g in range(total):
-                kern.steps(x_local, g, g + 1, total, self.alpha_range, self.radius_range)
-                dist.all_reduce(kern.ring(g), op=dist.ReduceOp.SUM, group=self.group)
+            comm = kern.exchange(self.group) if hasattr(kern, "exchange") else None
+            if comm is not None:     # step launches and their all-reduces back to back on one stream, one call
+                kern.steps(x_local, 0, total, total, self.alpha_range, self.radius_range, comm=comm)
+            else:
+                for g in range(total):
+                    kern.steps(x_local, g, g + 1, total, self.alpha_range, self.radius_range)
+                    dist.all_reduce(kern.ring(g), op=dist.ReduceOp.SUM, group=self.group)
         else:
             kern.steps(x_local, 0, total, total, self.alpha_range, self.radius_range)
         kern.finish(total, total, self.alpha_range, self.radius_range, w)
         return w
+
+
+_native_comms = {}   # process group -> RankComm | None (decided once per group, the same way on every rank)
+
+
+def _all_ranks_ok(ok: bool, group) -> bool:
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=_collective_device())
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(flag.item())
+
+
+def native_exchange(group=None):
+    """libpxsom's own RCCL communicator over the ranks of ``group`` (see HipKernels.exchange).  Collective: every
+    rank of the group calls it at the same point.  Two agreed phases, so that a rank that cannot take part
+    (no RCCL to bind, id not drawn) never leaves the others waiting inside ncclCommInitRank."""
+    import os
+    import warnings
+    key = id(group) if group is not None else None
+    if key in _native_comms:
+        return _native_comms[key]
+    comm = None
+    if (dist.get_backend(group) == "nccl" and os.environ.get("PXSOM_NATIVE_EXCHANGE", "1") != "0"):
+        from . import som_device
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        uid, err = None, None
+        try:
+            som_device.RankComm.bind()
+            if rank == 0:
+                uid = som_device.RankComm.unique_id()
+        except Exception as e:          # agreed below: all ranks fall back together
+            err = e
+        if _all_ranks_ok(err is None, group):
+            box = [uid]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            try:
+                comm = som_device.RankComm(box[0], world, rank)
+            except Exception as e:
+                err = e
+            if not _all_ranks_ok(comm is not None, group):
+                if comm is not None:
+                    comm.close()
+                comm = None
+        if comm is None and rank == 0:
+            warnings.warn("in-library RCCL exchange unavailable (%s): all-reducing through torch.distributed" % err)
+    _native_comms[key] = comm
+    return comm
 
 
 # ---- rank context of the drop-in pipeline --------------------------------------------------------------------

@@ -115,18 +115,74 @@ class BatchTrainState:
 
 
 def batch_train_steps(x: torch.Tensor, state: BatchTrainState, g_begin: int, g_end: int, total_steps: int,
-                      alpha_range, radius_range, unfused: bool = False) -> None:
+                      alpha_range, radius_range, unfused: bool = False, comm: "RankComm" = None) -> None:
     """Mini-batch steps [g_begin, g_end) of a batch training run, launched back to back by the library
-    (``state.wbuf[0]`` holds W_0 before step 0; see include/pxsom.h)."""
+    (``state.wbuf[0]`` holds W_0 before step 0; see include/pxsom.h).  ``comm``: the statistics of every step are
+    sum-all-reduced over its ranks right behind the step's launch (every rank makes the same call)."""
     n, c, ldx, dt = _matrix_args(x)
     if not state.fits(n, c, state.xdim, state.ydim, state.batch_steps):
         raise ValueError("batch-training state does not fit this matrix")
-    rc = _capi.lib().pxsom_batch_train_steps(
+    rc = _capi.lib().pxsom_batch_train_steps_sharded(
         x.data_ptr(), n, c, ldx, dt, state.wbuf.data_ptr(), state.ring.data_ptr(), state.xdim, state.ydim,
         state.batch_steps, int(g_begin), int(g_end), int(total_steps), float(alpha_range[0]), float(alpha_range[1]),
         float(radius_range[0]), float(radius_range[1]), state.ws.data_ptr(), state.ws_bytes,
-        TRAIN_UNFUSED if unfused else 0, _capi.stream_ptr())
-    _capi.check(rc, "pxsom_batch_train_steps")
+        TRAIN_UNFUSED if unfused else 0, comm.handle if comm is not None else None, _capi.stream_ptr())
+    _capi.check(rc, "pxsom_batch_train_steps_sharded")
+
+
+COMM_ID_BYTES = 128  # include/pxsom.h PXSOM_COMM_ID_BYTES
+
+
+def _torch_rccl_path() -> str:
+    """The librccl.so this process already uses: PyTorch's own copy (binding a second RCCL next to it is
+    what pxsom_comm_bind exists to avoid); empty = let the library fall back to the system one."""
+    import os
+    path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return path if os.path.exists(path) else ""
+
+
+class RankComm:
+    """RCCL communicator owned by libpxsom (pxsom_comm_*): what the in-library exchange of a multi-rank batch
+    run reduces over.  ``RankComm.unique_id()`` on one rank, the 128 bytes handed to the others by the
+    launcher's channel, then ``RankComm(id, nranks, rank)`` on every rank (collective) with its device current."""
+
+    def __init__(self, uid: bytes, nranks: int, rank: int):
+        import ctypes
+        self.bind()
+        if len(uid) != COMM_ID_BYTES:
+            raise ValueError("communicator id must be %d bytes" % COMM_ID_BYTES)
+        box = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(bytes(uid), COMM_ID_BYTES)
+        rc = _capi.lib().pxsom_comm_create(ctypes.cast(buf, ctypes.c_void_p), COMM_ID_BYTES, int(nranks), int(rank),
+                                           ctypes.byref(box))
+        _capi.check(rc, "pxsom_comm_create")
+        self.handle = box
+        self.nranks, self.rank = int(nranks), int(rank)
+
+    @staticmethod
+    def bind() -> None:
+        rc = _capi.lib().pxsom_comm_bind(_torch_rccl_path().encode())
+        _capi.check(rc, "pxsom_comm_bind")
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes
+        RankComm.bind()
+        buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+        rc = _capi.lib().pxsom_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p), COMM_ID_BYTES)
+        _capi.check(rc, "pxsom_comm_unique_id")
+        return buf.raw
+
+    def allreduce_sum(self, t: torch.Tensor) -> None:
+        if t.dtype != torch.float64 or not t.is_contiguous():
+            raise ValueError("the exchange reduces contiguous float64 buffers")
+        rc = _capi.lib().pxsom_comm_allreduce_sum_f64(self.handle, t.data_ptr(), t.numel(), _capi.stream_ptr())
+        _capi.check(rc, "pxsom_comm_allreduce_sum_f64")
+
+    def close(self) -> None:
+        if self.handle is not None:
+            h, self.handle = self.handle, None
+            _capi.check(_capi.lib().pxsom_comm_destroy(h), "pxsom_comm_destroy")
 
 
 def batch_train_finish(state: BatchTrainState, steps_done: int, total_steps: int, alpha_range, radius_range,

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PXSOM_ABI_VERSION 4
+#define PXSOM_ABI_VERSION 5
 
 typedef enum pxsom_status {
     PXSOM_OK = 0,
@@ -184,6 +184,29 @@ int pxsom_batch_train_steps(const void *x_dev, int64_t n, int c, int64_t ldx, in
 int pxsom_batch_train_finish(const double *wbuf_dev, const double *stats_ring_dev, int xdim, int ydim, int c,
                              int steps_done, int total_steps, double a0, double a1, double r0, double r1,
                              double *w_out_dev, void *stream);
+
+/* ---- the exchange of a multi-rank batch run, inside the library ---------------------------------------
+ * One process per GPU, rows sharded by rank: the rule's only exchange is the sum of ring[g % 3] over the ranks
+ * after every step.  pxsom_batch_train_steps_sharded is pxsom_batch_train_steps with that all-reduce (RCCL,
+ * in place, binary64) enqueued on `stream` right behind each step's launch, so a whole run of steps is one call
+ * here as well -- no host work between a step and its exchange.  comm == NULL: no exchange (single rank).
+ * RCCL is bound at run time: pxsom_comm_bind(path of the librccl.so this process uses; NULL = "librccl.so.1")
+ * once per process; rank 0 draws the id with pxsom_comm_unique_id and hands it to the other ranks by whatever
+ * channel launched them (the Python host uses the torch.distributed store); every rank then calls
+ * pxsom_comm_create -- collective -- with its HIP device current.  Every rank must run the same steps.
+ * The reference has no analogue (single-core training, cluster_helpers.py:106-109). */
+#define PXSOM_COMM_ID_BYTES 128
+typedef struct pxsom_comm pxsom_comm;
+int pxsom_comm_bind(const char *librccl_path);
+int pxsom_comm_unique_id(void *id_out, size_t id_bytes);
+int pxsom_comm_create(const void *id, size_t id_bytes, int nranks, int rank, pxsom_comm **out);
+int pxsom_comm_destroy(pxsom_comm *comm);
+int pxsom_comm_allreduce_sum_f64(pxsom_comm *comm, double *buf_dev, size_t count, void *stream);
+int pxsom_batch_train_steps_sharded(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, double *wbuf_dev,
+                                    double *stats_ring_dev, int xdim, int ydim, int batch_steps, int g_begin,
+                                    int g_end, int total_steps, double a0, double a1, double r0, double r1,
+                                    void *workspace_dev, size_t workspace_bytes, int flags, pxsom_comm *comm,
+                                    void *stream);
 
 /* ---- pre-processing (create_fov_pixel_data and the 99.9 % values) -----------------------------
  * reference: pixie_preprocessing.py:47-49 -> scipy.ndimage.gaussian_filter(plane, sigma) per channel:
