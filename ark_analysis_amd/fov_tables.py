@@ -16,10 +16,14 @@ stage is I/O bound, so
 * "which FOVs still lack column X" looks at the Arrow schema in the file footer instead of loading a
   whole table (:meth:`FovTableDir.column_names`).
 """
+import collections
 import os
 import queue
 import shutil
+import tempfile
 import threading
+import warnings
+from concurrent.futures import ThreadPoolExecutor
 from typing import Iterable, Iterator, List, Optional, Sequence, Tuple
 
 import pandas as pd
@@ -137,72 +141,79 @@ class FovTableDir:
         os.mkdir(self.staging)
 
     def commit(self, on_rm_error=None) -> None:
-        """Replace the directory by its staging twin."""
-        shutil.rmtree(self.root, onerror=on_rm_error)
+        """Replace the directory by its staging twin.  The old tables are moved aside (a hidden, uniquely named
+        directory next to ``root``) and unlinked on a background thread the interpreter waits for at exit:
+        deleting a page-cache-resident 218 MB table takes ~16 ms, a third of what labelling it costs, and nothing
+        downstream depends on it -- ``root`` holds the new tables when this returns."""
+        parent, name = os.path.split(os.path.abspath(self.root))
+        trash = tempfile.mkdtemp(prefix=".%s.old-" % name, dir=parent)
+        os.rename(self.root, os.path.join(trash, name))
         shutil.move(self.staging, self.root)
+        cleaner = threading.Thread(target=_remove_tree, args=(trash, on_rm_error), name="fov-cleanup", daemon=False)
+        cleaner.start()
+        _CLEANERS.append(cleaner)
+
+
+_CLEANERS: List[threading.Thread] = []
+
+
+def _remove_tree(path: str, on_rm_error) -> None:
+    try:
+        shutil.rmtree(path, onerror=on_rm_error)
+    except BaseException as err:      # nobody to raise to on this thread
+        warnings.warn("could not remove the replaced tables in %s: %r" % (path, err))
+
+
+def wait_for_cleanup() -> None:
+    """Blocks until every directory replaced by :meth:`FovTableDir.commit` so far has been deleted."""
+    while _CLEANERS:
+        _CLEANERS.pop().join()
 
 
 class TablePrefetcher:
-    """Iterates ``(fov, table-or-None)`` over ``fovs``, reading up to ``depth`` tables ahead on a
-    background thread (as DataFrames, or as Arrow tables with ``as_arrow``).  ``None`` stands for a table
-    that could not be opened."""
+    """Iterates ``(fov, table-or-None)`` over ``fovs`` in order, with up to ``depth`` tables being read ahead on
+    ``workers`` background threads (as DataFrames, or as Arrow tables with ``as_arrow``).  ``None`` stands for
+    a table that could not be opened."""
 
-    _END = object()
-
-    def __init__(self, tables: FovTableDir, fovs: Sequence[str], depth: int = 2, as_arrow: bool = False):
-        self._tables = tables
+    def __init__(self, tables: FovTableDir, fovs: Sequence[str], depth: int = 2, as_arrow: bool = False,
+                 workers: int = 1):
         self._fovs = list(fovs)
         self._read = tables.load_arrow if as_arrow else tables.load
-        self._slots: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
+        self._depth = max(1, depth)
         self._stop = threading.Event()
-        self._worker = threading.Thread(target=self._fill, name="fov-prefetch", daemon=True)
-        self._worker.start()
+        self._pool = ThreadPoolExecutor(max_workers=max(1, workers), thread_name_prefix="fov-prefetch")
+        self._ahead: "collections.deque" = collections.deque()    # (fov, future), in FOV order
+        self._next = 0
+        self._top_up()
 
-    def _put(self, item) -> bool:
-        """Queue ``item`` unless the consumer has gone away (``close``): the reader then stops instead of
-        sitting in ``put`` for ever with the tables it has read."""
-        while not self._stop.is_set():
-            try:
-                self._slots.put(item, timeout=0.1)
-                return True
-            except queue.Full:
-                continue
-        return False
+    def _load(self, fov):
+        if self._stop.is_set():
+            return None
+        try:
+            return self._read(fov)
+        except UNREADABLE:
+            return None
 
-    def _fill(self) -> None:
-        for fov in self._fovs:
-            if self._stop.is_set():
-                return
-            try:
-                item = (fov, self._read(fov))
-            except UNREADABLE:
-                item = (fov, None)
-            except BaseException as err:  # surfaced in the consumer thread
-                self._put((fov, err))
-                break
-            if not self._put(item):
-                return
-        self._put(self._END)
+    def _top_up(self) -> None:
+        while len(self._ahead) < self._depth and self._next < len(self._fovs) and not self._stop.is_set():
+            fov = self._fovs[self._next]
+            self._next += 1
+            self._ahead.append((fov, self._pool.submit(self._load, fov)))
 
     def __iter__(self) -> Iterator[Tuple[str, Optional[pd.DataFrame]]]:
-        while True:
-            item = self._slots.get()
-            if item is self._END:
-                return
-            if isinstance(item[1], BaseException):
-                raise item[1]
-            yield item
+        while self._ahead:
+            fov, pending = self._ahead.popleft()
+            self._top_up()
+            yield fov, pending.result()       # a reader's exception (other than "unreadable") surfaces here
 
     def close(self) -> None:
         """Stop reading ahead and drop what is queued (call from a ``finally``: a consumer that leaves early --
-        a GPU error, an exception in the caller -- must not leave the reader blocked holding tables)."""
+        a GPU error, an exception in the caller -- must not leave readers holding tables)."""
         self._stop.set()
-        try:
-            while True:
-                self._slots.get_nowait()
-        except queue.Empty:
-            pass
-        self._worker.join(timeout=5.0)
+        for _, pending in self._ahead:
+            pending.cancel()
+        self._ahead.clear()
+        self._pool.shutdown(wait=True)
 
 
 class TableWriter:
@@ -233,14 +244,17 @@ class TableWriter:
                         write_dataframe(job[0], job[1], compression="uncompressed")
                 except BaseException as err:
                     self._error = err
+            if not callable(job) and job[2] is not None:
+                job[2]()     # the table's buffers may be reused from here on (written, or abandoned after a failure)
 
     def _raise_if_failed(self) -> None:
         if self._error is not None:   # stop the stage at the first failed write, not at close()
             raise self._error
 
-    def submit(self, table, path: str) -> None:
+    def submit(self, table, path: str, done=None) -> None:
+        """``done()`` is called on the writer thread once the table is no longer needed."""
         self._raise_if_failed()
-        self._jobs.put((table, path))
+        self._jobs.put((table, path, done))
 
     def submit_call(self, fn) -> None:
         """Run ``fn()`` on the writer thread after everything submitted before it (e.g. a progress record

@@ -188,7 +188,7 @@ def compute_pixel_cluster_channel_avg(fovs, channels, base_dir, pixel_cluster_co
     # of the chosen files (the same list everywhere: it comes from the seeded draw above).
     from .. import distributed
     on_device = flowsom.cluster_sums is _DEVICE_SUMS
-    feed = TablePrefetcher(tables, distributed.shard(chosen), as_arrow=on_device)
+    feed = TablePrefetcher(tables, distributed.shard(chosen), depth=4, as_arrow=on_device, workers=3)
     try:
         for fov, table in feed:
             if table is None:

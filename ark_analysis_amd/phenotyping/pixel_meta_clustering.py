@@ -107,8 +107,8 @@ def _rewrite_tables(tables: FovTableDir, todo: Sequence[str], relabel, multiproc
     mine = distributed.shard(todo, rank, world)
     group = batch_size if multiprocess else 1
     done = 0
-    writer = TableWriter(depth=4, workers=3)
-    feed = TablePrefetcher(tables, mine, as_arrow=True)
+    writer = TableWriter(depth=8, workers=6)
+    feed = TablePrefetcher(tables, mine, depth=4, as_arrow=True, workers=3)
     try:
         rows = iter(feed)
         for names in fov_tables.batches(mine, group):

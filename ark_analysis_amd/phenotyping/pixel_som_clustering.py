@@ -64,11 +64,17 @@ def _say(*args) -> None:
 _DEVICE_BMU = flowsom.map_data_to_nodes   # the real device entry point (tests may swap the attribute)
 
 
-def _label_table(som, table, relabel: bool, block: int):
+def _label_table(som, table, relabel: bool, block: int, host_blocks=None):
     """One FOV table -> the same table with normalised channels and ``pixel_som_cluster``.
     ``relabel``: the table was produced by an earlier run (already normalised, old labels present).
     Arrow tables take the pandas-free device path when it covers them (and the device entry point has
-    not been replaced); everything else goes through ``PixelSOMCluster.assign_som_clusters``."""
+    not been replaced); everything else goes through ``PixelSOMCluster.assign_som_clusters``.
+    ``host_blocks`` (an ``arrow_assign.HostBlocks``): the result is ``(table, release-or-None)``."""
+    if host_blocks is not None:
+        if (not hasattr(table, "iloc") and flowsom.map_data_to_nodes is _DEVICE_BMU
+                and arrow_assign.applicable(som, table, not relabel)):
+            return arrow_assign.label_table(som, table, normalize=not relabel, blocks=host_blocks)
+        return _label_table(som, table, relabel, block), None
     if not hasattr(table, "iloc"):   # an Arrow table
         if flowsom.map_data_to_nodes is _DEVICE_BMU and arrow_assign.applicable(som, table, not relabel):
             return arrow_assign.label_table(som, table, normalize=not relabel)
@@ -146,8 +152,13 @@ def cluster_pixels(fovs, base_dir, pixel_pysom, data_dir='pixel_mat_data',
     mine = distributed.shard(todo, rank, world)
     group = batch_size if multiprocess else 1
     done = 0
-    writer = TableWriter(depth=4, workers=3)      # FOV tables are independent: written side by side
-    feed = TablePrefetcher(tables, mine, as_arrow=True)
+    # FOV tables are independent: read and written side by side.  Per 218 MB table: ~20 ms to read on a reader
+    # thread, ~8-14 ms on this thread (copies both ways + the kernels), ~30 ms to serialise on a writer thread.
+    # (Two labelling threads with a HIP stream each -- one table's download under the next one's upload -- were
+    # measured too: 17.9 instead of 20.0 ms per table on 40 tables, slower on 6; not kept.)
+    writer = TableWriter(depth=8, workers=6)
+    feed = TablePrefetcher(tables, mine, depth=4, as_arrow=True, workers=3)
+    host_blocks = arrow_assign.HostBlocks()
     try:
         rows = iter(feed)
         for names in fov_tables.batches(mine, group):
@@ -157,8 +168,8 @@ def cluster_pixels(fovs, base_dir, pixel_pysom, data_dir='pixel_mat_data',
                 if table is None:
                     spoiled.append(fov)
                     continue
-                writer.submit(_label_table(pixel_pysom, table, overwrite, num_parallel_pixels),
-                              tables.path(fov, staged=True))
+                labelled, release = _label_table(pixel_pysom, table, overwrite, num_parallel_pixels, host_blocks)
+                writer.submit(labelled, tables.path(fov, staged=True), done=release)
             for fov in spoiled:
                 print(_CORRUPT % fov)
             done += len(names) - len(spoiled)
@@ -167,6 +178,7 @@ def cluster_pixels(fovs, base_dir, pixel_pysom, data_dir='pixel_mat_data',
     finally:
         feed.close()
         writer.close()
+        host_blocks.close()
 
     if world > 1:
         # FOV files were dealt round robin: what the ranks saw is united, then one rank swaps the directories

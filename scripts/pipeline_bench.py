@@ -99,4 +99,5 @@ print(json.dumps({
     "cluster_pixels_Mpx_per_s": round(px / t_pipe / 1e6, 2),
     "cluster_channel_avg_s": round(t_avg, 3), "cluster_channel_avg_dataframe_route_s": round(t_avg_df, 3),
     "generated_in_s": round(t_gen, 1)}))
+fov_tables.wait_for_cleanup()
 shutil.rmtree(root)
