@@ -638,6 +638,38 @@ def test_fov_table_helpers(tmp_path):
         bad = TableWriter()
         bad.submit(frames["fov1"], str(tmp_path / "no_such_dir" / "x.feather"))
         bad.close()
+    # several readers still deliver in FOV order; several writers report every table as finished (written or not)
+    got = list(TablePrefetcher(tabs, tabs.fovs(), depth=3, workers=3))
+    assert [f for f, _ in got] == tabs.fovs() and got[2][1] is None
+    finished = []
+    w = TableWriter(depth=4, workers=3)
+    for n, df in frames.items():
+        w.submit(df, str(root / (n + "_copy.feather")), done=lambda n=n: finished.append(n))
+    w.close()
+    assert sorted(finished) == sorted(frames)
+    # commit: the staging twin replaces the directory at once, the old tables disappear in the background
+    from ark_analysis_amd import fov_tables
+    tabs.open_staging()
+    TableWriter().close()
+    fov_tables.write_dataframe(frames["fov1"], tabs.path("only", staged=True))
+    tabs.commit()
+    assert tabs.fovs() == ["only"] and not os.path.exists(tabs.staging)
+    fov_tables.wait_for_cleanup()
+    assert sorted(os.listdir(tmp_path)) == ["tabs"]
+
+
+def test_host_blocks_are_recycled():
+    from ark_analysis_amd.arrow_assign import HostBlocks
+    pool = HostBlocks()
+    a = pool.take(1000)
+    b = pool.take(500)
+    assert a.numel() >= 1000 and b.numel() >= 500 and a.data_ptr() != b.data_ptr()
+    pool.give(a)
+    pool.give(b)
+    assert pool.take(400).data_ptr() == b.data_ptr()      # the smallest block that fits
+    assert pool.take(400).data_ptr() == a.data_ptr()
+    assert pool.take(2000).numel() >= 2000                # nothing fits: a new block
+    pool.close()
 
 
 def test_reference_generate_som_avg_files(som_backend, tmp_path, capsys):
