@@ -18,6 +18,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "pxsom_assign.h"
 #include "pxsom_assign_filter_fast.h"
@@ -132,7 +133,8 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_kernel(
     };
 
     // fp32 row slice -> fp16 hi / lo B-fragments + partial squared norm
-    auto convert = [&](const T(&src)[NCH][CPLMAX], half8(&bh)[NCH], half8(&bl)[NCH], float &ss) {
+    auto convert = [&](const T(&src)[NCH][CPLMAX], half8(&bh)[NCH], half8(&bl)[NCH], float &ss, auto xlo_tag) {
+        constexpr bool XLO = decltype(xlo_tag)::value;
         float acc2 = 0.f;
 #pragma unroll
         for (int h = 0; h < NCH; h++) {
@@ -143,7 +145,8 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_kernel(
                 acc2 = fmaf(xf, xf, acc2);
                 const _Float16 hi = (_Float16)xf;
                 bh[h][i] = hi;
-                bl[h][i] = (_Float16)(xf - (float)hi);
+                if constexpr (XLO) bl[h][i] = (_Float16)(xf - (float)hi);
+                else bl[h][i] = (_Float16)0;
             }
         }
         ss = acc2;
@@ -196,13 +199,18 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_kernel(
             for (int t = 0; t < kTilesPerIter; t++) load_tile(g, t, raw[t]);
         }
     }
-    for (; g < ngroups; g += nwaves) {
+    // binary16 rows: x * scale (a power of two >= 1) IS a binary16 number, so the low part of the split is exactly
+    // zero: the Wh*Xl MFMA of every chunk and the conversions that feed it are dropped (XLO = false).  Only a
+    // codebook whose largest entry exceeds 128 makes scale < 1, where tiny x could lose bits: then the full split runs.
+    const bool lo_needed = sizeof(T) != 2 || scale < 1.f;
+    auto group = [&](auto xlo_tag) {
+        constexpr bool XLO = decltype(xlo_tag)::value;
         half8 bh[PREFETCH ? kTilesPerIter : TP][NCH], bl[PREFETCH ? kTilesPerIter : TP][NCH];
         float ss[PREFETCH ? kTilesPerIter : TP];
         if constexpr (PREFETCH) {
             // convert the current group's rows, then issue the next group's loads
 #pragma unroll
-            for (int t = 0; t < kTilesPerIter; t++) convert(raw[t], bh[t], bl[t], ss[t]);
+            for (int t = 0; t < kTilesPerIter; t++) convert(raw[t], bh[t], bl[t], ss[t], xlo_tag);
             int64_t gnext = g + nwaves;
             if (gnext > ngroups - 1) gnext = ngroups - 1;  // harmless re-read on the last trip
 #pragma unroll
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_kernel(
 #pragma unroll
                 for (int u = 0; u < TP; u++) {
                     load_tile(g, t0 + u, raw[u]);
-                    convert(raw[u], bh[u], bl[u], ss[u]);
+                    convert(raw[u], bh[u], bl[u], ss[u], xlo_tag);
                 }
             }
             float m1[TP], m2[TP];
@@ -252,7 +260,8 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_kernel(
 #pragma unroll
                         for (int u = 0; u < TP; u++) {
                             const int sl = PREFETCH ? t0 + u : u;
-                            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b][2 * h], bl[sl][h], acc[u], 0, 0, 0);
+                            if constexpr (XLO)
+                                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b][2 * h], bl[sl][h], acc[u], 0, 0, 0);
                         }
 #pragma unroll
                         for (int u = 0; u < TP; u++) {
@@ -285,7 +294,8 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_kernel(
                         for (int u = 0; u < TP; u++) {
                             const int sl = PREFETCH ? t0 + u : u;
                             acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh[sl][h], acc[u], 0, 0, 0);
-                            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl[sl][h], acc[u], 0, 0, 0);
+                            if constexpr (XLO)
+                                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl[sl][h], acc[u], 0, 0, 0);
                             acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh[sl][h], acc[u], 0, 0, 0);
                         }
                     }
@@ -308,6 +318,14 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_kernel(
             if (lane == 0) base = atomicAdd(&hdr->amb_count, (unsigned)__popcll(mask));
             base = __shfl(base, 0);
             if (push) amb_list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned)row;
+        }
+    };
+    for (; g < ngroups; g += nwaves) {
+        if constexpr (sizeof(T) == 2) {
+            if (lo_needed) group(std::true_type{});
+            else group(std::false_type{});
+        } else {
+            group(std::true_type{});
         }
     }
 }
