@@ -32,25 +32,83 @@ def _channel_file(folder: str, channel: str) -> str:
     raise FileNotFoundError("The file/path, %s.tiff, could not be found in %s" % (channel, folder))
 
 
-def read_image(path) -> np.ndarray:
-    """Any single image file as an array in its own dtype."""
+# Uncompressed TIFF strips are read straight from the file into the destination array (``readinto``: one copy, no
+# GIL while the kernel copies), not through Pillow's decoder: ``np.array(im)`` runs Pillow's raw codec chunk by
+# chunk from Python, ~1.2 GB/s per image and mostly under the GIL -- 16 decoder threads then starve the thread
+# that drives the GPU (measured: the per-FOV percentile call, 4 ms alone, took 150 ms beside them).
+# rawmode -> (dtype in the file, dtype Pillow's array would have)
+_RAW_MODES = {"F;32F": ("<f4", np.float32), "F;32BF": (">f4", np.float32), "I;32S": ("<i4", np.int32),
+              "I;32BS": (">i4", np.int32), "I;16": ("<u2", np.uint16), "I;16B": (">u2", np.uint16),
+              "I;16S": ("<i2", np.int32), "I;16BS": (">i2", np.int32), "L": ("u1", np.uint8)}
+
+
+def _raw_layout(im):
+    """``(file dtype, array dtype, [(row0, row1, file offset), ...])`` when the opened image is a single page of
+    uncompressed full-width strips in a sample format listed above; None otherwise (Pillow then decodes it)."""
+    tiles = getattr(im, "tile", None)
+    if not tiles or getattr(im, "n_frames", 1) != 1:
+        return None
+    width = im.size[0]
+    mode, strips = None, []
+    for tile in tiles:
+        codec, extents, offset, args = tile[0], tile[1], tile[2], tile[3]
+        if codec != "raw" or not isinstance(args, tuple) or len(args) < 3 or args[1] != 0 or args[2] != 1:
+            return None
+        if args[0] not in _RAW_MODES or (mode is not None and args[0] != mode):
+            return None
+        if extents[0] != 0 or extents[2] != width:
+            return None
+        mode = args[0]
+        strips.append((extents[1], extents[3], offset))
+    file_dtype, array_dtype = _RAW_MODES[mode]
+    return np.dtype(file_dtype), np.dtype(array_dtype), strips
+
+
+def _read_strips(path, shape, layout, out):
+    """Fills ``out`` ([H, W], C-contiguous, dtype = layout's array dtype) from the file; False if the file is
+    shorter than its directory says (the caller falls back to Pillow, which raises the proper error)."""
+    file_dtype, array_dtype, strips = layout
+    direct = file_dtype == array_dtype and file_dtype.isnative
+    with open(path, "rb", buffering=0) as f:
+        for row0, row1, offset in strips:
+            rows = out[row0:row1]
+            f.seek(offset)
+            if direct:
+                if f.readinto(memoryview(rows).cast("B")) != rows.nbytes:
+                    return False
+            else:
+                block = np.fromfile(f, dtype=file_dtype, count=rows.size)
+                if block.size != rows.size:
+                    return False
+                rows[...] = block.reshape(rows.shape)
+    return True
+
+
+def read_image(path, out=None) -> np.ndarray:
+    """Any single image file as an array in its own dtype (what ``np.array(PIL.Image.open(path))`` returns).
+    ``out``: a C-contiguous ``[H, W]`` array to fill when shape and dtype agree (else a new array is returned)."""
     from PIL import Image
     with Image.open(path) as im:
+        layout = _raw_layout(im)
+        if layout is not None:
+            shape = (im.size[1], im.size[0])
+            dest = out if (out is not None and out.shape == shape and out.dtype == layout[1]
+                           and out.flags.c_contiguous) else np.empty(shape, dtype=layout[1])
+            if _read_strips(path, shape, layout, dest):
+                return dest
         return np.array(im)
 
 
-def read_channel(tiff_dir, fov: str, channel: str, img_sub_folder: Optional[str] = None) -> np.ndarray:
+def read_channel(tiff_dir, fov: str, channel: str, img_sub_folder: Optional[str] = None, out=None) -> np.ndarray:
     """One channel image ``[H, W]`` in the file's dtype."""
-    from PIL import Image
-    with Image.open(_channel_file(_fov_folder(tiff_dir, fov, img_sub_folder), channel)) as im:
-        return np.array(im)
+    return read_image(_channel_file(_fov_folder(tiff_dir, fov, img_sub_folder), channel), out=out)
 
 
 _DECODERS = None
 
 
 def _decoder_pool():
-    """Shared thread pool for TIFF decoding (Pillow releases the GIL while it reads and decodes)."""
+    """Shared thread pool for reading / decoding the channel files of a FOV side by side."""
     global _DECODERS
     if _DECODERS is None:
         from concurrent.futures import ThreadPoolExecutor
@@ -70,7 +128,9 @@ def read_channels(tiff_dir, fov: str, channels: Sequence[str], img_sub_folder: O
     planar[0] = first
 
     def fill(j):
-        planar[j] = read_channel(tiff_dir, fov, channels[j], img_sub_folder)
+        got = read_channel(tiff_dir, fov, channels[j], img_sub_folder, out=planar[j])
+        if got is not planar[j]:       # another dtype / shape, or a compressed file: converted as numpy assigns
+            planar[j] = got
 
     list(_decoder_pool().map(fill, range(1, len(channels))))
     return planar.transpose(1, 2, 0)

@@ -55,9 +55,7 @@ _PER_FOV_QUANTILES = "channel_norm_post_rownorm_perfov.csv"
 
 
 def _read_segmentation(seg_dir, fov, seg_suffix):
-    from PIL import Image
-    with Image.open(os.path.join(seg_dir, fov + seg_suffix)) as im:
-        return np.array(im)
+    return image_io.read_image(os.path.join(seg_dir, fov + seg_suffix))
 
 
 def preprocess_fov(base_dir, tiff_dir, data_dir, subset_dir, seg_dir, seg_suffix,

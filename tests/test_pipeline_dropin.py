@@ -658,6 +658,42 @@ def test_fov_table_helpers(tmp_path):
     assert sorted(os.listdir(tmp_path)) == ["tabs"]
 
 
+def test_raw_tiff_reader_equals_pillow(tmp_path):
+    """image_io.read_image: uncompressed strips read straight from the file == np.array(PIL.Image.open(path)) for
+    every sample format the pixel path meets; compressed files and short files take Pillow's route."""
+    from PIL import Image
+    from ark_analysis_amd import image_io
+    rs = np.random.RandomState(3)
+    for dt in (np.float32, np.int32, np.uint16, np.uint8, np.int16, np.float64):
+        img = (rs.rand(37, 53) * 1000).astype(dt)
+        path = str(tmp_path / "img.tiff")
+        Image.fromarray(img).save(path, format="TIFF")
+        with Image.open(path) as im:
+            want = np.array(im)
+            assert image_io._raw_layout(im) is not None
+        got = image_io.read_image(path)
+        assert got.dtype == want.dtype
+        np.testing.assert_array_equal(got, want)
+        out = np.empty(want.shape, dtype=want.dtype)
+        assert image_io.read_image(path, out=out) is out
+        np.testing.assert_array_equal(out, want)
+        wrong = np.empty(want.shape, dtype=np.complex64)          # unusable destination: a new array comes back
+        np.testing.assert_array_equal(image_io.read_image(path, out=wrong), want)
+    img = rs.rand(64, 64).astype(np.float32)
+    packed = str(tmp_path / "deflate.tiff")
+    Image.fromarray(img).save(packed, format="TIFF", compression="tiff_deflate")
+    with Image.open(packed) as im:
+        assert image_io._raw_layout(im) is None
+    np.testing.assert_array_equal(image_io.read_image(packed), img)
+    whole = str(tmp_path / "whole.tiff")
+    Image.fromarray(img).save(whole, format="TIFF")
+    data = open(whole, "rb").read()
+    with open(whole, "wb") as f:
+        f.write(data[:len(data) // 2])
+    with pytest.raises(OSError):
+        image_io.read_image(whole)
+
+
 def test_host_blocks_are_recycled():
     from ark_analysis_amd.arrow_assign import HostBlocks
     pool = HostBlocks()
