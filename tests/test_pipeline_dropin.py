@@ -669,8 +669,8 @@ def test_raw_tiff_reader_equals_pillow(tmp_path):
         path = str(tmp_path / "img.tiff")
         Image.fromarray(img).save(path, format="TIFF")
         with Image.open(path) as im:
+            assert image_io._raw_layout(im) is not None       # (before the pixels are loaded: Pillow drops the tiles)
             want = np.array(im)
-            assert image_io._raw_layout(im) is not None
         got = image_io.read_image(path)
         assert got.dtype == want.dtype
         np.testing.assert_array_equal(got, want)
