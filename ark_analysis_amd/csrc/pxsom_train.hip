@@ -1363,12 +1363,13 @@ PXSOM_EXPORT int pxsom_batch_update_prepare(double *w_dev, int xdim, int ydim, i
 
 // ------------------------------------------------------------------------------------------------
 // Batch training pass driven from ONE call (pxsom_batch_train_steps): the host loop over the mini-batch steps
-// lives here, not in Python.  Register-resident shapes on a 10 x 10 grid take one launch per step (the fused
-// step kernel, pxsom_assign_filter_fast.h ACC == 2: pending update + prep + filter + table + flush); other
-// shapes run update / prep / filter / exact / cluster sums per step as before.  Both keep the same state:
+// lives here, not in Python.  Register-resident shapes on a 10 x 10 grid take one launch per step (batch_step_kernel,
+// pxsom_batch_step.hip: pending update + prep + filter + table + flush); other shapes run update-and-prepare /
+// filter / exact / cluster sums per step.  Both keep the same state:
 //   wbuf[g % 2]        W_g, the codebook step g searches with          (two buffers alternate)
 //   ring[g % 3]        statistics of step g; ring[(g+1) % 3] is cleared by step g
-// so a multi-rank caller runs one step per call and all-reduces ring[g % 3] in between.
+// so a multi-rank run all-reduces ring[g % 3] right behind step g (comm != NULL: enqueued here, pxsom_comm.hip; or the
+// caller runs one step per call and all-reduces in between).
 // ------------------------------------------------------------------------------------------------
 namespace {
 
