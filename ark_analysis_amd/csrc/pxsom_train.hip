@@ -31,9 +31,11 @@ using pxsom::wave_min_u32;
 // ------------------------------------------------------------------------------------------------
 // exact online SOM.  CMAX > 0: this thread's node (CMAX doubles) and the presented row live in
 // registers -- per step one burst of LDS reads for the row, then pure register arithmetic in the
-// oracle's order.  CMAX == 0: any channel count, codebook in LDS ([channel][node]).
+// oracle's order.  CMAX == 0: any channel count, codebook in LDS ([channel][node]) -- or, GLB, where it is:
+// codebooks past the LDS (K * C * 8 > ~150 KB, e.g. 264 nodes x 128 channels) are trained in place in w
+// (every thread touches only its own node's row; L2-resident, a few microseconds per step).
 // ------------------------------------------------------------------------------------------------
-template <typename T, int CMAX, int MAXT>
+template <typename T, int CMAX, int MAXT, bool GLB = false>
 __global__ __launch_bounds__(MAXT) void som_online_kernel(const T *__restrict__ x, int64_t n, int c,
                                                           int64_t ldx, double *w, int xdim, int ydim,
                                                           int rlen, double a0, double a1, double r0,
@@ -45,9 +47,10 @@ __global__ __launch_bounds__(MAXT) void som_online_kernel(const T *__restrict__ 
     const int tid = threadIdx.x, bd = blockDim.x;
     const int lane = tid & 63, wv = tid >> 6, nwv = bd >> 6;
     constexpr bool REG = CMAX > 0;
-    double *wt = reinterpret_cast<double *>(smem_raw);            // [c][K] (LDS codebook; unused if REG)
+    static_assert(!(REG && GLB), "register-resident nodes need no codebook storage");
+    double *wt = reinterpret_cast<double *>(smem_raw);            // [c][K] (LDS codebook; unused if REG / GLB)
     const int cs = REG ? CMAX : c;                                // row stride of the LDS ring
-    double *xs = wt + (REG ? 0 : (size_t)c * K);                  // [2][chunk][cs] (pad slots stay 0)
+    double *xs = wt + ((REG || GLB) ? 0 : (size_t)c * K);         // [2][chunk][cs] (pad slots stay 0)
     double *exd = xs + (size_t)2 * chunk * cs;                    // [2][nwv] best distance per wave
     int *exk = reinterpret_cast<int *>(exd + 2 * nwv);            // [2][nwv] best node per wave
     double *red = reinterpret_cast<double *>(exk + 2 * nwv);      // [nwv] change partials
@@ -56,11 +59,13 @@ __global__ __launch_bounds__(MAXT) void som_online_kernel(const T *__restrict__ 
     const bool has_node = tid < K;
     const int node = tid;
     const int nx = node / ydim, ny = node % ydim;
+    // channel j of this thread's node, wherever the codebook lives
+    auto wref = [&](int j) -> double & { return GLB ? w[(size_t)node * c + j] : wt[(size_t)j * K + node]; };
     double wr[REG ? CMAX : 1];
     if constexpr (REG) {
 #pragma unroll
         for (int j = 0; j < CMAX; j++) wr[j] = (has_node && j < c) ? w[(size_t)node * c + j] : 0.0;
-    } else {
+    } else if constexpr (!GLB) {
         if (has_node)
             for (int j = 0; j < c; j++) wt[(size_t)j * K + node] = w[(size_t)node * c + j];
     }
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(MAXT) void som_online_kernel(const T *__restrict__ 
             } else if (has_node) {
                 double xdist = 0.0;
                 for (int j = 0; j < c; j++) {
-                    const double tmp = xr[j] - wt[(size_t)j * K + node];
+                    const double tmp = xr[j] - wref(j);
                     xdist += tmp * tmp;
                 }
                 if (xdist == xdist) d2 = xdist;
@@ -241,10 +246,10 @@ __global__ __launch_bounds__(MAXT) void som_online_kernel(const T *__restrict__ 
                         }
                     } else {
                         for (int j = 0; j < c; j++) {
-                            const double wv_ = wt[(size_t)j * K + node];
+                            const double wv_ = wref(j);
                             const double tmp = xr[j] - wv_;
                             mychange += fabs(tmp);
-                            wt[(size_t)j * K + node] = wv_ + tmp * alpha;
+                            wref(j) = wv_ + tmp * alpha;
                         }
                     }
                 }
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(MAXT) void som_online_kernel(const T *__restrict__ 
 #pragma unroll
             for (int j = 0; j < CMAX; j++)
                 if (j < c) w[(size_t)node * c + j] = wr[j];
-        } else {
+        } else if constexpr (!GLB) {
             for (int j = 0; j < c; j++) w[(size_t)node * c + j] = wt[(size_t)j * K + node];
         }
     }
@@ -791,22 +796,40 @@ int launch_online(const T *x, int64_t n, int c, int64_t ldx, double *w, int xdim
     const int K = xdim * ydim;
     const int bd = ((K + 63) / 64) * 64;
     const int nwv = bd / 64;
-    const size_t fixed = (CMAX > 0 ? 0 : (size_t)c * K * 8) + (size_t)2 * nwv * 8 + (size_t)2 * nwv * 4 +
-                         (size_t)nwv * 8 + 2 * 64 * 8 + 64;
-    int chunk = 64;
     const int cs = CMAX > 0 ? CMAX : c;
-    while (chunk > 8 && fixed + (size_t)2 * chunk * cs * 8 > 150 * 1024) chunk >>= 1;
-    while ((chunk * c + bd - 1) / bd > 16) chunk >>= 1;  // gather registers per thread
-    const size_t lds = fixed + (size_t)2 * chunk * cs * 8;
+    // LDS besides the row ring: the codebook (CMAX == 0, when it fits) + per-wave exchange + learning rates
+    auto plan = [&](bool codebook_in_lds, int *chunk_out) -> size_t {
+        const size_t fixed = (codebook_in_lds ? (size_t)c * K * 8 : 0) + (size_t)2 * nwv * 8 + (size_t)2 * nwv * 4 +
+                             (size_t)nwv * 8 + 2 * 64 * 8 + 64;
+        int chunk = 64;
+        while (chunk > 8 && fixed + (size_t)2 * chunk * cs * 8 > 150 * 1024) chunk >>= 1;
+        while ((chunk * c + bd - 1) / bd > 16) chunk >>= 1;  // gather registers per thread
+        *chunk_out = chunk;
+        return fixed + (size_t)2 * chunk * cs * 8;
+    };
+    int chunk = 0;
+    size_t lds = plan(CMAX == 0, &chunk);
+    bool in_place = false;
+    if constexpr (CMAX == 0) {
+        if (chunk < 1 || lds > 160 * 1024) {   // the codebook does not fit beside the ring: train it where it lies
+            in_place = true;
+            lds = plan(false, &chunk);
+        }
+    }
     if (chunk < 1 || lds > 160 * 1024)
-        return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "pxsom_train_online: codebook %dx%d does not fit LDS", K, c);
-    auto kern = som_online_kernel<T, CMAX, MAXT>;
-    PXSOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(1), dim3(bd), lds, st, x, n, c, ldx, w, xdim, ydim, rlen, a0, a1, r0, r1,
-                       order, chunk);
-    PXSOM_LAUNCH_CHECK("som_online_kernel");
-    return PXSOM_OK;
+        return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "pxsom_train_online: %d nodes x %d channels: no LDS for the row ring", K, c);
+    auto launch = [&](auto kern) -> int {
+        PXSOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(1), dim3(bd), lds, st, x, n, c, ldx, w, xdim, ydim, rlen, a0, a1, r0, r1,
+                           order, chunk);
+        PXSOM_LAUNCH_CHECK("som_online_kernel");
+        return PXSOM_OK;
+    };
+    if constexpr (CMAX == 0) {
+        if (in_place) return launch(som_online_kernel<T, CMAX, MAXT, true>);
+    }
+    return launch(som_online_kernel<T, CMAX, MAXT, false>);
 }
 
 template <typename T, int CH, int L>
