@@ -449,7 +449,10 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
             const unsigned id = __float_as_uint(my_m1) & node_mask;
             const unsigned wq = id >> 5, wb = (id >> 2) & 7u, wr = id & 3u;
             const unsigned real = wb == (unsigned)(NB - 1) ? 16u * wb + 4u * wr + wq : 16u * wb + 4u * wq + wr;
-            labels[row] = (int)real + 1;
+            // ACC: rows of the shifted last group that the group before it owns are left alone -- that group may
+            // already have settled them exactly inside this launch, and a late provisional store would undo it
+            // (plain filter: the rewrite is harmless, the exact kernel runs in a launch of its own afterwards)
+            if (!ACC || row >= g * 64) labels[row] = (int)real + 1;
             if constexpr (ACC) {
                 // lane (q, pix) holds channels q*CPL.. of rows (t, pix), t = 0..3; their labels sit in
                 // lanes (t, pix).  Skipped: listed rows, rows a previous group already added.

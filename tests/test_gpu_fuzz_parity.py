@@ -128,7 +128,13 @@ def test_fuzz_batch_training(oracle):
                     w_g = out.cpu().numpy()
                 if prev is not None:
                     want_w = oracle.batch_update(prev[0], xdim, ydim, prev[1], prev[2], prev[3], prev[4])
-                    np.testing.assert_allclose(w_g, want_w, rtol=1e-12, atol=1e-300, err_msg=tag + " update %d" % (g - 1))
+                    # to rounding, measured against the size of the channel: where the gain 1 - (1-alpha)^den is within
+                    # an ulp of 1 the device's expm1 and libm's may round it differently (1 vs 1 - 2^-53), which moves
+                    # the new value by 2^-53 * |w - mean| -- next to nothing for the channel, a lot for an element
+                    # that is itself 1e5 times smaller than the value it replaces
+                    scale = np.maximum(np.abs(prev[0]).max(axis=0), np.abs(want_w).max(axis=0))[None, :]
+                    err = np.abs(w_g - want_w) / np.maximum(scale, 1e-300)
+                    assert err.max() <= 1e-13, tag + " update %d: %.3g of the channel's scale" % (g - 1, err.max())
                 if g == total:
                     break
                 rows = host[g % m::m]
