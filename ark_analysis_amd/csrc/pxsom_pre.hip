@@ -31,16 +31,13 @@ struct Taps {
 // scipy NI_EXTEND_REFLECT: (d c b a | a b c d | d c b a)
 __device__ __forceinline__ int reflect_idx(int i, int len)
 {
+    /* position i of the infinitely reflected line, for any i (the image may be shorter than the kernel radius:
+     * scipy's NI_ExtendLine keeps reflecting, period 2 * len) */
     if (len == 1) return 0;
     const int sz2 = 2 * len;
-    if (i < 0) {
-        if (i < -sz2) i = sz2 * (-i / sz2) + i;
-        i = i < -len ? i + sz2 : -i - 1;
-    } else if (i >= len) {
-        i -= sz2 * (i / sz2);
-        if (i >= len) i = sz2 - i - 1;
-    }
-    return i;
+    int m = i % sz2;
+    if (m < 0) m += sz2;
+    return m < len ? m : sz2 - 1 - m;
 }
 
 // One pass of scipy's correlate1d, symmetric-kernel branch:

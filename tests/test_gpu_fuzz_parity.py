@@ -168,3 +168,65 @@ def test_fuzz_online_training(oracle):
         w = torch.from_numpy(w0.copy()).cuda()
         som_device.train_online(x, w, xdim, ydim, rlen, alpha, radius, torch.from_numpy(order).cuda())
         assert np.array_equal(w.cpu().numpy(), want), tag
+
+
+def test_fuzz_preprocessing(oracle):
+    """K2-K5 and the small label kernels on random shapes: blur (binary64 and float32 semantics), row-sum filter +
+    normalisation, column normalisation, non-zero / positive quantiles against numpy, pair histogram, relabel."""
+    from scipy import ndimage
+    from ark_analysis_amd import som_device as sd
+    rs = np.random.RandomState(SEED + 3)
+    dev = torch.device("cuda")
+    for case in range(CASES):
+        h, w, c = int(rs.randint(1, 90)), int(rs.randint(1, 90)), int(rs.randint(1, 9))
+        sigma = float(rs.choice([0.5, 1.0, 2.0, 3.0]))
+        f32 = bool(rs.rand() < 0.5)
+        img = rs.gamma(0.5, 2.0, size=(h, w, c))
+        img[rs.rand(h, w, c) < 0.4] = 0.0
+        if f32:
+            img = img.astype(np.float32).astype(np.float64)
+        tag = "case %d: %dx%dx%d sigma %g f32=%s" % (case, h, w, c, sigma, f32)
+        t = torch.from_numpy(img.copy()).to(dev)
+        sd.gaussian_blur_hwc(t, sigma, f32_semantics=f32)
+        want = oracle.gaussian_blur_hwc(img, sigma, f32=f32)
+        assert np.array_equal(t.cpu().numpy(), want), tag + " blur"
+        for j in range(c):     # ... and the oracle against scipy itself (images shorter than the kernel included)
+            if f32:
+                ref = ndimage.gaussian_filter(img[:, :, j].astype(np.float32), sigma)
+                assert np.array_equal(want[:, :, j].astype(np.float32), ref), tag + " blur vs scipy (float32)"
+            else:
+                np.testing.assert_allclose(want[:, :, j], ndimage.gaussian_filter(img[:, :, j], sigma), rtol=1e-13,
+                                           atol=1e-300, err_msg=tag + " blur vs scipy")
+        # row-sum filter + row normalisation on the blurred pixels
+        flat = np.ascontiguousarray(want.reshape(-1, c))
+        thresh = float(rs.choice([0.0, np.median(flat.sum(1)), 1e30]))
+        rows, kept = sd.rowsum_filter_normalize(torch.from_numpy(flat).to(dev), thresh, f32_semantics=f32)
+        wr, wk = oracle.rowsum_filter_normalize(flat, thresh, sum_mode=2 if f32 else 0)
+        assert np.array_equal(kept.cpu().numpy(), wk), tag + " kept rows"
+        assert np.array_equal(rows.cpu().numpy(), wr), tag + " normalised rows"
+        # quantiles of the kept rows' channels and the column normalisation by them
+        if len(wk) > 0:
+            q = float(rs.choice([0.05, 0.5, 0.99, 0.999]))
+            mode = int(rs.choice([0, 1]))
+            got_q = sd.quantile_nonzero(torch.from_numpy(wr).to(dev), q, keep_mode=mode).cpu().numpy()
+            for j in range(c):
+                col = wr[:, j]
+                sel = col[col != 0] if mode == 0 else col[col > 0]
+                if len(sel) == 0:
+                    assert np.isnan(got_q[j]), tag + " empty quantile"
+                else:
+                    assert got_q[j] == np.quantile(sel, q), tag + " quantile of column %d" % j
+            norm = np.where(np.isnan(got_q) | (got_q == 0), 1.0, got_q)
+            out = sd.normalize_columns(torch.from_numpy(wr).to(dev), torch.from_numpy(norm).to(dev))
+            assert np.array_equal(out.cpu().numpy(), wr / norm[None, :]), tag + " column normalisation"
+        # label kernels
+        n = int(rs.randint(1, 5000))
+        na, nb = int(rs.randint(1, 300)), int(rs.randint(1, 40))
+        a = rs.randint(-2, na + 2, size=n).astype(np.int32)
+        b = rs.randint(-2, nb + 2, size=n).astype(np.int32)
+        hist = sd.pair_histogram(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev), na, nb).cpu().numpy()
+        assert np.array_equal(hist, oracle.pair_histogram(a, b, na, nb)), tag + " pair histogram"
+        lut = rs.randint(0, 50, size=nb).astype(np.int32)
+        got_l = sd.relabel(torch.from_numpy(b).to(dev), torch.from_numpy(lut).to(dev), fill=-7).cpu().numpy()
+        inside = (b >= 0) & (b < nb)
+        assert np.array_equal(got_l, np.where(inside, lut[np.clip(b, 0, nb - 1)], -7)), tag + " relabel"
