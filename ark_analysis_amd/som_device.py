@@ -16,9 +16,9 @@ def _matrix_args(x: torch.Tensor) -> Tuple[int, int, int, int]:
         raise ValueError("pixel matrix must be 2-D [rows, channels]")
     if not x.is_cuda:
         raise ValueError("pixel matrix must live in HBM (a cuda/HIP tensor)")
-    if x.stride(1) != 1:
-        raise ValueError("pixel matrix rows must be contiguous (stride(1) == 1)")
     n, c = x.shape
+    if c > 1 and x.stride(1) != 1:     # (a single column has no second stride to speak of: torch reports anything)
+        raise ValueError("pixel matrix rows must be contiguous (stride(1) == 1)")
     ldx = x.stride(0) if n > 1 else max(c, x.stride(0))
     return n, c, ldx, _capi.dtype_code(x)
 

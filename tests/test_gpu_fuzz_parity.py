@@ -230,3 +230,51 @@ def test_fuzz_preprocessing(oracle):
         got_l = sd.relabel(torch.from_numpy(b).to(dev), torch.from_numpy(lut).to(dev), fill=-7).cpu().numpy()
         inside = (b >= 0) & (b < nb)
         assert np.array_equal(got_l, np.where(inside, lut[np.clip(b, 0, nb - 1)], -7)), tag + " relabel"
+
+
+def test_fuzz_arrow_labelling_path(tmp_path):
+    """cluster_pixels' pandas-free labelling (arrow_assign.label_table, recycled host blocks) against the DataFrame
+    route (PixelSOMCluster.assign_som_clusters) on random tables: chunked columns, extra columns, re-labelling."""
+    import pandas as pd
+    import pyarrow as pa
+    from ark_analysis_amd import arrow_assign
+    from ark_analysis_amd.fov_tables import read_table, write_dataframe
+    from ark_analysis_amd.phenotyping import cluster_helpers
+    rs = np.random.RandomState(SEED + 4)
+    blocks = arrow_assign.HostBlocks()
+    for case in range(CASES):
+        n, c = int(rs.randint(1, 6000)), int(rs.randint(1, 9))
+        xdim, ydim = int(rs.randint(1, 7)), int(rs.randint(1, 7))
+        chans = ["ch%d" % j for j in range(c)]
+        df = pd.DataFrame(rs.gamma(0.5, 1.0, size=(n, c)), columns=chans)
+        df["fov"] = "fov0"
+        df["row_index"] = rs.randint(0, 100, n)
+        df["column_index"] = rs.randint(0, 100, n)
+        if rs.rand() < 0.5:
+            df["label"] = rs.randint(0, 50, n)
+        relabel = bool(rs.rand() < 0.3)
+        if relabel:
+            df["pixel_som_cluster"] = rs.randint(1, 5, n).astype(np.int32)
+        norm = pd.DataFrame(rs.uniform(0.5, 2.0, size=(1, c)), columns=chans)
+        weights = pd.DataFrame(rs.gamma(0.5, 1.0, size=(xdim * ydim, c)), columns=chans)
+        for name, frame in (("norm", norm), ("weights", weights)):
+            write_dataframe(frame, str(tmp_path / (name + ".feather")))
+        (tmp_path / "sub").mkdir(exist_ok=True)
+        write_dataframe(df.iloc[:1], str(tmp_path / "sub" / "fov0.feather"))
+        som = cluster_helpers.PixelSOMCluster(str(tmp_path / "sub"), str(tmp_path / "norm.feather"),
+                                              str(tmp_path / "weights.feather"), ["fov0"], chans, xdim=xdim, ydim=ydim)
+        path = str(tmp_path / "table.feather")
+        write_dataframe(df, path)
+        table = read_table(path)                                     # 64 Ki-row record batches: chunked columns
+        assert arrow_assign.applicable(som, table, not relabel)
+        got, release = arrow_assign.label_table(som, table, normalize=not relabel, blocks=blocks)
+        got = got.to_pandas()
+        if release is not None:
+            release()
+        seen_fast = set(som.som_clusters_seen)
+        som.som_clusters_seen = set()
+        base = df.drop(columns="pixel_som_cluster") if relabel else df
+        want = som.assign_som_clusters(base, normalize_data=not relabel)
+        pd.testing.assert_frame_equal(got, want)
+        assert seen_fast == som.som_clusters_seen
+    blocks.close()
