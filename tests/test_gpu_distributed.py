@@ -70,3 +70,30 @@ def test_two_ranks_hip_kernels_match_oracle(gpu, oracle, tmp_path):
     s, cnt = oracle.cluster_sums(g, lab, k)
     np.testing.assert_array_equal(res["counts"], cnt)
     np.testing.assert_allclose(res["sums"], s, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(10, 10, 22), (20, 20, 40), (5, 7, 3)])
+def test_empty_and_tiny_shards(shape):
+    """A rank that was dealt no rows (fewer FOVs than ranks) or fewer rows than mini-batch steps: the step loop must
+    run (the other ranks wait in the exchange), contribute nothing and leave the codebook finite."""
+    import torch
+    from ark_analysis_amd import som_device
+    from ark_analysis_amd.distributed import BatchSOMTrainer
+    xd, yd, c = shape
+    dev = torch.device("cuda")
+    for dt in (torch.float32, torch.float64):
+        x = torch.empty((0, c), dtype=dt, device=dev)
+        w = torch.rand(xd * yd, c, dtype=torch.float64, device=dev)
+        w0 = w.clone()
+        BatchSOMTrainer(xd, yd, c, dev, batch_steps=8).train(x, w, num_passes=1)
+        torch.cuda.synchronize()
+        assert torch.equal(w, w0)
+        labels, _ = som_device.assign(x, w)
+        assert labels.numel() == 0
+        sums, counts = som_device.cluster_sums(x, labels, xd * yd)
+        assert float(sums.abs().sum()) == 0.0 and int(counts.sum()) == 0
+        few = torch.rand((3, c), dtype=torch.float64, device=dev).to(dt)
+        BatchSOMTrainer(xd, yd, c, dev, batch_steps=8).train(few, w, num_passes=1)
+        torch.cuda.synchronize()
+        assert torch.isfinite(w).all()

@@ -26,7 +26,8 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, td, mode, out_path):
+def _worker(rank, world, port, td, mode, out_path, fovs=None):
+    fovs = list(FOVS) if fovs is None else list(fovs)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     import io
@@ -39,11 +40,11 @@ def _worker(rank, world, port, td, mode, out_path):
     oracle_backend.install(setattr)
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
-        obj = pixel_som_clustering.train_pixel_som(FOVS, CHANS, td, num_passes=1, seed=42, train_mode=mode,
+        obj = pixel_som_clustering.train_pixel_som(fovs, CHANS, td, num_passes=1, seed=42, train_mode=mode,
                                                    batch_steps=4)
         n_train = len(obj.train_data)
-        pixel_som_clustering.cluster_pixels(FOVS, td, obj)
-        pixel_som_clustering.generate_som_avg_files(FOVS, CHANS, td, obj, data_dir="pixel_mat_data")
+        pixel_som_clustering.cluster_pixels(fovs, td, obj)
+        pixel_som_clustering.generate_som_avg_files(fovs, CHANS, td, obj, data_dir="pixel_mat_data")
     assert dist.get_world_size() == world
     np.savez(out_path % rank, weights=obj.weights.values, n_train=n_train, stdout=np.array(buf.getvalue()),
              seen=np.array(sorted(int(v) for v in obj.som_clusters_seen), dtype=np.int64),
@@ -129,3 +130,28 @@ def test_two_rank_pipeline(oracle, tmp_path, mode):
         for fov in FOVS:
             res = read_dataframe(os.path.join(td, "pixel_mat_data", fov + ".feather"))
             np.testing.assert_array_equal(res["pixel_som_cluster"].values, g["labels_" + fov])
+
+
+def test_more_ranks_than_fovs(oracle, tmp_path):
+    """Three ranks, two FOV tables: the rank that is dealt nothing trains on no rows (and still takes part in every
+    exchange), labels no table, and ends with the same codebook and cluster set as the others."""
+    from ark_analysis_amd.phenotyping.cluster_helpers import read_dataframe
+    g = np.load(os.path.join(GOLD, "g7_pixel_pipeline.npz"))
+    td = str(tmp_path / "job")
+    os.mkdir(td)
+    _build(td, g)
+    for fov in FOVS[2:]:
+        for folder in ("pixel_mat_data", "pixel_mat_subsetted"):
+            os.remove(os.path.join(td, folder, fov + ".feather"))
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_worker, args=(3, _free_port(), td, "batch", out, FOVS[:2]), nprocs=3, join=True)
+    ranks = [np.load(out % r) for r in range(3)]
+    assert [int(r["n_train"]) for r in ranks] == [400, 400, 0]
+    for r in ranks[1:]:
+        np.testing.assert_array_equal(r["weights"], ranks[0]["weights"])
+        np.testing.assert_array_equal(r["seen"], ranks[0]["seen"])
+    w = ranks[0]["weights"]
+    for fov in FOVS[:2]:
+        res = read_dataframe(os.path.join(td, "pixel_mat_data", fov + ".feather"))
+        want_l, _ = oracle.map_data_to_nodes(w, res[CHANS].values)
+        np.testing.assert_array_equal(res["pixel_som_cluster"].values, want_l)
