@@ -295,3 +295,44 @@ def test_fuzz_arrow_labelling_path(tmp_path):
         pd.testing.assert_frame_equal(got, want)
         assert seen_fast == som.som_clusters_seen
     blocks.close()
+
+
+def test_fuzz_front_ends(oracle):
+    """The pyFlowSOM-shaped entry points on host arrays as callers hand them over: C / Fortran order, sliced views,
+    float32 / float64 / integer dtypes, a single row; labels, *distances* and the seeded ``som`` against the oracle."""
+    from ark_analysis_amd import flowsom
+    rs = np.random.RandomState(SEED + 5)
+    for case in range(CASES):
+        xdim, ydim = int(rs.randint(1, 13)), int(rs.randint(1, 13))
+        k = xdim * ydim
+        c = int(rs.randint(1, 41))
+        n = int(rs.randint(1, 3000))
+        base = rs.gamma(0.5, 1.0, size=(n, c + 2))
+        form = str(rs.choice(["c", "fortran", "sliced", "float32", "int"]))
+        if form == "fortran":
+            data = np.asfortranarray(base[:, :c])
+        elif form == "sliced":
+            data = base[:, 1:c + 1]
+        elif form == "float32":
+            data = base[:, :c].astype(np.float32)
+        elif form == "int":
+            data = (base[:, :c] * 10).astype(np.int64)
+        else:
+            data = np.ascontiguousarray(base[:, :c])
+        host = np.ascontiguousarray(data, dtype=np.float64)
+        w = rs.gamma(0.5, 1.0, size=(k, c))
+        tag = "case %d: n=%d c=%d k=%d %s" % (case, n, c, k, form)
+        labels, dists = flowsom.map_data_to_nodes(w, data)
+        want_l, want_d = oracle.map_data_to_nodes(w, host)
+        assert np.array_equal(labels, want_l), tag
+        assert np.array_equal(dists, want_d), tag + " distances"       # sqrt of the binary64 sum, bit for bit
+        one_l, one_d = flowsom.map_data_to_nodes(w, data[0])            # a single row, 1-D
+        assert one_l[0] == want_l[0] and one_d[0] == want_d[0], tag + " single row"
+        if n >= k and form != "int":
+            seed = int(rs.randint(0, 1000))
+            rlen = int(rs.choice([1, 2]))
+            got = flowsom.som(data, xdim, ydim, rlen, (0.05, 0.01), seed=seed)
+            init_idx, order = flowsom.som_init_and_order(n, k, rlen, seed)
+            want = oracle.som_online(host, host[init_idx], xdim, ydim, rlen, (0.05, 0.01),
+                                     flowsom.default_radius_range(xdim, ydim), order)
+            assert np.array_equal(got, want), tag + " som(seed=%d, rlen=%d)" % (seed, rlen)
