@@ -253,7 +253,6 @@ def test_fuzz_arrow_labelling_path(tmp_path):
     """cluster_pixels' pandas-free labelling (arrow_assign.label_table, recycled host blocks) against the DataFrame
     route (PixelSOMCluster.assign_som_clusters) on random tables: chunked columns, extra columns, re-labelling."""
     import pandas as pd
-    import pyarrow as pa
     from ark_analysis_amd import arrow_assign
     from ark_analysis_amd.fov_tables import read_table, write_dataframe
     from ark_analysis_amd.phenotyping import cluster_helpers

@@ -69,7 +69,7 @@ def _build(td, g):
 
 @pytest.mark.parametrize("mode", ["batch", "online"])
 def test_two_rank_pipeline(oracle, tmp_path, mode):
-    from ark_analysis_amd.flowsom import default_radius_range, som_init_and_order
+    from ark_analysis_amd.flowsom import default_radius_range
     from ark_analysis_amd.phenotyping.cluster_helpers import read_dataframe
     g = np.load(os.path.join(GOLD, "g7_pixel_pipeline.npz"))
     td = str(tmp_path / "job")
