@@ -15,7 +15,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from ark_analysis_amd import som_device as sd, synth          # noqa: E402
 from ark_analysis_amd.distributed import BatchSOMTrainer      # noqa: E402
