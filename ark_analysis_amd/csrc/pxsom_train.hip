@@ -641,6 +641,44 @@ __global__ __launch_bounds__(256) void batch_update_kernel(double *w, int xdim, 
 // table in LDS (ds_add_f64), flushed once with global_atomic_add_f64.
 // Loads are flat-coalesced: lane e reads element e of the row range.
 // ------------------------------------------------------------------------------------------------
+// How a value joins the workgroup's table.  binary32 / binary64 rows: ds_add_f64.  binary16 rows: every binary16 number is
+// an integer multiple of 2^-24 below 2^16, so v * 2^24 is an integer below 2^40 and the table holds exact 64-bit
+// fixed-point sums (ds_add_u64: 5.8 lane-atomics per clock per CU against 3.0 for ds_add_f64,
+// scripts/ubench/lds_atomic_rate.hip -- this kernel is bound by that rate).  Exact and order-independent: equal to the
+// oracle's binary64 sum whenever that one is exact too (sums below 2^29).  Infinities / NaNs go straight to the global
+// binary64 table, where they poison the sum as they do in the oracle.
+template <typename T>
+struct TableAdd {
+    static constexpr bool kFixed = false;
+    static __device__ __forceinline__ void add(double *ls, size_t slot, T v, double *)
+    {
+        __hip_atomic_fetch_add(ls + slot, (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    static __device__ __forceinline__ double value(const double *ls, size_t slot) { return ls[slot]; }
+};
+template <>
+struct TableAdd<_Float16> {
+    static constexpr bool kFixed = true;
+    static __device__ __forceinline__ void add(double *ls, size_t slot, _Float16 v, double *global_sums)
+    {
+        const unsigned b = __builtin_bit_cast(unsigned short, v);
+        const unsigned e = (b >> 10) & 31u, m = b & 1023u;
+        if (e == 31u) {   // inf / NaN
+            __hip_atomic_fetch_add(global_sums + slot, (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        const unsigned long long q = e ? (unsigned long long)(1024u + m) << (e - 1u) : (unsigned long long)m;
+        const unsigned long long sq = (b & 0x8000u) ? 0ull - q : q;   // two's complement
+        if (sq)
+            __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(ls) + slot, sq, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    static __device__ __forceinline__ double value(const double *ls, size_t slot)
+    {
+        return (double)reinterpret_cast<const long long *>(ls)[slot] * 0x1p-24;
+    }
+};
+
 template <typename T, bool COUNT_F64, int NT>
 __global__ __launch_bounds__(NT) void cluster_sums_kernel(const T *__restrict__ x, int64_t n, int c,
                                                            int64_t ldx, const int32_t *__restrict__ labels,
@@ -708,8 +746,7 @@ __global__ __launch_bounds__(NT) void cluster_sums_kernel(const T *__restrict__ 
                     for (int i = 0; i < VEC; i++) {
                         const int lb = lab[u][i];
                         if (lb >= 0 && lb < k) {
-                            __hip_atomic_fetch_add(&ls[(size_t)lb * c + chn[u][i]], (double)val[u][i], __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+                            TableAdd<T>::add(ls, (size_t)lb * c + chn[u][i], val[u][i], sums);
                             if (chn[u][i] == 0) atomicAdd(&lc[lb], 1u);
                         }
                     }
@@ -719,8 +756,7 @@ __global__ __launch_bounds__(NT) void cluster_sums_kernel(const T *__restrict__ 
                 const int64_t row = e / c;
                 const int ch = (int)(e - row * c), lb = labels[r0 + row] - 1;
                 if (lb >= 0 && lb < k) {
-                    __hip_atomic_fetch_add(&ls[(size_t)lb * c + ch], (double)xb[e], __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                    TableAdd<T>::add(ls, (size_t)lb * c + ch, xb[e], sums);
                     if (ch == 0) atomicAdd(&lc[lb], 1u);
                 }
             }
@@ -736,13 +772,13 @@ __global__ __launch_bounds__(NT) void cluster_sums_kernel(const T *__restrict__ 
         const int drow = NT / c, dch = NT % c;
         for (int64_t e = tid; e < total; e += 4 * NT) {
             int cc[4], lab[4];
-            double v[4];
+            T v[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 cc[u] = ch;
                 const bool ok = e + NT * u < total;
                 lab[u] = ok ? labels[row] - 1 : -1;
-                v[u] = ok ? (double)x[row * ldx + ch] : 0.0;
+                v[u] = ok ? x[row * ldx + ch] : (T)0;
                 row += drow;
                 ch += dch;
                 if (ch >= c) {
@@ -754,11 +790,10 @@ __global__ __launch_bounds__(NT) void cluster_sums_kernel(const T *__restrict__ 
             for (int u = 0; u < 4; u++) {
                 if (lab[u] >= 0 && lab[u] < k) {
                     if (use_lds) {
-                        __hip_atomic_fetch_add(&ls[(size_t)lab[u] * c + cc[u]], v[u], __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                        TableAdd<T>::add(ls, (size_t)lab[u] * c + cc[u], v[u], sums);
                         if (cc[u] == 0) atomicAdd(&lc[lab[u]], 1u);
                     } else {
-                        __hip_atomic_fetch_add(&sums[(size_t)lab[u] * c + cc[u]], v[u], __ATOMIC_RELAXED,
+                        __hip_atomic_fetch_add(&sums[(size_t)lab[u] * c + cc[u]], (double)v[u], __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT);
                         if (cc[u] == 0) {
                             if constexpr (COUNT_F64)
@@ -775,7 +810,7 @@ __global__ __launch_bounds__(NT) void cluster_sums_kernel(const T *__restrict__ 
     if (use_lds) {
         __syncthreads();
         for (int e = tid; e < k * c; e += NT) {
-            const double v = ls[e];
+            const double v = TableAdd<T>::value(ls, e);
             if (v != 0.0) __hip_atomic_fetch_add(&sums[e], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         for (int e = tid; e < k; e += NT)
