@@ -711,6 +711,47 @@ __global__ __launch_bounds__(NT) void cluster_sums_kernel(const T *__restrict__ 
             int64_t vrow = ((int64_t)VEC * tid) / c;
             int vch = (int)((int64_t)VEC * tid - vrow * c);
             const int drow = (NT * VEC) / c, dch = (NT * VEC) % c;
+            if (c >= VEC) {
+                // A 16-byte vector spans at most two rows: both labels are requested up front, unconditionally (clamped
+                // row), and every element picks its own -- no load behind a divergent branch (such a load gets its
+                // s_waitcnt right behind it: one serialised L2 round trip per vector, which held this kernel at a
+                // quarter of the LDS atomic rate)
+                const int64_t last_row = r1 - r0 - 1;
+                for (int64_t v0 = tid; v0 < nvec; v0 += 4 * NT) {
+                    T val[4][VEC];
+                    int lab_a[4], lab_b[4], ch0[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int64_t v = v0 + u * NT;
+                        const bool ok = v < nvec;
+                        const u4 raw = *reinterpret_cast<const u4 *>(xb + VEC * (ok ? v : nvec - 1));
+                        __builtin_memcpy(val[u], &raw, 16);
+                        const int64_t row = vrow < last_row ? vrow : last_row, row2 = vrow + 1 < last_row ? vrow + 1 : last_row;
+                        const int la = labels[r0 + row] - 1, lb2 = labels[r0 + row2] - 1;
+                        lab_a[u] = ok ? la : -1;
+                        lab_b[u] = (ok && vrow + 1 <= last_row) ? lb2 : -1;
+                        ch0[u] = vch;
+                        vrow += drow;
+                        vch += dch;
+                        if (vch >= c) {
+                            vch -= c;
+                            vrow++;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+#pragma unroll
+                        for (int i = 0; i < VEC; i++) {
+                            const bool wrapped = ch0[u] + i >= c;
+                            const int lb = wrapped ? lab_b[u] : lab_a[u];
+                            const int ch = ch0[u] + i - (wrapped ? c : 0);
+                            if (lb >= 0 && lb < k) {
+                                TableAdd<T>::add(ls, (size_t)lb * c + ch, val[u][i], sums);
+                                if (ch == 0) atomicAdd(&lc[lb], 1u);
+                            }
+                        }
+                }
+            } else
             for (int64_t v0 = tid; v0 < nvec; v0 += 4 * NT) {
                 T val[4][VEC];
                 int lab[4][VEC], chn[4][VEC];
