@@ -39,8 +39,11 @@ namespace {
 // channel slots past c re-read the row's last valid pair (their codebook slots are zero).
 // LDSW (streamed codebook only): fragments + bias are copied into LDS once per workgroup and read from there
 // (ds_read_b128) instead of from L1 / L2 for every tile set.
-template <typename T, int NCH_T, int CPL_T, int NB_T, bool VEC2, bool PREFETCH, int TP, bool LDSW>
-__global__ __launch_bounds__(256, 2) void bmu_filter_kernel(
+// BD: threads per workgroup.  256 (two workgroups per CU), or -- LDSW with a codebook that leaves room for one
+// workgroup only (config 5: 125 KB of fragments) -- 512: two waves per SIMD on one LDS copy (1024 threads spill: the
+// kernel holds ~110-190 VGPRs).
+template <typename T, int NCH_T, int CPL_T, int NB_T, bool VEC2, bool PREFETCH, int TP, bool LDSW, int BD = 256>
+__global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_kernel(
     const T *__restrict__ x, int64_t n, int c, int64_t ldx, const half8 *__restrict__ wfrag,
     const f32x4 *__restrict__ bias, AssignHdr *hdr, unsigned *__restrict__ amb_list,
     int32_t *__restrict__ labels)
@@ -60,8 +63,9 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_kernel(
 
     const int lane = threadIdx.x & 63;
     const int pix = lane & 15, q = lane >> 4;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    constexpr int WV = BD / 64;
+    const int64_t wave = (int64_t)blockIdx.x * WV + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * WV;
     const int64_t ngroups = (n + 63) / 64;
 
     // register-resident codebook
@@ -81,15 +85,15 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_kernel(
     f32x4 *lbias = reinterpret_cast<f32x4 *>(lfrag + (size_t)nb * NFR * 64);
     if constexpr (LDSW && NB_T == 0) {
         const int nf = nb * NFR * 64;
-        for (int i0 = threadIdx.x; i0 < nf; i0 += 4 * 256) {   // 4 x 16 B in flight per thread
+        for (int i0 = threadIdx.x; i0 < nf; i0 += 4 * BD) {   // 4 x 16 B in flight per thread
             half8 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) v[u] = wfrag[i0 + u * 256 < nf ? i0 + u * 256 : 0];
+            for (int u = 0; u < 4; u++) v[u] = wfrag[i0 + u * BD < nf ? i0 + u * BD : 0];
 #pragma unroll
             for (int u = 0; u < 4; u++)
-                if (i0 + u * 256 < nf) lfrag[i0 + u * 256] = v[u];
+                if (i0 + u * BD < nf) lfrag[i0 + u * BD] = v[u];
         }
-        for (int i = threadIdx.x; i < nb * 64; i += 256) lbias[i] = bias[i];
+        for (int i = threadIdx.x; i < nb * 64; i += BD) lbias[i] = bias[i];
         __syncthreads();
     }
 
@@ -365,6 +369,25 @@ void launch_filter_variant(const T *x, int64_t n, int c, int64_t ldx, char *ws, 
     // L1 / L2): C = 40, K = 400, 4.2 M rows: TP 1 / 2 / 4 = 1.27 / 0.83 / 0.75; C = 100, K = 100, 1 M rows:
     // 0.244 / 0.188 / 0.257 (four channel chunks x four tiles of fragments no longer fit the register file)
     constexpr int TP = (NB > 0) ? 2 : (PXSOM_STREAM_TP > 0 ? PXSOM_STREAM_TP : (NCH <= 2 ? 4 : 2));
+    const int64_t ngroups = (n + 63) / 64;
+    if constexpr (LDSW) {
+        if (lds > 64 * 1024) {   // one workgroup per CU: make it a big one
+            auto big = bmu_filter_kernel<T, NCH, CPL, NB, VEC2, PF, TP, LDSW, 512>;
+            static bool raised = false;
+            if (!raised) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(big), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          150 * 1024);
+                raised = true;
+            }
+            int grid = (int)std::min<int64_t>((ngroups + 7) / 8, (int64_t)pxsom::device_cu_count());
+            if (grid < 1) grid = 1;
+            hipLaunchKernelGGL(big, dim3(grid), dim3(512), lds, st, x, n, c, ldx,
+                               reinterpret_cast<const half8 *>(ws + L.off_wfrag),
+                               reinterpret_cast<const f32x4 *>(ws + L.off_bias), reinterpret_cast<AssignHdr *>(ws),
+                               reinterpret_cast<unsigned *>(ws + L.off_list), labels);
+            return;
+        }
+    }
     auto kern = bmu_filter_kernel<T, NCH, CPL, NB, VEC2, PF, TP, LDSW>;
     // persistent grid: exactly as many workgroups as are resident (VGPR- and LDS-limited), capped by the work
     static int by_regs = 0;
@@ -378,7 +401,6 @@ void launch_filter_variant(const T *x, int64_t n, int c, int64_t ldx, char *ws, 
     }
     int blocks_per_cu = by_regs;
     if (lds > 0) blocks_per_cu = std::max(1, std::min<int>(by_regs, (int)((160 * 1024) / lds)));
-    const int64_t ngroups = (n + 63) / 64;
     int grid = (int)std::min<int64_t>((ngroups + 3) / 4, (int64_t)pxsom::device_cu_count() * blocks_per_cu);
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, x, n, c, ldx,
