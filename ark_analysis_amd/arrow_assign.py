@@ -99,8 +99,9 @@ class HostBlocks:
 def label_table(som, table: pa.Table, normalize: bool, blocks: Optional[HostBlocks] = None):
     """``table`` with the SOM's channels normalised (if ``normalize``) and ``pixel_som_cluster`` appended;
     ``som.som_clusters_seen`` is updated.  Requires :func:`applicable`.  With ``blocks`` the result is
-    ``(table, release)``: the channel columns live in a recycled host block and ``release()`` must be called
-    when the table has been written (or dropped)."""
+    ``(table, release, totals)``: the channel columns live in a recycled host block and ``release()`` must be called
+    when the table has been written (or dropped); ``totals`` = ``(channels, sums [K, C], counts [K])`` of the rows as
+    written -- the per-cluster table ``generate_som_avg_files`` would otherwise re-read the file for."""
     import torch
 
     from . import _capi, som_device
@@ -123,7 +124,14 @@ def label_table(som, table: pa.Table, normalize: bool, blocks: Optional[HostBloc
         som_device.normalize_columns(rows, norm, out=rows)   # element-wise, in place
     codebook = torch.from_numpy(np.ascontiguousarray(som.weights.to_numpy(dtype=np.float64))).to(dev)
     labels, _ = som_device.assign(rows, codebook)
-    som.som_clusters_seen.update(torch.unique(labels).cpu().tolist())
+    totals = None
+    if blocks is not None:      # (the rows are in HBM now: their per-cluster sums cost 20 us, not a second file read)
+        sums, counts = som_device.cluster_sums(rows, labels, codebook.shape[0])
+        counts_host = counts.cpu().numpy()
+        totals = (tuple(feats), sums.cpu().numpy(), counts_host)
+        som.som_clusters_seen.update((np.flatnonzero(counts_host) + 1).tolist())
+    else:
+        som.som_clusters_seen.update(torch.unique(labels).cpu().tolist())
     label_array = pa.array(labels.cpu().numpy())         # int32, like the DataFrame path
 
     replaced, release = {}, None
@@ -151,4 +159,4 @@ def label_table(som, table: pa.Table, normalize: bool, blocks: Optional[HostBloc
     out = out.replace_schema_metadata(_with_label_metadata(table.schema.metadata, names))
     if blocks is None:
         return out
-    return out, release
+    return out, release, totals

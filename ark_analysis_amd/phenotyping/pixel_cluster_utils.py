@@ -158,10 +158,54 @@ class _ClusterTotals:
         return out
 
 
+class _CachedTotals:
+    """Per-cluster channel sums / pixel counts of the FOV tables ``cluster_pixels`` has just written, kept on the SOM
+    object: the rows were in HBM when they were labelled, so their table cost one 20 us kernel -- re-reading 218 MB
+    per FOV for it (what the reference's generate_som_avg_files does) costs a thousand times that.  An entry is
+    used only while the file it describes is still the one on disk (same size and modification time)."""
+
+    def __init__(self, root: str):
+        self.root = os.path.abspath(root)
+        self._entries = {}
+
+    @classmethod
+    def attach(cls, som, root: str) -> "_CachedTotals":
+        cache = cls(root)
+        som._fov_totals = cache
+        return cache
+
+    @staticmethod
+    def of(som, root: str):
+        cache = getattr(som, "_fov_totals", None)
+        return cache if cache is not None and cache.root == os.path.abspath(root) else None
+
+    def remember(self, fov: str, written_path: str, totals) -> None:
+        try:
+            st = os.stat(written_path)      # the staging file: the directory swap keeps size and mtime
+        except OSError:
+            return
+        self._entries[fov] = (st.st_size, st.st_mtime_ns, totals)
+
+    def lookup(self, fov: str, channels):
+        entry = self._entries.get(fov)
+        if entry is None:
+            return None
+        try:
+            st = os.stat(os.path.join(self.root, fov + ".feather"))
+        except OSError:
+            return None
+        size, mtime_ns, (feats, sums, counts) = entry
+        if (st.st_size, st.st_mtime_ns) != (size, mtime_ns) or any(ch not in feats for ch in channels):
+            return None
+        cols = [feats.index(ch) for ch in channels]
+        present = np.flatnonzero(counts)
+        return present + 1, sums[np.ix_(present, cols)], counts[present]
+
+
 def compute_pixel_cluster_channel_avg(fovs, channels, base_dir, pixel_cluster_col,
                                       num_pixel_clusters,
                                       pixel_data_dir='pixel_mat_data',
-                                      num_fovs_subset=100, seed=42, keep_count=False):
+                                      num_fovs_subset=100, seed=42, keep_count=False, *, _cached=None):
     """Mean channel expression of every pixel SOM / meta cluster over (a random subset of) the FOVs.
 
     ``num_pixel_clusters``: how many clusters the table must contain (``None``: do not check);
@@ -188,7 +232,18 @@ def compute_pixel_cluster_channel_avg(fovs, channels, base_dir, pixel_cluster_co
     # of the chosen files (the same list everywhere: it comes from the seeded draw above).
     from .. import distributed
     on_device = flowsom.cluster_sums is _DEVICE_SUMS
-    feed = TablePrefetcher(tables, distributed.shard(chosen), depth=4, as_arrow=on_device, workers=3)
+    mine = distributed.shard(chosen)
+    if _cached is not None and on_device and pixel_cluster_col == 'pixel_som_cluster':
+        # tables this process labelled a moment ago (and that are still the files on disk) are not read again
+        unread = []
+        for fov in mine:
+            hit = _cached.lookup(fov, totals.channels)
+            if hit is None:
+                unread.append(fov)
+            else:
+                totals._merge(*hit)
+        mine = unread
+    feed = TablePrefetcher(tables, mine, depth=4, as_arrow=on_device, workers=3)
     try:
         for fov, table in feed:
             if table is None:

@@ -69,12 +69,12 @@ def _label_table(som, table, relabel: bool, block: int, host_blocks=None):
     ``relabel``: the table was produced by an earlier run (already normalised, old labels present).
     Arrow tables take the pandas-free device path when it covers them (and the device entry point has
     not been replaced); everything else goes through ``PixelSOMCluster.assign_som_clusters``.
-    ``host_blocks`` (an ``arrow_assign.HostBlocks``): the result is ``(table, release-or-None)``."""
+    ``host_blocks`` (an ``arrow_assign.HostBlocks``): the result is ``(table, release-or-None, totals-or-None)``."""
     if host_blocks is not None:
         if (not hasattr(table, "iloc") and flowsom.map_data_to_nodes is _DEVICE_BMU
                 and arrow_assign.applicable(som, table, not relabel)):
             return arrow_assign.label_table(som, table, normalize=not relabel, blocks=host_blocks)
-        return _label_table(som, table, relabel, block), None
+        return _label_table(som, table, relabel, block), None, None
     if not hasattr(table, "iloc"):   # an Arrow table
         if flowsom.map_data_to_nodes is _DEVICE_BMU and arrow_assign.applicable(som, table, not relabel):
             return arrow_assign.label_table(som, table, normalize=not relabel)
@@ -82,6 +82,16 @@ def _label_table(som, table, relabel: bool, block: int, host_blocks=None):
     if relabel:
         table = table.drop(columns="pixel_som_cluster", errors="ignore")
     return som.assign_som_clusters(table, normalize_data=not relabel, num_parallel_pixels=block)
+
+
+def _after_write(release, cache, fov, staged_path, totals):
+    """Writer-thread epilogue of one table: hand the host block back, remember the table's totals."""
+    def done():
+        if release is not None:
+            release()
+        if totals is not None:
+            cache.remember(fov, staged_path, totals)
+    return done
 
 
 def run_pixel_som_assignment(pixel_data_path, pixel_pysom_obj, overwrite, num_parallel_pixels, fov):
@@ -159,6 +169,9 @@ def cluster_pixels(fovs, base_dir, pixel_pysom, data_dir='pixel_mat_data',
     writer = TableWriter(depth=8, workers=6)
     feed = TablePrefetcher(tables, mine, depth=4, as_arrow=True, workers=3)
     host_blocks = arrow_assign.HostBlocks()
+    # per-cluster totals of every table labelled here, keyed by FOV and stamped with the written file's size and
+    # mtime: generate_som_avg_files then needs no second pass over 218 MB per FOV (pixel_cluster_utils._CachedTotals)
+    cache = pixel_cluster_utils._CachedTotals.attach(pixel_pysom, root)
     try:
         rows = iter(feed)
         for names in fov_tables.batches(mine, group):
@@ -168,8 +181,9 @@ def cluster_pixels(fovs, base_dir, pixel_pysom, data_dir='pixel_mat_data',
                 if table is None:
                     spoiled.append(fov)
                     continue
-                labelled, release = _label_table(pixel_pysom, table, overwrite, num_parallel_pixels, host_blocks)
-                writer.submit(labelled, tables.path(fov, staged=True), done=release)
+                labelled, release, totals = _label_table(pixel_pysom, table, overwrite, num_parallel_pixels, host_blocks)
+                writer.submit(labelled, tables.path(fov, staged=True),
+                              done=_after_write(release, cache, fov, tables.path(fov, staged=True), totals))
             for fov in spoiled:
                 print(_CORRUPT % fov)
             done += len(names) - len(spoiled)
@@ -224,7 +238,8 @@ def generate_som_avg_files(fovs, channels, base_dir, pixel_pysom, data_dir='pixe
     # (with a process group the chosen FOV files are dealt to the ranks and the totals all-reduced)
     means = pixel_cluster_utils.compute_pixel_cluster_channel_avg(
         fovs, channels, base_dir, 'pixel_som_cluster', expected, data_dir,
-        num_fovs_subset=num_fovs_subset, seed=seed, keep_count=True)
+        num_fovs_subset=num_fovs_subset, seed=seed, keep_count=True,
+        _cached=pixel_cluster_utils._CachedTotals.of(pixel_pysom, os.path.join(base_dir, data_dir)))
     if rank == 0:
         means.to_csv(target, index=False)
     distributed.barrier()

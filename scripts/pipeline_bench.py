@@ -72,6 +72,10 @@ t0 = time.perf_counter()
 pixel_som_clustering.cluster_pixels(fovs, root, som)
 t_pipe = time.perf_counter() - t0
 px = n * args.fovs
+# generate_som_avg_files straight after cluster_pixels: the per-cluster totals were taken while the rows were in HBM
+t0 = time.perf_counter()
+pixel_som_clustering.generate_som_avg_files(fovs, chans, root, som, data_dir="pixel_mat_data", num_fovs_subset=len(fovs))
+t_avg_cached = time.perf_counter() - t0
 # the per-SOM-cluster mean table over the labelled tables (generate_som_avg_files' work): device path, then
 # the DataFrame path the reference shape implies (same kernel underneath)
 from ark_analysis_amd.phenotyping import pixel_cluster_utils  # noqa: E402
@@ -97,6 +101,7 @@ print(json.dumps({
                             "write": round(t_write, 3), "sum": round(t_read + t_label + t_write, 3)},
     "cluster_pixels_s": round(t_pipe, 3),
     "cluster_pixels_Mpx_per_s": round(px / t_pipe / 1e6, 2),
+    "generate_som_avg_files_after_cluster_pixels_s": round(t_avg_cached, 3),
     "cluster_channel_avg_s": round(t_avg, 3), "cluster_channel_avg_dataframe_route_s": round(t_avg_df, 3),
     "generated_in_s": round(t_gen, 1)}))
 fov_tables.wait_for_cleanup()

@@ -283,10 +283,18 @@ def test_fuzz_arrow_labelling_path(tmp_path):
         write_dataframe(df, path)
         table = read_table(path)                                     # 64 Ki-row record batches: chunked columns
         assert arrow_assign.applicable(som, table, not relabel)
-        got, release = arrow_assign.label_table(som, table, normalize=not relabel, blocks=blocks)
+        got, release, totals = arrow_assign.label_table(som, table, normalize=not relabel, blocks=blocks)
         got = got.to_pandas()
         if release is not None:
             release()
+        # the per-cluster totals handed to generate_som_avg_files' cache == a groupby over the table as written
+        feats, sums, counts = totals
+        assert list(feats) == chans
+        by = got.groupby("pixel_som_cluster")
+        present = np.flatnonzero(counts) + 1
+        assert np.array_equal(present, np.array(sorted(by.groups)))
+        assert np.array_equal(counts[present - 1], by.size().to_numpy())
+        np.testing.assert_allclose(sums[present - 1], by[chans].sum().to_numpy(), rtol=1e-12, atol=1e-300)
         seen_fast = set(som.som_clusters_seen)
         som.som_clusters_seen = set()
         base = df.drop(columns="pixel_som_cluster") if relabel else df

@@ -732,3 +732,33 @@ def test_reference_generate_som_avg_files(som_backend, tmp_path, capsys):
         pixel_cluster_utils.compute_pixel_cluster_channel_avg(FOVS, CHANS, td, "pixel_som_cluster", None,
                                                               "pixel_mat_data", num_fovs_subset=100)
     assert any("Provided num_fovs_subset" in str(w.message) for w in wlist)
+
+
+@pytest.mark.gpu
+def test_avg_files_use_the_totals_cluster_pixels_left_behind(tmp_path, monkeypatch):
+    """generate_som_avg_files right after cluster_pixels reads no table again (the per-cluster totals were taken
+    while the rows were in HBM), gives the numbers a fresh pass over the files gives, and falls back to reading as
+    soon as a file is no longer the one that was written."""
+    from ark_analysis_amd import fov_tables
+    g = np.load(os.path.join(GOLD, "g7_pixel_pipeline.npz"))
+    td = str(tmp_path)
+    _build_pixel_dirs(td, g)
+    obj = pixel_som_clustering.train_pixel_som(FOVS, CHANS, td)
+    pixel_som_clustering.cluster_pixels(FOVS, td, obj)
+    reads = []
+    real = fov_tables.FovTableDir.load_arrow
+    monkeypatch.setattr(fov_tables.FovTableDir, "load_arrow", lambda self, fov: reads.append(fov) or real(self, fov))
+    pixel_som_clustering.generate_som_avg_files(FOVS, CHANS, td, obj, data_dir="pixel_mat_data")
+    assert reads == []
+    cached = pd.read_csv(os.path.join(td, "pixel_channel_avg_som_cluster.csv"))
+    fresh = pixel_cluster_utils.compute_pixel_cluster_channel_avg(FOVS, CHANS, td, "pixel_som_cluster", None,
+                                                                  "pixel_mat_data", num_fovs_subset=len(FOVS), keep_count=True)
+    assert sorted(reads) == sorted(FOVS)
+    np.testing.assert_array_equal(cached["count"].values, fresh["count"].values)
+    np.testing.assert_allclose(cached[CHANS].values, fresh[CHANS].values, rtol=1e-13, atol=0)
+    # a rewritten table (same content, new modification time) is read again
+    del reads[:]
+    path = os.path.join(td, "pixel_mat_data", FOVS[0] + ".feather")
+    os.utime(path, ns=(1, 1))
+    pixel_som_clustering.generate_som_avg_files(FOVS, CHANS, td, obj, data_dir="pixel_mat_data", overwrite=True)
+    assert reads == [FOVS[0]]
