@@ -26,7 +26,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, td, mode, out_path, fovs=None):
+def _worker(rank, world, port, td, mode, out_path, fovs=None, kernels="oracle"):
     fovs = list(FOVS) if fovs is None else list(fovs)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
@@ -36,8 +36,15 @@ def _worker(rank, world, port, td, mode, out_path, fovs=None):
     from ark_analysis_amd import flowsom  # noqa: F401
     from ark_analysis_amd.phenotyping import pixel_som_clustering
     from ark_analysis_amd.phenotyping.cluster_helpers import read_dataframe
-    from tests import oracle_backend
-    oracle_backend.install(setattr)
+    if kernels == "oracle":
+        from tests import oracle_backend
+        oracle_backend.install(setattr)
+    else:
+        # the HIP path on ONE device shared by the ranks: RCCL refuses two ranks on a GPU, so the group is gloo
+        # (joined here, before the pipeline's own init_from_env would pick "nccl")
+        import torch
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         obj = pixel_som_clustering.train_pixel_som(fovs, CHANS, td, num_passes=1, seed=42, train_mode=mode,
@@ -155,3 +162,51 @@ def test_more_ranks_than_fovs(oracle, tmp_path):
         res = read_dataframe(os.path.join(td, "pixel_mat_data", fov + ".feather"))
         want_l, _ = oracle.map_data_to_nodes(w, res[CHANS].values)
         np.testing.assert_array_equal(res["pixel_som_cluster"].values, want_l)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["batch", "online"])
+def test_two_rank_pipeline_on_the_hip_path(oracle, tmp_path, mode):
+    """The same three pipeline functions on two ranks with the real kernels (both ranks on device 0, gloo group):
+    Arrow labelling path, recycled host blocks, totals cache, rank-sharded files -- against the oracle."""
+    from ark_analysis_amd.flowsom import default_radius_range
+    from ark_analysis_amd.phenotyping.cluster_helpers import read_dataframe
+    g = np.load(os.path.join(GOLD, "g7_pixel_pipeline.npz"))
+    td = str(tmp_path / "job")
+    os.mkdir(td)
+    _build(td, g)
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_worker, args=(2, _free_port(), td, mode, out, None, "hip"), nprocs=2, join=True)
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    np.testing.assert_array_equal(r0["weights"], r1["weights"])
+    w = r0["weights"]
+    if mode == "online":
+        np.testing.assert_array_equal(w, g["weights"])               # the reference-order run: bit-equal
+    else:
+        norm = g["norm"]
+        sub = {fov: g["sub_" + fov] / norm for fov in FOVS}
+        local = [np.concatenate([sub["fov0"], sub["fov2"]]), sub["fov1"]]
+        init = local[0][np.random.RandomState(42).choice(len(local[0]), 100, replace=False)]
+        blocks, m = [], 4
+        for j in range(len(local[0]) // m):
+            blocks.append(local[0][j * m:(j + 1) * m])
+            if (j + 1) * m <= len(local[1]):
+                blocks.append(local[1][j * m:(j + 1) * m])
+        want = oracle.som_batch(np.concatenate(blocks), init, 10, 10, 1, (0.05, 0.01), default_radius_range(10, 10), m)
+        np.testing.assert_allclose(w, want, rtol=1e-9, atol=0)
+    counts = np.zeros(100, dtype=np.int64)
+    sums = np.zeros((100, 4))
+    for fov in FOVS:
+        res = read_dataframe(os.path.join(td, "pixel_mat_data", fov + ".feather"))
+        np.testing.assert_array_equal(res[CHANS].values, g["normed_" + fov])
+        want_l, _ = oracle.map_data_to_nodes(w, res[CHANS].values)
+        np.testing.assert_array_equal(res["pixel_som_cluster"].values, want_l)
+        s_, c_ = oracle.cluster_sums(res[CHANS].values, want_l, 100)
+        sums += s_
+        counts += c_
+    seen = np.flatnonzero(counts) + 1
+    np.testing.assert_array_equal(r0["seen"], seen)
+    np.testing.assert_array_equal(r1["seen"], seen)
+    avg = pd.read_csv(os.path.join(td, "pixel_channel_avg_som_cluster.csv"))
+    np.testing.assert_array_equal(avg["count"].values, counts[seen - 1])
+    np.testing.assert_allclose(avg[CHANS].values, sums[seen - 1] / counts[seen - 1][:, None], rtol=1e-12, atol=0)
