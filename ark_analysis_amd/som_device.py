@@ -137,6 +137,9 @@ def _torch_rccl_path() -> str:
     """The librccl.so this process already uses: PyTorch's own copy (binding a second RCCL next to it is
     what pxsom_comm_bind exists to avoid); empty = let the library fall back to the system one."""
     import os
+    override = os.environ.get("PXSOM_RCCL_LIBRARY")     # another build of the collective library (tests: a stand-in)
+    if override:
+        return override
     path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
     return path if os.path.exists(path) else ""
 

@@ -79,3 +79,91 @@ def test_native_exchange_under_a_one_rank_rccl_group():
     env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
     res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert "EXCHANGE_OK" in res.stdout, res.stdout + res.stderr
+
+
+# ---- two real ranks through the in-library step loop --------------------------------------------------------------
+# RCCL will not put two ranks on one GPU, and the round's boxes have one.  tests/mock_rccl/mock_rccl.cpp implements the
+# five entry points pxsom_comm.hip binds (all-reduce through shared memory, binary64 sums in rank order); bound through
+# PXSOM_RCCL_LIBRARY it lets pxsom_batch_train_steps_sharded run its loop -- step launch, exchange, next step -- on two
+# processes that hold different rows.  What stays unexercised here is RCCL's own all-reduce.
+
+def _mock_library(tmpdir) -> str:
+    import shutil
+    src = os.path.join(ROOT, "tests", "mock_rccl", "mock_rccl.cpp")
+    out = os.path.join(str(tmpdir), "libmock_rccl.so")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    subprocess.check_call([hipcc, "-O2", "-fPIC", "-shared", "-std=c++17", src, "-o", out, "-lrt"])
+    return out
+
+
+def _sharded_worker(rank, world, lib_path, uid_path, out_path, shape, n_local, steps, passes):
+    os.environ["PXSOM_RCCL_LIBRARY"] = lib_path
+    import time
+    import torch as th
+    from ark_analysis_amd import som_device
+    th.cuda.set_device(0)
+    if rank == 0:
+        uid = som_device.RankComm.unique_id()
+        with open(uid_path + ".tmp", "wb") as f:
+            f.write(uid)
+        os.rename(uid_path + ".tmp", uid_path)
+    else:
+        while not os.path.exists(uid_path):
+            time.sleep(0.02)
+        uid = open(uid_path, "rb").read()
+    comm = som_device.RankComm(uid, world, rank)
+    xd, yd, c, dt = shape
+    rs = np.random.RandomState(100 + rank)
+    centers = np.random.RandomState(7).rand(16, c)
+    x_host = np.maximum(centers[rs.randint(0, 16, n_local[rank])] + 0.05 * rs.randn(n_local[rank], c), 0.0)
+    x = th.from_numpy(x_host).to(dt).cuda()
+    w0 = th.from_numpy(np.random.RandomState(3).rand(xd * yd, c)).cuda()
+    total = steps * passes
+    st = som_device.BatchTrainState(x.shape[0], c, xd, yd, steps, x.device)
+    st.wbuf[0].copy_(w0)
+    som_device.batch_train_steps(x, st, 0, total, total, (0.05, 0.01), (3.0, 1.0), comm=comm)
+    w = th.empty_like(w0)
+    som_device.batch_train_finish(st, total, total, (0.05, 0.01), (3.0, 1.0), w)
+    th.cuda.synchronize()
+    np.savez(out_path % rank, w=w.cpu().numpy(), x=x.cpu().to(th.float64).numpy(), w0=w0.cpu().numpy())
+    comm.close()
+
+
+@pytest.mark.parametrize("shape", [(10, 10, 22, torch.float32), (20, 20, 40, torch.float16), (7, 5, 9, torch.float64)])
+def test_two_ranks_run_the_sharded_step_loop(oracle, tmp_path, shape):
+    import torch.multiprocessing as mp
+    lib_path = _mock_library(tmp_path)
+    steps, passes = 8, 2
+    n_local = (4000, 2808)                       # unequal shards: the ranks' mini-batches differ in size
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_sharded_worker, args=(2, lib_path, str(tmp_path / "uid"), out, shape, n_local, steps, passes), nprocs=2,
+             join=True)
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    np.testing.assert_array_equal(r0["w"], r1["w"])          # identical codebooks without a second exchange
+    # single-process equivalent: global mini-batch t = union of the ranks' local mini-batches t
+    xd, yd, c, _ = shape
+    rows, sizes = [], []
+    for t in range(steps):
+        part = np.concatenate([r0["x"][t::steps], r1["x"][t::steps]])
+        rows.append(part)
+        sizes.append(len(part))
+    # orc_som_batch takes strided mini-batches of ONE matrix: interleave so that global row i % steps selects batch t
+    longest = max(sizes)
+    inter = np.full((longest * steps, c), np.nan)
+    for t in range(steps):
+        inter[t::steps][:sizes[t]] = rows[t]
+    keep = ~np.isnan(inter).any(axis=1)
+    if not keep.all():
+        # unequal batch sizes cannot be laid out as one strided matrix: replay the rule step by step instead
+        w = r0["w0"].copy()
+        total = steps * passes
+        for g in range(total):
+            part = rows[g % steps]
+            lab, _ = oracle.map_data_to_nodes(w, part)
+            s, cnt = oracle.cluster_sums(part, lab, xd * yd)
+            thr = 3.0 - (3.0 - 1.0) * g / total
+            w = oracle.batch_update(w, xd, yd, s, cnt, 0.5 if thr < 1.0 else thr, 0.05 - (0.05 - 0.01) * g / total)
+        want = w
+    else:
+        want = oracle.som_batch(inter, r0["w0"], xd, yd, passes, (0.05, 0.01), (3.0, 1.0), steps)
+    np.testing.assert_allclose(r0["w"], want, rtol=1e-9, atol=1e-300)
