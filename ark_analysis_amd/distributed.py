@@ -143,7 +143,8 @@ def native_exchange(group=None):
     if key in _native_comms:
         return _native_comms[key]
     comm = None
-    if (dist.get_backend(group) == "nccl" and os.environ.get("PXSOM_NATIVE_EXCHANGE", "1") != "0"):
+    wanted = os.environ.get("PXSOM_NATIVE_EXCHANGE", "1")     # "0": never; "force": on any backend (tests: gloo group
+    if wanted != "0" and (dist.get_backend(group) == "nccl" or wanted == "force"):   # + a stand-in collective library)
         from . import som_device
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         uid, err = None, None

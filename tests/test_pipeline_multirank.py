@@ -45,6 +45,8 @@ def _worker(rank, world, port, td, mode, out_path, fovs=None, kernels="oracle"):
         import torch
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", rank=rank, world_size=world)
+        if kernels.startswith("hip+"):     # the in-library exchange over a stand-in collective library
+            os.environ.update(PXSOM_RCCL_LIBRARY=kernels[4:], PXSOM_NATIVE_EXCHANGE="force")
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         obj = pixel_som_clustering.train_pixel_som(fovs, CHANS, td, num_passes=1, seed=42, train_mode=mode,
@@ -53,7 +55,10 @@ def _worker(rank, world, port, td, mode, out_path, fovs=None, kernels="oracle"):
         pixel_som_clustering.cluster_pixels(fovs, td, obj)
         pixel_som_clustering.generate_som_avg_files(fovs, CHANS, td, obj, data_dir="pixel_mat_data")
     assert dist.get_world_size() == world
+    from ark_analysis_amd import distributed as _d
+    in_library = any(c is not None for c in _d._native_comms.values())
     np.savez(out_path % rank, weights=obj.weights.values, n_train=n_train, stdout=np.array(buf.getvalue()),
+             in_library=in_library,
              seen=np.array(sorted(int(v) for v in obj.som_clusters_seen), dtype=np.int64),
              file_weights=read_dataframe(os.path.join(td, "pixel_som_weights.feather")).values)
     dist.barrier()
@@ -165,10 +170,16 @@ def test_more_ranks_than_fovs(oracle, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["batch", "online"])
+@pytest.mark.parametrize("mode", ["batch", "online", "batch, exchange inside the library"])
 def test_two_rank_pipeline_on_the_hip_path(oracle, tmp_path, mode):
     """The same three pipeline functions on two ranks with the real kernels (both ranks on device 0, gloo group):
-    Arrow labelling path, recycled host blocks, totals cache, rank-sharded files -- against the oracle."""
+    Arrow labelling path, recycled host blocks, totals cache, rank-sharded files -- against the oracle.  Third
+    variant: train_pixel_som -> BatchSOMTrainer -> distributed.native_exchange -> pxsom_batch_train_steps_sharded, the
+    collective library replaced by tests/mock_rccl (RCCL does not put two ranks on one GPU)."""
+    kernels = "hip"
+    if mode.endswith("library"):
+        from tests.test_gpu_exchange import _mock_library
+        kernels, mode = "hip+" + _mock_library(tmp_path), "batch"
     from ark_analysis_amd.flowsom import default_radius_range
     from ark_analysis_amd.phenotyping.cluster_helpers import read_dataframe
     g = np.load(os.path.join(GOLD, "g7_pixel_pipeline.npz"))
@@ -176,9 +187,10 @@ def test_two_rank_pipeline_on_the_hip_path(oracle, tmp_path, mode):
     os.mkdir(td)
     _build(td, g)
     out = str(tmp_path / "rank%d.npz")
-    mp.spawn(_worker, args=(2, _free_port(), td, mode, out, None, "hip"), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), td, mode, out, None, kernels), nprocs=2, join=True)
     r0, r1 = np.load(out % 0), np.load(out % 1)
     np.testing.assert_array_equal(r0["weights"], r1["weights"])
+    assert bool(r0["in_library"]) == bool(r1["in_library"]) == kernels.startswith("hip+")   # (no silent fallback)
     w = r0["weights"]
     if mode == "online":
         np.testing.assert_array_equal(w, g["weights"])               # the reference-order run: bit-equal
