@@ -247,6 +247,31 @@ def test_fuzz_preprocessing(oracle):
         got_l = sd.relabel(torch.from_numpy(b).to(dev), torch.from_numpy(lut).to(dev), fill=-7).cpu().numpy()
         inside = (b >= 0) & (b < nb)
         assert np.array_equal(got_l, np.where(inside, lut[np.clip(b, 0, nb - 1)], -7)), tag + " relabel"
+        # float32 TIFF-side statistics: numpy's binary32 quantile and row sum of img / norm
+        planes = img.astype(np.float32)
+        q = float(rs.choice([0.05, 0.5, 0.99, 0.999]))
+        got_q32 = sd.quantile_f32(torch.from_numpy(np.ascontiguousarray(planes.reshape(-1, c))).to(dev), q, keep_mode=1).cpu().numpy()
+        for j in range(c):
+            pos = planes[:, :, j][planes[:, :, j] > 0]
+            if pos.size == 0:
+                assert np.isnan(got_q32[j]), tag + " empty float32 quantile"
+            else:
+                assert got_q32[j] == np.quantile(pos, q), tag + " float32 quantile of channel %d" % j
+        norm32 = rs.uniform(0.5, 3.0, size=c).astype(np.float32)
+        got_rs = sd.scaled_rowsum_f32(torch.from_numpy(np.ascontiguousarray(planes.reshape(-1, c))).to(dev),
+                                      torch.from_numpy(norm32).to(dev)).cpu().numpy()
+        assert np.array_equal(got_rs.reshape(h, w), np.sum(planes / norm32.reshape([1, 1, c]), axis=-1)), tag + " scaled row sum"
+        # cluster-id mask: relabel + scatter, the last row wins for a pixel listed twice
+        m = int(rs.randint(1, h * w + 1))
+        pos = rs.randint(0, h * w, size=m)
+        lab = rs.randint(0, nb, size=m)
+        lut16 = rs.randint(-30000, 30000, size=nb).astype(np.int32)
+        mask, status = sd.cluster_mask(torch.from_numpy((pos // w).astype(np.int64)).to(dev),
+                                       torch.from_numpy((pos % w).astype(np.int64)).to(dev),
+                                       torch.from_numpy(lab.astype(np.int64)).to(dev), torch.from_numpy(lut16).to(dev), h, w)
+        want_mask = np.zeros(h * w, dtype=np.int16)
+        want_mask[pos] = lut16[lab].astype(np.int16)
+        assert status == 0 and np.array_equal(mask.cpu().numpy().ravel(), want_mask), tag + " cluster mask"
 
 
 def test_fuzz_arrow_labelling_path(tmp_path):
