@@ -57,9 +57,18 @@ __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_kernel(
     // running maximum is tracked beside it (2 VALU ops per block and tile).  With the whole (b, r) index packed,
     // K = 400 replaced 7 mantissa bits and the packing term was 60 % of the tolerance: 2.5x more rows listed.
     constexpr unsigned idx_mask = 3u;
-    const float scale = hdr->scale, wn_max = hdr->wn_max, tol_rel = hdr->tol_rel,
-                tol_abs = hdr->tol_abs, x_limit = hdr->x_limit;
+    const float scale = hdr->scale, wn_max = hdr->wn_max, tol_abs = hdr->tol_abs, x_limit = hdr->x_limit;
+    float tol_rel = hdr->tol_rel;
     const bool force_exact = hdr->force_exact != 0;
+    // binary16 rows: x * scale (a power of two >= 1) IS a binary16 number, so the low part of the split is exactly
+    // zero: the Wh*Xl MFMA of every chunk and the conversions that feed it are dropped (XLO = false below), and with
+    // them two terms of the rigorous bound -- C of the 3C products of the fp32 accumulation and the row's share of the
+    // split residual (2^-19 covers Xl*Wl and the rounding of both low parts; only the codebook's, 2^-21 with the same
+    // factor-of-two margin, remains): E shrinks from (2^-21 + (3C+2) 2^-24 + 2^-19 + 2^-23) to
+    // (2^-21 + (2C+2) 2^-24 + 2^-21 + 2^-23) times the same norms, ~40 % at C = 40, and with it the rows listed.
+    // Only a codebook whose largest entry exceeds 128 makes scale < 1, where tiny x could lose bits: the full split.
+    const bool lo_needed = sizeof(T) != 2 || scale < 1.f;
+    if (!lo_needed) tol_rel -= 2.5f * ((float)c * 0x1p-24f + (0x1p-19f - 0x1p-21f));
 
     const int lane = threadIdx.x & 63;
     const int pix = lane & 15, q = lane >> 4;
@@ -203,10 +212,6 @@ __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_kernel(
             for (int t = 0; t < kTilesPerIter; t++) load_tile(g, t, raw[t]);
         }
     }
-    // binary16 rows: x * scale (a power of two >= 1) IS a binary16 number, so the low part of the split is exactly
-    // zero: the Wh*Xl MFMA of every chunk and the conversions that feed it are dropped (XLO = false).  Only a
-    // codebook whose largest entry exceeds 128 makes scale < 1, where tiny x could lose bits: then the full split runs.
-    const bool lo_needed = sizeof(T) != 2 || scale < 1.f;
     auto group = [&](auto xlo_tag) {
         constexpr bool XLO = decltype(xlo_tag)::value;
         half8 bh[PREFETCH ? kTilesPerIter : TP][NCH], bl[PREFETCH ? kTilesPerIter : TP][NCH];

@@ -53,6 +53,7 @@ def _case(rs, max_work=6e7, wild=False):
     n = int(rs.choice([1, 2, 63, 64, 65, 127, 129, 1000])) if rs.rand() < 0.25 else int(rs.randint(1, n_max + 1))
     n = min(n, n_max)
     dtype = str(rs.choice(["f32", "f32", "f64", "f16"]))
+    dtype = os.environ.get("PXSOM_FUZZ_DTYPE", dtype)              # (pin the storage type of a sweep)
     kind = str(rs.choice(["mixture", "blob", "quantised", "sparse", "range"] + (["wild"] if wild else [])))
     host = _rows(rs, n, c, kind)
     pad = int(rs.choice([0, 0, 1, 2, 7]))
