@@ -130,6 +130,26 @@ def make_rows(cfg, n_units, rank, dev):
     return x
 
 
+def select_launch_counters(rows, counters):
+    """From one pass's counter rows of a kernel ({"Dispatch_Id", "Counter_Name", "Counter_Value"} dicts): the counters
+    of THE launch over all rows = the dispatches with the largest value of the pass's leading counter, averaged over
+    the timed repeats (everything within 10 % of the largest).  The training steps of the bigger configs launch the
+    same kernel with the same capped grid: the grid size does not tell them apart, the counters do."""
+    by_dispatch = {}
+    for r in rows:
+        d = by_dispatch.setdefault(r.get("Dispatch_Id"), {})
+        d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    lead = counters[-1] if "GRBM_GUI_ACTIVE" in counters else counters[0]
+    top = max((d.get(lead, 0.0) for d in by_dispatch.values()), default=0.0)
+    chosen = [d for d in by_dispatch.values() if d.get(lead, 0.0) >= 0.9 * top > 0.0]
+    out = {}
+    for name in counters:
+        vals = [d[name] for d in chosen if name in d]
+        if vals:
+            out[name] = sum(vals) / len(vals)
+    return out
+
+
 def pmc_passes(argv_inner, kernel_substr="bmu_filter"):
     """rocprofv3 counter passes over a short run of this script (its own processes; kernel-trace + pmc only).
     Returns {"FETCH_SIZE": v, ...} = per-dispatch means for the biggest launch of the filter kernel, or {}."""
@@ -153,20 +173,7 @@ def pmc_passes(argv_inner, kernel_substr="bmu_filter"):
                 rows += [r for r in csv.DictReader(open(f)) if kernel_substr in r["Kernel_Name"]]
             if not rows:
                 continue
-            # the launch over all rows = the dispatch with the largest value of the pass's leading counter (the
-            # training steps of the bigger configs launch the same kernel with the same capped grid: the grid size
-            # does not tell them apart); dispatches within 10 % of it (the timed repeats) are averaged
-            by_dispatch = {}
-            for r in rows:
-                d = by_dispatch.setdefault(r.get("Dispatch_Id"), {})
-                d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-            lead = counters[-1] if "GRBM_GUI_ACTIVE" in counters else counters[0]
-            top = max((d.get(lead, 0.0) for d in by_dispatch.values()), default=0.0)
-            chosen = [d for d in by_dispatch.values() if d.get(lead, 0.0) >= 0.9 * top > 0.0]
-            for name in counters:
-                vals = [d[name] for d in chosen if name in d]
-                if vals:
-                    out[name] = sum(vals) / len(vals)
+            out.update(select_launch_counters(rows, counters))
     return out
 
 

@@ -166,3 +166,26 @@ def test_bench_refuses_more_gpus_than_the_box_has():
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0
     assert "--gpus 2" in r.stderr and "device" in r.stderr
+
+
+def test_bench_picks_the_launch_over_all_rows_from_counter_rows():
+    """bench.py's PMC post-processing: training-step launches of the same kernel (same capped grid, small counters)
+    must not dilute the figures of the launch over all rows; repeats of that launch are averaged."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pxsom_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rows = []
+    for did in range(64):                                   # 64 training-step launches
+        rows.append({"Dispatch_Id": str(did), "Counter_Name": "FETCH_SIZE", "Counter_Value": "1500.5"})
+    for did, v in ((100, 450000.0), (101, 451000.0)):       # two timed launches over all rows, split in two rows each
+        rows.append({"Dispatch_Id": str(did), "Counter_Name": "FETCH_SIZE", "Counter_Value": str(v / 2)})
+        rows.append({"Dispatch_Id": str(did), "Counter_Name": "FETCH_SIZE", "Counter_Value": str(v / 2)})
+    assert bench.select_launch_counters(rows, ["FETCH_SIZE"]) == {"FETCH_SIZE": 450500.0}
+    multi = [{"Dispatch_Id": "1", "Counter_Name": "GRBM_GUI_ACTIVE", "Counter_Value": "10"},
+             {"Dispatch_Id": "1", "Counter_Name": "SQ_INSTS_MFMA", "Counter_Value": "3"},
+             {"Dispatch_Id": "2", "Counter_Name": "GRBM_GUI_ACTIVE", "Counter_Value": "4000"},
+             {"Dispatch_Id": "2", "Counter_Name": "SQ_INSTS_MFMA", "Counter_Value": "900"}]
+    assert bench.select_launch_counters(multi, ["SQ_INSTS_MFMA", "GRBM_GUI_ACTIVE"]) == {"SQ_INSTS_MFMA": 900.0,
+                                                                                       "GRBM_GUI_ACTIVE": 4000.0}
+    assert bench.select_launch_counters([], ["FETCH_SIZE"]) == {}
