@@ -3,6 +3,7 @@
 a K-row reduction of the cell table, thousands of rows: stays on the host) and ``create_c2pc_data``
 (:63-192; the cell x pixel-cluster count matrix that feeds the cell SOM -- its counting step is the device
 histogram pxsom_pair_histogram)."""
+import os
 import warnings
 
 import numpy as np
@@ -10,7 +11,7 @@ import pandas as pd
 
 from .. import flowsom
 from ..fov_tables import FovTableDir, unify_label_column
-from ..host_utils import verify_in_list
+from ..host_utils import validate_paths, verify_in_list
 
 
 def compute_cell_som_cluster_cols_avg(cell_cluster_data, cell_som_cluster_cols,
@@ -107,3 +108,20 @@ def create_c2pc_data(fovs, pixel_data_path, cell_table_path,
         warnings.warn('Pixel clusters %s do not appear in any cells, removed from analysis' % ','.join(empty))
         out, normed = out.drop(columns=empty), normed.drop(columns=empty)
     return out, normed
+
+
+def add_consensus_labels_cell_table(base_dir, cell_table_path, cell_som_input_data):
+    """The cell table with a ``cell_meta_cluster`` column (the renamed meta cluster of every cell; 'Unassigned' for
+    cells the clustering never saw, e.g. too small to own a clustered pixel), saved beside it as
+    ``<cell table>_cell_labels.csv`` (reference: cell_cluster_utils.py:195-247).  ``base_dir`` is unused, as there."""
+    validate_paths([cell_table_path])
+    cells = pd.read_csv(cell_table_path)
+    if "segmentation_label" in cell_som_input_data.columns:      # (renamed in place, as the reference does)
+        cell_som_input_data.rename(columns={"segmentation_label": "label"}, inplace=True)
+    merged = cells.merge(cell_som_input_data, how="left", on=["fov", "label"])
+    if "cell_size_y" in merged.columns.values:                   # both tables carry cell_size: keep the cell table's
+        merged = merged.drop(columns=["cell_size_y"]).rename({"cell_size_x": "cell_size"}, axis=1)
+    merged = merged[list(cells.columns.values) + ["cell_meta_cluster_rename"]]
+    merged = merged.rename({"cell_meta_cluster_rename": "cell_meta_cluster"}, axis=1)
+    merged["cell_meta_cluster"] = merged["cell_meta_cluster"].fillna("Unassigned")
+    merged.to_csv(os.path.splitext(cell_table_path)[0] + "_cell_labels.csv", index=False)

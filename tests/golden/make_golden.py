@@ -526,9 +526,64 @@ def g10_pixel_cluster_mask():
          pixel_meta_cluster=table["pixel_meta_cluster"].values, **out)
 
 
+def g12_cell_meta_clustering():
+    """The reference's cell_meta_clustering + add_consensus_labels_cell_table on a seeded cell table."""
+    from ark.phenotyping import cell_cluster_utils, cell_meta_clustering
+    rs = np.random.RandomState(31)
+    cols = ["pixel_meta_cluster_rename_%s" % c for c in ("a", "b", "c", "d", "e", "f")]
+    n, k = 700, 30
+    data = pd.DataFrame(rs.poisson(3.0, size=(n, 6)) / rs.uniform(50, 500, size=(n, 1)), columns=cols)
+    data.insert(0, "cell_size", rs.randint(50, 500, size=n))
+    data.insert(1, "fov", rs.choice(["fov0", "fov1", "fov2"], size=n))
+    data.insert(2, "segmentation_label", np.arange(1, n + 1))
+    data["cell_som_cluster"] = rs.randint(1, k + 1, size=n)
+    out = {"cell_values": data[cols].values, "cell_size": data["cell_size"].values.astype(np.int64),
+           "fov": data["fov"].values.astype("U8"), "segmentation_label": data["segmentation_label"].values.astype(np.int64),
+           "cell_som_cluster": data["cell_som_cluster"].values.astype(np.int64), "cols": np.array(cols)}
+    with tempfile.TemporaryDirectory() as td:
+        som_avg = cell_cluster_utils.compute_cell_som_cluster_cols_avg(data, cols, "cell_som_cluster", keep_count=True)
+        som_avg.to_csv(os.path.join(td, "som_avg.csv"), index=False)
+        out["som_avg_text"] = np.array(open(os.path.join(td, "som_avg.csv")).read())
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            cc, assigned = cell_meta_clustering.cell_consensus_cluster(td, cols, data.copy(), "som_avg.csv", max_k=6, cap=3, seed=42)
+            cell_meta_clustering.generate_meta_avg_files(td, cc, cols, assigned, "som_avg.csv", "meta_avg.csv")
+        out["stdout_consensus"] = np.array(buf.getvalue())
+        out["mapping"] = cc.mapping.values.astype(np.int64)
+        out["meta_labels"] = assigned["cell_meta_cluster"].values.astype(np.int64)
+        out["assigned_columns"] = np.array(list(assigned.columns))
+        out["meta_avg_text"] = np.array(open(os.path.join(td, "meta_avg.csv")).read())
+        out["som_avg_after_text"] = np.array(open(os.path.join(td, "som_avg.csv")).read())
+        # the user's remapping: meta clusters 5 and 6 merged into 5, everything named
+        remap = cc.mapping.copy()
+        remap["cell_meta_cluster"] = remap["cell_meta_cluster"].replace({6: 5})
+        remap["cell_meta_cluster_rename"] = remap["cell_meta_cluster"].map(lambda m: "type_%d" % m)
+        remap.to_csv(os.path.join(td, "remap.csv"), index=False)
+        out["remap_text"] = np.array(open(os.path.join(td, "remap.csv")).read())
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            remapped = cell_meta_clustering.apply_cell_meta_cluster_remapping(td, assigned.copy(), "remap.csv")
+            cell_meta_clustering.generate_remap_avg_count_files(td, remapped, "remap.csv", cols, "som_avg.csv", "meta_avg.csv")
+        out["stdout_remap"] = np.array(buf.getvalue())
+        out["remapped_meta"] = remapped["cell_meta_cluster"].values.astype(np.int64)
+        out["remapped_names"] = remapped["cell_meta_cluster_rename"].values.astype("U16")
+        out["meta_avg_remap_text"] = np.array(open(os.path.join(td, "meta_avg.csv")).read())
+        out["som_avg_remap_text"] = np.array(open(os.path.join(td, "som_avg.csv")).read())
+        # the cell table: every clustered cell plus 25 cells the clustering never saw
+        table = pd.DataFrame({"cell_size": np.concatenate([data["cell_size"].values, rs.randint(5, 20, size=25)]),
+                              "fov": np.concatenate([data["fov"].values, np.array(["fov1"] * 25)]),
+                              "label": np.concatenate([data["segmentation_label"].values, np.arange(n + 1, n + 26)]),
+                              "marker": rs.rand(n + 25)})
+        table.to_csv(os.path.join(td, "cell_table.csv"), index=False)
+        out["cell_table_text"] = np.array(open(os.path.join(td, "cell_table.csv")).read())
+        cell_cluster_utils.add_consensus_labels_cell_table(td, os.path.join(td, "cell_table.csv"), remapped.copy())
+        out["cell_table_labelled_text"] = np.array(open(os.path.join(td, "cell_table_cell_labels.csv")).read())
+    save("g12_cell_meta_clustering", **out)
+
+
 if __name__ == "__main__":
     ob.build()
     steps = {"g1": g1_normalize, "g2": g2_g5_preprocess, "g3": g3_quantiles, "g4": g4_cluster_avg, "g5": g5_meta_clustering, "g6": g6_som, "g7b": g7b_batch_mode,
-             "g7": g7_end_to_end, "g8": g8_c2pc, "g8s": g8s_c2pc_named, "g9": g9_create_pixel_matrix, "g10": g10_pixel_cluster_mask}
+             "g7": g7_end_to_end, "g8": g8_c2pc, "g8s": g8s_c2pc_named, "g9": g9_create_pixel_matrix, "g10": g10_pixel_cluster_mask, "g12": g12_cell_meta_clustering}
     for name in (sys.argv[1:] or list(steps)):
         steps[name]()
