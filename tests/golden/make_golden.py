@@ -581,9 +581,71 @@ def g12_cell_meta_clustering():
     save("g12_cell_meta_clustering", **out)
 
 
+def g13_weighted_channel():
+    """The reference's weighted_channel_comp (its plotting import stubbed out: ark.analysis.visualize is only used by
+    the heat-map function, which is not exercised) on a seeded cell-count table."""
+    import types
+    pkg, vis = types.ModuleType("ark.analysis"), types.ModuleType("ark.analysis.visualize")
+    pkg.visualize = vis
+    sys.modules.setdefault("ark.analysis", pkg)
+    sys.modules.setdefault("ark.analysis.visualize", vis)
+    from ark.phenotyping import weighted_channel_comp as wcc
+    rs = np.random.RandomState(47)
+    chans = ["chan%d" % i for i in range(5)]
+    names = ["B", "CD4_T", "CD8_T", "myeloid", "stroma", "tumor", "unassigned"]
+    n = 500
+    counts = pd.DataFrame(rs.poisson(4.0, size=(n, len(names))).astype(np.float64),
+                          columns=["pixel_meta_cluster_rename_%s" % s_ for s_ in names])
+    counts.insert(0, "cell_size", rs.randint(50, 400, size=n))
+    counts.insert(1, "fov", rs.choice(["fov0", "fov1", "fov2"], size=n))
+    counts.insert(2, "segmentation_label", np.arange(1, n + 1))
+    pix_avg = pd.DataFrame(rs.rand(len(names), len(chans)), columns=chans)
+    pix_avg.insert(0, "pixel_meta_cluster_rename", rs.permutation(names))
+    clusters = pd.DataFrame({"fov": counts["fov"].values, "label": counts["segmentation_label"].values,
+                             "cell_som_cluster": rs.randint(1, 21, size=n)})
+    mapping = pd.DataFrame({"cell_som_cluster": np.arange(1, 21), "cell_meta_cluster": rs.randint(1, 6, size=20)})
+    clusters["cell_meta_cluster"] = clusters["cell_som_cluster"].map(dict(mapping.values))
+    out = {"chans": np.array(chans), "names": np.array(names), "counts": counts.iloc[:, 3:].values,
+           "cell_size": counts["cell_size"].values.astype(np.int64), "fov": counts["fov"].values.astype("U8"),
+           "label": counts["segmentation_label"].values.astype(np.int64), "pix_avg": pix_avg[chans].values,
+           "pix_avg_ids": pix_avg["pixel_meta_cluster_rename"].values.astype("U16"),
+           "cell_som_cluster": clusters["cell_som_cluster"].values.astype(np.int64), "mapping": mapping.values.astype(np.int64)}
+    weighted = wcc.compute_p2c_weighted_channel_avg(pix_avg.copy(), chans, counts.copy())
+    out["weighted"] = weighted[chans].values
+    out["weighted_columns"] = np.array(list(weighted.columns))
+    sub = wcc.compute_p2c_weighted_channel_avg(pix_avg.copy(), chans[:3], counts.copy(), fovs=["fov1", "fov2"])
+    out["weighted_sub"] = sub[chans[:3]].values
+    out["weighted_sub_label"] = sub["label"].values.astype(np.int64)
+    with tempfile.TemporaryDirectory() as td:
+        feather.write_dataframe(weighted, os.path.join(td, "weighted_cell_channel.feather"), compression="uncompressed")
+        cc = types.SimpleNamespace(mapping=mapping)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            wcc.generate_wc_avg_files(["fov0", "fov1", "fov2"], chans, td, cc, clusters.copy())
+        out["stdout_wc"] = np.array(buf.getvalue())
+        out["som_wc_text"] = np.array(open(os.path.join(td, "cell_som_cluster_channel_avg.csv")).read())
+        out["meta_wc_text"] = np.array(open(os.path.join(td, "cell_meta_cluster_channel_avg.csv")).read())
+        remap = mapping.copy()
+        remap["cell_meta_cluster"] = remap["cell_meta_cluster"].replace({5: 4})
+        remap["cell_meta_cluster_rename"] = remap["cell_meta_cluster"].map(lambda m_: "type_%d" % m_)
+        remap.to_csv(os.path.join(td, "remap.csv"), index=False)
+        out["remap_text"] = np.array(open(os.path.join(td, "remap.csv")).read())
+        remapped = clusters.copy()
+        remapped["cell_meta_cluster"] = remapped["cell_som_cluster"].map(dict(remap[["cell_som_cluster", "cell_meta_cluster"]].values))
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            wcc.generate_remap_avg_wc_files(["fov0", "fov1", "fov2"], chans, td, remapped, "remap.csv",
+                                            "weighted_cell_channel.feather", "cell_som_cluster_channel_avg.csv",
+                                            "cell_meta_cluster_channel_avg.csv")
+        out["stdout_remap"] = np.array(buf.getvalue())
+        out["som_wc_remap_text"] = np.array(open(os.path.join(td, "cell_som_cluster_channel_avg.csv")).read())
+        out["meta_wc_remap_text"] = np.array(open(os.path.join(td, "cell_meta_cluster_channel_avg.csv")).read())
+    save("g13_weighted_channel", **out)
+
+
 if __name__ == "__main__":
     ob.build()
     steps = {"g1": g1_normalize, "g2": g2_g5_preprocess, "g3": g3_quantiles, "g4": g4_cluster_avg, "g5": g5_meta_clustering, "g6": g6_som, "g7b": g7b_batch_mode,
-             "g7": g7_end_to_end, "g8": g8_c2pc, "g8s": g8s_c2pc_named, "g9": g9_create_pixel_matrix, "g10": g10_pixel_cluster_mask, "g12": g12_cell_meta_clustering}
+             "g7": g7_end_to_end, "g8": g8_c2pc, "g8s": g8s_c2pc_named, "g9": g9_create_pixel_matrix, "g10": g10_pixel_cluster_mask, "g12": g12_cell_meta_clustering, "g13": g13_weighted_channel}
     for name in (sys.argv[1:] or list(steps)):
         steps[name]()
