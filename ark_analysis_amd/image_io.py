@@ -39,7 +39,9 @@ def _channel_file(folder: str, channel: str) -> str:
 # rawmode -> (dtype in the file, dtype Pillow's array would have)
 _RAW_MODES = {"F;32F": ("<f4", np.float32), "F;32BF": (">f4", np.float32), "I;32S": ("<i4", np.int32),
               "I;32BS": (">i4", np.int32), "I;16": ("<u2", np.uint16), "I;16B": (">u2", np.uint16),
-              "I;16S": ("<i2", np.int32), "I;16BS": (">i2", np.int32), "L": ("u1", np.uint8)}
+              "I;16S": ("<i2", np.int16), "I;16BS": (">i2", np.int16), "L": ("u1", np.uint8)}
+# (signed 16-bit stays int16, as the tifffile-based reader of the reference returns it -- cluster masks are saved
+# that way; Pillow's own decoder would widen it to int32)
 
 
 def _raw_layout(im):
@@ -175,3 +177,34 @@ def write_channel(path, image: np.ndarray) -> None:
     """Counterpart used by tests and the synthetic-cohort script."""
     from PIL import Image
     Image.fromarray(np.ascontiguousarray(image)).save(path, format="TIFF")
+
+
+_SAMPLE_FORMATS = {"u": 1, "i": 2, "f": 3}
+
+
+def write_image(path, image: np.ndarray) -> None:
+    """A 2-D uint8 / uint16 / int16 / int32 / float32 array as a baseline TIFF in its own dtype: little-endian,
+    uncompressed, one strip, with the SampleFormat tag -- what the cluster masks are saved as (int16 stays int16,
+    which Pillow cannot write).  :func:`read_image` reads it back unchanged."""
+    import struct
+    image = np.asarray(image)
+    if image.ndim != 2 or image.dtype.name not in ("uint8", "uint16", "int16", "int32", "float32"):
+        raise ValueError("write_image takes a 2-D uint8, uint16, int16, int32 or float32 array, got %s %s"
+                         % (image.dtype, image.shape))
+    data = np.ascontiguousarray(image, dtype=image.dtype.newbyteorder("<"))
+    if data.nbytes >= 1 << 32:
+        raise ValueError("image too large for a classic TIFF")
+    height, width = data.shape
+    short, long_ = 3, 4
+    tags = [(256, long_, width), (257, long_, height), (258, short, data.dtype.itemsize * 8), (259, short, 1),
+            (262, short, 1), (273, long_, 0), (277, short, 1), (278, long_, height), (279, long_, data.nbytes),
+            (339, short, _SAMPLE_FORMATS[data.dtype.kind])]
+    first_byte = 8 + 2 + 12 * len(tags) + 4
+    directory = struct.pack("<H", len(tags))
+    for tag, kind, value in tags:
+        value = first_byte if tag == 273 else value
+        directory += struct.pack("<HHI", tag, kind, 1) + (struct.pack("<HH", value, 0) if kind == short
+                                                            else struct.pack("<I", value))
+    with open(path, "wb") as f:
+        f.write(b"II*\0" + struct.pack("<I", 8) + directory + struct.pack("<I", 0))
+        f.write(memoryview(data).cast("B"))

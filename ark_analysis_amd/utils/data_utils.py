@@ -1,10 +1,13 @@
-"""The one function of ``ark.utils.data_utils`` that sits directly behind the pixel labels
+"""The functions of ``ark.utils.data_utils`` that sit directly behind the pixel labels
 (/root/reference/src/ark/utils/data_utils.py:476-555; SURVEY.md section 8 f, rank 4): a FOV's pixel table with
 SOM / meta cluster labels -> an ``[H, W]`` int16 image of cluster ids.  The relabel (label -> cluster_id) and
-the scatter run on the device; path checks, the mapping table and the table read stay on the host."""
+the scatter run on the device; path checks, the mapping table and the table read stay on the host.  Around it, the
+cohort loop that saves one mask per FOV (``generate_and_save_pixel_cluster_masks``, :558-635) and ``save_fov_mask``
+(:32-68)."""
 import os
 
 import numpy as np
+import pandas as pd
 
 from .. import flowsom, image_io
 from ..fov_tables import read_table
@@ -37,3 +40,30 @@ def generate_pixel_cluster_mask(fov, base_dir, tiff_dir, chan_file_path,
     id_mapping = dict(zip(pairs[pixel_cluster_col], pairs['cluster_id']))
     return flowsom.pixel_cluster_mask(column('row_index'), column('column_index'), labels, id_mapping,
                                       (sample.shape[0], sample.shape[1]))
+
+
+def save_fov_mask(fov, data_dir, mask_data, sub_dir=None, name_suffix=''):
+    """Saves a cluster mask as ``<data_dir>/[<sub_dir>/]<fov><name_suffix>.tiff``."""
+    validate_paths(data_dir)
+    folder = os.path.join(data_dir, sub_dir or '')
+    os.makedirs(folder, exist_ok=True)
+    image_io.write_image(os.path.join(folder, fov + name_suffix + '.tiff'), np.asarray(mask_data))
+
+
+def generate_and_save_pixel_cluster_masks(fovs, base_dir, save_dir, tiff_dir, chan_file, pixel_data_dir,
+                                          cluster_id_to_name_path, pixel_cluster_col='pixel_meta_cluster',
+                                          sub_dir=None, name_suffix=''):
+    """One cluster-id mask per FOV, saved under ``save_dir``.  The cluster -> name table at
+    ``cluster_id_to_name_path`` (the remapping GUI's output) gets a ``cluster_id`` column -- 1, 2, ... over the
+    distinct ``pixel_cluster_col`` values in ascending order -- and is rewritten in place; those ids are what the
+    masks hold.  ``chan_file``: a channel image inside every FOV folder, for the mask's size."""
+    names = pd.read_csv(cluster_id_to_name_path)
+    ids = names[[pixel_cluster_col]].drop_duplicates().sort_values(by=[pixel_cluster_col])
+    ids["cluster_id"] = list(range(1, len(ids) + 1))
+    mapping = names.drop(columns="cluster_id", errors="ignore").merge(ids, on=[pixel_cluster_col], how="left")
+    mapping.to_csv(cluster_id_to_name_path, index=False)
+    for fov in fovs:
+        mask = generate_pixel_cluster_mask(fov=fov, base_dir=base_dir, tiff_dir=tiff_dir,
+                                           chan_file_path=os.path.join(fov, chan_file), pixel_data_dir=pixel_data_dir,
+                                           cluster_mapping=mapping, pixel_cluster_col=pixel_cluster_col)
+        save_fov_mask(fov, data_dir=save_dir, mask_data=mask, sub_dir=sub_dir, name_suffix=name_suffix)

@@ -500,7 +500,7 @@ def g10_pixel_cluster_mask():
     h, w, k = 37, 41, 12
     keep = np.sort(rs.choice(h * w, size=1100, replace=False))
     som = rs.randint(1, k + 1, size=keep.size)
-    som_to_meta = rs.randint(1, 5, size=k + 1)
+    som_to_meta = rs.choice([2, 5, 7, 11], size=k + 1)              # ids 1..4 differ from the labels
     meta_to_id = {1: 7, 2: 300, 3: 2, 4: 41}
     table = pd.DataFrame({"chan0": rs.rand(keep.size), "fov": "fov0", "row_index": keep // w, "column_index": keep % w,
                           "pixel_som_cluster": som, "pixel_meta_cluster": som_to_meta[som].astype(np.float64)})
@@ -524,6 +524,45 @@ def g10_pixel_cluster_mask():
     save("g10_pixel_cluster_mask", shape=np.array([h, w]), row_index=table["row_index"].values,
          column_index=table["column_index"].values, pixel_som_cluster=table["pixel_som_cluster"].values,
          pixel_meta_cluster=table["pixel_meta_cluster"].values, **out)
+
+
+def g14_saved_pixel_masks():
+    """The reference's generate_and_save_pixel_cluster_masks (utils/data_utils.py:558-635) on two small FOVs: the
+    rewritten cluster-name table and the saved masks."""
+    from ark.utils import data_utils
+    from PIL import Image
+    import tqdm
+    data_utils.tqdm = tqdm.tqdm                                  # the notebook bar needs ipywidgets (absent here)
+    rs = np.random.RandomState(14)
+    h, w, k = 29, 33, 10
+    som_to_meta = rs.choice([2, 5, 7, 11], size=k + 1)              # ids 1..4 differ from the labels
+    names = pd.DataFrame({"pixel_som_cluster": np.arange(1, k + 1), "pixel_meta_cluster": som_to_meta[1:]})
+    names["pixel_meta_cluster_rename"] = ["type_%d" % m for m in names["pixel_meta_cluster"]]
+    names["cluster_id"] = 99                                     # a stale column the function must replace
+    out = {"shape": np.array([h, w]), "names_text": np.array(names.to_csv(index=False))}
+    with tempfile.TemporaryDirectory() as td:
+        os.makedirs(os.path.join(td, "pixel_mat_data"))
+        os.makedirs(os.path.join(td, "masks"))
+        names.to_csv(os.path.join(td, "names.csv"), index=False)
+        for fov in ("fov0", "fov1"):
+            os.makedirs(os.path.join(td, "tiffs", fov))
+            Image.fromarray(rs.rand(h, w).astype(np.float32)).save(os.path.join(td, "tiffs", fov, "chan0.tiff"))
+            keep = np.sort(rs.choice(h * w, size=700, replace=False))
+            som = rs.randint(1, k + 1, size=keep.size)
+            table = pd.DataFrame({"chan0": rs.rand(keep.size), "fov": fov, "row_index": keep // w, "column_index": keep % w,
+                                  "pixel_som_cluster": som, "pixel_meta_cluster": som_to_meta[som]})
+            feather.write_dataframe(table, os.path.join(td, "pixel_mat_data", fov + ".feather"))
+            out["row_index_" + fov], out["column_index_" + fov] = table["row_index"].values, table["column_index"].values
+            out["som_" + fov], out["meta_" + fov] = table["pixel_som_cluster"].values, table["pixel_meta_cluster"].values
+        data_utils.generate_and_save_pixel_cluster_masks(["fov0", "fov1"], td, os.path.join(td, "masks"), os.path.join(td, "tiffs"),
+                                                         "chan0.tiff", "pixel_mat_data", os.path.join(td, "names.csv"),
+                                                         pixel_cluster_col="pixel_meta_cluster", sub_dir="pixel_masks",
+                                                         name_suffix="_pixel_mask")
+        out["names_after_text"] = np.array(open(os.path.join(td, "names.csv")).read())
+        for fov in ("fov0", "fov1"):
+            with Image.open(os.path.join(td, "masks", "pixel_masks", fov + "_pixel_mask.tiff")) as im:
+                out["mask_" + fov] = np.array(im)
+    save("g14_saved_pixel_masks", **out)
 
 
 def g12_cell_meta_clustering():
@@ -646,6 +685,6 @@ def g13_weighted_channel():
 if __name__ == "__main__":
     ob.build()
     steps = {"g1": g1_normalize, "g2": g2_g5_preprocess, "g3": g3_quantiles, "g4": g4_cluster_avg, "g5": g5_meta_clustering, "g6": g6_som, "g7b": g7b_batch_mode,
-             "g7": g7_end_to_end, "g8": g8_c2pc, "g8s": g8s_c2pc_named, "g9": g9_create_pixel_matrix, "g10": g10_pixel_cluster_mask, "g12": g12_cell_meta_clustering, "g13": g13_weighted_channel}
+             "g7": g7_end_to_end, "g8": g8_c2pc, "g8s": g8s_c2pc_named, "g9": g9_create_pixel_matrix, "g10": g10_pixel_cluster_mask, "g12": g12_cell_meta_clustering, "g13": g13_weighted_channel, "g14": g14_saved_pixel_masks}
     for name in (sys.argv[1:] or list(steps)):
         steps[name]()

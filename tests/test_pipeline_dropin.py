@@ -611,6 +611,59 @@ def test_generate_pixel_cluster_mask_matches_reference_run(som_backend, tmp_path
         data_utils.generate_pixel_cluster_mask(*args, mapping, pixel_cluster_col="pixel_som_cluster")
 
 
+def test_saved_pixel_cluster_masks_match_reference_run(som_backend, tmp_path):
+    """The cohort loop around the mask (reference utils/data_utils.py:558-635) against a run of the reference on
+    the same inputs (tests/golden/g14_saved_pixel_masks.npz): the cluster-name table gets fresh ``cluster_id``s
+    (a stale column replaced) and is rewritten in place, one int16 TIFF per FOV lands under the sub-folder."""
+    import io
+    from ark_analysis_amd import image_io
+    from ark_analysis_amd.utils import data_utils
+    g = np.load(os.path.join(GOLD, "g14_saved_pixel_masks.npz"))
+    td = str(tmp_path)
+    h, w = (int(v) for v in g["shape"])
+    os.makedirs(os.path.join(td, "pixel_mat_data"))
+    os.makedirs(os.path.join(td, "masks"))
+    with open(os.path.join(td, "names.csv"), "w") as f:
+        f.write(str(g["names_text"][()]))
+    for fov in ("fov0", "fov1"):
+        os.makedirs(os.path.join(td, "tiffs", fov))
+        image_io.write_channel(os.path.join(td, "tiffs", fov, "chan0.tiff"), np.zeros((h, w), dtype=np.float32))
+        table = pd.DataFrame({"chan0": 0.5, "fov": fov, "row_index": g["row_index_" + fov],
+                              "column_index": g["column_index_" + fov], "pixel_som_cluster": g["som_" + fov],
+                              "pixel_meta_cluster": g["meta_" + fov]})
+        write_dataframe(table, os.path.join(td, "pixel_mat_data", fov + ".feather"))
+    data_utils.generate_and_save_pixel_cluster_masks(
+        ["fov0", "fov1"], td, os.path.join(td, "masks"), os.path.join(td, "tiffs"), "chan0.tiff", "pixel_mat_data",
+        os.path.join(td, "names.csv"), pixel_cluster_col="pixel_meta_cluster", sub_dir="pixel_masks",
+        name_suffix="_pixel_mask")
+    got = pd.read_csv(os.path.join(td, "names.csv"))
+    want = pd.read_csv(io.StringIO(str(g["names_after_text"][()])))
+    pd.testing.assert_frame_equal(got, want)
+    for fov in ("fov0", "fov1"):
+        mask = image_io.read_image(os.path.join(td, "masks", "pixel_masks", fov + "_pixel_mask.tiff"))
+        assert mask.dtype == np.int16 and mask.shape == (h, w)
+        np.testing.assert_array_equal(mask, g["mask_" + fov])
+    # without a sub-folder the files go straight into save_dir; a missing save_dir is an error
+    data_utils.save_fov_mask("fovA", os.path.join(td, "masks"), np.arange(6, dtype=np.int16).reshape(2, 3))
+    np.testing.assert_array_equal(image_io.read_image(os.path.join(td, "masks", "fovA.tiff")),
+                                  np.arange(6).reshape(2, 3))
+    with pytest.raises(FileNotFoundError):
+        data_utils.save_fov_mask("fovA", os.path.join(td, "nowhere"), np.zeros((2, 2), dtype=np.int16))
+    # the TIFF writer keeps every dtype it accepts; Pillow agrees on the values
+    from PIL import Image
+    for dtype in (np.uint8, np.uint16, np.int16, np.int32, np.float32):
+        image = (np.random.RandomState(3).randn(9, 4) * 90).astype(dtype)
+        image_io.write_image(os.path.join(td, "rt.tiff"), image)
+        back = image_io.read_image(os.path.join(td, "rt.tiff"))
+        assert back.dtype == image.dtype
+        np.testing.assert_array_equal(back, image)
+        with Image.open(os.path.join(td, "rt.tiff")) as im:
+            np.testing.assert_array_equal(np.array(im), image)
+    for bad in (np.zeros((2, 2, 2), dtype=np.int16), np.zeros((2, 2), dtype=np.float64), np.zeros((2, 2), dtype=bool)):
+        with pytest.raises(ValueError):
+            image_io.write_image(os.path.join(td, "rt.tiff"), bad)
+
+
 def test_fov_table_helpers(tmp_path):
     """Footer-only column listing, natural ordering, prefetcher / writer round trip, damaged files."""
     from ark_analysis_amd.fov_tables import FovTableDir, TablePrefetcher, TableWriter
