@@ -194,6 +194,28 @@ def pair_histogram(a, b, na: int, nb: int) -> np.ndarray:
     return som_device.pair_histogram(ad, bd, int(na), int(nb)).cpu().numpy()
 
 
+class HostStaging:
+    """One reusable host buffer for images on their way to the GPU: page-locked when a GPU is there (the upload
+    then runs at the link's rate instead of through the driver's bounce buffers, ~3 GB/s), and never fresh memory
+    after its first use (writing into fresh pages costs more than the arithmetic that fills them)."""
+
+    def __init__(self):
+        self._block = None
+
+    def array(self, shape, dtype) -> np.ndarray:
+        """A C-contiguous array of ``shape`` / ``dtype`` on the buffer (valid until the next call)."""
+        import torch
+        dtype = np.dtype(dtype)
+        need = int(np.prod(shape)) * dtype.itemsize
+        if self._block is None or self._block.numel() < need:
+            self._block = None
+            try:
+                self._block = torch.empty(need, dtype=torch.uint8, pin_memory=torch.cuda.is_available())
+            except RuntimeError:               # page-locking refused (limits): pageable memory still gets reused
+                self._block = torch.empty(need, dtype=torch.uint8)
+        return self._block[:need].numpy().view(dtype).reshape(shape)
+
+
 def _image_to_device(image, dev, dtype=None):
     """Host image ``[H, W]`` / ``[H, W, C]`` -> contiguous device tensor of the same shape (converted to the
     torch ``dtype`` on the device when given).  A stack whose storage is channel-planar (what
@@ -247,13 +269,15 @@ def total_intensity_quantile_f32(image_hwc, norm, q: float):
     return som_device.quantile_nonzero(sums.reshape(-1, 1), q, keep_mode=2).cpu().numpy()[0]
 
 
-def fov_pixel_rows(img_hwc, sigma: float, thresh: float, nonzero_q=None):
+def fov_pixel_rows(img_hwc, sigma: float, thresh: float, nonzero_q=None, blocks=None):
     """The numeric core of ``create_fov_pixel_data`` (pixie_preprocessing.py:45-75): per-channel Gaussian blur,
     keep pixels whose channel sum exceeds ``thresh`` and that are not all zero, divide the kept pixels by
     their channel sum.  Returns ``(rows [m, C], flat pixel index [m])``; a float32 image keeps the reference's
     float32 arithmetic (rows come back float32), anything else is processed in binary64.
     ``nonzero_q``: also return :func:`nonzero_quantiles` of the rows at that q, taken while they are still
-    in HBM (a third element)."""
+    in HBM (a third element).  ``blocks`` (an ``arrow_assign.HostBlocks``): the rows land in a recycled host block
+    instead of fresh memory (a device-to-host copy into fresh pages runs at the page-fault rate) and a last
+    element ``release()`` hands the block back once the caller is done with the rows."""
     import torch
     from . import _capi, som_device
     dev = _capi.require_gpu()
@@ -265,11 +289,19 @@ def fov_pixel_rows(img_hwc, sigma: float, thresh: float, nonzero_q=None):
     img = _image_to_device(img_hwc, dev, torch.float64)     # the kernels work on binary64 storage
     som_device.gaussian_blur_hwc(img, float(sigma), f32_semantics=f32)
     rows, kept = som_device.rowsum_filter_normalize(img.view(h * w, c), float(thresh), f32_semantics=f32)
-    values = (rows.to(torch.float32) if f32 else rows).cpu().numpy()
+    tail = ()
+    if blocks is None:
+        values = (rows.to(torch.float32) if f32 else rows).cpu().numpy()
+    else:
+        out = rows.to(torch.float32) if f32 else rows
+        block = blocks.take((out.numel() * out.element_size() + 7) // 8)
+        host = block.view(out.dtype)[:out.numel()].view(out.shape)
+        host.copy_(out)
+        values, tail = host.numpy(), (lambda: blocks.give(block),)
     if nonzero_q is None:
-        return values, kept.cpu().numpy()
+        return (values, kept.cpu().numpy()) + tail
     quantiles = som_device.quantile_nonzero(rows, float(nonzero_q), keep_mode=0).cpu().numpy()
-    return values, kept.cpu().numpy(), quantiles
+    return (values, kept.cpu().numpy(), quantiles) + tail
 
 
 def nonzero_quantiles(matrix, q: float) -> np.ndarray:

@@ -247,6 +247,11 @@ class TableWriter:
             if not callable(job) and job[2] is not None:
                 job[2]()     # the table's buffers may be reused from here on (written, or abandoned after a failure)
 
+    @property
+    def failed(self) -> bool:
+        """True once a write has failed (``done`` callbacks still run for the jobs abandoned after it)."""
+        return self._error is not None
+
     def _raise_if_failed(self) -> None:
         if self._error is not None:   # stop the stage at the first failed write, not at close()
             raise self._error

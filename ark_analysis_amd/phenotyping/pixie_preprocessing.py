@@ -12,31 +12,48 @@ import numpy as np
 import pandas as pd
 
 from .. import flowsom, image_io
+from ..arrow_assign import HostBlocks
 from ..fov_tables import FovTableDir, TableWriter, read_dataframe, write_dataframe
 from ..host_utils import natsort_key, validate_paths, verify_in_list
 from . import pixel_cluster_utils
+
+
+def _device_rows(channels, img_data, pixel_thresh_val, blur_factor, nonzero_q=None, blocks=None):
+    """The device half of create_fov_pixel_data: ``(values [n, C], flat pixel numbers of the kept rows, image
+    width, non-zero quantiles or None[, release])`` -- ``release`` with ``blocks``, see flowsom.fov_pixel_rows.  float32 images (what preprocess_fov passes for float32 TIFFs) keep
+    float32 semantics end to end: scipy stores each blur pass as float32, pandas sums and divides the float32
+    frame in binary32."""
+    channels.sort(key=natsort_key)                       # in place, like the reference (:44)
+    extra = {} if nonzero_q is None else {"nonzero_q": nonzero_q}
+    if blocks is not None:
+        extra["blocks"] = blocks
+    got = flowsom.fov_pixel_rows(np.asarray(img_data)[:, :, :len(channels)], blur_factor, pixel_thresh_val, **extra)
+    out = got[0], got[1], img_data.shape[1], (got[2] if nonzero_q is not None else None)
+    return out if blocks is None else out + (got[-1],)
+
+
+def _assemble_tables(fov, channels, values, kept_h, width, seg_labels, subset_proportion, seed=None):
+    """The host half: the reference's DataFrame (channels, fov, row_index, column_index[, label]) and its
+    training sub-sample (global numpy RNG state as the reference, :78; ``seed`` re-seeds it first, the way
+    preprocess_fov does before the call)."""
+    pixel_mat = pd.DataFrame(values, columns=channels)
+    pixel_mat['fov'] = fov
+    pixel_mat['row_index'] = (kept_h // width).astype(np.int64)
+    pixel_mat['column_index'] = (kept_h % width).astype(np.int64)
+    if seg_labels is not None:
+        pixel_mat['label'] = np.asarray(seg_labels).flatten()[kept_h]
+    if seed is not None:
+        np.random.seed(seed)
+    return pixel_mat, pixel_mat.sample(frac=subset_proportion)
 
 
 def _fov_tables(fov, channels, img_data, seg_labels, pixel_thresh_val, blur_factor, subset_proportion,
                 nonzero_q=None):
     """create_fov_pixel_data plus, on request, the non-zero quantile of every channel of the full table at
     ``nonzero_q`` (taken on the device while the rows are there; same numbers as quantiling the table)."""
-    channels.sort(key=natsort_key)                       # in place, like the reference (:44)
-    w = img_data.shape[1]
-    # float32 images (what preprocess_fov passes for float32 TIFFs) keep float32 semantics end to end: scipy
-    # stores each blur pass as float32, pandas sums and divides the float32 frame in binary32
-    got = flowsom.fov_pixel_rows(np.asarray(img_data)[:, :, :len(channels)], blur_factor, pixel_thresh_val,
-                                 **({} if nonzero_q is None else {"nonzero_q": nonzero_q}))
-    values, kept_h = got[0], got[1]
-    pixel_mat = pd.DataFrame(values, columns=channels)
-    pixel_mat['fov'] = fov
-    pixel_mat['row_index'] = (kept_h // w).astype(np.int64)
-    pixel_mat['column_index'] = (kept_h % w).astype(np.int64)
-    if seg_labels is not None:
-        pixel_mat['label'] = np.asarray(seg_labels).flatten()[kept_h]
-    # subset the pixel matrix for training (global numpy RNG state, as the reference: :78)
-    pixel_mat_subset = pixel_mat.sample(frac=subset_proportion)
-    return pixel_mat, pixel_mat_subset, (got[2] if nonzero_q is not None else None)
+    values, kept_h, width, quantiles = _device_rows(channels, img_data, pixel_thresh_val, blur_factor, nonzero_q)
+    full, subset = _assemble_tables(fov, channels, values, kept_h, width, seg_labels, subset_proportion)
+    return full, subset, quantiles
 
 
 def create_fov_pixel_data(fov, channels, img_data, seg_labels, pixel_thresh_val,
@@ -58,6 +75,55 @@ def _read_segmentation(seg_dir, fov, seg_suffix):
     return image_io.read_image(os.path.join(seg_dir, fov + seg_suffix))
 
 
+def _fov_device_half(tiff_dir, seg_dir, seg_suffix, img_sub_folder, is_mibitiff, channels, blur_factor,
+                     pixel_thresh_val, channel_norm_df, fov, stack=None, post_rownorm_q=None, staging=None,
+                     blocks=None):
+    """preprocess_fov up to the rows coming back from the device: ``(values, kept pixel numbers, width,
+    quantiles or None, segmentation labels or None[, release])``.  ``staging``: a ``flowsom.HostStaging`` that
+    receives the divided stack (same numbers; the buffer is reused FOV after FOV and uploads faster); ``blocks``:
+    recycled host blocks for the rows (``release()`` returns the block)."""
+    if is_mibitiff:
+        raise NotImplementedError("multi-page MIBItiff input is not built; export single-channel TIFFs")
+    verify_in_list(provided_chans=channels,
+                   pixel_mat_chans=image_io.channel_names(tiff_dir, fov, img_sub_folder))
+    labels = _read_segmentation(seg_dir, fov, seg_suffix) if seg_dir is not None else None
+
+    if stack is None:
+        stack = image_io.read_channels(tiff_dir, fov, channels, img_sub_folder)
+    stack = stack.astype(np.float32, copy=False)
+    norm = np.array(channel_norm_df.iloc[0].values).reshape([1, 1, -1])
+    if staging is not None and norm.dtype == np.float32:
+        # the same ufunc call writing into the staging buffer, in the stack's own memory order (channel-planar
+        # for stacks from image_io.read_channels)
+        h, w, c = stack.shape
+        if stack.transpose(2, 0, 1).flags.c_contiguous:
+            divided = staging.array((c, h, w), np.float32).transpose(1, 2, 0)
+        else:
+            divided = staging.array((h, w, c), np.float32)
+        stack = np.divide(stack, norm, out=divided)
+    else:
+        stack = stack / norm                                                       # float32 / float32 stays float32
+    q = None if post_rownorm_q is None else (post_rownorm_q * 100) / 100      # pandas' effective q
+    got = _device_rows(channels, stack, pixel_thresh_val, blur_factor, nonzero_q=q, blocks=blocks)
+    return got[:4] + (labels,) + got[4:]
+
+
+def _fov_table_half(base_dir, data_dir, subset_dir, channels, subset_proportion, seed, fov, rows, writer=None):
+    """The rest of preprocess_fov: seeded DataFrames out of the device's rows, the two writes; returns
+    ``(full table, quantile Series or None)``."""
+    values, kept_h, width, quantiles, labels = rows[:5]
+    full, subset = _assemble_tables(fov, channels, values, kept_h, width, labels, subset_proportion, seed=seed)
+    for table, folder in ((full, data_dir), (subset, subset_dir)):
+        path = os.path.join(base_dir, folder, fov + ".feather")
+        if writer is None:
+            write_dataframe(table, path, compression='uncompressed')
+        else:
+            writer.submit(table, path)
+    if quantiles is None:
+        return full, None
+    return full, pd.Series(quantiles, index=pd.Index(list(channels), name="channel"), name=fov)
+
+
 def preprocess_fov(base_dir, tiff_dir, data_dir, subset_dir, seg_dir, seg_suffix,
                    img_sub_folder, is_mibitiff, channels, blur_factor,
                    subset_proportion, pixel_thresh_val, seed, channel_norm_df, fov, stack=None,
@@ -68,30 +134,11 @@ def preprocess_fov(base_dir, tiff_dir, data_dir, subset_dir, seg_dir, seg_suffix
     Extensions used by :func:`create_pixel_matrix`: ``stack`` -- the FOV's channel stack when the caller has
     already read it; ``post_rownorm_q`` -- return ``(table, per-channel non-zero quantile Series)``, the
     quantile taken on the device; ``writer`` -- a ``TableWriter`` that takes over the two writes."""
-    if is_mibitiff:
-        raise NotImplementedError("multi-page MIBItiff input is not built; export single-channel TIFFs")
-    verify_in_list(provided_chans=channels,
-                   pixel_mat_chans=image_io.channel_names(tiff_dir, fov, img_sub_folder))
-    labels = _read_segmentation(seg_dir, fov, seg_suffix) if seg_dir is not None else None
-
-    if stack is None:
-        stack = image_io.read_channels(tiff_dir, fov, channels, img_sub_folder)
-    stack = stack.astype(np.float32, copy=False)
-    stack = stack / np.array(channel_norm_df.iloc[0].values).reshape([1, 1, -1])   # float32 / float32 stays float32
-
-    np.random.seed(seed)
-    q = None if post_rownorm_q is None else (post_rownorm_q * 100) / 100      # pandas' effective q
-    full, subset, quantiles = _fov_tables(fov, channels, stack, labels, pixel_thresh_val, blur_factor,
-                                          subset_proportion, nonzero_q=q)
-    for table, folder in ((full, data_dir), (subset, subset_dir)):
-        path = os.path.join(base_dir, folder, fov + ".feather")
-        if writer is None:
-            write_dataframe(table, path, compression='uncompressed')
-        else:
-            writer.submit(table, path)
-    if post_rownorm_q is None:
-        return full
-    return full, pd.Series(quantiles, index=pd.Index(list(channels), name="channel"), name=fov)
+    rows = _fov_device_half(tiff_dir, seg_dir, seg_suffix, img_sub_folder, is_mibitiff, channels, blur_factor,
+                            pixel_thresh_val, channel_norm_df, fov, stack=stack, post_rownorm_q=post_rownorm_q)
+    full, series = _fov_table_half(base_dir, data_dir, subset_dir, channels, subset_proportion, seed, fov, rows,
+                                   writer=writer)
+    return full if post_rownorm_q is None else (full, series)
 
 
 def create_pixel_matrix(fovs, channels, base_dir, tiff_dir, seg_dir,
@@ -167,32 +214,91 @@ def create_pixel_matrix(fovs, channels, base_dir, tiff_dir, seg_dir,
         write_dataframe(pd.DataFrame({'pixel_thresh_val': [pixel_thresh_val]}), thresh_file,
                         compression='uncompressed')
 
-    # tables (and, behind them, the per-FOV record) are written by a background thread while the next FOV
-    # is on the GPU; the record never reaches the disk before the tables it vouches for
-    writer = TableWriter(depth=4)
+    # Two stages per FOV, one FOV apart: the caller's thread drives the device (segmentation, channel division,
+    # kernels, rows back) while a finisher thread turns the previous FOV's rows into the two DataFrames (seeded
+    # sample included: the finisher is the only user of numpy's global RNG meanwhile) and hands them, and strictly
+    # behind them the per-FOV record, to the table writers (four: serialising a FOV's tables takes longer than
+    # either stage); the record never reaches the disk before the tables it vouches for.
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+    import threading
+    writer = TableWriter(depth=8, workers=4)
+    record = {"per_fov": per_fov, "snapshots": {}, "written": set(), "next": 0, "count": 0}
+    record_lock = threading.Lock()
+
+    def tables_written(index):
+        """Writer threads, once per FOV when both of its tables are out: the per-FOV record goes to disk for the
+        longest run of finished FOVs (in processing order), never ahead of a table it vouches for."""
+        if writer.failed:           # the callback also runs for tables abandoned after a failed write
+            return
+        with record_lock:
+            record["written"].add(index)
+            newest = None
+            while record["next"] in record["written"]:
+                newest = record["snapshots"].pop(record["next"])
+                record["next"] += 1
+            if newest is not None:
+                newest.to_csv(per_fov_file)
+
+    def finish(fov, rows):
+        index = record["count"]
+        record["count"] += 1
+        left = [2]
+
+        def one_written():
+            with record_lock:
+                left[0] -= 1
+                last = left[0] == 0
+            if last:
+                tables_written(index)
+
+        values, kept_h, width, quantiles, labels = rows[:5]
+        release = rows[5] if len(rows) > 5 else None
+        full, subset = _assemble_tables(fov, channels, values, kept_h, width, labels, subset_proportion, seed=seed)
+        row = pd.Series(quantiles, index=pd.Index(list(channels), name="channel"), name=fov)
+        table = record["per_fov"]
+        if fov in table.columns:                  # re-done after an interrupted run
+            table = table.drop(columns=[fov])
+        record["per_fov"] = table = table.merge(row, how="outer", left_index=True, right_index=True)
+        with record_lock:
+            record["snapshots"][index] = table.copy()      # after every FOV: an interrupted run keeps what it has
+        def full_written():            # the full table wraps the recycled block; the sub-sample owns its rows
+            if release is not None:
+                release()
+            one_written()
+
+        writer.submit(subset, os.path.join(base_dir, subset_dir, fov + ".feather"), done=one_written)
+        writer.submit(full, os.path.join(base_dir, data_dir, fov + ".feather"), done=full_written)
+
     group = batch_size if multiprocess else 1
     done = 0
     ahead = image_io.iter_stacks(tiff_dir, todo, channels, img_sub_folder, cache=stacks, fill=False)
+    finisher = ThreadPoolExecutor(max_workers=1, thread_name_prefix="pxsom-fov-tables")
+    staging = flowsom.HostStaging()
+    blocks = HostBlocks()
+    pending = deque()
     try:
         for start in range(0, len(todo), group):
             names = todo[start:start + group]
             for fov in names:
                 stack = next(ahead)[1]
                 stacks.pop(fov, None)     # last use of this FOV's stack
-                _, row = preprocess_fov(base_dir, tiff_dir, data_dir, subset_dir, seg_dir, seg_suffix,
-                                        img_sub_folder, is_mibitiff, channels, blur_factor, subset_proportion,
-                                        pixel_thresh_val, seed, pre_norm, fov, stack=stack,
-                                        post_rownorm_q=channel_percentile_post_rownorm, writer=writer)
-                if fov in per_fov.columns:            # re-done after an interrupted run
-                    per_fov = per_fov.drop(columns=[fov])
-                per_fov = per_fov.merge(row, how="outer", left_index=True, right_index=True)
-                # after every FOV: an interrupted run keeps what it has
-                writer.submit_call(lambda snapshot=per_fov.copy(): snapshot.to_csv(per_fov_file))
+                rows = _fov_device_half(tiff_dir, seg_dir, seg_suffix, img_sub_folder, is_mibitiff, channels,
+                                        blur_factor, pixel_thresh_val, pre_norm, fov, stack=stack,
+                                        post_rownorm_q=channel_percentile_post_rownorm, staging=staging,
+                                        blocks=blocks)
+                while len(pending) >= 2:              # at most two FOVs' rows wait for the finisher
+                    pending.popleft().result()
+                pending.append(finisher.submit(finish, fov, rows))
             done += len(names)
+            while (multiprocess or done == len(todo)) and pending:   # a batch / the cohort is reported once its
+                pending.popleft().result()                           # tables are handed to the writer
             if multiprocess or done % 10 == 0 or done == len(todo):
                 print("Processed %d fovs" % done)
     finally:
+        finisher.shutdown(wait=True)
         writer.close()
+    per_fov = record["per_fov"]
 
     # cohort value per channel = mean of the per-FOV values; channels in natural order
     cohort = pd.DataFrame(per_fov.mean(axis=1))

@@ -25,8 +25,9 @@ def wrap(obj, name, key):
         if key.startswith("_image") or key.startswith("som_device"): torch.cuda.synchronize()
         acc[key] += time.perf_counter() - t0; return r
     setattr(obj, name, timed)
-wrap(pp, "preprocess_fov", "preprocess_fov")
-wrap(pp, "_fov_tables", "_fov_tables")
+wrap(pp, "_fov_device_half", "device half (caller's thread)")
+wrap(pp, "_fov_table_half", "table half (finisher thread)")
+wrap(pp, "_assemble_tables", "DataFrames + sample (finisher thread)")
 wrap(flowsom, "fov_pixel_rows", "device rows (blur, filter, normalise, quantile, D2H)")
 wrap(pp, "_read_segmentation", "read segmentation")
 wrap(flowsom, "positive_quantile_f32", "positive_quantile_f32")

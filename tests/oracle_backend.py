@@ -94,14 +94,15 @@ def install(patch):
         m = np.asarray(matrix, dtype=np.float64)
         return np.array([ob.quantile_nonzero(np.ascontiguousarray(m[:, j]), q, 0) for j in range(m.shape[1])])
 
-    def fov_pixel_rows(img_hwc, sigma, thresh, nonzero_q=None):
+    def fov_pixel_rows(img_hwc, sigma, thresh, nonzero_q=None, blocks=None):
         img_hwc = np.ascontiguousarray(img_hwc)
         f32 = img_hwc.dtype == np.float32
         h, w, c = img_hwc.shape
         blurred = ob.gaussian_blur_hwc(img_hwc, float(sigma), f32=f32)
         rows, kept = ob.rowsum_filter_normalize(blurred.reshape(h * w, c), float(thresh), sum_mode=2 if f32 else 0)
         rows = rows.astype(np.float32) if f32 else rows
-        return (rows, kept) if nonzero_q is None else (rows, kept, nonzero_quantiles(rows, nonzero_q))
+        tail = () if blocks is None else (lambda: None,)        # "release" of a block that was never taken
+        return ((rows, kept) if nonzero_q is None else (rows, kept, nonzero_quantiles(rows, nonzero_q))) + tail
 
     # generate_pixel_cluster_mask's relabel + scatter is plain numpy in the reference (utils/data_utils.py:532-553)
     def pixel_cluster_mask(row_index, column_index, labels, id_mapping, shape):

@@ -565,6 +565,42 @@ def test_create_pixel_matrix_resumes_after_interruption(som_backend, tmp_path, c
     np.testing.assert_array_equal(t[["chan0", "chan1", "chan2", "chan10"]].values, g["pixel_mat_data_fov1_channels"])
 
 
+def test_create_pixel_matrix_record_never_vouches_for_a_failed_table(som_backend, tmp_path, monkeypatch):
+    """The tables go out on several writer threads; the per-FOV record (what a restart trusts) lists a FOV only
+    once both of its tables -- and those of every FOV before it -- are on disk.  A write that fails stops the
+    run, and neither that FOV nor a later one is on record."""
+    from ark_analysis_amd import fov_tables
+    from ark_analysis_amd.phenotyping import pixie_preprocessing
+    g = np.load(os.path.join(GOLD, "g9_create_pixel_matrix.npz"))
+    td = str(tmp_path)
+    fovs, chans, tiff_dir, seg_dir = _write_g9_cohort(g, td)
+    real_write = fov_tables.write_dataframe
+
+    def failing_write(table, path, **kw):
+        if path.endswith(os.path.join("pixel_mat_data", "fov1.feather")):
+            raise OSError("disk full")
+        return real_write(table, path, **kw)
+    monkeypatch.setattr(fov_tables, "write_dataframe", failing_write)
+    processed = []                 # create_pixel_matrix walks a set: note the order it took
+    real_half = pixie_preprocessing._fov_device_half
+
+    def noting_half(*args, **kw):
+        processed.append(args[9])
+        return real_half(*args, **kw)
+    monkeypatch.setattr(pixie_preprocessing, "_fov_device_half", noting_half)
+    with pytest.raises(OSError, match="disk full"):
+        pixie_preprocessing.create_pixel_matrix(list(fovs), list(chans), td, tiff_dir, seg_dir,
+                                                subset_proportion=0.25, seed=42)
+    record = os.path.join(td, "pixel_mat_data", "channel_norm_post_rownorm_perfov.csv")
+    listed = list(pd.read_csv(record, index_col="channel").columns) if os.path.exists(record) else []
+    assert "fov1" not in listed
+    for fov in listed:             # whatever is on record has both tables
+        assert os.path.exists(os.path.join(td, "pixel_mat_data", fov + ".feather"))
+        assert os.path.exists(os.path.join(td, "pixel_mat_subsetted", fov + ".feather"))
+    assert all(processed.index(fov) < processed.index("fov1") for fov in listed)
+    assert not os.path.exists(os.path.join(td, "channel_norm_post_rownorm.feather"))
+
+
 def test_generate_pixel_cluster_mask_matches_reference_run(som_backend, tmp_path):
     """Pixel table + mapping -> int16 cluster-id image, against the reference's own function on the same
     inputs (tests/golden/g10_pixel_cluster_mask.npz): SOM and meta columns, float-typed labels, repeated
