@@ -40,8 +40,9 @@ struct StepArgs {
 };
 
 struct Layout {
-    int k, nb, nch, cpl, nsteps, idx_bits, node_bits;
-    size_t off_wfrag, off_bias, off_wt, off_list, total;
+    int k, nb, nch, cpl, nsteps, idx_bits, node_bits, cp32;
+    size_t off_wfrag, off_bias, off_wt, off_w32, off_list, total;
+    bool has_wt() const { return off_w32 > off_wt; }
 };
 
 inline Layout make_layout(int64_t n, int c, int k)
@@ -67,7 +68,14 @@ inline Layout make_layout(int64_t n, int c, int k)
     // (config 5: 400 x 40 = 128 KB); smaller codebooks do not use the region (kept tiny)
     L.off_wt = pxsom::align_up(L.off_bias + (size_t)L.nb * 64 * sizeof(f32x4), 256);
     const size_t wt_bytes = (size_t)k * c * sizeof(double);
-    L.off_list = pxsom::align_up(L.off_wt + (wt_bytes > 64 * 1024 ? wt_bytes : 0), 256);
+    // binary32 copy [k][cp32] for the screening pass of the long-list exact kernel: rows zero-padded to one of the
+    // channel counts that kernel is built for
+    L.cp32 = 128;
+    constexpr int kScreenBlocks[] = {13, 10, 8, 6, 5, 4, 3, 2};
+    for (int cb : kScreenBlocks)
+        if (c <= 8 * cb) L.cp32 = 8 * cb;
+    L.off_w32 = pxsom::align_up(L.off_wt + (wt_bytes > 64 * 1024 ? wt_bytes : 0), 256);
+    L.off_list = pxsom::align_up(L.off_w32 + (size_t)k * L.cp32 * sizeof(float), 256);
     L.total = L.off_list + (size_t)(n > 0 ? n : 1) * sizeof(unsigned);
     return L;
 }

@@ -19,6 +19,7 @@
 // HBM traffic per pixel: C*sizeof(T) read + 4 written (DESIGN.md "K7").
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 
 #include "pxsom_assign.h"
 #include "pxsom_prep.h"
@@ -28,6 +29,17 @@ using namespace pxsom_bmu;
 
 namespace {
 
+// Lists at least this long go to bmu_exact_screened_kernel (a wave per 64 rows: throughput), shorter ones to
+// bmu_exact_kernel (a wave per row or four: latency).  A wave of the former walks all K nodes at ~1 us each whatever
+// the list's length; the latter settles a row in about 0.4 ps x K x C on the whole chip: they meet near 2.25e6 / C
+// rows (measured: 100 K rows at C = 22, 22 K at C = 100).
+// PXSOM_SCREEN_MIN_ROWS overrides it (the tests send short lists through the screened kernel as well).
+static unsigned screen_min_rows(int c)
+{
+    if (const char *forced = getenv("PXSOM_SCREEN_MIN_ROWS")) return (unsigned)strtoul(forced, nullptr, 10);
+    return (unsigned)(2250000 / (c > 0 ? c : 1));
+}
+
 // NT threads in ONE workgroup: 256, or 1024 for codebooks of more than 128 nodes (every phase is a loop over
 // nodes or fragments: four times the threads, a quarter of the trips)
 template <int NT>
@@ -35,7 +47,7 @@ __global__ __launch_bounds__(NT) void bmu_prep_kernel(const double *__restrict__
                                                        AssignHdr *hdr, half8 *wfrag, f32x4 *bias,
                                                        int nb, int nch, int cpl, int idx_bits,
                                                        int node_bits, int stage, double *zero_ptr,
-                                                       int zero_count, double *wt_out)
+                                                       int zero_count, double *wt_out, float *w32_out, int cp32)
 {
     PXSOM_PHASE_ANY(0);
     // fused batch accumulation: the statistics buffer is cleared here instead of by a memset node
@@ -59,8 +71,8 @@ __global__ __launch_bounds__(NT) void bmu_prep_kernel(const double *__restrict__
     PXSOM_PHASE_ANY(1);
     // two calls, not one with a selected pointer: each inlined copy then knows its address space (ds_read for
     // the staged codebook instead of flat loads)
-    if (stage) prep_body<NT>(sw, k, c, hdr, wfrag, bias, nb, nch, cpl, idx_bits, node_bits, wt_out);
-    else prep_body<NT>(w, k, c, hdr, wfrag, bias, nb, nch, cpl, idx_bits, node_bits, wt_out);
+    if (stage) prep_body<NT>(sw, k, c, hdr, wfrag, bias, nb, nch, cpl, idx_bits, node_bits, wt_out, w32_out, cp32);
+    else prep_body<NT>(w, k, c, hdr, wfrag, bias, nb, nch, cpl, idx_bits, node_bits, wt_out, w32_out, cp32);
 }
 
 
@@ -197,8 +209,9 @@ __global__ __launch_bounds__(256) void bmu_exact_kernel(const T *__restrict__ x,
                                                         const AssignHdr *hdr,
                                                         const unsigned *__restrict__ amb_list,
                                                         int32_t *__restrict__ labels, int use_lds,
-                                                        const double *__restrict__ wt_global)
+                                                        const double *__restrict__ wt_global, unsigned screened_from)
 {
+    if (hdr->amb_count >= screened_from) return;   // long lists: bmu_exact_screened_kernel (launched beside this one)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     // [c][k] transposed codebook: staged in LDS, or (too big for LDS) the copy prep wrote to the workspace
     const double *wt = use_lds ? reinterpret_cast<const double *>(smem_raw) : wt_global;
@@ -241,6 +254,172 @@ __global__ __launch_bounds__(256) void bmu_exact_kernel(const T *__restrict__ x,
         exact_rows_loop<T, 1, 8, 4>(x, c, ldx, w, wt, k, count, amb_list, labels, use_lds, wave, nwaves, lane, cur1);
     else
         exact_rows_loop<T, 1, 2, 8>(x, c, ldx, w, wt, k, count, amb_list, labels, use_lds, wave, nwaves, lane, cur1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3b. exact path for LONG lists (screen_min_rows(): crowded codebooks, discrete data, degenerate early codebooks).
+//     The kernel above spends K*C binary64 operations per listed row on nodes that are nowhere near the winner.
+//     Here lanes <-> listed rows (64 per wave) and the nodes are walked uniformly:
+//       1. reference distance D_ref: the oracle's arithmetic for the node the filter proposed for the row -- the
+//          distance of SOME node, hence an upper bound of the minimum;
+//       2. screening pass in packed binary32 over all K nodes (codebook values from the binary32 copy prep left
+//          in the workspace, read through the scalar cache: no vector memory traffic, no cross-lane traffic;
+//          one v_pk_add + one v_pk_fma per channel pair and 64 rows): node k stays a candidate unless its
+//          binary32 squared distance exceeds T = ((D_ref (1 + 1e-12) + delta) ^ 2) (1 + eta), where
+//          delta = 2^-24 (|x| + max|w|) bounds what rounding x and w to binary32 can move a distance (triangle
+//          inequality) and eta = (C + 4) 2^-24 the rounding of the binary32 sum of squares (eight chains of C/8
+//          fused multiply-adds); a node the oracle could pick has D_k <= D_ref and therefore passes.  Rows or
+//          codebooks outside binary32's comfortable range keep every node (T = inf);
+//       3. the surviving (row, node) pairs -- one or two per row as a rule -- are queued in LDS and evaluated lane
+//          per pair exactly as the oracle does (binary64, j ascending, no contraction, sqrt); the row keeps the
+//          smallest distance and, among equal ones, the smallest node: the oracle's first strict minimum.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPairCap = 512;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <typename T, int CB, int NU>   // c <= 8 * CB = Layout::cp32; NU nodes' codebook rows requested together
+__global__ __launch_bounds__(256) void bmu_exact_screened_kernel(const T *__restrict__ x, int c, int64_t ldx,
+                                                                 const double *__restrict__ w,
+                                                                 const float *__restrict__ w32, int k,
+                                                                 const AssignHdr *hdr,
+                                                                 const unsigned *__restrict__ amb_list,
+                                                                 int32_t *labels, unsigned min_rows)
+{
+    const unsigned count = hdr->amb_count;
+    if (count < min_rows) return;
+    __shared__ unsigned long long s_bestd[4][64];
+    __shared__ int s_bestk[4][64];
+    __shared__ unsigned s_pairs[4][kPairCap];
+    __shared__ long long s_row[4][64];
+    constexpr bool kNarrow = sizeof(T) <= 4;   // binary16 / binary32 rows: a NaN / Inf shows in the binary32 copy
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned nbatches = (count + 63) / 64;
+    const double u24 = 0x1p-24;
+    const bool blind = hdr->force_exact != 0 || !(hdr->scale > 0.f);
+    const double wn = blind ? 0.0 : (double)hdr->wn_max / (double)hdr->scale;
+    const double eta = (double)(c + 4) * u24;
+    const unsigned long long kInitD = (unsigned long long)__double_as_longlong(DBL_MAX);
+
+    // every wave works through batches of 64 listed rows on its own
+    for (unsigned bt = blockIdx.x * 4 + wv; bt < nbatches; bt += gridDim.x * 4) {
+        const unsigned e = bt * 64 + lane;
+        const bool valid = e < count;
+        const int64_t row = amb_list[valid ? e : count - 1];
+        const T *rp = x + row * ldx;
+        float xv[8 * CB];
+#pragma unroll
+        for (int j = 0; j < 8 * CB; j++) {
+            const float v = (float)rp[j < c ? j : c - 1];
+            xv[j] = j < c ? v : 0.f;
+        }
+        s_bestd[wv][lane] = kInitD;
+        s_bestk[wv][lane] = 0x7fffffff;
+        s_row[wv][lane] = row;
+        float n2 = 0.f;
+        bool finite_x = true;
+#pragma unroll
+        for (int j = 0; j < 8 * CB; j++) {
+            n2 = fmaf(xv[j], xv[j], n2);
+            finite_x &= fabsf(xv[j]) <= FLT_MAX;
+        }
+        int ref = labels[row] - 1;
+        if ((unsigned)ref >= (unsigned)k) ref = 0;
+        wave_lds_sync();
+        // the oracle's distance of one listed row to one node (rows re-read from memory: they are in L2)
+        auto oracle_distance = [&](int node, int64_t r) __attribute__((always_inline)) {
+#pragma clang fp contract(off)
+            const double *wk = w + (size_t)node * c;
+            const T *rq = x + r * ldx;
+            double acc = 0.0;
+#pragma unroll(CB >= 16 ? 4 : 8)
+            for (int j = 0; j < c; j++) {
+                const double t = (double)rq[j] - wk[j];
+                acc += t * t;
+            }
+            return sqrt(acc);
+        };
+        const double dref = oracle_distance(ref, row);
+        // rows with a NaN / Inf keep label 0 in the oracle (no distance is ever below DBL_MAX): nothing to evaluate
+        const bool skip = !valid || (kNarrow && !finite_x);
+        float thr = __builtin_inff();
+        if (!blind && n2 < 1.0e36f) {
+            const double delta = u24 * (sqrt((double)n2) + wn) * 1.001 + 1.0e-30;
+            const double tt = dref * (1.0 + 1.0e-12) + delta;
+            const double t64 = tt * tt * (1.0 + eta) * (1.0 + 0x1p-20);
+            if (t64 < 3.0e38) thr = fmaxf((float)t64, 1.2e-38f);
+        }
+
+        unsigned npairs = 0;
+        auto flush = [&]() __attribute__((always_inline)) {
+            for (unsigned p0 = 0; p0 < npairs; p0 += 64) {
+                const unsigned p = p0 + lane;
+                const bool on = p < npairs;
+                const unsigned pr = s_pairs[wv][on ? p : 0];
+                const int rl = (int)(pr >> 16), node = (int)(pr & 0xffffu);
+                const double dist = oracle_distance(node, s_row[wv][rl]);
+                const bool ok = on && dist < DBL_MAX;          // NaN / Inf never replace the oracle's DBL_MAX
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(dist);
+                const unsigned long long before = s_bestd[wv][rl];
+                wave_lds_sync();
+                if (ok) atomicMin(&s_bestd[wv][rl], bits);
+                wave_lds_sync();
+                const unsigned long long now = s_bestd[wv][rl];
+                if (ok && bits == now && now < before) s_bestk[wv][rl] = 0x7fffffff;   // a new minimum this round
+                wave_lds_sync();
+                if (ok && bits == now) atomicMin(&s_bestk[wv][rl], node);
+                wave_lds_sync();
+            }
+            npairs = 0;
+        };
+        for (int node = 0; node < k; node += NU) {
+            float d[NU];
+            {
+#pragma clang fp contract(fast)
+#pragma unroll
+                for (int u = 0; u < NU; u++) {
+                    const int nd = node + u < k ? node + u : k - 1;
+                    const float *wr = w32 + (size_t)nd * (8 * CB);   // rows are zero-padded to 8 * CB channels
+                    f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};   // independent chains
+#pragma unroll
+                    for (int i = 0; i < 4 * CB; i++) {
+                        const f32x2 wv2 = {wr[2 * i], wr[2 * i + 1]};
+                        const f32x2 xx = {xv[2 * i], xv[2 * i + 1]};
+                        const f32x2 t = xx - wv2;
+                        acc[i & 3] = t * t + acc[i & 3];
+                    }
+                    const f32x2 sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+                    d[u] = sum.x + sum.y;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NU; u++) {
+                const bool flag = !skip && node + u < k && !(d[u] > thr);   // a NaN stays in: binary64 decides
+                const unsigned long long m = __ballot(flag);
+                if (m) {
+                    const unsigned ahead = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    if (flag) s_pairs[wv][npairs + ahead] = ((unsigned)lane << 16) | (unsigned)(node + u);
+                    npairs += (unsigned)__popcll(m);
+                    if (npairs > (unsigned)(kPairCap - 64)) {
+                        wave_lds_sync();
+                        flush();
+                    }
+                }
+            }
+        }
+        wave_lds_sync();
+        flush();
+        if (valid) {
+            const int win = s_bestk[wv][lane];
+            labels[row] = win == 0x7fffffff ? 0 : win + 1;
+        }
+        wave_lds_sync();
+    }
 }
 
 // distance of every row to its labelled node (only when the caller asks for dists)
@@ -302,7 +481,8 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
                            reinterpret_cast<AssignHdr *>(ws),
                            reinterpret_cast<half8 *>(ws + L.off_wfrag), reinterpret_cast<f32x4 *>(ws + L.off_bias),
                            L.nb, L.nch, L.cpl, L.idx_bits, L.node_bits, stage, (double *)nullptr, 0,
-                           L.off_list > L.off_wt ? reinterpret_cast<double *>(ws + L.off_wt) : nullptr);
+                           L.has_wt() ? reinterpret_cast<double *>(ws + L.off_wt) : nullptr,
+                           reinterpret_cast<float *>(ws + L.off_w32), L.cp32);
         PXSOM_LAUNCH_CHECK("bmu_prep_kernel");
     }
 
@@ -324,8 +504,22 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
     hipLaunchKernelGGL(bmu_exact_kernel<T>, dim3(egrid), dim3(256), use_lds ? wt_bytes : 0, st, x, c, ldx, w,
                        k, reinterpret_cast<const AssignHdr *>(ws),
                        reinterpret_cast<const unsigned *>(ws + L.off_list), labels, use_lds,
-                       reinterpret_cast<const double *>(ws + L.off_wt));
+                       reinterpret_cast<const double *>(ws + L.off_wt), screen_min_rows(c));
     PXSOM_LAUNCH_CHECK("bmu_exact_kernel");
+    {
+        void (*kern)(const T *, int, int64_t, const double *, const float *, int, const AssignHdr *, const unsigned *, int32_t *,
+                     unsigned) = nullptr;
+        switch (L.cp32 / 8) {
+#define PXSOM_SCREENED(CB) case CB: kern = bmu_exact_screened_kernel<T, CB, (CB <= 3 ? 4 : CB <= 6 ? 2 : 1)>; break;
+            PXSOM_SCREENED(2) PXSOM_SCREENED(3) PXSOM_SCREENED(4) PXSOM_SCREENED(5) PXSOM_SCREENED(6) PXSOM_SCREENED(8)
+            PXSOM_SCREENED(10) PXSOM_SCREENED(13) PXSOM_SCREENED(16)
+#undef PXSOM_SCREENED
+        }
+        hipLaunchKernelGGL(kern, dim3(cus * 4), dim3(256), 0, st, x, c, ldx, w, reinterpret_cast<const float *>(ws + L.off_w32), k,
+                           reinterpret_cast<const AssignHdr *>(ws), reinterpret_cast<const unsigned *>(ws + L.off_list), labels,
+                           screen_min_rows(c));
+        PXSOM_LAUNCH_CHECK("bmu_exact_screened_kernel");
+    }
 
     if (dist) {
         int dgrid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)cus * 8);
@@ -418,7 +612,8 @@ int pxsom_bmu::prepare_only(const double *w_dev, int c, int k, void *workspace_d
                        reinterpret_cast<AssignHdr *>(ws), reinterpret_cast<half8 *>(ws + L.off_wfrag),
                        reinterpret_cast<f32x4 *>(ws + L.off_bias), L.nb, L.nch, L.cpl, L.idx_bits, L.node_bits, stage,
                        zero_stats, zero_stats ? k * (c + 1) : 0,
-                       L.off_list > L.off_wt ? reinterpret_cast<double *>(ws + L.off_wt) : nullptr);
+                       L.has_wt() ? reinterpret_cast<double *>(ws + L.off_wt) : nullptr,
+                           reinterpret_cast<float *>(ws + L.off_w32), L.cp32);
     PXSOM_LAUNCH_CHECK("bmu_prep_kernel");
     return PXSOM_OK;
 }

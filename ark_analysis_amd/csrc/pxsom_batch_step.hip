@@ -597,7 +597,8 @@ constexpr int kUpdThreads = 1024, kUpdWaves = 16;
 template <int XD, int YD, int CPP>
 __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs sa, int c, AssignHdr *hdr_g, half8 *wfrag,
                                                                         f32x4 *bias_g, double *wt_out, int nb, int nch,
-                                                                        int cpl, int idx_bits, int parts_log2)
+                                                                        int cpl, int idx_bits, int parts_log2,
+                                                                        float *w32_out, int cp32)
 {
     constexpr int K = XD * YD;
     extern __shared__ __attribute__((aligned(16))) char upd_smem[];
@@ -836,6 +837,19 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
         bias_g[f] = bv;
     }
     PXSOM_PHASE(9);
+    {   // binary32 copy for the long-list exact kernel (rows zero-padded to cp32 channels)
+        int nd = tid / cp32, j = tid - nd * cp32;
+        const int dn = kUpdThreads / cp32, dj = kUpdThreads % cp32;
+        for (int e2 = tid; e2 < K * cp32; e2 += kUpdThreads) {
+            w32_out[e2] = j < c ? (float)tl[(size_t)nd * c + j] : 0.f;
+            nd += dn;
+            j += dj;
+            if (j >= cp32) {
+                j -= cp32;
+                nd++;
+            }
+        }
+    }
     if (wt_out) {
         int j = tid / K, nd = tid - j * K;
         const int dj = kUpdThreads / K, dn = kUpdThreads % K;
@@ -903,10 +917,10 @@ bool launch_update_prepare(const StepArgs &sa, int xdim, int ydim, int c, char *
         }
         have = lds;
     }
-    double *wt_out = L.off_list > L.off_wt ? reinterpret_cast<double *>(ws + L.off_wt) : nullptr;
+    double *wt_out = L.has_wt() ? reinterpret_cast<double *>(ws + L.off_wt) : nullptr;
     hipLaunchKernelGGL(kern, dim3(1), dim3(kUpdThreads), lds, st, sa, c, reinterpret_cast<AssignHdr *>(ws),
                        reinterpret_cast<half8 *>(ws + L.off_wfrag), reinterpret_cast<f32x4 *>(ws + L.off_bias), wt_out, L.nb,
-                       L.nch, L.cpl, L.idx_bits, pl);
+                       L.nch, L.cpl, L.idx_bits, pl, reinterpret_cast<float *>(ws + L.off_w32), L.cp32);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) *rc = pxsom::hip_fail(e, "batch_update_prep_kernel");
     return true;

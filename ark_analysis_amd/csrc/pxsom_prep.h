@@ -45,8 +45,23 @@ __device__ long long g_phase_ticks[32];
 template <int NT>
 __device__ __forceinline__ void prep_body(const double *wl, int k, int c, AssignHdr *hdr, half8 *wfrag,
                                           f32x4 *bias, int nb, int nch, int cpl, int idx_bits, int node_bits,
-                                          double *wt_out = nullptr)
+                                          double *wt_out = nullptr, float *w32_out = nullptr, int cp32 = 0)
 {
+    // binary32 copy, rows zero-padded to cp32 channels: what the long-list exact kernel screens with
+    if (w32_out) {
+        int node = (int)threadIdx.x / cp32, j = (int)threadIdx.x - node * cp32;
+        const int dn = NT / cp32, dj = NT % cp32;
+#pragma unroll 4
+        for (int e = threadIdx.x; e < k * cp32; e += NT) {
+            w32_out[e] = j < c ? (float)wl[(size_t)node * c + j] : 0.f;
+            node += dn;
+            j += dj;
+            if (j >= cp32) {
+                j -= cp32;
+                node++;
+            }
+        }
+    }
     // big codebooks: a transposed copy [c][k] for the exact kernel (coalesced reads, lanes <-> nodes)
     // Written in ITS order (consecutive threads <-> consecutive nodes of a channel: coalesced stores, strided
     // reads of the staged codebook), the (channel, node) pair advanced without a division per element.

@@ -132,6 +132,52 @@ def test_assign_identical_codebook_rows(gpu, oracle):
     assert sd.last_exact_rows(sd.assign.last_workspace) >= 3000
 
 
+@pytest.mark.parametrize("n,c,k,dtype", [
+    (40_000, 22, 100, np.float32),     # config 2's codebook
+    (30_000, 40, 400, np.float16),     # config 5's
+    (30_000, 100, 100, np.float32),    # config 4's
+    (20_000, 7, 97, np.float64),       # odd channel count, binary64 rows
+    (12_000, 128, 225, np.float32),    # the widest rows
+    (9_000, 3, 1024, np.float32),      # the largest codebook
+])
+@pytest.mark.parametrize("pattern", ["crowded", "ties", "wild"])
+def test_long_exact_lists_are_screened_and_stay_bit_exact(gpu, oracle, monkeypatch, n, c, k, dtype, pattern):
+    """Thousands of listed rows (crowded codebooks, discrete data, non-finite and out-of-range rows) through the
+    screened exact kernel (binary32 screening against the distance of the filter's proposal, binary64 only for
+    the surviving nodes): labels equal the oracle's, first-minimum ties and label 0 for non-finite rows included.
+    The kernel takes over from 2.25e6 / C listed rows; ``PXSOM_SCREEN_MIN_ROWS`` sends these lists there too."""
+    monkeypatch.setenv("PXSOM_SCREEN_MIN_ROWS", "1")
+    rs = np.random.RandomState(n + c + k)
+    if pattern == "crowded":       # node pairs 1e-3 .. 1e-9 apart, a duplicated node, rows around them
+        half = rs.rand((k + 1) // 2, c)
+        w = np.concatenate([half, half * (1.0 + 10.0 ** rs.uniform(-9, -3, size=(len(half), 1)))])[:k]
+        w[k - 1] = w[0]
+        x = w[rs.randint(0, k, n)] * (1.0 + 1e-4 * rs.standard_normal((n, c)))
+    elif pattern == "ties":        # values on a coarse grid: exact distance ties between nodes, zero distances
+        x = rs.randint(0, 3, size=(n, c)).astype(np.float64) / 2.0
+        w = rs.randint(0, 3, size=(k, c)).astype(np.float64) / 2.0
+        w[: min(k, 50)] = x[: min(k, 50)]
+    else:                          # one blob (every row near-tied) with rows no shortcut survives
+        x = 0.5 + 0.01 * rs.standard_normal((n, c))
+        w = 0.5 + 0.01 * rs.standard_normal((k, c))
+        for value in (np.nan, np.inf, -np.inf, 1e30, -1e30, 1e-30, 6e4, 7e4, 1e19, 3e38):
+            hit = rs.randint(0, n, 40)
+            x[hit, rs.randint(0, c, 40)] = value
+        x[7] = np.nan
+        x[8] = 0.0
+    with np.errstate(over="ignore"):
+        x = np.ascontiguousarray(x.astype(dtype))
+    w = np.ascontiguousarray(w.astype(np.float64))
+    got, _ = _gpu_assign(gpu, x, w)
+    if pattern != "ties":          # (coarse-grid ties list thousands of rows for most shapes, not for all)
+        assert sd.last_exact_rows(sd.assign.last_workspace) >= 2048
+    want, _ = oracle.map_data_to_nodes(w, x.astype(np.float64))
+    np.testing.assert_array_equal(got, want)
+    monkeypatch.delenv("PXSOM_SCREEN_MIN_ROWS")        # and the default split between the two exact kernels
+    got, _ = _gpu_assign(gpu, x, w)
+    np.testing.assert_array_equal(got, want)
+
+
 def test_assign_nonfinite_rows(gpu, oracle):
     x = synth.make_fov_numpy(1000, 22, seed=6)
     x[5, 3] = np.nan
