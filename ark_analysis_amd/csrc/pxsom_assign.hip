@@ -284,7 +284,8 @@ __device__ __forceinline__ void wave_lds_sync()
 }
 
 template <typename T, int CB, int NU>   // c <= 8 * CB = Layout::cp32; NU nodes' codebook rows requested together
-__global__ __launch_bounds__(256) void bmu_exact_screened_kernel(const T *__restrict__ x, int c, int64_t ldx,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CB <= 3 || (sizeof(T) <= 4 && CB <= 5)) ? 4 : 2)))
+void bmu_exact_screened_kernel(const T *__restrict__ x, int c, int64_t ldx,
                                                                  const double *__restrict__ w,
                                                                  const float *__restrict__ w32, int k,
                                                                  const AssignHdr *hdr,
