@@ -679,6 +679,8 @@ struct TableAdd<_Float16> {
     }
 };
 
+constexpr int kSumsSpare = 16;   // table slots behind the last cluster: where elements without a valid label go
+
 template <typename T, bool COUNT_F64, int NT>
 __global__ __launch_bounds__(NT) void cluster_sums_kernel(const T *__restrict__ x, int64_t n, int c,
                                                            int64_t ldx, const int32_t *__restrict__ labels,
@@ -686,11 +688,11 @@ __global__ __launch_bounds__(NT) void cluster_sums_kernel(const T *__restrict__ 
                                                            int64_t rows_per_block, int use_lds)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double *ls = reinterpret_cast<double *>(smem_raw);                 // [k*c]
-    unsigned *lc = reinterpret_cast<unsigned *>(ls + (size_t)k * c);   // [k]
+    double *ls = reinterpret_cast<double *>(smem_raw);                 // [k*c] + kSumsSpare slots nobody reads
+    unsigned *lc = reinterpret_cast<unsigned *>(ls + (size_t)k * c + kSumsSpare);   // [k]
     const int tid = threadIdx.x;
     if (use_lds) {
-        for (int e = tid; e < k * c; e += NT) ls[e] = 0.0;
+        for (int e = tid; e < k * c + kSumsSpare; e += NT) ls[e] = 0.0;
         for (int e = tid; e < k; e += NT) lc[e] = 0u;
         __syncthreads();
     }
@@ -739,17 +741,50 @@ __global__ __launch_bounds__(NT) void cluster_sums_kernel(const T *__restrict__ 
                         }
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; u++)
+                    for (int u = 0; u < 4; u++) {
+                        bool plain = false;
+                        if constexpr (TableAdd<T>::kFixed) {
+                            // binary16, no Inf / NaN among the eight (the usual vector): branch-free.  v + 1.5 * 2^28 is
+                            // exact and lies in [2^28, 2^29), where one ulp is 2^-24: its bit pattern minus the
+                            // constant's IS v * 2^24 in two's complement (the constant's low word is zero: one
+                            // subtraction on the high word).  Elements without a valid label go to the spare slots.
+                            // (an exponent field of all ones <=> magnitude >= 0x7c00 <=> magnitude + 0x0400 reaches bit 15;
+                            // both halves of a word at once, no carry between them)
+                            unsigned raw[4], reach = 0u;
+                            __builtin_memcpy(raw, val[u], 16);
 #pragma unroll
-                        for (int i = 0; i < VEC; i++) {
-                            const bool wrapped = ch0[u] + i >= c;
-                            const int lb = wrapped ? lab_b[u] : lab_a[u];
-                            const int ch = ch0[u] + i - (wrapped ? c : 0);
-                            if (lb >= 0 && lb < k) {
-                                TableAdd<T>::add(ls, (size_t)lb * c + ch, val[u][i], sums);
-                                if (ch == 0) atomicAdd(&lc[lb], 1u);
+                            for (int d = 0; d < 4; d++) reach |= (raw[d] & 0x7fff7fffu) + 0x04000400u;
+                            plain = (reach & 0x80008000u) == 0u;
+                            if (plain) {
+                                const bool ok_a = (unsigned)lab_a[u] < (unsigned)k, ok_b = (unsigned)lab_b[u] < (unsigned)k;
+                                const int base_a = ok_a ? lab_a[u] * c + ch0[u] : k * c;
+                                const int base_b = ok_b ? lab_b[u] * c + ch0[u] - c : k * c;
+                                unsigned long long *table = reinterpret_cast<unsigned long long *>(ls);
+#pragma unroll
+                                for (int i = 0; i < VEC; i++) {
+                                    const double shifted = (double)val[u][i] + 0x1.8p+28;
+                                    const unsigned long long q =
+                                        (unsigned long long)__double_as_longlong(shifted) - 0x41B8000000000000ull;
+                                    const int slot = (ch0[u] + i >= c ? base_b : base_a) + i;
+                                    if (q) __hip_atomic_fetch_add(table + slot, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                }
+                                if (ok_a && ch0[u] == 0) atomicAdd(&lc[lab_a[u]], 1u);        // the vector starts a row,
+                                if (ok_b && ch0[u] + VEC > c) atomicAdd(&lc[lab_b[u]], 1u);   // or the next row starts inside it
                             }
                         }
+                        if (!plain) {
+#pragma unroll
+                            for (int i = 0; i < VEC; i++) {
+                                const bool wrapped = ch0[u] + i >= c;
+                                const int lb = wrapped ? lab_b[u] : lab_a[u];
+                                const int ch = ch0[u] + i - (wrapped ? c : 0);
+                                if (lb >= 0 && lb < k) {
+                                    TableAdd<T>::add(ls, (size_t)lb * c + ch, val[u][i], sums);
+                                    if (ch == 0) atomicAdd(&lc[lb], 1u);
+                                }
+                            }
+                        }
+                    }
                 }
             } else
             for (int64_t v0 = tid; v0 < nvec; v0 += 4 * NT) {
@@ -1217,7 +1252,7 @@ int cluster_sums_typed(const T *x, int64_t n, int c, int64_t ldx, const int32_t 
             }
         }
     }
-    const size_t lds = (size_t)k * c * 8 + (size_t)k * 4;
+    const size_t lds = ((size_t)k * c + kSumsSpare) * 8 + (size_t)k * 4;
     const int use_lds = lds <= 150 * 1024;
     const int cus = pxsom::device_cu_count();
     // small inputs are latency-bound per workgroup, so they are spread wide: 64 rows per workgroup (measured on
