@@ -18,15 +18,31 @@ from ..fov_tables import FovTableDir, TablePrefetcher
 from ..host_utils import natsort_key, validate_paths, verify_in_list
 
 
-def calculate_channel_percentiles(tiff_dir, fovs, channels, img_sub_folder, percentile, stacks=None):
+def _gathered_by_fov(fovs, ranks, per_fov_values):
+    """``per_fov_values(my_fovs) -> list`` evaluated on this rank's share of ``fovs`` and put back together in the
+    order of ``fovs`` on every rank (``ranks = (rank, world)``; None or one rank: everything here)."""
+    from .. import distributed
+    if ranks is None or ranks[1] <= 1:
+        return per_fov_values(list(fovs))
+    mine = distributed.shard(fovs, *ranks)
+    known = {}
+    for part in distributed.allgather_objects(dict(zip(mine, per_fov_values(mine)))):
+        known.update(part)
+    return [known[fov] for fov in fovs]
+
+
+def calculate_channel_percentiles(tiff_dir, fovs, channels, img_sub_folder, percentile, stacks=None, ranks=None):
     """One normalisation value per channel: the ``percentile`` quantile of the positive pixels of each
     FOV's channel image, averaged over the FOVs that have any (reference: pixel_cluster_utils.py:16-58).
     Returns a one-row DataFrame, columns naturally sorted.  ``stacks``: an ``image_io.stack_cache()`` shared
-    with the other passes over the same TIFFs."""
+    with the other passes over the same TIFFs.  ``ranks`` = (rank, world) under a process group: every rank
+    takes its share of the FOVs, the per-FOV values are gathered and averaged in the order of ``fovs`` -- the
+    same numbers on every rank, whatever the rank count."""
     # one device call per FOV covers all its channels (the reference walks channel by channel; the values it
     # averages -- and their order, FOV by FOV -- are the same); the next FOV is decoded meanwhile
-    by_fov = [flowsom.positive_quantile_f32(stack, percentile)
-              for _, stack in image_io.iter_stacks(tiff_dir, fovs, channels, img_sub_folder, cache=stacks)]
+    by_fov = _gathered_by_fov(fovs, ranks, lambda mine: [
+        flowsom.positive_quantile_f32(stack, percentile)
+        for _, stack in image_io.iter_stacks(tiff_dir, mine, channels, img_sub_folder, cache=stacks)])
     per_channel = []
     for j in range(len(channels)):
         found = [values[j] for values in by_fov if not np.isnan(values[j])]   # no positive pixel: not counted
@@ -36,12 +52,13 @@ def calculate_channel_percentiles(tiff_dir, fovs, channels, img_sub_folder, perc
 
 
 def calculate_pixel_intensity_percentile(tiff_dir, fovs, channels, img_sub_folder, channel_percentiles,
-                                         percentile=0.05, stacks=None):
+                                         percentile=0.05, stacks=None, ranks=None):
     """Mean over FOVs of the ``percentile`` quantile of the per-pixel total signal, each channel first
-    divided by its normalisation value (reference: pixel_cluster_utils.py:61-106)."""
+    divided by its normalisation value (reference: pixel_cluster_utils.py:61-106).  ``ranks``: as above."""
     divisors = channel_percentiles.iloc[0].values
-    per_fov = [flowsom.total_intensity_quantile_f32(stack, divisors, percentile)
-               for _, stack in image_io.iter_stacks(tiff_dir, fovs, channels, img_sub_folder, cache=stacks)]
+    per_fov = _gathered_by_fov(fovs, ranks, lambda mine: [
+        flowsom.total_intensity_quantile_f32(stack, divisors, percentile)
+        for _, stack in image_io.iter_stacks(tiff_dir, mine, channels, img_sub_folder, cache=stacks)])
     return np.mean(per_fov)
 
 

@@ -11,7 +11,7 @@ import shutil
 import numpy as np
 import pandas as pd
 
-from .. import flowsom, image_io
+from .. import distributed, flowsom, image_io
 from ..arrow_assign import HostBlocks
 from ..fov_tables import FovTableDir, TableWriter, read_dataframe, write_dataframe
 from ..host_utils import natsort_key, validate_paths, verify_in_list
@@ -163,56 +163,84 @@ def create_pixel_matrix(fovs, channels, base_dir, tiff_dir, seg_dir,
     out_root = os.path.join(base_dir, pixel_output_dir)
     validate_paths([base_dir, tiff_dir, out_root])
 
+    # Under a process group (torchrun, one process per GPU) the FOVs are dealt out by rank: every rank makes the
+    # tables of its share, the per-FOV values behind the three normalisation files are gathered and averaged in one
+    # agreed order, rank 0 writes those files.  Rank 0 alone looks at what is on disk; the others follow its plan.
+    rank, world = distributed.init_from_env()
+    ranks = (rank, world)
     data_root, subset_root = os.path.join(base_dir, data_dir), os.path.join(base_dir, subset_dir)
-    for folder in (data_root, subset_root):
-        os.makedirs(folder, exist_ok=True)
     pre_norm_file = os.path.join(out_root, norm_vals_name_pre_rownorm)
     thresh_file = os.path.join(out_root, pixel_thresh_name)
     per_fov_file = os.path.join(data_root, _PER_FOV_QUANTILES)
 
-    # a different channel selection invalidates everything derived so far
-    if os.path.exists(pre_norm_file) and set(read_dataframe(pre_norm_file).columns.values) != set(channels):
-        print("New channels provided: overwriting whole cohort")
+    plan = None
+    if rank == 0:
         for folder in (data_root, subset_root):
-            shutil.rmtree(folder)
-            os.mkdir(folder)
-        os.remove(pre_norm_file)
-        os.remove(thresh_file)
+            os.makedirs(folder, exist_ok=True)
+        # a different channel selection invalidates everything derived so far
+        if os.path.exists(pre_norm_file) and set(read_dataframe(pre_norm_file).columns.values) != set(channels):
+            print("New channels provided: overwriting whole cohort")
+            for folder in (data_root, subset_root):
+                shutil.rmtree(folder)
+                os.mkdir(folder)
+            os.remove(pre_norm_file)
+            os.remove(thresh_file)
 
-    # finished = both tables on disk; their per-FOV 99.9 % values must be on record as well
-    finished = set(FovTableDir(data_root).fovs()) & set(FovTableDir(subset_root).fovs())
-    todo = set(fovs) - finished
-    if not todo:
-        print("There are no more FOVs to preprocess, skipping")
+        # finished = both tables on disk; their per-FOV 99.9 % values must be on record as well
+        finished = set(FovTableDir(data_root).fovs()) & set(FovTableDir(subset_root).fovs())
+        todo = set(fovs) - finished
+        if not todo:
+            print("There are no more FOVs to preprocess, skipping")
+            plan = {"todo": []}
+        else:
+            per_fov = pd.read_csv(per_fov_file, index_col="channel") if os.path.exists(per_fov_file) else pd.DataFrame()
+            for name in sorted(os.listdir(data_root)):        # records the ranks of an interrupted sharded run left
+                if name.startswith(_PER_FOV_QUANTILES + ".rank"):
+                    part = pd.read_csv(os.path.join(data_root, name), index_col="channel")
+                    fresh = [col for col in part.columns if col not in per_fov.columns]
+                    if fresh:
+                        per_fov = part[fresh] if per_fov.empty else per_fov.merge(part[fresh], how="outer",
+                                                                                  left_index=True, right_index=True)
+            todo = list(todo | (set(fovs) - set(per_fov.columns)))
+            if len(todo) < len(fovs):
+                print("Restarting preprocessing from FOV %s, "
+                      "%d fovs left to process" % (todo[0], len(todo)))
+            pixel_cluster_utils.check_for_modified_channels(tiff_dir=tiff_dir, test_fov=fovs[0],
+                                                            img_sub_folder=img_sub_folder, channels=channels)
+            plan = {"todo": todo, "per_fov": per_fov, "pre_norm": os.path.exists(pre_norm_file),
+                    "thresh": os.path.exists(thresh_file)}
+    plan = distributed.broadcast_object(plan, 0)
+    if not plan["todo"]:
         return
-    per_fov = pd.read_csv(per_fov_file, index_col="channel") if os.path.exists(per_fov_file) else pd.DataFrame()
-    todo = list(todo | (set(fovs) - set(per_fov.columns)))
-    if len(todo) < len(fovs):
-        print("Restarting preprocessing from FOV %s, "
-              "%d fovs left to process" % (todo[0], len(todo)))
-
-    pixel_cluster_utils.check_for_modified_channels(tiff_dir=tiff_dir, test_fov=fovs[0],
-                                                    img_sub_folder=img_sub_folder, channels=channels)
+    cohort_todo, per_fov = plan["todo"], plan["per_fov"]
 
     # up to three passes read the same TIFFs (two percentile passes, then the tables): decoded stacks are kept
     # on the host between them while they fit the cache budget, and each pass reads one FOV ahead
     stacks = image_io.stack_cache()
-    if os.path.exists(pre_norm_file):
+    if plan["pre_norm"]:
         pre_norm = read_dataframe(pre_norm_file)
     else:
         pre_norm = pixel_cluster_utils.calculate_channel_percentiles(
             tiff_dir=tiff_dir, fovs=fovs, channels=channels, img_sub_folder=img_sub_folder,
-            percentile=channel_percentile_pre_rownorm, stacks=stacks)
-        write_dataframe(pre_norm, pre_norm_file, compression='uncompressed')
+            percentile=channel_percentile_pre_rownorm, stacks=stacks, ranks=ranks)
+        if rank == 0:
+            write_dataframe(pre_norm, pre_norm_file, compression='uncompressed')
 
-    if os.path.exists(thresh_file):
+    if plan["thresh"]:
         pixel_thresh_val = read_dataframe(thresh_file)['pixel_thresh_val'].values[0]
     else:
         pixel_thresh_val = pixel_cluster_utils.calculate_pixel_intensity_percentile(
             tiff_dir=tiff_dir, fovs=fovs, channels=channels, img_sub_folder=img_sub_folder,
-            channel_percentiles=pre_norm, stacks=stacks)
-        write_dataframe(pd.DataFrame({'pixel_thresh_val': [pixel_thresh_val]}), thresh_file,
-                        compression='uncompressed')
+            channel_percentiles=pre_norm, stacks=stacks, ranks=ranks)
+        if rank == 0:
+            write_dataframe(pd.DataFrame({'pixel_thresh_val': [pixel_thresh_val]}), thresh_file,
+                            compression='uncompressed')
+
+    # this rank's share of the tables; with several ranks each keeps the restart record of its own FOVs
+    todo = cohort_todo if world == 1 else distributed.shard(cohort_todo, rank, world)
+    if world > 1:
+        per_fov_file = per_fov_file + ".rank%d" % rank
+        per_fov = pd.DataFrame()
 
     # Two stages per FOV, one FOV apart: the caller's thread drives the device (segmentation, channel division,
     # kernels, rows back) while a finisher thread turns the previous FOV's rows into the two DataFrames (seeded
@@ -293,15 +321,34 @@ def create_pixel_matrix(fovs, channels, base_dir, tiff_dir, seg_dir,
             done += len(names)
             while (multiprocess or done == len(todo)) and pending:   # a batch / the cohort is reported once its
                 pending.popleft().result()                           # tables are handed to the writer
-            if multiprocess or done % 10 == 0 or done == len(todo):
+            if world == 1 and (multiprocess or done % 10 == 0 or done == len(todo)):
                 print("Processed %d fovs" % done)
     finally:
         finisher.shutdown(wait=True)
         writer.close()
     per_fov = record["per_fov"]
+    if world > 1:
+        # the ranks' new per-FOV values join what was on record, in the order of the agreed to-do list
+        parts = distributed.allgather_objects(per_fov)
+        if rank != 0:
+            distributed.barrier()
+            return
+        per_fov = plan["per_fov"]
+        for fov in cohort_todo:
+            for part in parts:
+                if fov in part.columns:
+                    if fov in per_fov.columns:            # re-done after an interrupted run
+                        per_fov = per_fov.drop(columns=[fov])
+                    per_fov = part[[fov]] if per_fov.empty else per_fov.merge(part[[fov]], how="outer",
+                                                                            left_index=True, right_index=True)
+        print("Processed %d fovs" % len(cohort_todo))
 
     # cohort value per channel = mean of the per-FOV values; channels in natural order
     cohort = pd.DataFrame(per_fov.mean(axis=1))
     cohort = cohort.loc[sorted(cohort.index, key=natsort_key)]
     write_dataframe(cohort.T, os.path.join(base_dir, norm_vals_name_post_rownorm), compression='uncompressed')
-    os.remove(per_fov_file)
+    for name in os.listdir(data_root):                     # the record (and the ranks' own) has done its job
+        if name.startswith(_PER_FOV_QUANTILES):
+            os.remove(os.path.join(data_root, name))
+    if world > 1:
+        distributed.barrier()

@@ -528,7 +528,9 @@ def test_channel_stacks_planar_view_prefetch_and_cache(tmp_path):
         list(image_io.iter_stacks(str(tmp_path), ["fov0"], chans, "TIFs"))
 
 
-def test_create_pixel_matrix_resumes_after_interruption(som_backend, tmp_path, capsys):
+@pytest.mark.parametrize("record_name", ["channel_norm_post_rownorm_perfov.csv",
+                                         "channel_norm_post_rownorm_perfov.csv.rank1"])
+def test_create_pixel_matrix_resumes_after_interruption(som_backend, tmp_path, capsys, record_name):
     """Tables of one FOV missing although its 99.9 % values are on record (a run killed between the two):
     only that FOV is redone and the cohort file comes out as in an uninterrupted run."""
     from ark_analysis_amd.phenotyping import pixie_preprocessing
@@ -551,7 +553,8 @@ def test_create_pixel_matrix_resumes_after_interruption(som_backend, tmp_path, c
     capsys.readouterr()
     real_remove(os.path.join(td, "pixel_mat_data", "fov1.feather"))
     real_remove(os.path.join(td, "channel_norm_post_rownorm.feather"))
-    with open(os.path.join(td, "pixel_mat_data", "channel_norm_post_rownorm_perfov.csv"), "w") as f:
+    # (the record of a single-process run, or what one rank of an interrupted sharded run left behind)
+    with open(os.path.join(td, "pixel_mat_data", record_name), "w") as f:
         f.write(kept["csv"])
     pixie_preprocessing.create_pixel_matrix(list(fovs), list(chans), td, tiff_dir, seg_dir,
                                             subset_proportion=0.25, seed=42)

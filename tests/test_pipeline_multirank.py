@@ -222,3 +222,62 @@ def test_two_rank_pipeline_on_the_hip_path(oracle, tmp_path, mode):
     avg = pd.read_csv(os.path.join(td, "pixel_channel_avg_som_cluster.csv"))
     np.testing.assert_array_equal(avg["count"].values, counts[seen - 1])
     np.testing.assert_allclose(avg[CHANS].values, sums[seen - 1] / counts[seen - 1][:, None], rtol=1e-12, atol=0)
+
+
+def _matrix_worker(rank, world, port, td, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import io
+    import contextlib
+    import torch.distributed as dist
+    from ark_analysis_amd.phenotyping import pixie_preprocessing
+    from tests import oracle_backend
+    oracle_backend.install(setattr)
+    fovs, chans = ["fov0", "fov1", "fov2"], ["chan0", "chan1", "chan2", "chan10"]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        pixie_preprocessing.create_pixel_matrix(list(fovs), list(chans), td, os.path.join(td, "tiffs"),
+                                                os.path.join(td, "seg"), subset_proportion=0.25, seed=42)
+        pixie_preprocessing.create_pixel_matrix(list(fovs), list(chans), td, os.path.join(td, "tiffs"),
+                                                os.path.join(td, "seg"), subset_proportion=0.25, seed=42)
+    assert dist.get_world_size() == world
+    with open(out_path % rank, "w") as f:
+        f.write(buf.getvalue())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_create_pixel_matrix_on_two_ranks(oracle, tmp_path):
+    """create_pixel_matrix under a 2-rank group (reference loop being sharded: pixie_preprocessing.py:375-432): the
+    FOVs' tables are made by different ranks, the per-FOV values behind the three normalisation files are gathered
+    and averaged in one agreed order -- every file equals the reference's single-process run (g9)."""
+    from tests.test_pipeline_dropin import _write_g9_cohort
+    from ark_analysis_amd.phenotyping.cluster_helpers import read_dataframe
+    g = np.load(os.path.join(GOLD, "g9_create_pixel_matrix.npz"))
+    td = str(tmp_path / "job")
+    os.mkdir(td)
+    fovs, chans, _, _ = _write_g9_cohort(g, td)
+    out = str(tmp_path / "rank%d.txt")
+    mp.spawn(_matrix_worker, args=(2, _free_port(), td, out), nprocs=2, join=True)
+    # rank 0 reports; the second call finds nothing to do
+    assert open(out % 0).read() == "Processed 3 fovs\nThere are no more FOVs to preprocess, skipping\n"
+    assert open(out % 1).read() == ""
+    pre = read_dataframe(os.path.join(td, "pixel_output_dir", "channel_norm_pre_rownorm.feather"))
+    assert list(pre.columns) == list(g["pre_columns"]) and pre.values.dtype == g["pre_values"].dtype
+    np.testing.assert_array_equal(pre.values[0], g["pre_values"])
+    th = read_dataframe(os.path.join(td, "pixel_output_dir", "pixel_thresh.feather"))["pixel_thresh_val"].values
+    np.testing.assert_array_equal(th, g["thresh"])
+    post = read_dataframe(os.path.join(td, "channel_norm_post_rownorm.feather"))
+    assert list(post.columns) == list(g["post_columns"])
+    # (a mean over the per-FOV columns in the order they were recorded: set order in the reference, the agreed
+    # to-do order here -- the last place may differ)
+    np.testing.assert_allclose(post.values[0], g["post_values"], rtol=1e-15, atol=0)
+    assert sorted(os.listdir(os.path.join(td, "pixel_mat_data"))) == list(g["data_dir_listing"])   # no record left
+    for fov in fovs:
+        for kind in ("pixel_mat_data", "pixel_mat_subsetted"):
+            t = read_dataframe(os.path.join(td, kind, fov + ".feather"))
+            tag = f"{kind}_{fov}"
+            assert list(t.columns) == list(g[tag + "_columns"])
+            np.testing.assert_array_equal(t[["chan0", "chan1", "chan2", "chan10"]].values, g[tag + "_channels"])
+            np.testing.assert_array_equal(t[["row_index", "column_index", "label"]].values.astype(np.int64),
+                                          g[tag + "_meta"])
