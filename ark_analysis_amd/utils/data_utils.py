@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pandas as pd
 
-from .. import flowsom, image_io
+from .. import distributed, flowsom, image_io
 from ..fov_tables import read_table
 from ..host_utils import validate_paths, verify_in_list
 
@@ -57,13 +57,19 @@ def generate_and_save_pixel_cluster_masks(fovs, base_dir, save_dir, tiff_dir, ch
     ``cluster_id_to_name_path`` (the remapping GUI's output) gets a ``cluster_id`` column -- 1, 2, ... over the
     distinct ``pixel_cluster_col`` values in ascending order -- and is rewritten in place; those ids are what the
     masks hold.  ``chan_file``: a channel image inside every FOV folder, for the mask's size."""
-    names = pd.read_csv(cluster_id_to_name_path)
-    ids = names[[pixel_cluster_col]].drop_duplicates().sort_values(by=[pixel_cluster_col])
-    ids["cluster_id"] = list(range(1, len(ids) + 1))
-    mapping = names.drop(columns="cluster_id", errors="ignore").merge(ids, on=[pixel_cluster_col], how="left")
-    mapping.to_csv(cluster_id_to_name_path, index=False)
-    for fov in fovs:
+    # under a process group (torchrun) rank 0 rewrites the table, the FOVs are dealt out by rank
+    rank, world = distributed.init_from_env()
+    mapping = None
+    if rank == 0:
+        names = pd.read_csv(cluster_id_to_name_path)
+        ids = names[[pixel_cluster_col]].drop_duplicates().sort_values(by=[pixel_cluster_col])
+        ids["cluster_id"] = list(range(1, len(ids) + 1))
+        mapping = names.drop(columns="cluster_id", errors="ignore").merge(ids, on=[pixel_cluster_col], how="left")
+        mapping.to_csv(cluster_id_to_name_path, index=False)
+    mapping = distributed.broadcast_object(mapping, 0)
+    for fov in distributed.shard(fovs, rank, world):
         mask = generate_pixel_cluster_mask(fov=fov, base_dir=base_dir, tiff_dir=tiff_dir,
                                            chan_file_path=os.path.join(fov, chan_file), pixel_data_dir=pixel_data_dir,
                                            cluster_mapping=mapping, pixel_cluster_col=pixel_cluster_col)
         save_fov_mask(fov, data_dir=save_dir, mask_data=mask, sub_dir=sub_dir, name_suffix=name_suffix)
+    distributed.barrier()
