@@ -502,12 +502,13 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
     // or two rounds (workgroups without rows leave at once)
     int egrid = (int)std::min<int64_t>((n + 31) / 32, (int64_t)cus * 4);
     if (egrid < 1) egrid = 1;
+    const unsigned screened_from = screen_min_rows(c);
     hipLaunchKernelGGL(bmu_exact_kernel<T>, dim3(egrid), dim3(256), use_lds ? wt_bytes : 0, st, x, c, ldx, w,
                        k, reinterpret_cast<const AssignHdr *>(ws),
                        reinterpret_cast<const unsigned *>(ws + L.off_list), labels, use_lds,
-                       reinterpret_cast<const double *>(ws + L.off_wt), screen_min_rows(c));
+                       reinterpret_cast<const double *>(ws + L.off_wt), screened_from);
     PXSOM_LAUNCH_CHECK("bmu_exact_kernel");
-    {
+    if ((uint64_t)n >= screened_from) {   // (an input shorter than the crossover cannot list that many rows)
         void (*kern)(const T *, int, int64_t, const double *, const float *, int, const AssignHdr *, const unsigned *, int32_t *,
                      unsigned) = nullptr;
         switch (L.cp32 / 8) {
@@ -518,7 +519,7 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
         }
         hipLaunchKernelGGL(kern, dim3(cus * 4), dim3(256), 0, st, x, c, ldx, w, reinterpret_cast<const float *>(ws + L.off_w32), k,
                            reinterpret_cast<const AssignHdr *>(ws), reinterpret_cast<const unsigned *>(ws + L.off_list), labels,
-                           screen_min_rows(c));
+                           screened_from);
         PXSOM_LAUNCH_CHECK("bmu_exact_screened_kernel");
     }
 
