@@ -224,15 +224,20 @@ def test_two_rank_pipeline_on_the_hip_path(oracle, tmp_path, mode):
     np.testing.assert_allclose(avg[CHANS].values, sums[seen - 1] / counts[seen - 1][:, None], rtol=1e-12, atol=0)
 
 
-def _matrix_worker(rank, world, port, td, out_path):
+def _matrix_worker(rank, world, port, td, out_path, kernels="oracle"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     import io
     import contextlib
     import torch.distributed as dist
     from ark_analysis_amd.phenotyping import pixie_preprocessing
-    from tests import oracle_backend
-    oracle_backend.install(setattr)
+    if kernels == "oracle":
+        from tests import oracle_backend
+        oracle_backend.install(setattr)
+    else:     # both ranks on device 0: the group has to be gloo (joined before init_from_env would pick "nccl")
+        import torch
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     fovs, chans = ["fov0", "fov1", "fov2"], ["chan0", "chan1", "chan2", "chan10"]
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
@@ -247,10 +252,12 @@ def _matrix_worker(rank, world, port, td, out_path):
     dist.destroy_process_group()
 
 
-def test_create_pixel_matrix_on_two_ranks(oracle, tmp_path):
+@pytest.mark.parametrize("kernels", ["oracle", pytest.param("hip", marks=pytest.mark.gpu)])
+def test_create_pixel_matrix_on_two_ranks(oracle, tmp_path, kernels):
     """create_pixel_matrix under a 2-rank group (reference loop being sharded: pixie_preprocessing.py:375-432): the
     FOVs' tables are made by different ranks, the per-FOV values behind the three normalisation files are gathered
-    and averaged in one agreed order -- every file equals the reference's single-process run (g9)."""
+    and averaged in one agreed order -- every file equals the reference's single-process run (g9).  On CPU with the
+    oracle stand-ins, on the GPU box with the real kernels (both ranks on device 0)."""
     from tests.test_pipeline_dropin import _write_g9_cohort
     from ark_analysis_amd.phenotyping.cluster_helpers import read_dataframe
     g = np.load(os.path.join(GOLD, "g9_create_pixel_matrix.npz"))
@@ -258,7 +265,7 @@ def test_create_pixel_matrix_on_two_ranks(oracle, tmp_path):
     os.mkdir(td)
     fovs, chans, _, _ = _write_g9_cohort(g, td)
     out = str(tmp_path / "rank%d.txt")
-    mp.spawn(_matrix_worker, args=(2, _free_port(), td, out), nprocs=2, join=True)
+    mp.spawn(_matrix_worker, args=(2, _free_port(), td, out, kernels), nprocs=2, join=True)
     # rank 0 reports; the second call finds nothing to do
     assert open(out % 0).read() == "Processed 3 fovs\nThere are no more FOVs to preprocess, skipping\n"
     assert open(out % 1).read() == ""
