@@ -189,3 +189,21 @@ def test_bench_picks_the_launch_over_all_rows_from_counter_rows():
     assert bench.select_launch_counters(multi, ["SQ_INSTS_MFMA", "GRBM_GUI_ACTIVE"]) == {"SQ_INSTS_MFMA": 900.0,
                                                                                        "GRBM_GUI_ACTIVE": 4000.0}
     assert bench.select_launch_counters([], ["FETCH_SIZE"]) == {}
+
+
+def test_binary16_fixed_point_conversion_is_exact_for_every_finite_half():
+    """The mean-table kernel turns a binary16 value into 2^-24 fixed point as bits(v + 1.5 * 2^28) - bits(1.5 * 2^28)
+    (csrc/pxsom_train.hip, cluster_sums_kernel): checked here for all 63 488 finite bit patterns, signed zeros and
+    subnormals included; and the vector-wide Inf / NaN test ((bits & 0x7fff) + 0x0400 reaches bit 15) for all 65 536."""
+    bits = np.arange(1 << 16, dtype=np.uint16)
+    halves = bits.view(np.float16)
+    finite = np.isfinite(halves)
+    v = halves[finite].astype(np.float64)
+    magic = np.float64(1.5 * 2.0 ** 28)
+    assert magic.view(np.uint64) == np.uint64(0x41B8000000000000)
+    shifted = v + magic
+    q = (shifted.view(np.uint64) - magic.view(np.uint64)).view(np.int64)      # wraps for negative values, as the kernel's
+    np.testing.assert_array_equal(q, np.round(v * 2.0 ** 24).astype(np.int64))
+    np.testing.assert_array_equal(q.astype(np.float64) * 2.0 ** -24, v)       # exact both ways
+    special = (((bits & 0x7FFF).astype(np.uint32) + 0x0400) & 0x8000) != 0
+    np.testing.assert_array_equal(special, ~finite)
