@@ -207,3 +207,48 @@ def test_binary16_fixed_point_conversion_is_exact_for_every_finite_half():
     np.testing.assert_array_equal(q.astype(np.float64) * 2.0 ** -24, v)       # exact both ways
     special = (((bits & 0x7FFF).astype(np.uint32) + 0x0400) & 0x8000) != 0
     np.testing.assert_array_equal(special, ~finite)
+
+
+def test_screening_rule_of_the_long_list_exact_kernel_never_drops_a_possible_winner():
+    """Numpy model of bmu_exact_screened_kernel's screening rule (csrc/pxsom_assign.hip): a node stays a candidate
+    unless its binary32 squared distance exceeds T = ((D_ref (1 + 1e-12) + delta)^2 (1 + eta), delta =
+    2^-24 (|x| + max|w|) 1.001 + 1e-30, eta = (C + 4) 2^-24.  Whatever order the binary32 sum is taken in, every node
+    whose binary64 (oracle-order) distance is <= D_ref must pass -- checked on crowded codebooks, rows sitting on
+    nodes, tiny and large magnitudes, binary64 rows (rounded to binary32 for the screening pass)."""
+    rs = np.random.RandomState(20260928)
+    u24 = 2.0 ** -24
+    for case in range(300):
+        c = int(rs.choice([1, 2, 7, 22, 40, 100, 128]))
+        k = int(rs.choice([4, 100, 400]))
+        scale = 10.0 ** rs.uniform(-6, 6)
+        w = rs.rand(k, c) * scale
+        w[k // 2:] = w[: k - k // 2] * (1.0 + 10.0 ** rs.uniform(-12, -3))        # crowded pairs
+        x = w[rs.randint(0, k)] * (1.0 + 10.0 ** rs.uniform(-9, -2) * rs.standard_normal(c))
+        if case % 5 == 0:
+            x = w[rs.randint(0, k)].copy()                                        # distance 0 to a node
+        if case % 2 == 0:
+            x = x.astype(np.float32).astype(np.float64)                           # binary32 storage
+        dist = np.empty(k)
+        for node in range(k):                                                     # the oracle's order
+            acc = 0.0
+            for j in range(c):
+                t = x[j] - w[node, j]
+                acc += t * t
+            dist[node] = np.sqrt(acc)
+        ref = int(np.argsort(dist)[min(k - 1, rs.randint(0, 3))])                 # the filter's proposal: a near-best node
+        x32, w32 = x.astype(np.float32), w.astype(np.float32)
+        n2 = np.float32(np.sum(x32 * x32, dtype=np.float32))
+        wn = float(np.sqrt((w * w).sum(axis=1)).max()) * (1.0 + 1e-6)
+        delta = u24 * (np.sqrt(float(n2)) + wn) * 1.001 + 1.0e-30
+        eta = (c + 4) * u24
+        tt = dist[ref] * (1.0 + 1.0e-12) + delta
+        thr = np.float32(max(float(np.float32(tt * tt * (1.0 + eta) * (1.0 + 2.0 ** -20))), 1.2e-38))
+        t32 = x32[None, :] - w32
+        sq = t32 * t32
+        orders = [np.sum(sq, axis=1, dtype=np.float32),                                            # numpy's pairwise order
+                  np.add.accumulate(sq, axis=1, dtype=np.float32)[:, -1],                          # sequential
+                  np.add.accumulate(sq[:, ::-1], axis=1, dtype=np.float32)[:, -1],                 # reversed
+                  sum(np.add.accumulate(sq[:, r::8], axis=1, dtype=np.float32)[:, -1] for r in range(min(8, c)))]   # 8 chains
+        must_pass = dist <= dist[ref]
+        for d32 in orders:
+            assert not (d32[must_pass] > thr).any(), (case, c, k, scale)
