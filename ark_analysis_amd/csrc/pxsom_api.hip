@@ -24,7 +24,8 @@ int fail(int code, const char *fmt, ...)
 
 int device_cu_count()
 {
-    static int cached = 0;
+    static PerDevice<int> counts;
+    int &cached = counts.here();
     if (cached > 0) return cached;
     int dev = 0;
     hipDeviceProp_t prop;

@@ -457,7 +457,8 @@ static bool prep_wide(int k, int c) { return k > 128 || k * c > 4096; }
 static int prep_stage(size_t stage_bytes)
 {
     constexpr size_t kPrepStageMax = 132 * 1024;
-    static bool raised = false;
+    static pxsom::PerDevice<bool> raised_on;
+    bool &raised = raised_on.here();
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bmu_prep_kernel<256>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPrepStageMax);

@@ -349,7 +349,8 @@ void launch_fast(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layo
         if (m && m[0] == '1') kern = bmu_filter_fast<T, CPL, NB, RU, 1, false>;
         if (m && m[0] == '2') kern = bmu_filter_fast<T, CPL, NB, RU, 2, false>;
     }
-    static int bpc = 0;
+    static pxsom::PerDevice<int> bpc_on;
+    int &bpc = bpc_on.here();
     if (bpc == 0) {
         int nbk = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, kern, 256, 0) != hipSuccess || nbk < 1) nbk = 2;
@@ -378,7 +379,8 @@ void launch_filter_variant(const T *x, int64_t n, int c, int64_t ldx, char *ws, 
     if constexpr (LDSW) {
         if (lds > 64 * 1024) {   // one workgroup per CU: make it a big one
             auto big = bmu_filter_kernel<T, NCH, CPL, NB, VEC2, PF, TP, LDSW, 512>;
-            static bool raised = false;
+            static pxsom::PerDevice<bool> raised_on;
+            bool &raised = raised_on.here();
             if (!raised) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(big), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           150 * 1024);
@@ -395,7 +397,8 @@ void launch_filter_variant(const T *x, int64_t n, int c, int64_t ldx, char *ws, 
     }
     auto kern = bmu_filter_kernel<T, NCH, CPL, NB, VEC2, PF, TP, LDSW>;
     // persistent grid: exactly as many workgroups as are resident (VGPR- and LDS-limited), capped by the work
-    static int by_regs = 0;
+    static pxsom::PerDevice<int> by_regs_on;
+    int &by_regs = by_regs_on.here();
     if (by_regs == 0) {
         if (LDSW)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),

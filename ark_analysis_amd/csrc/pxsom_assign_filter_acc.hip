@@ -18,7 +18,8 @@ void launch_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layou
     const size_t lds = ((size_t)L.k * c + L.k + 2 * (size_t)L.k * c) * sizeof(double) +
                        (size_t)7 * 2 * 64 * sizeof(half8) + (size_t)7 * 64 * sizeof(f32x4) + kHdrBytes +
                        256 * sizeof(int64_t) + 16;   // + queue of listed rows and its counter
-    static int bpc = 0;
+    static pxsom::PerDevice<int> bpc_on;
+    int &bpc = bpc_on.here();
     if (bpc == 0) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   128 * 1024);

@@ -873,7 +873,8 @@ int launch_step(const T *x, int64_t n, int c, int64_t ldx, double *stats, const 
     const size_t lds = step_lds(c).total;
     auto k1 = batch_step_kernel<T, CPL, 1>;
     auto k2 = batch_step_kernel<T, CPL, 2>;
-    static size_t attr_lds = 0;   // per process = per device (one process per GPU)
+    static pxsom::PerDevice<size_t> attr_lds_on;
+    size_t &attr_lds = attr_lds_on.here();
     if (attr_lds < lds) {
         for (const void *fn : {reinterpret_cast<const void *>(k1), reinterpret_cast<const void *>(k2)}) {
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -907,8 +908,8 @@ bool launch_update_prepare(const StepArgs &sa, int xdim, int ydim, int c, char *
     const size_t lds = ((size_t)k * (c + 1) + k + 2 * kUpdWaves) * 8 + (size_t)k * 4 + 64;
     if (lds > 158 * 1024) return false;
     auto kern = xdim == 10 ? batch_update_prep_kernel<10, 10, 20> : batch_update_prep_kernel<20, 20, 20>;
-    static size_t attr[2] = {0, 0};
-    size_t &have = attr[xdim == 10 ? 0 : 1];
+    static pxsom::PerDevice<size_t> attr[2];
+    size_t &have = attr[xdim == 10 ? 0 : 1].here();
     if (have < lds) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {

@@ -56,8 +56,22 @@ inline bool dtype_ok(int dtype) { return dtype == PXSOM_F32 || dtype == PXSOM_F6
         return CALL;                                                    \
     } while (0)
 
-// number of CUs of the current device (256 on MI355X); cached per process
+// number of CUs of the current device (256 on MI355X); cached per device
 int device_cu_count();
+
+// One slot per device for what the launch code caches (occupancy, raised LDS limits, CU counts): a process that drives
+// several GPUs -- not this build's usual one process per GPU -- gets every device's own values.
+template <typename T>
+struct PerDevice {
+    static constexpr int kSlots = 64;
+    T slot[kSlots] = {};
+    T &here()
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kSlots) dev = 0;
+        return slot[dev];
+    }
+};
 
 // Optional in-library kernel timer (pxsom_prof_*): HIP event pairs recorded on the launch stream
 // immediately around the dominant kernel of a call, so a caller can report that kernel's
