@@ -633,8 +633,17 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
 #pragma unroll
     for (int u = 0; u < kE; u++) wold[u] = sa.w_in[(u < ne && tid + kUpdThreads * u < K * c) ? tid + kUpdThreads * u : 0];
     if (tid == 0) flags[0] = 0;
-    if (sa.stats_zero)
-        for (int e = tid; e < sa.zero_count; e += kUpdThreads) sa.stats_zero[e] = 0.0;
+    // Several workgroups run this kernel: each redoes the update and the norms (they need all of it, and it stays in
+    // their own LDS: no traffic between workgroups), and takes a share of the OUTPUT -- node blocks [b0, b1) of the
+    // duplicate test, fragments, bias and the two codebook copies; workgroup 0 also writes W_g and the header.
+    const int bper = (nb + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int b0 = (int)blockIdx.x * bper, b1 = min(b0 + bper, nb);
+    const int n0 = min(16 * b0, K), n1 = min(16 * b1, K);
+    if (sa.stats_zero) {
+        const int zper = (sa.zero_count + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int z1 = min(((int)blockIdx.x + 1) * zper, sa.zero_count);
+        for (int e = (int)blockIdx.x * zper + tid; e < z1; e += kUpdThreads) sa.stats_zero[e] = 0.0;
+    }
     PXSOM_PHASE(1);
     if (sa.has_update) {
         const double thr = sa.thr;
@@ -695,7 +704,7 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
                         v = gain == 1.0 ? mean : v + gain * (mean - v);
                     }
                     wold[u] = v;
-                    if (sa.w_out) sa.w_out[e] = v;
+                    if (sa.w_out && blockIdx.x == 0) sa.w_out[e] = v;
                 }
                 nd += dnd;
                 j += dj;
@@ -767,7 +776,7 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
     const double scale = ldexp(1.0, e);
     __syncthreads();
     const bool badw = flags[0] != 0 || !(wn2max * scale * scale <= 1.0e30);
-    if (tid == 0) {
+    if (tid == 0 && blockIdx.x == 0) {
         hdr_g->amb_count = 0;
         hdr_g->scale = (float)scale;
         hdr_g->wn_max = badw ? 0.f : (float)(sqrt(wn2max) * scale * (1.0 + 1e-6));
@@ -783,7 +792,7 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
     }
     PXSOM_PHASE(7);
     // ---- exact duplicates of an earlier node: key scan shared by the node's lanes, then channel-by-channel
-    if (has_node) {
+    if (has_node && node >= n0 && node < n1) {
         auto same_as = [&](int prev) {
             bool eq = true;
 #pragma unroll
@@ -809,8 +818,8 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
     __syncthreads();
     // ---- what the generic BMU search reads: fragments, bias, transposed copy (pxsom_prep.h layouts)
     const int nsteps = 2 * nch;
-    for (int f = tid; f < nb * nch * 64; f += kUpdThreads) {
-        const int fl = f & 63, h = (f >> 6) % nch, b = (f >> 6) / nch;
+    for (int f = tid; f < (b1 - b0) * nch * 64; f += kUpdThreads) {
+        const int fl = f & 63, h = (f >> 6) % nch, b = b0 + (f >> 6) / nch;
         const int m = fl & 15, q = fl >> 4;
         const int nd = node_of_row(b, m, nb);
         half8 fhi, flo;
@@ -826,21 +835,22 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
         wfrag[(size_t)(b * nsteps + 2 * h) * 64 + fl] = fhi;
         wfrag[(size_t)(b * nsteps + 2 * h + 1) * 64 + fl] = flo;
     }
-    for (int f = tid; f < nb * 64; f += kUpdThreads) {
-        const int fl = f & 63, b = f >> 6, q = fl >> 4;
+    for (int f = tid; f < (b1 - b0) * 64; f += kUpdThreads) {
+        const int fl = f & 63, b = b0 + (f >> 6), q = fl >> 4;
         f32x4 bv;
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
             const int nd = node_of_row(b, q * 4 + rr, nb);
             bv[rr] = nd < K ? biasv[nd] : kNegBig;
         }
-        bias_g[f] = bv;
+        bias_g[(size_t)b * 64 + fl] = bv;
     }
     PXSOM_PHASE(9);
     {   // binary32 copy for the long-list exact kernel (rows zero-padded to cp32 channels)
-        int nd = tid / cp32, j = tid - nd * cp32;
+        const int first = n0 * cp32 + tid;
+        int nd = first / cp32, j = first - nd * cp32;
         const int dn = kUpdThreads / cp32, dj = kUpdThreads % cp32;
-        for (int e2 = tid; e2 < K * cp32; e2 += kUpdThreads) {
+        for (int e2 = first; e2 < n1 * cp32; e2 += kUpdThreads) {
             w32_out[e2] = j < c ? (float)tl[(size_t)nd * c + j] : 0.f;
             nd += dn;
             j += dj;
@@ -850,17 +860,11 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
             }
         }
     }
-    if (wt_out) {
-        int j = tid / K, nd = tid - j * K;
-        const int dj = kUpdThreads / K, dn = kUpdThreads % K;
-        for (int e2 = tid; e2 < K * c; e2 += kUpdThreads) {
-            wt_out[e2] = tl[(size_t)nd * c + j];
-            j += dj;
-            nd += dn;
-            if (nd >= K) {
-                nd -= K;
-                j++;
-            }
+    if (wt_out && n1 > n0) {   // [c][K]: this workgroup's nodes of every channel (runs of n1 - n0 consecutive words)
+        const int span = n1 - n0;
+        for (int e2 = tid; e2 < span * c; e2 += kUpdThreads) {
+            const int j = e2 / span, nd = n0 + (e2 - j * span);
+            wt_out[(size_t)j * K + nd] = tl[(size_t)nd * c + j];
         }
     }
     PXSOM_PHASE(10);
@@ -919,7 +923,16 @@ bool launch_update_prepare(const StepArgs &sa, int xdim, int ydim, int c, char *
         have = lds;
     }
     double *wt_out = L.has_wt() ? reinterpret_cast<double *>(ws + L.off_wt) : nullptr;
-    hipLaunchKernelGGL(kern, dim3(1), dim3(kUpdThreads), lds, st, sa, c, reinterpret_cast<AssignHdr *>(ws),
+    // workgroups: each redoes the update, the output (duplicates, fragments, bias, copies) is shared out by node
+    // blocks -- 4 blocks of 16 nodes each at K = 400 (7 workgroups), 2 at K = 100 (4 workgroups)
+    static int share = -1;
+    if (share < 0) {
+        const char *e = getenv("PXSOM_UPDATE_SHARE");
+        share = !(e && e[0] == '0');
+    }
+    const int bper = xdim == 10 ? 2 : 4;
+    const int grid = share ? (L.nb + bper - 1) / bper : 1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kUpdThreads), lds, st, sa, c, reinterpret_cast<AssignHdr *>(ws),
                        reinterpret_cast<half8 *>(ws + L.off_wfrag), reinterpret_cast<f32x4 *>(ws + L.off_bias), wt_out, L.nb,
                        L.nch, L.cpl, L.idx_bits, pl, reinterpret_cast<float *>(ws + L.off_w32), L.cp32);
     const hipError_t e = hipGetLastError();
