@@ -33,8 +33,11 @@ import scipy.ndimage as ndimage  # noqa: E402
 from tests import oracle_binding as ob  # noqa: E402
 
 
+OUT_DIR = os.environ.get("PXSOM_GOLDEN_OUT", HERE)     # tests/test_golden_regenerates.py writes to a scratch directory
+
+
 def save(name, **arrays):
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(OUT_DIR, name + ".npz")
     np.savez_compressed(path, **arrays)
     print("wrote", os.path.relpath(path, ROOT), {k: getattr(v, "shape", None) for k, v in arrays.items()})
 
@@ -500,7 +503,7 @@ def g10_pixel_cluster_mask():
     h, w, k = 37, 41, 12
     keep = np.sort(rs.choice(h * w, size=1100, replace=False))
     som = rs.randint(1, k + 1, size=keep.size)
-    som_to_meta = rs.choice([2, 5, 7, 11], size=k + 1)              # ids 1..4 differ from the labels
+    som_to_meta = rs.randint(1, 5, size=k + 1)
     meta_to_id = {1: 7, 2: 300, 3: 2, 4: 41}
     table = pd.DataFrame({"chan0": rs.rand(keep.size), "fov": "fov0", "row_index": keep // w, "column_index": keep % w,
                           "pixel_som_cluster": som, "pixel_meta_cluster": som_to_meta[som].astype(np.float64)})
