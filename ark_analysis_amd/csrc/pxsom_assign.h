@@ -37,6 +37,11 @@ struct StepArgs {
     int has_update;
     double thr, lg;            // schedule of the pending update (step g-1): window threshold, log(1 - alpha)
     float tol_rel, tol_abs;    // filter tolerance coefficients (depend on c only: computed on the host)
+    // two-level row view of a scheduled step (fused kernel only): row f of the step is
+    // x[(f / group_w) * group_stride + (f % group_w) * ldx] -- group_w consecutive rows (the phases the step
+    // takes) out of every `phases` rows; group_w == 1: a plain strided view (ldx is then ignored)
+    int group_w = 1;
+    int64_t group_stride = 0;
 };
 
 struct Layout {
@@ -104,7 +109,7 @@ template <typename T>
 bool filter_fast_path(const T *x, int64_t n, int c, int64_t ldx, const Layout &L);
 // fused mini-batch step (pxsom_batch_step.hip): which shapes it covers, and its launch
 template <typename T>
-bool step_fused_shape(const T *x, int64_t n, int c, int64_t ldx, int xdim, int ydim);
+bool step_fused_shape(const T *x, int64_t n, int c, int64_t ldx, int xdim, int ydim, int64_t group_stride = 0);
 template <typename T>
 int launch_batch_step(const T *x, int64_t n, int c, int64_t ldx, double *stats, const StepArgs &sa,
                       int tiles_per_wave, hipStream_t st);

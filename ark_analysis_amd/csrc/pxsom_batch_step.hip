@@ -144,12 +144,19 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
     // ---- P0: everything that does not depend on the codebook is requested first --------------------------
     // rows of this wave's tiles (rows past the end re-read the last row and are ignored afterwards)
     P2 raw[TPW][NP];
+    const unsigned group_w = (unsigned)sa.group_w;
     auto load_rows = [&](int64_t blk) {
 #pragma unroll
         for (int t = 0; t < TPW; t++) {
             int64_t row = blk * kRowsPerWg + (int64_t)wv * kRowsPerWave + t * 16 + pix;
             if (row > n - 1) row = n - 1;
-            const T *rp = x + row * ldx;
+            const T *rp;
+            if (group_w == 1u) {
+                rp = x + row * ldx;
+            } else {   // a scheduled step: group_w consecutive rows out of every `phases` (rows per step < 2^32: host check)
+                const unsigned grp = (unsigned)row / group_w, sub = (unsigned)row - grp * group_w;
+                rp = x + (int64_t)grp * sa.group_stride + (int64_t)sub * ldx;
+            }
 #pragma unroll
             for (int p = 0; p < NP; p++) {
                 int ch = q * CPL + 2 * p;
@@ -890,8 +897,10 @@ int launch_step(const T *x, int64_t n, int c, int64_t ldx, double *stats, const 
     }
     const int tpw = tiles_per_wave == 1 ? 1 : 2;
     const int64_t rows_per_wg = (int64_t)kStepWaves * 16 * tpw;
-    int grid = (int)std::min<int64_t>((n + rows_per_wg - 1) / rows_per_wg, (int64_t)pxsom::device_cu_count());
-    if (grid < 1) grid = 1;
+    // a step larger than one block per CU: the fewest rounds, spread evenly (853 blocks -> 214 workgroups x 4, not 256 x 3.3)
+    const int64_t nblocks = std::max<int64_t>((n + rows_per_wg - 1) / rows_per_wg, 1), cus = pxsom::device_cu_count();
+    const int64_t rounds = (nblocks + cus - 1) / cus;
+    const int grid = (int)((nblocks + rounds - 1) / rounds);
     hipLaunchKernelGGL(tpw == 1 ? k1 : k2, dim3(grid), dim3(kStepThreads), lds, st, x, n, c, ldx, stats, sa);
     PXSOM_LAUNCH_CHECK("batch_step_kernel");
     return PXSOM_OK;
@@ -942,10 +951,10 @@ bool launch_update_prepare(const StepArgs &sa, int xdim, int ydim, int c, char *
 
 // Shapes the fused step kernel covers: the Pixie pixel SOM's -- 10 x 10 grid, even c <= 32, pair-aligned rows.
 template <typename T>
-bool step_fused_shape(const T *x, int64_t n, int c, int64_t ldx, int xdim, int ydim)
+bool step_fused_shape(const T *x, int64_t n, int c, int64_t ldx, int xdim, int ydim, int64_t group_stride)
 {
-    return xdim == kXD && ydim == kYD && n >= 1 && c >= 2 && c <= 32 && c % 2 == 0 && ldx % 2 == 0 &&
-           reinterpret_cast<uintptr_t>(x) % (2 * sizeof(T)) == 0;
+    return xdim == kXD && ydim == kYD && n >= 1 && n < (int64_t)1 << 32 && c >= 2 && c <= 32 && c % 2 == 0 && ldx % 2 == 0 &&
+           group_stride % 2 == 0 && reinterpret_cast<uintptr_t>(x) % (2 * sizeof(T)) == 0;
 }
 
 template <typename T>
@@ -960,7 +969,7 @@ int launch_batch_step(const T *x, int64_t n, int c, int64_t ldx, double *stats, 
 }
 
 #define PXSOM_INSTANTIATE_STEP(T)                                                                                   \
-    template bool step_fused_shape<T>(const T *, int64_t, int, int64_t, int, int);                                  \
+    template bool step_fused_shape<T>(const T *, int64_t, int, int64_t, int, int, int64_t);                         \
     template int launch_batch_step<T>(const T *, int64_t, int, int64_t, double *, const StepArgs &, int, hipStream_t);
 PXSOM_INSTANTIATE_STEP(float)
 PXSOM_INSTANTIATE_STEP(double)

@@ -10,7 +10,9 @@
 //   pxsom_cluster_sums  replaces the pandas groupby-sum of compute_pixel_cluster_channel_avg
 //                       (pixel_cluster_utils.py:369-404) and is the accumulation half of the batch rule.
 //   pxsom_batch_update  the batch rule's codebook update (oracle of record: orc_batch_update).
+#include <algorithm>
 #include <cfloat>
+#include <vector>
 #include <cmath>
 
 #include "pxsom_assign.h"
@@ -1510,15 +1512,128 @@ PXSOM_EXPORT int pxsom_batch_update_prepare(double *w_dev, int xdim, int ydim, i
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-inline void batch_schedule(int g, int total, double a0, double a1, double r0, double r1, double *thr, double *alpha)
+// (thr, alpha) of the online schedule at position pos / span of the run (pos = rows presented before the step, in
+// phases: orc_som_batch_sched)
+inline void batch_schedule(int64_t pos, int64_t span, double a0, double a1, double r0, double r1, double *thr, double *alpha)
 {
-    double t = r0 - (r0 - r1) * (double)g / (double)total;
+    double t = r0 - (r0 - r1) * (double)pos / (double)span;
     if (t < 1.0) t = 0.5;
     *thr = t;
-    *alpha = a0 - (a0 - a1) * (double)g / (double)total;
+    *alpha = a0 - (a0 - a1) * (double)pos / (double)span;
 }
 
-inline int64_t step_rows(int64_t n, int m, int t) { return n > t ? (n - t + m - 1) / m : 0; }
+// A pass's schedule: row i belongs to phase i % phases, step g takes the phases [edges[g], edges[g+1]).
+struct Sched {
+    int phases, steps;
+    const int32_t *edges;   // host, [steps + 1]
+    int e0(int g) const { return edges[g]; }
+    int width(int g) const { return edges[g + 1] - edges[g]; }
+    int64_t rows(int64_t n, int g) const
+    {
+        const int64_t full = n / phases, rem = n % phases;
+        const int64_t part = std::min<int64_t>(std::max<int64_t>(rem - e0(g), 0), width(g));
+        return full * width(g) + part;
+    }
+    int64_t offset(int64_t n, int g) const   // rows of the steps before g
+    {
+        const int64_t full = n / phases, rem = n % phases;
+        return full * e0(g) + std::min<int64_t>(e0(g), rem);
+    }
+    int64_t rows_max(int64_t n) const
+    {
+        int64_t m = 0;
+        for (int g = 0; g < steps; g++) m = std::max(m, rows(n, g));
+        return m;
+    }
+    bool any_wide() const
+    {
+        for (int g = 0; g < steps; g++)
+            if (width(g) > 1) return true;
+        return false;
+    }
+    int64_t pos(int gg) const { return (int64_t)(gg / steps) * phases + e0(gg % steps); }   // of global step gg
+};
+
+int check_sched(const char *fn, int phases, const int32_t *edges, int steps)
+{
+    if (phases < 1 || steps < 1 || steps > PXSOM_MAX_SCHED_STEPS || !edges || edges[0] != 0 || edges[steps] != phases)
+        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "%s: schedule needs 1 <= steps <= %d, edges[0] == 0, edges[steps] == phases", fn,
+                           PXSOM_MAX_SCHED_STEPS);
+    for (int g = 0; g < steps; g++)
+        if (edges[g + 1] < edges[g]) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "%s: schedule edges must not decrease", fn);
+    return PXSOM_OK;
+}
+
+// Steps that take several phases (width > 1) on shapes outside the fused kernel: their rows are gathered ONCE per run
+// into step-contiguous order (the generic search / exact / sums kernels take plain strided matrices).  One work item
+// per (destination row, 16 / 8 / 4 / 2-byte chunk); the step of a destination row by binary search over the
+// closed-form offsets.
+struct SchedArg {
+    int phases, steps;
+    int edges[PXSOM_MAX_SCHED_STEPS + 1];
+};
+
+template <typename V>
+__global__ __launch_bounds__(256) void gather_steps_kernel(const V *__restrict__ x, int64_t n, int cpr, int64_t ldx_v,
+                                                           V *__restrict__ out, SchedArg s)
+{
+    const int64_t full = n / s.phases, rem = n % s.phases;
+    auto off = [&](int g) { return full * s.edges[g] + min((int64_t)s.edges[g], rem); };
+    const int64_t items = n * cpr;
+    for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < items; it += (int64_t)gridDim.x * 256) {
+        const int64_t d = it / cpr;
+        const int ch = (int)(it - d * cpr);
+        int lo = 0, hi = s.steps;   // the step with off(lo) <= d < off(lo + 1)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (off(mid) <= d) lo = mid;
+            else hi = mid;
+        }
+        const int64_t r = d - off(lo);
+        const int w = s.edges[lo + 1] - s.edges[lo];
+        const int64_t src = (r / w) * s.phases + s.edges[lo] + (r % w);
+        out[d * cpr + ch] = x[src * ldx_v + ch];
+    }
+}
+
+template <typename T>
+int launch_gather(const T *x, int64_t n, int c, int64_t ldx, T *out, const Sched &sc, hipStream_t st)
+{
+    SchedArg a;
+    a.phases = sc.phases;
+    a.steps = sc.steps;
+    for (int g = 0; g <= sc.steps; g++) a.edges[g] = sc.edges[g];
+    const size_t rb = (size_t)c * sizeof(T), lb = (size_t)ldx * sizeof(T);
+    const uintptr_t ax = reinterpret_cast<uintptr_t>(x), ao = reinterpret_cast<uintptr_t>(out);
+    const int64_t grid_max = (int64_t)pxsom::device_cu_count() * 16;
+    auto go = [&](auto tag) {
+        typedef decltype(tag) V;
+        const int cpr = (int)(rb / sizeof(V));
+        const int64_t grid = std::min<int64_t>((n * cpr + 255) / 256, grid_max);
+        hipLaunchKernelGGL(gather_steps_kernel<V>, dim3((unsigned)std::max<int64_t>(grid, 1)), dim3(256), 0, st,
+                           reinterpret_cast<const V *>(x), n, cpr, (int64_t)(lb / sizeof(V)), reinterpret_cast<V *>(out), a);
+    };
+    if (rb % 16 == 0 && lb % 16 == 0 && ax % 16 == 0 && ao % 16 == 0) go(uint4{});
+    else if (rb % 8 == 0 && lb % 8 == 0 && ax % 8 == 0 && ao % 8 == 0) go(uint2{});
+    else if (rb % 4 == 0 && lb % 4 == 0 && ax % 4 == 0 && ao % 4 == 0) go((unsigned)0);
+    else go((unsigned short)0);
+    PXSOM_LAUNCH_CHECK("gather_steps_kernel");
+    return PXSOM_OK;
+}
+
+struct TrainWs {
+    size_t assign_ws, off_labels, off_gather, total;
+};
+inline TrainWs train_ws(int64_t n, int c, int k, size_t esize, const Sched &sc)
+{
+    TrainWs w;
+    const int64_t rmax = sc.rows_max(n);
+    w.assign_ws = pxsom_assign_workspace_bytes(rmax, c, k);
+    w.off_labels = pxsom::align_up(w.assign_ws, 256);
+    w.off_gather = w.off_labels + pxsom::align_up((size_t)(rmax > 0 ? rmax : 1) * sizeof(int32_t), 256);
+    w.total = w.off_gather + (sc.any_wide() ? pxsom::align_up((size_t)(n > 0 ? n : 1) * c * esize, 256) : 0);
+    return w;
+}
 }  // namespace
 namespace pxsom {
 int comm_allreduce_sum_f64(pxsom_comm *c, double *buf, size_t count, hipStream_t st);   // pxsom_comm.hip
@@ -1527,39 +1642,52 @@ namespace {
 
 template <typename T>
 int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, double *wbuf, double *ring, int xdim,
-                      int ydim, int m, int g_begin, int g_end, int total, double a0, double a1, double r0, double r1,
-                      char *ws, size_t ws_bytes, int flags, pxsom_comm *comm, hipStream_t st)
+                      int ydim, const Sched &sc, int g_begin, int g_end, int num_passes, double a0, double a1, double r0,
+                      double r1, char *ws, size_t ws_bytes, int flags, pxsom_comm *comm, hipStream_t st)
 {
     const int k = xdim * ydim;
     const size_t nstats = (size_t)k * (c + 1), nw = (size_t)k * c;
-    const int64_t rows_max = step_rows(n, m, 0);
-    const size_t assign_ws = pxsom_assign_workspace_bytes(rows_max, c, k);
-    int32_t *labels = reinterpret_cast<int32_t *>(ws + pxsom::align_up(assign_ws, 256));
+    const TrainWs tw = train_ws(n, c, k, sizeof(T), sc);
+    const size_t assign_ws = tw.assign_ws;
+    int32_t *labels = reinterpret_cast<int32_t *>(ws + tw.off_labels);
+    T *xg = reinterpret_cast<T *>(ws + tw.off_gather);
+    const int64_t span = (int64_t)num_passes * sc.phases;
     static int tpw = 0;   // 16-row tiles per wave of the fused step (tuning hook)
     if (tpw == 0) {
         const char *e = getenv("PXSOM_STEP_TPW");
         tpw = e ? atoi(e) : 1;   // measured on config 2 (16 K-row steps): 1 tile per wave 0.93 ms / pass, 2 tiles 0.99
         if (tpw != 2) tpw = 1;
     }
-    for (int g = g_begin; g < g_end; g++) {
-        const int t = g % m;
-        const int64_t rows = step_rows(n, m, t);
-        const T *xv = x + (size_t)t * ldx;
-        const int64_t ldv = ldx * m;
-        double *w_prev = wbuf + (size_t)((g + 1) % 2) * nw, *w_cur = wbuf + (size_t)(g % 2) * nw;
-        double *s_prev = ring + (size_t)((g + 2) % 3) * nstats, *s_cur = ring + (size_t)(g % 3) * nstats,
-               *s_next = ring + (size_t)((g + 1) % 3) * nstats;
+    // which route a step takes (one decision per run: every step of a shape shares it, and so do all ranks -- the fused
+    // kernel needs rows >= 1, which a rank with a short shard may not have, so empty steps are allowed there)
+    const bool fused_shape = !(flags & PXSOM_TRAIN_UNFUSED) &&
+                             pxsom_bmu::step_fused_shape<T>(x, 1, c, ldx, xdim, ydim, (int64_t)sc.phases * ldx);
+    const bool gathered = !fused_shape && sc.any_wide();
+    if (gathered && g_begin == 0 && n > 0) {
+        int rc = launch_gather<T>(x, n, c, ldx, xg, sc, st);
+        if (rc) return rc;
+    }
+    for (int gg = g_begin; gg < g_end; gg++) {
+        const int g = gg % sc.steps;
+        const int64_t rows = sc.rows(n, g);
+        const int wd = sc.width(g);
+        // the step's rows as a strided matrix: phase view (one phase), or its slice of the gathered copy
+        const T *xv = gathered ? xg + (size_t)sc.offset(n, g) * c : x + (size_t)sc.e0(g) * ldx;
+        const int64_t ldv = gathered ? c : ldx * sc.phases;
+        if (rows >= (int64_t)1 << 31) return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "pxsom_batch_train: a step of %lld rows", (long long)rows);
+        double *w_prev = wbuf + (size_t)((gg + 1) % 2) * nw, *w_cur = wbuf + (size_t)(gg % 2) * nw;
+        double *s_prev = ring + (size_t)((gg + 2) % 3) * nstats, *s_cur = ring + (size_t)(gg % 3) * nstats,
+               *s_next = ring + (size_t)((gg + 1) % 3) * nstats;
         double thr = 0.0, alpha = 0.0;
-        if (g > 0) batch_schedule(g - 1, total, a0, a1, r0, r1, &thr, &alpha);
-        const bool fused = !(flags & PXSOM_TRAIN_UNFUSED) && pxsom_bmu::step_fused_shape<T>(xv, rows, c, ldv, xdim, ydim);
-        if (fused) {
+        if (gg > 0) batch_schedule(sc.pos(gg - 1), span, a0, a1, r0, r1, &thr, &alpha);
+        if (fused_shape) {
             pxsom_bmu::StepArgs sa;
-            sa.w_in = g > 0 ? w_prev : w_cur;
+            sa.w_in = gg > 0 ? w_prev : w_cur;
             sa.w_out = w_cur;
             sa.stats_prev = s_prev;
             sa.stats_zero = s_next;
             sa.zero_count = (int)nstats;
-            sa.has_update = g > 0 ? 1 : 0;
+            sa.has_update = gg > 0 ? 1 : 0;
             sa.thr = thr;
             sa.lg = log1p(-alpha);
             // coefficients of the filter's rigorous |score - exact| bound (DESIGN.md "K7 error bound"; 7 index bits
@@ -1567,7 +1695,12 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
             sa.tol_rel = (float)(2.5 * (ldexp(1.0, -(23 - 7)) + (3.0 * c + 2.0) * ldexp(1.0, -24) + ldexp(1.0, -19) +
                                         ldexp(1.0, -23)));
             sa.tol_abs = (float)(2.5 * ldexp(1.0, -24) * sqrt((double)c));
-            int rc = pxsom_bmu::launch_batch_step<T>(xv, rows, c, ldv, s_cur, sa, tpw, st);
+            sa.group_w = wd > 1 ? wd : 1;
+            sa.group_stride = (int64_t)sc.phases * ldx;
+            // (an empty step -- a rank whose shard is shorter than the schedule -- still launches: the update, the
+            // clearing of the next buffer and W_g are the kernel's, and every rank must take the same route)
+            int rc = pxsom_bmu::launch_batch_step<T>(x + (size_t)sc.e0(g) * ldx, rows, c, wd > 1 ? ldx : ldx * sc.phases,
+                                                     s_cur, sa, tpw, st);
             if (rc) return rc;
             if (comm && (rc = pxsom::comm_allreduce_sum_f64(comm, s_cur, nstats, st))) return rc;
             continue;
@@ -1577,12 +1710,12 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
         if (!(flags & PXSOM_TRAIN_UNFUSED)) {
             const pxsom_bmu::Layout L = pxsom_bmu::make_layout(rows, c, k);
             pxsom_bmu::StepArgs sa;
-            sa.w_in = g > 0 ? w_prev : w_cur;
-            sa.w_out = g > 0 ? w_cur : nullptr;
+            sa.w_in = gg > 0 ? w_prev : w_cur;
+            sa.w_out = gg > 0 ? w_cur : nullptr;
             sa.stats_prev = s_prev;
             sa.stats_zero = s_next;
             sa.zero_count = (int)nstats;
-            sa.has_update = g > 0 ? 1 : 0;
+            sa.has_update = gg > 0 ? 1 : 0;
             sa.thr = thr;
             sa.lg = log1p(-alpha);
             sa.tol_rel = (float)(2.5 * (ldexp(1.0, -(23 - L.idx_bits)) + (3.0 * c + 2.0) * ldexp(1.0, -24) + ldexp(1.0, -19) +
@@ -1601,7 +1734,7 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
                 continue;
             }
         }
-        if (g > 0) {
+        if (gg > 0) {
             PXSOM_HIP_TRY(hipMemcpyAsync(w_cur, w_prev, nw * sizeof(double), hipMemcpyDeviceToDevice, st));
             int rc = pxsom_batch_update(w_cur, xdim, ydim, c, s_prev, s_prev + nw, thr, alpha, st);
             if (rc) return rc;
@@ -1611,17 +1744,62 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
         if (rc) return rc;
         if (comm && (rc = pxsom::comm_allreduce_sum_f64(comm, s_cur, nstats, st))) return rc;
     }
+    (void)ws_bytes;
     return PXSOM_OK;
+}
+
+inline std::vector<int32_t> equal_edges(int m)
+{
+    std::vector<int32_t> e((size_t)m + 1);
+    for (int t = 0; t <= m; t++) e[(size_t)t] = t;
+    return e;
 }
 
 }  // namespace
 
+PXSOM_EXPORT size_t pxsom_batch_train_sched_workspace_bytes(int64_t n, int c, int k, int dtype, int phases,
+                                                            const int32_t *edges, int steps_per_pass)
+{
+    if (n < 0 || c < 1 || c > PXSOM_MAX_CHANNELS || k < 1 || k > PXSOM_MAX_NODES || !pxsom::dtype_ok(dtype)) return 0;
+    if (check_sched("pxsom_batch_train_sched_workspace_bytes", phases, edges, steps_per_pass)) return 0;
+    const Sched sc{phases, steps_per_pass, edges};
+    return train_ws(n, c, k, dtype == PXSOM_F64 ? 8 : (dtype == PXSOM_F32 ? 4 : 2), sc).total;
+}
+
 PXSOM_EXPORT size_t pxsom_batch_train_workspace_bytes(int64_t n, int batch_steps, int c, int k)
 {
-    if (n < 0 || batch_steps < 1 || c < 1 || c > PXSOM_MAX_CHANNELS || k < 1 || k > PXSOM_MAX_NODES) return 0;
-    const int64_t rows_max = step_rows(n, batch_steps, 0);
-    return pxsom::align_up(pxsom_assign_workspace_bytes(rows_max, c, k), 256) +
-           pxsom::align_up((size_t)(rows_max > 0 ? rows_max : 1) * sizeof(int32_t), 256);
+    if (batch_steps < 1 || batch_steps > PXSOM_MAX_SCHED_STEPS) return 0;
+    const std::vector<int32_t> e = equal_edges(batch_steps);
+    return pxsom_batch_train_sched_workspace_bytes(n, c, k, PXSOM_F64, batch_steps, e.data(), batch_steps);
+}
+
+PXSOM_EXPORT int pxsom_batch_train_sched(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, double *wbuf_dev,
+                                         double *stats_ring_dev, int xdim, int ydim, int phases, const int32_t *edges,
+                                         int steps_per_pass, int g_begin, int g_end, int num_passes, double a0, double a1,
+                                         double r0, double r1, void *workspace_dev, size_t workspace_bytes, int flags,
+                                         pxsom_comm *comm, void *stream)
+{
+    int rc = check_matrix("pxsom_batch_train_sched", x_dev, n, c, ldx, dtype);
+    if (rc) return rc;
+    if (xdim < 1 || ydim < 1 || (int64_t)xdim * ydim > PXSOM_MAX_NODES)
+        return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "pxsom_batch_train_sched: grid %dx%d outside [1, %d] nodes", xdim, ydim,
+                           PXSOM_MAX_NODES);
+    if ((rc = check_sched("pxsom_batch_train_sched", phases, edges, steps_per_pass))) return rc;
+    if (num_passes < 1 || g_begin < 0 || g_end < g_begin || (int64_t)g_end > (int64_t)num_passes * steps_per_pass)
+        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_batch_train_sched: steps [%d, %d) of %d passes x %d", g_begin, g_end,
+                           num_passes, steps_per_pass);
+    if (!wbuf_dev || !stats_ring_dev) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_batch_train_sched: null pointer");
+    const size_t need = pxsom_batch_train_sched_workspace_bytes(n, c, xdim * ydim, dtype, phases, edges, steps_per_pass);
+    if (!workspace_dev || workspace_bytes < need)
+        return pxsom::fail(PXSOM_ERR_WORKSPACE, "pxsom_batch_train_sched: workspace %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (g_begin == 0)   // the first step's statistics buffer; every later one is cleared by the step before it
+        PXSOM_HIP_TRY(hipMemsetAsync(stats_ring_dev, 0, (size_t)xdim * ydim * (c + 1) * sizeof(double), st));
+    const Sched sc{phases, steps_per_pass, edges};
+    PXSOM_DISPATCH_DTYPE(dtype, x_dev, xp,
+                         train_steps_typed<T>(xp, n, c, ldx, dtype, wbuf_dev, stats_ring_dev, xdim, ydim, sc, g_begin, g_end,
+                                              num_passes, a0, a1, r0, r1, reinterpret_cast<char *>(workspace_dev),
+                                              workspace_bytes, flags, comm, st));
 }
 
 PXSOM_EXPORT int pxsom_batch_train_steps(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, double *wbuf_dev,
@@ -1634,33 +1812,56 @@ PXSOM_EXPORT int pxsom_batch_train_steps(const void *x_dev, int64_t n, int c, in
                                            flags, nullptr, stream);
 }
 
+// equal steps (the round-1/2 entry points): total_steps = num_passes * batch_steps
 PXSOM_EXPORT int pxsom_batch_train_steps_sharded(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype,
                                                  double *wbuf_dev, double *stats_ring_dev, int xdim, int ydim,
                                                  int batch_steps, int g_begin, int g_end, int total_steps, double a0,
                                                  double a1, double r0, double r1, void *workspace_dev,
                                                  size_t workspace_bytes, int flags, pxsom_comm *comm, void *stream)
 {
-    int rc = check_matrix("pxsom_batch_train_steps", x_dev, n, c, ldx, dtype);
-    if (rc) return rc;
-    if (xdim < 1 || ydim < 1 || (int64_t)xdim * ydim > PXSOM_MAX_NODES)
-        return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "pxsom_batch_train_steps: grid %dx%d outside [1, %d] nodes", xdim, ydim,
-                           PXSOM_MAX_NODES);
-    if (batch_steps < 1 || total_steps < 1 || g_begin < 0 || g_end < g_begin || g_end > total_steps)
-        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_batch_train_steps: steps [%d, %d) of %d, %d per pass", g_begin,
-                           g_end, total_steps, batch_steps);
-    if (!wbuf_dev || !stats_ring_dev) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_batch_train_steps: null pointer");
-    const size_t need = pxsom_batch_train_workspace_bytes(n, batch_steps, c, xdim * ydim);
-    if (!workspace_dev || workspace_bytes < need)
-        return pxsom::fail(PXSOM_ERR_WORKSPACE, "pxsom_batch_train_steps: workspace %zu < %zu bytes", workspace_bytes, need);
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (g_begin == 0)   // the first step's statistics buffer; every later one is cleared by the step before it
-        PXSOM_HIP_TRY(hipMemsetAsync(stats_ring_dev, 0, (size_t)xdim * ydim * (c + 1) * sizeof(double), st));
-    PXSOM_DISPATCH_DTYPE(dtype, x_dev, xp,
-                         train_steps_typed<T>(xp, n, c, ldx, dtype, wbuf_dev, stats_ring_dev, xdim, ydim, batch_steps,
-                                              g_begin, g_end, total_steps, a0, a1, r0, r1,
-                                              reinterpret_cast<char *>(workspace_dev), workspace_bytes, flags, comm, st));
+    if (batch_steps < 1 || batch_steps > PXSOM_MAX_SCHED_STEPS || total_steps < 1 || total_steps % batch_steps != 0)
+        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_batch_train_steps: steps [%d, %d) of %d, %d per pass (1..%d, whole passes)",
+                           g_begin, g_end, total_steps, batch_steps, PXSOM_MAX_SCHED_STEPS);
+    const std::vector<int32_t> e = equal_edges(batch_steps);
+    return pxsom_batch_train_sched(x_dev, n, c, ldx, dtype, wbuf_dev, stats_ring_dev, xdim, ydim, batch_steps, e.data(),
+                                   batch_steps, g_begin, g_end, total_steps / batch_steps, a0, a1, r0, r1, workspace_dev,
+                                   workspace_bytes, flags, comm, stream);
 }
 
+namespace {
+int finish_at(const double *wbuf_dev, const double *stats_ring_dev, int xdim, int ydim, int c, int steps_done, int64_t pos,
+              int64_t span, double a0, double a1, double r0, double r1, double *w_out_dev, void *stream)
+{
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int k = xdim * ydim, g = steps_done - 1;
+    const size_t nw = (size_t)k * c, nstats = (size_t)k * (c + 1);
+    const double *w_last = wbuf_dev + (size_t)(g % 2) * nw, *s_last = stats_ring_dev + (size_t)(g % 3) * nstats;
+    if (w_out_dev != w_last)
+        PXSOM_HIP_TRY(hipMemcpyAsync(w_out_dev, w_last, nw * sizeof(double), hipMemcpyDeviceToDevice, st));
+    double thr, alpha;
+    batch_schedule(pos, span, a0, a1, r0, r1, &thr, &alpha);
+    return pxsom_batch_update(w_out_dev, xdim, ydim, c, s_last, s_last + nw, thr, alpha, stream);
+}
+}  // namespace
+
+PXSOM_EXPORT int pxsom_batch_train_sched_finish(const double *wbuf_dev, const double *stats_ring_dev, int xdim, int ydim,
+                                                int c, int phases, const int32_t *edges, int steps_per_pass, int steps_done,
+                                                int num_passes, double a0, double a1, double r0, double r1,
+                                                double *w_out_dev, void *stream)
+{
+    if (xdim < 1 || ydim < 1 || (int64_t)xdim * ydim > PXSOM_MAX_NODES || c < 1 || c > PXSOM_MAX_CHANNELS)
+        return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "pxsom_batch_train_finish: shape %dx%d x %d", xdim, ydim, c);
+    int rc = check_sched("pxsom_batch_train_finish", phases, edges, steps_per_pass);
+    if (rc) return rc;
+    if (!wbuf_dev || !stats_ring_dev || !w_out_dev || num_passes < 1 || steps_done < 1 ||
+        (int64_t)steps_done > (int64_t)num_passes * steps_per_pass)
+        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_batch_train_finish: bad arguments");
+    const Sched sc{phases, steps_per_pass, edges};
+    return finish_at(wbuf_dev, stats_ring_dev, xdim, ydim, c, steps_done, sc.pos(steps_done - 1), (int64_t)num_passes * phases,
+                     a0, a1, r0, r1, w_out_dev, stream);
+}
+
+// equal steps: the position of step g of total_steps is g / total_steps whatever the steps per pass
 PXSOM_EXPORT int pxsom_batch_train_finish(const double *wbuf_dev, const double *stats_ring_dev, int xdim, int ydim, int c,
                                           int steps_done, int total_steps, double a0, double a1, double r0, double r1,
                                           double *w_out_dev, void *stream)
@@ -1669,13 +1870,18 @@ PXSOM_EXPORT int pxsom_batch_train_finish(const double *wbuf_dev, const double *
         return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "pxsom_batch_train_finish: shape %dx%d x %d", xdim, ydim, c);
     if (!wbuf_dev || !stats_ring_dev || !w_out_dev || steps_done < 1 || steps_done > total_steps)
         return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_batch_train_finish: bad arguments");
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int k = xdim * ydim, g = steps_done - 1;
-    const size_t nw = (size_t)k * c, nstats = (size_t)k * (c + 1);
-    const double *w_last = wbuf_dev + (size_t)(g % 2) * nw, *s_last = stats_ring_dev + (size_t)(g % 3) * nstats;
-    if (w_out_dev != w_last)
-        PXSOM_HIP_TRY(hipMemcpyAsync(w_out_dev, w_last, nw * sizeof(double), hipMemcpyDeviceToDevice, st));
-    double thr, alpha;
-    batch_schedule(g, total_steps, a0, a1, r0, r1, &thr, &alpha);
-    return pxsom_batch_update(w_out_dev, xdim, ydim, c, s_last, s_last + nw, thr, alpha, stream);
+    return finish_at(wbuf_dev, stats_ring_dev, xdim, ydim, c, steps_done, steps_done - 1, total_steps, a0, a1, r0, r1, w_out_dev,
+                     stream);
+}
+
+// 1: the steps of this (matrix, shape, schedule) take the one-launch fused kernel; 0: the launch-per-phase route.  A
+// multi-rank job agrees on the route before it starts (MIN over the ranks; PXSOM_TRAIN_UNFUSED for everyone otherwise):
+// the two routes produce the same statistics but round the codebook's last bits differently.
+PXSOM_EXPORT int pxsom_batch_train_fused_route(const void *x_dev, int c, int64_t ldx, int dtype, int xdim, int ydim, int phases)
+{
+    if (!pxsom::dtype_ok(dtype) || phases < 1) return 0;
+    const int64_t gs = (int64_t)phases * ldx;
+    if (dtype == PXSOM_F32) return pxsom_bmu::step_fused_shape<float>(static_cast<const float *>(x_dev), 1, c, ldx, xdim, ydim, gs);
+    if (dtype == PXSOM_F16) return pxsom_bmu::step_fused_shape<_Float16>(static_cast<const _Float16 *>(x_dev), 1, c, ldx, xdim, ydim, gs);
+    return pxsom_bmu::step_fused_shape<double>(static_cast<const double *>(x_dev), 1, c, ldx, xdim, ydim, gs);
 }

@@ -7,14 +7,17 @@ This is the throughput-mode rule BASELINE.json's north_star asks for: pixels nev
 GPU; the only exchange is one all-reduce of the [K, C+1] binary64 statistics per
 mini-batch step (18.4 KB at K=100, C=22 -- latency-bound, xGMI bandwidth is irrelevant).
 
-One pass = ``batch_steps`` mini-batch steps; step g (of G = rlen*batch_steps) uses the local
-rows i with i % batch_steps == g % batch_steps:
+One pass runs on a schedule (``ark_analysis_amd.schedule.BatchSchedule``): the local rows are dealt into
+``phases`` phases (row i: phase i % phases), step g takes the phases [edges[g], edges[g+1]):
     labels = BMU(rows, W); S[b] += x_i, n[b] += 1          -> all-reduce(S, n)
-    thr = r0 - (r0-r1) g/G (0.5 once < 1);  alpha = a0 - (a0-a1) g/G
+    f = (rows presented before the step) / (rows of the run)
+    thr = r0 - (r0-r1) f (0.5 once < 1);  alpha = a0 - (a0-a1) f
     W_k += (1 - (1-alpha)^den_k) (num_k/den_k - W_k)
-pxsom_batch_train_steps runs the step loop inside the library: for the register-resident shapes a step is ONE
-launch (the update of step g-1 and the codebook preparation sit at the head of step g's BMU search).
-Oracle of record: oracle/pxsom_oracle.c (orc_som_batch).
+``batch_steps=G`` (an int) is the equal schedule of rounds 1-2 (rows i % G == g); the default is the two-phase
+schedule (8 large steps while the radius is >= 1, 24 small ones in the BMU-only tail: the quality of 64 equal steps in
+half the dependent launches).  pxsom_batch_train_sched runs the step loop inside the library: for the
+register-resident shapes a step is ONE launch (the update of step g-1 and the codebook preparation sit at the head of
+step g's BMU search).  Oracle of record: oracle/pxsom_oracle.c (orc_som_batch_sched).
 """
 from typing import Optional, Sequence, Tuple
 
@@ -24,8 +27,8 @@ import torch.distributed as dist
 
 def batch_schedule(g: int, total_steps: int, alpha_range: Sequence[float],
                    radius_range: Sequence[float]) -> Tuple[float, float]:
-    """(neighbourhood threshold, learning rate) of mini-batch step g -- the online schedule
-    sampled at the step's first presentation."""
+    """(neighbourhood threshold, learning rate) at position g / total_steps of the online schedule (equal steps: step
+    g of total_steps; a scheduled run: phases presented before the step / phases of the run)."""
     a0, a1 = float(alpha_range[0]), float(alpha_range[1])
     r0, r1 = float(radius_range[0]), float(radius_range[1])
     thr = r0 - (r0 - r1) * float(g) / float(total_steps)
@@ -38,10 +41,10 @@ def batch_schedule(g: int, total_steps: int, alpha_range: Sequence[float],
 class HipKernels:
     """The product kernel set: libpxsom.so through the C ABI (no other implementation ships).
 
-    Interface the trainer drives (tests/test_distributed_gloo.py holds an oracle-backed stand-in with the same
-    four methods, for the host logic on CPU):
-        begin(x, w, xdim, ydim, batch_steps)      state for this matrix; W_0 = w
-        steps(x, g0, g1, total, alpha, radius)    mini-batch steps [g0, g1), launched back to back
+    Interface the trainer drives (tests/oracle_backend.py holds an oracle-backed stand-in with the same
+    methods, for the host logic on CPU):
+        begin(x, w, xdim, ydim, schedule)         state for this matrix; W_0 = w
+        steps(x, g0, g1, total, alpha, radius)    mini-batch steps [g0, g1) of total = passes x steps, back to back
         ring(g)                                   statistics of step g: what the ranks all-reduce after it
         finish(steps_done, total, alpha, radius, w)   last pending update; w receives the result
     """
@@ -52,17 +55,23 @@ class HipKernels:
         self._state = None
         self.unfused = bool(unfused)
 
-    def begin(self, x: torch.Tensor, w: torch.Tensor, xdim: int, ydim: int, batch_steps: int) -> None:
+    def begin(self, x: torch.Tensor, w: torch.Tensor, xdim: int, ydim: int, schedule, group=None) -> None:
         n, c = x.shape
         st = self._state
-        if st is None or not st.fits(n, c, xdim, ydim, batch_steps) or st.wbuf.device != x.device:
-            st = self._state = self._sd.BatchTrainState(n, c, xdim, ydim, batch_steps, x.device)
+        if st is None or not st.fits(n, c, xdim, ydim, schedule, x.dtype) or st.wbuf.device != x.device:
+            st = self._state = self._sd.BatchTrainState(n, c, xdim, ydim, schedule, x.device, dtype=x.dtype)
             self._rings = [st.ring[i] for i in range(3)]     # views made once: ring(g) sits in the per-step loop
         st.wbuf[0].copy_(w)
+        # The route (one-launch fused step / launch per phase) is a collective decision: the two routes apply the same
+        # statistics but round the codebook's last bits differently, and a rank with an oddly aligned or empty shard
+        # must not part ways with the others.
+        self._unfused_now = self.unfused
+        if not self.unfused and _world(group) > 1:
+            self._unfused_now = not _all_ranks_ok(self._sd.batch_train_fused_route(x, xdim, ydim, st.schedule), group)
 
     def steps(self, x, g0: int, g1: int, total: int, alpha_range, radius_range, comm=None) -> None:
-        self._sd.batch_train_steps(x, self._state, g0, g1, total, alpha_range, radius_range, unfused=self.unfused,
-                                   comm=comm)
+        self._sd.batch_train_steps(x, self._state, g0, g1, total, alpha_range, radius_range,
+                                   unfused=self._unfused_now, comm=comm)
 
     def exchange(self, group=None):
         """The in-library exchange over ``group`` (an RCCL communicator owned by libpxsom, made once per process
@@ -83,17 +92,18 @@ def _world(group) -> int:
 
 class BatchSOMTrainer:
     """Batch-rule SOM training on this rank's rows; collective when world_size > 1.  One process: the whole
-    run is ONE library call (the step loop lives in libpxsom); several ranks: one call per step with the
-    packed statistics all-reduced in between."""
+    run is ONE library call (the step loop lives in libpxsom); several ranks: the same call with the library's own
+    RCCL exchange behind every step, or one call per step with the packed statistics all-reduced in between.
+    ``batch_steps``: an int (equal steps), "two-phase" / None (the default schedule) or a BatchSchedule."""
 
-    def __init__(self, xdim: int, ydim: int, channels: int, device, batch_steps: int = 64,
+    def __init__(self, xdim: int, ydim: int, channels: int, device, batch_steps=None,
                  alpha_range: Sequence[float] = (0.05, 0.01),
                  radius_range: Optional[Sequence[float]] = None, group=None, kernels=None):
         from .flowsom import default_radius_range
+        from .schedule import resolve
         self.xdim, self.ydim, self.k, self.c = int(xdim), int(ydim), int(xdim * ydim), int(channels)
-        self.batch_steps = int(batch_steps)
-        if self.batch_steps < 1:
-            raise ValueError("batch_steps must be >= 1")
+        self.schedule = resolve(batch_steps)
+        self.batch_steps = self.schedule.steps
         self.alpha_range = tuple(alpha_range)
         self.radius_range = tuple(radius_range) if radius_range is not None else \
             default_radius_range(xdim, ydim)
@@ -109,7 +119,10 @@ class BatchSOMTrainer:
             raise ValueError(f"matrix [{tuple(x_local.shape)}] / codebook [{tuple(w.shape)}] do not match "
                              f"the trainer's {self.k} nodes x {self.c} channels")
         kern = self.kernels
-        kern.begin(x_local, w, self.xdim, self.ydim, self.batch_steps)
+        if isinstance(kern, HipKernels):
+            kern.begin(x_local, w, self.xdim, self.ydim, self.schedule, group=self.group)
+        else:
+            kern.begin(x_local, w, self.xdim, self.ydim, self.schedule)
         if _world(self.group) > 1:
             comm = kern.exchange(self.group) if hasattr(kern, "exchange") else None
             if comm is not None:     # step launches and their all-reduces back to back on one stream, one call
@@ -121,16 +134,40 @@ class BatchSOMTrainer:
         else:
             kern.steps(x_local, 0, total, total, self.alpha_range, self.radius_range)
         kern.finish(total, total, self.alpha_range, self.radius_range, w)
+        if _world(self.group) > 1:
+            # every rank applied the same all-reduced statistics, so the replicas are equal already; the broadcast makes
+            # that unconditional (rank 0's file is the codebook of record) for the price of one 18 KB message
+            dist.broadcast(w, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
         return w
 
 
-_native_comms = {}   # process group -> RankComm | None (decided once per group, the same way on every rank)
+_native_comms = {}   # global ranks of a process group -> RankComm | None (decided once per group, the same on every rank)
+
+
+def _close_native_comms():
+    for comm in list(_native_comms.values()):
+        if comm is not None:
+            try:
+                comm.close()
+            except Exception:   # noqa: BLE001 -- interpreter shutdown: the runtime may be gone already
+                pass
+    _native_comms.clear()
+
+
+import atexit  # noqa: E402
+atexit.register(_close_native_comms)
 
 
 def _all_ranks_ok(ok: bool, group) -> bool:
-    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=_collective_device())
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=_collective_device(group))
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
     return bool(flag.item())
+
+
+def _group_key(group):
+    """What identifies a process group for the communicator cache: its global ranks (an ``id()`` can be reused once the
+    group object is collected)."""
+    return tuple(sorted(dist.get_process_group_ranks(group))) if group is not None else None
 
 
 def native_exchange(group=None):
@@ -139,7 +176,7 @@ def native_exchange(group=None):
     (no RCCL to bind, id not drawn) never leaves the others waiting inside ncclCommInitRank."""
     import os
     import warnings
-    key = id(group) if group is not None else None
+    key = _group_key(group)
     if key in _native_comms:
         return _native_comms[key]
     comm = None
@@ -219,9 +256,9 @@ def barrier() -> None:
         dist.barrier()
 
 
-def _collective_device() -> torch.device:
-    """Where tensors handed to a collective must live: HBM for RCCL, host memory for gloo."""
-    if dist.get_backend() == "nccl":
+def _collective_device(group=None) -> torch.device:
+    """Where tensors handed to a collective of ``group`` must live: HBM for RCCL, host memory for gloo."""
+    if dist.get_backend(group) == "nccl":
         return torch.device("cuda", torch.cuda.current_device())
     return torch.device("cpu")
 
@@ -233,6 +270,24 @@ def broadcast_object(obj, src: int = 0):
     box = [obj]
     dist.broadcast_object_list(box, src=src)
     return box[0]
+
+
+def on_rank0(fn):
+    """``fn()`` of rank 0 on every rank.  An exception on rank 0 travels instead of the result and is re-raised by
+    EVERY rank: work that only rank 0 does in front of a collective must not leave the others waiting in it."""
+    rank, world = context()
+    if world <= 1:
+        return fn()
+    box = None
+    if rank == 0:
+        try:
+            box = (True, fn())
+        except Exception as e:      # noqa: BLE001 -- re-raised below, on every rank
+            box = (False, e)
+    ok, payload = broadcast_object(box, 0)
+    if not ok:
+        raise payload
+    return payload
 
 
 def allgather_objects(obj) -> list:

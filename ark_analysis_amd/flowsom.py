@@ -122,13 +122,16 @@ def _batch_backend():
 
 def som_batch(data, xdim: int = 10, ydim: int = 10, rlen: int = 1,
               alpha_range: Sequence[float] = (0.05, 0.01), radius_range=None, nodes=None, seed=None,
-              batch_steps: int = 64) -> np.ndarray:
-    """Throughput-mode SOM training (the batch rule of DESIGN.md "K6b"; oracle of record ``orc_som_batch``):
-    ``rlen`` passes of ``batch_steps`` mini-batch steps over ``data`` -- THIS RANK's rows when a process group
-    exists (the per-step statistics are all-reduced, every rank returns the same codebook), all rows otherwise.
+              batch_steps=None) -> np.ndarray:
+    """Throughput-mode SOM training (the batch rule of DESIGN.md "K6b"; oracle of record ``orc_som_batch_sched``):
+    ``rlen`` passes over ``data`` -- THIS RANK's rows when a process group exists (the per-step statistics are
+    all-reduced, every rank returns the same codebook), all rows otherwise -- on the schedule ``batch_steps`` names:
+    an int (that many equal mini-batch steps per pass), ``None`` / "two-phase" (the default: 8 large steps while the
+    neighbourhood radius is >= 1, 24 small ones in the BMU-only tail) or a ``schedule.BatchSchedule``.
     Same arguments as :func:`som` otherwise.  Initial nodes: ``nodes`` if given, else
-    ``data[RandomState(seed).choice(n, K, replace=False)]`` of rank 0's rows (broadcast), the rule ``som`` uses.
-    Not the reference's algorithm: labels equal the batch oracle's, not those of an online pyFlowSOM run."""
+    ``rows[RandomState(seed).choice(n, K, replace=False)]`` -- of rank 0's rows when it holds at least K, else of the
+    first K rows of every rank pooled in rank order (a cohort with enough rows never fails because rank 0's share is
+    short).  Not the reference's algorithm: labels equal the batch oracle's, not those of an online pyFlowSOM run."""
     import torch
     from . import distributed
     dev, kernels = _batch_backend()
@@ -136,13 +139,20 @@ def som_batch(data, xdim: int = 10, ydim: int = 10, rlen: int = 1,
     arr = data if isinstance(data, torch.Tensor) else np.asarray(data)
     n, c = int(arr.shape[0]), int(arr.shape[1])
     k = xdim * ydim
+
+    def host_rows(sel):
+        src = arr[sel]
+        return src.cpu().numpy() if hasattr(src, "cpu") else np.asarray(src)
+
     if nodes is None:
-        if rank == 0:
-            if n < k:
-                raise ValueError(f"som needs at least as many rows ({n}) as nodes ({k})")
-            src = arr[np.random.RandomState(seed).choice(n, k, replace=False)]
-            nodes = src.cpu().numpy() if hasattr(src, "cpu") else np.asarray(src)
-        nodes = distributed.broadcast_object(nodes, 0)
+        counts = distributed.allgather_objects(n)
+        if sum(counts) < k:      # decided on the job's row count, the same way on every rank
+            raise ValueError(f"som needs at least as many rows ({sum(counts)}) as nodes ({k})")
+        if counts[0] >= k:
+            nodes = distributed.on_rank0(lambda: host_rows(np.random.RandomState(seed).choice(n, k, replace=False)))
+        else:
+            pool = np.concatenate([p for p in distributed.allgather_objects(host_rows(slice(0, k))) if len(p)])
+            nodes = pool[np.random.RandomState(seed).choice(len(pool), k, replace=False)]
     if radius_range is None:
         radius_range = default_radius_range(xdim, ydim)
     x = _as_device_matrix(arr, dev)

@@ -16,7 +16,7 @@ _NOT_FEATURES = ('fov', 'label', 'cell_size')
 def train_cell_som(fovs, base_dir, cell_table_path, cell_som_cluster_cols,
                    cell_som_input_data, som_weights_name='cell_som_weights.feather',
                    xdim=10, ydim=10, lr_start=0.05, lr_end=0.01, num_passes=1, seed=42,
-                   overwrite=False, normalize=True, *, train_mode="online", batch_steps=64):
+                   overwrite=False, normalize=True, *, train_mode="online", batch_steps=None):
     """Train the cell SOM on ``cell_som_cluster_cols`` of ``cell_som_input_data`` (rows of ``fovs``) and
     store the codebook in ``base_dir/som_weights_name``; returns the ``CellSOMCluster``.
     ``train_mode`` / ``batch_steps`` (keyword-only, beyond the reference): see ``train_pixel_som``."""

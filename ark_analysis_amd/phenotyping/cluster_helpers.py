@@ -64,12 +64,12 @@ class PixieSOMCluster(ABC):
     @abstractmethod
     def __init__(self, weights_path: pathlib.Path, columns: List[str], num_passes: int = 1,
                  xdim: int = 10, ydim: int = 10, lr_start: float = 0.05, lr_end: float = 0.01,
-                 seed=42, *, train_mode: str = "online", batch_steps: int = 64):
+                 seed=42, *, train_mode: str = "online", batch_steps=None):
         if train_mode not in ("online", "batch"):
             raise ValueError("train_mode must be 'online' (the reference's rule) or 'batch', got %r" % (train_mode,))
-        if int(batch_steps) < 1:
-            raise ValueError("batch_steps must be a positive integer")
-        self.train_mode, self.batch_steps = train_mode, int(batch_steps)
+        from ..schedule import resolve
+        resolve(batch_steps)     # ValueError("batch_steps ...") for anything but a positive int / "two-phase" / a schedule
+        self.train_mode, self.batch_steps = train_mode, batch_steps
         # limits of the gfx950 kernels (include/pxsom.h): said here, where the user chose the shape, rather than as
         # a kernel status code in the middle of a run
         if len(columns) > _capi_limits()[0] or int(xdim) * int(ydim) > _capi_limits()[1]:
@@ -116,8 +116,8 @@ class PixieSOMCluster(ABC):
         if self.train_mode == "batch":
             codebook = flowsom.som_batch(data=_as_f64_matrix(data), batch_steps=self.batch_steps, **args)
         else:
-            codebook = flowsom.som(data=_as_f64_matrix(data), **args) if rank == 0 else None
-            codebook = distributed.broadcast_object(codebook, 0)
+            # rank 0 trains, the others receive the codebook -- or rank 0's exception (never a wait without end)
+            codebook = distributed.on_rank0(lambda: flowsom.som(data=_as_f64_matrix(data), **args))
         nodes = self.xdim * self.ydim
         self.weights = pd.DataFrame(np.asarray(codebook).reshape(nodes, -1), columns=data.columns.values)
         if rank == 0:
@@ -153,7 +153,7 @@ class PixelSOMCluster(PixieSOMCluster):
                  weights_path: pathlib.Path, fovs: List[str], columns: List[str],
                  num_passes: int = 1, xdim: int = 10, ydim: int = 10,
                  lr_start: float = 0.05, lr_end: float = 0.01, seed=42, *,
-                 train_mode: str = "online", batch_steps: int = 64):
+                 train_mode: str = "online", batch_steps=None):
         super().__init__(weights_path, columns, num_passes, xdim, ydim, lr_start, lr_end, seed,
                          train_mode=train_mode, batch_steps=batch_steps)
         validate_paths([norm_vals_path, pixel_subset_folder])
@@ -208,7 +208,7 @@ class CellSOMCluster(PixieSOMCluster):
     def __init__(self, cell_data: pd.DataFrame, weights_path: pathlib.Path,
                  fovs: List[str], columns: List[str], num_passes: int = 1,
                  xdim: int = 10, ydim: int = 10, lr_start: float = 0.05, lr_end: float = 0.01,
-                 seed=42, normalize=True, *, train_mode: str = "online", batch_steps: int = 64):
+                 seed=42, normalize=True, *, train_mode: str = "online", batch_steps=None):
         super().__init__(weights_path, columns, num_passes, xdim, ydim, lr_start, lr_end, seed,
                          train_mode=train_mode, batch_steps=batch_steps)
         self.fovs = fovs

@@ -29,13 +29,14 @@ def train_pixel_som(fovs, channels, base_dir,
                     norm_vals_name='post_rowsum_chan_norm.feather',
                     som_weights_name='pixel_som_weights.feather', xdim=10, ydim=10,
                     lr_start=0.05, lr_end=0.01, num_passes=1, seed=42,
-                    overwrite=False, *, train_mode="online", batch_steps=64):
+                    overwrite=False, *, train_mode="online", batch_steps=None):
     """Train the pixel SOM on the sub-sampled tables of ``base_dir/subset_dir`` and store the codebook
     in ``base_dir/som_weights_name``; returns the :class:`~.cluster_helpers.PixelSOMCluster`.
 
-    Beyond the reference (keyword-only): ``train_mode="batch"`` selects the data-parallel batch rule with
-    ``batch_steps`` mini-batch steps per pass (throughput mode; under ``torchrun`` the training tables are
-    sharded by rank and the per-step statistics all-reduced).  The default is the reference's online rule."""
+    Beyond the reference (keyword-only): ``train_mode="batch"`` selects the data-parallel batch rule (throughput mode;
+    under ``torchrun`` the training tables are sharded by rank and the per-step statistics all-reduced) on the schedule
+    ``batch_steps`` names: an int = that many equal mini-batch steps per pass, ``None`` / "two-phase" = the default
+    schedule (``ark_analysis_amd.schedule``).  The default mode is the reference's online rule."""
     distributed.init_from_env()
     subset_root = os.path.join(base_dir, subset_dir)
     norm_file = os.path.join(base_dir, norm_vals_name)

@@ -95,39 +95,61 @@ TRAIN_UNFUSED = 1  # include/pxsom.h PXSOM_TRAIN_UNFUSED
 
 
 class BatchTrainState:
-    """Caller-owned state of ``pxsom_batch_train_steps``: the codebook twin buffer ``wbuf`` [2, K, C], the
+    """Caller-owned state of ``pxsom_batch_train_sched``: the codebook twin buffer ``wbuf`` [2, K, C], the
     rotating statistics ``ring`` [3, K*(C+1)] (float64; ``ring[g % 3]`` is what a multi-rank job all-reduces
-    after step g) and the scratch workspace for ``n`` training rows in ``batch_steps`` mini-batches."""
+    after step g) and the scratch workspace for ``n`` training rows of ``dtype`` on ``schedule`` (an int: that many
+    equal steps per pass)."""
 
-    def __init__(self, n: int, c: int, xdim: int, ydim: int, batch_steps: int, device):
+    def __init__(self, n: int, c: int, xdim: int, ydim: int, schedule, device, dtype=torch.float32):
+        from .schedule import resolve
         self.n, self.c, self.xdim, self.ydim = int(n), int(c), int(xdim), int(ydim)
-        self.k, self.batch_steps = self.xdim * self.ydim, int(batch_steps)
-        self.ws_bytes = _capi.lib().pxsom_batch_train_workspace_bytes(self.n, self.batch_steps, self.c, self.k)
+        self.k, self.schedule, self.dtype = self.xdim * self.ydim, resolve(schedule), dtype
+        self.batch_steps = self.schedule.steps
+        self.edges = self.schedule.edges_array()            # host array handed to every call (kept alive here)
+        self.ws_bytes = _capi.lib().pxsom_batch_train_sched_workspace_bytes(
+            self.n, self.c, self.k, _capi.dtype_code(torch.empty(0, dtype=dtype)), self.schedule.phases,
+            self.edges.ctypes.data, self.schedule.steps)
         if self.ws_bytes == 0:
             raise _capi.PxsomError(f"unsupported batch-training shape n={n} c={c} k={self.k}")
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
         self.wbuf = torch.empty((2, self.k, self.c), dtype=torch.float64, device=device)
         self.ring = torch.zeros((3, self.k * (self.c + 1)), dtype=torch.float64, device=device)
 
-    def fits(self, n: int, c: int, xdim: int, ydim: int, batch_steps: int) -> bool:
-        return (c == self.c and xdim == self.xdim and ydim == self.ydim and batch_steps == self.batch_steps
-                and n <= self.n)
+    def fits(self, n: int, c: int, xdim: int, ydim: int, schedule, dtype=None) -> bool:
+        from .schedule import resolve
+        return (c == self.c and xdim == self.xdim and ydim == self.ydim and resolve(schedule) == self.schedule
+                and n <= self.n and (dtype is None or torch.empty(0, dtype=dtype).element_size()
+                                     <= torch.empty(0, dtype=self.dtype).element_size()))
+
+
+def batch_train_fused_route(x: torch.Tensor, xdim: int, ydim: int, schedule) -> bool:
+    """Whether the steps of this matrix take the one-launch fused kernel (a multi-rank job agrees on the route before
+    it starts: include/pxsom.h pxsom_batch_train_fused_route)."""
+    from .schedule import resolve
+    n, c, ldx, dt = _matrix_args(x)
+    return bool(_capi.lib().pxsom_batch_train_fused_route(x.data_ptr(), c, ldx, dt, int(xdim), int(ydim),
+                                                          resolve(schedule).phases))
 
 
 def batch_train_steps(x: torch.Tensor, state: BatchTrainState, g_begin: int, g_end: int, total_steps: int,
                       alpha_range, radius_range, unfused: bool = False, comm: "RankComm" = None) -> None:
-    """Mini-batch steps [g_begin, g_end) of a batch training run, launched back to back by the library
-    (``state.wbuf[0]`` holds W_0 before step 0; see include/pxsom.h).  ``comm``: the statistics of every step are
-    sum-all-reduced over its ranks right behind the step's launch (every rank makes the same call)."""
+    """Mini-batch steps [g_begin, g_end) of a batch training run of ``total_steps`` = passes x steps per pass, launched
+    back to back by the library (``state.wbuf[0]`` holds W_0 before step 0; see include/pxsom.h).  ``comm``: the
+    statistics of every step are sum-all-reduced over its ranks right behind the step's launch (every rank makes the
+    same call)."""
     n, c, ldx, dt = _matrix_args(x)
-    if not state.fits(n, c, state.xdim, state.ydim, state.batch_steps):
+    if not state.fits(n, c, state.xdim, state.ydim, state.schedule, x.dtype):
         raise ValueError("batch-training state does not fit this matrix")
-    rc = _capi.lib().pxsom_batch_train_steps_sharded(
+    sch = state.schedule
+    if int(total_steps) % sch.steps:
+        raise ValueError("total_steps must be a whole number of passes")
+    rc = _capi.lib().pxsom_batch_train_sched(
         x.data_ptr(), n, c, ldx, dt, state.wbuf.data_ptr(), state.ring.data_ptr(), state.xdim, state.ydim,
-        state.batch_steps, int(g_begin), int(g_end), int(total_steps), float(alpha_range[0]), float(alpha_range[1]),
-        float(radius_range[0]), float(radius_range[1]), state.ws.data_ptr(), state.ws_bytes,
-        TRAIN_UNFUSED if unfused else 0, comm.handle if comm is not None else None, _capi.stream_ptr())
-    _capi.check(rc, "pxsom_batch_train_steps_sharded")
+        sch.phases, state.edges.ctypes.data, sch.steps, int(g_begin), int(g_end), int(total_steps) // sch.steps,
+        float(alpha_range[0]), float(alpha_range[1]), float(radius_range[0]), float(radius_range[1]),
+        state.ws.data_ptr(), state.ws_bytes, TRAIN_UNFUSED if unfused else 0,
+        comm.handle if comm is not None else None, _capi.stream_ptr())
+    _capi.check(rc, "pxsom_batch_train_sched")
 
 
 COMM_ID_BYTES = 128  # include/pxsom.h PXSOM_COMM_ID_BYTES
@@ -192,11 +214,12 @@ def batch_train_finish(state: BatchTrainState, steps_done: int, total_steps: int
                        w_out: torch.Tensor) -> None:
     """Applies the last pending update of a run: ``w_out`` [K, C] receives the codebook after ``steps_done`` steps."""
     w_out = _codebook(w_out)
-    rc = _capi.lib().pxsom_batch_train_finish(
-        state.wbuf.data_ptr(), state.ring.data_ptr(), state.xdim, state.ydim, state.c, int(steps_done),
-        int(total_steps), float(alpha_range[0]), float(alpha_range[1]), float(radius_range[0]),
-        float(radius_range[1]), w_out.data_ptr(), _capi.stream_ptr())
-    _capi.check(rc, "pxsom_batch_train_finish")
+    sch = state.schedule
+    rc = _capi.lib().pxsom_batch_train_sched_finish(
+        state.wbuf.data_ptr(), state.ring.data_ptr(), state.xdim, state.ydim, state.c, sch.phases,
+        state.edges.ctypes.data, sch.steps, int(steps_done), int(total_steps) // sch.steps, float(alpha_range[0]),
+        float(alpha_range[1]), float(radius_range[0]), float(radius_range[1]), w_out.data_ptr(), _capi.stream_ptr())
+    _capi.check(rc, "pxsom_batch_train_sched_finish")
 
 
 ACC_PREPARED = 1  # include/pxsom.h PXSOM_ACC_PREPARED

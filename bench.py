@@ -80,7 +80,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
     ap.add_argument("--fovs-per-gpu", type=int, default=None)
-    ap.add_argument("--batch-steps", type=int, default=64)
+    ap.add_argument("--batch-steps", default="two-phase",
+                    help="training schedule: 'two-phase' (default: 8 large steps while the radius is >= 1, 24 small ones in "
+                         "the BMU-only tail) or an integer = that many equal mini-batch steps per pass (64: rounds 1-2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-online", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (traffic / mfma_util)")
@@ -221,7 +223,9 @@ def main():
     w = w0.clone()
     labels = torch.empty(n_all, dtype=torch.int32, device=dev)
     ws_all = som_device.AssignWorkspace(n_all, C, K, dev) if (not args.one_pass) else som_device.AssignSumsWorkspace(n_all, C, K, dev)
-    trainer = BatchSOMTrainer(XD, YD, C, dev, batch_steps=args.batch_steps)
+    batch_spec = int(args.batch_steps) if str(args.batch_steps).isdigit() else args.batch_steps
+    trainer = BatchSOMTrainer(XD, YD, C, dev, batch_steps=batch_spec)
+    sched = trainer.schedule
     k8_sums = torch.empty((K, C), dtype=torch.float64, device=dev)
     k8_counts = torch.empty(K, dtype=torch.int64, device=dev)
     means = torch.empty((K, C), dtype=torch.float64, device=dev)
@@ -305,7 +309,10 @@ def main():
         "scaling": cfg["scaling"], "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
         "config": {"workload": cfg["desc"].format(u=units_label), "name": args.config,
                    "rows_per_gpu": n_all, "channels": C, "som_nodes": K,
-                   "train_mode": "batch", "batch_steps": args.batch_steps, "train_fraction": cfg["frac"],
+                   "train_mode": "batch", "batch_steps": sched.steps,
+                   "batch_schedule": ("two-phase: %d steps over %d phases, widths %s" % (sched.steps, sched.phases, list(np.diff(sched.edges))))
+                   if str(args.batch_steps) == "two-phase" else "equal steps",
+                   "train_fraction": cfg["frac"],
                    "num_passes": 1, "step": "train + assign + per-cluster mean table",
                    "parallelism": f"{'row' if cfg['kind'] == 'cell' else 'fov'}-shard x{world}",
                    "rccl_ranks": world if use_dist else 0},
@@ -407,11 +414,11 @@ def main():
             w0h = w0.cpu().numpy()
             # the timed training mode at FULL size against its oracle (the bench's own codebook, last timed step)
             tt = time.perf_counter()
-            want_b = ob.som_batch(xt, w0h, XD, YD, 1, (0.05, 0.01), rr, args.batch_steps)
+            want_b = ob.som_batch_sched(xt, w0h, XD, YD, 1, (0.05, 0.01), rr, sched.phases, sched.edges)
             t_b = time.perf_counter() - tt
             got_b = w.cpu().numpy()
             rel = float(np.max(np.abs(got_b - want_b) / np.maximum(np.abs(want_b), 1e-300)))
-            out["batch_train"] = {"rows": n_train, "steps": args.batch_steps,
+            out["batch_train"] = {"rows": n_train, "steps": sched.steps,
                                   "codebook_matches_oracle_rtol_1e-9": bool(np.allclose(got_b, want_b, rtol=1e-9, atol=0)),
                                   "max_rel_err": rel, "oracle_s": round(t_b, 2)}
             rs = np.random.RandomState(7)
@@ -419,6 +426,15 @@ def main():
             tt = time.perf_counter()
             oracle_w = ob.som_online(xt, w0h, XD, YD, 1, (0.05, 0.01), rr, order)
             t_train = time.perf_counter() - tt
+            # quality of the timed mode: mean quantisation error (distance to the BMU) over ALL rows of the batch
+            # codebook against the codebook the online (reference-order) oracle reaches from the same initial nodes
+            def mean_qe(codebook):
+                _, d = som_device.assign(x_all, torch.from_numpy(np.ascontiguousarray(codebook)).to(dev), want_dists=True)
+                return float(d.mean().item())
+            qe_batch, qe_online = mean_qe(got_b), mean_qe(oracle_w)
+            out["batch_train"]["quantisation_error"] = {"batch": qe_batch, "online_oracle": qe_online,
+                                                         "batch_vs_online_pct": round((qe_batch / qe_online - 1.0) * 100.0, 3),
+                                                         "rows": n_all}
             # the reference labels one FOV table per call (cluster_pixels): so does this leg, FOV by FOV, over
             # 8 of the FOVs (~10 s of host work together with the training leg)
             P = cfg["unit_rows"]

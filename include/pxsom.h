@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PXSOM_ABI_VERSION 5
+#define PXSOM_ABI_VERSION 6
 
 typedef enum pxsom_status {
     PXSOM_OK = 0,
@@ -185,6 +185,37 @@ int pxsom_batch_train_finish(const double *wbuf_dev, const double *stats_ring_de
                              int steps_done, int total_steps, double a0, double a1, double r0, double r1,
                              double *w_out_dev, void *stream);
 
+/* ---- batch SOM training on a SCHEDULE (round 3): unequal mini-batch steps ----------------------------------
+ * The rows are dealt into `phases` phases (row i: phase i % phases); step g of a pass takes the phases
+ * [edges[g], edges[g+1]) (edges_host [steps_per_pass + 1], edges[0] == 0, edges[steps_per_pass] == phases,
+ * non-decreasing; steps_per_pass <= PXSOM_MAX_SCHED_STEPS).  Its update is taken at the point of the online schedule
+ * (threshold, alpha) where the rows presented before it end: (pass * phases + edges[g]) / (num_passes * phases).
+ * Equal steps (edges = 0..phases) are pxsom_batch_train_steps, bit for bit.  A step is one latency-bound launch
+ * whatever its size, so a pass is priced in steps: few large steps while the neighbourhood is wide, many small ones
+ * in the BMU-only tail reach the quality of 64 equal steps in half the launches (DESIGN.md "K6b").
+ * State (wbuf_dev, stats_ring_dev), routes, flags and comm as pxsom_batch_train_steps[_sharded]; steps are numbered
+ * over the whole run, g in [0, num_passes * steps_per_pass); the call with g_begin == 0 must come first on a workspace
+ * (it clears ring[0] and, for shapes outside the fused kernel with steps wider than one phase, gathers the rows into
+ * step order inside the workspace -- one extra read + write of the matrix per run).  Every rank runs the same steps.
+ * Oracle of record: oracle/pxsom_oracle.c orc_som_batch_sched.  Reference call replaced: cluster_helpers.py:98-116. */
+#define PXSOM_MAX_SCHED_STEPS 256
+typedef struct pxsom_comm pxsom_comm; /* the library-owned RCCL communicator, below */
+size_t pxsom_batch_train_sched_workspace_bytes(int64_t n, int c, int k, int dtype, int phases, const int32_t *edges_host,
+                                               int steps_per_pass);
+int pxsom_batch_train_sched(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, double *wbuf_dev,
+                            double *stats_ring_dev, int xdim, int ydim, int phases, const int32_t *edges_host,
+                            int steps_per_pass, int g_begin, int g_end, int num_passes, double a0, double a1, double r0,
+                            double r1, void *workspace_dev, size_t workspace_bytes, int flags, pxsom_comm *comm,
+                            void *stream);
+int pxsom_batch_train_sched_finish(const double *wbuf_dev, const double *stats_ring_dev, int xdim, int ydim, int c,
+                                   int phases, const int32_t *edges_host, int steps_per_pass, int steps_done,
+                                   int num_passes, double a0, double a1, double r0, double r1, double *w_out_dev,
+                                   void *stream);
+/* 1 when the steps of this matrix / shape take the one-launch fused kernel, 0 for the launch-per-phase route.  The
+ * ranks of a job agree on the route before the run (MIN over ranks, PXSOM_TRAIN_UNFUSED for all otherwise): the two
+ * routes round the codebook's last bits differently, and every rank must hold the same codebook. */
+int pxsom_batch_train_fused_route(const void *x_dev, int c, int64_t ldx, int dtype, int xdim, int ydim, int phases);
+
 /* ---- the exchange of a multi-rank batch run, inside the library ---------------------------------------
  * One process per GPU, rows sharded by rank: the rule's only exchange is the sum of ring[g % 3] over the ranks
  * after every step.  pxsom_batch_train_steps_sharded is pxsom_batch_train_steps with that all-reduce (RCCL,
@@ -196,7 +227,6 @@ int pxsom_batch_train_finish(const double *wbuf_dev, const double *stats_ring_de
  * pxsom_comm_create -- collective -- with its HIP device current.  Every rank must run the same steps.
  * The reference has no analogue (single-core training, cluster_helpers.py:106-109). */
 #define PXSOM_COMM_ID_BYTES 128
-typedef struct pxsom_comm pxsom_comm;
 int pxsom_comm_bind(const char *librccl_path);
 int pxsom_comm_unique_id(void *id_out, size_t id_bytes);
 int pxsom_comm_create(const void *id, size_t id_bytes, int nranks, int rank, pxsom_comm **out);

@@ -12,8 +12,9 @@ import torch
 class OracleKernels:
     """Same interface as ark_analysis_amd.distributed.HipKernels, backed by oracle/pxsom_oracle.c."""
 
-    def begin(self, x, w, xdim, ydim, batch_steps):
-        self.xdim, self.ydim, self.m = xdim, ydim, batch_steps
+    def begin(self, x, w, xdim, ydim, schedule):
+        from ark_analysis_amd.schedule import resolve
+        self.xdim, self.ydim, self.sch = xdim, ydim, resolve(schedule)
         k, c = w.shape
         self.w = [w.clone(), w.clone()]
         self.rings = [torch.zeros(k * (c + 1), dtype=torch.float64) for _ in range(3)]
@@ -25,7 +26,8 @@ class OracleKernels:
         from tests import oracle_binding as ob
         from ark_analysis_amd.distributed import batch_schedule
         k, c = w.shape
-        thr, alpha = batch_schedule(g, total, alpha_range, radius_range)
+        passes = total // self.sch.steps
+        thr, alpha = batch_schedule(self.sch.position(g), passes * self.sch.phases, alpha_range, radius_range)
         st = self.rings[g % 3]
         return torch.from_numpy(ob.batch_update(w.numpy(), self.xdim, self.ydim, st[: k * c].view(k, c).numpy(),
                                                 st[k * c:].numpy().astype(np.int64), thr, alpha))
@@ -37,7 +39,8 @@ class OracleKernels:
                 self.w[g % 2] = self._update(self.w[(g - 1) % 2], g - 1, total, alpha_range, radius_range)
             w = self.w[g % 2]
             k, c = w.shape
-            xn = np.ascontiguousarray(x[(g % self.m)::self.m].numpy(), dtype=np.float64).reshape(-1, c)
+            rows = self.sch.rows_of_step(x.shape[0], g)
+            xn = np.ascontiguousarray(x.numpy()[rows], dtype=np.float64).reshape(-1, c)
             lab, _ = ob.map_data_to_nodes(w.numpy(), xn)
             s, cnt = ob.cluster_sums(xn, lab, k)
             st = self.rings[g % 3]
