@@ -100,11 +100,11 @@ __host__ __device__ inline int node_of_row(int b, int m, int nb)
 // [k*c sums | k counts] for every row it does not list
 template <typename T>
 void launch_filter_any(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L,
-                       int32_t *labels, double *stats, const double *w, hipStream_t st);
+                       int32_t *labels, double *stats, const double *w, hipStream_t st, bool fixed = false);
 // the accumulating variant (pxsom_assign_filter_acc.hip): also settles its listed rows itself
 template <typename T>
 void launch_filter_fast_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels,
-                            double *stats, const double *w, hipStream_t st);
+                            double *stats, const double *w, hipStream_t st, bool fixed = false);
 template <typename T>
 bool filter_fast_path(const T *x, int64_t n, int c, int64_t ldx, const Layout &L);
 // fused mini-batch step (pxsom_batch_step.hip): which shapes it covers, and its launch
@@ -120,9 +120,11 @@ bool launch_update_prepare(const StepArgs &sa, int xdim, int ydim, int c, char *
 
 // pxsom_assign with the batch rule's accumulation fused in (pxsom_assign.hip).  *fused = false: the shape
 // is outside the fused path, nothing was done, the caller runs assign + cluster sums separately.
+// fixed: the workgroup tables are 64-bit fixed point (pxsom_assign_sums: sums within 2^-38 of the codebook's largest
+// magnitude per value instead of the exact binary64 sums the batch rule's tests pin; 3.4x the LDS atomic rate)
 int assign_accumulate(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev, int k,
                       int32_t *labels_dev, double *stats_dev, void *workspace_dev, size_t workspace_bytes,
-                      hipStream_t st, bool *fused);
+                      hipStream_t st, bool *fused, bool fixed = false);
 int assign_prepared(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev, int k,
                     int32_t *labels_dev, void *workspace_dev, size_t workspace_bytes, hipStream_t st);
 int prepare_only(const double *w_dev, int c, int k, void *workspace_dev, size_t workspace_bytes,

@@ -472,7 +472,7 @@ static int prep_stage(size_t stage_bytes)
 template <typename T>
 int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int k, int32_t *labels,
                  double *dist, char *ws, const Layout &L, hipStream_t st, double *stats = nullptr,
-                 bool prepared = false)
+                 bool prepared = false, bool fixed = false)
 {
     if (!prepared && !stats) {  // prepared: pxsom_batch_update_prepare did this; stats: the accumulating filter
                                  // prepares the codebook inside its own launch
@@ -491,7 +491,7 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
     const int cus = pxsom::device_cu_count();
     pxsom::Prof *prof = pxsom::current_prof();
     pxsom::prof_mark(prof, st, true, n);
-    launch_filter_any<T>(x, n, c, ldx, ws, L, labels, stats, w, st);
+    launch_filter_any<T>(x, n, c, ldx, ws, L, labels, stats, w, st, fixed);
     pxsom::prof_mark(prof, st, false, n);
     PXSOM_LAUNCH_CHECK("bmu_filter_kernel");
 
@@ -570,7 +570,7 @@ PXSOM_EXPORT int pxsom_assign(const void *x_dev, int64_t n, int c, int64_t ldx, 
 
 int pxsom_bmu::assign_accumulate(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev,
                                  int k, int32_t *labels_dev, double *stats_dev, void *workspace_dev,
-                                 size_t workspace_bytes, hipStream_t st, bool *fused)
+                                 size_t workspace_bytes, hipStream_t st, bool *fused, bool fixed)
 {
     *fused = false;
     if (n < 64 || n > 0x7fffffffLL || c < 1 || c > PXSOM_MAX_CHANNELS || k < 1 || k > PXSOM_MAX_NODES || ldx < c ||
@@ -583,7 +583,7 @@ int pxsom_bmu::assign_accumulate(const void *x_dev, int64_t n, int c, int64_t ld
     PXSOM_DISPATCH_DTYPE(dtype, x_dev, xp,
                          (filter_fast_path<T>(xp, n, c, ldx, L)
                               ? (*fused = true, assign_typed<T>(xp, n, c, ldx, w_dev, k, labels_dev, nullptr, ws, L, st,
-                                                                stats_dev, false))
+                                                                stats_dev, false, fixed))
                               : PXSOM_OK));
 }
 

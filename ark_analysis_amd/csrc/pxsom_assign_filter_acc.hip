@@ -3,22 +3,24 @@
 // settled inline in binary64.  Compiled WITHOUT -ffinite-math-only: the inline exact path relies on IEEE
 // NaN comparisons (a NaN row must end up with label 0).
 #include <algorithm>
+#include <cstdlib>
 
 #include "pxsom_assign_filter_fast.h"
 
 namespace pxsom_bmu {
 namespace {
 
-template <typename T, int CPL>
+template <typename T, int CPL, bool FIX>
 void launch_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels, double *stats,
                 const double *w, hipStream_t st)
 {
-    auto kern = bmu_filter_fast<T, CPL, 7, 1, 0, true>;
-    // table | transposed codebook | row-major codebook | fragments | bias | header copy | listed-row queue
-    const size_t lds = ((size_t)L.k * c + L.k + 2 * (size_t)L.k * c) * sizeof(double) +
+    auto kern = bmu_filter_fast<T, CPL, 7, 1, 0, true, FIX>;
+    // table (first the row-major codebook prep reads) | transposed codebook | fragments | bias | header copy | listed-row queue:
+    // 62 KB at k = 100, c = 22 -- two workgroups per CU
+    const size_t lds = ((((size_t)(L.k + 1) * (c + 1) + 1) & ~(size_t)1) + (size_t)L.k * c) * sizeof(double) +
                        (size_t)7 * 2 * 64 * sizeof(half8) + (size_t)7 * 64 * sizeof(f32x4) + kHdrBytes +
                        256 * sizeof(int64_t) + 16;   // + queue of listed rows and its counter
-    static pxsom::PerDevice<int> bpc_on;
+    static pxsom::PerDevice<int> bpc_on;   // (one per instantiation)
     int &bpc = bpc_on.here();
     if (bpc == 0) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -33,33 +35,48 @@ void launch_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layou
     // (fewer workgroups share the exact rows among fewer waves; more pay the prologue and the flush more often)
     int grid = (int)std::min<int64_t>((ngroups + 1) / 2, (int64_t)pxsom::device_cu_count() * bpc);
     if (grid < 1) grid = 1;
+    // FIX: ceil(log2(rows one workgroup can meet)) -- 4 waves x 64 rows per round of the grid, shifted last group included
+    int fix_rows_log2 = 0;
+    {
+        const int64_t rows_wg = ((ngroups + (int64_t)grid * 4 - 1) / ((int64_t)grid * 4)) * 256 + 64;
+        while (((int64_t)1 << fix_rows_log2) < rows_wg) fix_rows_log2++;
+    }
+#ifdef PXSOM_ACC_EXPERIMENT
+    if (const char *e = getenv("PXSOM_ACC_EXP")) fix_rows_log2 |= atoi(e) << 8;
+    if (const char *e = getenv("PXSOM_ACC_GRID")) grid = std::min(grid, atoi(e));
+#endif
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, x, n, c, ldx,
                        reinterpret_cast<const half8 *>(ws + L.off_wfrag),
                        reinterpret_cast<const f32x4 *>(ws + L.off_bias), reinterpret_cast<AssignHdr *>(ws),
-                       reinterpret_cast<unsigned *>(ws + L.off_list), labels, L.k, stats, w, L.idx_bits, L.node_bits);
+                       reinterpret_cast<unsigned *>(ws + L.off_list), labels, L.k, stats, w, L.idx_bits, L.node_bits,
+                       fix_rows_log2);
 }
 
 }  // namespace
 
 template <typename T>
 void launch_filter_fast_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels,
-                            double *stats, const double *w, hipStream_t st)
+                            double *stats, const double *w, hipStream_t st, bool fixed)
 {
+#define PXSOM_ACC(CPL)                                                            \
+    (fixed ? launch_acc<T, CPL, true>(x, n, c, ldx, ws, L, labels, stats, w, st)  \
+           : launch_acc<T, CPL, false>(x, n, c, ldx, ws, L, labels, stats, w, st))
     if (L.cpl == 6)
-        launch_acc<T, 6>(x, n, c, ldx, ws, L, labels, stats, w, st);
+        PXSOM_ACC(6);
     else if (L.cpl == 8)
-        launch_acc<T, 8>(x, n, c, ldx, ws, L, labels, stats, w, st);
+        PXSOM_ACC(8);
     else if (L.cpl == 4)
-        launch_acc<T, 4>(x, n, c, ldx, ws, L, labels, stats, w, st);
+        PXSOM_ACC(4);
     else
-        launch_acc<T, 2>(x, n, c, ldx, ws, L, labels, stats, w, st);
+        PXSOM_ACC(2);
+#undef PXSOM_ACC
 }
 
 template void launch_filter_fast_acc<float>(const float *, int64_t, int, int64_t, char *, const Layout &, int32_t *,
-                                            double *, const double *, hipStream_t);
+                                            double *, const double *, hipStream_t, bool);
 template void launch_filter_fast_acc<double>(const double *, int64_t, int, int64_t, char *, const Layout &, int32_t *,
-                                             double *, const double *, hipStream_t);
+                                             double *, const double *, hipStream_t, bool);
 template void launch_filter_fast_acc<_Float16>(const _Float16 *, int64_t, int, int64_t, char *, const Layout &,
-                                               int32_t *, double *, const double *, hipStream_t);
+                                               int32_t *, double *, const double *, hipStream_t, bool);
 
 }  // namespace pxsom_bmu

@@ -85,10 +85,38 @@ __device__ __forceinline__ void consume(float &m1, float &m2, const f32x4 &acc, 
 // path), the row's channels broadcast with v_readlane, distances exactly as bmu_exact_kernel / the oracle
 // form them.  The winner becomes the row's label and the row is added to the workgroup's table.
 #pragma clang fp contract(off)
-template <typename T>
+// Fixed-point table (FIX, the one-pass labels + mean-table kernel): a value v with |v| < 2^(51-s) is added as the BIT
+// PATTERN of the binary64 number v + M, M = 1.5 * 2^(52-s): in that binade an ulp is 2^-s, so bits(v + M) - bits(M) is
+// round(v * 2^s) in two's complement, and the table takes ds_add_u64 (3.4x the rate of ds_add_f64 on this chip,
+// scripts/ubench/lds_atomic_rate.hip) instead of a floating-point atomic.  Sums wrap modulo 2^64; the flush subtracts
+// count * bits(M) and scales by 2^-s.  Per value the error is at most 2^-(s+1); s is chosen per launch so that neither a
+// filter-approved row (|x * scale| < 2^16) nor a workgroup's sum can overflow (make_fixpoint).
+struct FixPoint {
+    double magic;                // 1.5 * 2^(52 - s)
+    double limit;                // 2^(51 - s): values at or above it (and non-finite ones) bypass the table
+    double unit;                 // 2^-s
+    unsigned long long mbits;    // bits(magic)
+};
+// scale = 2^scale_exp is the filter's power-of-two scale, rows_log2 = ceil(log2(rows a workgroup can meet)).  Values the
+// table takes are below 2^(16 - scale_exp) (every row the filter vouches for: |x * scale|_2 < 60000), so with
+// s = 46 + scale_exp - rows_log2 a workgroup's sums stay below 2^62 units; per value the error is <= 2^-(s+1), i.e.
+// 2^-(39 - rows_log2) relative to the codebook's largest magnitude (|W|max * scale is in [128, 256)).
+__device__ __forceinline__ FixPoint make_fixpoint(int scale_exp, int rows_log2)
+{
+    const int s = 46 + scale_exp - rows_log2;
+    FixPoint f;
+    f.magic = ldexp(1.5, 52 - s);
+    f.limit = ldexp(1.0, min(51 - s, 16 - scale_exp));
+    f.unit = ldexp(1.0, -s);
+    f.mbits = (unsigned long long)__double_as_longlong(f.magic);
+    return f;
+}
+
+template <typename T, bool FIX = false>
 __device__ __forceinline__ void exact_row_accumulate(const T *__restrict__ x, int64_t row, int c, int64_t ldx,
                                                      const double *wt, int k, int32_t *__restrict__ labels,
-                                                     double *ls, int lane)
+                                                     double *ls, int lane, const FixPoint *fx = nullptr,
+                                                     double *stats = nullptr)
 {
     const double xa = (double)x[row * ldx + (lane < c ? lane : 0)];   // c <= 32 here: lane j holds channel j
     const unsigned xlo = (unsigned)__double_as_longlong(xa), xhi = (unsigned)(__double_as_longlong(xa) >> 32);
@@ -136,10 +164,27 @@ __device__ __forceinline__ void exact_row_accumulate(const T *__restrict__ x, in
     const int win = (int)pxsom::wave_min_u32(best == smin ? (unsigned)bestk : 0xffffffffu);
     if (lane == 0) labels[row] = win == 0x7fffffff ? 0 : win + 1;   // no finite distance (NaN row): label 0
     if (win != 0x7fffffff) {
-        if (lane < c)
-            __hip_atomic_fetch_add(ls + (size_t)win * c + lane, xa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (lane == 0)
-            __hip_atomic_fetch_add(ls + (size_t)k * c + win, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if constexpr (FIX) {
+            // a listed row may hold values the table's format cannot (it was listed for its size, perhaps): such a row
+            // goes straight to the global binary64 statistics
+            const bool fits = fabs(lane < c ? xa : 0.0) < fx->limit;
+            unsigned long long *lu = reinterpret_cast<unsigned long long *>(ls);
+            if (__ballot(!fits) == 0ull) {
+                if (lane < c)
+                    __hip_atomic_fetch_add(lu + (size_t)win * c + lane, (unsigned long long)__double_as_longlong(xa + fx->magic),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane == 0)
+                    __hip_atomic_fetch_add(lu + (size_t)(k + 1) * c + win, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                if (lane < c) __hip_atomic_fetch_add(stats + (size_t)win * c + lane, xa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_fetch_add(stats + (size_t)k * c + win, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            if (lane < c)
+                __hip_atomic_fetch_add(ls + (size_t)win * c + lane, xa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0)
+                __hip_atomic_fetch_add(ls + (size_t)(k + 1) * c + win, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     }
 }
 #pragma clang fp contract(fast)
@@ -158,16 +203,20 @@ typedef unsigned uint2v __attribute__((ext_vector_type(2)));
 // exactly as the exact kernel would (binary64, j ascending, no contraction, sqrt, first strict minimum)
 // against a transposed binary64 copy of the codebook in LDS, and added to the table too -- so a
 // mini-batch step needs no exact-kernel launch.  One pass over x, one launch.
-template <typename T, int CPL, int NB, int RU, int MODE, bool ACC>
+// FIX (with ACC; pxsom_assign_sums): the workgroup's table is 64-bit fixed point (FixPoint above), fix_rows_log2 =
+// ceil(log2(rows a workgroup can meet)).
+template <typename T, int CPL, int NB, int RU, int MODE, bool ACC, bool FIX = false>
 __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
     const T *__restrict__ x, int64_t n, int c, int64_t ldx, const half8 *__restrict__ wfrag,
     const f32x4 *__restrict__ bias, AssignHdr *hdr, unsigned *__restrict__ amb_list,
     int32_t *__restrict__ labels, int k, double *__restrict__ stats, const double *__restrict__ wcodes,
-    int idx_bits, int node_bits)
+    int idx_bits, int node_bits, int fix_rows_log2 = 0)
 {
     extern __shared__ __attribute__((aligned(16))) char acc_smem[];
-    double *ls = reinterpret_cast<double *>(acc_smem);  // [k*c + k]
-    double *wt = ls + (size_t)k * c + k;                 // [c][k] transposed codebook (ACC only)
+    // ACC: table [(k+1)*c sums | (k+1) counts]; row k is a spare one that takes the adds of rows / channel slots that must
+    // not count (listed rows, rows a previous group owns, clamped channel slots): the accumulation has no branch
+    double *ls = reinterpret_cast<double *>(acc_smem);
+    double *wt = ls + (((size_t)(k + 1) * (c + 1) + 1) & ~(size_t)1);   // [c][k] transposed codebook (ACC only); 16-byte aligned
     // ACC: rows the filter is not sure of wait in a per-workgroup queue and are settled after the group loop by
     // whichever wave is free (a mini-batch lists 0..6 rows per wave early in training: the slowest wave set the pace)
     constexpr unsigned kAmbQueue = 256;
@@ -177,14 +226,14 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
         // Every workgroup prepares the codebook for itself (no prep launch in front of a mini-batch step):
         // row-major copy in LDS -> prep_body -> fragments / bias / constants in LDS, read below exactly as
         // the plain filter reads them from the workspace.
-        double *wrow = wt + (size_t)k * c;                                           // [k][c]
-        half8 *frag_l = reinterpret_cast<half8 *>(wrow + (size_t)k * c);             // [NB][2][64]
+        // the row-major copy prep_body reads lives in the table's storage (needed before the first row is added only)
+        double *wrow = ls;                                                           // [k][c]
+        half8 *frag_l = reinterpret_cast<half8 *>(wt + (size_t)k * c);               // [NB][2][64]
         f32x4 *bias_l = reinterpret_cast<f32x4 *>(frag_l + NB * 2 * 64);             // [NB][64]
         AssignHdr *hdr_l = reinterpret_cast<AssignHdr *>(bias_l + NB * 64);
         amb_q = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(hdr_l) + kHdrBytes);   // [kAmbQueue]
         amb_n = reinterpret_cast<unsigned *>(amb_q + kAmbQueue);
         if (threadIdx.x == 0) *amb_n = 0u;
-        for (int e = threadIdx.x; e < k * c + k; e += 256) ls[e] = 0.0;
         // element e = tid + 256 u  <->  (node, channel), advanced without a division per element
         int node = (int)threadIdx.x / c, j = (int)threadIdx.x - node * c;
         const int dnode = 256 / c, dj = 256 % c;
@@ -208,7 +257,9 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
             }
         }
         __syncthreads();
-        prep_body<256>(wrow, k, c, hdr_l, frag_l, bias_l, NB, 1, CPL, idx_bits, node_bits);
+        prep_body<256, 128>(wrow, k, c, hdr_l, frag_l, bias_l, NB, 1, CPL, idx_bits, node_bits);
+        __syncthreads();
+        for (int e = threadIdx.x; e < (k + 1) * (c + 1); e += 256) ls[e] = 0.0;   // (the first add comes after the loads' wait)
         __syncthreads();
         wfrag = frag_l;
         bias = bias_l;
@@ -223,6 +274,13 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
     const float scale = hdr->scale, wn_max = hdr->wn_max, tol_rel = hdr->tol_rel,
                 tol_abs = hdr->tol_abs, x_limit = hdr->x_limit;
     const bool force_exact = hdr->force_exact != 0;
+    FixPoint fx = {};
+    if constexpr (FIX) {
+        int e = 0;
+        frexpf(scale, &e);                       // scale = 2^(e-1)
+        fx = make_fixpoint(e - 1, fix_rows_log2 & 255);
+    }
+    unsigned long long *lu = reinterpret_cast<unsigned long long *>(ls);
 
     const int lane = threadIdx.x & 63;
     const int pix = lane & 15, q = lane >> 4;
@@ -454,26 +512,49 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
             // (plain filter: the rewrite is harmless, the exact kernel runs in a launch of its own afterwards)
             if (!ACC || row >= g * 64) labels[row] = (int)real + 1;
             if constexpr (ACC) {
-                // lane (q, pix) holds channels q*CPL.. of rows (t, pix), t = 0..3; their labels sit in
-                // lanes (t, pix).  Skipped: listed rows, rows a previous group already added.
-                const unsigned mine = real | ((my_amb || row < g * 64) ? 0x80000000u : 0u);
+                // lane (q, pix) holds channels q*CPL.. of rows (t, pix), t = 0..3; their labels sit in lanes (t, pix).
+                // Listed rows and rows a previous group already added go to the spare row k, clamped channel slots
+                // (they re-read the row's last valid pair) too: straight-line code, the four label exchanges in flight
+                // together.
+                const unsigned mine = (my_amb || row < g * 64) ? (unsigned)k : real;
+                unsigned lab[kTilesPerIter];
+#pragma unroll
+                for (int t = 0; t < kTilesPerIter; t++) lab[t] = (unsigned)__shfl((int)mine, t * 16 + pix);
 #pragma unroll
                 for (int t = 0; t < kTilesPerIter; t++) {
-                    const unsigned v = (unsigned)__shfl((int)mine, t * 16 + pix);
-                    if (!(v >> 31)) {
-                        double *dst = ls + (size_t)v * c + q * CPL;
+                    const unsigned base = lab[t] * (unsigned)c, spare = (unsigned)k * (unsigned)c;
 #pragma unroll
-                        for (int p = 0; p < NP; p++) {
-                            if (q * CPL + 2 * p <= c - 2) {  // clamped slots re-read the last pair: not theirs
-                                __hip_atomic_fetch_add(dst + 2 * p, (double)keep[t][p].x, __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-                                __hip_atomic_fetch_add(dst + 2 * p + 1, (double)keep[t][p].y, __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                    for (int p = 0; p < NP; p++) {
+                        const bool own = q * CPL + 2 * p <= c - 2;
+                        const unsigned idx = (own ? base : spare) + (unsigned)(own ? q * CPL + 2 * p : 0);
+                        if constexpr (FIX) {
+#ifdef PXSOM_ACC_EXPERIMENT
+                            const int exp_mode = fix_rows_log2 >> 8;     // timing experiments: results are wrong in modes 1-3
+                            if (exp_mode == 1 || exp_mode == 2) continue;
+                            if (exp_mode == 3) {
+                                unsigned *d32 = reinterpret_cast<unsigned *>(lu) + idx;
+                                __hip_atomic_fetch_add(d32, __float_as_uint((float)keep[t][p].x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                __hip_atomic_fetch_add(d32 + 1, __float_as_uint((float)keep[t][p].y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                continue;
                             }
+#endif
+                            __hip_atomic_fetch_add(lu + idx, (unsigned long long)__double_as_longlong((double)keep[t][p].x + fx.magic),
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(lu + idx + 1, (unsigned long long)__double_as_longlong((double)keep[t][p].y + fx.magic),
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        } else {
+                            __hip_atomic_fetch_add(ls + idx, (double)keep[t][p].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(ls + idx + 1, (double)keep[t][p].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
-                        if (q == 0)
-                            __hip_atomic_fetch_add(ls + (size_t)k * c + v, 1.0, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    if (q == 0) {
+#ifdef PXSOM_ACC_EXPERIMENT
+                        if ((fix_rows_log2 >> 8) == 1) continue;
+#endif
+                        if constexpr (FIX)
+                            __hip_atomic_fetch_add(lu + (size_t)(k + 1) * c + lab[t], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        else
+                            __hip_atomic_fetch_add(ls + (size_t)(k + 1) * c + lab[t], 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
             }
@@ -491,7 +572,7 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
                 while (late) {
                     const int src = __builtin_ctzll(late);
                     late &= late - 1;
-                    exact_row_accumulate<T>(x, row0 + src, c, ldx, wt, k, labels, ls, lane);
+                    exact_row_accumulate<T, FIX>(x, row0 + src, c, ldx, wt, k, labels, ls, lane, &fx, stats);
                 }
             } else {
                 unsigned base = 0;
@@ -505,11 +586,33 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
         __syncthreads();   // every wave is through its groups: the queue is complete
         const unsigned queued = *amb_n < kAmbQueue ? *amb_n : kAmbQueue;   // rows past the end were settled at once
         for (unsigned i = threadIdx.x >> 6; i < queued; i += 4)
-            exact_row_accumulate<T>(x, amb_q[i], c, ldx, wt, k, labels, ls, lane);
+            exact_row_accumulate<T, FIX>(x, amb_q[i], c, ldx, wt, k, labels, ls, lane, &fx, stats);
         __syncthreads();
-        for (int e = threadIdx.x; e < k * c + k; e += 256) {
-            const double v = ls[e];
-            if (v != 0.0) __hip_atomic_fetch_add(stats + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (FIX) {
+            int node = (int)threadIdx.x / c, j = (int)threadIdx.x - node * c;   // element e <-> (node, channel), no division per element
+            const int dnode = 256 / c, dj = 256 % c;
+            for (int e = threadIdx.x; e < k * c; e += 256) {
+                const unsigned long long cnt = lu[(size_t)(k + 1) * c + node];
+                if (cnt) {
+                    const long long units = (long long)(lu[e] - cnt * fx.mbits);
+                    if (units) __hip_atomic_fetch_add(stats + e, (double)units * fx.unit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                node += dnode;
+                j += dj;
+                if (j >= c) {
+                    j -= c;
+                    node++;
+                }
+            }
+            for (int e = threadIdx.x; e < k; e += 256) {
+                const unsigned long long cnt = lu[(size_t)(k + 1) * c + e];
+                if (cnt) __hip_atomic_fetch_add(stats + (size_t)k * c + e, (double)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            for (int e = threadIdx.x; e < k * c + k; e += 256) {
+                const double v = ls[e < k * c ? e : e + c + 0];   // counts sit behind the spare row
+                if (v != 0.0) __hip_atomic_fetch_add(stats + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }

@@ -213,6 +213,16 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
         double md[kXD > kYD ? kXD : kYD];
 #pragma unroll
         for (int d = 0; d < (kXD > kYD ? kXD : kYD); d++) md[d] = d <= r ? 1.0 : 0.0;
+        // BMU-only steps (the tail of a pass: thr = 0.5, r = 0): the window of a node is the node, both passes would add
+        // +-0 to S[x][y] -- the same bits -- so the statistics go to the scratch as they are (one barrier instead of two,
+        // no chains of 10 + 10 dependent additions)
+        if (r == 0) {
+            if (p1) {
+#pragma unroll
+                for (int y = 0; y < kYD; y++) tl[(size_t)(y * kXD + gx) * NC + cc] = 0.0 + S[y];
+            }
+            __syncthreads();
+        } else {
         if (p1) {
 #pragma unroll
             for (int yp = 0; yp < kYD; yp++) {
@@ -241,6 +251,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
         }
         PXSOM_PHASE(11);
         __syncthreads();
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < CPL; i++) {
@@ -884,10 +895,11 @@ int launch_step(const T *x, int64_t n, int c, int64_t ldx, double *stats, const 
     const size_t lds = step_lds(c).total;
     auto k1 = batch_step_kernel<T, CPL, 1>;
     auto k2 = batch_step_kernel<T, CPL, 2>;
+    auto k4 = batch_step_kernel<T, CPL, 4>;
     static pxsom::PerDevice<size_t> attr_lds_on;
     size_t &attr_lds = attr_lds_on.here();
     if (attr_lds < lds) {
-        for (const void *fn : {reinterpret_cast<const void *>(k1), reinterpret_cast<const void *>(k2)}) {
+        for (const void *fn : {reinterpret_cast<const void *>(k1), reinterpret_cast<const void *>(k2), reinterpret_cast<const void *>(k4)}) {
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess)
                 return pxsom::fail(PXSOM_ERR_HIP, "batch step kernel: cannot raise the LDS limit to %zu bytes: %s", lds,
@@ -895,13 +907,30 @@ int launch_step(const T *x, int64_t n, int c, int64_t ldx, double *stats, const 
         }
         attr_lds = lds;
     }
-    const int tpw = tiles_per_wave == 1 ? 1 : 2;
+    // 16-row tiles per wave: one for the steps that fit the chip in one round (a step is latency, the shortest chain wins:
+    // measured on 16 K-row steps, 0.93 ms per 64-step pass against 0.99 with two); the large steps of a schedule take 2 or
+    // 4 -- a round costs ~3.5 us whatever it holds, and the search itself runs at a fraction of the filter kernel's rate
+    // workgroup slots: one per CU.  (Two fit -- 77 KB of LDS, <= 128 VGPRs each -- and were measured on the two-phase
+    // schedule's large steps: SLOWER, pass 0.505 -> 0.574 ms; a step's time grows with the number of workgroups that flush
+    // their tables into the same 18 KB of statistics.  PXSOM_STEP_WGS_PER_CU=2 reproduces it.)
+    static int wgs_per_cu = 0;
+    if (wgs_per_cu == 0) {
+        const char *e = getenv("PXSOM_STEP_WGS_PER_CU");
+        wgs_per_cu = e ? atoi(e) : 1;
+        if (wgs_per_cu < 1 || wgs_per_cu > 2) wgs_per_cu = 1;
+    }
+    const int64_t cus = pxsom::device_cu_count(), slots = cus * wgs_per_cu;
+    int tpw = tiles_per_wave == 2 ? 2 : (tiles_per_wave == 4 ? 4 : 1);
+    if (tiles_per_wave <= 0) {
+        const int64_t blocks1 = (n + kStepWaves * 16 - 1) / (kStepWaves * 16);
+        tpw = blocks1 <= slots ? 1 : (blocks1 <= 2 * slots ? 2 : 4);
+    }
     const int64_t rows_per_wg = (int64_t)kStepWaves * 16 * tpw;
-    // a step larger than one block per CU: the fewest rounds, spread evenly (853 blocks -> 214 workgroups x 4, not 256 x 3.3)
-    const int64_t nblocks = std::max<int64_t>((n + rows_per_wg - 1) / rows_per_wg, 1), cus = pxsom::device_cu_count();
-    const int64_t rounds = (nblocks + cus - 1) / cus;
+    // a step larger than one block per slot: the fewest rounds, spread evenly (853 blocks -> 214 workgroups x 4, not 256 x 3.3)
+    const int64_t nblocks = std::max<int64_t>((n + rows_per_wg - 1) / rows_per_wg, 1);
+    const int64_t rounds = (nblocks + slots - 1) / slots;
     const int grid = (int)((nblocks + rounds - 1) / rounds);
-    hipLaunchKernelGGL(tpw == 1 ? k1 : k2, dim3(grid), dim3(kStepThreads), lds, st, x, n, c, ldx, stats, sa);
+    hipLaunchKernelGGL(tpw == 1 ? k1 : (tpw == 2 ? k2 : k4), dim3(grid), dim3(kStepThreads), lds, st, x, n, c, ldx, stats, sa);
     PXSOM_LAUNCH_CHECK("batch_step_kernel");
     return PXSOM_OK;
 }

@@ -12,7 +12,9 @@
 // results equal the oracle's, which is pinned to scipy / pandas / numpy (tests/test_oracle_golden.py).
 // These kernels are HBM-streaming: every element is read and written O(1) times; the 17-tap windows are
 // served by L1/L2.
+#include <algorithm>
 #include <cfloat>
+#include <cstdlib>
 #include <cmath>
 
 #include "pxsom_common.h"
@@ -43,9 +45,10 @@ __device__ __forceinline__ int reflect_idx(int i, int len)
 // One pass of scipy's correlate1d, symmetric-kernel branch:
 //   tmp = in[0]*w[0];  for d = r .. 1:  tmp += (in[-d] + in[+d]) * w[d]
 // AXIS 0: along image rows (stride W*C), AXIS 1: along image columns (stride C).
-// Thread <-> one output element; consecutive threads walk (x, c), so every tap is a coalesced read.
 // R32: the image holds float32 values (widened): scipy then computes each line in binary64 but stores the pass's
 // result as float32, so each pass rounds its output to float32.
+//
+// Generic form (any radius, tiny images): thread <-> one output element, every tap a coalesced read served by L1 / L2.
 template <int AXIS, bool R32>
 __global__ __launch_bounds__(256) void blur_pass_kernel(const double *__restrict__ in, double *__restrict__ out,
                                                         int H, int W, int C, Taps taps)
@@ -67,6 +70,91 @@ __global__ __launch_bounds__(256) void blur_pass_kernel(const double *__restrict
             tmp += (in[base + (int64_t)lo * stride] + in[base + (int64_t)hi * stride]) * taps.w[d];
         }
         out[e] = R32 ? (double)(float)tmp : tmp;
+    }
+}
+
+// Tiles of the two fast forms are dealt to the XCDs in contiguous runs: workgroup b runs on XCD b % 8 (round robin),
+// and every XCD has an L2 of its own -- neighbouring tiles share their halo, so they should meet in the same L2
+// (the generic form above fetched 1.7x / 2.4x the image from HBM per pass: profiles/r03/preprocess.txt).
+__device__ __forceinline__ int64_t xcd_contiguous(int64_t b, int64_t nb)
+{
+    constexpr int kXcds = 8;
+    const int64_t per = (nb + kXcds - 1) / kXcds;
+    return (b % kXcds) * per + b / kXcds;     // may be >= nb: the caller skips those
+}
+
+// AXIS 0, radius R (the pipeline's sigma = 2: R = 8): thread <-> one image column element (x, c), walking down a strip
+// of rows with the last 2R+1 values of its column in REGISTERS -- every input is read once per strip (coalesced across
+// the threads), every output is formed from registers with the reference's operation order.  Strip height TY: the
+// halo of 2R rows is re-read by the strip below ((TY + 2R) / TY = 1.25x at TY = 64).
+template <int R, bool R32>
+__global__ __launch_bounds__(256) void blur_rows_window_kernel(const double *__restrict__ in, double *__restrict__ out,
+                                                               int H, int64_t wc, Taps taps, int TY, int64_t ncb, int64_t nblocks)
+{
+    constexpr int NW = 2 * R + 1;
+    const int64_t b = xcd_contiguous(blockIdx.x, nblocks);
+    if (b >= nblocks) return;
+    // strips of one column block are consecutive: their shared halo rows stay in one L2
+    const int64_t cb = b / ((H + TY - 1) / TY), strip = b - cb * ((H + TY - 1) / TY);
+    (void)ncb;
+    const int64_t col = cb * 256 + threadIdx.x;
+    if (col >= wc) return;
+    const int y0 = (int)strip * TY, y1 = min(y0 + TY, H);
+    double win[NW];   // win[i] = in[reflect(y - R + i)] for the output row y being formed
+#pragma unroll
+    for (int i = 0; i < NW; i++) win[i] = in[(int64_t)reflect_idx(y0 - R + i, H) * wc + col];
+    double w[R + 1];
+#pragma unroll
+    for (int d = 0; d <= R; d++) w[d] = taps.w[d];
+    for (int y = y0; y < y1; y += NW) {          // NW outputs per trip: the window rotates through the registers
+#pragma unroll
+        for (int u = 0; u < NW; u++) {
+            if (y + u < y1) {
+                // the window starts at register u (rotation by u): centre = win[(u + R) % NW]
+                double tmp = win[(u + R) % NW] * w[0];
+#pragma unroll
+                for (int d = R; d >= 1; d--) tmp += (win[(u + R - d) % NW] + win[(u + R + d) % NW]) * w[d];
+                out[(int64_t)(y + u) * wc + col] = R32 ? (double)(float)tmp : tmp;
+                // the oldest value (register u) makes room for row y + u + R + 1
+                win[u] = in[(int64_t)reflect_idx(y + u + R + 1, H) * wc + col];
+            }
+        }
+    }
+}
+
+// AXIS 1, radius R: a workgroup stages a run of TX consecutive elements of one image row plus R pixels (R*C elements)
+// of halo on either side in LDS -- reflection resolved while staging -- and forms TX outputs from it: every tap is an
+// LDS read at stride C elements from its neighbour's (conflict-free: consecutive threads read consecutive words).
+template <int R, bool R32>
+__global__ __launch_bounds__(256) void blur_cols_lds_kernel(const double *__restrict__ in, double *__restrict__ out,
+                                                            int H, int W, int C, Taps taps, int TX, int64_t nblocks)
+{
+    extern __shared__ double blur_tile[];     // [TX + 2 R C]
+    const int64_t b = xcd_contiguous(blockIdx.x, nblocks);
+    if (b >= nblocks) return;
+    const int64_t wc = (int64_t)W * C;
+    const int tiles_per_row = (int)((wc + TX - 1) / TX);
+    const int y = (int)(b / tiles_per_row);
+    const int64_t e0 = (b - (int64_t)y * tiles_per_row) * TX;
+    const int halo = R * C, span = TX + 2 * halo;
+    const double *row = in + (int64_t)y * wc;
+    for (int i = threadIdx.x; i < span; i += 256) {
+        const int64_t e = e0 - halo + i;                         // element of the row's infinite reflected extension
+        // pixel index floor(e / C) reflected, channel kept
+        int64_t px = e >= 0 ? e / C : -((-e + C - 1) / C);
+        const int ch = (int)(e - px * C);
+        blur_tile[i] = px >= W + R ? 0.0 : row[(int64_t)reflect_idx((int)px, W) * C + ch];   // (past the tile's last real output: unused)
+    }
+    __syncthreads();
+    double w[R + 1];
+#pragma unroll
+    for (int d = 0; d <= R; d++) w[d] = taps.w[d];
+    for (int i = threadIdx.x; i < TX && e0 + i < wc; i += 256) {
+        const double *c0 = blur_tile + halo + i;
+        double tmp = c0[0] * w[0];
+#pragma unroll
+        for (int d = R; d >= 1; d--) tmp += (c0[-d * C] + c0[d * C]) * w[d];
+        out[(int64_t)y * wc + e0 + i] = R32 ? (double)(float)tmp : tmp;
     }
 }
 
@@ -98,18 +186,45 @@ __device__ __forceinline__ bool row_keep(const double *__restrict__ row, int c, 
     return (s > thresh) && any;
 }
 
+// A workgroup owns 256 consecutive rows.  The rows are staged in LDS with coalesced loads (element e of the block's
+// 256 * c elements by thread e % 256), each thread then sums ITS row from LDS left to right -- the reference's order --
+// at a padded stride (c | 1 doubles: a thread-per-row walk over global memory costs a cache line per lane and load).
+constexpr int kRowBlock = 256;
+__host__ __device__ __forceinline__ int row_pad(int c) { return c | 1; }
+
+__device__ __forceinline__ void stage_rows(const double *__restrict__ x, int64_t row0, int64_t n, int c, double *tile)
+{
+    const int64_t e_end = min((int64_t)kRowBlock, n - row0) * c;
+    const double *src = x + row0 * c;
+    const int cp = row_pad(c);
+    int r = (int)threadIdx.x / c, j = (int)threadIdx.x - r * c;       // element e <-> (row r, channel j), no division per element
+    const int dr = kRowBlock / c, dj = kRowBlock % c;
+    for (int64_t e = threadIdx.x; e < e_end; e += kRowBlock) {
+        tile[r * cp + j] = src[e];
+        r += dr;
+        j += dj;
+        if (j >= c) {
+            j -= c;
+            r++;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void rowfilter_count_kernel(const double *__restrict__ x, int64_t n, int c,
                                                               double thresh, unsigned *__restrict__ block_counts,
                                                               int f32)
 {
+    extern __shared__ double rf_tile[];
     __shared__ unsigned s_cnt;
     if (threadIdx.x == 0) s_cnt = 0;
+    const int64_t row0 = (int64_t)blockIdx.x * kRowBlock;
+    stage_rows(x, row0, n, c, rf_tile);
     __syncthreads();
-    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = row0 + threadIdx.x;
     bool keep = false;
     if (row < n) {
         double s;
-        keep = row_keep(x + row * c, c, thresh, s, f32);
+        keep = row_keep(rf_tile + (size_t)threadIdx.x * row_pad(c), c, thresh, s, f32);
     }
     const unsigned long long m = __ballot(keep);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(&s_cnt, (unsigned)__popcll(m));
@@ -149,6 +264,74 @@ __global__ __launch_bounds__(256) void rowfilter_write_kernel(const double *__re
                                                               double thresh, const unsigned *__restrict__ block_off,
                                                               double *__restrict__ out_rows,
                                                               int64_t *__restrict__ out_index, int f32)
+{
+    extern __shared__ double rf_tile[];                    // [256][c | 1] rows, then [256] row sums, then [256] u16 kept rows
+    __shared__ unsigned s_wave[4];
+    const int cp = row_pad(c);
+    double *sums = rf_tile + (size_t)kRowBlock * cp;
+    unsigned short *kept = reinterpret_cast<unsigned short *>(sums + kRowBlock);
+    const int64_t row0 = (int64_t)blockIdx.x * kRowBlock;
+    stage_rows(x, row0, n, c, rf_tile);
+    __syncthreads();
+    const int64_t row = row0 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    bool keep = false;
+    double s = 0.0;
+    if (row < n) keep = row_keep(rf_tile + (size_t)threadIdx.x * cp, c, thresh, s, f32);
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) s_wave[wv] = (unsigned)__popcll(m);
+    __syncthreads();
+    unsigned local = 0;
+    for (int i = 0; i < wv; i++) local += s_wave[i];
+    const unsigned nkept = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    const int64_t dst0 = block_off[blockIdx.x];
+    if (keep) {
+        const unsigned slot = local + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        kept[slot] = (unsigned short)threadIdx.x;
+        sums[slot] = s;
+        out_index[dst0 + slot] = row;
+    }
+    __syncthreads();
+    // the kept rows are consecutive in the output: element e of the block's nkept * c outputs by thread e % 256
+    double *dst = out_rows + dst0 * c;
+    int r = (int)threadIdx.x / c, j = (int)threadIdx.x - r * c;
+    const int dr = kRowBlock / c, dj = kRowBlock % c;
+    for (int e = threadIdx.x; e < (int)nkept * c; e += kRowBlock) {
+        const double v = rf_tile[(size_t)kept[r] * cp + j], sr = sums[r];
+        dst[e] = f32 ? (double)((float)v / (float)sr) : v / sr;
+        r += dr;
+        j += dj;
+        if (j >= c) {
+            j -= c;
+            r++;
+        }
+    }
+}
+
+// Wide rows (c > 72: 256 staged rows would not fit the LDS): thread <-> row straight from global memory.
+__global__ __launch_bounds__(256) void rowfilter_count_direct_kernel(const double *__restrict__ x, int64_t n, int c,
+                                                                     double thresh, unsigned *__restrict__ block_counts,
+                                                                     int f32)
+{
+    __shared__ unsigned s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool keep = false;
+    if (row < n) {
+        double s;
+        keep = row_keep(x + row * c, c, thresh, s, f32);
+    }
+    const unsigned long long m = __ballot(keep);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&s_cnt, (unsigned)__popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = s_cnt;
+}
+
+__global__ __launch_bounds__(256) void rowfilter_write_direct_kernel(const double *__restrict__ x, int64_t n, int c,
+                                                                     double thresh, const unsigned *__restrict__ block_off,
+                                                                     double *__restrict__ out_rows,
+                                                                     int64_t *__restrict__ out_index, int f32)
 {
     __shared__ unsigned s_wave[4];
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -213,94 +396,153 @@ struct QState {              // per column, in the workspace
 
 // pass (shift = 56, 48, ..., 0): histogram of byte (key >> shift) over kept values whose higher bits equal
 // prefix.  hist [c][256] u64 in the workspace (zeroed before every pass).
+// ONE sweep over the matrix serves a chunk of up to kQCols columns: consecutive threads read consecutive elements of a
+// row (a kernel per column read 8 bytes of every cache line: 12x the matrix from HBM per pass, profiles/r03), every
+// column has its own 256-bin histogram in LDS.
+constexpr int kQCols = 48, kQRows = 1024;
 template <typename T>
 __global__ __launch_bounds__(256) void q_hist_kernel(const T *__restrict__ x, int64_t n, int c, int64_t ldx,
                                                      int keep_mode, int shift, const QState *__restrict__ st,
-                                                     unsigned long long *__restrict__ hist, int first_pass)
+                                                     unsigned long long *__restrict__ hist, int first_pass, int col0, int ncols)
 {
-    __shared__ unsigned s_h[256];
-    const int col = blockIdx.y;
-    s_h[threadIdx.x] = 0;
+    __shared__ unsigned s_h[kQCols * 256];
+    __shared__ unsigned long long s_prefix[kQCols];
+    (void)c;
+    for (int i = threadIdx.x; i < ncols * 256; i += 256) s_h[i] = 0;
+    if ((int)threadIdx.x < ncols) s_prefix[threadIdx.x] = first_pass ? 0ull : st[col0 + threadIdx.x].prefix;
     __syncthreads();
-    const unsigned long long prefix = first_pass ? 0ull : st[col].prefix;
     const unsigned long long himask = shift >= 56 ? 0ull : (~0ull << (shift + 8));
-    for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < n; row += (int64_t)gridDim.x * 256) {
-        const double v = (double)x[row * ldx + col];   // binary32 values are exact in binary64
-        if (!q_keep(v, keep_mode)) continue;
-        const unsigned long long k = f64_key(v);
-        if ((k & himask) != (prefix & himask)) continue;
-        atomicAdd(&s_h[(unsigned)(k >> shift) & 255u], 1u);
+    const int dr = 256 / ncols, dj = 256 % ncols;
+    for (int64_t row0 = (int64_t)blockIdx.x * kQRows; row0 < n; row0 += (int64_t)gridDim.x * kQRows) {
+        const int e_end = (int)min((int64_t)kQRows, n - row0) * ncols;
+        int r = (int)threadIdx.x / ncols, j = (int)threadIdx.x - r * ncols;
+        for (int e = threadIdx.x; e < e_end; e += 4 * 256) {     // four loads in flight per thread
+            double v[4];
+            int jj[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                jj[u] = j;
+                v[u] = e + u * 256 < e_end ? (double)x[(row0 + r) * ldx + col0 + j] : 0.0;   // binary32 values are exact in binary64
+                r += dr;
+                j += dj;
+                if (j >= ncols) {
+                    j -= ncols;
+                    r++;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (e + u * 256 < e_end && q_keep(v[u], keep_mode)) {
+                    const unsigned long long k = f64_key(v[u]);
+                    if ((k & himask) == (s_prefix[jj[u]] & himask)) atomicAdd(&s_h[jj[u] * 256 + ((unsigned)(k >> shift) & 255u)], 1u);
+                }
+            }
+        }
     }
     __syncthreads();
-    if (s_h[threadIdx.x]) atomicAdd(&hist[(size_t)col * 256 + threadIdx.x], (unsigned long long)s_h[threadIdx.x]);
+    for (int i = threadIdx.x; i < ncols * 256; i += 256)
+        if (s_h[i]) atomicAdd(&hist[(size_t)col0 * 256 + i], (unsigned long long)s_h[i]);
 }
 
 // one thread per column: locate the bucket holding `rank`, narrow the prefix.  On the first pass also
 // derive m and the target rank lo = floor(q*(m-1)).
 // arith32: the virtual index is formed in binary32 -- what numpy does for a float32 array
 // (q is cast to the array's dtype, then (n-1)*q, floor and the fraction are all float32).
-__global__ void q_select_kernel(QState *st, unsigned long long *hist, int c, int shift, double q, int first_pass,
-                                int arith32)
+__global__ __launch_bounds__(64) void q_select_kernel(QState *st, unsigned long long *hist, int c, int shift, double q,
+                                                      int first_pass, int arith32)
 {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    // one wave per column: lane l owns bins 4 l .. 4 l + 3; an inclusive scan over the lanes' sums finds the bucket
+    const int col = blockIdx.x, lane = threadIdx.x;
     if (col >= c) return;
     unsigned long long *h = hist + (size_t)col * 256;
+    unsigned long long b4[4], mine = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        b4[i] = h[4 * lane + i];
+        mine += b4[i];
+        h[4 * lane + i] = 0;   // ready for the next pass
+    }
+    unsigned long long incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    const unsigned long long total = __shfl(incl, 63);
     QState s = st[col];
     if (first_pass) {
-        unsigned long long m = 0;
-        for (int b = 0; b < 256; b++) m += h[b];
-        s.m = m;
+        s.m = total;
         s.prefix = 0;
-        const double vi = arith32 ? (double)((float)(m > 0 ? m - 1 : 0) * (float)q) : q * (double)(m > 0 ? m - 1 : 0);
+        const double vi = arith32 ? (double)((float)(total > 0 ? total - 1 : 0) * (float)q) : q * (double)(total > 0 ? total - 1 : 0);
         unsigned long long lo = (unsigned long long)floor(vi);
-        if (m > 0 && lo > m - 1) lo = m - 1;
+        if (total > 0 && lo > total - 1) lo = total - 1;
         s.rank = lo;
     }
     if (s.m > 0) {
-        unsigned long long acc = 0;
-        int b = 0;
-        for (; b < 256; b++) {
-            if (acc + h[b] > s.rank) break;
-            acc += h[b];
+        // the first bin b with (sum of bins <= b) > rank; rank < m always holds, the clamp to bin 255 mirrors the serial form
+        const unsigned long long excl = incl - mine;
+        int bin = -1;
+        unsigned long long before = 0, acc = excl;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (bin < 0 && acc + b4[i] > s.rank) {
+                bin = 4 * lane + i;
+                before = acc;
+            }
+            acc += b4[i];
         }
-        if (b > 255) b = 255;
-        s.rank -= acc;
-        s.prefix |= (unsigned long long)b << shift;
+        const unsigned long long has = __ballot(bin >= 0);
+        int src = has ? __builtin_ctzll(has) : 63;
+        int wbin = __shfl(bin, src);
+        unsigned long long wbefore = __shfl(before, src);
+        if (!has) {   // cannot happen while rank < m: keep the serial form's behaviour (last bin, everything before it)
+            wbin = 255;
+            wbefore = total - __shfl(b4[3], 63);
+        }
+        s.rank -= wbefore;
+        s.prefix |= (unsigned long long)wbin << shift;
     }
-    for (int b = 0; b < 256; b++) h[b] = 0;  // ready for the next pass
-    st[col] = s;
+    if (lane == 0) st[col] = s;
 }
 
-// after the last pass prefix == key of the order statistic lo.  One more sweep: count keys <= lo_key and
-// find the smallest key above it (the next order statistic unless lo_key is repeated).
+// after the last pass prefix == key of the order statistic lo.  One more sweep (same shape as q_hist_kernel): count
+// keys <= lo_key and find the smallest key above it (the next order statistic unless lo_key is repeated).
 template <typename T>
 __global__ __launch_bounds__(256) void q_next_kernel(const T *__restrict__ x, int64_t n, int c, int64_t ldx,
-                                                     int keep_mode, QState *st)
+                                                     int keep_mode, QState *st, int col0, int ncols)
 {
-    __shared__ unsigned long long s_min;
-    __shared__ unsigned s_cnt;
-    const int col = blockIdx.y;
-    if (threadIdx.x == 0) {
-        s_min = ~0ull;
-        s_cnt = 0;
+    __shared__ unsigned long long s_min[kQCols], s_lo[kQCols];
+    __shared__ unsigned s_cnt[kQCols];
+    (void)c;
+    if ((int)threadIdx.x < ncols) {
+        s_min[threadIdx.x] = ~0ull;
+        s_cnt[threadIdx.x] = 0;
+        s_lo[threadIdx.x] = st[col0 + threadIdx.x].prefix;
     }
     __syncthreads();
-    const unsigned long long lo_key = st[col].prefix;
-    unsigned long long mymin = ~0ull;
-    unsigned mycnt = 0;
-    for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < n; row += (int64_t)gridDim.x * 256) {
-        const double v = (double)x[row * ldx + col];
-        if (!q_keep(v, keep_mode)) continue;
-        const unsigned long long k = f64_key(v);
-        if (k <= lo_key) mycnt++;
-        else if (k < mymin) mymin = k;
+    const int dr = 256 / ncols, dj = 256 % ncols;
+    for (int64_t row0 = (int64_t)blockIdx.x * kQRows; row0 < n; row0 += (int64_t)gridDim.x * kQRows) {
+        const int e_end = (int)min((int64_t)kQRows, n - row0) * ncols;
+        int r = (int)threadIdx.x / ncols, j = (int)threadIdx.x - r * ncols;
+        for (int e = threadIdx.x; e < e_end; e += 256) {
+            const double v = (double)x[(row0 + r) * ldx + col0 + j];
+            if (q_keep(v, keep_mode)) {
+                const unsigned long long k = f64_key(v);
+                if (k <= s_lo[j]) atomicAdd(&s_cnt[j], 1u);
+                else if (k < s_min[j]) atomicMin(&s_min[j], k);     // (the plain read only skips hopeless atomics)
+            }
+            r += dr;
+            j += dj;
+            if (j >= ncols) {
+                j -= ncols;
+                r++;
+            }
+        }
     }
-    atomicMin(&s_min, mymin);
-    atomicAdd(&s_cnt, mycnt);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicMin(&st[col].hi_key, s_min);
-        atomicAdd(&st[col].count_le, (unsigned long long)s_cnt);
+    if ((int)threadIdx.x < ncols) {
+        atomicMin(&st[col0 + threadIdx.x].hi_key, s_min[threadIdx.x]);
+        atomicAdd(&st[col0 + threadIdx.x].count_le, (unsigned long long)s_cnt[threadIdx.x]);
     }
 }
 
@@ -369,6 +611,29 @@ PXSOM_EXPORT int pxsom_gaussian_blur_hwc(double *img_dev, double *tmp_dev, int h
     for (int d = radius + 1; d <= kMaxRadius; d++) taps.w[d] = 0.0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int64_t total = (int64_t)h * w * c;
+    const int64_t wc = (int64_t)w * c;
+    const bool generic = (f32_semantics & PXSOM_BLUR_GENERIC_FORM) != 0;   // tests compare the two forms
+    f32_semantics &= 1;
+    // the pipeline's kernel (sigma = 2 -> radius 8) on images of at least a strip: register window down the rows, LDS
+    // tile along the columns; anything else (other radii, images shorter than the window) takes the generic form
+    if (radius == 8 && !generic && h >= 17 && w >= 9 && (int64_t)c * 16 + 256 <= 16 * 1024) {
+        constexpr int R = 8;
+        const int TY = 64;
+        const int64_t ncb = (wc + 255) / 256, strips = (h + TY - 1) / TY, nb0 = ncb * strips;
+        const int64_t g0 = (nb0 + 7) / 8 * 8;
+        const int TX = 1024;
+        const int64_t nb1 = (int64_t)h * ((wc + TX - 1) / TX), g1 = (nb1 + 7) / 8 * 8;
+        const size_t lds1 = (size_t)(TX + 2 * R * c) * sizeof(double);
+        if (f32_semantics) {
+            hipLaunchKernelGGL((blur_rows_window_kernel<R, true>), dim3((unsigned)g0), dim3(256), 0, st, img_dev, tmp_dev, h, wc, taps, TY, ncb, nb0);
+            hipLaunchKernelGGL((blur_cols_lds_kernel<R, true>), dim3((unsigned)g1), dim3(256), lds1, st, tmp_dev, img_dev, h, w, c, taps, TX, nb1);
+        } else {
+            hipLaunchKernelGGL((blur_rows_window_kernel<R, false>), dim3((unsigned)g0), dim3(256), 0, st, img_dev, tmp_dev, h, wc, taps, TY, ncb, nb0);
+            hipLaunchKernelGGL((blur_cols_lds_kernel<R, false>), dim3((unsigned)g1), dim3(256), lds1, st, tmp_dev, img_dev, h, w, c, taps, TX, nb1);
+        }
+        PXSOM_LAUNCH_CHECK("blur_rows_window_kernel / blur_cols_lds_kernel");
+        return PXSOM_OK;
+    }
     const int grid = (int)std::min<int64_t>((total + 255) / 256, (int64_t)pxsom::device_cu_count() * 16);
     if (f32_semantics) {
         hipLaunchKernelGGL((blur_pass_kernel<0, true>), dim3(grid), dim3(256), 0, st, img_dev, tmp_dev, h, w, c, taps);
@@ -394,6 +659,7 @@ PXSOM_EXPORT int pxsom_rowsum_filter_normalize(const double *x_dev, int64_t n, i
 {
     if (n < 0 || n > 0x7fffffffLL || c < 1 || !out_count_dev || (n > 0 && (!x_dev || !out_rows_dev || !out_index_dev)))
         return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_rowsum_filter_normalize: bad arguments");
+
     if (!workspace_dev || workspace_bytes < pxsom_rownorm_workspace_bytes(n))
         return pxsom::fail(PXSOM_ERR_WORKSPACE, "pxsom_rowsum_filter_normalize: workspace too small");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -403,13 +669,35 @@ PXSOM_EXPORT int pxsom_rowsum_filter_normalize(const double *x_dev, int64_t n, i
     }
     unsigned *counts = reinterpret_cast<unsigned *>(workspace_dev);
     const int64_t nblocks = (n + 255) / 256;
-    hipLaunchKernelGGL(rowfilter_count_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, x_dev, n, c, thresh, counts,
-                       f32_semantics);
+    const size_t tile_bytes = (size_t)kRowBlock * row_pad(c) * sizeof(double);
+    const size_t write_bytes = tile_bytes + kRowBlock * sizeof(double) + kRowBlock * sizeof(unsigned short);
+    const bool staged = c <= 72;   // 256 rows x (c | 1) doubles of LDS per workgroup
+    if (staged && write_bytes > 64 * 1024) {   // c > 30: beyond the default dynamic LDS limit
+        static pxsom::PerDevice<size_t> raised;
+        size_t &have = raised.here();
+        if (have < write_bytes) {
+            PXSOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(rowfilter_count_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)write_bytes));
+            PXSOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(rowfilter_write_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)write_bytes));
+            have = write_bytes;
+        }
+    }
+    if (staged)
+        hipLaunchKernelGGL(rowfilter_count_kernel, dim3((unsigned)nblocks), dim3(256), tile_bytes, st, x_dev, n, c, thresh, counts,
+                           f32_semantics);
+    else
+        hipLaunchKernelGGL(rowfilter_count_direct_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, x_dev, n, c, thresh, counts,
+                           f32_semantics);
     PXSOM_LAUNCH_CHECK("rowfilter_count_kernel");
     hipLaunchKernelGGL(block_scan_kernel, dim3(1), dim3(1024), 0, st, counts, nblocks, out_count_dev);
     PXSOM_LAUNCH_CHECK("block_scan_kernel");
-    hipLaunchKernelGGL(rowfilter_write_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, x_dev, n, c, thresh, counts,
-                       out_rows_dev, out_index_dev, f32_semantics);
+    if (staged)
+        hipLaunchKernelGGL(rowfilter_write_kernel, dim3((unsigned)nblocks), dim3(256), write_bytes, st, x_dev, n, c, thresh, counts,
+                           out_rows_dev, out_index_dev, f32_semantics);
+    else
+        hipLaunchKernelGGL(rowfilter_write_direct_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, x_dev, n, c, thresh, counts,
+                           out_rows_dev, out_index_dev, f32_semantics);
     PXSOM_LAUNCH_CHECK("rowfilter_write_kernel");
     return PXSOM_OK;
 }
@@ -450,14 +738,17 @@ int quantile_typed(const char *fn, const T *x_dev, int64_t n, int c, int64_t ldx
     const int cgrid = (c + 63) / 64;
     hipLaunchKernelGGL(q_init_kernel, dim3(cgrid), dim3(64), 0, st, qs, c);
     PXSOM_HIP_TRY(hipMemsetAsync(hist, 0, (size_t)c * 256 * sizeof(unsigned long long), st));
-    int rgrid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)pxsom::device_cu_count() * 2);
+    int rgrid = (int)std::min<int64_t>((n + kQRows - 1) / kQRows, (int64_t)pxsom::device_cu_count() * 4);
     if (rgrid < 1) rgrid = 1;
     for (int shift = 56, first = 1; shift >= 0; shift -= 8, first = 0) {
-        hipLaunchKernelGGL(q_hist_kernel<T>, dim3(rgrid, c), dim3(256), 0, st, x_dev, n, c, ldx, keep_mode, shift, qs,
-                           hist, first);
-        hipLaunchKernelGGL(q_select_kernel, dim3(cgrid), dim3(64), 0, st, qs, hist, c, shift, q, first, arith32);
+        for (int col0 = 0; col0 < c; col0 += kQCols)
+            hipLaunchKernelGGL(q_hist_kernel<T>, dim3(rgrid), dim3(256), 0, st, x_dev, n, c, ldx, keep_mode, shift, qs, hist, first,
+                               col0, std::min(kQCols, c - col0));
+        hipLaunchKernelGGL(q_select_kernel, dim3(c), dim3(64), 0, st, qs, hist, c, shift, q, first, arith32);
     }
-    hipLaunchKernelGGL(q_next_kernel<T>, dim3(rgrid, c), dim3(256), 0, st, x_dev, n, c, ldx, keep_mode, qs);
+    for (int col0 = 0; col0 < c; col0 += kQCols)
+        hipLaunchKernelGGL(q_next_kernel<T>, dim3(rgrid), dim3(256), 0, st, x_dev, n, c, ldx, keep_mode, qs, col0,
+                           std::min(kQCols, c - col0));
     hipLaunchKernelGGL(q_finish_kernel, dim3(cgrid), dim3(64), 0, st, qs, c, q, out_dev, arith32);
     PXSOM_LAUNCH_CHECK(fn);
     return PXSOM_OK;

@@ -42,7 +42,9 @@ __device__ long long g_phase_ticks[32];
 // 1. prep: one workgroup of NT threads.  prep_body works on a codebook that is already in `wl` (LDS when
 //    it fits, else HBM); the callers differ in how it got there.
 // ------------------------------------------------------------------------------------------------
-template <int NT>
+// MAXK: the largest k the caller can have (sizes the static per-node scratch: 21 bytes per node -- the accumulating
+// filter's workgroups, k <= 128, must not carry the 22 KB that 1024 nodes need, or only one of them fits a CU).
+template <int NT, int MAXK = PXSOM_MAX_NODES>
 __device__ __forceinline__ void prep_body(const double *wl, int k, int c, AssignHdr *hdr, half8 *wfrag,
                                           f32x4 *bias, int nb, int nch, int cpl, int idx_bits, int node_bits,
                                           double *wt_out = nullptr, float *w32_out = nullptr, int cp32 = 0)
@@ -79,8 +81,8 @@ __device__ __forceinline__ void prep_body(const double *wl, int k, int c, Assign
             }
         }
     }
-    __shared__ double s_norm2[PXSOM_MAX_NODES];
-    __shared__ unsigned long long s_key[PXSOM_MAX_NODES];  // hash of the row's bit patterns (duplicate test)
+    __shared__ double s_norm2[MAXK];
+    __shared__ unsigned long long s_key[MAXK];  // hash of the row's bit patterns (duplicate test)
     __shared__ double s_red[2 * (NT / 64)];
     __shared__ int s_bad;
     const int tid = threadIdx.x;
@@ -199,7 +201,7 @@ __device__ __forceinline__ void prep_body(const double *wl, int k, int c, Assign
     // training: while the neighbourhood radius still spans the grid, all central nodes receive the same
     // update and are bit-identical, which would otherwise send every row they win to the exact path.
     // (s_dup reuses s_red's storage class: one flag per node.)
-    __shared__ unsigned char s_dup[PXSOM_MAX_NODES];
+    __shared__ unsigned char s_dup[MAXK];
     PXSOM_PHASE_ANY(5);
     for (int node = tid; node < k; node += NT) s_dup[node] = 0;
     __syncthreads();
@@ -218,12 +220,12 @@ __device__ __forceinline__ void prep_body(const double *wl, int k, int c, Assign
             if (a[j] != b[j]) return false;
         return true;
     };
-    if (k <= PXSOM_MAX_NODES) {
+    {
         // all pairs on the row keys (equal rows have equal keys; norms are useless here: near-duplicates
         // often round to the same norm), the range of earlier nodes split over NT/k threads per node;
         // full channel comparison only on a key match.  (Also for k > 256, where each thread scans for several
-        // nodes: the hash table below took 60 us at k = 400 -- slot collisions fall back to scans one by one.)
-        __shared__ int s_first[PXSOM_MAX_NODES];
+        // nodes: a hash table took 60 us at k = 400 -- slot collisions fall back to scans one by one.)
+        __shared__ int s_first[MAXK];
         for (int node = tid; node < k; node += NT) s_first[node] = 0x7fffffff;
         __syncthreads();
         int sp = 1;
@@ -234,7 +236,7 @@ __device__ __forceinline__ void prep_body(const double *wl, int k, int c, Assign
             const int lo = part * len, hi = min(node, lo + len);
             const unsigned long long n2 = s_key[node];
             int hit = 0x7fffffff;
-#pragma unroll 8
+    #pragma unroll 8
             for (int prev = lo; prev < hi; prev++) hit = min(hit, s_key[prev] == n2 ? prev : 0x7fffffff);
             if (hit != 0x7fffffff) atomicMin(&s_first[node], hit);
         }
@@ -243,42 +245,11 @@ __device__ __forceinline__ void prep_body(const double *wl, int k, int c, Assign
             const int first = s_first[node];
             if (first >= node) continue;
             bool dup = same_rows(first, node);
-#ifdef PXSOM_PHASE_TIMING
+    #ifdef PXSOM_PHASE_TIMING
             atomicAdd((unsigned long long *)&g_phase_ticks[24], 1ull);
             if (!dup) atomicAdd((unsigned long long *)&g_phase_ticks[25], 1ull);
-#endif
+    #endif
             for (int prev = first + 1; prev < node && !dup; prev++) dup = same_rows(prev, node);  // key collision
-            if (dup) s_dup[node] = 1;
-        }
-    } else
-    // hash table keyed by the row key: slot <- smallest node index hashing there; a node is a duplicate
-    // iff an earlier node with identical channels exists.
-    {
-        __shared__ int s_tab[1024];
-        for (int i = tid; i < 1024; i += NT) s_tab[i] = 0x7fffffff;
-        __syncthreads();
-        auto slot_of = [&](int node) {
-            const unsigned long long b = s_key[node];
-            return (int)((b ^ (b >> 17) ^ (b >> 41)) & 1023ull);
-        };
-        for (int node = tid; node < k; node += NT) atomicMin(&s_tab[slot_of(node)], node);
-        __syncthreads();
-        for (int node = tid; node < k; node += NT) {
-            const int first = s_tab[slot_of(node)];
-            if (first >= node) continue;
-            auto same_as = [&](int prev) { return same_rows(prev, node); };
-            bool dup = same_as(first);
-            if (!dup) {  // slot shared with a different earlier node: scan the norms (no early exit, so
-                         // the LDS reads pipeline), full comparison only on a norm match
-                const unsigned long long n2 = s_key[node];
-                int hit = -1;
-#pragma unroll 8
-                for (int prev = 0; prev < node; prev++)
-                    if (s_key[prev] == n2 && prev != first && hit < 0) hit = prev;
-                if (hit >= 0) {
-                    for (int prev = hit; prev < node && !dup; prev++) dup = same_as(prev);
-                }
-            }
             if (dup) s_dup[node] = 1;
         }
     }

@@ -1410,8 +1410,13 @@ PXSOM_EXPORT int pxsom_assign_sums(const void *x_dev, int64_t n, int c, int64_t 
     double *scratch = reinterpret_cast<double *>(reinterpret_cast<char *>(workspace_dev) + assign_ws);
     PXSOM_HIP_TRY(hipMemsetAsync(scratch, 0, (size_t)k * (c + 1) * sizeof(double), st));
     bool fused = false;
+    static int fixed = -1;   // PXSOM_SUMS_F64=1: binary64 workgroup tables (the round-2 form) instead of fixed point
+    if (fixed < 0) {
+        const char *e = getenv("PXSOM_SUMS_F64");
+        fixed = !(e && e[0] == '1');
+    }
     rc = pxsom_bmu::assign_accumulate(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, scratch, workspace_dev, assign_ws, st,
-                                      &fused);
+                                      &fused, fixed != 0);
     if (rc) return rc;
     if (fused) {
         hipLaunchKernelGGL(stats_to_tables_kernel, dim3((k * (c + 1) + 255) / 256), dim3(256), 0, st, scratch, k, c, sums_dev,
@@ -1652,11 +1657,11 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
     int32_t *labels = reinterpret_cast<int32_t *>(ws + tw.off_labels);
     T *xg = reinterpret_cast<T *>(ws + tw.off_gather);
     const int64_t span = (int64_t)num_passes * sc.phases;
-    static int tpw = 0;   // 16-row tiles per wave of the fused step (tuning hook)
-    if (tpw == 0) {
+    static int tpw = -1;   // 16-row tiles per wave of the fused step: 0 = by step size (launch_step), PXSOM_STEP_TPW = 1 / 2 / 4 forces
+    if (tpw < 0) {
         const char *e = getenv("PXSOM_STEP_TPW");
-        tpw = e ? atoi(e) : 1;   // measured on config 2 (16 K-row steps): 1 tile per wave 0.93 ms / pass, 2 tiles 0.99
-        if (tpw != 2) tpw = 1;
+        tpw = e ? atoi(e) : 0;
+        if (tpw != 1 && tpw != 2 && tpw != 4) tpw = 0;
     }
     // which route a step takes (one decision per run: every step of a shape shares it, and so do all ranks -- the fused
     // kernel needs rows >= 1, which a rank with a short shard may not have, so empty steps are allowed there)

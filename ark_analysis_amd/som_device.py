@@ -97,10 +97,10 @@ TRAIN_UNFUSED = 1  # include/pxsom.h PXSOM_TRAIN_UNFUSED
 class BatchTrainState:
     """Caller-owned state of ``pxsom_batch_train_sched``: the codebook twin buffer ``wbuf`` [2, K, C], the
     rotating statistics ``ring`` [3, K*(C+1)] (float64; ``ring[g % 3]`` is what a multi-rank job all-reduces
-    after step g) and the scratch workspace for ``n`` training rows of ``dtype`` on ``schedule`` (an int: that many
-    equal steps per pass)."""
+    after step g) and the scratch workspace for ``n`` training rows of ``dtype`` (default: the widest, so that the
+    state fits any matrix) on ``schedule`` (an int: that many equal steps per pass)."""
 
-    def __init__(self, n: int, c: int, xdim: int, ydim: int, schedule, device, dtype=torch.float32):
+    def __init__(self, n: int, c: int, xdim: int, ydim: int, schedule, device, dtype=torch.float64):
         from .schedule import resolve
         self.n, self.c, self.xdim, self.ydim = int(n), int(c), int(xdim), int(ydim)
         self.k, self.schedule, self.dtype = self.xdim * self.ydim, resolve(schedule), dtype
@@ -313,7 +313,7 @@ def gaussian_kernel1d(sigma: float, truncate: float = 4.0):
 
 
 def gaussian_blur_hwc(img: torch.Tensor, sigma: float, tmp: Optional[torch.Tensor] = None,
-                      f32_semantics: bool = False) -> torch.Tensor:
+                      f32_semantics: bool = False, generic_form: bool = False) -> torch.Tensor:
     """In-place per-channel Gaussian blur of an [H, W, C] float64 HBM image (scipy semantics).
     ``f32_semantics``: the values are widened float32 and every pass is stored as float32, as scipy does
     for a float32 image."""
@@ -324,8 +324,8 @@ def gaussian_blur_hwc(img: torch.Tensor, sigma: float, tmp: Optional[torch.Tenso
         tmp = torch.empty_like(img)
     weights, radius = gaussian_kernel1d(sigma)
     rc = _capi.lib().pxsom_gaussian_blur_hwc(img.data_ptr(), tmp.data_ptr(), h, w, c,
-                                             weights.ctypes.data, radius, int(bool(f32_semantics)),
-                                             _capi.stream_ptr())
+                                             weights.ctypes.data, radius,
+                                             int(bool(f32_semantics)) | (2 if generic_form else 0), _capi.stream_ptr())
     _capi.check(rc, "pxsom_gaussian_blur_hwc")
     return img
 

@@ -244,6 +244,9 @@ int pxsom_batch_train_steps_sharded(const void *x_dev, int64_t n, int c, int64_t
  * order.  weights_host [2*radius+1] is the normalised kernel exactly as scipy builds it
  * (numpy exp / sum on the host: part of the reference numerics), radius = int(4*sigma + 0.5).
  * img_dev [h, w, c] binary64 interleaved, blurred in place; tmp_dev: same-size scratch. */
+#define PXSOM_BLUR_GENERIC_FORM 2 /* OR-ed into f32_semantics: the thread-per-output kernel for every shape (the pipeline's
+                                    radius-8 blur otherwise runs a register-window pass down the rows and an LDS-tiled pass
+                                    along the columns; same results bit for bit -- the tests compare the two) */
 int pxsom_gaussian_blur_hwc(double *img_dev, double *tmp_dev, int h, int w, int c,
                             const double *weights_host, int radius, int f32_semantics, void *stream);
 /* f32_semantics (here and below): the matrix holds float32 values widened to binary64 -- what the

@@ -187,3 +187,48 @@ def test_total_intensity_quantile_matches_numpy(gpu, c):
         np.testing.assert_array_equal(got64.cpu().numpy().reshape(61, 47), want64)
         for q in (0.05, 0.5):
             assert flowsom.total_intensity_quantile_f32(image, divisors, q) == np.quantile(want64, q)
+
+
+@pytest.mark.parametrize("h,w,c,f32", [(1024, 1024, 22, False), (300, 257, 7, True), (17, 9, 40, False), (130, 2000, 3, True),
+                                       (65, 33, 128, False)])
+def test_fast_blur_forms_equal_the_generic_form(gpu, oracle, h, w, c, f32):
+    """The pipeline's radius-8 blur (register window down the rows, LDS tile along the columns, tiles dealt to the XCDs
+    in contiguous runs) against the thread-per-output form on the same image: bit for bit, strip / tile / image borders
+    included; a corner of the big image against the oracle."""
+    g = torch.Generator(device=gpu)
+    g.manual_seed(h * 7 + w)
+    img = torch.empty((h, w, c), dtype=torch.float64, device=gpu).exponential_(1.0, generator=g)
+    img.mul_((torch.rand((h, w, c), generator=g, device=gpu) >= 0.4).to(torch.float64))
+    if f32:
+        img = img.float().double()
+    fast = sd.gaussian_blur_hwc(img.clone(), 2.0, f32_semantics=f32)
+    slow = sd.gaussian_blur_hwc(img.clone(), 2.0, f32_semantics=f32, generic_form=True)
+    assert torch.equal(fast, slow)
+    hh, ww = min(h, 40), min(w, 48)          # the top-left corner depends on the top-left (hh + 8) x (ww + 8) pixels only
+    if h >= hh + 8 and w >= ww + 8:
+        want = oracle.gaussian_blur_hwc(img[:hh + 8, :ww + 8].cpu().numpy().copy(), 2.0, f32=f32)
+        # (the cropped image reflects at its own lower / right border: compare the part no reflection reaches)
+        np.testing.assert_array_equal(fast[:hh, :ww].cpu().numpy(), want[:hh, :ww])
+
+
+@pytest.mark.parametrize("n,c,f32", [(1024 * 1024, 22, False), (100_003, 22, True), (5_000, 72, False), (3_001, 100, False),
+                                     (257, 1, False), (70_000, 31, True)])
+def test_rowfilter_and_quantiles_at_size(gpu, oracle, n, c, f32):
+    """Row filter + normalisation (rows staged in LDS, coalesced both ways) and the one-sweep quantile kernels on
+    inputs large enough for many workgroups: kept rows, values and per-column 99.9 % values against the oracle."""
+    rs = np.random.RandomState(n % 1000 + c)
+    x = rs.gamma(0.7, 1.0, size=(n, c))
+    x[rs.rand(n, c) < 0.45] = 0.0
+    x[::97] = 0.0                                        # all-zero rows are dropped
+    if f32:
+        x = x.astype(np.float32).astype(np.float64)
+    xd = torch.from_numpy(x).to(gpu)
+    rows, kept = sd.rowsum_filter_normalize(xd, 0.8, f32_semantics=f32)
+    want_rows, want_kept = oracle.rowsum_filter_normalize(x, 0.8, sum_mode=2 if f32 else 0)
+    np.testing.assert_array_equal(kept.cpu().numpy(), want_kept)
+    np.testing.assert_array_equal(rows.cpu().numpy(), want_rows)
+    q = sd.quantile_nonzero(rows, 0.999).cpu().numpy()
+    cols = range(c) if c <= 8 else rs.choice(c, 6, replace=False)
+    for j in cols:
+        assert q[j] == oracle.quantile_nonzero(np.ascontiguousarray(want_rows[:, j]), 0.999, 0) or \
+            (np.isnan(q[j]) and not np.any(want_rows[:, j] != 0))
