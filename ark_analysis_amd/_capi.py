@@ -14,7 +14,7 @@ from . import _build
 PXSOM_F32 = 0
 PXSOM_F64 = 1
 PXSOM_F16 = 2
-MAX_CHANNELS = 128
+MAX_CHANNELS = 1024
 MAX_NODES = 1024
 
 _STATUS = {0: "PXSOM_OK", -1: "PXSOM_ERR_INVALID_ARG", -2: "PXSOM_ERR_UNSUPPORTED",
@@ -23,7 +23,7 @@ _STATUS = {0: "PXSOM_OK", -1: "PXSOM_ERR_INVALID_ARG", -2: "PXSOM_ERR_UNSUPPORTE
 # every symbol include/pxsom.h declares: (restype, argtypes)
 _vp, _i32, _i64, _f64, _sz = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double,
                               ctypes.c_size_t)
-ABI_VERSION = 6  # include/pxsom.h PXSOM_ABI_VERSION
+ABI_VERSION = 7  # include/pxsom.h PXSOM_ABI_VERSION
 
 SYMBOLS = {
     "pxsom_abi_version": (_i32, []),
@@ -65,7 +65,9 @@ SYMBOLS = {
                                                _f64, _f64, _f64, _f64, _vp, _sz, _i32, _vp, _vp]),
     "pxsom_batch_train_sched_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32, _vp, _i32]),
     "pxsom_batch_train_sched": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32,
-                                       _f64, _f64, _f64, _f64, _vp, _sz, _i32, _vp, _vp]),
+                                       _f64, _f64, _f64, _f64, _f64, _vp, _sz, _i32, _vp, _vp]),
+    "pxsom_exact_sum_quantum": (_f64, [_f64, _i64]),
+    "pxsom_absmax": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _vp]),
     "pxsom_batch_train_sched_finish": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _f64, _f64, _f64, _f64,
                                               _vp, _vp]),
     "pxsom_batch_train_fused_route": (_i32, [_vp, _i32, _i64, _i32, _i32, _i32, _i32]),

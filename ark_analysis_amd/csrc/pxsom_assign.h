@@ -1,5 +1,7 @@
 // pxsom_assign.h -- declarations shared by the BMU-assignment translation units.
 #pragma once
+#include <algorithm>
+
 #include "pxsom_common.h"
 
 namespace pxsom_bmu {
@@ -10,6 +12,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kHdrBytes = 256;
 constexpr int kTilesPerIter = 4;  // 4 tiles x 16 pixels = one 64-row group per wave iteration
 constexpr float kNegBig = -3.0e38f;
+constexpr int kFilterMaxChannels = 128;   // the MFMA filter's row width (4 chunks of 32 slots); wider rows: bmu_wide_kernel
 
 // workspace header (one per pxsom_assign workspace)
 struct AssignHdr {
@@ -42,7 +45,13 @@ struct StepArgs {
     // takes) out of every `phases` rows; group_w == 1: a plain strided view (ldx is then ignored)
     int group_w = 1;
     int64_t group_stride = 0;
+    // binary64 rows enter the statistics rounded to multiples of the run's quantum q (include/pxsom.h "Reproducible
+    // statistics"): qmagic = 1.5 * 2^52 * q, (v + qmagic) - qmagic is that rounding; 0: off
+    double qmagic = 0.0;
 };
+
+// round-half-even to the quantum behind qmagic (exact while |v| < 2^51 q)
+__device__ __forceinline__ double qround(double v, double qmagic) { return qmagic != 0.0 ? (v + qmagic) - qmagic : v; }
 
 struct Layout {
     int k, nb, nch, cpl, nsteps, idx_bits, node_bits, cp32;
@@ -55,7 +64,7 @@ inline Layout make_layout(int64_t n, int c, int k)
     Layout L;
     L.k = k;
     L.nb = (k + 15) / 16;
-    L.nch = (c + 31) / 32;
+    L.nch = (std::min(c, kFilterMaxChannels) + 31) / 32;   // (wide rows take no filter: the fragment regions stay small)
     int per_chunk = (c + L.nch - 1) / L.nch;          // channels per chunk
     int cpl = (per_chunk + 3) / 4;                     // per lane (4 lane groups)
     cpl = (cpl + 1) & ~1;                              // even, so float2/double2 loads stay aligned
@@ -79,7 +88,7 @@ inline Layout make_layout(int64_t n, int c, int k)
     constexpr int kScreenBlocks[] = {13, 10, 8, 6, 5, 4, 3, 2};
     for (int cb : kScreenBlocks)
         if (c <= 8 * cb) L.cp32 = 8 * cb;
-    L.off_w32 = pxsom::align_up(L.off_wt + (wt_bytes > 64 * 1024 ? wt_bytes : 0), 256);
+    L.off_w32 = pxsom::align_up(L.off_wt + ((wt_bytes > 64 * 1024 || c > kFilterMaxChannels) ? wt_bytes : 0), 256);
     L.off_list = pxsom::align_up(L.off_w32 + (size_t)k * L.cp32 * sizeof(float), 256);
     L.total = L.off_list + (size_t)(n > 0 ? n : 1) * sizeof(unsigned);
     return L;

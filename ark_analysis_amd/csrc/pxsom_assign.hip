@@ -423,6 +423,104 @@ void bmu_exact_screened_kernel(const T *__restrict__ x, int c, int64_t ldx,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3c. WIDE rows (c > 128: cell x pixel-cluster count tables over the 400 nodes of a 20 x 20 pixel SOM,
+//     cell_cluster_utils.py:63-192 -> cluster_helpers.py:304-416).  No filter: every row is evaluated in the
+//     oracle's arithmetic (binary64, j ascending, no contraction, sqrt, first strict minimum).  Cell tables hold
+//     10^5 .. 10^6 rows, so the plain form is enough: a wave takes RB rows at a time, stages them in LDS (coalesced
+//     loads; every later read of x_j is an LDS broadcast), lanes <-> nodes read consecutive nodes of channel j from
+//     the transposed codebook [c][k] (workspace, L2-resident: 320 KB at 100 x 400) and share each value among the RB
+//     rows.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wide_transpose_kernel(const double *__restrict__ w, int k, int c, double *__restrict__ wt,
+                                                             AssignHdr *hdr, unsigned n)
+{
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < k * c; e += gridDim.x * 256) {
+        const int j = e / k, node = e - j * k;
+        wt[e] = w[(size_t)node * c + j];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        hdr->amb_count = n;        // every row takes the exact arithmetic (pxsom_assign_last_exact_rows)
+        hdr->force_exact = 1;
+    }
+}
+
+constexpr int kWideRows = 4;   // rows a wave evaluates together
+template <typename T>
+__global__ __launch_bounds__(256) void bmu_wide_kernel(const T *__restrict__ x, int64_t n, int c, int64_t ldx,
+                                                       const double *__restrict__ wt, int k, int32_t *__restrict__ labels)
+{
+    extern __shared__ double wide_rows[];                       // [4 waves][kWideRows][c]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double *mine = wide_rows + (size_t)wv * kWideRows * c;
+    const int64_t nbatches = (n + kWideRows - 1) / kWideRows;
+    for (int64_t b = (int64_t)blockIdx.x * 4 + wv; b < nbatches; b += (int64_t)gridDim.x * 4) {
+        const int64_t row0 = b * kWideRows;
+#pragma unroll
+        for (int u = 0; u < kWideRows; u++) {
+            const int64_t row = row0 + u < n ? row0 + u : n - 1;      // surplus slots redo the last row
+            const T *rp = x + row * ldx;
+            for (int j = lane; j < c; j += 64) mine[(size_t)u * c + j] = (double)rp[j];
+        }
+        wave_lds_sync();
+        double best[kWideRows];
+        int bestk[kWideRows];
+#pragma unroll
+        for (int u = 0; u < kWideRows; u++) {
+            best[u] = DBL_MAX;
+            bestk[u] = 0x7fffffff;
+        }
+        for (int base = 0; base < k; base += 128) {                  // two node slots per lane and sweep
+            const int n0 = base + lane, n1 = base + 64 + lane;
+            const int c0 = n0 < k ? n0 : k - 1, c1 = n1 < k ? n1 : k - 1;
+            double d0[kWideRows], d1[kWideRows];
+#pragma unroll
+            for (int u = 0; u < kWideRows; u++) d0[u] = d1[u] = 0.0;
+            for (int j0 = 0; j0 < c; j0 += 4) {                      // four channels' codebook values requested together
+                double wa[4], wb[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int j = j0 + i < c ? j0 + i : c - 1;
+                    wa[i] = wt[(size_t)j * k + c0];
+                    wb[i] = wt[(size_t)j * k + c1];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (j0 + i < c) {   // uniform
+#pragma unroll
+                        for (int u = 0; u < kWideRows; u++) {
+                            const double xj = mine[(size_t)u * c + j0 + i];
+                            const double t0 = xj - wa[i], t1 = xj - wb[i];
+                            d0[u] += t0 * t0;
+                            d1[u] += t1 * t1;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kWideRows; u++) {                    // ascending node order within the lane
+                const double s0 = sqrt(d0[u]), s1 = sqrt(d1[u]);
+                if (n0 < k && s0 < best[u]) {
+                    best[u] = s0;
+                    bestk[u] = n0;
+                }
+                if (n1 < k && s1 < best[u]) {
+                    best[u] = s1;
+                    bestk[u] = n1;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kWideRows; u++) {
+            const double smin = pxsom::wave_min_f64(best[u]);
+            const unsigned cand = best[u] == smin ? (unsigned)bestk[u] : 0xffffffffu;
+            const int win = (int)pxsom::wave_min_u32(cand);          // 0x7fffffff: no finite distance (NaN row)
+            if (lane == 0 && row0 + u < n) labels[row0 + u] = win == 0x7fffffff ? 0 : win + 1;
+        }
+        wave_lds_sync();                                             // the rows are overwritten by the next batch
+    }
+}
+
 // distance of every row to its labelled node (only when the caller asks for dists)
 template <typename T>
 __global__ __launch_bounds__(256) void bmu_dist_kernel(const T *__restrict__ x, int64_t n, int c,
@@ -474,6 +572,33 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
                  double *dist, char *ws, const Layout &L, hipStream_t st, double *stats = nullptr,
                  bool prepared = false, bool fixed = false)
 {
+    if (c > kFilterMaxChannels) {   // wide rows: no filter, every row in the oracle's arithmetic (section 3c)
+        double *wt = reinterpret_cast<double *>(ws + L.off_wt);
+        hipLaunchKernelGGL(wide_transpose_kernel, dim3((unsigned)std::min<int64_t>(((int64_t)k * c + 255) / 256, 1024)), dim3(256), 0, st,
+                           w, k, c, wt, reinterpret_cast<AssignHdr *>(ws), (unsigned)n);
+        PXSOM_LAUNCH_CHECK("wide_transpose_kernel");
+        const size_t lds = (size_t)4 * kWideRows * c * sizeof(double);
+        auto kern = bmu_wide_kernel<T>;
+        static pxsom::PerDevice<size_t> raised;
+        size_t &have = raised.here();
+        if (lds > 48 * 1024 && have < lds) {
+            PXSOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            have = lds;
+        }
+        const int wcus = pxsom::device_cu_count();
+        const int64_t wgrid = std::max<int64_t>(1, std::min<int64_t>((n + 4 * kWideRows - 1) / (4 * kWideRows), (int64_t)wcus * 4));
+        pxsom::Prof *wprof = pxsom::current_prof();
+        pxsom::prof_mark(wprof, st, true, n);
+        hipLaunchKernelGGL(kern, dim3((unsigned)wgrid), dim3(256), lds, st, x, n, c, ldx, wt, k, labels);
+        pxsom::prof_mark(wprof, st, false, n);
+        PXSOM_LAUNCH_CHECK("bmu_wide_kernel");
+        if (dist) {
+            int dgrid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)wcus * 8);
+            hipLaunchKernelGGL(bmu_dist_kernel<T>, dim3(dgrid < 1 ? 1 : dgrid), dim3(256), 0, st, x, n, c, ldx, w, labels, dist);
+            PXSOM_LAUNCH_CHECK("bmu_dist_kernel");
+        }
+        return PXSOM_OK;
+    }
     if (!prepared && !stats) {  // prepared: pxsom_batch_update_prepare did this; stats: the accumulating filter
                                  // prepares the codebook inside its own launch
         const size_t stage_bytes = (size_t)k * c * sizeof(double);

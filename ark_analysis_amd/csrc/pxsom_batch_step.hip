@@ -65,7 +65,8 @@ __host__ __device__ inline StepLds step_lds(int c)
 #pragma clang fp contract(off)
 // One listed row settled by a whole wave: lanes <-> nodes lane and lane + 64, the row's values read from LDS
 // (one address for the wave: a broadcast), distances exactly as the oracle forms them.
-__device__ __forceinline__ void exact_row_from_lds(const double *xr, int c, const double *wt, double *ls, int lane)
+__device__ __forceinline__ void exact_row_from_lds(const double *xr, int c, const double *wt, double *ls, int lane,
+                                                   double qmagic)
 {
     const int n0 = lane, n1 = lane + 64;
     const int c1 = n1 < kK ? n1 : kK - 1;
@@ -107,7 +108,7 @@ __device__ __forceinline__ void exact_row_from_lds(const double *xr, int c, cons
     const int win = (int)pxsom::wave_min_u32(best == smin ? (unsigned)bestk : 0xffffffffu);
     if (win != 0x7fffffff) {   // 0x7fffffff: no finite distance (NaN row): label 0, not accumulated
         if (lane < c)
-            __hip_atomic_fetch_add(ls + (size_t)win * c + lane, xr[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(ls + (size_t)win * c + lane, qround(xr[lane], qmagic), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (lane == 0)
             __hip_atomic_fetch_add(ls + (size_t)kK * c + win, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
     // rows of this wave's tiles (rows past the end re-read the last row and are ignored afterwards)
     P2 raw[TPW][NP];
     const unsigned group_w = (unsigned)sa.group_w;
+    const double qmagic = sizeof(T) == 8 ? sa.qmagic : 0.0;
     auto load_rows = [&](int64_t blk) {
 #pragma unroll
         for (int t = 0; t < TPW; t++) {
@@ -519,8 +521,13 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
 #pragma unroll
                 for (int p = 0; p < NP; p++) {
                     if (q * CPL + 2 * p <= c - 2) {   // clamped slots re-read the last pair: not theirs
-                        __hip_atomic_fetch_add(dst + 2 * p, (double)cur[t][p].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(dst + 2 * p + 1, (double)cur[t][p].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        double v0 = (double)cur[t][p].x, v1 = (double)cur[t][p].y;
+                        if constexpr (sizeof(T) == 8) {   // binary64 rows: rounded to the run's quantum (exact, order-free sums)
+                            v0 = qround(v0, qmagic);
+                            v1 = qround(v1, qmagic);
+                        }
+                        __hip_atomic_fetch_add(dst + 2 * p, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(dst + 2 * p + 1, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
                 if (q == 0)
@@ -560,7 +567,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    exact_row_from_lds(slot, c, wt, ls, lane);
+                    exact_row_from_lds(slot, c, wt, ls, lane, qmagic);
                     __builtin_amdgcn_wave_barrier();
                 }
             }
@@ -568,7 +575,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
         PXSOM_PHASE(16);
         __syncthreads();   // every wave is through its tiles: the queue is complete
         const unsigned queued = hdr->q_n < (unsigned)kQueueRows ? hdr->q_n : (unsigned)kQueueRows;
-        for (unsigned i = wv; i < queued; i += kStepWaves) exact_row_from_lds(qrows + (size_t)i * c, c, wt, ls, lane);
+        for (unsigned i = wv; i < queued; i += kStepWaves) exact_row_from_lds(qrows + (size_t)i * c, c, wt, ls, lane, qmagic);
         __syncthreads();
         if (blk + gridDim.x < nblocks && tid == 0) hdr->q_n = 0u;
         PXSOM_PHASE(17);

@@ -616,7 +616,7 @@ PXSOM_EXPORT int pxsom_gaussian_blur_hwc(double *img_dev, double *tmp_dev, int h
     f32_semantics &= 1;
     // the pipeline's kernel (sigma = 2 -> radius 8) on images of at least a strip: register window down the rows, LDS
     // tile along the columns; anything else (other radii, images shorter than the window) takes the generic form
-    if (radius == 8 && !generic && h >= 17 && w >= 9 && (int64_t)c * 16 + 256 <= 16 * 1024) {
+    if (radius == 8 && !generic && h >= 17 && w >= 9 && c <= 256) {   // (tile + halo of the column pass: <= 41 KB of LDS)
         constexpr int R = 8;
         const int TY = 64;
         const int64_t ncb = (wc + 255) / 256, strips = (h + TY - 1) / TY, nb0 = ncb * strips;

@@ -611,28 +611,28 @@ __global__ __launch_bounds__(256) void batch_update_kernel(double *w, int xdim, 
         lc = ss + ne;
         boff = b_lo;
     }
-    const int j = tid;
-    if (j >= c) return;
-    const double wv = w[(size_t)k * c + j];
-    // separable order of orc_batch_update: T[bx] = sum over the window's by (ascending), num = sum of T[bx]
-    double num = 0.0, den = 0.0;
-    for (int bx = x0; bx <= x1; bx++) {
-        double tn = 0.0, td = 0.0;
+    for (int j = tid; j < c; j += 256) {   // (wide rows: more channels than threads)
+        const double wv = w[(size_t)k * c + j];
+        // separable order of orc_batch_update: T[bx] = sum over the window's by (ascending), num = sum of T[bx]
+        double num = 0.0, den = 0.0;
+        for (int bx = x0; bx <= x1; bx++) {
+            double tn = 0.0, td = 0.0;
 #pragma unroll 4
-        for (int by = y0; by <= y1; by++) {
-            const int b = bx * ydim + by - boff;
-            td += lc[b];
-            tn += ls[(size_t)b * c + j];
+            for (int by = y0; by <= y1; by++) {
+                const int b = bx * ydim + by - boff;
+                td += lc[b];
+                tn += ls[(size_t)b * c + j];
+            }
+            den += td;
+            num += tn;
         }
-        den += td;
-        num += tn;
-    }
-    if (den > 0.0) {
-        // 1 - (1-alpha)^den as -expm1(den * log(1-alpha)), the logarithm taken on the host (orc_batch_update)
-        const double gain = -expm1(den * lg), inv = 1.0 / den;
-        // gain == 1 exactly (wide windows): the node is the window mean itself, so nodes sharing a window are
-        // bit-identical (and masked as duplicates by prep) instead of one ulp apart (orc_batch_update)
-        w[(size_t)k * c + j] = gain == 1.0 ? num * inv : wv + gain * (num * inv - wv);
+        if (den > 0.0) {
+            // 1 - (1-alpha)^den as -expm1(den * log(1-alpha)), the logarithm taken on the host (orc_batch_update)
+            const double gain = -expm1(den * lg), inv = 1.0 / den;
+            // gain == 1 exactly (wide windows): the node is the window mean itself, so nodes sharing a window are
+            // bit-identical (and masked as duplicates by prep) instead of one ulp apart (orc_batch_update)
+            w[(size_t)k * c + j] = gain == 1.0 ? num * inv : wv + gain * (num * inv - wv);
+        }
     }
 }
 
@@ -687,7 +687,7 @@ template <typename T, bool COUNT_F64, int NT>
 __global__ __launch_bounds__(NT) void cluster_sums_kernel(const T *__restrict__ x, int64_t n, int c,
                                                            int64_t ldx, const int32_t *__restrict__ labels,
                                                            int k, double *sums, unsigned long long *counts,
-                                                           int64_t rows_per_block, int use_lds)
+                                                           int64_t rows_per_block, int use_lds, double qmagic)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double *ls = reinterpret_cast<double *>(smem_raw);                 // [k*c] + kSumsSpare slots nobody reads
@@ -866,6 +866,7 @@ __global__ __launch_bounds__(NT) void cluster_sums_kernel(const T *__restrict__ 
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
+                if constexpr (sizeof(T) == 8) v[u] = pxsom_bmu::qround(v[u], qmagic);   // binary64 rows of a reproducible run
                 if (lab[u] >= 0 && lab[u] < k) {
                     if (use_lds) {
                         TableAdd<T>::add(ls, (size_t)lab[u] * c + cc[u], v[u], sums);
@@ -1224,15 +1225,18 @@ int launch_sums_private(const T *x, int64_t n, int c, int64_t ldx, const int32_t
     return PXSOM_OK;
 }
 
+// qmagic != 0 (binary64 rows of a reproducible training run, include/pxsom.h): values are rounded to the run's quantum
+// as they are added; only the atomic kernel knows how.
 template <typename T, bool COUNT_F64 = false>
 int cluster_sums_typed(const T *x, int64_t n, int c, int64_t ldx, const int32_t *labels, int k, double *sums,
-                       int64_t *counts, hipStream_t st)
+                       int64_t *counts, hipStream_t st, double qmagic = 0.0)
 {
+    if (sizeof(T) != 8) qmagic = 0.0;
     // wave-private tables (see cluster_sums_private_kernel): 13 <= c <= 64 (RPI = 64 / c <= 4 rows per
     // instruction, fewer idle lanes than channels), at least two tables per CU, an input big enough to
     // fill them, and a wave's byte range addressable by the 32-bit buffer offsets.  Measured against the
     // atomic kernel below on 2-4 M rows: 1.4-1.9x faster there, slower outside (c <= 8, one table per CU).
-    if (c >= 13 && c <= 64 && n >= 32768) {
+    if (c >= 13 && c <= 64 && n >= 32768 && qmagic == 0.0) {
         const size_t tbytes = ((size_t)(k + 1) * c + 64) * 8, budget = 160 * 1024 - 1024;
         int nwv = 0, per_cu = 1;
         if (8 * tbytes + (size_t)k * 8 <= budget) nwv = 4, per_cu = 2;
@@ -1273,7 +1277,7 @@ int cluster_sums_typed(const T *x, int64_t n, int c, int64_t ldx, const int32_t 
         PXSOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(wide ? 1024 : 256), use_lds ? lds : 0, st, x, n, c, ldx, labels, k,
-                       sums, reinterpret_cast<unsigned long long *>(counts), rows_per_block, use_lds);
+                       sums, reinterpret_cast<unsigned long long *>(counts), rows_per_block, use_lds, qmagic);
     PXSOM_LAUNCH_CHECK("cluster_sums_kernel");
     return PXSOM_OK;
 }
@@ -1441,10 +1445,25 @@ static bool self_preparing_shape(int c, int k)
 // multi-GPU all-reduce is a single sum over one buffer.
 // flags & PXSOM_ACC_PREPARED: pxsom_batch_update_prepare already cleared stats_dev (and prepared the workspace
 // for w_dev where the shape needs one).
+static int batch_accumulate_impl(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev, int k,
+                                 int32_t *labels_dev, double *stats_dev, void *workspace_dev, size_t workspace_bytes, int flags,
+                                 void *stream, double qmagic);
+
 PXSOM_EXPORT int pxsom_batch_accumulate(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype,
                                         const double *w_dev, int k, int32_t *labels_dev, double *stats_dev,
                                         void *workspace_dev, size_t workspace_bytes, int flags, void *stream)
 {
+    return batch_accumulate_impl(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, stats_dev, workspace_dev, workspace_bytes, flags,
+                                 stream, 0.0);
+}
+
+// qmagic != 0: binary64 rows rounded to the run's quantum as they join the statistics (the one-launch accumulating filter
+// does not know the rounding: search and sums run as two kernels then)
+static int batch_accumulate_impl(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev, int k,
+                                 int32_t *labels_dev, double *stats_dev, void *workspace_dev, size_t workspace_bytes, int flags,
+                                 void *stream, double qmagic)
+{
+    if (dtype != PXSOM_F64) qmagic = 0.0;
     if (!stats_dev || k < 1 || k > PXSOM_MAX_NODES || c < 1 || c > PXSOM_MAX_CHANNELS)
         return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_batch_accumulate: bad statistics buffer / shape");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -1453,7 +1472,9 @@ PXSOM_EXPORT int pxsom_batch_accumulate(const void *x_dev, int64_t n, int c, int
     // fused route (register-resident filter shapes): ONE launch prepares the codebook, labels every row,
     // settles the listed rows and accumulates -- one pass over x
     bool fused = false;
-    int rc = pxsom_bmu::assign_accumulate(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, stats_dev, workspace_dev,
+    int rc = PXSOM_OK;
+    if (qmagic == 0.0)
+        rc = pxsom_bmu::assign_accumulate(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, stats_dev, workspace_dev,
                                           workspace_bytes, st, &fused);
     if (fused) return rc;
     if (n == 0) return PXSOM_OK;
@@ -1469,7 +1490,7 @@ PXSOM_EXPORT int pxsom_batch_accumulate(const void *x_dev, int64_t n, int c, int
     if (rc) return rc;
     double *sums = stats_dev;
     int64_t *counts = reinterpret_cast<int64_t *>(stats_dev + (size_t)k * c);
-    PXSOM_DISPATCH_DTYPE(dtype, x_dev, xp, (cluster_sums_typed<T, true>(xp, n, c, ldx, labels_dev, k, sums, counts, st)));
+    PXSOM_DISPATCH_DTYPE(dtype, x_dev, xp, (cluster_sums_typed<T, true>(xp, n, c, ldx, labels_dev, k, sums, counts, st, qmagic)));
 }
 
 // The update half of a mini-batch step plus what the NEXT pxsom_batch_accumulate(PXSOM_ACC_PREPARED) relies on:
@@ -1648,8 +1669,10 @@ namespace {
 template <typename T>
 int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, double *wbuf, double *ring, int xdim,
                       int ydim, const Sched &sc, int g_begin, int g_end, int num_passes, double a0, double a1, double r0,
-                      double r1, char *ws, size_t ws_bytes, int flags, pxsom_comm *comm, hipStream_t st)
+                      double r1, double sum_quantum, char *ws, size_t ws_bytes, int flags, pxsom_comm *comm, hipStream_t st)
 {
+    // binary64 rows of a reproducible run: (v + qmagic) - qmagic rounds v to a multiple of the quantum
+    const double qmagic = (sizeof(T) == 8 && sum_quantum > 0.0) ? 6755399441055744.0 /* 1.5 * 2^52 */ * sum_quantum : 0.0;
     const int k = xdim * ydim;
     const size_t nstats = (size_t)k * (c + 1), nw = (size_t)k * c;
     const TrainWs tw = train_ws(n, c, k, sizeof(T), sc);
@@ -1702,6 +1725,7 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
             sa.tol_abs = (float)(2.5 * ldexp(1.0, -24) * sqrt((double)c));
             sa.group_w = wd > 1 ? wd : 1;
             sa.group_stride = (int64_t)sc.phases * ldx;
+            sa.qmagic = qmagic;
             // (an empty step -- a rank whose shard is shorter than the schedule -- still launches: the update, the
             // clearing of the next buffer and W_g are the kernel's, and every rank must take the same route)
             int rc = pxsom_bmu::launch_batch_step<T>(x + (size_t)sc.e0(g) * ldx, rows, c, wd > 1 ? ldx : ldx * sc.phases,
@@ -1732,7 +1756,7 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
                 if (rows > 0) {
                     rc = pxsom_bmu::assign_prepared(xv, rows, c, ldv, dtype, w_cur, k, labels, ws, assign_ws, st);
                     if (rc) return rc;
-                    rc = cluster_sums_typed<T, true>(xv, rows, c, ldv, labels, k, s_cur, reinterpret_cast<int64_t *>(s_cur + nw), st);
+                    rc = cluster_sums_typed<T, true>(xv, rows, c, ldv, labels, k, s_cur, reinterpret_cast<int64_t *>(s_cur + nw), st, qmagic);
                     if (rc) return rc;
                 }
                 if (comm && (rc = pxsom::comm_allreduce_sum_f64(comm, s_cur, nstats, st))) return rc;
@@ -1745,7 +1769,7 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
             if (rc) return rc;
         }
         PXSOM_HIP_TRY(hipMemsetAsync(s_next, 0, nstats * sizeof(double), st));
-        int rc = pxsom_batch_accumulate(xv, rows, c, ldv, dtype, w_cur, k, labels, s_cur, ws, assign_ws, 0, st);
+        int rc = batch_accumulate_impl(xv, rows, c, ldv, dtype, w_cur, k, labels, s_cur, ws, assign_ws, 0, st, qmagic);
         if (rc) return rc;
         if (comm && (rc = pxsom::comm_allreduce_sum_f64(comm, s_cur, nstats, st))) return rc;
     }
@@ -1781,10 +1805,16 @@ PXSOM_EXPORT size_t pxsom_batch_train_workspace_bytes(int64_t n, int batch_steps
 PXSOM_EXPORT int pxsom_batch_train_sched(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, double *wbuf_dev,
                                          double *stats_ring_dev, int xdim, int ydim, int phases, const int32_t *edges,
                                          int steps_per_pass, int g_begin, int g_end, int num_passes, double a0, double a1,
-                                         double r0, double r1, void *workspace_dev, size_t workspace_bytes, int flags,
-                                         pxsom_comm *comm, void *stream)
+                                         double r0, double r1, double sum_quantum, void *workspace_dev, size_t workspace_bytes,
+                                         int flags, pxsom_comm *comm, void *stream)
 {
     int rc = check_matrix("pxsom_batch_train_sched", x_dev, n, c, ldx, dtype);
+    if (rc) return rc;
+    {
+        int qe = 0;
+        if (!(sum_quantum >= 0.0) || (sum_quantum > 0.0 && frexp(sum_quantum, &qe) != 0.5))
+            return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_batch_train_sched: sum_quantum must be 0 or a power of two");
+    }
     if (rc) return rc;
     if (xdim < 1 || ydim < 1 || (int64_t)xdim * ydim > PXSOM_MAX_NODES)
         return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "pxsom_batch_train_sched: grid %dx%d outside [1, %d] nodes", xdim, ydim,
@@ -1803,7 +1833,7 @@ PXSOM_EXPORT int pxsom_batch_train_sched(const void *x_dev, int64_t n, int c, in
     const Sched sc{phases, steps_per_pass, edges};
     PXSOM_DISPATCH_DTYPE(dtype, x_dev, xp,
                          train_steps_typed<T>(xp, n, c, ldx, dtype, wbuf_dev, stats_ring_dev, xdim, ydim, sc, g_begin, g_end,
-                                              num_passes, a0, a1, r0, r1, reinterpret_cast<char *>(workspace_dev),
+                                              num_passes, a0, a1, r0, r1, sum_quantum, reinterpret_cast<char *>(workspace_dev),
                                               workspace_bytes, flags, comm, st));
 }
 
@@ -1829,7 +1859,7 @@ PXSOM_EXPORT int pxsom_batch_train_steps_sharded(const void *x_dev, int64_t n, i
                            g_begin, g_end, total_steps, batch_steps, PXSOM_MAX_SCHED_STEPS);
     const std::vector<int32_t> e = equal_edges(batch_steps);
     return pxsom_batch_train_sched(x_dev, n, c, ldx, dtype, wbuf_dev, stats_ring_dev, xdim, ydim, batch_steps, e.data(),
-                                   batch_steps, g_begin, g_end, total_steps / batch_steps, a0, a1, r0, r1, workspace_dev,
+                                   batch_steps, g_begin, g_end, total_steps / batch_steps, a0, a1, r0, r1, 0.0, workspace_dev,
                                    workspace_bytes, flags, comm, stream);
 }
 
@@ -1889,4 +1919,56 @@ PXSOM_EXPORT int pxsom_batch_train_fused_route(const void *x_dev, int c, int64_t
     if (dtype == PXSOM_F32) return pxsom_bmu::step_fused_shape<float>(static_cast<const float *>(x_dev), 1, c, ldx, xdim, ydim, gs);
     if (dtype == PXSOM_F16) return pxsom_bmu::step_fused_shape<_Float16>(static_cast<const _Float16 *>(x_dev), 1, c, ldx, xdim, ydim, gs);
     return pxsom_bmu::step_fused_shape<double>(static_cast<const double *>(x_dev), 1, c, ldx, xdim, ydim, gs);
+}
+
+// ---- reproducible statistics for binary64 rows (include/pxsom.h) ----------------------------------------------------
+PXSOM_EXPORT double pxsom_exact_sum_quantum(double value_bound, int64_t rows_bound)
+{
+    if (!(value_bound > 0.0) || !(value_bound <= DBL_MAX)) return 0.0;   // all-zero / unbounded data: nothing to round to
+    if (rows_bound < 2) rows_bound = 2;
+    // sums stay below rows * bound < 2^e; with q = 2^(e - 52) they are multiples of q below 2^52 q: exactly representable,
+    // and so is every partial sum in any order
+    int e = 0;
+    frexp(value_bound, &e);                    // value_bound < 2^e
+    int r = 0;
+    while (((int64_t)1 << r) < rows_bound && r < 62) r++;
+    return ldexp(1.0, e + r - 52);
+}
+
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void absmax_kernel(const T *__restrict__ x, int64_t n, int c, int64_t ldx,
+                                                     unsigned long long *out)
+{
+    double m = 0.0;
+    const int64_t total = n * c;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t row = e / c;
+        const double v = fabs((double)x[row * ldx + (e - row * c)]);
+        if (v <= DBL_MAX && v > m) m = v;      // (NaN and Inf fail the first test)
+    }
+    m = -pxsom::wave_min_f64(-m);
+    // non-negative binary64 numbers order like their bit patterns
+    if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+}
+}  // namespace
+
+PXSOM_EXPORT int pxsom_absmax(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, double *out_dev, void *stream)
+{
+    int rc = check_matrix("pxsom_absmax", x_dev, n, c, ldx, dtype);
+    if (rc) return rc;
+    if (!out_dev) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_absmax: null output");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    PXSOM_HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(double), st));
+    if (n == 0) return PXSOM_OK;
+    const int64_t grid = std::min<int64_t>((n * c + 255) / 256, (int64_t)pxsom::device_cu_count() * 8);
+    unsigned long long *out = reinterpret_cast<unsigned long long *>(out_dev);
+    if (dtype == PXSOM_F32)
+        hipLaunchKernelGGL(absmax_kernel<float>, dim3((unsigned)grid), dim3(256), 0, st, static_cast<const float *>(x_dev), n, c, ldx, out);
+    else if (dtype == PXSOM_F16)
+        hipLaunchKernelGGL(absmax_kernel<_Float16>, dim3((unsigned)grid), dim3(256), 0, st, static_cast<const _Float16 *>(x_dev), n, c, ldx, out);
+    else
+        hipLaunchKernelGGL(absmax_kernel<double>, dim3((unsigned)grid), dim3(256), 0, st, static_cast<const double *>(x_dev), n, c, ldx, out);
+    PXSOM_LAUNCH_CHECK("absmax_kernel");
+    return PXSOM_OK;
 }

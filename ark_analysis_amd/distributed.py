@@ -55,13 +55,17 @@ class HipKernels:
         self._state = None
         self.unfused = bool(unfused)
 
-    def begin(self, x: torch.Tensor, w: torch.Tensor, xdim: int, ydim: int, schedule, group=None) -> None:
+    def absmax(self, x: torch.Tensor) -> float:
+        return float(self._sd.absmax(x).item()) if x.shape[0] else 0.0
+
+    def begin(self, x: torch.Tensor, w: torch.Tensor, xdim: int, ydim: int, schedule, group=None, quantum: float = 0.0) -> None:
         n, c = x.shape
         st = self._state
         if st is None or not st.fits(n, c, xdim, ydim, schedule, x.dtype) or st.wbuf.device != x.device:
             st = self._state = self._sd.BatchTrainState(n, c, xdim, ydim, schedule, x.device, dtype=x.dtype)
             self._rings = [st.ring[i] for i in range(3)]     # views made once: ring(g) sits in the per-step loop
         st.wbuf[0].copy_(w)
+        st.quantum = float(quantum)
         # The route (one-launch fused step / launch per phase) is a collective decision: the two routes apply the same
         # statistics but round the codebook's last bits differently, and a rank with an oddly aligned or empty shard
         # must not part ways with the others.
@@ -110,6 +114,25 @@ class BatchSOMTrainer:
         self.group = group
         self.kernels = kernels if kernels is not None else HipKernels()
 
+    def _sum_quantum(self, x_local: torch.Tensor) -> float:
+        """binary64 rows (what the drop-in classes hand over) train reproducibly: every value joins the per-BMU sums
+        rounded to a power of two q chosen so that all partial sums are exact -- the statistics, hence the whole run, are
+        then independent of summation order, workgroup count and rank count (include/pxsom.h "Reproducible statistics";
+        reference property: same-seed retraining gives the same weights, tests/phenotyping/cluster_helpers_test.py:323-332).
+        q follows from the job's largest |value| and the most rows a step holds over all ranks; 0 for other dtypes."""
+        if x_local.dtype != torch.float64:
+            return 0.0
+        from . import som_device
+        world = _world(self.group)
+        vmax, n_total = self.kernels.absmax(x_local), int(x_local.shape[0])
+        if world > 1:
+            t = torch.tensor([vmax, float(n_total)], dtype=torch.float64, device=_collective_device(self.group))
+            dist.all_reduce(t[:1], op=dist.ReduceOp.MAX, group=self.group)
+            dist.all_reduce(t[1:], op=dist.ReduceOp.SUM, group=self.group)
+            vmax, n_total = float(t[0].item()), int(t[1].item())
+        widest = max(b - a for a, b in zip(self.schedule.edges, self.schedule.edges[1:]))
+        return som_device.exact_sum_quantum(vmax, (n_total // self.schedule.phases + world) * max(widest, 1))
+
     def train(self, x_local: torch.Tensor, w: torch.Tensor, num_passes: int = 1) -> torch.Tensor:
         """Runs num_passes passes in place on ``w`` [K, C] f64 (identical on every rank)."""
         total = int(num_passes) * self.batch_steps
@@ -119,10 +142,11 @@ class BatchSOMTrainer:
             raise ValueError(f"matrix [{tuple(x_local.shape)}] / codebook [{tuple(w.shape)}] do not match "
                              f"the trainer's {self.k} nodes x {self.c} channels")
         kern = self.kernels
+        quantum = self._sum_quantum(x_local)
         if isinstance(kern, HipKernels):
-            kern.begin(x_local, w, self.xdim, self.ydim, self.schedule, group=self.group)
+            kern.begin(x_local, w, self.xdim, self.ydim, self.schedule, group=self.group, quantum=quantum)
         else:
-            kern.begin(x_local, w, self.xdim, self.ydim, self.schedule)
+            kern.begin(x_local, w, self.xdim, self.ydim, self.schedule, quantum=quantum)
         if _world(self.group) > 1:
             comm = kern.exchange(self.group) if hasattr(kern, "exchange") else None
             if comm is not None:     # step launches and their all-reduces back to back on one stream, one call

@@ -39,7 +39,8 @@ from ..host_utils import validate_paths, verify_in_list
 
 def _capi_limits() -> Tuple[int, int]:
     """(max feature columns, max nodes) of the kernels: PXSOM_MAX_CHANNELS, PXSOM_MAX_NODES."""
-    return 128, 1024
+    from .. import _capi
+    return _capi.MAX_CHANNELS, _capi.MAX_NODES
 
 
 def _row_blocks(n_rows: int, block: int) -> Iterator[Tuple[int, int]]:
@@ -74,9 +75,7 @@ class PixieSOMCluster(ABC):
         # a kernel status code in the middle of a run
         if len(columns) > _capi_limits()[0] or int(xdim) * int(ydim) > _capi_limits()[1]:
             raise ValueError("this build's SOM kernels take at most %d feature columns and %d nodes; got %d columns "
-                             "on a %d x %d grid (e.g. a cell SOM over pixel_som_cluster counts of a 20 x 20 pixel "
-                             "SOM has 400 columns: cluster on pixel_meta_cluster_rename instead)"
-                             % (_capi_limits() + (len(columns), xdim, ydim)))
+                             "on a %d x %d grid" % (_capi_limits() + (len(columns), xdim, ydim)))
         self.weights_path = weights_path
         self.columns = columns
         self.xdim, self.ydim = xdim, ydim

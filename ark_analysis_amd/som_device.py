@@ -114,12 +114,27 @@ class BatchTrainState:
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
         self.wbuf = torch.empty((2, self.k, self.c), dtype=torch.float64, device=device)
         self.ring = torch.zeros((3, self.k * (self.c + 1)), dtype=torch.float64, device=device)
+        self.quantum = 0.0      # > 0: binary64 rows join the statistics rounded to its multiples (exact, order-free sums)
 
     def fits(self, n: int, c: int, xdim: int, ydim: int, schedule, dtype=None) -> bool:
         from .schedule import resolve
         return (c == self.c and xdim == self.xdim and ydim == self.ydim and resolve(schedule) == self.schedule
                 and n <= self.n and (dtype is None or torch.empty(0, dtype=dtype).element_size()
                                      <= torch.empty(0, dtype=self.dtype).element_size()))
+
+
+def absmax(x: torch.Tensor) -> torch.Tensor:
+    """max |x| over the finite entries of a matrix, as a 1-element float64 HBM tensor (0 when there is none)."""
+    n, c, ldx, dt = _matrix_args(x)
+    out = torch.empty(1, dtype=torch.float64, device=x.device)
+    _capi.check(_capi.lib().pxsom_absmax(x.data_ptr(), n, c, ldx, dt, out.data_ptr(), _capi.stream_ptr()), "pxsom_absmax")
+    return out
+
+
+def exact_sum_quantum(value_bound: float, rows_bound: int) -> float:
+    """The power of two q for which sums of at most ``rows_bound`` multiples of q below ``value_bound`` are exact in binary64
+    (include/pxsom.h "Reproducible statistics"); 0 for all-zero data.  Host arithmetic, no GPU."""
+    return float(_capi.lib().pxsom_exact_sum_quantum(float(value_bound), int(rows_bound)))
 
 
 def batch_train_fused_route(x: torch.Tensor, xdim: int, ydim: int, schedule) -> bool:
@@ -146,7 +161,7 @@ def batch_train_steps(x: torch.Tensor, state: BatchTrainState, g_begin: int, g_e
     rc = _capi.lib().pxsom_batch_train_sched(
         x.data_ptr(), n, c, ldx, dt, state.wbuf.data_ptr(), state.ring.data_ptr(), state.xdim, state.ydim,
         sch.phases, state.edges.ctypes.data, sch.steps, int(g_begin), int(g_end), int(total_steps) // sch.steps,
-        float(alpha_range[0]), float(alpha_range[1]), float(radius_range[0]), float(radius_range[1]),
+        float(alpha_range[0]), float(alpha_range[1]), float(radius_range[0]), float(radius_range[1]), float(state.quantum),
         state.ws.data_ptr(), state.ws_bytes, TRAIN_UNFUSED if unfused else 0,
         comm.handle if comm is not None else None, _capi.stream_ptr())
     _capi.check(rc, "pxsom_batch_train_sched")

@@ -9,8 +9,8 @@ One "step" = one pass of the hot path over one batch of synthetic input, residen
 the clock starts ("normalised pixel matrix resident" -> "labels + codebook + mean table
 resident"):  batch-mode SOM training (1 pass over the training subset, `--batch-steps` mini-batch
 steps, statistics all-reduced over RCCL when N > 1)  +  BMU assignment of every row  +  the per-cluster
-mean-expression table over all rows (sums/counts all-reduced once when N > 1); `--one-pass` takes labels and table from
-one pass over x (pxsom_assign_sums) instead of two kernels.
+mean-expression table over all rows (sums/counts all-reduced once when N > 1) -- labels and table from ONE pass over x
+(pxsom_assign_sums; `--two-pass`: pxsom_assign + pxsom_cluster_sums, the round-1/2 form).
 Workloads (`--config`; BASELINE.json configs):
   cfg2  10 FOVs 1024x1024x22 fp32 per GPU, 10x10 SOM     (configs[1] at N = 1; the metric's configuration; default)
   cfg3  25 FOVs 1024x1024x22 fp32 per GPU, 10x10 SOM     (configs[2]: 200 FOVs over 8 GPUs)
@@ -86,12 +86,15 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-online", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (traffic / mfma_util)")
-    ap.add_argument("--one-pass", action="store_true",
-                    help="labels and mean table from ONE pass over x (pxsom_assign_sums) instead of pxsom_assign + "
-                         "pxsom_cluster_sums; measured on config 2: 0.444 ms against 0.488 ms for the two kernels, the merged "
-                         "kernel bound by the LDS binary64 atomic rate (0.29 of the HBM roofline against 0.52 + 0.53)")
+    ap.add_argument("--two-pass", action="store_true",
+                    help="labels and mean table from two kernels (pxsom_assign + pxsom_cluster_sums, x read twice: 0.49 ms on "
+                         "config 2) instead of ONE pass over x (pxsom_assign_sums: 0.36 ms, fixed-point workgroup tables; the "
+                         "default since round 3)")
+    ap.add_argument("--no-operating-range", action="store_true", help="skip the operating-range legs (data-row / near-tie codebooks)")
     ap.add_argument("--pmc-inner", action="store_true", help=argparse.SUPPRESS)   # the run rocprofv3 wraps
-    return ap.parse_args()
+    a = ap.parse_args()
+    a.one_pass = not a.two_pass
+    return a
 
 
 def respawn_under_torchrun(args):
@@ -283,8 +286,20 @@ def main():
     train_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_train]))
     k8_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_k8]))
     # (the one-pass kernel settles its listed rows inside the launch: no list to count afterwards)
+    comm_ranks = 0
     exact_rows = som_device.last_exact_rows(ws_all) if (not args.one_pass) or cfg["c"] > 32 or K != 100 else None
 
+    # every rank's own phase times (N > 1: the first multi-GPU line must be readable rank by rank)
+    per_rank = None
+    if use_dist:
+        mine = torch.tensor([train_ms, k8_ms], dtype=torch.float64, device=dev)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        per_rank = {"train_batch": [round(float(g[0]), 4) for g in gathered],
+                    "assign_and_mean_table": [round(float(g[1]), 4) for g in gathered]}
+        from ark_analysis_amd.distributed import native_exchange
+        comm_ranks = world if native_exchange(None) is not None else 0     # (made once per group: cached by now)
+        assert dist.get_world_size() == args.gpus, "process group size and --gpus disagree"
     if rank != 0 or args.pmc_inner:
         if use_dist:
             dist.barrier()
@@ -315,12 +330,15 @@ def main():
                    "train_fraction": cfg["frac"],
                    "num_passes": 1, "step": "train + assign + per-cluster mean table",
                    "parallelism": f"{'row' if cfg['kind'] == 'cell' else 'fov'}-shard x{world}",
-                   "rccl_ranks": world if use_dist else 0},
+                   "rccl_ranks": world if use_dist else 0,
+                   "exchange": ("in-library RCCL all-reduce behind every step" if comm_ranks else "torch.distributed all-reduce per step")
+                   if use_dist else "none (one rank)"},
         "phases_ms": {"train_batch": round(train_ms, 4),
                       "assign_and_mean_table": round(k8_ms, 4),
                       "assign_filter_kernel": round(kern_avg_ms, 4),
                       "assign_exact_rows": exact_rows,
-                      "passes_over_x": 2 if (not args.one_pass) else 1},
+                      "passes_over_x": 2 if (not args.one_pass) else 1,
+                      **({"per_rank": per_rank} if per_rank else {})},
         "roofline": ({"kernel": "bmu_filter_kernel", "bound": "mfma", "achieved": round(achieved_tf, 1),
                       "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved_tf / MFMA_F16_PEAK_TFLOPS, 4),
                       "traffic": None, "flops_per_row": flops_assign, "hbm_frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -342,7 +360,7 @@ def main():
     pmc = {}
     if world == 1 and not args.no_pmc:
         inner = ["--config", args.config, "--steps", "2", "--warmup", "1", "--batch-steps", str(args.batch_steps),
-                 "--no-cpu-baseline", "--no-online", "--no-pmc", "--pmc-inner"] + (["--one-pass"] if args.one_pass else [])
+                 "--no-cpu-baseline", "--no-online", "--no-pmc", "--pmc-inner"] + ([] if args.one_pass else ["--two-pass"])
         if args.fovs_per_gpu:
             inner += ["--fovs-per-gpu", str(args.fovs_per_gpu)]
         pmc = pmc_passes(inner)
@@ -357,20 +375,47 @@ def main():
         # rocprofv3 reports KiB; FETCH_SIZE counts 128-B requests at 64 B on gfx950 (MI355X_MICROARCH.md "HBM")
         out["roofline"]["traffic"] = round((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0)
         out["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes inside this run"
-    elif args.config == "cfg2" and not mfma_bound and recorded.get("bmu_filter_kernel_hbm_bytes_per_launch"):
+    elif args.config == "cfg2" and not mfma_bound and not args.one_pass and recorded.get("bmu_filter_kernel_hbm_bytes_per_launch"):
         out["roofline"]["traffic"] = recorded["bmu_filter_kernel_hbm_bytes_per_launch"]
         out["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (recorded; no in-run PMC pass)"
     if "SQ_VALU_MFMA_BUSY_CYCLES" in pmc and pmc.get("GRBM_GUI_ACTIVE"):
         kernel_cycles = pmc["GRBM_GUI_ACTIVE"] / N_XCDS     # cycles the kernel was resident (per XCD)
-        out["mfma_util"] = {"kernel": "bmu_filter_kernel",
+        out["mfma_util"] = {"kernel": out["roofline"]["kernel"].split(" ")[0],
                             "value": round(pmc["SQ_VALU_MFMA_BUSY_CYCLES"] / (N_SIMDS * kernel_cycles), 4),
                             "mfma_busy_cycles": pmc["SQ_VALU_MFMA_BUSY_CYCLES"], "kernel_cycles": round(kernel_cycles),
                             "mfma_insts": pmc.get("SQ_INSTS_MFMA"), "valu_insts": pmc.get("SQ_INSTS_VALU"),
                             "source": "rocprofv3 --pmc inside this run: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x "
                                       "GRBM_GUI_ACTIVE / 8 XCDs)"}
-    elif recorded.get("bmu_filter_kernel_mfma_util") and args.config == "cfg2":
+    elif recorded.get("bmu_filter_kernel_mfma_util") and args.config == "cfg2" and not args.one_pass:
         out["mfma_util"] = {"kernel": "bmu_filter_kernel", "value": recorded["bmu_filter_kernel_mfma_util"],
                             "source": "profiles/pmc_traffic.json (recorded; no in-run PMC pass)"}
+
+    if world == 1 and args.config == "cfg2" and not args.no_operating_range:
+        # Operating range of "bit-exact at HBM speed" (tests/tools/robustness_sweep.py holds the full sweep): the synthetic
+        # workload lists 0.02 % of its rows for the exact path; codebooks made of data rows (distance-0 matches) and
+        # codebooks with node pairs 1e-2 apart list far more.  Same rows, labels only (pxsom_assign), HIP-event timed.
+        def timed_assign(wcb, reps=3):
+            ws_r = som_device.AssignWorkspace(n_all, C, K, dev)
+            lab_r = torch.empty(n_all, dtype=torch.int32, device=dev)
+            som_device.assign(x_all, wcb, labels=lab_r, workspace=ws_r)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                som_device.assign(x_all, wcb, labels=lab_r, workspace=ws_r)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            listed = som_device.last_exact_rows(ws_r)
+            return {"assign_ms": round(ms, 4), "listed_rows": listed, "listed_frac": round(listed / n_all, 6),
+                    "Gpx_per_s": round(n_all / ms / 1e6, 2)}
+        near = w.clone()
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(5)
+        near[K // 2:] = near[:K - K // 2] * (1.0 + 1e-2 * torch.randn((K - K // 2, C), dtype=torch.float64, device=dev, generator=gen))
+        out["operating_range"] = {"trained codebook": timed_assign(w), "codebook = data rows": timed_assign(w0),
+                                  "node pairs 1e-2 apart": timed_assign(near),
+                                  "note": "labels of all rows, bit-equal to the oracle in every case (tests); time follows the rows the "
+                                          "filter lists for the exact binary64 path"}
 
     if args.config == "cfg5":
         # "+ consensus meta-cluster" (BASELINE.json configs[4]): Ward on the K x C mean table on the host (the

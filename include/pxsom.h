@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PXSOM_ABI_VERSION 6
+#define PXSOM_ABI_VERSION 7
 
 typedef enum pxsom_status {
     PXSOM_OK = 0,
@@ -50,8 +50,10 @@ typedef enum pxsom_dtype {
                       real number it encodes -- results equal those for the same values held in binary64 */
 } pxsom_dtype;
 
-/* Limits of the gfx950 kernels in this build. */
-#define PXSOM_MAX_CHANNELS 128
+/* Limits of the gfx950 kernels in this build.  Rows of up to 128 channels take the MFMA filter + exact recheck; wider
+ * rows (the cell SOM over the 400 cluster counts of a 20 x 20 pixel SOM: cell_cluster_utils.py:63-192) are evaluated
+ * directly in the oracle's arithmetic -- same labels, a lower rate, sized for cell tables (10^5 .. 10^6 rows). */
+#define PXSOM_MAX_CHANNELS 1024
 #define PXSOM_MAX_NODES 1024
 
 int pxsom_abi_version(void);
@@ -198,6 +200,19 @@ int pxsom_batch_train_finish(const double *wbuf_dev, const double *stats_ring_de
  * (it clears ring[0] and, for shapes outside the fused kernel with steps wider than one phase, gathers the rows into
  * step order inside the workspace -- one extra read + write of the matrix per run).  Every rank runs the same steps.
  * Oracle of record: oracle/pxsom_oracle.c orc_som_batch_sched.  Reference call replaced: cluster_helpers.py:98-116. */
+/* Reproducible statistics for binary64 rows (sum_quantum > 0; ignored for binary32 / binary16 rows).  The per-BMU sums
+ * of a step are floating-point additions in whatever order the workgroups and ranks deliver them; for binary64 rows that
+ * order leaves 1e-16 noise which the degenerate first steps of a pass (near-identical nodes) can amplify into different
+ * BMUs -- two runs on the same data then end in different codebooks, where the reference pins same-seed retraining
+ * (tests/phenotyping/cluster_helpers_test.py:323-332 of the reference).  With sum_quantum = q (a power of two) every
+ * value enters the statistics rounded to a multiple of q (round-half-even; the BMU search still sees the value itself);
+ * q = pxsom_exact_sum_quantum(max |x| over the job's rows, most rows any step holds over all ranks) makes every partial
+ * sum exactly representable, hence every addition exact, hence the statistics -- and the whole run -- independent of
+ * order, workgroup count and rank count.  The rounding is part of the rule: orc_som_batch_sched takes the same q.
+ * pxsom_absmax: max |x| over the finite entries of a matrix into out_dev[0] (0 when there is none). */
+double pxsom_exact_sum_quantum(double value_bound, int64_t rows_bound);
+int pxsom_absmax(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, double *out_dev, void *stream);
+
 #define PXSOM_MAX_SCHED_STEPS 256
 typedef struct pxsom_comm pxsom_comm; /* the library-owned RCCL communicator, below */
 size_t pxsom_batch_train_sched_workspace_bytes(int64_t n, int c, int k, int dtype, int phases, const int32_t *edges_host,
@@ -205,8 +220,8 @@ size_t pxsom_batch_train_sched_workspace_bytes(int64_t n, int c, int k, int dtyp
 int pxsom_batch_train_sched(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, double *wbuf_dev,
                             double *stats_ring_dev, int xdim, int ydim, int phases, const int32_t *edges_host,
                             int steps_per_pass, int g_begin, int g_end, int num_passes, double a0, double a1, double r0,
-                            double r1, void *workspace_dev, size_t workspace_bytes, int flags, pxsom_comm *comm,
-                            void *stream);
+                            double r1, double sum_quantum, void *workspace_dev, size_t workspace_bytes, int flags,
+                            pxsom_comm *comm, void *stream);
 int pxsom_batch_train_sched_finish(const double *wbuf_dev, const double *stats_ring_dev, int xdim, int ydim, int c,
                                    int phases, const int32_t *edges_host, int steps_per_pass, int steps_done,
                                    int num_passes, double a0, double a1, double r0, double r1, double *w_out_dev,

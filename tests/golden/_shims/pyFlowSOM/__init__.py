@@ -22,8 +22,13 @@ def som(data, xdim=10, ydim=10, rlen=10, alpha_range=(0.05, 0.01), radius_range=
     if radius_range is None:
         radius_range = default_radius_range(xdim, ydim)
     steps = os.environ.get("PXSOM_SHIM_BATCH_STEPS")
-    if steps:   # make_golden.py g7b: the same reference pipeline with the build's batch rule underneath
-        return ob.som_batch(data, codes, xdim, ydim, rlen, alpha_range, radius_range, int(steps))
+    if steps:   # make_golden.py g7b: the same reference pipeline with the build's batch rule underneath -- as the drop-in
+        # classes run it on their binary64 tables: the rows join the statistics rounded to the run's quantum
+        from ark_analysis_amd import _capi
+        vmax = float(np.abs(data[np.isfinite(data)]).max()) if data.size else 0.0
+        quantum = float(_capi.lib().pxsom_exact_sum_quantum(vmax, n // int(steps) + 1))
+        return ob.som_batch_sched(data, codes, xdim, ydim, rlen, alpha_range, radius_range, int(steps), list(range(int(steps) + 1)),
+                                  quantum=quantum)
     return ob.som_online(data, codes, xdim, ydim, rlen, alpha_range, radius_range, order)
 
 

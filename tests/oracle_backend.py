@@ -12,9 +12,14 @@ import torch
 class OracleKernels:
     """Same interface as ark_analysis_amd.distributed.HipKernels, backed by oracle/pxsom_oracle.c."""
 
-    def begin(self, x, w, xdim, ydim, schedule):
+    def absmax(self, x):
+        a = np.abs(x.numpy())
+        a = a[np.isfinite(a)]
+        return float(a.max()) if a.size else 0.0
+
+    def begin(self, x, w, xdim, ydim, schedule, quantum=0.0):
         from ark_analysis_amd.schedule import resolve
-        self.xdim, self.ydim, self.sch = xdim, ydim, resolve(schedule)
+        self.xdim, self.ydim, self.sch, self.quantum = xdim, ydim, resolve(schedule), float(quantum)
         k, c = w.shape
         self.w = [w.clone(), w.clone()]
         self.rings = [torch.zeros(k * (c + 1), dtype=torch.float64) for _ in range(3)]
@@ -42,7 +47,7 @@ class OracleKernels:
             rows = self.sch.rows_of_step(x.shape[0], g)
             xn = np.ascontiguousarray(x.numpy()[rows], dtype=np.float64).reshape(-1, c)
             lab, _ = ob.map_data_to_nodes(w.numpy(), xn)
-            s, cnt = ob.cluster_sums(xn, lab, k)
+            s, cnt = ob.cluster_sums(ob.quantize(xn, self.quantum), lab, k)
             st = self.rings[g % 3]
             st[: k * c].copy_(torch.from_numpy(s.reshape(-1)))
             st[k * c:].copy_(torch.from_numpy(cnt.astype(np.float64)))

@@ -52,10 +52,10 @@ def lib():
         L.orc_som_batch.argtypes = [c_dp, ctypes.c_int64, ctypes.c_int, c_dp, ctypes.c_int, ctypes.c_int,
                                     ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                     ctypes.c_double, ctypes.c_int, ctypes.c_int]
-        L.orc_som_batch_sched.restype = ctypes.c_int
-        L.orc_som_batch_sched.argtypes = [c_dp, ctypes.c_int64, ctypes.c_int, c_dp, ctypes.c_int, ctypes.c_int,
-                                          ctypes.c_double, ctypes.c_double, ctypes.c_double,
-                                          ctypes.c_double, ctypes.c_int, ctypes.c_int, c_i32p, ctypes.c_int]
+        L.orc_som_batch_sched_q.restype = ctypes.c_int
+        L.orc_som_batch_sched_q.argtypes = [c_dp, ctypes.c_int64, ctypes.c_int, c_dp, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                            ctypes.c_double, ctypes.c_int, ctypes.c_int, c_i32p, ctypes.c_int, ctypes.c_double]
         L.orc_gaussian_blur_hwc.restype = ctypes.c_int
         L.orc_gaussian_blur_hwc.argtypes = [c_dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_dp,
                                             ctypes.c_int]
@@ -208,17 +208,24 @@ def som_batch(data, codes, xdim, ydim, rlen, alpha_range, radius_range, M):
     return codes
 
 
-def som_batch_sched(data, codes, xdim, ydim, rlen, alpha_range, radius_range, phases, edges):
-    """The scheduled batch rule (orc_som_batch_sched): step g of a pass takes the rows i with i % phases in
-    [edges[g], edges[g+1])."""
+def quantize(x, quantum):
+    """Rows as they join the statistics of a reproducible run: rounded to multiples of ``quantum`` (half to even)."""
+    x = _f64(x)
+    return np.rint(x / quantum) * quantum if quantum else x
+
+
+def som_batch_sched(data, codes, xdim, ydim, rlen, alpha_range, radius_range, phases, edges, quantum=0.0):
+    """The scheduled batch rule (orc_som_batch_sched_q): step g of a pass takes the rows i with i % phases in
+    [edges[g], edges[g+1]); ``quantum`` > 0: the rows join the sums rounded to its multiples."""
     data = _f64(data)
     codes = _f64(codes).copy()
     n, px = data.shape
     assert codes.shape[0] == xdim * ydim
     e = np.ascontiguousarray(np.asarray(edges, dtype=np.int32))
-    rc = lib().orc_som_batch_sched(_dp(data), n, px, _dp(codes), int(xdim), int(ydim), float(alpha_range[0]),
-                                   float(alpha_range[1]), float(radius_range[0]), float(radius_range[1]), int(rlen),
-                                   int(phases), e.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), int(e.size - 1))
+    rc = lib().orc_som_batch_sched_q(_dp(data), n, px, _dp(codes), int(xdim), int(ydim), float(alpha_range[0]),
+                                     float(alpha_range[1]), float(radius_range[0]), float(radius_range[1]), int(rlen),
+                                     int(phases), e.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), int(e.size - 1),
+                                     float(quantum))
     assert rc == 0, "orc_som_batch_sched rejected the schedule"
     return codes
 

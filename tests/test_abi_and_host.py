@@ -25,7 +25,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/pxsom.h but not exported"
     assert set(declared) == set(_capi.SYMBOLS), "ctypes prototype table and header disagree"
-    assert lib.pxsom_abi_version() == _capi.ABI_VERSION == 6
+    assert lib.pxsom_abi_version() == _capi.ABI_VERSION == 7
 
 
 def test_argument_validation_without_gpu():
@@ -35,8 +35,10 @@ def test_argument_validation_without_gpu():
     assert lib.pxsom_assign_workspace_bytes(1000, 22, 100) > 1000 * 4
     assert lib.pxsom_assign_workspace_bytes(1000, 0, 100) == 0
     assert lib.pxsom_assign_workspace_bytes(1000, 22, 5000) == 0
-    rc = lib.pxsom_assign(None, 10, 500, 500, 0, None, 100, None, None, None, 0, None)
-    assert rc == -2 and b"c=500" in lib.pxsom_last_error()
+    rc = lib.pxsom_assign(None, 10, 5000, 5000, 0, None, 100, None, None, None, 0, None)
+    assert rc == -2 and b"c=5000" in lib.pxsom_last_error()
+    assert lib.pxsom_assign_workspace_bytes(1000, 400, 100) > 400 * 100 * 8      # wide rows: the transposed codebook copy
+    assert lib.pxsom_exact_sum_quantum(4.0, 200_000) == 2.0 ** (3 + 18 - 52) and lib.pxsom_exact_sum_quantum(0.0, 10) == 0.0
     rc = lib.pxsom_assign(None, 10, 22, 22, 7, None, 100, None, None, None, 0, None)
     assert rc == -2
     rc = lib.pxsom_train_online(None, 0, 22, 22, 0, None, 40, 40, 1, 0.05, 0.01, 6.0, 0.0, None, None)

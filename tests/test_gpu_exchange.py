@@ -167,3 +167,29 @@ def test_two_ranks_run_the_sharded_step_loop(oracle, tmp_path, shape):
     else:
         want = oracle.som_batch(inter, r0["w0"], xd, yd, passes, (0.05, 0.01), (3.0, 1.0), steps)
     np.testing.assert_allclose(r0["w"], want, rtol=1e-9, atol=1e-300)
+
+
+@pytest.mark.parametrize("n_local", [(3000, 0), (3000, 5)])
+def test_a_rank_with_an_empty_or_short_shard_keeps_the_same_codebook(oracle, tmp_path, n_local):
+    """More ranks than data: a rank whose shard is empty (or shorter than the schedule) takes the SAME kernel route as the
+    others -- the route is a property of the shape, not of the rank's row count -- applies the same all-reduced statistics
+    and ends with the same bits (round-2 advice: the replicas drifted apart when such a rank fell back to another route)."""
+    import torch.multiprocessing as mp
+    lib_path = _mock_library(tmp_path)
+    steps, passes = 8, 1
+    shape = (10, 10, 22, torch.float32)
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_sharded_worker, args=(2, lib_path, str(tmp_path / "uid"), out, shape, n_local, steps, passes), nprocs=2, join=True)
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    np.testing.assert_array_equal(r0["w"], r1["w"])
+    assert np.isfinite(r0["w"]).all()
+    x_all = np.concatenate([r0["x"], r1["x"].reshape(-1, 22)])
+    w = r0["w0"].copy()
+    for g in range(steps):
+        part = np.concatenate([r0["x"][g::steps], r1["x"].reshape(-1, 22)[g::steps]])
+        lab, _ = oracle.map_data_to_nodes(w, part)
+        s, cnt = oracle.cluster_sums(part, lab, 100)
+        thr = 3.0 - (3.0 - 1.0) * g / steps
+        w = oracle.batch_update(w, 10, 10, s, cnt, 0.5 if thr < 1.0 else thr, 0.05 - (0.05 - 0.01) * g / steps)
+    np.testing.assert_allclose(r0["w"], w, rtol=1e-9, atol=1e-300)
+    del x_all

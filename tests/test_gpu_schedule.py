@@ -142,3 +142,62 @@ def test_config3_share_at_full_size(gpu, oracle):
     assert int(cnt.sum()) == n
     np.testing.assert_array_equal(cnt.cpu().numpy(), torch.bincount(labels.long() - 1, minlength=k).cpu().numpy())
     np.testing.assert_allclose(sums.sum(dim=0).cpu().numpy(), x.sum(dim=0, dtype=torch.float64).cpu().numpy(), rtol=1e-9)
+
+
+@pytest.mark.parametrize("c,grid,n,sch,unfused", [(22, 10, 30_000, MIXED, False), (22, 10, 30_000, MIXED, True), (100, 10, 20_001, MIXED, False),
+                                                  (40, 20, 25_000, SMALL_TWO_PHASE, False), (400, 10, 4_000, MIXED, False)])
+def test_binary64_rows_train_reproducibly(gpu, oracle, c, grid, n, sch, unfused):
+    """binary64 rows with the run's quantum (include/pxsom.h "Reproducible statistics"): every step's statistics are the
+    EXACT sums of the quantised rows -- equal to the oracle's bit for bit whatever the order the workgroups delivered
+    them in --, two runs end in bit-identical codebooks (the reference pins same-seed retraining:
+    tests/phenotyping/cluster_helpers_test.py:323-332), and the trainer picks the quantum itself for float64 input.
+    Data with many near-identical rows and a crowded initial codebook: what used to let two runs part ways."""
+    xdim = ydim = grid
+    k = xdim * ydim
+    rs = np.random.RandomState(c + n)
+    x = synth.make_fov_numpy(n, c, seed=51, dtype=np.float64)
+    x[1::3] = x[0::3][: len(x[1::3])] * (1.0 + 1e-13 * rs.standard_normal((len(x[1::3]), 1)))     # near-duplicates
+    w0 = np.ascontiguousarray(x[rs.choice(n, k, replace=False)])
+    w0[k // 2:] = w0[: k - k // 2] * (1.0 + 1e-12)                                                # near-identical node pairs
+    xd = torch.from_numpy(x).to(gpu)
+    rr = default_radius_range(xdim, ydim)
+    widest = int(np.diff(sch.edges).max())
+    q = sd.exact_sum_quantum(float(np.abs(x).max()), (n // sch.phases + 1) * widest)
+    assert q > 0 and np.log2(q) == np.round(np.log2(q))
+    assert float(sd.absmax(xd).item()) == float(np.abs(x).max())
+    total = sch.steps
+    runs = []
+    for rep in range(2):
+        st = sd.BatchTrainState(n, c, xdim, ydim, sch, gpu, dtype=xd.dtype)
+        st.quantum = q
+        st.wbuf[0].copy_(torch.from_numpy(w0))
+        w_prev = s_prev = cnt_prev = None
+        for g in range(total):
+            sd.batch_train_steps(xd, st, g, g + 1, total, (0.05, 0.01), rr, unfused=unfused)
+            w_g = st.wbuf[g % 2].cpu().numpy()
+            ring = st.ring[g % 3].cpu().numpy()
+            if rep == 0:
+                if g > 0:
+                    thr, alpha = batch_schedule(sch.position(g - 1), sch.phases, (0.05, 0.01), rr)
+                    np.testing.assert_allclose(w_g, oracle.batch_update(w_prev, xdim, ydim, s_prev, cnt_prev, thr, alpha), rtol=1e-12, atol=1e-300)
+                rows = x[sch.rows_of_step(n, g)]
+                lab, _ = oracle.map_data_to_nodes(w_g, rows)
+                s, cnt = oracle.cluster_sums(oracle.quantize(rows, q), lab, k)
+                np.testing.assert_array_equal(ring[k * c:], cnt.astype(np.float64))
+                np.testing.assert_array_equal(ring[: k * c].reshape(k, c), s)          # exact sums: bit for bit
+                w_prev, s_prev, cnt_prev = w_g, s, cnt
+        wa = torch.empty((k, c), dtype=torch.float64, device=gpu)
+        sd.batch_train_finish(st, total, total, (0.05, 0.01), rr, wa)
+        runs.append(wa.cpu().numpy())
+    assert np.array_equal(runs[0], runs[1])
+    # the trainer on float64 input: quantum chosen by itself, whole run in one call, twice
+    outs = []
+    for rep in range(2):
+        w = torch.from_numpy(w0.copy()).to(gpu)
+        tr = BatchSOMTrainer(xdim, ydim, c, gpu, batch_steps=sch)
+        tr.train(xd, w, num_passes=1)
+        assert tr.kernels._state.quantum == q
+        outs.append(w.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    if not unfused:
+        assert np.array_equal(outs[0], runs[0])
