@@ -55,13 +55,28 @@ __device__ __forceinline__ double qround(double v, double qmagic) { return qmagi
 
 struct Layout {
     int k, nb, nch, cpl, nsteps, idx_bits, node_bits, cp32;
+    int npk = 0;   // > 0: packed-K fragments (binary16 rows, c % 8 == 0): npk MFMAs per node block, see packed_k()
     size_t off_wfrag, off_bias, off_wt, off_w32, off_list, total;
     bool has_wt() const { return off_w32 > off_wt; }
 };
 
-inline Layout make_layout(int64_t n, int c, int k)
+// Packed K axis (round 3; config 5: binary16 rows, 40 channels, 400 nodes).  binary16 rows need two terms of the split,
+// Wh*Xh + Wl*Xh (x * scale is a binary16 number: Xl == 0).  The chunked layout spends one 32-slot MFMA per term and chunk
+// of <= 32 channels: 4 per node block at C = 40, 62 % of the k-slots used.  Packed, the two terms lie back to back along K
+// -- slots [Wh(0..C) | Wl(0..C)] against [Xh | Xh] -- and a block takes ceil(2C / 32) MFMAs: 3 at C = 40.  Slots come in
+// groups of 8 (one lane's half8): group sg = 4 m + q of MFMA m, lane group q; term = sg / (C / 8), channels 8 (sg % (C / 8))...
+// Needs c % 8 == 0 (a lane's 16-byte load never straddles a term or the row's end).  Worth it from 33 channels on.
+inline int packed_k(int c, int k, bool rows_binary16)
+{
+    if (!rows_binary16 || c % 8 != 0 || c <= 32 || c > 128 || k <= 128) return 0;
+    const int npk = (2 * c + 31) / 32, chunked = 2 * ((c + 31) / 32);
+    return npk < chunked ? npk : 0;
+}
+
+inline Layout make_layout(int64_t n, int c, int k, int npk = 0)
 {
     Layout L;
+    L.npk = npk;
     L.k = k;
     L.nb = (k + 15) / 16;
     L.nch = (std::min(c, kFilterMaxChannels) + 31) / 32;   // (wide rows take no filter: the fragment regions stay small)
@@ -70,11 +85,11 @@ inline Layout make_layout(int64_t n, int c, int k)
     cpl = (cpl + 1) & ~1;                              // even, so float2/double2 loads stay aligned
     if (cpl > 8) cpl = 8;
     L.cpl = cpl;
-    L.nsteps = 2 * L.nch;  // stored fragments per node block: {Wh, Wl} per chunk
+    L.nsteps = npk > 0 ? npk : 2 * L.nch;  // stored fragments per node block: {Wh, Wl} per chunk, or the packed run
     // low mantissa bits of the scores that the top-2 logic replaces by an index -- its only perturbation, and a
     // term of the tolerance prep derives: the register-resident kernel (one chunk, 7 node blocks) packs a 7-bit
     // (q, b, r) id, the streamed kernel only the 2-bit accumulator register index r
-    L.idx_bits = (L.nch == 1 && L.nb <= 8) ? 7 : 2;
+    L.idx_bits = (L.nch == 1 && L.nb <= 8 && npk == 0) ? 7 : 2;
     L.node_bits = L.idx_bits;
     L.off_wfrag = kHdrBytes;
     L.off_bias = L.off_wfrag + (size_t)L.nb * L.nsteps * 64 * sizeof(half8);
@@ -126,6 +141,14 @@ int launch_batch_step(const T *x, int64_t n, int c, int64_t ldx, double *stats, 
 // pending update + codebook preparation for the generic BMU search in one launch (pxsom_batch_step.hip); returns
 // false when the shape is not covered (then *rc is untouched and the caller takes the launch-per-phase route)
 bool launch_update_prepare(const StepArgs &sa, int xdim, int ydim, int c, char *ws, const Layout &L, hipStream_t st, int *rc);
+// the streamed filter on packed-K fragments (pxsom_assign_filter.hip)
+void launch_filter_packed(const _Float16 *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels, hipStream_t st);
+// rows the packed kernel can read: 16-byte aligned rows of binary16
+template <typename T>
+inline bool packed_rows_ok(const T *x, int64_t ldx)
+{
+    return sizeof(T) == 2 && ldx % 8 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0;
+}
 
 // pxsom_assign with the batch rule's accumulation fused in (pxsom_assign.hip).  *fused = false: the shape
 // is outside the fused path, nothing was done, the caller runs assign + cluster sums separately.
@@ -135,7 +158,7 @@ int assign_accumulate(const void *x_dev, int64_t n, int c, int64_t ldx, int dtyp
                       int32_t *labels_dev, double *stats_dev, void *workspace_dev, size_t workspace_bytes,
                       hipStream_t st, bool *fused, bool fixed = false);
 int assign_prepared(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev, int k,
-                    int32_t *labels_dev, void *workspace_dev, size_t workspace_bytes, hipStream_t st);
+                    int32_t *labels_dev, void *workspace_dev, size_t workspace_bytes, hipStream_t st, int npk = 0);
 int prepare_only(const double *w_dev, int c, int k, void *workspace_dev, size_t workspace_bytes,
                  double *zero_stats, hipStream_t st);
 

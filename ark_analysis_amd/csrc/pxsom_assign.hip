@@ -47,7 +47,7 @@ __global__ __launch_bounds__(NT) void bmu_prep_kernel(const double *__restrict__
                                                        AssignHdr *hdr, half8 *wfrag, f32x4 *bias,
                                                        int nb, int nch, int cpl, int idx_bits,
                                                        int node_bits, int stage, double *zero_ptr,
-                                                       int zero_count, double *wt_out, float *w32_out, int cp32)
+                                                       int zero_count, double *wt_out, float *w32_out, int cp32, int npk)
 {
     PXSOM_PHASE_ANY(0);
     // fused batch accumulation: the statistics buffer is cleared here instead of by a memset node
@@ -71,8 +71,8 @@ __global__ __launch_bounds__(NT) void bmu_prep_kernel(const double *__restrict__
     PXSOM_PHASE_ANY(1);
     // two calls, not one with a selected pointer: each inlined copy then knows its address space (ds_read for
     // the staged codebook instead of flat loads)
-    if (stage) prep_body<NT>(sw, k, c, hdr, wfrag, bias, nb, nch, cpl, idx_bits, node_bits, wt_out, w32_out, cp32);
-    else prep_body<NT>(w, k, c, hdr, wfrag, bias, nb, nch, cpl, idx_bits, node_bits, wt_out, w32_out, cp32);
+    if (stage) prep_body<NT>(sw, k, c, hdr, wfrag, bias, nb, nch, cpl, idx_bits, node_bits, wt_out, w32_out, cp32, npk);
+    else prep_body<NT>(w, k, c, hdr, wfrag, bias, nb, nch, cpl, idx_bits, node_bits, wt_out, w32_out, cp32, npk);
 }
 
 
@@ -569,9 +569,13 @@ static int prep_stage(size_t stage_bytes)
 
 template <typename T>
 int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int k, int32_t *labels,
-                 double *dist, char *ws, const Layout &L, hipStream_t st, double *stats = nullptr,
+                 double *dist, char *ws, const Layout &L_in, hipStream_t st, double *stats = nullptr,
                  bool prepared = false, bool fixed = false)
 {
+    // binary16 rows of a wide codebook: packed-K fragments (pxsom_assign.h packed_k).  `prepared`: the caller's layout
+    // says what the workspace holds.
+    const int npk = prepared ? L_in.npk : (packed_rows_ok<T>(x, ldx) && !stats ? packed_k(c, k, sizeof(T) == 2) : 0);
+    const Layout L = make_layout(n, c, k, npk);
     if (c > kFilterMaxChannels) {   // wide rows: no filter, every row in the oracle's arithmetic (section 3c)
         double *wt = reinterpret_cast<double *>(ws + L.off_wt);
         hipLaunchKernelGGL(wide_transpose_kernel, dim3((unsigned)std::min<int64_t>(((int64_t)k * c + 255) / 256, 1024)), dim3(256), 0, st,
@@ -609,14 +613,19 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
                            reinterpret_cast<half8 *>(ws + L.off_wfrag), reinterpret_cast<f32x4 *>(ws + L.off_bias),
                            L.nb, L.nch, L.cpl, L.idx_bits, L.node_bits, stage, (double *)nullptr, 0,
                            L.has_wt() ? reinterpret_cast<double *>(ws + L.off_wt) : nullptr,
-                           reinterpret_cast<float *>(ws + L.off_w32), L.cp32);
+                           reinterpret_cast<float *>(ws + L.off_w32), L.cp32, L.npk);
         PXSOM_LAUNCH_CHECK("bmu_prep_kernel");
     }
 
     const int cus = pxsom::device_cu_count();
     pxsom::Prof *prof = pxsom::current_prof();
     pxsom::prof_mark(prof, st, true, n);
-    launch_filter_any<T>(x, n, c, ldx, ws, L, labels, stats, w, st, fixed);
+    if constexpr (sizeof(T) == 2) {
+        if (L.npk > 0) launch_filter_packed(x, n, c, ldx, ws, L, labels, st);
+        else launch_filter_any<T>(x, n, c, ldx, ws, L, labels, stats, w, st, fixed);
+    } else {
+        launch_filter_any<T>(x, n, c, ldx, ws, L, labels, stats, w, st, fixed);
+    }
     pxsom::prof_mark(prof, st, false, n);
     PXSOM_LAUNCH_CHECK("bmu_filter_kernel");
 
@@ -715,9 +724,9 @@ int pxsom_bmu::assign_accumulate(const void *x_dev, int64_t n, int c, int64_t ld
 // pxsom_assign on a workspace that pxsom_batch_update_prepare prepared for w_dev (no prep launch)
 int pxsom_bmu::assign_prepared(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev,
                                int k, int32_t *labels_dev, void *workspace_dev, size_t workspace_bytes,
-                               hipStream_t st)
+                               hipStream_t st, int npk)
 {
-    const Layout L = make_layout(n, c, k);
+    const Layout L = make_layout(n, c, k, npk);
     if (!workspace_dev || workspace_bytes < L.total)
         return pxsom::fail(PXSOM_ERR_WORKSPACE, "pxsom_batch_accumulate: workspace %zu < %zu bytes", workspace_bytes,
                            L.total);
@@ -741,7 +750,7 @@ int pxsom_bmu::prepare_only(const double *w_dev, int c, int k, void *workspace_d
                        reinterpret_cast<f32x4 *>(ws + L.off_bias), L.nb, L.nch, L.cpl, L.idx_bits, L.node_bits, stage,
                        zero_stats, zero_stats ? k * (c + 1) : 0,
                        L.has_wt() ? reinterpret_cast<double *>(ws + L.off_wt) : nullptr,
-                           reinterpret_cast<float *>(ws + L.off_w32), L.cp32);
+                           reinterpret_cast<float *>(ws + L.off_w32), L.cp32, 0);
     PXSOM_LAUNCH_CHECK("bmu_prep_kernel");
     return PXSOM_OK;
 }

@@ -417,6 +417,194 @@ void launch_filter_variant(const T *x, int64_t n, int c, int64_t ldx, char *ws, 
                        reinterpret_cast<unsigned *>(ws + L.off_list), labels);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Packed-K streamed filter (round 3; binary16 rows, c % 8 == 0, wide codebooks -- config 5: 40 channels, 400 nodes).
+// The two terms of a binary16 row's split (Wh*Xh + Wl*Xh) lie back to back along K (pxsom_assign.h packed_k): NPK MFMAs per
+// node block instead of 2 per 32-channel chunk (3 instead of 4 at C = 40).  Lane (q, pix) of MFMA m holds slot group
+// sg = 4 m + q: one 16-byte load of channels 8 (sg % (c / 8)) .. of its pixel's row -- the same channels feed both terms, so
+// a row is read twice from L1, once from HBM.  Everything after the MFMAs (top-2 with the 2-bit register index, node block
+// beside the score, transposing merge, tolerance, exact list) is the streamed kernel's.  A codebook so large that
+// x * scale could lose bits (scale < 1: entries >= 256) sends every row to the exact path instead.
+// ------------------------------------------------------------------------------------------------
+template <int NPK, int TP, bool LDSW, int BD>
+__global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_packed_kernel(
+    const _Float16 *__restrict__ x, int64_t n, int c, int64_t ldx, const half8 *__restrict__ wfrag,
+    const f32x4 *__restrict__ bias, AssignHdr *hdr, unsigned *__restrict__ amb_list, int32_t *__restrict__ labels)
+{
+    const int nb = hdr->nb;
+    constexpr unsigned idx_mask = 3u;
+    const float scale = hdr->scale, wn_max = hdr->wn_max, tol_abs = hdr->tol_abs, x_limit = hdr->x_limit;
+    // binary16 rows without the Xl terms: the bound of the streamed kernel (see there)
+    const float tol_rel = hdr->tol_rel - 2.5f * ((float)c * 0x1p-24f + (0x1p-19f - 0x1p-21f));
+    const bool force_exact = hdr->force_exact != 0 || scale < 1.f;
+    const int lane = threadIdx.x & 63;
+    const int pix = lane & 15, q = lane >> 4;
+    constexpr int WV = BD / 64;
+    const int64_t wave = (int64_t)blockIdx.x * WV + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * WV;
+    const int64_t ngroups = (n + 63) / 64;
+
+    extern __shared__ __attribute__((aligned(16))) char filt_smem[];
+    half8 *lfrag = reinterpret_cast<half8 *>(filt_smem);
+    f32x4 *lbias = reinterpret_cast<f32x4 *>(lfrag + (size_t)nb * NPK * 64);
+    if constexpr (LDSW) {
+        const int nf = nb * NPK * 64;
+        for (int i0 = threadIdx.x; i0 < nf; i0 += 4 * BD) {
+            half8 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = wfrag[i0 + u * BD < nf ? i0 + u * BD : 0];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (i0 + u * BD < nf) lfrag[i0 + u * BD] = v[u];
+        }
+        for (int i = threadIdx.x; i < nb * 64; i += BD) lbias[i] = bias[i];
+        __syncthreads();
+    }
+    // this lane's slot groups: channel offset of its 16-byte load per MFMA (-1: a slot group past both terms)
+    const int g8 = c / 8;
+    int choff[NPK];
+    bool first_term[NPK];
+#pragma unroll
+    for (int m = 0; m < NPK; m++) {
+        const int sg = 4 * m + q, term = sg / g8;
+        choff[m] = term < 2 ? 8 * (sg - term * g8) : -1;
+        first_term[m] = term == 0;
+    }
+    const _Float16 hscale = (_Float16)scale;   // a power of two in [1, 2^15]: exact
+
+    for (int64_t g = wave; g < ngroups; g += nwaves) {
+        int my_node = 0;
+        bool my_amb = false;
+#pragma unroll
+        for (int t0 = 0; t0 < kTilesPerIter; t0 += TP) {
+            half8 bx[TP][NPK];
+            float ss[TP];
+#pragma unroll
+            for (int u = 0; u < TP; u++) {
+                int64_t row = g * 64 + (t0 + u) * 16 + pix;
+                if (row > n - 1) row = n - 1;
+                const _Float16 *rp = x + row * ldx;
+                float acc2 = 0.f;
+#pragma unroll
+                for (int m = 0; m < NPK; m++) {
+                    half8 v = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
+                    if (choff[m] >= 0) v = *reinterpret_cast<const half8 *>(rp + choff[m]);
+                    v = v * hscale;
+                    if (first_term[m]) {   // |X|^2 from the first term's groups: every channel once
+#pragma unroll
+                        for (int i = 0; i < 8; i += 2) {
+                            const half2_t h2 = {v[i], v[i + 1]};
+                            acc2 = __builtin_amdgcn_fdot2(h2, h2, acc2, false);
+                        }
+                    }
+                    bx[u][m] = v;
+                }
+                ss[u] = acc2;
+            }
+            float m1[TP], m2[TP];
+            int bsel[TP];
+#pragma unroll
+            for (int u = 0; u < TP; u++) {
+                m1[u] = m2[u] = kNegBig;
+                bsel[u] = 0;
+            }
+            for (int b = 0; b < nb; b++) {
+                f32x4 acc[TP];
+                const f32x4 bv = LDSW ? lbias[b * 64 + lane] : bias[b * 64 + lane];
+#pragma unroll
+                for (int u = 0; u < TP; u++) acc[u] = bv;
+#pragma unroll
+                for (int m = 0; m < NPK; m++) {
+                    const half8 wf = LDSW ? lfrag[(b * NPK + m) * 64 + lane] : wfrag[(b * NPK + m) * 64 + lane];
+#pragma unroll
+                    for (int u = 0; u < TP; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, bx[u][m], acc[u], 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < TP; u++) {
+                    const float before = m1[u];
+                    consume(m1[u], m2[u], acc[u], 0, idx_mask);
+                    bsel[u] = m1[u] != before ? b : bsel[u];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < TP; u++) {
+                // node index beside the score through the merge of the 4 lane groups of a pixel (streamed kernel's finish)
+                float a1 = m1[u], a2 = m2[u], s2 = ss[u];
+                int node;
+                {
+                    const unsigned bb = (unsigned)bsel[u], r = __float_as_uint(a1) & idx_mask;
+                    node = (int)((int)bb == nb - 1 ? (bb << 4) | (r << 2) | (unsigned)q : (bb << 4) | ((unsigned)q << 2) | r);
+                }
+                auto merge_step = [&](bool wide) {
+                    const F2 e1 = wide ? xchg32(a1) : xchg16(a1), e2 = wide ? xchg32(a2) : xchg16(a2),
+                             es = wide ? xchg32(s2) : xchg16(s2),
+                             en = wide ? xchg32(__int_as_float(node)) : xchg16(__int_as_float(node));
+                    const int na = __float_as_int(en.a), nb_ = __float_as_int(en.b);
+                    const bool take_b = e1.b > e1.a || (e1.b == e1.a && nb_ < na);
+                    a2 = fmaxf(fmaxf(fminf(e1.a, e1.b), e2.a), e2.b);
+                    a1 = take_b ? e1.b : e1.a;
+                    node = take_b ? nb_ : na;
+                    s2 = es.a + es.b;
+                };
+                merge_step(false);
+                merge_step(true);
+                if (q == t0 + u) {
+                    const float xn = __builtin_amdgcn_sqrtf(s2) * 1.000001f;
+                    const float tol = tol_rel * (xn * wn_max + 0.5f * wn_max * wn_max) + tol_abs * (xn + wn_max);
+                    unsigned sbits = __float_as_uint(s2);
+                    asm volatile("" : "+v"(sbits));
+                    const bool nonfinite = (sbits & 0x7f800000u) == 0x7f800000u;
+                    my_amb = !((a1 - a2) > tol) || !(xn < x_limit) || nonfinite || force_exact;
+                    my_node = node;
+                }
+            }
+        }
+        const int64_t row = g * 64 + lane;
+        const bool valid = row < n;
+        if (valid) labels[row] = my_node + 1;
+        const bool push = valid && my_amb;
+        const unsigned long long mask = __ballot(push);
+        if (mask) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&hdr->amb_count, (unsigned)__popcll(mask));
+            base = __shfl(base, 0);
+            if (push) amb_list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned)row;
+        }
+    }
+}
+
+template <int NPK>
+void launch_packed(const _Float16 *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels, hipStream_t st)
+{
+    const size_t lds = (size_t)L.nb * (NPK + 1) * 1024;       // fragments + bias of the whole codebook
+    const int64_t ngroups = (n + 63) / 64;
+    const half8 *wf = reinterpret_cast<const half8 *>(ws + L.off_wfrag);
+    const f32x4 *bi = reinterpret_cast<const f32x4 *>(ws + L.off_bias);
+    AssignHdr *hd = reinterpret_cast<AssignHdr *>(ws);
+    unsigned *al = reinterpret_cast<unsigned *>(ws + L.off_list);
+    const int cus = pxsom::device_cu_count();
+    if (lds <= 150 * 1024 && lds > 64 * 1024) {          // one workgroup per CU: a big one (two waves per SIMD on one LDS copy)
+        auto kern = bmu_filter_packed_kernel<NPK, 4, true, 512>;
+        static pxsom::PerDevice<bool> raised_on;
+        bool &raised = raised_on.here();
+        if (!raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            raised = true;
+        }
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((ngroups + 7) / 8, cus));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, x, n, c, ldx, wf, bi, hd, al, labels);
+    } else if (lds <= 64 * 1024) {
+        auto kern = bmu_filter_packed_kernel<NPK, 4, true, 256>;
+        const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / lds)));
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((ngroups + 3) / 4, (int64_t)cus * per_cu));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, x, n, c, ldx, wf, bi, hd, al, labels);
+    } else {                                              // fragments from L1 / L2
+        auto kern = bmu_filter_packed_kernel<NPK, 4, false, 256>;
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((ngroups + 3) / 4, (int64_t)cus * 2));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, x, n, c, ldx, wf, bi, hd, al, labels);
+    }
+}
+
 template <typename T, int NCH, int CPL, int NB, bool VEC2>
 void launch_filter(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels,
                    hipStream_t st)
@@ -488,6 +676,18 @@ template void launch_filter_any<double>(const double *, int64_t, int, int64_t, c
                                         double *, const double *, hipStream_t, bool);
 template void launch_filter_any<_Float16>(const _Float16 *, int64_t, int, int64_t, char *, const Layout &, int32_t *,
                                           double *, const double *, hipStream_t, bool);
+void launch_filter_packed(const _Float16 *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels, hipStream_t st)
+{
+    switch (L.npk) {   // ceil(2 c / 32) for c = 40 .. 128 (c % 8 == 0)
+        case 3: launch_packed<3>(x, n, c, ldx, ws, L, labels, st); break;
+        case 4: launch_packed<4>(x, n, c, ldx, ws, L, labels, st); break;
+        case 5: launch_packed<5>(x, n, c, ldx, ws, L, labels, st); break;
+        case 6: launch_packed<6>(x, n, c, ldx, ws, L, labels, st); break;
+        case 7: launch_packed<7>(x, n, c, ldx, ws, L, labels, st); break;
+        default: launch_packed<8>(x, n, c, ldx, ws, L, labels, st); break;
+    }
+}
+
 template bool filter_fast_path<_Float16>(const _Float16 *, int64_t, int, int64_t, const Layout &);
 template bool filter_fast_path<float>(const float *, int64_t, int, int64_t, const Layout &);
 template bool filter_fast_path<double>(const double *, int64_t, int, int64_t, const Layout &);

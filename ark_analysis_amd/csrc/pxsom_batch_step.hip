@@ -623,7 +623,7 @@ template <int XD, int YD, int CPP>
 __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs sa, int c, AssignHdr *hdr_g, half8 *wfrag,
                                                                         f32x4 *bias_g, double *wt_out, int nb, int nch,
                                                                         int cpl, int idx_bits, int parts_log2,
-                                                                        float *w32_out, int cp32)
+                                                                        float *w32_out, int cp32, int npk)
 {
     constexpr int K = XD * YD;
     extern __shared__ __attribute__((aligned(16))) char upd_smem[];
@@ -842,8 +842,25 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
     PXSOM_PHASE(8);
     __syncthreads();
     // ---- what the generic BMU search reads: fragments, bias, transposed copy (pxsom_prep.h layouts)
+    if (npk > 0) {   // packed K axis (pxsom_assign.h packed_k; pxsom_prep.h holds the same loop)
+        const int g8 = c / 8;
+        for (int f = tid; f < (b1 - b0) * npk * 64; f += kUpdThreads) {
+            const int fl = f & 63, m = (f >> 6) % npk, b = b0 + (f >> 6) / npk;
+            const int nd = node_of_row(b, fl & 15, nb);
+            const int sg = 4 * m + (fl >> 4), term = sg / g8, ch0 = 8 * (sg - term * g8);
+            half8 fr;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                float W = 0.f;
+                if (term < 2 && nd < K) W = (float)(tl[(size_t)nd * c + ch0 + i] * scale);
+                const _Float16 hi = (_Float16)W;
+                fr[i] = term == 0 ? hi : (_Float16)(W - (float)hi);
+            }
+            wfrag[(size_t)(b * npk + m) * 64 + fl] = fr;
+        }
+    }
     const int nsteps = 2 * nch;
-    for (int f = tid; f < (b1 - b0) * nch * 64; f += kUpdThreads) {
+    for (int f = tid; f < (npk > 0 ? 0 : (b1 - b0) * nch * 64); f += kUpdThreads) {
         const int fl = f & 63, h = (f >> 6) % nch, b = b0 + (f >> 6) / nch;
         const int m = fl & 15, q = fl >> 4;
         const int nd = node_of_row(b, m, nb);
@@ -931,6 +948,13 @@ int launch_step(const T *x, int64_t n, int c, int64_t ldx, double *stats, const 
     if (tiles_per_wave <= 0) {
         const int64_t blocks1 = (n + kStepWaves * 16 - 1) / (kStepWaves * 16);
         tpw = blocks1 <= slots ? 1 : (blocks1 <= 2 * slots ? 2 : 4);
+        static int small_tpw = 0;      // tuning hook: tiles per wave of the steps that fit one round (PXSOM_STEP_TPW_SMALL)
+        if (small_tpw == 0) {
+            const char *e = getenv("PXSOM_STEP_TPW_SMALL");
+            small_tpw = e ? atoi(e) : 1;
+            if (small_tpw != 1 && small_tpw != 2 && small_tpw != 4) small_tpw = 1;
+        }
+        if (blocks1 <= slots && blocks1 >= 8 * small_tpw) tpw = small_tpw;
     }
     const int64_t rows_per_wg = (int64_t)kStepWaves * 16 * tpw;
     // a step larger than one block per slot: the fewest rounds, spread evenly (853 blocks -> 214 workgroups x 4, not 256 x 3.3)
@@ -979,7 +1003,7 @@ bool launch_update_prepare(const StepArgs &sa, int xdim, int ydim, int c, char *
     const int grid = share ? (L.nb + bper - 1) / bper : 1;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kUpdThreads), lds, st, sa, c, reinterpret_cast<AssignHdr *>(ws),
                        reinterpret_cast<half8 *>(ws + L.off_wfrag), reinterpret_cast<f32x4 *>(ws + L.off_bias), wt_out, L.nb,
-                       L.nch, L.cpl, L.idx_bits, pl, reinterpret_cast<float *>(ws + L.off_w32), L.cp32);
+                       L.nch, L.cpl, L.idx_bits, pl, reinterpret_cast<float *>(ws + L.off_w32), L.cp32, L.npk);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) *rc = pxsom::hip_fail(e, "batch_update_prep_kernel");
     return true;

@@ -47,7 +47,7 @@ __device__ long long g_phase_ticks[32];
 template <int NT, int MAXK = PXSOM_MAX_NODES>
 __device__ __forceinline__ void prep_body(const double *wl, int k, int c, AssignHdr *hdr, half8 *wfrag,
                                           f32x4 *bias, int nb, int nch, int cpl, int idx_bits, int node_bits,
-                                          double *wt_out = nullptr, float *w32_out = nullptr, int cp32 = 0)
+                                          double *wt_out = nullptr, float *w32_out = nullptr, int cp32 = 0, int npk = 0)
 {
     // binary32 copy, rows zero-padded to cp32 channels: what the long-list exact kernel screens with
     if (w32_out) {
@@ -177,9 +177,27 @@ __device__ __forceinline__ void prep_body(const double *wl, int k, int c, Assign
 
     // A-fragments: wfrag[(b*nsteps + s)*64 + lane], lane = (q<<4 | m): node 16b+m,
     // slot i of lane group q in chunk h <-> channel h*4*cpl + q*cpl + i (i < cpl); s = 2h: hi, 2h+1: lo
-    const int nsteps = 2 * nch;
     PXSOM_PHASE_ANY(4);
-    for (int f = tid; f < nb * nch * 64; f += NT) {
+    if (npk > 0) {   // packed K axis (pxsom_assign.h packed_k): fragment m of block b holds slot groups 4m .. 4m + 3
+        const int g8 = c / 8;
+        for (int f = tid; f < nb * npk * 64; f += NT) {
+            const int lane = f & 63, m = (f >> 6) % npk, b = (f >> 6) / npk;
+            const int row = lane & 15, q = lane >> 4;
+            const int node = node_of_row(b, row, nb);
+            const int sg = 4 * m + q, term = sg / g8, ch0 = 8 * (sg - term * g8);
+            half8 fr;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                float W = 0.f;
+                if (term < 2 && node < k) W = (float)(wl[(size_t)node * c + ch0 + i] * scale);
+                const _Float16 hi = (_Float16)W;
+                fr[i] = term == 0 ? hi : (_Float16)(W - (float)hi);
+            }
+            wfrag[(size_t)(b * npk + m) * 64 + lane] = fr;
+        }
+    }
+    const int nsteps = 2 * nch;
+    for (int f = tid; f < (npk > 0 ? 0 : nb * nch * 64); f += NT) {
         const int lane = f & 63, h = (f >> 6) % nch, b = (f >> 6) / nch;
         const int m = lane & 15, q = lane >> 4;
         const int node = node_of_row(b, m, nb);

@@ -1737,7 +1737,8 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
         // codebooks the all-in-one kernel cannot hold (K = 400, or C > 32): ONE launch applies the pending update and
         // prepares the assign workspace for W_g (copy + update + clears + prep before), then search / exact / sums
         if (!(flags & PXSOM_TRAIN_UNFUSED)) {
-            const pxsom_bmu::Layout L = pxsom_bmu::make_layout(rows, c, k);
+            const int npk = pxsom_bmu::packed_rows_ok<T>(xv, ldv) ? pxsom_bmu::packed_k(c, k, sizeof(T) == 2) : 0;
+            const pxsom_bmu::Layout L = pxsom_bmu::make_layout(rows, c, k, npk);
             pxsom_bmu::StepArgs sa;
             sa.w_in = gg > 0 ? w_prev : w_cur;
             sa.w_out = gg > 0 ? w_cur : nullptr;
@@ -1754,7 +1755,7 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
             if (pxsom_bmu::launch_update_prepare(sa, xdim, ydim, c, ws, L, st, &rc)) {
                 if (rc) return rc;
                 if (rows > 0) {
-                    rc = pxsom_bmu::assign_prepared(xv, rows, c, ldv, dtype, w_cur, k, labels, ws, assign_ws, st);
+                    rc = pxsom_bmu::assign_prepared(xv, rows, c, ldv, dtype, w_cur, k, labels, ws, assign_ws, st, npk);
                     if (rc) return rc;
                     rc = cluster_sums_typed<T, true>(xv, rows, c, ldv, labels, k, s_cur, reinterpret_cast<int64_t *>(s_cur + nw), st, qmagic);
                     if (rc) return rc;

@@ -48,6 +48,10 @@ def _gpu_assign(gpu, x, w, want_dists=False):
     (30_000, 40, 400, np.float16),    # config 5: fp16 pixel matrix, 20x20 SOM
     (20_001, 22, 100, np.float16),    # fp16 rows on the register-resident path
     (2_000, 7, 30, np.float16),       # fp16, odd channel count
+    (20_000, 48, 400, np.float16),    # packed-K fragments (binary16 rows, c % 8 == 0, K > 128): 3 MFMAs per block instead of 4
+    (9_000, 72, 200, np.float16),     # packed: 5 instead of 6
+    (5_000, 104, 144, np.float16),    # packed: 7 instead of 8
+    (6_000, 64, 400, np.float16),     # c % 8 == 0 but nothing to gain: chunked layout
 ])
 def test_assign_matches_oracle(gpu, oracle, n, c, k, dtype):
     x = synth.make_fov_numpy(max(n, 2 * k), c, seed=11, dtype=dtype)[:n]
@@ -720,3 +724,27 @@ def test_assign_sums_one_pass_equals_two_passes(gpu, oracle, n, c, k, dtype):
     l3, s3, c3 = sd.assign_sums(xd, wd, sums=pre_s.clone(), counts=pre_c.clone())
     assert torch.equal(l3, l1) and torch.equal(c3, c1)
     np.testing.assert_allclose(s3.cpu().numpy(), s1.cpu().numpy(), rtol=1e-13, atol=0)
+
+
+def test_packed_k_filter_equals_chunked_filter_and_oracle(gpu, oracle):
+    """Config 5's shape (binary16 rows, 40 channels, 20 x 20 SOM): the packed-K streamed filter (aligned rows) against the
+    chunked one (the same rows at an odd element offset, which the packed kernel cannot read) and the oracle; rows with
+    values the binary16 range barely holds, duplicates and a NaN."""
+    n, c, k = 150_001, 40, 400
+    x = synth.make_fov_numpy(n, c, seed=21, dtype=np.float32).astype(np.float16)
+    x[10:20] = x[10]
+    x[33, 4] = np.float16(6.0e4)
+    x[34, 0] = np.nan
+    w = _codebook(x.astype(np.float64), k, seed=9)
+    w[7] = w[300]
+    xd, wd = torch.from_numpy(x).to(gpu), torch.from_numpy(w).to(gpu)
+    packed, _ = sd.assign(xd, wd)
+    listed_packed = sd.last_exact_rows(sd.assign.last_workspace)
+    shifted = torch.empty(n * c + 1, dtype=torch.float16, device=gpu)
+    shifted[1:] = xd.reshape(-1)
+    chunked, _ = sd.assign(shifted[1:].view(n, c), wd)          # 2-byte aligned only: the chunked kernel
+    listed_chunked = sd.last_exact_rows(sd.assign.last_workspace)
+    assert torch.equal(packed, chunked)
+    want, _ = oracle.map_data_to_nodes(w, x.astype(np.float64))
+    np.testing.assert_array_equal(packed.cpu().numpy(), want)
+    assert listed_packed < n // 10 and listed_packed <= 2 * listed_chunked + 64     # same bound, same order of listed rows
