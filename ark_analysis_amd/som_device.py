@@ -17,6 +17,8 @@ def _matrix_args(x: torch.Tensor) -> Tuple[int, int, int, int]:
     if not x.is_cuda:
         raise ValueError("pixel matrix must live in HBM (a cuda/HIP tensor)")
     n, c = x.shape
+    if n == 0:                         # an empty shard (more ranks than rows): no element, no stride to check
+        return 0, c, c, _capi.dtype_code(x)
     if c > 1 and x.stride(1) != 1:     # (a single column has no second stride to speak of: torch reports anything)
         raise ValueError("pixel matrix rows must be contiguous (stride(1) == 1)")
     ldx = x.stride(0) if n > 1 else max(c, x.stride(0))

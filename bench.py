@@ -449,6 +449,37 @@ def main():
                             "meta_clusters_found": int(torch.unique(meta).numel()),
                             "note": "K x C table on the host (as the reference), K-entry lookup in HBM; not part of the timed step"}
 
+    if world == 1 and args.config != "cfg2" and not args.no_cpu_baseline:
+        # The other configurations: the same oracle (online FlowSOM training + reference-shaped BMU search + per-cluster
+        # sums, one host core) on a BOUNDED sample -- about 10 s of training steps and 10 s of row labelling -- scaled
+        # linearly to the configuration's rows; the GPU labels of the sampled rows are compared on the way.
+        from tests import oracle_binding as ob
+        rr = default_radius_range(XD, YD)
+        s_train = int(min(n_train, max(20_000, 8e9 / (K * C))))
+        s_assign = int(min(n_all, max(50_000, 1.2e10 / (K * C))))
+        xt = x_train[:s_train].cpu().numpy().astype(np.float64)
+        w0h = w0.cpu().numpy()
+        order = np.random.RandomState(7).randint(0, s_train, size=s_train).astype(np.int64)
+        tt = time.perf_counter()
+        oracle_w = ob.som_online(xt, w0h, XD, YD, 1, (0.05, 0.01), rr, order)
+        t_train = time.perf_counter() - tt
+        xs = x_all[:s_assign].cpu().numpy().astype(np.float64)
+        tt = time.perf_counter()
+        lab_cpu, _ = ob.map_data_to_nodes(oracle_w, xs, column_major_copy=True)
+        t_assign = time.perf_counter() - tt
+        tt = time.perf_counter()
+        ob.cluster_sums(xs, lab_cpu, K)
+        t_means = time.perf_counter() - tt
+        cpu_s = t_train * (n_train / s_train) + (t_assign + t_means) * (n_all / s_assign)
+        lab_gpu, _ = som_device.assign(x_all[:s_assign], torch.from_numpy(oracle_w).to(dev))
+        out["cpu_baseline"] = {
+            "value": round(n_all / cpu_s / 1e6, 4), "unit": "Mpx/s" if cfg["kind"] == "pixel" else "M cells/s", "cores": 1,
+            "host_cores": os.cpu_count(), "kind": "port",
+            "sample": f"oracle online FlowSOM training on {s_train} of {n_train} training rows ({t_train:.2f} s) + "
+                      f"reference-shaped BMU search ({t_assign:.2f} s) and per-cluster sums ({t_means:.2f} s) on {s_assign} of "
+                      f"{n_all} rows, each scaled linearly; fp64, 1 thread",
+            "gpu_labels_equal_on_sample": bool(np.array_equal(lab_gpu.cpu().numpy(), lab_cpu))}
+
     if world == 1 and args.config == "cfg2":
         oracle_w = None
         order = None
