@@ -49,6 +49,10 @@ def _case(rs, max_work=6e7, wild=False):
     c = int(rs.choice([1, 2, 3, 5, 8, 13, 16, 22, 24, 31, 32, 33, 40, 64, 100, 128]))
     if rs.rand() < 0.3:
         c = int(rs.randint(1, 129))
+    if rs.rand() < 0.06:
+        c = int(rs.choice([48, 72, 104, 112]))                      # packed-K shapes (binary16 rows, K > 128)
+    if rs.rand() < 0.04:
+        c = int(rs.randint(129, 420))                               # wide rows: no filter, every row exact
     n_max = int(max(1, min(120000, max_work / (k * c))))
     n = int(rs.choice([1, 2, 63, 64, 65, 127, 129, 1000])) if rs.rand() < 0.25 else int(rs.randint(1, n_max + 1))
     n = min(n, n_max)
@@ -76,15 +80,17 @@ def _codebook(rs, host, k, kind):
     return np.ascontiguousarray(w)
 
 
-def _assert_sums_close(oracle, got, want, host, labels, k, tag):
+def _assert_sums_close(oracle, got, want, host, labels, k, tag, per_row=0.0):
     """Per-cluster sums to rounding, measured against sum |x| of the cluster's rows (values of both signs may cancel:
-    1e30 - 1e30 + 7e4 depends on the order); entries whose rows are not all finite must agree in being non-finite."""
-    mag, _ = oracle.cluster_sums(np.abs(host), labels, k)
+    1e30 - 1e30 + 7e4 depends on the order); entries whose rows are not all finite must agree in being non-finite.
+    ``per_row``: absolute error allowed per row of the cluster on top (the fixed-point tables of the one-pass kernel)."""
+    mag, cnt = oracle.cluster_sums(np.abs(host), labels, k)
     finite = np.isfinite(mag)
     assert np.array_equal(np.isfinite(got) & finite, np.isfinite(want) & finite), tag + ": finiteness of the sums"
     ok = finite & np.isfinite(want)
     err = np.abs(got[ok] - want[ok])
-    assert (err <= 1e-12 * mag[ok]).all(), tag + ": sums off by up to %.3g of sum|x|" % (err / np.maximum(mag[ok], 1e-300)).max()
+    bound = 1e-12 * mag[ok] + per_row * np.broadcast_to(cnt[:, None].astype(np.float64), mag.shape)[ok]
+    assert (err <= bound).all(), tag + ": sums off by up to %.3g of the bound" % (err / np.maximum(bound, 1e-300)).max()
 
 
 def test_fuzz_assign_and_sums(oracle):
@@ -106,7 +112,10 @@ def test_fuzz_assign_and_sums(oracle):
         lab2, s2, c2 = som_device.assign_sums(x, torch.from_numpy(w).cuda())
         assert np.array_equal(lab2.cpu().numpy(), want), tag + " (one pass)"
         assert np.array_equal(c2.cpu().numpy(), wc), tag + " (one pass)"
-        _assert_sums_close(oracle, s2.cpu().numpy(), ws, host, want, k, tag + " (one pass)")
+        # the register-resident shapes accumulate in fixed point: per value at most 2^-39 x rows-per-workgroup of the
+        # codebook's largest magnitude; 2^-28 covers workgroups of up to 2 K rows
+        wmax = float(np.abs(w[np.isfinite(w)]).max()) if np.isfinite(w).any() else 0.0
+        _assert_sums_close(oracle, s2.cpu().numpy(), ws, host, want, k, tag + " (one pass)", per_row=wmax * 2.0 ** -28)
 
 
 def test_fuzz_batch_training(oracle):
@@ -128,12 +137,27 @@ def test_fuzz_batch_training(oracle):
         w0 = _codebook(rs, host, k, kind)
         if n < 2:
             continue
+        # the schedule: m equal steps, or m steps of unequal widths over a random number of phases
+        from ark_analysis_amd.schedule import BatchSchedule
+        if rs.rand() < 0.5:
+            sch = BatchSchedule.equal(m)
+        else:
+            phases = int(rs.randint(m, 4 * m + 8))
+            cuts = np.sort(rs.choice(np.arange(1, phases), size=m - 1, replace=False)) if m > 1 else np.empty(0, dtype=np.int64)
+            sch = BatchSchedule(phases, [0] + [int(v) for v in cuts] + [phases])
+        # binary64 rows: half of the cases train with the reproducible-statistics quantum (sums then equal the oracle's
+        # on the quantised rows bit for bit)
+        quantum = 0.0
+        if dtype == "f64" and rs.rand() < 0.5 and np.isfinite(host).all():
+            widest = int(np.diff(sch.edges).max())
+            quantum = som_device.exact_sum_quantum(float(np.abs(host).max()), (n // sch.phases + 1) * max(widest, 1))
         total = m * passes
         alpha, radius = (0.05, 0.01), default_radius_range(xdim, ydim)
         for unfused in (False, True):
-            tag = "case %d: n=%d c=%d grid=%dx%d %s %s steps=%d x %d%s" % (
-                case, n, c, xdim, ydim, dtype, kind, m, passes, " (unfused)" if unfused else "")
-            st = som_device.BatchTrainState(n, c, xdim, ydim, m, x.device)
+            tag = "case %d: n=%d c=%d grid=%dx%d %s %s steps=%d x %d phases=%d q=%g%s" % (
+                case, n, c, xdim, ydim, dtype, kind, m, passes, sch.phases, quantum, " (unfused)" if unfused else "")
+            st = som_device.BatchTrainState(n, c, xdim, ydim, sch, x.device)
+            st.quantum = quantum
             st.wbuf[0].copy_(torch.from_numpy(w0))
             prev = None          # (W_g, statistics of step g, threshold, rate) of the step before
             for g in range(total + 1):
@@ -155,15 +179,19 @@ def test_fuzz_batch_training(oracle):
                     assert err.max() <= 1e-13, tag + " update %d: %.3g of the channel's scale" % (g - 1, err.max())
                 if g == total:
                     break
-                rows = host[g % m::m]
-                want_l, _ = oracle.map_data_to_nodes(w_g, rows)
-                want_s, want_c = oracle.cluster_sums(rows, want_l, k)
+                rows = host[sch.rows_of_step(n, g)].reshape(-1, c)
+                want_l, _ = oracle.map_data_to_nodes(w_g, rows) if len(rows) else (np.empty(0, np.int32), None)
+                want_s, want_c = oracle.cluster_sums(oracle.quantize(rows, quantum), want_l, k)
                 ring = st.ring[g % 3].cpu().numpy()
                 got_s, got_c = ring[:k * c].reshape(k, c), ring[k * c:]
                 assert np.array_equal(got_c, want_c.astype(np.float64)), tag + " counts of step %d" % g
-                np.testing.assert_allclose(got_s, want_s, rtol=1e-12, atol=1e-300, err_msg=tag + " sums of step %d" % g)
-                thr = radius[0] - (radius[0] - radius[1]) * g / total
-                a = alpha[0] - (alpha[0] - alpha[1]) * g / total
+                if quantum:
+                    assert np.array_equal(got_s, want_s), tag + " exact sums of step %d" % g
+                else:
+                    np.testing.assert_allclose(got_s, want_s, rtol=1e-12, atol=1e-300, err_msg=tag + " sums of step %d" % g)
+                pos, span = sch.position(g), passes * sch.phases
+                thr = radius[0] - (radius[0] - radius[1]) * pos / span
+                a = alpha[0] - (alpha[0] - alpha[1]) * pos / span
                 prev = (w_g, got_s.copy(), got_c.astype(np.int64), 0.5 if thr < 1.0 else thr, a)
 
 
