@@ -35,6 +35,11 @@ __device__ long long g_block_ticks[2 * 256];   // per workgroup: first and last 
 constexpr int kXD = 10, kYD = 10, kK = 100, kNB = 7;
 constexpr int kStepThreads = 512, kStepWaves = 8;
 constexpr int kQueueRows = 96;       // listed rows a workgroup keeps in LDS; further ones are settled on the spot
+// Copies of the workgroup's statistics table: pixel lane pix adds into copy pix % copies.  While the codebook is
+// crowded (the first steps of a pass: a handful of distinct nodes take every row) the lanes of one ds_add_f64 hit the same
+// few words and the LDS serialises them; with four copies a word is shared by a quarter of the lanes.  The flush adds the
+// copies up (a fixed order; binary32 / binary16 rows and quantised binary64 rows sum exactly anyway).
+__host__ __device__ inline int table_copies(int c) { return c <= 26 ? 4 : 2; }   // what fits 160 KB of LDS beside the rest
 
 struct StepHdr {
     int bad;          // NaN / Inf met in the codebook
@@ -49,7 +54,7 @@ __host__ __device__ inline StepLds step_lds(int c)
 {
     StepLds L;
     size_t o = 0;
-    L.ls = o;    o += ((size_t)kK * c + kK) * 8;          // table [K*c sums | K counts]
+    L.ls = o;    o += ((size_t)kK * c + kK) * 8 * table_copies(c);   // copies x table [K*c sums | K counts]
     L.wt = o;    o += (size_t)c * kK * 8;                 // codebook, transposed [c][K]
     L.tl = o;    o += (size_t)kK * (c + 1) * 8;           // window-sum scratch; later the queue of listed rows
     L.key = o;   o += (size_t)kK * 8;
@@ -145,6 +150,8 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
     // ---- P0: everything that does not depend on the codebook is requested first --------------------------
     // rows of this wave's tiles (rows past the end re-read the last row and are ignored afterwards)
     P2 raw[TPW][NP];
+    const size_t tstride = (size_t)kK * c + kK;      // doubles per copy of the statistics table
+    const int ncopies = table_copies(c);
     const unsigned group_w = (unsigned)sa.group_w;
     const double qmagic = sizeof(T) == 8 ? sa.qmagic : 0.0;
     auto load_rows = [&](int64_t blk) {
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
         if (blk < nblocks) load_rows(blk);
         PXSOM_PHASE(9);
         // (while those are in flight) clear the table and this workgroup's slice of the next buffer
-        for (int e = tid; e < kK * c + kK; e += kStepThreads) ls[e] = 0.0;
+        for (int e = tid; e < (kK * c + kK) * ncopies; e += kStepThreads) ls[e] = 0.0;
         if (tid == 0) {
             hdr->q_n = 0u;
             hdr->bad = 0;
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
         }
         if (blk < nblocks) load_rows(blk);
         PXSOM_PHASE(9);
-        for (int e = tid; e < kK * c + kK; e += kStepThreads) ls[e] = 0.0;
+        for (int e = tid; e < (kK * c + kK) * ncopies; e += kStepThreads) ls[e] = 0.0;
         if (tid == 0) {
             hdr->q_n = 0u;
             hdr->bad = 0;
@@ -517,7 +524,8 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
             const unsigned wq = id >> 5, wb = (id >> 2) & 7u, wr = id & 3u;
             const unsigned real = wb == (unsigned)(kNB - 1) ? 16u * wb + 4u * wr + wq : 16u * wb + 4u * wq + wr;
             if (valid && !amb) {
-                double *dst = ls + (size_t)real * c + q * CPL;
+                double *tab = ls + (size_t)(pix & (ncopies - 1)) * tstride;
+                double *dst = tab + (size_t)real * c + q * CPL;
 #pragma unroll
                 for (int p = 0; p < NP; p++) {
                     if (q * CPL + 2 * p <= c - 2) {   // clamped slots re-read the last pair: not theirs
@@ -531,7 +539,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
                     }
                 }
                 if (q == 0)
-                    __hip_atomic_fetch_add(ls + (size_t)kK * c + real, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(tab + (size_t)kK * c + real, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             // listed rows: values into the queue (all four lanes of a pixel agree on amb and on the slot)
             const unsigned mask16 = (unsigned)(__ballot(amb) & 0xffffull);
@@ -567,7 +575,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    exact_row_from_lds(slot, c, wt, ls, lane, qmagic);
+                    exact_row_from_lds(slot, c, wt, ls + (size_t)(wv & (ncopies - 1)) * tstride, lane, qmagic);
                     __builtin_amdgcn_wave_barrier();
                 }
             }
@@ -575,7 +583,8 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
         PXSOM_PHASE(16);
         __syncthreads();   // every wave is through its tiles: the queue is complete
         const unsigned queued = hdr->q_n < (unsigned)kQueueRows ? hdr->q_n : (unsigned)kQueueRows;
-        for (unsigned i = wv; i < queued; i += kStepWaves) exact_row_from_lds(qrows + (size_t)i * c, c, wt, ls, lane, qmagic);
+        for (unsigned i = wv; i < queued; i += kStepWaves)
+            exact_row_from_lds(qrows + (size_t)i * c, c, wt, ls + (size_t)(wv & (ncopies - 1)) * tstride, lane, qmagic);
         __syncthreads();
         if (blk + gridDim.x < nblocks && tid == 0) hdr->q_n = 0u;
         PXSOM_PHASE(17);
@@ -592,7 +601,8 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
         for (int it = 0; it < span; it += kStepThreads) {
             if (e >= span) e -= span;
             if (e < total) {
-                const double v = ls[e];
+                double v = ls[e];
+                for (int j = 1; j < ncopies; j++) v += ls[e + (size_t)j * tstride];
                 if (v != 0.0) __hip_atomic_fetch_add(stats + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             e += kStepThreads;

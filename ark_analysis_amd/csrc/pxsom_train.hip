@@ -1387,6 +1387,29 @@ __global__ __launch_bounds__(256) void stats_to_tables_kernel(const double *__re
         else counts[e - k * c] += (long long)stats[e];
     }
 }
+
+// the same, OVERWRITING the caller's tables and forming the means (pxsom_assign_means)
+__global__ __launch_bounds__(256) void stats_to_means_kernel(const double *__restrict__ stats, int k, int c, double *sums,
+                                                             long long *counts, double *means)
+{
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < k * c + k; e += gridDim.x * 256) {
+        if (e < k * c) {
+            const double s = stats[e], cnt = stats[(size_t)k * c + e / c];
+            sums[e] = s;
+            if (means) means[e] = s / (cnt > 0.0 ? cnt : 1.0);
+        } else {
+            counts[e - k * c] = (long long)stats[e];
+        }
+    }
+}
+__global__ __launch_bounds__(256) void tables_to_means_kernel(const double *__restrict__ sums, const long long *__restrict__ counts,
+                                                              int k, int c, double *means)
+{
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < k * c; e += gridDim.x * 256) {
+        const long long cnt = counts[e / c];
+        means[e] = sums[e] / (double)(cnt > 0 ? cnt : 1);
+    }
+}
 }  // namespace
 
 PXSOM_EXPORT size_t pxsom_assign_sums_workspace_bytes(int64_t n, int c, int k)
@@ -1431,6 +1454,48 @@ PXSOM_EXPORT int pxsom_assign_sums(const void *x_dev, int64_t n, int c, int64_t 
     rc = pxsom_assign(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, nullptr, workspace_dev, assign_ws, stream);
     if (rc) return rc;
     return pxsom_cluster_sums(x_dev, n, c, ldx, dtype, labels_dev, k, sums_dev, counts_dev, stream);
+}
+
+PXSOM_EXPORT int pxsom_assign_means(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev, int k,
+                                    int32_t *labels_dev, double *sums_dev, int64_t *counts_dev, double *means_dev,
+                                    void *workspace_dev, size_t workspace_bytes, void *stream)
+{
+    int rc = check_matrix("pxsom_assign_means", x_dev, n, c, ldx, dtype);
+    if (rc) return rc;
+    if (k < 1 || k > PXSOM_MAX_NODES)
+        return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "pxsom_assign_means: k=%d outside [1, %d]", k, PXSOM_MAX_NODES);
+    if (!w_dev || !sums_dev || !counts_dev || (n > 0 && !labels_dev))
+        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_assign_means: null pointer");
+    const size_t need = pxsom_assign_sums_workspace_bytes(n, c, k);
+    if (!workspace_dev || workspace_bytes < need)
+        return pxsom::fail(PXSOM_ERR_WORKSPACE, "pxsom_assign_means: workspace %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t assign_ws = pxsom::align_up(pxsom_assign_workspace_bytes(n, c, k), 256);
+    double *scratch = reinterpret_cast<double *>(reinterpret_cast<char *>(workspace_dev) + assign_ws);
+    const unsigned fgrid = (unsigned)((k * (c + 1) + 255) / 256);
+    PXSOM_HIP_TRY(hipMemsetAsync(scratch, 0, (size_t)k * (c + 1) * sizeof(double), st));
+    bool fused = false;
+    if (n > 0) {
+        rc = pxsom_bmu::assign_accumulate(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, scratch, workspace_dev, assign_ws, st, &fused,
+                                          true);
+        if (rc) return rc;
+    }
+    if (fused || n == 0) {   // one launch writes the three tables
+        hipLaunchKernelGGL(stats_to_means_kernel, dim3(fgrid), dim3(256), 0, st, scratch, k, c, sums_dev,
+                           reinterpret_cast<long long *>(counts_dev), means_dev);
+        PXSOM_LAUNCH_CHECK("stats_to_means_kernel");
+        return PXSOM_OK;
+    }
+    PXSOM_HIP_TRY(hipMemsetAsync(sums_dev, 0, (size_t)k * c * sizeof(double), st));
+    PXSOM_HIP_TRY(hipMemsetAsync(counts_dev, 0, (size_t)k * sizeof(int64_t), st));
+    rc = pxsom_assign(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, nullptr, workspace_dev, assign_ws, stream);
+    if (rc) return rc;
+    rc = pxsom_cluster_sums(x_dev, n, c, ldx, dtype, labels_dev, k, sums_dev, counts_dev, stream);
+    if (rc || !means_dev) return rc;
+    hipLaunchKernelGGL(tables_to_means_kernel, dim3(fgrid), dim3(256), 0, st, sums_dev, reinterpret_cast<const long long *>(counts_dev), k, c,
+                       means_dev);
+    PXSOM_LAUNCH_CHECK("tables_to_means_kernel");
+    return PXSOM_OK;
 }
 
 // codebooks the accumulating filter prepares for itself inside its own launch (register-resident shapes)

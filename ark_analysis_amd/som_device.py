@@ -524,3 +524,18 @@ def assign_sums(x: torch.Tensor, w: torch.Tensor, labels: Optional[torch.Tensor]
                                        counts.data_ptr(), workspace.buf.data_ptr(), workspace.bytes, _capi.stream_ptr())
     _capi.check(rc, "pxsom_assign_sums")
     return labels, sums, counts
+
+
+def assign_means(x: torch.Tensor, w: torch.Tensor, labels: torch.Tensor, sums: torch.Tensor, counts: torch.Tensor,
+                 means: Optional[torch.Tensor], workspace: AssignSumsWorkspace) -> None:
+    """Labels, per-cluster sums / counts (OVERWRITTEN) and means = sums / max(count, 1) in one library call and one pass
+    over ``x`` where the shape allows (pxsom_assign_means)."""
+    n, c, ldx, dt = _matrix_args(x)
+    w = _codebook(w)
+    k = w.shape[0]
+    if not workspace.fits(n, c, k):
+        raise ValueError("workspace does not fit this matrix")
+    rc = _capi.lib().pxsom_assign_means(x.data_ptr(), n, c, ldx, dt, w.data_ptr(), k, labels.data_ptr(), sums.data_ptr(),
+                                        counts.data_ptr(), means.data_ptr() if means is not None else None,
+                                        workspace.buf.data_ptr(), workspace.bytes, _capi.stream_ptr())
+    _capi.check(rc, "pxsom_assign_means")

@@ -236,6 +236,10 @@ def main():
     def assign_and_mean_table():
         """K7 + K8: BMU label of every row and the per-cluster channel means over every row of every rank -- one
         pass over x (pxsom_assign_sums) with --one-pass, else the BMU search followed by the K8 kernel."""
+        if args.one_pass and not use_dist:
+            # one process: labels, tables and means from one library call (pxsom_assign_means overwrites its outputs)
+            som_device.assign_means(x_all, w, labels, k8_sums, k8_counts, means, ws_all)
+            return
         k8_sums.zero_()
         k8_counts.zero_()
         if (not args.one_pass):

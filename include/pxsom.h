@@ -116,6 +116,13 @@ int pxsom_assign_sums(const void *x_dev, int64_t n, int c, int64_t ldx, int dtyp
                       int32_t *labels_dev, double *sums_dev, int64_t *counts_dev, void *workspace_dev,
                       size_t workspace_bytes, void *stream);
 
+/* The same pass with the tables OVERWRITTEN (no clearing by the caller) and the per-cluster means formed in the same
+ * final launch: means_dev [k, c] = sums / max(count, 1), or NULL.  What generate_som_avg_files needs from one process
+ * (pixel_cluster_utils.py:369-404); a multi-rank job all-reduces sums / counts and divides itself. */
+int pxsom_assign_means(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev, int k,
+                       int32_t *labels_dev, double *sums_dev, int64_t *counts_dev, double *means_dev, void *workspace_dev,
+                       size_t workspace_bytes, void *stream);
+
 /* ---- cell x pixel-cluster counts: the counting step of create_c2pc_data --------------------------
  * reference: cell_cluster_utils.py:128-141 (groupby(['label', pixel_cluster_col]).size() + pivot per
  * FOV).  hist[a_i * nb + b_i] += 1 for every i with 0 <= a_i < na and 0 <= b_i < nb (other pairs are

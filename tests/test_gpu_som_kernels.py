@@ -748,3 +748,26 @@ def test_packed_k_filter_equals_chunked_filter_and_oracle(gpu, oracle):
     want, _ = oracle.map_data_to_nodes(w, x.astype(np.float64))
     np.testing.assert_array_equal(packed.cpu().numpy(), want)
     assert listed_packed < n // 10 and listed_packed <= 2 * listed_chunked + 64     # same bound, same order of listed rows
+
+
+@pytest.mark.parametrize("n,c,k,dtype", [(200_000, 22, 100, np.float32), (30_000, 40, 400, np.float16), (40, 22, 100, np.float32), (0, 8, 100, np.float32)])
+def test_assign_means_equals_assign_sums(gpu, n, c, k, dtype):
+    """pxsom_assign_means = pxsom_assign_sums on cleared tables + the division, in one call: labels, sums, counts equal, means =
+    sums / max(count, 1); the outputs are overwritten (stale contents do not leak)."""
+    x = synth.make_fov_numpy(max(n, 1), c, seed=17, dtype=np.float32).astype(dtype)[:n]
+    w = _codebook(synth.make_fov_numpy(4 * k, c, seed=18, dtype=np.float64), k, seed=2)
+    xd, wd = torch.from_numpy(x).to(gpu), torch.from_numpy(w).to(gpu)
+    ws = sd.AssignSumsWorkspace(max(n, 1), c, k, gpu)
+    labels = torch.full((n,), -5, dtype=torch.int32, device=gpu)
+    sums = torch.full((k, c), 7.0, dtype=torch.float64, device=gpu)
+    counts = torch.full((k,), 9, dtype=torch.int64, device=gpu)
+    means = torch.full((k, c), -1.0, dtype=torch.float64, device=gpu)
+    sd.assign_means(xd, wd, labels, sums, counts, means, ws)
+    if n:
+        l2, s2, c2 = sd.assign_sums(xd, wd)
+        assert torch.equal(labels, l2) and torch.equal(counts, c2)
+        np.testing.assert_allclose(sums.cpu().numpy(), s2.cpu().numpy(), rtol=1e-13, atol=0)
+    else:
+        assert int(counts.abs().sum()) == 0 and float(sums.abs().sum()) == 0.0
+    want = sums / counts.clamp(min=1).to(torch.float64).unsqueeze(1)
+    assert torch.equal(means, want)
