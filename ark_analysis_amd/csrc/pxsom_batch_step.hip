@@ -35,11 +35,11 @@ __device__ long long g_block_ticks[2 * 256];   // per workgroup: first and last 
 constexpr int kXD = 10, kYD = 10, kK = 100, kNB = 7;
 constexpr int kStepThreads = 512, kStepWaves = 8;
 constexpr int kQueueRows = 96;       // listed rows a workgroup keeps in LDS; further ones are settled on the spot
-// Copies of the workgroup's statistics table: pixel lane pix adds into copy pix % copies.  While the codebook is
-// crowded (the first steps of a pass: a handful of distinct nodes take every row) the lanes of one ds_add_f64 hit the same
-// few words and the LDS serialises them; with four copies a word is shared by a quarter of the lanes.  The flush adds the
-// copies up (a fixed order; binary32 / binary16 rows and quantised binary64 rows sum exactly anyway).
-__host__ __device__ inline int table_copies(int c) { return c <= 26 ? 4 : 2; }   // what fits 160 KB of LDS beside the rest
+// Copies of the workgroup's statistics table (pixel lane pix adds into copy pix % copies) against same-word contention of
+// the ds_add_f64 lanes while the codebook is crowded.  Measured in round 3 with 4 copies: the crowded head steps did not
+// move (36.0 / 33.1 us before and after: the LDS serialisation is not what holds them) and every step paid for clearing and
+// adding up the copies (tail step 11.4 -> 12.1 us): one table.
+__host__ __device__ inline int table_copies(int c) { return (void)c, 1; }
 
 struct StepHdr {
     int bad;          // NaN / Inf met in the codebook

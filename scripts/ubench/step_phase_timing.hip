@@ -10,7 +10,8 @@
 
 int main(int argc, char **argv)
 {
-    const int M = 64, c = 22, K = 100, tpw = argc > 1 ? atoi(argv[1]) : 2;
+    // argv: tiles per wave (0 = by step size), steps per pass M (64: round 2's 16 K-row steps; 144: the 7 280-row steps of round 3's tail)
+    const int M = argc > 2 ? atoi(argv[2]) : 64, c = 22, K = 100, tpw = argc > 1 ? atoi(argv[1]) : 2;
     const int64_t n = 1048576;
     std::vector<float> x((size_t)n * c);
     srand(1);
@@ -48,7 +49,7 @@ int main(int argc, char **argv)
             const int64_t rows = (n - g + M - 1) / M;
             int rc = launch_batch_step<float>(dx + (size_t)g * c, rows, c, (int64_t)c * M, dring + (g % 3) * ns, sa, tpw, 0);
             if (rc) { printf("rc %d %s\n", rc, pxsom_last_error()); return 1; }
-            if (rep == 1 && (g == 1 || g == 20 || g == 40 || g == 63)) {
+            if (rep == 1 && (g == 1 || g == M / 3 || g == (2 * M) / 3 || g == M - 4 || g == M - 1)) {
                 hipDeviceSynchronize();
                 long long t[32];
                 hipMemcpyFromSymbol(t, HIP_SYMBOL(g_phase_ticks), sizeof(t));
@@ -62,7 +63,7 @@ int main(int argc, char **argv)
                 {
                     long long bt[512];
                     hipMemcpyFromSymbol(bt, HIP_SYMBOL(g_block_ticks), sizeof(bt));
-                    const int nwg = (int)((rows + (tpw == 1 ? 127 : 255)) / (tpw == 1 ? 128 : 256));
+                    const int nwg = std::min(256, (int)((rows + (tpw <= 1 ? 127 : 255)) / (tpw <= 1 ? 128 : 256)));
                     long long s0 = bt[0], s1 = bt[0], e0 = bt[1], e1 = bt[1];
                     double dsum = 0;
                     for (int b = 0; b < nwg; b++) {
