@@ -144,8 +144,16 @@ class FovTableDir:
         """Replace the directory by its staging twin.  The old tables are moved aside (a hidden, uniquely named
         directory next to ``root``) and unlinked on a background thread the interpreter waits for at exit:
         deleting a page-cache-resident 218 MB table takes ~16 ms, a third of what labelling it costs, and nothing
-        downstream depends on it -- ``root`` holds the new tables when this returns."""
+        downstream depends on it -- ``root`` holds the new tables when this returns.  The public pipeline functions
+        call :func:`wait_for_cleanup` before they return (a caller that deletes or lists the parent directory right
+        after them must not race the cleaner); the deletion then overlaps only with what they do after the swap."""
         parent, name = os.path.split(os.path.abspath(self.root))
+        # what an earlier process that was killed between its rename and the end of its clean-up left behind (a full
+        # copy of the cohort's tables): swept here, behind the directories this process is still deleting itself
+        wait_for_cleanup()
+        for stale in os.listdir(parent):
+            if stale.startswith(".%s.old-" % name) and os.path.isdir(os.path.join(parent, stale)):
+                _remove_tree(os.path.join(parent, stale), on_rm_error)
         trash = tempfile.mkdtemp(prefix=".%s.old-" % name, dir=parent)
         os.rename(self.root, os.path.join(trash, name))
         shutil.move(self.staging, self.root)

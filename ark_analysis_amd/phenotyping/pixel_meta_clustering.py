@@ -132,6 +132,7 @@ def _rewrite_tables(tables: FovTableDir, todo: Sequence[str], relabel, multiproc
     distributed.barrier()
     if rank == 0:
         tables.commit()
+        fov_tables.wait_for_cleanup()
     distributed.barrier()
 
 

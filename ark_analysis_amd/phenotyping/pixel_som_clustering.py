@@ -205,6 +205,7 @@ def cluster_pixels(fovs, base_dir, pixel_pysom, data_dir='pixel_mat_data',
         _say("Processed %d fovs" % total)
     if rank == 0:
         tables.commit(on_rm_error=_ignore_extended_attributes)
+        fov_tables.wait_for_cleanup()      # nobody lists or deletes base_dir under the cleaner (reference: a blocking rmtree)
     distributed.barrier()
 
 

@@ -47,7 +47,24 @@ def save_fov_mask(fov, data_dir, mask_data, sub_dir=None, name_suffix=''):
     validate_paths(data_dir)
     folder = os.path.join(data_dir, sub_dir or '')
     os.makedirs(folder, exist_ok=True)
-    image_io.write_image(os.path.join(folder, fov + name_suffix + '.tiff'), np.asarray(mask_data))
+    mask = np.asarray(mask_data)
+    path = os.path.join(folder, fov + name_suffix + '.tiff')
+    if mask.dtype.kind in "biu" and mask.dtype not in (np.uint8, np.uint16, np.int16, np.int32):
+        # dtypes the baseline TIFF writer has no sample format for (bool, uint32, int64 ... masks: the reference's tifffile
+        # takes them all): the narrowest one it has that holds every value -- pixel values are unchanged
+        lo, hi = (int(mask.min()), int(mask.max())) if mask.size else (0, 0)
+        for dt in (np.uint8, np.uint16, np.int16, np.int32):
+            if np.iinfo(dt).min <= lo and hi <= np.iinfo(dt).max:
+                mask = mask.astype(dt)
+                break
+        else:
+            raise ValueError("mask values [%d, %d] do not fit a 32-bit TIFF sample" % (lo, hi))
+    elif mask.dtype == np.float64:
+        as32 = mask.astype(np.float32)
+        if not np.array_equal(as32.astype(np.float64), mask, equal_nan=True):
+            raise ValueError("float64 mask with values float32 cannot hold: save it with a full TIFF library")
+        mask = as32
+    image_io.write_image(path, mask)
 
 
 def generate_and_save_pixel_cluster_masks(fovs, base_dir, save_dir, tiff_dir, chan_file, pixel_data_dir,

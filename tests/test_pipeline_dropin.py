@@ -701,6 +701,13 @@ def test_saved_pixel_cluster_masks_match_reference_run(som_backend, tmp_path):
                                   np.arange(6).reshape(2, 3))
     with pytest.raises(FileNotFoundError):
         data_utils.save_fov_mask("fovA", os.path.join(td, "nowhere"), np.zeros((2, 2), dtype=np.int16))
+    # mask dtypes the reference's tifffile accepts and the baseline writer has no sample format for: same pixel values
+    for mask in (np.array([[0, 70000], [3, 1]], dtype=np.uint32), np.arange(6, dtype=np.int64).reshape(2, 3) - 2,
+                 np.array([[True, False]]), np.array([[0.5, 2.0]], dtype=np.float64)):
+        data_utils.save_fov_mask("fovB", os.path.join(td, "masks"), mask)
+        np.testing.assert_array_equal(image_io.read_image(os.path.join(td, "masks", "fovB.tiff")), mask)
+    with pytest.raises(ValueError):
+        data_utils.save_fov_mask("fovB", os.path.join(td, "masks"), np.array([[2 ** 40]], dtype=np.int64))
     # the TIFF writer keeps every dtype it accepts; Pillow agrees on the values
     from PIL import Image
     for dtype in (np.uint8, np.uint16, np.int16, np.int32, np.float32):
