@@ -379,8 +379,8 @@ def main():
         # rocprofv3 reports KiB; FETCH_SIZE counts 128-B requests at 64 B on gfx950 (MI355X_MICROARCH.md "HBM")
         out["roofline"]["traffic"] = round((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0)
         out["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes inside this run"
-    elif args.config == "cfg2" and not mfma_bound and not args.one_pass and recorded.get("bmu_filter_kernel_hbm_bytes_per_launch"):
-        out["roofline"]["traffic"] = recorded["bmu_filter_kernel_hbm_bytes_per_launch"]
+    elif args.config == "cfg2" and not mfma_bound and recorded.get(("onepass" if args.one_pass else "bmu_filter") + "_kernel_hbm_bytes_per_launch"):
+        out["roofline"]["traffic"] = recorded[("onepass" if args.one_pass else "bmu_filter") + "_kernel_hbm_bytes_per_launch"]
         out["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (recorded; no in-run PMC pass)"
     if "SQ_VALU_MFMA_BUSY_CYCLES" in pmc and pmc.get("GRBM_GUI_ACTIVE"):
         kernel_cycles = pmc["GRBM_GUI_ACTIVE"] / N_XCDS     # cycles the kernel was resident (per XCD)
@@ -390,8 +390,9 @@ def main():
                             "mfma_insts": pmc.get("SQ_INSTS_MFMA"), "valu_insts": pmc.get("SQ_INSTS_VALU"),
                             "source": "rocprofv3 --pmc inside this run: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x "
                                       "GRBM_GUI_ACTIVE / 8 XCDs)"}
-    elif recorded.get("bmu_filter_kernel_mfma_util") and args.config == "cfg2" and not args.one_pass:
-        out["mfma_util"] = {"kernel": "bmu_filter_kernel", "value": recorded["bmu_filter_kernel_mfma_util"],
+    elif recorded.get(("onepass" if args.one_pass else "bmu_filter") + "_kernel_mfma_util") and args.config == "cfg2":
+        out["mfma_util"] = {"kernel": out["roofline"]["kernel"].split(" ")[0],
+                            "value": recorded[("onepass" if args.one_pass else "bmu_filter") + "_kernel_mfma_util"],
                             "source": "profiles/pmc_traffic.json (recorded; no in-run PMC pass)"}
 
     if world == 1 and args.config == "cfg2" and not args.no_operating_range:
