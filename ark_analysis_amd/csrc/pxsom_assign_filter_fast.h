@@ -62,14 +62,25 @@ __device__ __forceinline__ void top2_pair(float &m1, float &m2, float a, float b
     m2 = fmaxf(tm, m2);
 }
 
+// four values per update in FIVE operations (two top2_pair take six): the runner-up is the largest of the old one and the
+// two medians, and v_max3 takes all three at once
+//   t1 = med3(m1, a, b); m1' = max3(m1, a, b); t2 = med3(m1', c, d); m1'' = max3(m1', c, d); m2' = max3(m2, t1, t2)
+__device__ __forceinline__ void top2_quad(float &m1, float &m2, float a, float b, float c, float d)
+{
+    const float t1 = __builtin_amdgcn_fmed3f(m1, a, b);
+    m1 = fmaxf(fmaxf(m1, a), b);
+    const float t2 = __builtin_amdgcn_fmed3f(m1, c, d);
+    m1 = fmaxf(fmaxf(m1, c), d);
+    m2 = fmaxf(fmaxf(m2, t1), t2);
+}
+
 __device__ __forceinline__ void consume(float &m1, float &m2, const f32x4 &acc, int b, unsigned idx_mask)
 {
     const float p0 = pack_idx(acc[0], (unsigned)(b * 4 + 0), idx_mask);
     const float p1 = pack_idx(acc[1], (unsigned)(b * 4 + 1), idx_mask);
     const float p2 = pack_idx(acc[2], (unsigned)(b * 4 + 2), idx_mask);
     const float p3 = pack_idx(acc[3], (unsigned)(b * 4 + 3), idx_mask);
-    top2_pair(m1, m2, p0, p1);
-    top2_pair(m1, m2, p2, p3);
+    top2_quad(m1, m2, p0, p1, p2, p3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -414,9 +425,9 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
                         if (b < NB - 1 || RU == 4) {
-                            top2_pair(m1[u], m2[u], pack_idx(acc[u][0], (unsigned)(b * 4 + 0), idx_mask),
-                                      pack_idx(acc[u][1], (unsigned)(b * 4 + 1), idx_mask));
-                            top2_pair(m1[u], m2[u], pack_idx(acc[u][2], (unsigned)(b * 4 + 2), idx_mask),
+                            top2_quad(m1[u], m2[u], pack_idx(acc[u][0], (unsigned)(b * 4 + 0), idx_mask),
+                                      pack_idx(acc[u][1], (unsigned)(b * 4 + 1), idx_mask),
+                                      pack_idx(acc[u][2], (unsigned)(b * 4 + 2), idx_mask),
                                       pack_idx(acc[u][3], (unsigned)(b * 4 + 3), idx_mask));
                         } else {
                             // last block: only registers 0..RU-1 hold real nodes

@@ -477,9 +477,9 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
 #pragma unroll
             for (int t = 0; t < TPW; t++) {
                 if (b < kNB - 1) {
-                    top2_pair(m1[t], m2[t], pack_idx(acc[t][0], (unsigned)(b * 4 + 0), idx_mask),
-                              pack_idx(acc[t][1], (unsigned)(b * 4 + 1), idx_mask));
-                    top2_pair(m1[t], m2[t], pack_idx(acc[t][2], (unsigned)(b * 4 + 2), idx_mask),
+                    top2_quad(m1[t], m2[t], pack_idx(acc[t][0], (unsigned)(b * 4 + 0), idx_mask),
+                              pack_idx(acc[t][1], (unsigned)(b * 4 + 1), idx_mask),
+                              pack_idx(acc[t][2], (unsigned)(b * 4 + 2), idx_mask),
                               pack_idx(acc[t][3], (unsigned)(b * 4 + 3), idx_mask));
                 } else {   // last block: only accumulator register 0 holds real nodes (K = 100)
                     const float p0 = pack_idx(acc[t][0], (unsigned)(b * 4 + 0), idx_mask);
