@@ -91,3 +91,45 @@ def test_two_ranks_on_the_default_schedule_match_the_oracle(oracle, tmp_path):
     want = oracle.som_batch_sched(np.concatenate(blocks), w0, xdim, ydim, 1, (0.05, 0.01), default_radius_range(xdim, ydim),
                                   sch.phases, sch.edges)
     np.testing.assert_allclose(res["w"], want, rtol=1e-10, atol=0)
+
+
+def _failing_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ark_analysis_amd import distributed, flowsom
+    from tests import oracle_backend
+    oracle_backend.install(setattr)
+    outcome = []
+    # (1) work only rank 0 does in front of a collective fails: every rank gets the exception, nobody waits in the broadcast
+    try:
+        distributed.on_rank0(lambda: (_ for _ in ()).throw(ValueError("rank 0 could not train")))
+    except ValueError as e:
+        outcome.append(str(e))
+    # (2) som_batch on a job with fewer rows than nodes: decided on the JOB's row count, the same error on every rank
+    rs = np.random.RandomState(rank)
+    try:
+        flowsom.som_batch(rs.rand(3, 4), xdim=3, ydim=3, seed=1, batch_steps=2)
+    except ValueError as e:
+        outcome.append(str(e))
+    # (3) rank 0's share is shorter than K but the job has enough rows: initial nodes come from the pooled candidates
+    n_local = 4 if rank == 0 else 40
+    w = flowsom.som_batch(rs.rand(n_local, 4), xdim=3, ydim=3, seed=1, batch_steps=2)
+    outcome.append(w.shape)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, w.tobytes())
+    outcome.append(len(set(gathered)) == 1)
+    np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.array(outcome, dtype=object), allow_pickle=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank0_failures_reach_every_rank_and_short_shards_still_train(tmp_path):
+    """Round-2 advice: rank-0-only work in front of a collective must not strand the other ranks; `n >= K` is a property of
+    the job, not of rank 0's shard."""
+    mp.spawn(_failing_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for rank in range(2):
+        got = np.load(str(tmp_path / ("rank%d.npy" % rank)), allow_pickle=True)
+        assert got[0] == "rank 0 could not train"
+        assert "at least as many rows (6) as nodes (9)" in got[1]
+        assert tuple(got[2]) == (9, 4) and bool(got[3])
