@@ -166,7 +166,19 @@ _CLEANERS: List[threading.Thread] = []
 
 
 def _remove_tree(path: str, on_rm_error) -> None:
+    """Deletes a directory of replaced tables.  The files are unlinked side by side first (releasing a 218 MB page-cache
+    resident table takes tens of milliseconds inside the kernel, and a cohort has hundreds of them), the rest -- empty
+    directories, anything unexpected -- goes through shutil.rmtree with the caller's error hook."""
     try:
+        files = [os.path.join(folder, name) for folder, _, names in os.walk(path) for name in names]
+        if len(files) > 1:
+            def unlink(file_path):
+                try:
+                    os.unlink(file_path)
+                except OSError:
+                    pass                      # left for rmtree below, which reports through on_rm_error
+            with ThreadPoolExecutor(max_workers=min(16, len(files)), thread_name_prefix="fov-unlink") as pool:
+                list(pool.map(unlink, files))
         shutil.rmtree(path, onerror=on_rm_error)
     except BaseException as err:      # nobody to raise to on this thread
         warnings.warn("could not remove the replaced tables in %s: %r" % (path, err))

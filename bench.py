@@ -411,8 +411,17 @@ def main():
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / reps
             listed = som_device.last_exact_rows(ws_r)
+            # the default path of the step on the same codebook: labels + tables + means in one pass (its listed rows are
+            # settled inside the launch, one wave per row)
+            ws_m = som_device.AssignSumsWorkspace(n_all, C, K, dev)
+            som_device.assign_means(x_all, wcb, lab_r, k8_sums, k8_counts, means, ws_m)
+            e0.record()
+            for _ in range(reps):
+                som_device.assign_means(x_all, wcb, lab_r, k8_sums, k8_counts, means, ws_m)
+            e1.record()
+            torch.cuda.synchronize()
             return {"assign_ms": round(ms, 4), "listed_rows": listed, "listed_frac": round(listed / n_all, 6),
-                    "Gpx_per_s": round(n_all / ms / 1e6, 2)}
+                    "Gpx_per_s": round(n_all / ms / 1e6, 2), "labels_and_mean_table_one_pass_ms": round(e0.elapsed_time(e1) / reps, 4)}
         near = w.clone()
         gen = torch.Generator(device=dev)
         gen.manual_seed(5)
