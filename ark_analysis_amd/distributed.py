@@ -154,14 +154,14 @@ class BatchSOMTrainer:
             else:
                 for g in range(total):
                     kern.steps(x_local, g, g + 1, total, self.alpha_range, self.radius_range)
-                    dist.all_reduce(kern.ring(g), op=dist.ReduceOp.SUM, group=self.group)
+                    all_reduce_(kern.ring(g), group=self.group)
         else:
             kern.steps(x_local, 0, total, total, self.alpha_range, self.radius_range)
         kern.finish(total, total, self.alpha_range, self.radius_range, w)
         if _world(self.group) > 1:
             # every rank applied the same all-reduced statistics, so the replicas are equal already; the broadcast makes
             # that unconditional (rank 0's file is the codebook of record) for the price of one 18 KB message
-            dist.broadcast(w, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            broadcast_codebook(w, dist.get_global_rank(self.group, 0) if self.group is not None else 0, self.group)
         return w
 
 
@@ -334,15 +334,32 @@ def allreduce_sum_numpy(arr):
     return t.cpu().numpy()
 
 
+def _staged(t: torch.Tensor, group, fn) -> None:
+    """Runs the in-place collective ``fn`` on ``t`` where the group's backend can see it: RCCL takes the HBM tensor as it
+    is, a gloo group (the CPU test suite; a dry run of the multi-rank code on one GPU) takes a host copy."""
+    dev = _collective_device(group)
+    if t.device.type == dev.type:
+        fn(t)
+    else:
+        h = t.to(dev)
+        fn(h)
+        t.copy_(h)
+
+
+def all_reduce_(t: torch.Tensor, op=None, group=None) -> torch.Tensor:
+    if _world(group) > 1:
+        _staged(t, group, lambda v: dist.all_reduce(v, op=op if op is not None else dist.ReduceOp.SUM, group=group))
+    return t
+
+
 def broadcast_codebook(w: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
     if _world(group) > 1:
-        dist.broadcast(w, src=src, group=group)
+        _staged(w, group, lambda v: dist.broadcast(v, src=src, group=group))
     return w
 
 
 def allreduce_cluster_tables(sums: torch.Tensor, counts: torch.Tensor, group=None):
     """K8 across ranks: one sum all-reduce each for the [K, C] f64 sums and [K] i64 counts."""
-    if _world(group) > 1:
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    all_reduce_(sums, group=group)
+    all_reduce_(counts, group=group)
     return sums, counts

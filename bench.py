@@ -50,7 +50,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from ark_analysis_amd import _capi, som_device, synth  # noqa: E402
-from ark_analysis_amd.distributed import (BatchSOMTrainer, allreduce_cluster_tables,  # noqa: E402
+from ark_analysis_amd.distributed import (BatchSOMTrainer, all_reduce_, allreduce_cluster_tables,  # noqa: E402
                                           broadcast_codebook)
 from ark_analysis_amd.flowsom import default_radius_range  # noqa: E402
 
@@ -192,6 +192,12 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     _capi.require_gpu()
+    # PXSOM_BENCH_DRY_RANKS=1 (tests/test_gpu_bench_multirank.py): every rank on device 0 over a gloo group -- RCCL will not
+    # put two ranks on one GPU -- so that the N > 1 code of this script runs on the one-GPU boxes too.  Timings of such
+    # a run mean nothing and the line says so.
+    dry = os.environ.get("PXSOM_BENCH_DRY_RANKS") == "1"
+    if dry:
+        local_rank = 0
     if local_rank >= torch.cuda.device_count():
         raise SystemExit(f"bench.py: rank {rank} has no device (LOCAL_RANK={local_rank}, {torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
@@ -201,7 +207,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if dry:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg = CONFIGS[args.config]
     C, XD, YD = cfg["c"], cfg["xdim"], cfg["ydim"]
@@ -285,7 +294,7 @@ def main():
         kern_ms, kern_launches = timer.collect()
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if use_dist:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        all_reduce_(elapsed, op=dist.ReduceOp.MAX)
     elapsed_s = float(elapsed.item())
     train_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_train]))
     k8_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_k8]))
@@ -296,7 +305,7 @@ def main():
     # every rank's own phase times (N > 1: the first multi-GPU line must be readable rank by rank)
     per_rank = None
     if use_dist:
-        mine = torch.tensor([train_ms, k8_ms], dtype=torch.float64, device=dev)
+        mine = torch.tensor([train_ms, k8_ms], dtype=torch.float64, device="cpu" if dry else dev)
         gathered = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
         per_rank = {"train_batch": [round(float(g[0]), 4) for g in gathered],
@@ -334,7 +343,8 @@ def main():
                    "train_fraction": cfg["frac"],
                    "num_passes": 1, "step": "train + assign + per-cluster mean table",
                    "parallelism": f"{'row' if cfg['kind'] == 'cell' else 'fov'}-shard x{world}",
-                   "rccl_ranks": world if use_dist else 0,
+                   "rccl_ranks": (0 if dry else world) if use_dist else 0,
+                   **({"dry_run": "all ranks on one GPU over gloo: exercises the N > 1 code, timings are meaningless"} if dry else {}),
                    "exchange": ("in-library RCCL all-reduce behind every step" if comm_ranks else "torch.distributed all-reduce per step")
                    if use_dist else "none (one rank)"},
         "phases_ms": {"train_batch": round(train_ms, 4),

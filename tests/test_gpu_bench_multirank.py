@@ -1,0 +1,49 @@
+"""bench.py's N > 1 code on a one-GPU box: two ranks launched exactly as the driver launches them
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 ... bench.py --gpus 2 ...`), both on device 0 over a gloo
+group (PXSOM_BENCH_DRY_RANKS=1: RCCL will not put two ranks on one GPU).  What it proves: the script's distributed code
+runs -- rank-sharded rows, the agreed kernel route, the per-step exchange (through torch.distributed, and through the
+library's own communicator over tests/mock_rccl), the table all-reduce, MAX-over-ranks timing, per-rank phases -- and
+prints one well-formed line.  What it cannot prove: anything about speed.  `-m gpu` only."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from tests.test_gpu_exchange import _mock_library
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("exchange", ["torch.distributed", "in-library"])
+@pytest.mark.parametrize("config", ["cfg2", "cfg4"])
+def test_two_rank_bench_line(gpu, tmp_path, exchange, config):
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", PXSOM_BENCH_DRY_RANKS="1")
+    if exchange == "in-library":
+        env.update(PXSOM_NATIVE_EXCHANGE="force", PXSOM_RCCL_LIBRARY=_mock_library(tmp_path))
+    else:
+        env.update(PXSOM_NATIVE_EXCHANGE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--config", config, "--fovs-per-gpu", "1", "--no-pmc", "--no-cpu-baseline", "--no-online", "--no-operating-range"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert res.returncode == 0 and len(lines) == 1, res.stdout[-2000:] + res.stderr[-4000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["value"] > 0
+    assert line["config"]["name"] == config and "dry_run" in line["config"]
+    assert line["config"]["exchange"].startswith("in-library" if exchange == "in-library" else "torch.distributed")
+    per_rank = line["phases_ms"]["per_rank"]
+    assert len(per_rank["train_batch"]) == 2 and all(v > 0 for v in per_rank["train_batch"])
+    assert line["scaling"] == ("weak" if config == "cfg2" else "strong")
