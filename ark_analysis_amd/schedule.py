@@ -7,11 +7,12 @@ The rows of a pass are dealt into ``phases`` phases (row i: phase ``i % phases``
 before it end.  A step costs the GPU one latency-bound launch whatever its size, so a pass is priced in steps:
 
 * ``BatchSchedule.equal(G)``: G equal steps (rows ``i % G == g``) -- the rule of rounds 1 and 2;
-* ``BatchSchedule.two_phase()`` (the default of ``train_mode="batch"``): 8 shrinking steps over the 5/6 of a pass in
-  which the neighbourhood radius is >= 1, then 24 equal steps over the BMU-only tail.  On the bench workload its mean
-  quantisation error against the online rule's codebook is +0.4 % (six seeds) where 64 equal steps give +0.6 % and 32
-  equal steps +1.6 % (scripts/study/batch_schedule_scan2.py): the tail is a mini-batch k-means whose quality follows
-  the number of its iterations, the ordering phase needs few.
+* ``BatchSchedule.two_phase()`` (the default of ``train_mode="batch"``): 6 shrinking steps over the 5/6 of a pass in
+  which the neighbourhood radius is >= 1, then 20 equal steps over the BMU-only tail.  On the bench workload its mean
+  quantisation error against the online rule's codebook is +0.45 % (eight seeds, +- 0.08) where 64 equal steps give
+  +0.6 % and 32 equal steps +1.6 % (scripts/study/batch_schedule_scan{2,3}.py): the tail is a mini-batch k-means whose
+  quality follows the number of its iterations, the ordering phase needs few.  Between 5 - 8 head and 18 - 32 tail steps
+  the quality is flat within the seeds' scatter (+0.3 ... +0.6 %); 6 + 20 sits in the middle of that plateau.
 """
 from typing import Sequence, Tuple, Union
 
@@ -64,7 +65,7 @@ class BatchSchedule:
         return cls(steps, range(steps + 1))
 
     @classmethod
-    def two_phase(cls, head_steps: int = 8, tail_steps: int = 24, head_ratio: float = 0.25,
+    def two_phase(cls, head_steps: int = 6, tail_steps: int = 20, head_ratio: float = 0.25,
                   tail_phases_per_step: int = 8) -> "BatchSchedule":
         """``head_steps`` steps with geometrically shrinking sizes (last / first = ``head_ratio``) over the first 5/6 of
         the rows -- where the default radius schedule (r0 -> 0) keeps the neighbourhood radius >= 1 for a 10 x 10 map --,

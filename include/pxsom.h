@@ -201,7 +201,7 @@ int pxsom_batch_train_finish(const double *wbuf_dev, const double *stats_ring_de
  * (threshold, alpha) where the rows presented before it end: (pass * phases + edges[g]) / (num_passes * phases).
  * Equal steps (edges = 0..phases) are pxsom_batch_train_steps, bit for bit.  A step is one latency-bound launch
  * whatever its size, so a pass is priced in steps: few large steps while the neighbourhood is wide, many small ones
- * in the BMU-only tail reach the quality of 64 equal steps in half the launches (DESIGN.md "K6b").
+ * in the BMU-only tail reach the quality of 64 equal steps in under half the launches (DESIGN.md "K6b").
  * State (wbuf_dev, stats_ring_dev), routes, flags and comm as pxsom_batch_train_steps[_sharded]; steps are numbered
  * over the whole run, g in [0, num_passes * steps_per_pass); the call with g_begin == 0 must come first on a workspace
  * (it clears ring[0] and, for shapes outside the fused kernel with steps wider than one phase, gathers the rows into
