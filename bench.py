@@ -338,7 +338,7 @@ def main():
         "config": {"workload": cfg["desc"].format(u=units_label), "name": args.config,
                    "rows_per_gpu": n_all, "channels": C, "som_nodes": K,
                    "train_mode": "batch", "batch_steps": sched.steps,
-                   "batch_schedule": ("two-phase: %d steps over %d phases, widths %s" % (sched.steps, sched.phases, list(np.diff(sched.edges))))
+                   "batch_schedule": ("two-phase: %d steps over %d phases, widths %s" % (sched.steps, sched.phases, [int(v) for v in np.diff(sched.edges)]))
                    if str(args.batch_steps) == "two-phase" else "equal steps",
                    "train_fraction": cfg["frac"],
                    "num_passes": 1, "step": "train + assign + per-cluster mean table",
