@@ -28,7 +28,15 @@ struct AssignHdr {
     int idx_bits;
     int node_bits;        // bits of the node index packed into the winner at the cross-lane merge
     int force_exact;      // codebook not representable by the filter: list every row
+    // Centred filter (register-resident kernels, c <= 32; DESIGN.md "K7 centring").  The filter ranks the nodes by
+    // X'.W' - |W'|^2 / 2 with X' = x * scale - mu_s, W' = w * scale - mu_s: the same ranking as by distance whatever mu_s
+    // is, but every term of the error bound is relative to the norms of the centred vectors.  mu_s = 0: off.
+    float wn_raw;         // max_k |w_k|_2 (unscaled, uncentred, rounded up): the screened exact kernel's rounding bound
+    int fix_exp;          // every row the filter vouches for has |x_j| < 2^(16 - fix_exp) (fixed-point tables)
+    int centred;
+    float mu_s[32];       // centring vector in scaled units (a binary32 number times the power-of-two scale: exact)
 };
+static_assert(sizeof(AssignHdr) <= 256, "workspace header");
 
 // the pending update a fused mini-batch step applies at its head, and its housekeeping (pxsom_batch_step.hip)
 struct StepArgs {
@@ -48,6 +56,8 @@ struct StepArgs {
     // binary64 rows enter the statistics rounded to multiples of the run's quantum q (include/pxsom.h "Reproducible
     // statistics"): qmagic = 1.5 * 2^52 * q, (v + qmagic) - qmagic is that rounding; 0: off
     double qmagic = 0.0;
+    // centring vector of the one-launch step's filter: c binary32 values in HBM (AssignHdr::mu_s before scaling); NULL: zeros
+    const float *mu32 = nullptr;
 };
 
 // round-half-even to the quantum behind qmagic (exact while |v| < 2^51 q)

@@ -47,7 +47,8 @@ __global__ __launch_bounds__(NT) void bmu_prep_kernel(const double *__restrict__
                                                        AssignHdr *hdr, half8 *wfrag, f32x4 *bias,
                                                        int nb, int nch, int cpl, int idx_bits,
                                                        int node_bits, int stage, double *zero_ptr,
-                                                       int zero_count, double *wt_out, float *w32_out, int cp32, int npk)
+                                                       int zero_count, double *wt_out, float *w32_out, int cp32, int npk,
+                                                       int center)
 {
     PXSOM_PHASE_ANY(0);
     // fused batch accumulation: the statistics buffer is cleared here instead of by a memset node
@@ -71,8 +72,8 @@ __global__ __launch_bounds__(NT) void bmu_prep_kernel(const double *__restrict__
     PXSOM_PHASE_ANY(1);
     // two calls, not one with a selected pointer: each inlined copy then knows its address space (ds_read for
     // the staged codebook instead of flat loads)
-    if (stage) prep_body<NT>(sw, k, c, hdr, wfrag, bias, nb, nch, cpl, idx_bits, node_bits, wt_out, w32_out, cp32, npk);
-    else prep_body<NT>(w, k, c, hdr, wfrag, bias, nb, nch, cpl, idx_bits, node_bits, wt_out, w32_out, cp32, npk);
+    if (stage) prep_body<NT>(sw, k, c, hdr, wfrag, bias, nb, nch, cpl, idx_bits, node_bits, wt_out, w32_out, cp32, npk, center != 0);
+    else prep_body<NT>(w, k, c, hdr, wfrag, bias, nb, nch, cpl, idx_bits, node_bits, wt_out, w32_out, cp32, npk, center != 0);
 }
 
 
@@ -303,7 +304,7 @@ void bmu_exact_screened_kernel(const T *__restrict__ x, int c, int64_t ldx,
     const unsigned nbatches = (count + 63) / 64;
     const double u24 = 0x1p-24;
     const bool blind = hdr->force_exact != 0 || !(hdr->scale > 0.f);
-    const double wn = blind ? 0.0 : (double)hdr->wn_max / (double)hdr->scale;
+    const double wn = blind ? 0.0 : (double)hdr->wn_raw;   // (uncentred: the bound is on rounding x and w themselves)
     const double eta = (double)(c + 4) * u24;
     const unsigned long long kInitD = (unsigned long long)__double_as_longlong(DBL_MAX);
 
@@ -613,7 +614,9 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
                            reinterpret_cast<half8 *>(ws + L.off_wfrag), reinterpret_cast<f32x4 *>(ws + L.off_bias),
                            L.nb, L.nch, L.cpl, L.idx_bits, L.node_bits, stage, (double *)nullptr, 0,
                            L.has_wt() ? reinterpret_cast<double *>(ws + L.off_wt) : nullptr,
-                           reinterpret_cast<float *>(ws + L.off_w32), L.cp32, L.npk);
+                           reinterpret_cast<float *>(ws + L.off_w32), L.cp32, L.npk,
+                           // the register-resident filter centres rows and codebook (the only reader of AssignHdr::mu_s)
+                           filter_fast_path<T>(x, n, c, ldx, L) ? 1 : 0);
         PXSOM_LAUNCH_CHECK("bmu_prep_kernel");
     }
 
@@ -750,7 +753,7 @@ int pxsom_bmu::prepare_only(const double *w_dev, int c, int k, void *workspace_d
                        reinterpret_cast<f32x4 *>(ws + L.off_bias), L.nb, L.nch, L.cpl, L.idx_bits, L.node_bits, stage,
                        zero_stats, zero_stats ? k * (c + 1) : 0,
                        L.has_wt() ? reinterpret_cast<double *>(ws + L.off_wt) : nullptr,
-                           reinterpret_cast<float *>(ws + L.off_w32), L.cp32, 0);
+                           reinterpret_cast<float *>(ws + L.off_w32), L.cp32, 0, 0);
     PXSOM_LAUNCH_CHECK("bmu_prep_kernel");
     return PXSOM_OK;
 }

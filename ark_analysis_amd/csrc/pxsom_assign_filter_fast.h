@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
             }
         }
         __syncthreads();
-        prep_body<256, 128>(wrow, k, c, hdr_l, frag_l, bias_l, NB, 1, CPL, idx_bits, node_bits);
+        prep_body<256, 128>(wrow, k, c, hdr_l, frag_l, bias_l, NB, 1, CPL, idx_bits, node_bits, nullptr, nullptr, 0, 0, true);
         __syncthreads();
         for (int e = threadIdx.x; e < (k + 1) * (c + 1); e += 256) ls[e] = 0.0;   // (the first add comes after the loads' wait)
         __syncthreads();
@@ -286,11 +286,7 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
                 tol_abs = hdr->tol_abs, x_limit = hdr->x_limit;
     const bool force_exact = hdr->force_exact != 0;
     FixPoint fx = {};
-    if constexpr (FIX) {
-        int e = 0;
-        frexpf(scale, &e);                       // scale = 2^(e-1)
-        fx = make_fixpoint(e - 1, fix_rows_log2 & 255);
-    }
+    if constexpr (FIX) fx = make_fixpoint(hdr->fix_exp, fix_rows_log2 & 255);
     unsigned long long *lu = reinterpret_cast<unsigned long long *>(ls);
 
     const int lane = threadIdx.x & 63;
@@ -321,6 +317,15 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
         loff[p] = (unsigned)((pix * ldx + ch) * (int64_t)sizeof(T));
     }
     const int64_t tile_bytes = 16 * ldx * (int64_t)sizeof(T);
+    // centring vector of this lane's channels, scaled (zeros when the workspace was prepared without it)
+    float mus[NP][2];
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        int ch = q * CPL + 2 * p;
+        if (ch > c - 2) ch = c - 2;
+        mus[p][0] = hdr->mu_s[ch];
+        mus[p][1] = hdr->mu_s[ch + 1];
+    }
 
     typedef typename Pair<T>::type P2;
     typedef P2 RowSet[kTilesPerIter][NP];
@@ -376,11 +381,19 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
             for (int p = 0; p < 4; p++) {
                 half2_t h2 = {(_Float16)0, (_Float16)0}, l2 = {(_Float16)0, (_Float16)0};
                 if (p < NP) {
-                    const float x0 = (float)raw[t][p < NP ? p : 0].x, x1 = (float)raw[t][p < NP ? p : 0].y;
-                    h2[0] = (_Float16)(x0 * scale);
-                    h2[1] = (_Float16)(x1 * scale);
-                    l2[0] = (_Float16)fmaf(x0, scale, -(float)h2[0]);
-                    l2[1] = (_Float16)fmaf(x1, scale, -(float)h2[1]);
+                    // x' = fl(x * scale - mu_s): one rounding (binary64 rows: formed in binary64, then rounded once more)
+                    float xs0, xs1;
+                    if constexpr (sizeof(T) == 8) {
+                        xs0 = (float)__builtin_fma((double)raw[t][p < NP ? p : 0].x, (double)scale, -(double)mus[p < NP ? p : 0][0]);
+                        xs1 = (float)__builtin_fma((double)raw[t][p < NP ? p : 0].y, (double)scale, -(double)mus[p < NP ? p : 0][1]);
+                    } else {
+                        xs0 = fmaf((float)raw[t][p < NP ? p : 0].x, scale, -mus[p < NP ? p : 0][0]);
+                        xs1 = fmaf((float)raw[t][p < NP ? p : 0].y, scale, -mus[p < NP ? p : 0][1]);
+                    }
+                    h2[0] = (_Float16)xs0;
+                    h2[1] = (_Float16)xs1;
+                    l2[0] = (_Float16)(xs0 - (float)h2[0]);
+                    l2[1] = (_Float16)(xs1 - (float)h2[1]);
                     acc2 = __builtin_amdgcn_fdot2(h2, h2, acc2, false);
                 }
                 bh[t][2 * p] = h2[0];

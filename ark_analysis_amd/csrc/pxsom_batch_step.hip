@@ -187,7 +187,25 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
     const int node = tid >> 2, nq = tid & 3;
     const bool has_node = node < kK;
     double wv_[CPL];   // this thread's node values: old, then new
+    // the run's centring vector: at this thread's node channels (prep) and at this lane's row channels (search) -- 2 x CPL
+    // cached words requested with everything else, needed after the statistics
+    float mud32[CPL], muq[NP][2], mu_norm = 0.f;   // mu_norm: |mu|_2, word 32 of the vector
     const int NC = c + 1;
+    auto load_centring = [&]() {
+#pragma unroll
+        for (int i = 0; i < CPL; i++) {
+            const int ch = nq * CPL + i;
+            mud32[i] = sa.mu32 ? sa.mu32[ch < c ? ch : 0] : 0.f;
+        }
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            int ch = q * CPL + 2 * p;
+            if (ch > c - 2) ch = c - 2;
+            muq[p][0] = sa.mu32 ? sa.mu32[ch] : 0.f;
+            muq[p][1] = sa.mu32 ? sa.mu32[ch + 1] : 0.f;
+        }
+        mu_norm = sa.mu32 ? sa.mu32[32] : 0.f;
+    };
     // Order of the requests matters: vmcnt retires loads in issue order, so what is needed first is asked for
     // first -- the statistics (pass 1), then the old node values (P3), the step's rows (HBM, slowest) last.
     if (sa.has_update) {
@@ -203,6 +221,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
             const int ch = nq * CPL + i;
             wv_[i] = sa.w_in[(has_node && ch < c) ? (size_t)node * c + ch : 0];
         }
+        load_centring();
         if (blk < nblocks) load_rows(blk);
         PXSOM_PHASE(9);
         // (while those are in flight) clear the table and this workgroup's slice of the next buffer
@@ -267,6 +286,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
             const int ch = nq * CPL + i;
             wv_[i] = sa.w_in[(has_node && ch < c) ? (size_t)node * c + ch : 0];
         }
+        load_centring();
         if (blk < nblocks) load_rows(blk);
         PXSOM_PHASE(9);
         for (int e = tid; e < (kK * c + kK) * ncopies; e += kStepThreads) ls[e] = 0.0;
@@ -284,7 +304,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
     }
 
     // ---- P3: new node values in registers; norms, duplicate key, maxima -----------------------------------
-    double nrm = 0.0, mymax = 0.0;
+    double nrm = 0.0, mymax = 0.0;   // of the centred node
     unsigned long long kkey = 0;
     {
         bool bad = false;
@@ -316,8 +336,9 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
                     wt[(size_t)ch * kK + node] = v;
                     if (blockIdx.x == 0 && sa.w_out && (sa.has_update || sa.w_out != sa.w_in)) sa.w_out[(size_t)node * c + ch] = v;
                     bad |= !(fabs(v) <= DBL_MAX);
-                    nrm += v * v;
-                    mymax = fmax(mymax, fabs(v));
+                    const double vc = v - (double)mud32[i];
+                    nrm += vc * vc;
+                    mymax = fmax(mymax, fabs(vc));
                     // duplicate key: the bit pattern rotated by a channel-dependent amount, xor-ed up (no multiplies:
                     // integer multiplies run at quarter rate; a key match is verified channel by channel anyway)
                     const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
@@ -354,12 +375,19 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
             maxabs = fmax(maxabs, red[i]);
             wn2max = fmax(wn2max, red[kStepWaves + i]);
         }
-        // scale = 2^e with maxabs*scale in [128, 256) (pxsom_prep.h)
+        // scale = 2^e with maxabs*scale in [128, 256) (pxsom_prep.h) -- but a codebook that has (nearly) collapsed onto the
+        // centring vector must not blow the scale up (the rows lie where they did): at most 2^6 over what the norm of the
+        // centring vector itself would choose (no reduction of the step's own for it)
         int e = 0;
         if (maxabs > 0.0 && maxabs <= DBL_MAX) {
             int ex;
             frexp(maxabs, &ex);
             e = 8 - ex;
+            if (mu_norm > 0.f) {
+                int exn;
+                frexpf(mu_norm, &exn);
+                if (e > 8 - exn + 6) e = 8 - exn + 6;
+            }
             if (e > 100) e = 100;
             if (e < -100) e = -100;
         }
@@ -377,7 +405,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 float W = 0.f;
-                if (i < CPL && nq * CPL + i < c) W = (float)(wv_[i < CPL ? i : 0] * scale);
+                if (i < CPL && nq * CPL + i < c) W = (float)((wv_[i < CPL ? i : 0] - (double)mud32[i < CPL ? i : 0]) * scale);
                 const _Float16 hi = (_Float16)W;
                 fhi[i] = hi;
                 flo[i] = (_Float16)(W - (float)hi);
@@ -434,6 +462,12 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
     const float tol_rel = sa.tol_rel, tol_abs = sa.tol_abs, x_limit = 60000.0f;
     double *qrows = tl;   // the window-sum scratch is free now: [kQueueRows][c]
     constexpr unsigned idx_mask = 127u;
+    float mus[NP][2];   // the centring vector at this lane's channels, scaled (a binary32 value times a power of two: exact)
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        mus[p][0] = muq[p][0] * fscale;
+        mus[p][1] = muq[p][1] * fscale;
+    }
     for (; blk < nblocks; blk += gridDim.x) {
         half8 bh[TPW], bl[TPW];
         float ss[TPW];
@@ -444,11 +478,19 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
             for (int p = 0; p < 4; p++) {
                 half2_t h2 = {(_Float16)0, (_Float16)0}, l2 = {(_Float16)0, (_Float16)0};
                 if (p < NP) {
-                    const float x0 = (float)raw[t][p < NP ? p : 0].x, x1 = (float)raw[t][p < NP ? p : 0].y;
-                    h2[0] = (_Float16)(x0 * fscale);
-                    h2[1] = (_Float16)(x1 * fscale);
-                    l2[0] = (_Float16)fmaf(x0, fscale, -(float)h2[0]);
-                    l2[1] = (_Float16)fmaf(x1, fscale, -(float)h2[1]);
+                    // x' = fl(x * scale - mu_s): one rounding (binary64 rows: formed in binary64, then rounded once more)
+                    float xs0, xs1;
+                    if constexpr (sizeof(T) == 8) {
+                        xs0 = (float)__builtin_fma((double)raw[t][p < NP ? p : 0].x, (double)fscale, -(double)mus[p < NP ? p : 0][0]);
+                        xs1 = (float)__builtin_fma((double)raw[t][p < NP ? p : 0].y, (double)fscale, -(double)mus[p < NP ? p : 0][1]);
+                    } else {
+                        xs0 = fmaf((float)raw[t][p < NP ? p : 0].x, fscale, -mus[p < NP ? p : 0][0]);
+                        xs1 = fmaf((float)raw[t][p < NP ? p : 0].y, fscale, -mus[p < NP ? p : 0][1]);
+                    }
+                    h2[0] = (_Float16)xs0;
+                    h2[1] = (_Float16)xs1;
+                    l2[0] = (_Float16)(xs0 - (float)h2[0]);
+                    l2[1] = (_Float16)(xs1 - (float)h2[1]);
                     acc2 = __builtin_amdgcn_fdot2(h2, h2, acc2, false);
                 }
                 bh[t][2 * p] = h2[0];
@@ -824,7 +866,12 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
         hdr_g->cpl = cpl;
         hdr_g->idx_bits = idx_bits;
         hdr_g->node_bits = idx_bits;
+        // the generic filters are not centred: the uncentred norm is the norm
+        hdr_g->wn_raw = badw ? 0.f : (float)(sqrt(wn2max) * (1.0 + 1e-6));
+        hdr_g->fix_exp = e;
+        hdr_g->centred = 0;
     }
+    if (blockIdx.x == 0 && tid < 32) hdr_g->mu_s[tid] = 0.f;
     PXSOM_PHASE(7);
     // ---- exact duplicates of an earlier node: key scan shared by the node's lanes, then channel-by-channel
     if (has_node && node >= n0 && node < n1) {

@@ -47,7 +47,8 @@ __device__ long long g_phase_ticks[32];
 template <int NT, int MAXK = PXSOM_MAX_NODES>
 __device__ __forceinline__ void prep_body(const double *wl, int k, int c, AssignHdr *hdr, half8 *wfrag,
                                           f32x4 *bias, int nb, int nch, int cpl, int idx_bits, int node_bits,
-                                          double *wt_out = nullptr, float *w32_out = nullptr, int cp32 = 0, int npk = 0)
+                                          double *wt_out = nullptr, float *w32_out = nullptr, int cp32 = 0, int npk = 0,
+                                          bool center = false)
 {
     // binary32 copy, rows zero-padded to cp32 channels: what the long-list exact kernel screens with
     if (w32_out) {
@@ -83,38 +84,58 @@ __device__ __forceinline__ void prep_body(const double *wl, int k, int c, Assign
     }
     __shared__ double s_norm2[MAXK];
     __shared__ unsigned long long s_key[MAXK];  // hash of the row's bit patterns (duplicate test)
-    __shared__ double s_red[2 * (NT / 64)];
+    __shared__ double s_red[3 * (NT / 64)];
+    __shared__ double s_mud[32];   // centring vector (unscaled; binary32-representable values): zeros when off
     __shared__ int s_bad;
     const int tid = threadIdx.x;
     if (tid == 0) s_bad = 0;
+    if (tid < 32) s_mud[tid] = 0.0;
     __syncthreads();
+    // centring (register-resident filters only: c <= 32): mu = the nodes' mean per channel, rounded to binary32 -- any
+    // vector would do for the ranking, the mean keeps the centred norms (what the error bound is relative to) small.
+    // NT / 32 adjacent lanes share a channel.
+    if (center) {
+        constexpr int per = NT / 32;
+        const int j = tid / per, part = tid % per;
+        double sum = 0.0;
+        if (j < c)
+            for (int node = part; node < k; node += per) sum += wl[(size_t)node * c + j];
+#pragma unroll
+        for (int d = 1; d < per; d *= 2) sum += __shfl_xor(sum, d);
+        if (part == 0 && j < c) s_mud[j] = (double)(float)(sum / (double)k);
+        __syncthreads();
+    }
 
     // per-node squared norm (binary64), max |w| and max norm.  `parts` adjacent lanes share a node
     // (interleaved channels, butterfly sum: every node is summed in the same order, so bit-identical
     // rows get bit-identical norms -- the duplicate test below relies on it).
     const int parts = 4 * k <= NT ? 4 : (2 * k <= NT ? 2 : 1);
     const int pshift = parts == 4 ? 2 : (parts == 2 ? 1 : 0);
-    double mymax = 0.0, mynorm = 0.0;
+    double mymax = 0.0, mynorm = 0.0, myraw = 0.0;
     bool bad = false;
     for (int p = tid; p < (k << pshift); p += NT) {
         const int node = p >> pshift, part = p & (parts - 1);
-        double sum = 0.0;
+        double sum = 0.0, raw2 = 0.0;
         unsigned long long key = 0;
         for (int j = part; j < c; j += parts) {
-            const double v = wl[(size_t)node * c + j];
-            bad |= !(fabs(v) <= DBL_MAX);  // NaN / Inf in the codebook
+            const double vr = wl[(size_t)node * c + j];
+            const double v = vr - s_mud[j < 32 ? j : 0];   // (zeros when the filter is not centred: v == vr, bit for bit)
+            bad |= !(fabs(vr) <= DBL_MAX);  // NaN / Inf in the codebook
             sum += v * v;
+            raw2 += vr * vr;
             mymax = fmax(mymax, fabs(v));
-            const unsigned long long hb = (unsigned long long)__double_as_longlong(v) * 0x9E3779B97F4A7C15ull +
+            const unsigned long long hb = (unsigned long long)__double_as_longlong(vr) * 0x9E3779B97F4A7C15ull +
                                           (unsigned long long)(j + 1) * 0xC2B2AE3D27D4EB4Full;
             key ^= hb ^ (hb >> 29);
         }
         if (parts >= 2) {
             sum += __shfl_xor(sum, 1);
+            raw2 += __shfl_xor(raw2, 1);
             key ^= __shfl_xor(key, 1);
         }
         if (parts == 4) {
             sum += __shfl_xor(sum, 2);
+            raw2 += __shfl_xor(raw2, 2);
             key ^= __shfl_xor(key, 2);
         }
         if (part == 0) {
@@ -122,23 +143,27 @@ __device__ __forceinline__ void prep_body(const double *wl, int k, int c, Assign
             s_key[node] = key;
         }
         mynorm = fmax(mynorm, sum);
+        myraw = fmax(myraw, raw2);
     }
     if (bad) s_bad = 1;
-    // both maxima: DPP wave reduction (max(a, b) = -min(-a, -b)), then 4 partials through LDS
+    // the maxima: DPP wave reduction (max(a, b) = -min(-a, -b)), then 4 partials through LDS
     mymax = -pxsom::wave_min_f64(-mymax);
     mynorm = mynorm == mynorm ? -pxsom::wave_min_f64(-mynorm) : mynorm;
+    myraw = myraw == myraw ? -pxsom::wave_min_f64(-myraw) : myraw;
     constexpr int NW = NT / 64;
     if ((tid & 63) == 0) {
         s_red[tid >> 6] = mymax;
         s_red[NW + (tid >> 6)] = mynorm;
+        s_red[2 * NW + (tid >> 6)] = myraw;
     }
     __syncthreads();
     PXSOM_PHASE_ANY(2);
-    double maxabs = s_red[0], wn2max = s_red[NW];
+    double maxabs = s_red[0], wn2max = s_red[NW], raw2max = s_red[2 * NW];
 #pragma unroll
     for (int i = 1; i < NW; i++) {
         maxabs = fmax(maxabs, s_red[i]);
         wn2max = fmax(wn2max, s_red[NW + i]);
+        raw2max = fmax(raw2max, s_red[2 * NW + i]);
     }
     // scale = 2^e with maxabs*scale in [128, 256): fp16 keeps 11 significant bits there and the
     // low halves of the split stay normal down to |x| ~ 1e-4 * maxabs.
@@ -147,6 +172,14 @@ __device__ __forceinline__ void prep_body(const double *wl, int k, int c, Assign
         int ex;
         frexp(maxabs, &ex);  // maxabs = m * 2^ex, m in [0.5, 1)
         e = 8 - ex;
+        if (center && raw2max > 0.0 && raw2max <= DBL_MAX) {
+            // a codebook that has (nearly) collapsed onto its mean must not blow the scale up: rows lie as far from the
+            // mean as they did before, and x' * scale has to stay inside binary16 -- at most 2^6 over what the largest
+            // uncentred node norm alone would choose (rows up to ~3.6 |w|max from the mean stay in range)
+            int exn;
+            frexp(sqrt(raw2max), &exn);
+            if (e > 8 - exn + 6) e = 8 - exn + 6;
+        }
         if (e > 100) e = 100;
         if (e < -100) e = -100;
     }
@@ -163,8 +196,9 @@ __device__ __forceinline__ void prep_body(const double *wl, int k, int c, Assign
         //   index packing 2^-(23-idx_bits) (idx_bits low mantissa bits replaced), fp32 accumulation
         //   (3C+2)*2^-24, split residual 2^-19,
         //   f64->f32 input rounding 2^-23;  tol = 2 * 1.25 * E
+        //   centred filter: + 2^-24, the rounding of x' = fl(x * scale - mu_s) (one fused operation)
         const double coef = ldexp(1.0, -(23 - idx_bits)) +
-                            (3.0 * c + 2.0) * ldexp(1.0, -24) + ldexp(1.0, -19) + ldexp(1.0, -23);
+                            (3.0 * c + 2.0) * ldexp(1.0, -24) + ldexp(1.0, -19) + ldexp(1.0, -23) + (center ? ldexp(1.0, -24) : 0.0);
         hdr->tol_rel = (float)(2.5 * coef);
         hdr->tol_abs = (float)(2.5 * ldexp(1.0, -24) * sqrt((double)c));  // fp16 subnormal floor
         hdr->x_limit = 60000.0f;
@@ -173,7 +207,17 @@ __device__ __forceinline__ void prep_body(const double *wl, int k, int c, Assign
         hdr->cpl = cpl;
         hdr->idx_bits = idx_bits;
         hdr->node_bits = node_bits;
+        hdr->wn_raw = badw ? 0.f : (float)(sqrt(raw2max) * (1.0 + 1e-6));
+        hdr->centred = center ? 1 : 0;
+        // a row the filter vouches for has |x' * scale|_2 < x_limit, hence |x_j * scale| < x_limit + max_j |mu_s_j|:
+        // below 2^(16 + t) for the smallest such t >= 0
+        double mumax = 0.0;
+        for (int j = 0; j < (c < 32 ? c : 32); j++) mumax = fmax(mumax, fabs(s_mud[j]) * scale);
+        int t = 0;
+        while (t < 60 && !(60000.0 + mumax <= ldexp(65536.0, t))) t++;
+        hdr->fix_exp = e - t;
     }
+    if (tid < 32) hdr->mu_s[tid] = (float)(s_mud[tid] * scale);
 
     // A-fragments: wfrag[(b*nsteps + s)*64 + lane], lane = (q<<4 | m): node 16b+m,
     // slot i of lane group q in chunk h <-> channel h*4*cpl + q*cpl + i (i < cpl); s = 2h: hi, 2h+1: lo
@@ -206,7 +250,7 @@ __device__ __forceinline__ void prep_body(const double *wl, int k, int c, Assign
         for (int i = 0; i < 8; i++) {
             const int ch = h * 4 * cpl + q * cpl + i;
             float W = 0.f;
-            if (i < cpl && ch < c && node < k) W = (float)(wl[(size_t)node * c + ch] * scale);
+            if (i < cpl && ch < c && node < k) W = (float)((wl[(size_t)node * c + ch] - s_mud[ch < 32 ? ch : 0]) * scale);
             const _Float16 hi = (_Float16)W;
             fhi[i] = hi;
             flo[i] = (_Float16)(W - (float)hi);

@@ -1712,8 +1712,34 @@ int launch_gather(const T *x, int64_t n, int c, int64_t ldx, T *out, const Sched
     return PXSOM_OK;
 }
 
+// The run's centring vector for the one-launch step's filter (AssignHdr::mu_s, DESIGN.md "K7 centring"): the mean of the
+// codebook the run starts from, per channel, in binary32.  Any vector keeps the search exact; this one stays close to the
+// nodes' mean for the whole run (they follow the data), so the steps need no reduction of their own for it.
+__global__ __launch_bounds__(256) void centring_vector_kernel(const double *__restrict__ w, int k, int c, float *__restrict__ mu32)
+{
+    const int j = threadIdx.x >> 3, part = threadIdx.x & 7;   // 8 adjacent lanes share a channel (c <= 32)
+    double sum = 0.0;
+    if (j < c)
+        for (int node = part; node < k; node += 8) sum += w[(size_t)node * c + j];
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    sum += __shfl_xor(sum, 4);
+    float m = (float)(sum / (double)k);
+    if (!(j < c && fabsf(m) <= 3.0e38f)) m = 0.f;   // a non-finite codebook: not centred (every row is listed anyway)
+    if (part == 0) mu32[j] = m;
+    // word 32: the vector's norm (the steps cap their power-of-two scale with it: pxsom_batch_step.hip)
+    __shared__ float s_m[32];
+    if (part == 0) s_m[j] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double n2 = 0.0;
+        for (int i = 0; i < 32; i++) n2 += (double)s_m[i] * (double)s_m[i];
+        mu32[32] = (float)sqrt(n2);
+    }
+}
+
 struct TrainWs {
-    size_t assign_ws, off_labels, off_gather, total;
+    size_t assign_ws, off_labels, off_mu, off_gather, total;
 };
 inline TrainWs train_ws(int64_t n, int c, int k, size_t esize, const Sched &sc)
 {
@@ -1721,7 +1747,8 @@ inline TrainWs train_ws(int64_t n, int c, int k, size_t esize, const Sched &sc)
     const int64_t rmax = sc.rows_max(n);
     w.assign_ws = pxsom_assign_workspace_bytes(rmax, c, k);
     w.off_labels = pxsom::align_up(w.assign_ws, 256);
-    w.off_gather = w.off_labels + pxsom::align_up((size_t)(rmax > 0 ? rmax : 1) * sizeof(int32_t), 256);
+    w.off_mu = w.off_labels + pxsom::align_up((size_t)(rmax > 0 ? rmax : 1) * sizeof(int32_t), 256);   // 33 floats: the run's centring vector and its norm
+    w.off_gather = w.off_mu + 256;
     w.total = w.off_gather + (sc.any_wide() ? pxsom::align_up((size_t)(n > 0 ? n : 1) * c * esize, 256) : 0);
     return w;
 }
@@ -1755,6 +1782,11 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
     // kernel needs rows >= 1, which a rank with a short shard may not have, so empty steps are allowed there)
     const bool fused_shape = !(flags & PXSOM_TRAIN_UNFUSED) &&
                              pxsom_bmu::step_fused_shape<T>(x, 1, c, ldx, xdim, ydim, (int64_t)sc.phases * ldx);
+    float *mu32 = reinterpret_cast<float *>(ws + tw.off_mu);
+    if (fused_shape && g_begin == 0) {
+        hipLaunchKernelGGL(centring_vector_kernel, dim3(1), dim3(256), 0, st, wbuf, k, c, mu32);
+        PXSOM_LAUNCH_CHECK("centring_vector_kernel");
+    }
     const bool gathered = !fused_shape && sc.any_wide();
     if (gathered && g_begin == 0 && n > 0) {
         int rc = launch_gather<T>(x, n, c, ldx, xg, sc, st);
@@ -1785,9 +1817,12 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
             sa.lg = log1p(-alpha);
             // coefficients of the filter's rigorous |score - exact| bound (DESIGN.md "K7 error bound"; 7 index bits
             // packed into the scores): tol = 2 * 1.25 * E
+            // (+ 2^-24: the rounding of the centred row, x' = fl(x * scale - mu_s))
             sa.tol_rel = (float)(2.5 * (ldexp(1.0, -(23 - 7)) + (3.0 * c + 2.0) * ldexp(1.0, -24) + ldexp(1.0, -19) +
-                                        ldexp(1.0, -23)));
+                                        ldexp(1.0, -23) + ldexp(1.0, -24)));
             sa.tol_abs = (float)(2.5 * ldexp(1.0, -24) * sqrt((double)c));
+            static const bool no_centre = getenv("PXSOM_STEP_NO_CENTRE") != nullptr;   // timing hook
+            sa.mu32 = no_centre ? nullptr : mu32;
             sa.group_w = wd > 1 ? wd : 1;
             sa.group_stride = (int64_t)sc.phases * ldx;
             sa.qmagic = qmagic;
