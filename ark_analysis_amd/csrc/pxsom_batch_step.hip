@@ -48,7 +48,7 @@ struct StepHdr {
 
 // LDS carve-up (bytes from the start of the dynamic segment)
 struct StepLds {
-    size_t ls, wt, tl, key, red, ovf, frag, bias, hdr, total;
+    size_t ls, wt, tl, key, red, ovf, frag, bias, hdr, mu, total;
 };
 __host__ __device__ inline StepLds step_lds(int c)
 {
@@ -63,6 +63,7 @@ __host__ __device__ inline StepLds step_lds(int c)
     L.frag = o;  o += (size_t)kNB * 2 * 64 * 16;          // [NB][hi, lo][64] half8
     L.bias = o;  o += (size_t)kNB * 64 * 16;              // [NB][64] f32x4
     L.hdr = o;   o += 64;
+    L.mu = o;    o += 40 * 4;                             // the run's centring vector (32 words) and its norm (word 32)
     L.total = o;
     return L;
 }
@@ -135,6 +136,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
     half8 *frag_l = reinterpret_cast<half8 *>(step_smem + L.frag);
     f32x4 *bias_l = reinterpret_cast<f32x4 *>(step_smem + L.bias);
     StepHdr *hdr = reinterpret_cast<StepHdr *>(step_smem + L.hdr);
+    float *mu_l = reinterpret_cast<float *>(step_smem + L.mu);
 
     constexpr int NP = CPL / 2;
     typedef typename Pair<T>::type P2;
@@ -187,24 +189,15 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
     const int node = tid >> 2, nq = tid & 3;
     const bool has_node = node < kK;
     double wv_[CPL];   // this thread's node values: old, then new
-    // the run's centring vector: at this thread's node channels (prep) and at this lane's row channels (search) -- 2 x CPL
-    // cached words requested with everything else, needed after the statistics
-    float mud32[CPL], muq[NP][2], mu_norm = 0.f;   // mu_norm: |mu|_2, word 32 of the vector
+    // the run's centring vector (33 words of HBM): one word per thread of the first wave, requested with everything else,
+    // parked in LDS before the first barrier; prep and search read it from there
+    float mu_word = 0.f;
     const int NC = c + 1;
     auto load_centring = [&]() {
-#pragma unroll
-        for (int i = 0; i < CPL; i++) {
-            const int ch = nq * CPL + i;
-            mud32[i] = sa.mu32 ? sa.mu32[ch < c ? ch : 0] : 0.f;
-        }
-#pragma unroll
-        for (int p = 0; p < NP; p++) {
-            int ch = q * CPL + 2 * p;
-            if (ch > c - 2) ch = c - 2;
-            muq[p][0] = sa.mu32 ? sa.mu32[ch] : 0.f;
-            muq[p][1] = sa.mu32 ? sa.mu32[ch + 1] : 0.f;
-        }
-        mu_norm = sa.mu32 ? sa.mu32[32] : 0.f;
+        if (tid < 33 && sa.mu32) mu_word = sa.mu32[tid];
+    };
+    auto park_centring = [&]() {
+        if (tid < 40) mu_l[tid] = mu_word;
     };
     // Order of the requests matters: vmcnt retires loads in issue order, so what is needed first is asked for
     // first -- the statistics (pass 1), then the old node values (P3), the step's rows (HBM, slowest) last.
@@ -236,6 +229,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
             const int z1 = min(((int)blockIdx.x + 1) * per, sa.zero_count);
             for (int e = (int)blockIdx.x * per + tid; e < z1; e += kStepThreads) sa.stats_zero[e] = 0.0;
         }
+        park_centring();
         const double thr = sa.thr;
         const int r = thr < 0.0 ? -1 : (thr > 1.0e6 ? 1000000 : (int)floor(thr));
         double md[kXD > kYD ? kXD : kYD];
@@ -300,11 +294,16 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
             const int z1 = min(((int)blockIdx.x + 1) * per, sa.zero_count);
             for (int e = (int)blockIdx.x * per + tid; e < z1; e += kStepThreads) sa.stats_zero[e] = 0.0;
         }
+        park_centring();
         __syncthreads();
     }
 
     // ---- P3: new node values in registers; norms, duplicate key, maxima -----------------------------------
     double nrm = 0.0, mymax = 0.0;   // of the centred node
+    float mud32[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; i++) mud32[i] = mu_l[nq * CPL + i < 32 ? nq * CPL + i : 0];
+    const float mu_norm = mu_l[32];
     unsigned long long kkey = 0;
     {
         bool bad = false;
@@ -465,8 +464,10 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
     float mus[NP][2];   // the centring vector at this lane's channels, scaled (a binary32 value times a power of two: exact)
 #pragma unroll
     for (int p = 0; p < NP; p++) {
-        mus[p][0] = muq[p][0] * fscale;
-        mus[p][1] = muq[p][1] * fscale;
+        int ch = q * CPL + 2 * p;
+        if (ch > c - 2) ch = c - 2;
+        mus[p][0] = mu_l[ch] * fscale;
+        mus[p][1] = mu_l[ch + 1] * fscale;
     }
     for (; blk < nblocks; blk += gridDim.x) {
         half8 bh[TPW], bl[TPW];
