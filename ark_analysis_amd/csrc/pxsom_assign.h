@@ -35,6 +35,7 @@ struct AssignHdr {
     int fix_exp;          // every row the filter vouches for has |x_j| < 2^(16 - fix_exp) (fixed-point tables)
     int centred;
     float mu_s[32];       // centring vector in scaled units (a binary32 number times the power-of-two scale: exact)
+    float tol_rel_coarse; // tol_rel of the register-resident filter's first stage (Wh*Xh alone)
 };
 static_assert(sizeof(AssignHdr) <= 256, "workspace header");
 

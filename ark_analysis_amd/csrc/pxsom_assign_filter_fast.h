@@ -208,6 +208,9 @@ typedef unsigned uint2v __attribute__((ext_vector_type(2)));
 #ifndef SGB_VALU
 #define SGB_VALU 0
 #endif
+#ifndef PXSOM_FINE_BLOCKS
+#define PXSOM_FINE_BLOCKS 2
+#endif
 // ACC (batch-rule accumulation fused in, pxsom_batch_accumulate): every row the filter is sure of adds
 // itself to a per-workgroup binary64 table [K*c sums | K counts] in LDS (ds_add_f64), flushed once with
 // global atomics into `stats`.  Rows it is NOT sure of are settled on the spot by the wave that met them,
@@ -216,7 +219,7 @@ typedef unsigned uint2v __attribute__((ext_vector_type(2)));
 // mini-batch step needs no exact-kernel launch.  One pass over x, one launch.
 // FIX (with ACC; pxsom_assign_sums): the workgroup's table is 64-bit fixed point (FixPoint above), fix_rows_log2 =
 // ceil(log2(rows a workgroup can meet)).
-template <typename T, int CPL, int NB, int RU, int MODE, bool ACC, bool FIX = false>
+template <typename T, int CPL, int NB, int RU, int MODE, bool ACC, bool FIX = false, bool TWO = true>
 __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
     const T *__restrict__ x, int64_t n, int c, int64_t ldx, const half8 *__restrict__ wfrag,
     const f32x4 *__restrict__ bias, AssignHdr *hdr, unsigned *__restrict__ amb_list,
@@ -283,7 +286,10 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
     constexpr unsigned node_mask = 127u;
     static_assert(NB <= 8, "7-bit packed node index");
     const float scale = hdr->scale, wn_max = hdr->wn_max, tol_rel = hdr->tol_rel,
-                tol_abs = hdr->tol_abs, x_limit = hdr->x_limit;
+                tol_abs = hdr->tol_abs, x_limit = hdr->x_limit, tol_rel_coarse = hdr->tol_rel_coarse;
+    // two-stage search (TWO): tiles searched in full / tiles seen so far by this wave, and its verdict on the codebook
+    unsigned fine_tiles = 0, seen_tiles = 0;
+    bool direct = false;
     const bool force_exact = hdr->force_exact != 0;
     FixPoint fx = {};
     if constexpr (FIX) fx = make_fixpoint(hdr->fix_exp, fix_rows_log2 & 255);
@@ -298,12 +304,16 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     const int64_t ngroups = (n + 63) / 64;
 
-    half8 wreg[NB][2];
+    // the low fragments serve stage 2 only (a tile in nine on a trained codebook): the accumulating variant, which is
+    // short of registers, leaves them in its LDS copy
+    constexpr bool kLowInRegs = !ACC;
+    half8 wreg[NB][kLowInRegs ? 2 : 1];
+    const half8 *wlow = wfrag;   // (ACC: wfrag points at the workgroup's LDS copy by now)
     f32x4 breg[NB];
 #pragma unroll
     for (int b = 0; b < NB; b++) {
         wreg[b][0] = wfrag[(b * 2 + 0) * 64 + lane];
-        wreg[b][1] = wfrag[(b * 2 + 1) * 64 + lane];
+        if constexpr (kLowInRegs) wreg[b][1] = wfrag[(b * 2 + 1) * 64 + lane];
         breg[b] = bias[b * 64 + lane];
     }
 
@@ -372,37 +382,53 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
     // dead once converted)
     auto trip = [&](RowSet &raw, RowSet &nxt) {
         RowSet &keep = raw;
-        half8 bh[kTilesPerIter], bl[kTilesPerIter];
+        half8 bh[kTilesPerIter];
         float ss[kTilesPerIter];
+        // x' = fl(x * scale - mu_s): one rounding (binary64 rows: formed in binary64, then rounded once more)
+        auto centred = [&](int t, int p, float &xs0, float &xs1) {
+            if constexpr (sizeof(T) == 8) {
+                xs0 = (float)__builtin_fma((double)raw[t][p].x, (double)scale, -(double)mus[p][0]);
+                xs1 = (float)__builtin_fma((double)raw[t][p].y, (double)scale, -(double)mus[p][1]);
+            } else {
+                xs0 = fmaf((float)raw[t][p].x, scale, -mus[p][0]);
+                xs1 = fmaf((float)raw[t][p].y, scale, -mus[p][1]);
+            }
+        };
 #pragma unroll
         for (int t = 0; t < kTilesPerIter; t++) {
             float acc2 = 0.f;
 #pragma unroll
             for (int p = 0; p < 4; p++) {
-                half2_t h2 = {(_Float16)0, (_Float16)0}, l2 = {(_Float16)0, (_Float16)0};
+                half2_t h2 = {(_Float16)0, (_Float16)0};
                 if (p < NP) {
-                    // x' = fl(x * scale - mu_s): one rounding (binary64 rows: formed in binary64, then rounded once more)
                     float xs0, xs1;
-                    if constexpr (sizeof(T) == 8) {
-                        xs0 = (float)__builtin_fma((double)raw[t][p < NP ? p : 0].x, (double)scale, -(double)mus[p < NP ? p : 0][0]);
-                        xs1 = (float)__builtin_fma((double)raw[t][p < NP ? p : 0].y, (double)scale, -(double)mus[p < NP ? p : 0][1]);
-                    } else {
-                        xs0 = fmaf((float)raw[t][p < NP ? p : 0].x, scale, -mus[p < NP ? p : 0][0]);
-                        xs1 = fmaf((float)raw[t][p < NP ? p : 0].y, scale, -mus[p < NP ? p : 0][1]);
-                    }
+                    centred(t, p < NP ? p : 0, xs0, xs1);
                     h2[0] = (_Float16)xs0;
                     h2[1] = (_Float16)xs1;
-                    l2[0] = (_Float16)(xs0 - (float)h2[0]);
-                    l2[1] = (_Float16)(xs1 - (float)h2[1]);
                     acc2 = __builtin_amdgcn_fdot2(h2, h2, acc2, false);
                 }
                 bh[t][2 * p] = h2[0];
                 bh[t][2 * p + 1] = h2[1];
-                bl[t][2 * p] = l2[0];
-                bl[t][2 * p + 1] = l2[1];
             }
             ss[t] = acc2;
         }
+        // the low halves of a tile's split, on demand (the rows stay in `raw` for the whole trip: the next group's go to `nxt`)
+        auto low_halves = [&](int t) {
+            half8 bl;
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                half2_t l2 = {(_Float16)0, (_Float16)0};
+                if (p < NP) {
+                    float xs0, xs1;
+                    centred(t, p < NP ? p : 0, xs0, xs1);
+                    l2[0] = (_Float16)(xs0 - (float)bh[t][2 * p]);
+                    l2[1] = (_Float16)(xs1 - (float)bh[t][2 * p + 1]);
+                }
+                bl[2 * p] = l2[0];
+                bl[2 * p + 1] = l2[1];
+            }
+            return bl;
+        };
         {
             int64_t gnext = g + nwaves;
             if (gnext > ngroups - 1) gnext = ngroups - 1;  // harmless re-read on the last trip
@@ -417,54 +443,49 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
             for (int t = 0; t < kTilesPerIter; t++) acc += ss[t];
             my_m1 = __uint_as_float(__float_as_uint(acc) & node_mask);
         } else {
-            float tm1[kTilesPerIter], tm2[kTilesPerIter];
-#pragma unroll
-            for (int t0 = 0; t0 < kTilesPerIter; t0 += 2) {
-                float m1[2] = {kNegBig, kNegBig}, m2[2] = {kNegBig, kNegBig};
-#pragma unroll
-                for (int b = 0; b < NB; b++) {
-                    f32x4 acc[2];
-                    // Wh*Xh + Wh*Xl + Wl*Xh, the two tiles' chains interleaved
-#pragma unroll
-                    for (int u = 0; u < 2; u++)
-                        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b][0], bh[t0 + u], breg[b], 0, 0, 0);
-#pragma unroll
-                    for (int u = 0; u < 2; u++)
-                        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b][0], bl[t0 + u], acc[u], 0, 0, 0);
-#pragma unroll
-                    for (int u = 0; u < 2; u++)
-                        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b][1], bh[t0 + u], acc[u], 0, 0, 0);
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        if (b < NB - 1 || RU == 4) {
-                            top2_quad(m1[u], m2[u], pack_idx(acc[u][0], (unsigned)(b * 4 + 0), idx_mask),
-                                      pack_idx(acc[u][1], (unsigned)(b * 4 + 1), idx_mask),
-                                      pack_idx(acc[u][2], (unsigned)(b * 4 + 2), idx_mask),
-                                      pack_idx(acc[u][3], (unsigned)(b * 4 + 3), idx_mask));
-                        } else {
-                            // last block: only registers 0..RU-1 hold real nodes
-                            const float p0 = pack_idx(acc[u][0], (unsigned)(b * 4 + 0), idx_mask);
-                            if (RU == 1) {
-                                m2[u] = __builtin_amdgcn_fmed3f(m1[u], m2[u], p0);
-                                m1[u] = fmaxf(m1[u], p0);
-                            } else {
-                                const float p1 = pack_idx(acc[u][1], (unsigned)(b * 4 + 1), idx_mask);
-                                top2_pair(m1[u], m2[u], p0, p1);
-                                if (RU == 3) {
-                                    const float p2 = pack_idx(acc[u][2], (unsigned)(b * 4 + 2), idx_mask);
-                                    m2[u] = __builtin_amdgcn_fmed3f(m1[u], m2[u], p2);
-                                    m1[u] = fmaxf(m1[u], p2);
-                                }
-                            }
+            // block b's scores of one tile into that tile's running top-2 (last block: only registers 0..RU-1 hold real nodes)
+            auto absorb = [&](float &m1, float &m2, const f32x4 &acc, int b) {
+                if (b < NB - 1 || RU == 4) {
+                    top2_quad(m1, m2, pack_idx(acc[0], (unsigned)(b * 4 + 0), idx_mask), pack_idx(acc[1], (unsigned)(b * 4 + 1), idx_mask),
+                              pack_idx(acc[2], (unsigned)(b * 4 + 2), idx_mask), pack_idx(acc[3], (unsigned)(b * 4 + 3), idx_mask));
+                } else {
+                    const float p0 = pack_idx(acc[0], (unsigned)(b * 4 + 0), idx_mask);
+                    if (RU == 1) {
+                        m2 = __builtin_amdgcn_fmed3f(m1, m2, p0);
+                        m1 = fmaxf(m1, p0);
+                    } else {
+                        const float p1 = pack_idx(acc[1], (unsigned)(b * 4 + 1), idx_mask);
+                        top2_pair(m1, m2, p0, p1);
+                        if (RU == 3) {
+                            const float p2 = pack_idx(acc[2], (unsigned)(b * 4 + 2), idx_mask);
+                            m2 = __builtin_amdgcn_fmed3f(m1, m2, p2);
+                            m1 = fmaxf(m1, p2);
                         }
                     }
                 }
+            };
+            float tm1[kTilesPerIter], tm2[kTilesPerIter];
+            // Stage 1: Wh*Xh alone, all four tiles' chains side by side -- a third of the MFMAs.  Its bound is the full one
+            // with the two dropped cross terms charged to it (2^-10 |X'||W'|: AssignHdr::tol_rel_coarse); a row whose top-2
+            // gap clears THAT tolerance is as sure as any.  The others' tiles are searched again below.  (A wave that has
+            // given up on stage 1 -- `direct` -- leaves every row unsure here.)
+            float m1[kTilesPerIter], m2[kTilesPerIter];
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    // (b*4 + r) -> id (q << 5 | b*4 + r): one OR
-                    tm1[t0 + u] = __uint_as_float(__float_as_uint(m1[u]) | ((unsigned)q << 5));
-                    tm2[t0 + u] = m2[u];
+            for (int t = 0; t < kTilesPerIter; t++) m1[t] = m2[t] = kNegBig;
+            if (!direct) {
+#pragma unroll
+                for (int b = 0; b < NB; b++) {
+                    f32x4 acc[kTilesPerIter];
+#pragma unroll
+                    for (int t = 0; t < kTilesPerIter; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b][0], bh[t], breg[b], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < kTilesPerIter; t++) absorb(m1[t], m2[t], acc[t], b);
                 }
+            }
+#pragma unroll
+            for (int t = 0; t < kTilesPerIter; t++) {
+                tm1[t] = __uint_as_float(__float_as_uint(m1[t]) | ((unsigned)q << 5));   // (b*4 + r) -> id (q << 5 | b*4 + r)
+                tm2[t] = m2[t];
             }
             // Transposing merge of the 4 lane groups (rows of 16 lanes) that share a pixel.
             //   v_permlane16_swap(A, B): odd rows of A <-> even rows of B.  With A = tile 2i's value and
@@ -494,19 +515,77 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
             merge(tm1[0], tm1[1], tm2[0], tm2[1], ss[0], ss[1], false, p1, p2, ps);
             merge(tm1[2], tm1[3], tm2[2], tm2[3], ss[2], ss[3], false, q1, q2, qs);
             merge(p1, q1, p2, q2, ps, qs, true, a1, a2, s2);
+            // |Xh| <= |X| (1 + 2^-11): folded into the 1.001 factor with the sqrt's ulp
+            const float xn = __builtin_amdgcn_sqrtf(s2) * 1.001f;
+            unsigned sbits = __float_as_uint(s2);
+            asm("" : "+v"(sbits));  // opaque copy: keeps the exponent test under finite-math
+            const unsigned unfit = (unsigned)!(xn < x_limit) | (unsigned)((sbits & 0x7f800000u) == 0x7f800000u) | (unsigned)force_exact;
+            auto unsure = [&](float b1, float b2, float trel) {
+                const float tol = trel * (xn * wn_max + 0.5f * wn_max * wn_max) + tol_abs * (xn + wn_max);
+                return ((unsigned)!((b1 - b2) > tol) | unfit) != 0u;
+            };
+            my_amb = direct || unsure(a1, a2, tol_rel_coarse);
+            my_m1 = a1;
             {
-                // |Xh| <= |X| (1 + 2^-11): folded into the 1.001 factor with the sqrt's ulp
-                const float xn = __builtin_amdgcn_sqrtf(s2) * 1.001f;
-                const float tol = tol_rel * (xn * wn_max + 0.5f * wn_max * wn_max) + tol_abs * (xn + wn_max);
-                unsigned sbits = __float_as_uint(s2);
-                asm("" : "+v"(sbits));  // opaque copy: keeps the exponent test under finite-math
-                const unsigned nonfinite = (unsigned)((sbits & 0x7f800000u) == 0x7f800000u);
-                const unsigned amb = (unsigned)!((a1 - a2) > tol) | (unsigned)!(xn < x_limit) | nonfinite |
-                                     (unsigned)force_exact;
-                my_amb = amb != 0u;
-                my_m1 = a1;
+                // Stage 2: the full three-term search for the tiles that hold a row stage 1 could not vouch for (lane row t
+                // owns tile t's rows: 16 ballot bits per tile).  One tile at a time, two node blocks' chains side by side;
+                // the four lane groups of a pixel are merged in place and lane row t takes the result.
+                const unsigned long long um = __ballot(my_amb);
+                if (um) {
+                    unsigned redone = 0;
+#pragma unroll
+                    for (int t = 0; t < kTilesPerIter; t++) {
+                        if ((um >> (16 * t)) & 0xffffull) {
+                            redone++;
+                            const half8 bl = low_halves(t);
+                            float m1 = kNegBig, m2 = kNegBig;
+#pragma unroll
+                            for (int b = 0; b < NB; b += PXSOM_FINE_BLOCKS) {
+                                constexpr int kPair = PXSOM_FINE_BLOCKS;   // node blocks whose chains run side by side
+                                f32x4 acc[kPair];
+#pragma unroll
+                                for (int u = 0; u < kPair; u++)
+                                    if (b + u < NB) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b + u < NB ? b + u : b][0], bh[t], breg[b + u < NB ? b + u : b], 0, 0, 0);
+#pragma unroll
+                                for (int u = 0; u < kPair; u++)
+                                    if (b + u < NB) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b + u < NB ? b + u : b][0], bl, acc[u], 0, 0, 0);
+#pragma unroll
+                                for (int u = 0; u < kPair; u++)
+                                    if (b + u < NB) {
+                                        half8 wl;
+                                        if constexpr (kLowInRegs) wl = wreg[b + u < NB ? b + u : b][1];
+                                        else wl = wlow[((b + u) * 2 + 1) * 64 + lane];
+                                        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh[t], acc[u], 0, 0, 0);
+                                    }
+#pragma unroll
+                                for (int u = 0; u < kPair; u++)
+                                    if (b + u < NB) absorb(m1, m2, acc[u], b + u);
+                            }
+                            float f1 = __uint_as_float(__float_as_uint(m1) | ((unsigned)q << 5)), f2 = m2;
+                            {
+                                const F2 e1 = xchg16(f1), e2 = xchg16(f2);
+                                f1 = fmaxf(e1.a, e1.b);
+                                f2 = fmaxf(fmaxf(fminf(e1.a, e1.b), e2.a), e2.b);
+                            }
+                            {
+                                const F2 e1 = xchg32(f1), e2 = xchg32(f2);
+                                f1 = fmaxf(e1.a, e1.b);
+                                f2 = fmaxf(fmaxf(fminf(e1.a, e1.b), e2.a), e2.b);
+                            }
+                            if (q == t) {
+                                my_amb = unsure(f1, f2, tol_rel);
+                                my_m1 = f1;
+                            }
+                        }
+                    }
+                    fine_tiles += redone;
+                }
+                seen_tiles += kTilesPerIter;
+                // a codebook whose rows mostly need stage 2 (crowded nodes, early training steps): this wave stops trying stage 1
+                if (seen_tiles >= 32u && fine_tiles * 2u > seen_tiles) direct = true;
             }
         }
+
         // Both waves of a SIMD run this same stream, so MFMA bursts and VALU stretches would line up
         // and the two pipes would take turns instead of overlapping (measured: VALU-active + MFMA-busy
         // ~= 100 % of the runtime).  Ask the scheduler for a fine interleave inside each wave:
@@ -605,16 +684,12 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
             }
         }
     };
-    if constexpr (ACC) {
-        while (g < ngroups) {
-            trip(rows_a, rows_b);
-            g += nwaves;
-            if (g >= ngroups) break;
-            trip(rows_b, rows_a);
-            g += nwaves;
-        }
-    } else {
-        for (; g < ngroups; g += nwaves) trip(rows_a, rows_a);
+    while (g < ngroups) {
+        trip(rows_a, rows_b);
+        g += nwaves;
+        if (g >= ngroups) break;
+        trip(rows_b, rows_a);
+        g += nwaves;
     }
     if constexpr (ACC) {
         __syncthreads();   // every wave is through its groups: the queue is complete

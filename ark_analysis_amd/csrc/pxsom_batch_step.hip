@@ -860,6 +860,7 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
         hdr_g->wn_max = badw ? 0.f : (float)(sqrt(wn2max) * scale * (1.0 + 1e-6));
         hdr_g->force_exact = badw ? 1 : 0;
         hdr_g->tol_rel = sa.tol_rel;
+        hdr_g->tol_rel_coarse = sa.tol_rel + 2.5f * 0x1.004p-10f;   // (the register-resident filter's first stage; not used by the shapes this kernel serves)
         hdr_g->tol_abs = sa.tol_abs;
         hdr_g->x_limit = 60000.0f;
         hdr_g->nb = nb;

@@ -200,6 +200,11 @@ __device__ __forceinline__ void prep_body(const double *wl, int k, int c, Assign
         const double coef = ldexp(1.0, -(23 - idx_bits)) +
                             (3.0 * c + 2.0) * ldexp(1.0, -24) + ldexp(1.0, -19) + ldexp(1.0, -23) + (center ? ldexp(1.0, -24) : 0.0);
         hdr->tol_rel = (float)(2.5 * coef);
+        // first stage of the register-resident filter: Wh*Xh alone.  |X'.W' - Xh.Wh| <= (2^-11 + 2^-11 (1 + 2^-11)) |X'||W'|
+        // (binary16 unit roundoff 2^-11 on either factor), C products + the bias in the fp32 accumulation
+        const double coef_c = ldexp(1.0, -10) + ldexp(1.0, -20) + ldexp(1.0, -(23 - idx_bits)) + (1.0 * c + 2.0) * ldexp(1.0, -24) +
+                              ldexp(1.0, -23) + (center ? ldexp(1.0, -24) : 0.0);
+        hdr->tol_rel_coarse = (float)(2.5 * coef_c);
         hdr->tol_abs = (float)(2.5 * ldexp(1.0, -24) * sqrt((double)c));  // fp16 subnormal floor
         hdr->x_limit = 60000.0f;
         hdr->nb = nb;
