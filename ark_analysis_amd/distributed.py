@@ -14,8 +14,8 @@ One pass runs on a schedule (``ark_analysis_amd.schedule.BatchSchedule``): the l
     thr = r0 - (r0-r1) f (0.5 once < 1);  alpha = a0 - (a0-a1) f
     W_k += (1 - (1-alpha)^den_k) (num_k/den_k - W_k)
 ``batch_steps=G`` (an int) is the equal schedule of rounds 1-2 (rows i % G == g); the default is the two-phase
-schedule (6 large steps while the radius is >= 1, 20 small ones in the BMU-only tail: the quality of 64 equal steps in
-26 dependent launches).  pxsom_batch_train_sched runs the step loop inside the library: for the
+schedule (6 large steps while the radius is >= 1, 16 in the BMU-only tail, the last one five times the others: the quality of 64 equal
+steps in 22 dependent launches).  pxsom_batch_train_sched runs the step loop inside the library: for the
 register-resident shapes a step is ONE launch (the update of step g-1 and the codebook preparation sit at the head of
 step g's BMU search).  Oracle of record: oracle/pxsom_oracle.c (orc_som_batch_sched).
 """

@@ -127,7 +127,7 @@ def som_batch(data, xdim: int = 10, ydim: int = 10, rlen: int = 1,
     ``rlen`` passes over ``data`` -- THIS RANK's rows when a process group exists (the per-step statistics are
     all-reduced, every rank returns the same codebook), all rows otherwise -- on the schedule ``batch_steps`` names:
     an int (that many equal mini-batch steps per pass), ``None`` / "two-phase" (the default: 6 large steps while the
-    neighbourhood radius is >= 1, 20 small ones in the BMU-only tail) or a ``schedule.BatchSchedule``.
+    neighbourhood radius is >= 1, 16 in the BMU-only tail, the last one larger) or a ``schedule.BatchSchedule``.
     Same arguments as :func:`som` otherwise.  Initial nodes: ``nodes`` if given, else
     ``rows[RandomState(seed).choice(n, K, replace=False)]`` -- of rank 0's rows when it holds at least K, else of the
     first K rows of every rank pooled in rank order (a cohort with enough rows never fails because rank 0's share is

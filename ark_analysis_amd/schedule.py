@@ -8,11 +8,12 @@ before it end.  A step costs the GPU one latency-bound launch whatever its size,
 
 * ``BatchSchedule.equal(G)``: G equal steps (rows ``i % G == g``) -- the rule of rounds 1 and 2;
 * ``BatchSchedule.two_phase()`` (the default of ``train_mode="batch"``): 6 shrinking steps over the 5/6 of a pass in
-  which the neighbourhood radius is >= 1, then 20 equal steps over the BMU-only tail.  On the bench workload its mean
-  quantisation error against the online rule's codebook is +0.45 % (eight seeds, +- 0.08) where 64 equal steps give
-  +0.6 % and 32 equal steps +1.6 % (scripts/study/batch_schedule_scan{2,3}.py): the tail is a mini-batch k-means whose
-  quality follows the number of its iterations, the ordering phase needs few.  Between 5 - 8 head and 18 - 32 tail steps
-  the quality is flat within the seeds' scatter (+0.3 ... +0.6 %); 6 + 20 sits in the middle of that plateau.
+  which the neighbourhood radius is >= 1, then 16 steps over the BMU-only tail -- 15 equal ones and a last one five times
+  their size.  On the bench workload its mean quantisation error against the online rule's codebook is +0.4 ... +0.6 %
+  (two sets of eight seeds, +- 0.1 ... 0.2) where 64 equal steps give +0.6 % and 32 equal steps +1.6 %
+  (scripts/study/batch_schedule_scan{2,3,4,5}.py): the tail is a mini-batch k-means whose quality follows the number of
+  its iterations, the ordering phase needs few, and the codebook a pass returns carries the sampling noise of its LAST
+  mini-batch -- a larger last step buys back what four fewer launches cost (6 + 20 equal tail steps: the same quality).
 """
 from typing import Sequence, Tuple, Union
 
@@ -65,20 +66,22 @@ class BatchSchedule:
         return cls(steps, range(steps + 1))
 
     @classmethod
-    def two_phase(cls, head_steps: int = 6, tail_steps: int = 20, head_ratio: float = 0.25,
-                  tail_phases_per_step: int = 8) -> "BatchSchedule":
+    def two_phase(cls, head_steps: int = 6, tail_steps: int = 16, head_ratio: float = 0.25,
+                  tail_phases_per_step: int = 8, last_step_factor: int = 5) -> "BatchSchedule":
         """``head_steps`` steps with geometrically shrinking sizes (last / first = ``head_ratio``) over the first 5/6 of
         the rows -- where the default radius schedule (r0 -> 0) keeps the neighbourhood radius >= 1 for a 10 x 10 map --,
-        ``tail_steps`` equal steps over the last 1/6."""
-        head_steps, tail_steps = int(head_steps), int(tail_steps)
-        if head_steps < 1 or tail_steps < 1:
+        ``tail_steps`` steps over the last 1/6: equal ones, the last ``last_step_factor`` times their size (the codebook
+        a pass returns carries the sampling noise of its last mini-batch)."""
+        head_steps, tail_steps, factor = int(head_steps), int(tail_steps), int(last_step_factor)
+        if head_steps < 1 or tail_steps < 1 or factor < 1:
             raise ValueError("two_phase needs at least one step in each part")
-        tail = tail_steps * int(tail_phases_per_step)
+        unit = int(tail_phases_per_step)
+        tail = (tail_steps - 1 + factor) * unit
         phases = 6 * tail
         sizes = np.geomspace(1.0, float(head_ratio), head_steps)
         cum = np.round(np.cumsum(sizes) / sizes.sum() * (phases - tail)).astype(np.int64)
         cum[-1] = phases - tail
-        edges = [0] + [int(v) for v in cum] + [phases - tail + (i + 1) * int(tail_phases_per_step) for i in range(tail_steps)]
+        edges = [0] + [int(v) for v in cum] + [phases - tail + (i + 1) * unit for i in range(tail_steps - 1)] + [phases]
         return cls(phases, edges)
 
 

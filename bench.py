@@ -81,7 +81,7 @@ def parse():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
     ap.add_argument("--fovs-per-gpu", type=int, default=None)
     ap.add_argument("--batch-steps", default="two-phase",
-                    help="training schedule: 'two-phase' (default: 6 large steps while the radius is >= 1, 20 small ones in "
+                    help="training schedule: 'two-phase' (default: 6 large steps while the radius is >= 1, 16 in "
                          "the BMU-only tail) or an integer = that many equal mini-batch steps per pass (64: rounds 1-2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-online", action="store_true")

@@ -89,7 +89,7 @@ def test_scheduled_steps_match_the_oracle_per_step(gpu, oracle, c, dtype, n, gri
 
 @pytest.mark.parametrize("c,dtype,n,grid", [(22, np.float32, 300_000, 10), (40, np.float16, 120_000, 20), (100, np.float32, 60_000, 10)])
 def test_default_schedule_run_matches_the_oracle(gpu, oracle, c, dtype, n, grid):
-    """BatchSOMTrainer on its default (two-phase, 26 steps, 960 phases) schedule, one call, against orc_som_batch_sched;
+    """BatchSOMTrainer on its default (two-phase, 22 steps, 960 phases) schedule, one call, against orc_som_batch_sched;
     a strided view (rows with padding) takes the same route and gives the same codebook."""
     xdim = ydim = grid
     k = xdim * ydim
@@ -97,7 +97,7 @@ def test_default_schedule_run_matches_the_oracle(gpu, oracle, c, dtype, n, grid)
     w0 = _codebook(x, k, seed=6)
     xd = torch.from_numpy(x).to(gpu)
     tr = BatchSOMTrainer(xdim, ydim, c, gpu)
-    assert tr.schedule == BatchSchedule.two_phase() and tr.batch_steps == 26
+    assert tr.schedule == BatchSchedule.two_phase() and tr.batch_steps == 22
     w = torch.from_numpy(w0.copy()).to(gpu)
     tr.train(xd, w, num_passes=1)
     want = oracle.som_batch_sched(x.astype(np.float64), w0, xdim, ydim, 1, (0.05, 0.01), default_radius_range(xdim, ydim),
@@ -204,7 +204,7 @@ def test_binary64_rows_train_reproducibly(gpu, oracle, c, grid, n, sch, unfused)
 
 
 def test_default_schedule_quality_against_equal_steps_and_online(gpu, oracle):
-    """What the two-phase schedule is for: the quality of 64 equal steps in 26 launches.  Mean quantisation error (distance
+    """What the two-phase schedule is for: the quality of 64 equal steps in 22 launches.  Mean quantisation error (distance
     to the BMU over all rows) of the codebooks three rules reach from the same initial nodes on a 400 k-row mixture: the
     default schedule within 1 % of 64 equal steps and of the ONLINE oracle (the reference's rule); 32 EQUAL steps are
     measurably worse than both (DESIGN.md K6b holds the six-seed study)."""

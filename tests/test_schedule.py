@@ -30,9 +30,10 @@ def test_schedule_partitions_the_rows():
 
 def test_default_schedule_shape_and_positions():
     sch = resolve(None)
-    assert sch == BatchSchedule.two_phase() == resolve("two-phase") and sch.steps == 26
+    assert sch == BatchSchedule.two_phase() == resolve("two-phase") and sch.steps == 22 and sch.phases == 960
     widths = np.diff(sch.edges)
-    assert np.all(widths[:6] >= widths[1:7]) and np.all(widths[6:] == widths[6]) and widths[:6].sum() * 6 == sch.phases * 5
+    assert np.all(widths[:6] >= widths[1:7]) and np.all(widths[6:-1] == widths[6]) and widths[-1] == 5 * widths[6]
+    assert widths[:6].sum() * 6 == sch.phases * 5
     assert sch.position(0) == 0 and sch.position(6) * 6 == sch.phases * 5         # the tail starts where the radius reaches 1
     assert sch.position(sch.steps + 3) == sch.phases + sch.edges[3]               # second pass
     assert resolve(64) == BatchSchedule.equal(64) and resolve(64).position(70) == 70
