@@ -448,8 +448,11 @@ __global__ __launch_bounds__(256) void q_hist_kernel(const T *__restrict__ x, in
 // derive m and the target rank lo = floor(q*(m-1)).
 // arith32: the virtual index is formed in binary32 -- what numpy does for a float32 array
 // (q is cast to the array's dtype, then (n-1)*q, floor and the fraction are all float32).
+// fill_low: the rows are binary32 values, whose binary64 images end in 29 zero bits -- key bits below `fill_low` are all
+// zeros (positive values) or all ones (negative ones: the key is the complement) for every candidate, so the passes over
+// them are not run: this pass completes the prefix.
 __global__ __launch_bounds__(64) void q_select_kernel(QState *st, unsigned long long *hist, int c, int shift, double q,
-                                                      int first_pass, int arith32)
+                                                      int first_pass, int arith32, int fill_low)
 {
     // one wave per column: lane l owns bins 4 l .. 4 l + 3; an inclusive scan over the lanes' sums finds the bucket
     const int col = blockIdx.x, lane = threadIdx.x;
@@ -501,6 +504,7 @@ __global__ __launch_bounds__(64) void q_select_kernel(QState *st, unsigned long 
         }
         s.rank -= wbefore;
         s.prefix |= (unsigned long long)wbin << shift;
+        if (fill_low > 0 && !(s.prefix >> 63)) s.prefix |= (1ull << fill_low) - 1ull;
     }
     if (lane == 0) st[col] = s;
 }
@@ -740,11 +744,14 @@ int quantile_typed(const char *fn, const T *x_dev, int64_t n, int c, int64_t ldx
     PXSOM_HIP_TRY(hipMemsetAsync(hist, 0, (size_t)c * 256 * sizeof(unsigned long long), st));
     int rgrid = (int)std::min<int64_t>((n + kQRows - 1) / kQRows, (int64_t)pxsom::device_cu_count() * 4);
     if (rgrid < 1) rgrid = 1;
-    for (int shift = 56, first = 1; shift >= 0; shift -= 8, first = 0) {
+    // binary32 rows: key bits 0 .. 23 follow from the sign (three sweeps fewer)
+    const int last_shift = sizeof(T) == 4 ? 24 : 0;
+    for (int shift = 56, first = 1; shift >= last_shift; shift -= 8, first = 0) {
         for (int col0 = 0; col0 < c; col0 += kQCols)
             hipLaunchKernelGGL(q_hist_kernel<T>, dim3(rgrid), dim3(256), 0, st, x_dev, n, c, ldx, keep_mode, shift, qs, hist, first,
                                col0, std::min(kQCols, c - col0));
-        hipLaunchKernelGGL(q_select_kernel, dim3(c), dim3(64), 0, st, qs, hist, c, shift, q, first, arith32);
+        hipLaunchKernelGGL(q_select_kernel, dim3(c), dim3(64), 0, st, qs, hist, c, shift, q, first, arith32,
+                           (shift == last_shift && last_shift > 0) ? last_shift : 0);
     }
     for (int col0 = 0; col0 < c; col0 += kQCols)
         hipLaunchKernelGGL(q_next_kernel<T>, dim3(rgrid), dim3(256), 0, st, x_dev, n, c, ldx, keep_mode, qs, col0,
