@@ -311,8 +311,24 @@ def main():
         per_rank = {"train_batch": [round(float(g[0]), 4) for g in gathered],
                     "assign_and_mean_table": [round(float(g[1]), 4) for g in gathered]}
         from ark_analysis_amd.distributed import native_exchange
-        comm_ranks = world if native_exchange(None) is not None else 0     # (made once per group: cached by now)
+        native = native_exchange(None)                                     # (made once per group: cached by now)
+        comm_ranks = world if native is not None else 0
         assert dist.get_world_size() == args.gpus, "process group size and --gpus disagree"
+        # the rule's only exchange, timed on its own after the timed region: one [K*C + K] binary64 all-reduce per step, back
+        # to back on the route the pass uses -- what the training pass of an N-rank job pays on top of its kernels
+        probe = torch.zeros(K * (C + 1), dtype=torch.float64, device=dev)
+        reps = 50
+        for _ in range(5):
+            native.allreduce_sum(probe) if native is not None else all_reduce_(probe)
+        fence()
+        tp = time.perf_counter()
+        for _ in range(reps):
+            native.allreduce_sum(probe) if native is not None else all_reduce_(probe)
+        fence()
+        exch = torch.tensor([(time.perf_counter() - tp) / reps * 1e6], dtype=torch.float64, device="cpu" if dry else dev)
+        all_reduce_(exch, op=dist.ReduceOp.MAX)
+        per_rank["exchange_us_per_step"] = round(float(exch.item()), 2)
+        per_rank["exchange_ms_per_pass"] = round(float(exch.item()) * sched.steps * 1e-3, 4)
     if rank != 0 or args.pmc_inner:
         if use_dist:
             dist.barrier()

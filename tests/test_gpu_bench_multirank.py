@@ -46,4 +46,5 @@ def test_two_rank_bench_line(gpu, tmp_path, exchange, config):
     assert line["config"]["exchange"].startswith("in-library" if exchange == "in-library" else "torch.distributed")
     per_rank = line["phases_ms"]["per_rank"]
     assert len(per_rank["train_batch"]) == 2 and all(v > 0 for v in per_rank["train_batch"])
+    assert per_rank["exchange_us_per_step"] > 0 and per_rank["exchange_ms_per_pass"] > 0     # the exchange timed on its own
     assert line["scaling"] == ("weak" if config == "cfg2" else "strong")
