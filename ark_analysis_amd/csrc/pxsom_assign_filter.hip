@@ -26,6 +26,9 @@
 #ifndef PXSOM_STREAM_TP
 #define PXSOM_STREAM_TP 0
 #endif
+#ifndef PXSOM_PACKED_TMERGE
+#define PXSOM_PACKED_TMERGE 1
+#endif
 namespace pxsom_bmu {
 namespace {
 
@@ -526,6 +529,56 @@ __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_packed_kerne
                     bsel[u] = m1[u] != before ? b : bsel[u];
                 }
             }
+            if constexpr (TP == kTilesPerIter && PXSOM_PACKED_TMERGE) {
+                // Transposing merge of the four tiles at once (the register-resident filter's, with the node index beside
+                // the score): v_permlane16_swap(A, B) exchanges the odd lane rows of A with the even ones of B, so with
+                // A = tile 2i's values and B = tile 2i+1's a lane ends up with {own, partner} of the tile its row will own;
+                // v_permlane32_swap does the same for lane halves.  Afterwards lane row q holds tile q's merged result:
+                // 12 swaps per 64 rows where the tile-by-tile merge took 32.
+                float a1[TP], a2[TP], s2[TP];
+                int node[TP];
+#pragma unroll
+                for (int u = 0; u < TP; u++) {
+                    a1[u] = m1[u];
+                    a2[u] = m2[u];
+                    s2[u] = ss[u];
+                    const unsigned bb = (unsigned)bsel[u], r = __float_as_uint(a1[u]) & idx_mask;
+                    node[u] = (int)((int)bb == nb - 1 ? (bb << 4) | (r << 2) | (unsigned)q : (bb << 4) | ((unsigned)q << 2) | r);
+                }
+                auto tmerge = [&](int x, int y, bool wide) {   // tiles x, y -> slot x
+                    uint2v r1, r2, rs, rn;
+                    if (wide) {
+                        r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a1[x]), __float_as_uint(a1[y]), false, false);
+                        r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a2[x]), __float_as_uint(a2[y]), false, false);
+                        rs = __builtin_amdgcn_permlane32_swap(__float_as_uint(s2[x]), __float_as_uint(s2[y]), false, false);
+                        rn = __builtin_amdgcn_permlane32_swap((unsigned)node[x], (unsigned)node[y], false, false);
+                    } else {
+                        r1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(a1[x]), __float_as_uint(a1[y]), false, false);
+                        r2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(a2[x]), __float_as_uint(a2[y]), false, false);
+                        rs = __builtin_amdgcn_permlane16_swap(__float_as_uint(s2[x]), __float_as_uint(s2[y]), false, false);
+                        rn = __builtin_amdgcn_permlane16_swap((unsigned)node[x], (unsigned)node[y], false, false);
+                    }
+                    const float ea = __uint_as_float(r1[0]), eb = __uint_as_float(r1[1]);
+                    const int na = (int)rn[0], nb_ = (int)rn[1];
+                    const bool take_b = eb > ea || (eb == ea && nb_ < na);
+                    a2[x] = fmaxf(fmaxf(fminf(ea, eb), __uint_as_float(r2[0])), __uint_as_float(r2[1]));
+                    a1[x] = take_b ? eb : ea;
+                    node[x] = take_b ? nb_ : na;
+                    s2[x] = __uint_as_float(rs[0]) + __uint_as_float(rs[1]);
+                };
+                tmerge(0, 1, false);
+                tmerge(2, 3, false);
+                tmerge(0, 2, true);
+                {
+                    const float xn = __builtin_amdgcn_sqrtf(s2[0]) * 1.000001f;
+                    const float tol = tol_rel * (xn * wn_max + 0.5f * wn_max * wn_max) + tol_abs * (xn + wn_max);
+                    unsigned sbits = __float_as_uint(s2[0]);
+                    asm volatile("" : "+v"(sbits));
+                    const bool nonfinite = (sbits & 0x7f800000u) == 0x7f800000u;
+                    my_amb = !((a1[0] - a2[0]) > tol) || !(xn < x_limit) || nonfinite || force_exact;
+                    my_node = node[0];
+                }
+            } else {
 #pragma unroll
             for (int u = 0; u < TP; u++) {
                 // node index beside the score through the merge of the 4 lane groups of a pixel (streamed kernel's finish)
@@ -557,6 +610,7 @@ __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_packed_kerne
                     my_amb = !((a1 - a2) > tol) || !(xn < x_limit) || nonfinite || force_exact;
                     my_node = node;
                 }
+            }
             }
         }
         const int64_t row = g * 64 + lane;
