@@ -168,44 +168,6 @@ __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_kernel(
         ss = acc2;
     };
 
-    // finish one tile: node index into the winner, merge the 4 lane groups of a pixel, decide
-    auto finish = [&](float m1, float m2, float s2, int bsel, int &out_node, bool &out_amb, int t) {
-        // the node index travels beside the score through the merge (no second packing: the only
-        // perturbation of the scores is the 2-bit register index)
-        int node;
-        {
-            const unsigned bb = (unsigned)bsel, r = __float_as_uint(m1) & idx_mask;
-            node = (int)((int)bb == nb - 1 ? (bb << 4) | (r << 2) | (unsigned)q : (bb << 4) | ((unsigned)q << 2) | r);
-        }
-        // xchg(v) returns (value of the lower lane, value of the upper lane) in BOTH partner lanes, so the
-        // selection below is identical on the two sides
-        auto merge_step = [&](bool wide) {
-            const F2 e1 = wide ? xchg32(m1) : xchg16(m1), e2 = wide ? xchg32(m2) : xchg16(m2),
-                     es = wide ? xchg32(s2) : xchg16(s2),
-                     en = wide ? xchg32(__int_as_float(node)) : xchg16(__int_as_float(node));
-            const int na = __float_as_int(en.a), nb_ = __float_as_int(en.b);
-            const bool take_b = e1.b > e1.a || (e1.b == e1.a && nb_ < na);
-            m2 = fmaxf(fmaxf(fminf(e1.a, e1.b), e2.a), e2.b);
-            m1 = take_b ? e1.b : e1.a;
-            node = take_b ? nb_ : na;
-            s2 = es.a + es.b;
-        };
-        merge_step(false);
-        merge_step(true);
-        if (q == t) {
-            // |X| up to 2^-20 relative; integer test catches NaN/Inf rows under finite-math
-            const float xn = __builtin_amdgcn_sqrtf(s2) * 1.000001f;
-            const float tol = tol_rel * (xn * wn_max + 0.5f * wn_max * wn_max) + tol_abs * (xn + wn_max);
-            // launder the bits through an empty asm: under -ffinite-math-only the optimiser would
-            // otherwise fold this exponent test (it recognises it as an is-nan-or-inf query) to false
-            unsigned sbits = __float_as_uint(s2);
-            asm volatile("" : "+v"(sbits));
-            const bool nonfinite = (sbits & 0x7f800000u) == 0x7f800000u;
-            out_amb = !((m1 - m2) > tol) || !(xn < x_limit) || nonfinite || force_exact;
-            out_node = node;
-        }
-    };
-
     T raw[PREFETCH ? kTilesPerIter : TP][NCH][CPLMAX];
 
     int64_t g = wave;
@@ -231,6 +193,8 @@ __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_kernel(
 
         int my_node = 0;
         bool my_amb = false;
+        float g1[kTilesPerIter], g2[kTilesPerIter], gs[kTilesPerIter];   // per tile: top-2, |X|^2 share, winner's node
+        int gn[kTilesPerIter];
 #pragma unroll
         for (int t0 = 0; t0 < kTilesPerIter; t0 += TP) {
             if constexpr (!PREFETCH) {
@@ -316,8 +280,53 @@ __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_kernel(
                 }
             }
 #pragma unroll
-            for (int u = 0; u < TP; u++)
-                finish(m1[u], m2[u], ss[PREFETCH ? t0 + u : u], bsel[u], my_node, my_amb, t0 + u);
+            for (int u = 0; u < TP; u++) {   // the tile's result waits for the other three: one merge for the group below
+                const unsigned bb = (unsigned)bsel[u], r = __float_as_uint(m1[u]) & idx_mask;
+                g1[t0 + u] = m1[u];
+                g2[t0 + u] = m2[u];
+                gs[t0 + u] = ss[PREFETCH ? t0 + u : u];
+                gn[t0 + u] = (int)((int)bb == nb - 1 ? (bb << 4) | (r << 2) | (unsigned)q : (bb << 4) | ((unsigned)q << 2) | r);
+            }
+        }
+        {
+            // Transposing merge of the group's four tiles (the register-resident filter's, with the node index beside the
+            // score -- the only perturbation of the scores is the 2-bit register index): v_permlane16_swap(A, B) exchanges
+            // the odd lane rows of A with the even ones of B, v_permlane32_swap the lane halves; afterwards lane row q holds
+            // tile q's merged result.  12 swaps per 64 rows where the tile-by-tile merge took 32.
+            auto tmerge = [&](int x, int y, bool wide) {   // tiles x, y -> slot x
+                uint2v r1, r2, rs, rn;
+                if (wide) {
+                    r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(g1[x]), __float_as_uint(g1[y]), false, false);
+                    r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(g2[x]), __float_as_uint(g2[y]), false, false);
+                    rs = __builtin_amdgcn_permlane32_swap(__float_as_uint(gs[x]), __float_as_uint(gs[y]), false, false);
+                    rn = __builtin_amdgcn_permlane32_swap((unsigned)gn[x], (unsigned)gn[y], false, false);
+                } else {
+                    r1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(g1[x]), __float_as_uint(g1[y]), false, false);
+                    r2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(g2[x]), __float_as_uint(g2[y]), false, false);
+                    rs = __builtin_amdgcn_permlane16_swap(__float_as_uint(gs[x]), __float_as_uint(gs[y]), false, false);
+                    rn = __builtin_amdgcn_permlane16_swap((unsigned)gn[x], (unsigned)gn[y], false, false);
+                }
+                const float ea = __uint_as_float(r1[0]), eb = __uint_as_float(r1[1]);
+                const int na = (int)rn[0], nb_ = (int)rn[1];
+                const bool take_b = eb > ea || (eb == ea && nb_ < na);
+                g2[x] = fmaxf(fmaxf(fminf(ea, eb), __uint_as_float(r2[0])), __uint_as_float(r2[1]));
+                g1[x] = take_b ? eb : ea;
+                gn[x] = take_b ? nb_ : na;
+                gs[x] = __uint_as_float(rs[0]) + __uint_as_float(rs[1]);
+            };
+            tmerge(0, 1, false);
+            tmerge(2, 3, false);
+            tmerge(0, 2, true);
+            // |X| up to 2^-20 relative; integer test catches NaN/Inf rows under finite-math
+            const float xn = __builtin_amdgcn_sqrtf(gs[0]) * 1.000001f;
+            const float tol = tol_rel * (xn * wn_max + 0.5f * wn_max * wn_max) + tol_abs * (xn + wn_max);
+            // launder the bits through an empty asm: under -ffinite-math-only the optimiser would
+            // otherwise fold this exponent test (it recognises it as an is-nan-or-inf query) to false
+            unsigned sbits = __float_as_uint(gs[0]);
+            asm volatile("" : "+v"(sbits));
+            const bool nonfinite = (sbits & 0x7f800000u) == 0x7f800000u;
+            my_amb = !((g1[0] - g2[0]) > tol) || !(xn < x_limit) || nonfinite || force_exact;
+            my_node = gn[0];
         }
         // lane (q, pix) now owns row g*64 + q*16 + pix == g*64 + lane
         const int64_t row = g * 64 + lane;
