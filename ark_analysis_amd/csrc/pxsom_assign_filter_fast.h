@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
                 }
                 seen_tiles += kTilesPerIter;
                 // a codebook whose rows mostly need stage 2 (crowded nodes, early training steps): this wave stops trying stage 1
-                if (seen_tiles >= 32u && fine_tiles * 2u > seen_tiles) direct = true;
+                if (seen_tiles >= 16u && fine_tiles * 2u > seen_tiles) direct = true;
             }
         }
 
