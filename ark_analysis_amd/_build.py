@@ -12,7 +12,7 @@ import subprocess
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 SO_PATH = os.path.join(_PKG, "libpxsom.so")
-SOURCES = ["pxsom_api.hip", "pxsom_assign.hip", "pxsom_assign_filter.hip", "pxsom_assign_filter_acc.hip", "pxsom_batch_step.hip", "pxsom_train.hip",
+SOURCES = ["pxsom_api.hip", "pxsom_assign.hip", "pxsom_assign_filter.hip", "pxsom_assign_filter_acc.hip", "pxsom_batch_step.hip", "pxsom_batch_tail.hip", "pxsom_train.hip",
            "pxsom_pre.hip", "pxsom_sums.hip", "pxsom_comm.hip"]
 # per-file extra flags: the filter works on provably finite scores (see the file header)
 EXTRA_FLAGS = {"pxsom_assign_filter.hip": ["-ffinite-math-only"] + (
@@ -32,7 +32,7 @@ def _hipcc() -> str:
     return exe
 
 
-HEADERS = ["pxsom_common.h", "pxsom_assign.h", "pxsom_wave.h", "pxsom_assign_filter_fast.h", "pxsom_prep.h",
+HEADERS = ["pxsom_common.h", "pxsom_assign.h", "pxsom_wave.h", "pxsom_assign_filter_fast.h", "pxsom_batch_step.h", "pxsom_prep.h",
            "pxsom_sums.h"]
 STAMP_PATH = SO_PATH + ".srchash"
 

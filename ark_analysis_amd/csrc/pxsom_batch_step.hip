@@ -23,7 +23,7 @@
 #include <cfloat>
 #include <cmath>
 
-#include "pxsom_assign_filter_fast.h"
+#include "pxsom_batch_step.h"
 
 namespace pxsom_bmu {
 namespace {
@@ -32,19 +32,12 @@ namespace {
 __device__ long long g_block_ticks[2 * 256];   // per workgroup: first and last instruction (s_memtime)
 #endif
 
-constexpr int kXD = 10, kYD = 10, kK = 100, kNB = 7;
 constexpr int kStepThreads = 512, kStepWaves = 8;
-constexpr int kQueueRows = 96;       // listed rows a workgroup keeps in LDS; further ones are settled on the spot
 // Copies of the workgroup's statistics table (pixel lane pix adds into copy pix % copies) against same-word contention of
 // the ds_add_f64 lanes while the codebook is crowded.  Measured in round 3 with 4 copies: the crowded head steps did not
 // move (36.0 / 33.1 us before and after: the LDS serialisation is not what holds them) and every step paid for clearing and
 // adding up the copies (tail step 11.4 -> 12.1 us): one table.
 __host__ __device__ inline int table_copies(int c) { return (void)c, 1; }
-
-struct StepHdr {
-    int bad;          // NaN / Inf met in the codebook
-    unsigned q_n;     // rows in the queue
-};
 
 // LDS carve-up (bytes from the start of the dynamic segment)
 struct StepLds {
@@ -67,59 +60,6 @@ __host__ __device__ inline StepLds step_lds(int c)
     L.total = o;
     return L;
 }
-
-#pragma clang fp contract(off)
-// One listed row settled by a whole wave: lanes <-> nodes lane and lane + 64, the row's values read from LDS
-// (one address for the wave: a broadcast), distances exactly as the oracle forms them.
-__device__ __forceinline__ void exact_row_from_lds(const double *xr, int c, const double *wt, double *ls, int lane,
-                                                   double qmagic)
-{
-    const int n0 = lane, n1 = lane + 64;
-    const int c1 = n1 < kK ? n1 : kK - 1;
-    double d0 = 0.0, d1 = 0.0;
-    int j = 0;
-    for (; j + 4 <= c; j += 4) {   // the LDS reads of a trip are issued together; sums stay in j order
-        double xa[4], wa[4], wb[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            xa[u] = xr[j + u];
-            wa[u] = wt[(size_t)(j + u) * kK + n0];
-            wb[u] = wt[(size_t)(j + u) * kK + c1];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const double t0 = xa[u] - wa[u], t1 = xa[u] - wb[u];
-            d0 += t0 * t0;
-            d1 += t1 * t1;
-        }
-    }
-    for (; j < c; j++) {
-        const double xj = xr[j];
-        const double t0 = xj - wt[(size_t)j * kK + n0], t1 = xj - wt[(size_t)j * kK + c1];
-        d0 += t0 * t0;
-        d1 += t1 * t1;
-    }
-    double best = DBL_MAX;
-    int bestk = 0x7fffffff;
-    const double s0 = sqrt(d0), s1 = sqrt(d1);
-    if (s0 < best) {
-        best = s0;
-        bestk = n0;
-    }
-    if (n1 < kK && s1 < best) {
-        best = s1;
-        bestk = n1;
-    }
-    const double smin = pxsom::wave_min_f64(best);
-    const int win = (int)pxsom::wave_min_u32(best == smin ? (unsigned)bestk : 0xffffffffu);
-    if (win != 0x7fffffff) {   // 0x7fffffff: no finite distance (NaN row): label 0, not accumulated
-        if (lane < c)
-            __hip_atomic_fetch_add(ls + (size_t)win * c + lane, qround(xr[lane], qmagic), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (lane == 0)
-            __hip_atomic_fetch_add(ls + (size_t)kK * c + win, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-}
-#pragma clang fp contract(fast)
 
 template <typename T, int CPL, int TPW>
 __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__restrict__ x, int64_t n, int c, int64_t ldx,

@@ -1739,7 +1739,7 @@ __global__ __launch_bounds__(256) void centring_vector_kernel(const double *__re
 }
 
 struct TrainWs {
-    size_t assign_ws, off_labels, off_mu, off_gather, total;
+    size_t assign_ws, off_labels, off_mu, off_gather, off_tail, total;
 };
 inline TrainWs train_ws(int64_t n, int c, int k, size_t esize, const Sched &sc)
 {
@@ -1749,7 +1749,9 @@ inline TrainWs train_ws(int64_t n, int c, int k, size_t esize, const Sched &sc)
     w.off_labels = pxsom::align_up(w.assign_ws, 256);
     w.off_mu = w.off_labels + pxsom::align_up((size_t)(rmax > 0 ? rmax : 1) * sizeof(int32_t), 256);   // 33 floats: the run's centring vector and its norm
     w.off_gather = w.off_mu + 256;
-    w.total = w.off_gather + (sc.any_wide() ? pxsom::align_up((size_t)(n > 0 ? n : 1) * c * esize, 256) : 0);
+    w.off_tail = w.off_gather + (sc.any_wide() ? pxsom::align_up((size_t)(n > 0 ? n : 1) * c * esize, 256) : 0);
+    // the persistent BMU-only tail's scratch (control words, member tables, published codebook: pxsom_batch_tail.hip)
+    w.total = w.off_tail + ((k == 100 && c <= 32) ? pxsom_bmu::tail_scratch_bytes(c) : 0);
     return w;
 }
 }  // namespace
@@ -1792,7 +1794,35 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
         int rc = launch_gather<T>(x, n, c, ldx, xg, sc, st);
         if (rc) return rc;
     }
-    for (int gg = g_begin; gg < g_end; gg++) {
+    // coefficients of the fused kernels' rigorous |score - exact| bound (DESIGN.md "K7 error bound"; 7 index bits packed
+    // into the scores): tol = 2 * 1.25 * E (+ 2^-24: the rounding of the centred row, x' = fl(x * scale - mu_s))
+    const float fused_tol_rel = (float)(2.5 * (ldexp(1.0, -(23 - 7)) + (3.0 * c + 2.0) * ldexp(1.0, -24) + ldexp(1.0, -19) +
+                                               ldexp(1.0, -23) + ldexp(1.0, -24)));
+    const float fused_tol_abs = (float)(2.5 * ldexp(1.0, -24) * sqrt((double)c));
+    static const bool no_centre = getenv("PXSOM_STEP_NO_CENTRE") != nullptr;   // timing hook
+    // Opt-in (PXSOM_TRAIN_PERSISTENT_TAIL): the BMU-only steps at the end of the call (threshold pinned at 0.5: a node's
+    // window is the node) as ONE persistent launch on one XCD (pxsom_batch_tail.hip) -- single rank only: the all-reduce of
+    // a sharded run sits between the steps.  Not the default: 12.2 us per step against 12.0 us for the launches (config 2).
+    int g_tail = g_end;
+    {
+        static const bool tail_env = getenv("PXSOM_TRAIN_TAIL") != nullptr && getenv("PXSOM_TRAIN_TAIL")[0] == '1';
+        if (fused_shape && !comm && (tail_env || (flags & PXSOM_TRAIN_PERSISTENT_TAIL))) {
+            int g = g_end;
+            while (g > g_begin) {
+                const int gg = g - 1;
+                if (gg > 0) {
+                    double thr = 0.0, alpha = 0.0;
+                    batch_schedule(sc.pos(gg - 1), span, a0, a1, r0, r1, &thr, &alpha);
+                    if (thr != 0.5) break;
+                }
+                const int64_t rows = sc.rows(n, gg % sc.steps);
+                if (rows < 1 || rows >= (int64_t)1 << 31 || sc.width(gg % sc.steps) < 1) break;
+                g--;
+            }
+            if (g_end - g >= 2 && g_end - g <= pxsom_bmu::kMaxTailSteps) g_tail = g;
+        }
+    }
+    for (int gg = g_begin; gg < g_tail; gg++) {
         const int g = gg % sc.steps;
         const int64_t rows = sc.rows(n, g);
         const int wd = sc.width(g);
@@ -1815,13 +1845,8 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
             sa.has_update = gg > 0 ? 1 : 0;
             sa.thr = thr;
             sa.lg = log1p(-alpha);
-            // coefficients of the filter's rigorous |score - exact| bound (DESIGN.md "K7 error bound"; 7 index bits
-            // packed into the scores): tol = 2 * 1.25 * E
-            // (+ 2^-24: the rounding of the centred row, x' = fl(x * scale - mu_s))
-            sa.tol_rel = (float)(2.5 * (ldexp(1.0, -(23 - 7)) + (3.0 * c + 2.0) * ldexp(1.0, -24) + ldexp(1.0, -19) +
-                                        ldexp(1.0, -23) + ldexp(1.0, -24)));
-            sa.tol_abs = (float)(2.5 * ldexp(1.0, -24) * sqrt((double)c));
-            static const bool no_centre = getenv("PXSOM_STEP_NO_CENTRE") != nullptr;   // timing hook
+            sa.tol_rel = fused_tol_rel;
+            sa.tol_abs = fused_tol_abs;
             sa.mu32 = no_centre ? nullptr : mu32;
             sa.group_w = wd > 1 ? wd : 1;
             sa.group_stride = (int64_t)sc.phases * ldx;
@@ -1873,6 +1898,37 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
         int rc = batch_accumulate_impl(xv, rows, c, ldv, dtype, w_cur, k, labels, s_cur, ws, assign_ws, 0, st, qmagic);
         if (rc) return rc;
         if (comm && (rc = pxsom::comm_allreduce_sum_f64(comm, s_cur, nstats, st))) return rc;
+    }
+    if (g_tail < g_end) {
+        pxsom_bmu::TailArgs ta;
+        ta.nsteps = g_end - g_tail;
+        ta.phases = sc.phases;
+        ta.first_has_update = g_tail > 0 ? 1 : 0;
+        ta.final_update = 0;
+        ta.lg_final = 0.0;
+        ta.stats_first = ring + (size_t)((g_tail + 2) % 3) * nstats;
+        ta.w_in = g_tail > 0 ? wbuf + (size_t)((g_tail + 1) % 2) * nw : wbuf + (size_t)(g_tail % 2) * nw;
+        ta.w_last = wbuf + (size_t)((g_end - 1) % 2) * nw;
+        ta.stats_last = ring + (size_t)((g_end - 1) % 3) * nstats;
+        ta.stats_zero = ring + (size_t)(g_end % 3) * nstats;
+        ta.w_final = nullptr;
+        ta.scratch = ws + tw.off_tail;
+        ta.tol_rel = fused_tol_rel;
+        ta.tol_abs = fused_tol_abs;
+        ta.mu32 = no_centre ? nullptr : mu32;
+        ta.qmagic = qmagic;
+        for (int gg = g_tail; gg < g_end; gg++) {
+            const int g = gg % sc.steps;
+            pxsom_bmu::TailStep &ts = ta.st[gg - g_tail];
+            ts.e0 = sc.e0(g);
+            ts.width = sc.width(g);
+            ts.rows = sc.rows(n, g);
+            double thr = 0.0, alpha = 0.0;
+            if (gg > 0) batch_schedule(sc.pos(gg - 1), span, a0, a1, r0, r1, &thr, &alpha);
+            ts.lg = log1p(-alpha);
+        }
+        int rc = pxsom_bmu::launch_batch_tail<T>(x, c, ldx, ta, st);
+        if (rc) return rc;
     }
     (void)ws_bytes;
     return PXSOM_OK;

@@ -94,6 +94,7 @@ def cluster_sums(x: torch.Tensor, labels: torch.Tensor, k: int,
 
 
 TRAIN_UNFUSED = 1  # include/pxsom.h PXSOM_TRAIN_UNFUSED
+TRAIN_PERSISTENT_TAIL = 2  # include/pxsom.h PXSOM_TRAIN_PERSISTENT_TAIL
 
 
 class BatchTrainState:
@@ -149,11 +150,13 @@ def batch_train_fused_route(x: torch.Tensor, xdim: int, ydim: int, schedule) -> 
 
 
 def batch_train_steps(x: torch.Tensor, state: BatchTrainState, g_begin: int, g_end: int, total_steps: int,
-                      alpha_range, radius_range, unfused: bool = False, comm: "RankComm" = None) -> None:
+                      alpha_range, radius_range, unfused: bool = False, comm: "RankComm" = None,
+                      persistent_tail: bool = False) -> None:
     """Mini-batch steps [g_begin, g_end) of a batch training run of ``total_steps`` = passes x steps per pass, launched
     back to back by the library (``state.wbuf[0]`` holds W_0 before step 0; see include/pxsom.h).  ``comm``: the
     statistics of every step are sum-all-reduced over its ranks right behind the step's launch (every rank makes the
-    same call)."""
+    same call).  ``persistent_tail`` (opt-in, single rank): the BMU-only steps at the end of the call run as one
+    persistent launch on one XCD (csrc/pxsom_batch_tail.hip; same codebook bit for bit, not faster yet)."""
     n, c, ldx, dt = _matrix_args(x)
     if not state.fits(n, c, state.xdim, state.ydim, state.schedule, x.dtype):
         raise ValueError("batch-training state does not fit this matrix")
@@ -164,7 +167,7 @@ def batch_train_steps(x: torch.Tensor, state: BatchTrainState, g_begin: int, g_e
         x.data_ptr(), n, c, ldx, dt, state.wbuf.data_ptr(), state.ring.data_ptr(), state.xdim, state.ydim,
         sch.phases, state.edges.ctypes.data, sch.steps, int(g_begin), int(g_end), int(total_steps) // sch.steps,
         float(alpha_range[0]), float(alpha_range[1]), float(radius_range[0]), float(radius_range[1]), float(state.quantum),
-        state.ws.data_ptr(), state.ws_bytes, TRAIN_UNFUSED if unfused else 0,
+        state.ws.data_ptr(), state.ws_bytes, (TRAIN_UNFUSED if unfused else 0) | (TRAIN_PERSISTENT_TAIL if persistent_tail else 0),
         comm.handle if comm is not None else None, _capi.stream_ptr())
     _capi.check(rc, "pxsom_batch_train_sched")
 

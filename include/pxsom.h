@@ -185,6 +185,12 @@ int pxsom_batch_update_prepare(double *w_dev, int xdim, int ydim, int c, double 
  * workgroup; other shapes run update / prepare / search / exact / sums launches per step.  Same results either
  * way (PXSOM_TRAIN_UNFUSED forces the second route).  Oracle of record: oracle/pxsom_oracle.c orc_som_batch. */
 #define PXSOM_TRAIN_UNFUSED 1
+/* Opt-in (round 4, experimental): the BMU-only steps at the end of a single-rank call (neighbourhood threshold pinned at
+ * 0.5) run as ONE persistent launch whose workgroups all sit on one XCD and synchronise through that XCD's L2
+ * (csrc/pxsom_batch_tail.hip: same rule, same state left behind, bit-equal codebooks -- tests/test_gpu_schedule.py).
+ * Measured on config 2: 12.2 us per step against 12.0 us for the launch-per-step route (profiles/r04/tail_phase_timing.txt),
+ * so it is NOT the default; the environment variable PXSOM_TRAIN_TAIL=1 turns it on for every call. */
+#define PXSOM_TRAIN_PERSISTENT_TAIL 2
 size_t pxsom_batch_train_workspace_bytes(int64_t n, int batch_steps, int c, int k);
 int pxsom_batch_train_steps(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, double *wbuf_dev,
                             double *stats_ring_dev, int xdim, int ydim, int batch_steps, int g_begin, int g_end,

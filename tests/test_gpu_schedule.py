@@ -230,3 +230,52 @@ def test_default_schedule_quality_against_equal_steps_and_online(gpu, oracle):
     assert q_default <= 1.01 * q_64, (q_default, q_64)
     assert q_default <= 1.015 * q_online, (q_default, q_online)
     assert q_32 >= q_default, (q_32, q_default)
+
+
+TAIL_HEAVY = BatchSchedule.two_phase(head_steps=2, tail_steps=9, head_ratio=0.5, tail_phases_per_step=3)
+
+
+@pytest.mark.parametrize("c,dtype,n,sch,passes", [
+    (22, np.float32, 120_007, None, 1),                  # the default schedule: 6 launches + one 16-step persistent launch
+    (22, np.float32, 20_011, TAIL_HEAVY, 1),
+    (16, np.float16, 31_000, SMALL_TWO_PHASE, 2),        # two passes: the tail is the end of the second
+    (32, np.float64, 12_000, TAIL_HEAVY, 1),             # binary64 rows (rounded to the run's quantum), widest fused rows
+    (8, np.float32, 2_500, SMALL_TWO_PHASE, 1),          # a few rows per member and step
+    (2, np.float32, 4_001, TAIL_HEAVY, 1),
+])
+def test_persistent_tail_equals_the_launch_per_step_route(gpu, oracle, c, dtype, n, sch, passes):
+    """The BMU-only tail as one persistent launch on one XCD (csrc/pxsom_batch_tail.hip; opt-in) against the launch-per-step
+    route: the codebook and the state left behind (W of the last step, its statistics, the cleared next buffer) bit for
+    bit on data whose sums are exact, and the run against orc_som_batch_sched."""
+    xdim = ydim = 10
+    k = 100
+    sch = BatchSchedule.two_phase() if sch is None else sch
+    # values on a 2^-12 grid: every partial sum is exact, so the trajectory does not depend on the order the rows are
+    # added in (with arbitrary binary32 values the collapsed codebooks of the first steps amplify a last-bit difference
+    # between two summation orders into different BMUs, and an independent oracle run parts ways with any GPU run)
+    x = synth.make_fov_numpy(max(n, 2 * k), c, seed=51, dtype=np.float32)[:n]
+    x = (np.round(x.astype(np.float64) * 4096.0) / 4096.0).astype(dtype)
+    w0 = _codebook(synth.make_fov_numpy(4 * k, c, seed=52, dtype=np.float64), k, seed=7)
+    w0[k - 2] = w0[3]                                    # a duplicate node: not masked out by the tail's filter
+    xd = torch.from_numpy(x).to(gpu)
+    rr = default_radius_range(xdim, ydim)
+    total = passes * sch.steps
+    quantum = sd.exact_sum_quantum(float(np.abs(x).max()), n) if dtype == np.float64 else 0.0
+    outs = []
+    for tail in (True, False):
+        st = sd.BatchTrainState(n, c, xdim, ydim, sch, gpu, dtype=xd.dtype)
+        st.quantum = quantum
+        st.wbuf[0].copy_(torch.from_numpy(w0))
+        sd.batch_train_steps(xd, st, 0, total, total, (0.05, 0.01), rr, persistent_tail=tail)
+        w = torch.empty((k, c), dtype=torch.float64, device=gpu)
+        sd.batch_train_finish(st, total, total, (0.05, 0.01), rr, w)
+        outs.append((w, st.wbuf.clone(), st.ring.clone()))
+    (wa, wbuf_a, ring_a), (wb, wbuf_b, ring_b) = outs
+    g = total - 1
+    assert torch.equal(wbuf_a[g % 2], wbuf_b[g % 2]), "codebook of the last step"
+    assert torch.equal(ring_a[g % 3], ring_b[g % 3]), "statistics of the last step"
+    assert float(ring_a[(g + 1) % 3].abs().max()) == 0.0, "next statistics buffer not cleared"
+    assert torch.equal(wa, wb)
+    want = oracle.som_batch_sched(x.astype(np.float64), w0, xdim, ydim, passes, (0.05, 0.01), rr, sch.phases, sch.edges,
+                                  quantum=quantum)
+    np.testing.assert_allclose(wa.cpu().numpy(), want, rtol=1e-9, atol=0)
