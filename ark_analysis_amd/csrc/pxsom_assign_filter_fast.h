@@ -114,6 +114,9 @@ struct FixPoint {
 // 2^-(39 - rows_log2) relative to the codebook's largest magnitude (|W|max * scale is in [128, 256)).
 __device__ __forceinline__ FixPoint make_fixpoint(int scale_exp, int rows_log2)
 {
+    // (rows_log2 below 11 would put the table's limit under the 2^(16 - scale_exp) every vouched row is only known to respect --
+    // small launches -- and the vouched-row path does not test it: a workgroup's budget is sized for at least 2^11 rows)
+    if (rows_log2 < 11) rows_log2 = 11;
     const int s = 46 + scale_exp - rows_log2;
     FixPoint f;
     f.magic = ldexp(1.5, 52 - s);

@@ -727,6 +727,29 @@ def test_assign_sums_one_pass_equals_two_passes(gpu, oracle, n, c, k, dtype):
     np.testing.assert_allclose(s3.cpu().numpy(), s1.cpu().numpy(), rtol=1e-13, atol=0)
 
 
+@pytest.mark.parametrize("n", [2_000, 20_000, 150_000])
+def test_assign_sums_small_launch_large_vouched_value(gpu, oracle, n):
+    """A row the filter VOUCHES for may hold values up to 2^16 / scale -- a hundred times the codebook's largest entry.
+    The fixed-point tables of a small launch (few rows per workgroup, hence many fractional bits) must still take it:
+    their limit used to fall below that bound when a workgroup met fewer than 2^11 rows (20 000 -> 18 192 in the sum)."""
+    c, k = 22, 100
+    x = synth.make_fov_numpy(n, c, seed=93, dtype=np.float32)
+    w = _codebook(x.astype(np.float64), k, seed=5)
+    wmax = float(np.abs(w).max())
+    x[800, 0] = 150.0 * wmax              # far from every node, yet inside the filter's range: not listed
+    x[801, 3] = -100.0 * wmax
+    xd, wd = torch.from_numpy(x).to(gpu), torch.from_numpy(w).to(gpu)
+    l2, _ = sd.assign(xd, wd)
+    listed = sd.last_exact_rows(sd.assign.last_workspace)
+    s2, c2 = sd.cluster_sums(xd, l2, k)
+    l1, s1, c1 = sd.assign_sums(xd, wd)
+    assert torch.equal(l1, l2) and torch.equal(c1, c2)
+    want, _ = oracle.map_data_to_nodes(w, x.astype(np.float64))
+    np.testing.assert_array_equal(l1.cpu().numpy(), want)
+    np.testing.assert_allclose(s1.cpu().numpy(), s2.cpu().numpy(), rtol=1e-6, atol=1e-9 * wmax * n)
+    assert listed < n // 10, listed       # (the two large rows must not owe their exact sums to the exact path alone)
+
+
 @pytest.mark.parametrize("dtype,offset,spread,collapse", [
     (np.float32, 100.0, 1.0, 1.0),      # a blob far from the origin: uncentred, every row is a near-tie
     (np.float32, 100.0, 1.0, 1e-3),     # ... and a codebook that has collapsed onto its mean (early training steps)
