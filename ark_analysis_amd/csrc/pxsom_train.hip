@@ -571,8 +571,10 @@ __global__ __launch_bounds__(256) void batch_update_kernel(double *w, int xdim, 
                                                            const double *__restrict__ sums,
                                                            const double *__restrict__ counts,
                                                            double thr, double lg, int stage,
-                                                           double *__restrict__ zero_out, int zero_count)
+                                                           double *__restrict__ zero_out, int zero_count,
+                                                           const double *w_src = nullptr)
 {
+    if (!w_src) w_src = w;   // (w_src != w: the updated codebook goes to w, the source stays as it is -- no copy launch)
     extern __shared__ __attribute__((aligned(16))) char upd_smem[];
     const int k = blockIdx.x, tid = threadIdx.x;
     // the OTHER statistics buffer (the next accumulate's target) is cleared here, a slice per workgroup
@@ -612,7 +614,7 @@ __global__ __launch_bounds__(256) void batch_update_kernel(double *w, int xdim, 
         boff = b_lo;
     }
     for (int j = tid; j < c; j += 256) {   // (wide rows: more channels than threads)
-        const double wv = w[(size_t)k * c + j];
+        const double wv = w_src[(size_t)k * c + j];
         // separable order of orc_batch_update: T[bx] = sum over the window's by (ascending), num = sum of T[bx]
         double num = 0.0, den = 0.0;
         for (int bx = x0; bx <= x1; bx++) {
@@ -632,6 +634,8 @@ __global__ __launch_bounds__(256) void batch_update_kernel(double *w, int xdim, 
             // gain == 1 exactly (wide windows): the node is the window mean itself, so nodes sharing a window are
             // bit-identical (and masked as duplicates by prep) instead of one ulp apart (orc_batch_update)
             w[(size_t)k * c + j] = gain == 1.0 ? num * inv : wv + gain * (num * inv - wv);
+        } else if (w_src != w) {
+            w[(size_t)k * c + j] = wv;
         }
     }
 }
@@ -1715,8 +1719,10 @@ int launch_gather(const T *x, int64_t n, int c, int64_t ldx, T *out, const Sched
 // The run's centring vector for the one-launch step's filter (AssignHdr::mu_s, DESIGN.md "K7 centring"): the mean of the
 // codebook the run starts from, per channel, in binary32.  Any vector keeps the search exact; this one stays close to the
 // nodes' mean for the whole run (they follow the data), so the steps need no reduction of their own for it.
-__global__ __launch_bounds__(256) void centring_vector_kernel(const double *__restrict__ w, int k, int c, float *__restrict__ mu32)
+__global__ __launch_bounds__(256) void centring_vector_kernel(const double *__restrict__ w, int k, int c, float *__restrict__ mu32,
+                                                              double *__restrict__ zero_out, int zero_count)
 {
+    for (int e = threadIdx.x; e < zero_count; e += 256) zero_out[e] = 0.0;   // the first step's statistics buffer (no memset launch)
     const int j = threadIdx.x >> 3, part = threadIdx.x & 7;   // 8 adjacent lanes share a channel (c <= 32)
     double sum = 0.0;
     if (j < c)
@@ -1785,9 +1791,13 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
     const bool fused_shape = !(flags & PXSOM_TRAIN_UNFUSED) &&
                              pxsom_bmu::step_fused_shape<T>(x, 1, c, ldx, xdim, ydim, (int64_t)sc.phases * ldx);
     float *mu32 = reinterpret_cast<float *>(ws + tw.off_mu);
-    if (fused_shape && g_begin == 0) {
-        hipLaunchKernelGGL(centring_vector_kernel, dim3(1), dim3(256), 0, st, wbuf, k, c, mu32);
-        PXSOM_LAUNCH_CHECK("centring_vector_kernel");
+    if (g_begin == 0) {   // the first step's statistics buffer; every later one is cleared by the step before it
+        if (fused_shape) {
+            hipLaunchKernelGGL(centring_vector_kernel, dim3(1), dim3(256), 0, st, wbuf, k, c, mu32, ring, (int)nstats);
+            PXSOM_LAUNCH_CHECK("centring_vector_kernel");
+        } else {
+            PXSOM_HIP_TRY(hipMemsetAsync(ring, 0, nstats * sizeof(double), st));
+        }
     }
     const bool gathered = !fused_shape && sc.any_wide();
     if (gathered && g_begin == 0 && n > 0) {
@@ -1985,8 +1995,6 @@ PXSOM_EXPORT int pxsom_batch_train_sched(const void *x_dev, int64_t n, int c, in
     if (!workspace_dev || workspace_bytes < need)
         return pxsom::fail(PXSOM_ERR_WORKSPACE, "pxsom_batch_train_sched: workspace %zu < %zu bytes", workspace_bytes, need);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (g_begin == 0)   // the first step's statistics buffer; every later one is cleared by the step before it
-        PXSOM_HIP_TRY(hipMemsetAsync(stats_ring_dev, 0, (size_t)xdim * ydim * (c + 1) * sizeof(double), st));
     const Sched sc{phases, steps_per_pass, edges};
     PXSOM_DISPATCH_DTYPE(dtype, x_dev, xp,
                          train_steps_typed<T>(xp, n, c, ldx, dtype, wbuf_dev, stats_ring_dev, xdim, ydim, sc, g_begin, g_end,
@@ -2028,11 +2036,15 @@ int finish_at(const double *wbuf_dev, const double *stats_ring_dev, int xdim, in
     const int k = xdim * ydim, g = steps_done - 1;
     const size_t nw = (size_t)k * c, nstats = (size_t)k * (c + 1);
     const double *w_last = wbuf_dev + (size_t)(g % 2) * nw, *s_last = stats_ring_dev + (size_t)(g % 3) * nstats;
-    if (w_out_dev != w_last)
-        PXSOM_HIP_TRY(hipMemcpyAsync(w_out_dev, w_last, nw * sizeof(double), hipMemcpyDeviceToDevice, st));
     double thr, alpha;
     batch_schedule(pos, span, a0, a1, r0, r1, &thr, &alpha);
-    return pxsom_batch_update(w_out_dev, xdim, ydim, c, s_last, s_last + nw, thr, alpha, stream);
+    // one launch: the update reads W of the last step where it lies and writes the result to w_out (no copy in front)
+    const size_t stage_bytes = (size_t)k * (c + 1) * sizeof(double);
+    const int stage = stage_bytes <= 60 * 1024;
+    hipLaunchKernelGGL(batch_update_kernel, dim3(k), dim3(256), stage ? stage_bytes : 0, st, w_out_dev, xdim, ydim, c, s_last,
+                       s_last + nw, thr, log1p(-alpha), stage, (double *)nullptr, 0, w_last);
+    PXSOM_LAUNCH_CHECK("batch_update_kernel");
+    return PXSOM_OK;
 }
 }  // namespace
 
