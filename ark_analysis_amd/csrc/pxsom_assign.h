@@ -9,7 +9,7 @@ namespace pxsom_bmu {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kHdrBytes = 256;
+constexpr int kHdrBytes = 1024;
 constexpr int kTilesPerIter = 4;  // 4 tiles x 16 pixels = one 64-row group per wave iteration
 constexpr float kNegBig = -3.0e38f;
 constexpr int kFilterMaxChannels = 128;   // the MFMA filter's row width (4 chunks of 32 slots); wider rows: bmu_wide_kernel
@@ -28,16 +28,16 @@ struct AssignHdr {
     int idx_bits;
     int node_bits;        // bits of the node index packed into the winner at the cross-lane merge
     int force_exact;      // codebook not representable by the filter: list every row
-    // Centred filter (register-resident kernels, c <= 32; DESIGN.md "K7 centring").  The filter ranks the nodes by
+    // Centred filter (register-resident kernels; round 4: the streamed kernel on binary32 / binary64 rows too; DESIGN.md "K7 centring").  The filter ranks the nodes by
     // X'.W' - |W'|^2 / 2 with X' = x * scale - mu_s, W' = w * scale - mu_s: the same ranking as by distance whatever mu_s
     // is, but every term of the error bound is relative to the norms of the centred vectors.  mu_s = 0: off.
     float wn_raw;         // max_k |w_k|_2 (unscaled, uncentred, rounded up): the screened exact kernel's rounding bound
     int fix_exp;          // every row the filter vouches for has |x_j| < 2^(16 - fix_exp) (fixed-point tables)
     int centred;
-    float mu_s[32];       // centring vector in scaled units (a binary32 number times the power-of-two scale: exact)
+    float mu_s[kFilterMaxChannels];   // centring vector in scaled units (a binary32 number times the power-of-two scale: exact)
     float tol_rel_coarse; // tol_rel of the register-resident filter's first stage (Wh*Xh alone)
 };
-static_assert(sizeof(AssignHdr) <= 256, "workspace header");
+static_assert(sizeof(AssignHdr) <= kHdrBytes, "workspace header");
 
 // the pending update a fused mini-batch step applies at its head, and its housekeeping (pxsom_batch_step.hip)
 struct StepArgs {
@@ -82,7 +82,7 @@ struct TailArgs {
     double *w_final;           // final_update: [k, c]
     char *scratch;             // tail_scratch_bytes(c): control words, member tables, published codebook
     float tol_rel, tol_abs;
-    const float *mu32;         // centring vector (33 words) or NULL
+    const float *mu32;         // centring vector (kFilterMaxChannels words + its norm) or NULL
     double qmagic;
     TailStep st[kMaxTailSteps];
 };

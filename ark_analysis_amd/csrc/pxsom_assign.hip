@@ -615,8 +615,9 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
                            L.nb, L.nch, L.cpl, L.idx_bits, L.node_bits, stage, (double *)nullptr, 0,
                            L.has_wt() ? reinterpret_cast<double *>(ws + L.off_wt) : nullptr,
                            reinterpret_cast<float *>(ws + L.off_w32), L.cp32, L.npk,
-                           // the register-resident filter centres rows and codebook (the only reader of AssignHdr::mu_s)
-                           filter_fast_path<T>(x, n, c, ldx, L) ? 1 : 0);
+                           // the filters centre rows and codebook (AssignHdr::mu_s) -- all but the streamed one on binary16
+                           // rows, whose two-term split needs x * scale to BE a binary16 number
+                           (filter_fast_path<T>(x, n, c, ldx, L) || (sizeof(T) != 2 && L.npk == 0)) ? 1 : 0);
         PXSOM_LAUNCH_CHECK("bmu_prep_kernel");
     }
 

@@ -70,7 +70,9 @@ __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_kernel(
     // factor-of-two margin, remains): E shrinks from (2^-21 + (3C+2) 2^-24 + 2^-19 + 2^-23) to
     // (2^-21 + (2C+2) 2^-24 + 2^-21 + 2^-23) times the same norms, ~40 % at C = 40, and with it the rows listed.
     // Only a codebook whose largest entry exceeds 128 makes scale < 1, where tiny x could lose bits: the full split.
-    const bool lo_needed = sizeof(T) != 2 || scale < 1.f;
+    // (a centred workspace -- binary32 / binary64 rows only, pxsom_assign.hip -- keeps the full split: x * scale - mu_s is not
+    // a binary16 number)
+    const bool lo_needed = sizeof(T) != 2 || scale < 1.f || hdr->centred != 0;
     if (!lo_needed) tol_rel -= 2.5f * ((float)c * 0x1p-24f + (0x1p-19f - 0x1p-21f));
 
     const int lane = threadIdx.x & 63;
@@ -126,6 +128,21 @@ __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_kernel(
         }
     }
 
+    // the centring vector at this lane's channel slots, scaled (AssignHdr::mu_s: zeros when the workspace was prepared
+    // without it -- the fused operation below then IS the plain product, bit for bit)
+    float mus[NCH][CPLMAX];
+#pragma unroll
+    for (int h = 0; h < NCH; h++) {
+#pragma unroll
+        for (int i = 0; i < CPLMAX; i++) {
+            int ch = choff[h][i];
+            if constexpr (VEC2) {
+                if (i & 1) ch = choff[h][i - (i & 1)] + 1;   // pairs are addressed by their even slot
+            }
+            mus[h][i] = hdr->mu_s[ch < kFilterMaxChannels ? ch : 0];
+        }
+    }
+
     // dst[h][i]: channel h*4*cpl + q*cpl + i of row g*64 + t*16 + pix
     auto load_tile = [&](int64_t g, int t, T(&dst)[NCH][CPLMAX]) {
         int64_t row = g * 64 + t * 16 + pix;
@@ -156,8 +173,14 @@ __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_kernel(
         for (int h = 0; h < NCH; h++) {
 #pragma unroll
             for (int i = 0; i < 8; i++) {
+                // x' = fl(x * scale - mu_s): one rounding (binary64 rows: formed in binary64, then rounded once more)
                 float xf = 0.f;
-                if (i < CPLMAX) xf = (float)src[h][i < CPLMAX ? i : 0] * scale;
+                if (i < CPLMAX) {
+                    if constexpr (sizeof(T) == 8)
+                        xf = (float)__builtin_fma((double)src[h][i < CPLMAX ? i : 0], (double)scale, -(double)mus[h][i < CPLMAX ? i : 0]);
+                    else
+                        xf = fmaf((float)src[h][i < CPLMAX ? i : 0], scale, -mus[h][i < CPLMAX ? i : 0]);
+                }
                 acc2 = fmaf(xf, xf, acc2);
                 const _Float16 hi = (_Float16)xf;
                 bh[h][i] = hi;

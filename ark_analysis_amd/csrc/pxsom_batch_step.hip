@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
     float mu_word = 0.f;
     const int NC = c + 1;
     auto load_centring = [&]() {
-        if (tid < 33 && sa.mu32) mu_word = sa.mu32[tid];
+        if (tid < 33 && sa.mu32) mu_word = sa.mu32[tid < 32 ? tid : kFilterMaxChannels];   // 32 channels + the vector's norm
     };
     auto park_centring = [&]() {
         if (tid < 40) mu_l[tid] = mu_word;
@@ -623,9 +623,10 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
     const int NC = c + 1;
     double *tl = reinterpret_cast<double *>(upd_smem);                       // [K * NC] window sums; then W_new [K][c]
     unsigned long long *key = reinterpret_cast<unsigned long long *>(tl + (size_t)K * NC);   // [K]
-    double *red = reinterpret_cast<double *>(key + K);                       // [2 * waves]
-    float *biasv = reinterpret_cast<float *>(red + 2 * kUpdWaves);           // [K]
+    double *red = reinterpret_cast<double *>(key + K);                       // [3 * waves]
+    float *biasv = reinterpret_cast<float *>(red + 3 * kUpdWaves);           // [K]
     int *flags = reinterpret_cast<int *>(biasv + K);                         // [0]: NaN / Inf met
+    float *s_mu = reinterpret_cast<float *>(flags + 16);                     // [128] the run's centring vector (zeros: not centred)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int parts = 1 << parts_log2;
     const int node = tid >> parts_log2, part = tid & (parts - 1);
@@ -651,6 +652,8 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
 #pragma unroll
     for (int u = 0; u < kE; u++) wold[u] = sa.w_in[(u < ne && tid + kUpdThreads * u < K * c) ? tid + kUpdThreads * u : 0];
     if (tid == 0) flags[0] = 0;
+    if (tid < kFilterMaxChannels) s_mu[tid] = (sa.mu32 && tid < c) ? sa.mu32[tid] : 0.f;
+    const float mu_norm = sa.mu32 ? sa.mu32[kFilterMaxChannels] : 0.f;
     // Several workgroups run this kernel: each redoes the update and the norms (they need all of it, and it stays in
     // their own LDS: no traffic between workgroups), and takes a share of the OUTPUT -- node blocks [b0, b1) of the
     // duplicate test, fragments, bias and the two codebook copies; workgroup 0 also writes W_g and the header.
@@ -742,7 +745,7 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
     __syncthreads();
 
     // ---- norms, keys, maxima: thread <-> (node, part) over the LDS copy
-    double nrm = 0.0, mymax = 0.0, wv_[CPP];
+    double nrm = 0.0, raw2 = 0.0, mymax = 0.0, wv_[CPP];   // (nrm, mymax: of the centred node)
     unsigned long long kkey = 0;
     bool bad = false;
 #pragma unroll
@@ -753,8 +756,10 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
             const double v = tl[(size_t)node * c + ch];
             wv_[i] = v;
             bad |= !(fabs(v) <= DBL_MAX);
-            nrm += v * v;
-            mymax = fmax(mymax, fabs(v));
+            const double vc = v - (double)s_mu[ch < kFilterMaxChannels ? ch : 0];
+            nrm += vc * vc;
+            raw2 += v * v;
+            mymax = fmax(mymax, fabs(vc));
             const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
             const int rot = (7 * ch + 1) & 63;
             kkey ^= (bits << rot) | (bits >> ((64 - rot) & 63));
@@ -762,6 +767,7 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
     }
     for (int m = 1; m < parts; m <<= 1) {   // the lanes of a node are adjacent: butterfly
         nrm += __shfl_xor(nrm, m);
+        raw2 += __shfl_xor(raw2, m);
         kkey ^= __shfl_xor(kkey, m);
     }
     PXSOM_PHASE(6);
@@ -771,23 +777,31 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
     {
         const double wmax = -pxsom::wave_min_f64(-mymax);
         const double nmax = -pxsom::wave_min_f64(-((has_node && nrm == nrm) ? nrm : 0.0));
+        const double rmax = -pxsom::wave_min_f64(-((has_node && raw2 == raw2) ? raw2 : 0.0));
         if (lane == 0) {
             red[wv] = wmax;
             red[kUpdWaves + wv] = nmax;
+            red[2 * kUpdWaves + wv] = rmax;
         }
     }
     __syncthreads();
-    double maxabs = red[0], wn2max = red[kUpdWaves];
+    double maxabs = red[0], wn2max = red[kUpdWaves], raw2max = red[2 * kUpdWaves];
 #pragma unroll
     for (int i = 1; i < kUpdWaves; i++) {
         maxabs = fmax(maxabs, red[i]);
         wn2max = fmax(wn2max, red[kUpdWaves + i]);
+        raw2max = fmax(raw2max, red[2 * kUpdWaves + i]);
     }
     int e = 0;
     if (maxabs > 0.0 && maxabs <= DBL_MAX) {
         int ex;
         frexp(maxabs, &ex);
         e = 8 - ex;
+        if (mu_norm > 0.f) {   // a codebook collapsed onto the centring vector must not blow the scale up (batch_step_kernel P4)
+            int exn;
+            frexpf(mu_norm, &exn);
+            if (e > 8 - exn + 6) e = 8 - exn + 6;
+        }
         if (e > 100) e = 100;
         if (e < -100) e = -100;
     }
@@ -808,12 +822,17 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
         hdr_g->cpl = cpl;
         hdr_g->idx_bits = idx_bits;
         hdr_g->node_bits = idx_bits;
-        // the generic filters are not centred: the uncentred norm is the norm
-        hdr_g->wn_raw = badw ? 0.f : (float)(sqrt(wn2max) * (1.0 + 1e-6));
-        hdr_g->fix_exp = e;
-        hdr_g->centred = 0;
+        // (the screened exact kernel's rounding bound is on the raw vectors)
+        hdr_g->wn_raw = badw ? 0.f : (float)(sqrt(raw2max) * (1.0 + 1e-6));
+        // a row the filter vouches for has |x_j * scale| < x_limit + max_j |mu_s_j| (pxsom_prep.h)
+        double mumax = 0.0;
+        for (int j = 0; j < (c < kFilterMaxChannels ? c : kFilterMaxChannels); j++) mumax = fmax(mumax, fabs((double)s_mu[j]) * scale);
+        int t = 0;
+        while (t < 60 && !(60000.0 + mumax <= ldexp(65536.0, t))) t++;
+        hdr_g->fix_exp = e - t;
+        hdr_g->centred = sa.mu32 ? 1 : 0;
     }
-    if (blockIdx.x == 0 && tid < 32) hdr_g->mu_s[tid] = 0.f;
+    if (blockIdx.x == 0 && tid < kFilterMaxChannels) hdr_g->mu_s[tid] = (float)((double)s_mu[tid] * scale);
     PXSOM_PHASE(7);
     // ---- exact duplicates of an earlier node: key scan shared by the node's lanes, then channel-by-channel
     if (has_node && node >= n0 && node < n1) {
@@ -851,7 +870,7 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 float W = 0.f;
-                if (term < 2 && nd < K) W = (float)(tl[(size_t)nd * c + ch0 + i] * scale);
+                if (term < 2 && nd < K) W = (float)(tl[(size_t)nd * c + ch0 + i] * scale);   // (packed K: binary16 rows, never centred)
                 const _Float16 hi = (_Float16)W;
                 fr[i] = term == 0 ? hi : (_Float16)(W - (float)hi);
             }
@@ -868,7 +887,7 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
         for (int i = 0; i < 8; i++) {
             const int ch = h * 4 * cpl + q * cpl + i;
             float W = 0.f;
-            if (i < cpl && ch < c && nd < K) W = (float)(tl[(size_t)nd * c + ch] * scale);
+            if (i < cpl && ch < c && nd < K) W = (float)((tl[(size_t)nd * c + ch] - (double)s_mu[ch < kFilterMaxChannels ? ch : 0]) * scale);
             const _Float16 hi = (_Float16)W;
             fhi[i] = hi;
             flo[i] = (_Float16)(W - (float)hi);
@@ -977,7 +996,7 @@ bool launch_update_prepare(const StepArgs &sa, int xdim, int ydim, int c, char *
     while ((k << (pl + 1)) <= kUpdThreads && pl < 3) pl++;
     const int parts = 1 << pl, cpp = (c + parts - 1) / parts;
     if (cpp > 20 || xdim * (c + 1) > kUpdThreads || (k * c + kUpdThreads - 1) / kUpdThreads > 16) return false;
-    const size_t lds = ((size_t)k * (c + 1) + k + 2 * kUpdWaves) * 8 + (size_t)k * 4 + 64;
+    const size_t lds = ((size_t)k * (c + 1) + k + 3 * kUpdWaves) * 8 + (size_t)k * 4 + 64 + kFilterMaxChannels * 4;
     if (lds > 158 * 1024) return false;
     auto kern = xdim == 10 ? batch_update_prep_kernel<10, 10, 20> : batch_update_prep_kernel<20, 20, 20>;
     static pxsom::PerDevice<size_t> attr[2];

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(kTailThreads) void batch_tail_kernel(const T *__res
     load_round(ta.st[0], 0);
 
     // ---- one-off set-up --------------------------------------------------------------------------------------------
-    if (tid < 40) mu_l[tid] = (tid < 33 && ta.mu32) ? ta.mu32[tid] : 0.f;
+    if (tid < 40) mu_l[tid] = (tid < 33 && ta.mu32) ? ta.mu32[tid < 32 ? tid : kFilterMaxChannels] : 0.f;   // 32 channels + the norm
     for (int e = tid; e < nstats; e += kTailThreads) ls[e] = 0.0;
     if (tid == 0) {
         hdr->q_n = 0u;

@@ -85,24 +85,27 @@ __device__ __forceinline__ void prep_body(const double *wl, int k, int c, Assign
     __shared__ double s_norm2[MAXK];
     __shared__ unsigned long long s_key[MAXK];  // hash of the row's bit patterns (duplicate test)
     __shared__ double s_red[3 * (NT / 64)];
-    __shared__ double s_mud[32];   // centring vector (unscaled; binary32-representable values): zeros when off
+    __shared__ double s_mud[kFilterMaxChannels];   // centring vector (unscaled; binary32-representable values): zeros when off
     __shared__ int s_bad;
     const int tid = threadIdx.x;
     if (tid == 0) s_bad = 0;
-    if (tid < 32) s_mud[tid] = 0.0;
+    for (int j = tid; j < kFilterMaxChannels; j += NT) s_mud[j] = 0.0;
     __syncthreads();
-    // centring (register-resident filters only: c <= 32): mu = the nodes' mean per channel, rounded to binary32 -- any
-    // vector would do for the ranking, the mean keeps the centred norms (what the error bound is relative to) small.
-    // NT / 32 adjacent lanes share a channel.
+    // centring (every filter but the one on binary16 rows, c <= 128): mu = the nodes' mean per channel, rounded to binary32 --
+    // any vector would do for the ranking, the mean keeps the centred norms (what the error bound is relative to) small.
+    // NT / 128 adjacent lanes share a channel.
     if (center) {
-        constexpr int per = NT / 32;
+        constexpr int per = NT / kFilterMaxChannels;
         const int j = tid / per, part = tid % per;
         double sum = 0.0;
         if (j < c)
             for (int node = part; node < k; node += per) sum += wl[(size_t)node * c + j];
 #pragma unroll
         for (int d = 1; d < per; d *= 2) sum += __shfl_xor(sum, d);
-        if (part == 0 && j < c) s_mud[j] = (double)(float)(sum / (double)k);
+        if (part == 0 && j < c) {
+            const float m = (float)(sum / (double)k);
+            s_mud[j] = fabsf(m) <= 3.0e38f ? (double)m : 0.0;   // (a non-finite codebook lists every row anyway)
+        }
         __syncthreads();
     }
 
@@ -119,7 +122,7 @@ __device__ __forceinline__ void prep_body(const double *wl, int k, int c, Assign
         unsigned long long key = 0;
         for (int j = part; j < c; j += parts) {
             const double vr = wl[(size_t)node * c + j];
-            const double v = vr - s_mud[j < 32 ? j : 0];   // (zeros when the filter is not centred: v == vr, bit for bit)
+            const double v = vr - s_mud[j < kFilterMaxChannels ? j : 0];   // (zeros when the filter is not centred: v == vr, bit for bit)
             bad |= !(fabs(vr) <= DBL_MAX);  // NaN / Inf in the codebook
             sum += v * v;
             raw2 += vr * vr;
@@ -217,12 +220,12 @@ __device__ __forceinline__ void prep_body(const double *wl, int k, int c, Assign
         // a row the filter vouches for has |x' * scale|_2 < x_limit, hence |x_j * scale| < x_limit + max_j |mu_s_j|:
         // below 2^(16 + t) for the smallest such t >= 0
         double mumax = 0.0;
-        for (int j = 0; j < (c < 32 ? c : 32); j++) mumax = fmax(mumax, fabs(s_mud[j]) * scale);
+        for (int j = 0; j < (c < kFilterMaxChannels ? c : kFilterMaxChannels); j++) mumax = fmax(mumax, fabs(s_mud[j]) * scale);
         int t = 0;
         while (t < 60 && !(60000.0 + mumax <= ldexp(65536.0, t))) t++;
         hdr->fix_exp = e - t;
     }
-    if (tid < 32) hdr->mu_s[tid] = (float)(s_mud[tid] * scale);
+    for (int j = tid; j < kFilterMaxChannels; j += NT) hdr->mu_s[j] = (float)(s_mud[j] * scale);
 
     // A-fragments: wfrag[(b*nsteps + s)*64 + lane], lane = (q<<4 | m): node 16b+m,
     // slot i of lane group q in chunk h <-> channel h*4*cpl + q*cpl + i (i < cpl); s = 2h: hi, 2h+1: lo
@@ -255,7 +258,7 @@ __device__ __forceinline__ void prep_body(const double *wl, int k, int c, Assign
         for (int i = 0; i < 8; i++) {
             const int ch = h * 4 * cpl + q * cpl + i;
             float W = 0.f;
-            if (i < cpl && ch < c && node < k) W = (float)((wl[(size_t)node * c + ch] - s_mud[ch < 32 ? ch : 0]) * scale);
+            if (i < cpl && ch < c && node < k) W = (float)((wl[(size_t)node * c + ch] - s_mud[ch < kFilterMaxChannels ? ch : 0]) * scale);
             const _Float16 hi = (_Float16)W;
             fhi[i] = hi;
             flo[i] = (_Float16)(W - (float)hi);

@@ -1723,24 +1723,22 @@ __global__ __launch_bounds__(256) void centring_vector_kernel(const double *__re
                                                               double *__restrict__ zero_out, int zero_count)
 {
     for (int e = threadIdx.x; e < zero_count; e += 256) zero_out[e] = 0.0;   // the first step's statistics buffer (no memset launch)
-    const int j = threadIdx.x >> 3, part = threadIdx.x & 7;   // 8 adjacent lanes share a channel (c <= 32)
+    const int j = threadIdx.x >> 1, part = threadIdx.x & 1;   // 2 adjacent lanes share a channel (c <= 128)
     double sum = 0.0;
     if (j < c)
-        for (int node = part; node < k; node += 8) sum += w[(size_t)node * c + j];
+        for (int node = part; node < k; node += 2) sum += w[(size_t)node * c + j];
     sum += __shfl_xor(sum, 1);
-    sum += __shfl_xor(sum, 2);
-    sum += __shfl_xor(sum, 4);
     float m = (float)(sum / (double)k);
     if (!(j < c && fabsf(m) <= 3.0e38f)) m = 0.f;   // a non-finite codebook: not centred (every row is listed anyway)
     if (part == 0) mu32[j] = m;
-    // word 32: the vector's norm (the steps cap their power-of-two scale with it: pxsom_batch_step.hip)
-    __shared__ float s_m[32];
+    // word 128: the vector's norm (the steps cap their power-of-two scale with it: pxsom_batch_step.hip)
+    __shared__ float s_m[pxsom_bmu::kFilterMaxChannels];
     if (part == 0) s_m[j] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
         double n2 = 0.0;
-        for (int i = 0; i < 32; i++) n2 += (double)s_m[i] * (double)s_m[i];
-        mu32[32] = (float)sqrt(n2);
+        for (int i = 0; i < pxsom_bmu::kFilterMaxChannels; i++) n2 += (double)s_m[i] * (double)s_m[i];
+        mu32[pxsom_bmu::kFilterMaxChannels] = (float)sqrt(n2);
     }
 }
 
@@ -1753,8 +1751,8 @@ inline TrainWs train_ws(int64_t n, int c, int k, size_t esize, const Sched &sc)
     const int64_t rmax = sc.rows_max(n);
     w.assign_ws = pxsom_assign_workspace_bytes(rmax, c, k);
     w.off_labels = pxsom::align_up(w.assign_ws, 256);
-    w.off_mu = w.off_labels + pxsom::align_up((size_t)(rmax > 0 ? rmax : 1) * sizeof(int32_t), 256);   // 33 floats: the run's centring vector and its norm
-    w.off_gather = w.off_mu + 256;
+    w.off_mu = w.off_labels + pxsom::align_up((size_t)(rmax > 0 ? rmax : 1) * sizeof(int32_t), 256);
+    w.off_gather = w.off_mu + 1024;   // 129 floats: the run's centring vector (c <= 128) and its norm
     w.off_tail = w.off_gather + (sc.any_wide() ? pxsom::align_up((size_t)(n > 0 ? n : 1) * c * esize, 256) : 0);
     // the persistent BMU-only tail's scratch (control words, member tables, published codebook: pxsom_batch_tail.hip)
     w.total = w.off_tail + ((k == 100 && c <= 32) ? pxsom_bmu::tail_scratch_bytes(c) : 0);
@@ -1791,8 +1789,10 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
     const bool fused_shape = !(flags & PXSOM_TRAIN_UNFUSED) &&
                              pxsom_bmu::step_fused_shape<T>(x, 1, c, ldx, xdim, ydim, (int64_t)sc.phases * ldx);
     float *mu32 = reinterpret_cast<float *>(ws + tw.off_mu);
+    // rows of 2-byte floats on the generic route keep the uncentred two-term split (pxsom_assign_filter.hip)
+    const bool centred_run = fused_shape || (sizeof(T) != 2 && c <= pxsom_bmu::kFilterMaxChannels && !(flags & PXSOM_TRAIN_UNFUSED));
     if (g_begin == 0) {   // the first step's statistics buffer; every later one is cleared by the step before it
-        if (fused_shape) {
+        if (centred_run) {
             hipLaunchKernelGGL(centring_vector_kernel, dim3(1), dim3(256), 0, st, wbuf, k, c, mu32, ring, (int)nstats);
             PXSOM_LAUNCH_CHECK("centring_vector_kernel");
         } else {
@@ -1883,8 +1883,11 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
             sa.has_update = gg > 0 ? 1 : 0;
             sa.thr = thr;
             sa.lg = log1p(-alpha);
+            // the generic filter is centred on the run's vector too (binary32 / binary64 rows): + 2^-24, the rounding of
+            // x' = fl(x * scale - mu_s)
+            sa.mu32 = (centred_run && !no_centre && npk == 0) ? mu32 : nullptr;
             sa.tol_rel = (float)(2.5 * (ldexp(1.0, -(23 - L.idx_bits)) + (3.0 * c + 2.0) * ldexp(1.0, -24) + ldexp(1.0, -19) +
-                                        ldexp(1.0, -23)));
+                                        ldexp(1.0, -23) + (sa.mu32 ? ldexp(1.0, -24) : 0.0)));
             sa.tol_abs = (float)(2.5 * ldexp(1.0, -24) * sqrt((double)c));
             int rc = PXSOM_OK;
             if (pxsom_bmu::launch_update_prepare(sa, xdim, ydim, c, ws, L, st, &rc)) {
