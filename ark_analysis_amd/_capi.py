@@ -23,7 +23,7 @@ _STATUS = {0: "PXSOM_OK", -1: "PXSOM_ERR_INVALID_ARG", -2: "PXSOM_ERR_UNSUPPORTE
 # every symbol include/pxsom.h declares: (restype, argtypes)
 _vp, _i32, _i64, _f64, _sz = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double,
                               ctypes.c_size_t)
-ABI_VERSION = 7  # include/pxsom.h PXSOM_ABI_VERSION
+ABI_VERSION = 8  # include/pxsom.h PXSOM_ABI_VERSION
 
 SYMBOLS = {
     "pxsom_abi_version": (_i32, []),
@@ -39,6 +39,8 @@ SYMBOLS = {
     "pxsom_cluster_sums": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _i32, _vp, _vp, _vp]),
     "pxsom_train_online": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _i32, _i32, _i32, _f64, _f64,
                                   _f64, _f64, _vp, _vp]),
+    "pxsom_train_online_ex": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _i32, _i32, _i32, _f64, _f64,
+                                     _f64, _f64, _vp, _i32, _vp]),
     "pxsom_batch_accumulate": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _sz, _i32, _vp]),
     "pxsom_quantile_f32": (_i32, [_vp, _i64, _i32, _i64, _f64, _i32, _vp, _vp, _sz, _vp]),
     "pxsom_scaled_rowsum_f32": (_i32, [_vp, _i64, _i32, _i64, _vp, _vp, _vp]),

@@ -37,12 +37,20 @@ using pxsom::wave_min_u32;
 // codebooks past the LDS (K * C * 8 > ~150 KB, e.g. 264 nodes x 128 channels) are trained in place in w
 // (every thread touches only its own node's row; L2-resident, a few microseconds per step).
 // ------------------------------------------------------------------------------------------------
+// One term of FlowSOM's `change` accumulator (only ever consulted at the start of a pass, when rlen > 1).  The build reads the
+// published loop as `change += fabs(tmp)`; PXSOM_ONLINE_INT_ABS is the other recollection -- C's integer abs(), i.e. the
+// double truncated towards zero first, which makes every |tmp| < 1 count as 0 (oracle: ORC_V_INT_ABS).
+__device__ __forceinline__ double change_term(double tmp, int flags)
+{
+    return ((flags & PXSOM_ONLINE_INT_ABS) && fabs(tmp) < 2147483648.0) ? (double)abs((int)tmp) : fabs(tmp);
+}
+
 template <typename T, int CMAX, int MAXT, bool GLB = false>
 __global__ __launch_bounds__(MAXT) void som_online_kernel(const T *__restrict__ x, int64_t n, int c,
                                                           int64_t ldx, double *w, int xdim, int ydim,
                                                           int rlen, double a0, double a1, double r0,
                                                           double r1, const int64_t *__restrict__ order,
-                                                          int chunk)
+                                                          int chunk, int flags)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int K = xdim * ydim;
@@ -243,14 +251,14 @@ __global__ __launch_bounds__(MAXT) void som_online_kernel(const T *__restrict__ 
 #pragma unroll
                         for (int j = 0; j < CMAX; j++) {
                             const double tmp = xreg[j] - wr[j];
-                            if (track) mychange += fabs(tmp);  // only ever consulted when rlen > 1
+                            if (track) mychange += change_term(tmp, flags);  // only ever consulted when rlen > 1
                             wr[j] = wr[j] + tmp * alpha;
                         }
                     } else {
                         for (int j = 0; j < c; j++) {
                             const double wv_ = wref(j);
                             const double tmp = xr[j] - wv_;
-                            mychange += fabs(tmp);
+                            mychange += change_term(tmp, flags);
                             wref(j) = wv_ + tmp * alpha;
                         }
                     }
@@ -312,7 +320,7 @@ __global__ __launch_bounds__(CH * L > 40 ? 512 : 256) void som_online_split_kern
                                                                int64_t ldx, double *w, int xdim, int ydim,
                                                                int rlen, double a0, double a1, double r0,
                                                                double r1, const int64_t *__restrict__ order,
-                                                               int chunk)
+                                                               int chunk, int flags)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int CMAX = CH * L;
@@ -539,7 +547,7 @@ __global__ __launch_bounds__(CH * L > 40 ? 512 : 256) void som_online_split_kern
                 for (int j = 0; j < CH; j++) wr[j] = wr[j] + tmp[j] * alpha;
                 if (track) {  // only ever consulted when rlen > 1
 #pragma unroll
-                    for (int j = 0; j < CH; j++) mychange += fabs(tmp[j]);
+                    for (int j = 0; j < CH; j++) mychange += change_term(tmp[j], flags);
                 }
             }
             threshold -= thresholdStep;
@@ -909,7 +917,7 @@ __global__ __launch_bounds__(NT) void cluster_sums_kernel(const T *__restrict__ 
 
 template <typename T, int CMAX, int MAXT>
 int launch_online(const T *x, int64_t n, int c, int64_t ldx, double *w, int xdim, int ydim, int rlen, double a0,
-                  double a1, double r0, double r1, const int64_t *order, hipStream_t st)
+                  double a1, double r0, double r1, const int64_t *order, int flags, hipStream_t st)
 {
     const int K = xdim * ydim;
     const int bd = ((K + 63) / 64) * 64;
@@ -940,7 +948,7 @@ int launch_online(const T *x, int64_t n, int c, int64_t ldx, double *w, int xdim
         PXSOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(1), dim3(bd), lds, st, x, n, c, ldx, w, xdim, ydim, rlen, a0, a1, r0, r1,
-                           order, chunk);
+                           order, chunk, flags);
         PXSOM_LAUNCH_CHECK("som_online_kernel");
         return PXSOM_OK;
     };
@@ -952,7 +960,7 @@ int launch_online(const T *x, int64_t n, int c, int64_t ldx, double *w, int xdim
 
 template <typename T, int CH, int L>
 int launch_online_split(const T *x, int64_t n, int c, int64_t ldx, double *w, int xdim, int ydim, int rlen,
-                        double a0, double a1, double r0, double r1, const int64_t *order, hipStream_t st)
+                        double a0, double a1, double r0, double r1, const int64_t *order, int flags, hipStream_t st)
 {
     const int K = xdim * ydim;
     const int bd = ((K * L + 63) / 64) * 64;
@@ -965,19 +973,19 @@ int launch_online_split(const T *x, int64_t n, int c, int64_t ldx, double *w, in
         PXSOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(1), dim3(bd), lds, st, x, n, c, ldx, w, xdim, ydim, rlen, a0, a1, r0, r1,
-                       order, chunk);
+                       order, chunk, flags);
     PXSOM_LAUNCH_CHECK("som_online_split_kernel");
     return PXSOM_OK;
 }
 
 template <typename T>
 int train_online_typed(const T *x, int64_t n, int c, int64_t ldx, double *w, int xdim, int ydim, int rlen,
-                       double a0, double a1, double r0, double r1, const int64_t *order, hipStream_t st)
+                       double a0, double a1, double r0, double r1, const int64_t *order, int flags, hipStream_t st)
 {
 #define PXSOM_ONLINE(CM, MT) \
-    return launch_online<T, CM, MT>(x, n, c, ldx, w, xdim, ydim, rlen, a0, a1, r0, r1, order, st)
+    return launch_online<T, CM, MT>(x, n, c, ldx, w, xdim, ydim, rlen, a0, a1, r0, r1, order, flags, st)
 #define PXSOM_ONLINE_SPLIT(CH, L) \
-    return launch_online_split<T, CH, L>(x, n, c, ldx, w, xdim, ydim, rlen, a0, a1, r0, r1, order, st)
+    return launch_online_split<T, CH, L>(x, n, c, ldx, w, xdim, ydim, rlen, a0, a1, r0, r1, order, flags, st)
     // small maps: several lanes per node (fewer binary64 instructions per wave per step)
     if (xdim * ydim <= 64 && c <= 40) {
         if (c <= 16) PXSOM_ONLINE_SPLIT(4, 4);
@@ -1299,9 +1307,9 @@ int check_matrix(const char *fn, const void *x, int64_t n, int c, int64_t ldx, i
 
 }  // namespace
 
-PXSOM_EXPORT int pxsom_train_online(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, double *w_dev,
-                                    int xdim, int ydim, int rlen, double a0, double a1, double r0, double r1,
-                                    const int64_t *order_dev, void *stream)
+PXSOM_EXPORT int pxsom_train_online_ex(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, double *w_dev,
+                                       int xdim, int ydim, int rlen, double a0, double a1, double r0, double r1,
+                                       const int64_t *order_dev, int flags, void *stream)
 {
     int rc = check_matrix("pxsom_train_online", x_dev, n, c, ldx, dtype);
     if (rc) return rc;
@@ -1309,11 +1317,19 @@ PXSOM_EXPORT int pxsom_train_online(const void *x_dev, int64_t n, int c, int64_t
         return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "pxsom_train_online: grid %dx%d outside [1, %d] nodes", xdim,
                            ydim, PXSOM_MAX_NODES);
     if (rlen < 0 || !w_dev) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_train_online: bad rlen / null codebook");
+    if (flags & ~PXSOM_ONLINE_INT_ABS) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_train_online: unknown flags %d", flags);
     if (n == 0 || rlen == 0) return PXSOM_OK;
     if (!order_dev) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_train_online: null order");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     PXSOM_DISPATCH_DTYPE(dtype, x_dev, xp,
-                         train_online_typed<T>(xp, n, c, ldx, w_dev, xdim, ydim, rlen, a0, a1, r0, r1, order_dev, st));
+                         train_online_typed<T>(xp, n, c, ldx, w_dev, xdim, ydim, rlen, a0, a1, r0, r1, order_dev, flags, st));
+}
+
+PXSOM_EXPORT int pxsom_train_online(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, double *w_dev,
+                                    int xdim, int ydim, int rlen, double a0, double a1, double r0, double r1,
+                                    const int64_t *order_dev, void *stream)
+{
+    return pxsom_train_online_ex(x_dev, n, c, ldx, dtype, w_dev, xdim, ydim, rlen, a0, a1, r0, r1, order_dev, 0, stream);
 }
 
 PXSOM_EXPORT int pxsom_cluster_sums(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype,

@@ -37,6 +37,8 @@ RECALLED = {
                                    "int(n * random_sample()) of that stream"),
     "init_rule": ("numpy_choice", "initial nodes = data[RandomState(seed).choice(n, K, replace=False)]"),
     "node_order": ("xy", "node k = x*ydim + y ('yx': k = y*xdim + x)"),
+    "change_abs": ("fabs", "the early-stop accumulator adds fabs(x - w) ('int_abs': C's integer abs(), which truncates "
+                           "every |x - w| < 1 to 0 -- a run with rlen >= 2 on normalised data then stops at its second pass)"),
 }
 
 
@@ -79,8 +81,9 @@ def _as_device_matrix(data, device):
 
 def som_with_inputs(data, init_nodes, order, xdim: int = 10, ydim: int = 10, rlen: int = 10,
                     alpha_range: Sequence[float] = (0.05, 0.01),
-                    radius_range: Optional[Sequence[float]] = None) -> np.ndarray:
-    """Exact online SOM with explicit initial nodes [K, C] and presentation order [n*rlen]."""
+                    radius_range: Optional[Sequence[float]] = None, change_abs: Optional[str] = None) -> np.ndarray:
+    """Exact online SOM with explicit initial nodes [K, C] and presentation order [n*rlen].  ``change_abs``: one of the
+    alternatives of :data:`RECALLED` (default: the build's reading)."""
     import torch
     from . import _capi, som_device
     dev = _capi.require_gpu()
@@ -89,7 +92,10 @@ def som_with_inputs(data, init_nodes, order, xdim: int = 10, ydim: int = 10, rle
     od = torch.from_numpy(np.ascontiguousarray(order, dtype=np.int64)).to(dev)
     if radius_range is None:
         radius_range = default_radius_range(xdim, ydim)
-    som_device.train_online(x, w, xdim, ydim, rlen, alpha_range, radius_range, od)
+    reading = RECALLED["change_abs"][0] if change_abs is None else change_abs
+    if reading not in ("fabs", "int_abs"):
+        raise ValueError("unknown change_abs %r" % (reading,))
+    som_device.train_online(x, w, xdim, ydim, rlen, alpha_range, radius_range, od, int_abs=reading == "int_abs")
     return w.cpu().numpy()
 
 

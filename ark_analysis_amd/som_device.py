@@ -291,20 +291,24 @@ def batch_update_prepare(w: torch.Tensor, xdim: int, ydim: int, stats: torch.Ten
     _capi.check(rc, "pxsom_batch_update_prepare")
 
 
+ONLINE_INT_ABS = 1  # include/pxsom.h PXSOM_ONLINE_INT_ABS
+
+
 def train_online(x: torch.Tensor, w: torch.Tensor, xdim: int, ydim: int, rlen: int,
-                 alpha_range, radius_range, order: torch.Tensor) -> torch.Tensor:
-    """Exact online SOM (FlowSOM C_SOM) in place on ``w`` [xdim*ydim, C] f64."""
+                 alpha_range, radius_range, order: torch.Tensor, int_abs: bool = False) -> torch.Tensor:
+    """Exact online SOM (FlowSOM C_SOM) in place on ``w`` [xdim*ydim, C] f64.  ``int_abs``: the other reading of the
+    early-stop accumulator (``flowsom.RECALLED["change_abs"]``)."""
     n, c, ldx, dt = _matrix_args(x)
     w = _codebook(w)
     if w.shape != (xdim * ydim, c):
         raise ValueError(f"codebook shape {tuple(w.shape)} != ({xdim * ydim}, {c})")
     if order.dtype != torch.int64 or not order.is_cuda or order.numel() != n * rlen:
         raise ValueError("order must be an int64 HBM vector of n*rlen row indices")
-    rc = _capi.lib().pxsom_train_online(x.data_ptr(), n, c, ldx, dt, w.data_ptr(), int(xdim),
-                                        int(ydim), int(rlen), float(alpha_range[0]),
-                                        float(alpha_range[1]), float(radius_range[0]),
-                                        float(radius_range[1]), order.data_ptr(),
-                                        _capi.stream_ptr())
+    rc = _capi.lib().pxsom_train_online_ex(x.data_ptr(), n, c, ldx, dt, w.data_ptr(), int(xdim),
+                                           int(ydim), int(rlen), float(alpha_range[0]),
+                                           float(alpha_range[1]), float(radius_range[0]),
+                                           float(radius_range[1]), order.data_ptr(),
+                                           ONLINE_INT_ABS if int_abs else 0, _capi.stream_ptr())
     _capi.check(rc, "pxsom_train_online")
     return w
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PXSOM_ABI_VERSION 7
+#define PXSOM_ABI_VERSION 8
 
 typedef enum pxsom_status {
     PXSOM_OK = 0,
@@ -141,6 +141,14 @@ int pxsom_pair_histogram(const int32_t *a_dev, const int32_t *b_dev, int64_t n, 
 int pxsom_train_online(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, double *w_dev,
                        int xdim, int ydim, int rlen, double a0, double a1, double r0, double r1,
                        const int64_t *order_dev, void *stream);
+/* The same with `flags` for the RECALLED details of the loop (pyFlowSOM 0.1.16 is absent from the build image: each
+ * recollection is a named switch, oracle/pxsom_oracle.c ORC_V_*).  PXSOM_ONLINE_INT_ABS: the accumulator behind the
+ * "stop at the start of a pass when change < 1" test adds C's integer abs() of each difference -- truncated towards zero
+ * first, so every |x - w| < 1 counts as 0 -- instead of fabs() (oracle: ORC_V_INT_ABS).  Only observable with rlen >= 2. */
+#define PXSOM_ONLINE_INT_ABS 1
+int pxsom_train_online_ex(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, double *w_dev,
+                          int xdim, int ydim, int rlen, double a0, double a1, double r0, double r1,
+                          const int64_t *order_dev, int flags, void *stream);
 
 /* ---- batch SOM training (throughput mode; no pyFlowSOM analogue) -----------------------------
  * One mini-batch step = pxsom_batch_accumulate [+ all-reduce of stats across ranks] + pxsom_batch_update.

@@ -14,7 +14,8 @@ documented guess.  It needs nothing from this repository but numpy; the arrays i
 
 Cases: C in {4, 22, 40} x K in {100 (10x10), 400 (20x20)} x rlen in {1, 2}, seeds 42 / 7; plus, where this
 pyFlowSOM accepts ``nodes=``, the same runs with explicit initial nodes (separates the init rule from the order
-stream), an exact-tie pair and a NaN row for map_data_to_nodes.
+stream), an exact-tie pair and a NaN row for map_data_to_nodes; plus two multi-pass runs on data clipped to [0, 0.9]
+(every |x - w| < 1: tells FlowSOM's `change += abs(tmp)` -- integer abs -- from fabs, see flowsom.RECALLED["change_abs"]).
 """
 import os
 import sys
@@ -34,13 +35,19 @@ def main():
     for c in (4, 22, 40):
         for (xdim, ydim) in ((10, 10), (20, 20)):
             for rlen in (1, 2):
-                cases.append((c, xdim, ydim, rlen, 42 if rlen == 1 else 7))
-    for idx, (c, xdim, ydim, rlen, seed) in enumerate(cases):
+                cases.append((c, xdim, ydim, rlen, 42 if rlen == 1 else 7, False))
+    # two-pass runs on data clipped to [0, 0.9]: every |x - w| stays below 1, so the two readings of the early-stop
+    # accumulator (fabs / integer abs: flowsom.RECALLED["change_abs"], oracle ORC_V_INT_ABS) give different codebooks
+    cases.append((22, 10, 10, 2, 11, True))
+    cases.append((8, 10, 10, 3, 12, True))
+    for idx, (c, xdim, ydim, rlen, seed, clipped) in enumerate(cases):
         tag = "case%02d" % idx
         rs = np.random.RandomState(1000 + idx)
         n = 1500 if xdim == 10 else 2400
         x = rs.gamma(0.7, 0.4, size=(n, c))
         x[rs.rand(n, c) < 0.2] = 0.0
+        if clipped:
+            x = np.minimum(x, 0.9)
         x = np.ascontiguousarray(x, dtype=np.float64)
         codes = som(x, xdim=xdim, ydim=ydim, rlen=rlen, alpha_range=(0.05, 0.01), seed=seed)
         codes = np.asarray(codes, dtype=np.float64).reshape(xdim * ydim, -1)

@@ -94,7 +94,7 @@ def nhbrdist(xdim, ydim):
 
 
 # named switches for the RECALLED details of pyFlowSOM (oracle/pxsom_oracle.c ORC_V_*): 0 = the build's reading
-V_COMPARE_SQUARED, V_NO_THRESHOLD_PIN, V_NO_EARLY_STOP, V_LAST_MINIMUM = 1, 2, 4, 8
+V_COMPARE_SQUARED, V_NO_THRESHOLD_PIN, V_NO_EARLY_STOP, V_LAST_MINIMUM, V_INT_ABS = 1, 2, 4, 8, 16
 
 
 def som_online(data, codes, xdim, ydim, rlen, alpha_range, radius_range, order, variant=0, node_order="xy"):

@@ -348,6 +348,44 @@ def test_train_online_bit_exact(gpu, oracle, n, c, xdim, ydim, rlen, dtype):
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("n,c,xdim,ydim,rlen,dtype", [
+    (1_500, 22, 10, 10, 2, np.float32),   # 2 lanes per node
+    (900, 8, 6, 6, 3, np.float64),        # 4 lanes per node
+    (700, 70, 10, 10, 2, np.float32),     # wide rows, 4 lanes per node in 512 threads
+    (600, 30, 14, 14, 2, np.float32),     # thread <-> node form
+    (500, 110, 10, 10, 2, np.float32),    # codebook in LDS
+])
+def test_train_online_early_stop_fires(gpu, oracle, n, c, xdim, ydim, rlen, dtype):
+    """FlowSOM's "if (change < 1) stop at the start of a pass" (one more step runs, then the loop ends), with BOTH readings
+    of its accumulator (oracle ORC_V_INT_ABS / pxsom_train_online_ex PXSOM_ONLINE_INT_ABS): the integer abs() adds nothing
+    while every |x - w| < 1, so the run stops at the start of its second pass; fabs stops only when a whole pass moved the
+    codebook by less than 1 in total (tiny data).  Codebooks bit-equal to the oracle's in all four combinations."""
+    k = xdim * ydim
+    x = np.minimum(synth.make_fov_numpy(max(n, k), c, seed=25, dtype=np.float32)[:n], 0.9).astype(dtype)
+    rs = np.random.RandomState(26)
+    w0 = np.ascontiguousarray(x[rs.choice(n, k, replace=n < k)].astype(np.float64))
+    order = rs.randint(0, n, size=n * rlen).astype(np.int64)
+    ar, rr = (0.05, 0.01), default_radius_range(xdim, ydim)
+    xd, od = torch.from_numpy(x).to(gpu), torch.from_numpy(order).to(gpu)
+    outs = {}
+    for int_abs in (False, True):
+        want = oracle.som_online(x.astype(np.float64), w0, xdim, ydim, rlen, ar, rr, order, variant=oracle.V_INT_ABS if int_abs else 0)
+        wd = torch.from_numpy(w0.copy()).to(gpu)
+        sd.train_online(xd, wd, xdim, ydim, rlen, ar, rr, od, int_abs=int_abs)
+        np.testing.assert_array_equal(wd.cpu().numpy(), want)
+        outs[int_abs] = want
+    assert not np.array_equal(outs[False], outs[True])        # the stop fired under the integer reading only
+    # a data set so small in magnitude that fabs stops too: the two readings agree again
+    tiny = (x.astype(np.float64) * 1e-7).astype(dtype) if dtype != np.float32 else (x * np.float32(1e-7))
+    w0t = np.ascontiguousarray(tiny[rs.choice(n, k, replace=n < k)].astype(np.float64))
+    want = oracle.som_online(tiny.astype(np.float64), w0t, xdim, ydim, rlen, ar, rr, order)
+    stopped = oracle.som_online(tiny.astype(np.float64), w0t, xdim, ydim, rlen, ar, rr, order, variant=oracle.V_NO_EARLY_STOP)
+    assert not np.array_equal(want, stopped)                  # (the early stop did fire in the default reading)
+    wd = torch.from_numpy(w0t.copy()).to(gpu)
+    sd.train_online(torch.from_numpy(tiny).to(gpu), wd, xdim, ydim, rlen, ar, rr, od)
+    np.testing.assert_array_equal(wd.cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("c,xdim,ydim", [(22, 10, 10), (6, 7, 9), (12, 5, 5), (30, 16, 16), (100, 10, 10), (50, 8, 8)])
 def test_train_online_ties_bit_exact(gpu, oracle, c, xdim, ydim):
     """Coarsely quantised rows and duplicated initial nodes: equal and near-equal distances are the

@@ -49,7 +49,7 @@ def _sweep(oracle, g, tag, init, want):
     x = g[tag + "_x"]
     hits = []
     for stream, quant, node_order, variant in itertools.product(
-            ("glibc_rand", "numpy_randint", "numpy_sample"), (0.67, 0.5, 0.75), ("xy", "yx"), range(16)):
+            ("glibc_rand", "numpy_randint", "numpy_sample"), (0.67, 0.5, 0.75), ("xy", "yx"), range(32)):
         _, order = flowsom.som_init_and_order(len(x), xdim * ydim, rlen, seed, order_stream=stream)
         rr = flowsom.default_radius_range(xdim, ydim, quantile=quant)
         got = oracle.som_online(x, init, xdim, ydim, rlen, (0.05, 0.01), rr, order, variant=variant, node_order=node_order)
@@ -124,6 +124,17 @@ def test_recalled_switches_are_wired(oracle):
     first, _ = oracle.map_data_to_nodes(w, w[3:4])
     last, _ = oracle.map_data_to_nodes_variant(w, w[3:4], oracle.V_LAST_MINIMUM)
     assert first[0] == 4 and last[0] == 25
+    # the two readings of the early-stop accumulator part ways on data whose differences all stay below 1: the integer
+    # abs() adds nothing, the run stops at the start of its second pass (one more step runs, as in FlowSOM's loop)
+    small = np.minimum(x, 0.9)
+    b2 = oracle.som_online(small, small[init_idx], 5, 5, 2, (0.05, 0.01), rr, order)
+    i2 = oracle.som_online(small, small[init_idx], 5, 5, 2, (0.05, 0.01), rr, order, variant=oracle.V_INT_ABS)
+    assert not np.array_equal(b2, i2)
+    np.testing.assert_array_equal(i2, oracle.som_online(small, small[init_idx], 5, 5, 2, (0.05, 0.01), rr, order,
+                                                        variant=oracle.V_INT_ABS | oracle.V_NO_THRESHOLD_PIN))
+    np.testing.assert_array_equal(b2, oracle.som_online(small, small[init_idx], 5, 5, 2, (0.05, 0.01), rr, order,
+                                                        variant=oracle.V_INT_ABS | oracle.V_NO_EARLY_STOP))
+    assert flowsom.RECALLED["change_abs"][0] == "fabs"
     sq, dsq = oracle.map_data_to_nodes_variant(base, x, oracle.V_COMPARE_SQUARED)
     lab, d = oracle.map_data_to_nodes(base, x)
     np.testing.assert_array_equal(sq, lab)
