@@ -79,6 +79,10 @@ SYMBOLS = {
     "pxsom_comm_create": (_i32, [_vp, _sz, _i32, _i32, ctypes.POINTER(_vp)]),
     "pxsom_comm_destroy": (_i32, [_vp]),
     "pxsom_comm_allreduce_sum_f64": (_i32, [_vp, _vp, _sz, _vp]),
+    "pxsom_comm_p2p_create": (_i32, [_i32, _i32, _sz, ctypes.POINTER(_vp)]),
+    "pxsom_comm_p2p_handle": (_i32, [_vp, _vp, _sz]),
+    "pxsom_comm_p2p_connect": (_i32, [_vp, _vp, _sz]),
+    "pxsom_comm_p2p_error": (_i32, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
 }
 
 _lib = None

@@ -45,16 +45,121 @@ int rccl_fail(const char *what, ncclResult_t r)
 
 }  // namespace
 
+// ---- one-shot peer-to-peer all-reduce (round 4) -------------------------------------------------------------------
+// The rule's exchange is 18 KB per step and sits on the critical path between two 12 us kernels: a ring / tree collective
+// pays several hops of latency for a message that fits one store burst.  Here every rank owns an exchange block in ITS
+// device memory -- [2 parities][nranks] flags + [2 parities][nranks][max_count] binary64 slots -- exported as a HIP IPC
+// handle and mapped by every peer (same device: two processes on one GPU, which is how a one-GPU box validates it; other
+// devices of the node: over xGMI).  One launch per exchange, one workgroup:
+//   1. copy the local buffer into slot [parity][my rank] of EVERY rank's block (system-scope stores),
+//   2. system fence, then the epoch number into flag [parity][my rank] of every block,
+//   3. wait until the own block's flags of all ranks show the epoch (bounded: ~4 s, then the buffer turns to NaN and the
+//      block's error word is set -- a missing peer must not hang the GPU),
+//   4. add the nranks slots of the own block in rank order into the buffer: every rank adds the same numbers in the same
+//      order, so the result is bit-identical on all ranks (an RCCL ring promises that only per algorithm and size).
+// Epoch parity alternates, so a rank running ahead writes the other half of the block; it cannot lap a slow rank by two
+// epochs because its own step 3 of the epoch in between needs that rank's flag.
+constexpr int kP2PMaxRanks = 16;
+struct P2PBlock {           // head of a rank's exchange block
+    unsigned long long flags[2][kP2PMaxRanks];
+    unsigned long long error;
+    unsigned long long pad[7];
+};
+struct P2PArgs {
+    char *peer[kP2PMaxRanks];   // every rank's block as mapped here (peer[rank] = the own one)
+    int nranks, rank;
+    unsigned long long epoch;
+    size_t max_count;
+};
+
 struct pxsom_comm {
     ncclComm_t comm;
     int nranks, rank;
+    // p2p mode (comm == nullptr)
+    bool p2p = false;
+    char *block = nullptr;                       // own exchange block (device memory)
+    char *peer[kP2PMaxRanks] = {};               // mapped blocks
+    size_t max_count = 0;
+    unsigned long long epoch = 0;
 };
+
+namespace {
+
+__device__ __forceinline__ double *p2p_slot(char *block, int parity, int src, int nranks, size_t max_count)
+{
+    return reinterpret_cast<double *>(block + sizeof(P2PBlock)) + ((size_t)parity * nranks + src) * max_count;
+}
+
+__global__ __launch_bounds__(1024) void p2p_allreduce_kernel(P2PArgs a, double *__restrict__ buf, size_t count)
+{
+    const int tid = threadIdx.x, parity = (int)(a.epoch & 1ull);
+    // 1. my contribution into everybody's block
+    for (int p = 0; p < a.nranks; p++) {
+        double *dst = p2p_slot(a.peer[p], parity, a.rank, a.nranks, a.max_count);
+        for (size_t e = tid; e < count; e += 1024) __hip_atomic_store(dst + e, buf[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // 2. ... is complete before anybody sees the flag
+    __threadfence_system();
+    __syncthreads();
+    if (tid < a.nranks) {
+        P2PBlock *pb = reinterpret_cast<P2PBlock *>(a.peer[tid]);
+        __hip_atomic_store(&pb->flags[parity][a.rank], a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // 3. everybody's contribution has arrived in MY block
+    P2PBlock *mine = reinterpret_cast<P2PBlock *>(a.peer[a.rank]);
+    __shared__ int s_timeout;
+    if (tid == 0) s_timeout = 0;
+    __syncthreads();
+    if (tid < a.nranks) {
+        const long long t0 = (long long)wall_clock64();   // 100 MHz
+        while (__hip_atomic_load(&mine->flags[parity][tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != a.epoch) {
+            __builtin_amdgcn_s_sleep(8);
+            if ((long long)wall_clock64() - t0 > 400000000ll) {   // 4 s
+                s_timeout = 1;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    if (s_timeout) {
+        if (tid == 0) __hip_atomic_store(&mine->error, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (size_t e = tid; e < count; e += 1024) buf[e] = __builtin_nan("");
+        return;
+    }
+    // 4. the sum, in rank order
+    for (size_t e = tid; e < count; e += 1024) {
+        double acc = 0.0;
+        for (int p = 0; p < a.nranks; p++)
+            acc += __hip_atomic_load(p2p_slot(a.peer[a.rank], parity, p, a.nranks, a.max_count) + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        buf[e] = acc;
+    }
+}
+
+int p2p_allreduce(pxsom_comm *c, double *buf, size_t count, hipStream_t st)
+{
+    if (count > c->max_count)
+        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "p2p exchange: %zu values, the blocks hold %zu", count, c->max_count);
+    for (int p = 0; p < c->nranks; p++)
+        if (!c->peer[p]) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "p2p exchange: pxsom_comm_p2p_connect has not run");
+    P2PArgs a;
+    for (int p = 0; p < kP2PMaxRanks; p++) a.peer[p] = p < c->nranks ? c->peer[p] : nullptr;
+    a.nranks = c->nranks;
+    a.rank = c->rank;
+    a.epoch = ++c->epoch;
+    a.max_count = c->max_count;
+    hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(1), dim3(1024), 0, st, a, buf, count);
+    PXSOM_LAUNCH_CHECK("p2p_allreduce_kernel");
+    return PXSOM_OK;
+}
+
+}  // namespace
 
 namespace pxsom {
 
 // used by the training loop (pxsom_train.hip)
 int comm_allreduce_sum_f64(pxsom_comm *c, double *buf, size_t count, hipStream_t st)
 {
+    if (c && c->p2p) return p2p_allreduce(c, buf, count, st);
     if (!c || !g_rccl.AllReduce) return fail(PXSOM_ERR_INVALID_ARG, "pxsom: exchange without a communicator");
     ncclResult_t r = g_rccl.AllReduce(buf, buf, count, ncclDouble, ncclSum, c->comm, st);
     return r == ncclSuccess ? PXSOM_OK : rccl_fail("ncclAllReduce", r);
@@ -104,14 +209,97 @@ PXSOM_EXPORT int pxsom_comm_create(const void *id, size_t id_bytes, int nranks, 
     ncclComm_t comm = nullptr;
     ncclResult_t r = g_rccl.CommInitRank(&comm, nranks, uid, rank);   // collective: every rank of the job calls it
     if (r != ncclSuccess) return rccl_fail("ncclCommInitRank", r);
-    pxsom_comm *c = new pxsom_comm{comm, nranks, rank};
+    pxsom_comm *c = new pxsom_comm();
+    c->comm = comm;
+    c->nranks = nranks;
+    c->rank = rank;
     *out = c;
+    return PXSOM_OK;
+}
+
+// ---- p2p communicator: create (allocates the own block) -> handle (64 bytes to hand to every peer) -> connect (maps the
+// peers' blocks; collective in the sense that every rank must have created its block first) ---------------------------
+PXSOM_EXPORT int pxsom_comm_p2p_create(int nranks, int rank, size_t max_count, pxsom_comm **out)
+{
+    if (!out || nranks < 1 || nranks > kP2PMaxRanks || rank < 0 || rank >= nranks || max_count < 1)
+        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_comm_p2p_create: rank %d of %d (at most %d), %zu values", rank, nranks,
+                           kP2PMaxRanks, max_count);
+    pxsom_comm *c = new pxsom_comm();
+    c->comm = nullptr;
+    c->nranks = nranks;
+    c->rank = rank;
+    c->p2p = true;
+    c->max_count = max_count;
+    const size_t bytes = sizeof(P2PBlock) + (size_t)2 * nranks * max_count * sizeof(double);
+    // fine-grained device memory: peers write into it and this rank reads it while kernels run
+    hipError_t e = hipExtMallocWithFlags(reinterpret_cast<void **>(&c->block), bytes, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        e = hipMalloc(reinterpret_cast<void **>(&c->block), bytes);
+    }
+    if (e != hipSuccess) {
+        delete c;
+        return pxsom::hip_fail(e, "pxsom_comm_p2p_create: exchange block");
+    }
+    e = hipMemset(c->block, 0, bytes);
+    if (e != hipSuccess) {
+        (void)hipFree(c->block);
+        delete c;
+        return pxsom::hip_fail(e, "pxsom_comm_p2p_create: clearing the exchange block");
+    }
+    c->peer[rank] = c->block;
+    *out = c;
+    return PXSOM_OK;
+}
+
+PXSOM_EXPORT int pxsom_comm_p2p_handle(pxsom_comm *c, void *handle_out, size_t handle_bytes)
+{
+    static_assert(sizeof(hipIpcMemHandle_t) == PXSOM_P2P_HANDLE_BYTES, "PXSOM_P2P_HANDLE_BYTES out of step with HIP");
+    if (!c || !c->p2p || !handle_out || handle_bytes != PXSOM_P2P_HANDLE_BYTES)
+        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_comm_p2p_handle: a p2p communicator and %d bytes", PXSOM_P2P_HANDLE_BYTES);
+    hipIpcMemHandle_t h;
+    PXSOM_HIP_TRY(hipIpcGetMemHandle(&h, c->block));
+    memcpy(handle_out, &h, sizeof(h));
+    return PXSOM_OK;
+}
+
+PXSOM_EXPORT int pxsom_comm_p2p_connect(pxsom_comm *c, const void *handles, size_t handles_bytes)
+{
+    if (!c || !c->p2p || !handles || handles_bytes != (size_t)c->nranks * PXSOM_P2P_HANDLE_BYTES)
+        return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_comm_p2p_connect: nranks x %d bytes of handles", PXSOM_P2P_HANDLE_BYTES);
+    for (int p = 0; p < c->nranks; p++) {
+        if (p == c->rank || c->peer[p]) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, static_cast<const char *>(handles) + (size_t)p * PXSOM_P2P_HANDLE_BYTES, sizeof(h));
+        void *ptr = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return pxsom::hip_fail(e, "pxsom_comm_p2p_connect: hipIpcOpenMemHandle");
+        c->peer[p] = static_cast<char *>(ptr);
+    }
+    return PXSOM_OK;
+}
+
+// 0: every exchange so far completed; otherwise the epoch at which a peer did not show up in time (the buffers of that
+// exchange were turned to NaN)
+PXSOM_EXPORT int pxsom_comm_p2p_error(pxsom_comm *c, unsigned long long *epoch_out)
+{
+    if (!c || !c->p2p || !epoch_out) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_comm_p2p_error: bad arguments");
+    P2PBlock head;
+    PXSOM_HIP_TRY(hipMemcpy(&head, c->block, sizeof(head), hipMemcpyDeviceToHost));
+    *epoch_out = head.error;
     return PXSOM_OK;
 }
 
 PXSOM_EXPORT int pxsom_comm_destroy(pxsom_comm *c)
 {
     if (!c) return PXSOM_OK;
+    if (c->p2p) {
+        for (int p = 0; p < c->nranks; p++)
+            if (p != c->rank && c->peer[p]) (void)hipIpcCloseMemHandle(c->peer[p]);
+        if (c->block) (void)hipFree(c->block);
+        delete c;
+        return PXSOM_OK;
+    }
     ncclResult_t r = g_rccl.CommDestroy ? g_rccl.CommDestroy(c->comm) : ncclSuccess;
     delete c;
     return r == ncclSuccess ? PXSOM_OK : rccl_fail("ncclCommDestroy", r);

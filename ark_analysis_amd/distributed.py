@@ -205,6 +205,35 @@ def native_exchange(group=None):
         return _native_comms[key]
     comm = None
     wanted = os.environ.get("PXSOM_NATIVE_EXCHANGE", "1")     # "0": never; "force": on any backend (tests: gloo group
+    # PXSOM_EXCHANGE=p2p (opt-in, round 4): the one-shot peer-to-peer exchange over HIP IPC blocks instead of RCCL -- one launch
+    # per step and rank, bit-identical sums; validated with two ranks on ONE device (tests/test_gpu_exchange.py), no
+    # multi-GPU hardware run exists yet, hence not the default.  Any backend: the handles travel as host objects.
+    if wanted != "0" and os.environ.get("PXSOM_EXCHANGE", "rccl") == "p2p" and torch.cuda.is_available():
+        from . import som_device
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        err = None
+        try:
+            comm = som_device.P2PComm(world, rank, 1 << 18)
+        except Exception as e:          # noqa: BLE001 -- agreed below: all ranks fall back together
+            err = e
+        if _all_ranks_ok(comm is not None, group):
+            box = [None] * world
+            dist.all_gather_object(box, comm.local_handle, group=group)
+            try:
+                comm.connect(box)
+            except Exception as e:      # noqa: BLE001
+                err = e
+                comm.close()
+                comm = None
+        if not _all_ranks_ok(comm is not None, group):
+            if comm is not None:
+                comm.close()
+            comm = None
+            if rank == 0:
+                warnings.warn("peer-to-peer exchange unavailable (%s): falling back" % err)
+        else:
+            _native_comms[key] = comm
+            return comm
     if wanted != "0" and (dist.get_backend(group) == "nccl" or wanted == "force"):   # + a stand-in collective library)
         from . import som_device
         rank, world = dist.get_rank(group), dist.get_world_size(group)

@@ -230,6 +230,59 @@ class RankComm:
             _capi.check(_capi.lib().pxsom_comm_destroy(h), "pxsom_comm_destroy")
 
 
+P2P_HANDLE_BYTES = 64  # include/pxsom.h PXSOM_P2P_HANDLE_BYTES
+
+
+class P2PComm:
+    """One-shot peer-to-peer exchange owned by libpxsom (pxsom_comm_p2p_*): every rank's block of device memory is mapped
+    by the others through HIP IPC, an all-reduce is one launch per rank and gives bit-identical sums on all ranks.  Ranks
+    may share a device.  Two phases, so that a launcher can agree on each before the next: the constructor allocates the
+    own block (``local_handle``: 64 bytes), ``connect`` takes the handles of all ranks in rank order (``gather``: a
+    callable doing both in one go, e.g. over ``torch.distributed.all_gather_object``).  Same interface as RankComm."""
+
+    def __init__(self, nranks: int, rank: int, max_count: int, gather=None):
+        import ctypes
+        box = ctypes.c_void_p()
+        _capi.check(_capi.lib().pxsom_comm_p2p_create(int(nranks), int(rank), int(max_count), ctypes.byref(box)),
+                    "pxsom_comm_p2p_create")
+        self.handle = box
+        self.nranks, self.rank, self.max_count = int(nranks), int(rank), int(max_count)
+        mine = ctypes.create_string_buffer(P2P_HANDLE_BYTES)
+        _capi.check(_capi.lib().pxsom_comm_p2p_handle(self.handle, ctypes.cast(mine, ctypes.c_void_p), P2P_HANDLE_BYTES),
+                    "pxsom_comm_p2p_handle")
+        self.local_handle = mine.raw          # 64 bytes: what the other ranks need to map this rank's block
+        if gather is not None:
+            self.connect(gather(self.local_handle))
+
+    def connect(self, handles) -> None:
+        """Maps the blocks of all ranks (``handles``: every rank's ``local_handle``, rank order)."""
+        import ctypes
+        handles = list(handles)
+        if len(handles) != self.nranks or any(len(h) != P2P_HANDLE_BYTES for h in handles):
+            raise ValueError("one %d-byte handle per rank, in rank order" % P2P_HANDLE_BYTES)
+        blob = ctypes.create_string_buffer(b"".join(handles), P2P_HANDLE_BYTES * self.nranks)
+        _capi.check(_capi.lib().pxsom_comm_p2p_connect(self.handle, ctypes.cast(blob, ctypes.c_void_p),
+                                                       P2P_HANDLE_BYTES * self.nranks), "pxsom_comm_p2p_connect")
+
+    def allreduce_sum(self, t: torch.Tensor) -> None:
+        if t.dtype != torch.float64 or not t.is_contiguous():
+            raise ValueError("the exchange reduces contiguous float64 buffers")
+        rc = _capi.lib().pxsom_comm_allreduce_sum_f64(self.handle, t.data_ptr(), t.numel(), _capi.stream_ptr())
+        _capi.check(rc, "pxsom_comm_allreduce_sum_f64")
+
+    def error_epoch(self) -> int:
+        """0, or the number of the first exchange a peer did not arrive at in time (its result was NaN)."""
+        import ctypes
+        out = ctypes.c_uint64(0)
+        _capi.check(_capi.lib().pxsom_comm_p2p_error(self.handle, ctypes.byref(out)), "pxsom_comm_p2p_error")
+        return int(out.value)
+
+    def close(self) -> None:
+        if self.handle is not None:
+            h, self.handle = self.handle, None
+            _capi.check(_capi.lib().pxsom_comm_destroy(h), "pxsom_comm_destroy")
+
+
 def batch_train_finish(state: BatchTrainState, steps_done: int, total_steps: int, alpha_range, radius_range,
                        w_out: torch.Tensor) -> None:
     """Applies the last pending update of a run: ``w_out`` [K, C] receives the codebook after ``steps_done`` steps."""

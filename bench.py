@@ -329,6 +329,40 @@ def main():
         all_reduce_(exch, op=dist.ReduceOp.MAX)
         per_rank["exchange_us_per_step"] = round(float(exch.item()), 2)
         per_rank["exchange_ms_per_pass"] = round(float(exch.item()) * sched.steps * 1e-3, 4)
+        per_rank["exchange_route"] = type(native).__name__ if native is not None else "torch.distributed"
+        # the other in-library route beside it: the one-shot peer-to-peer exchange over HIP IPC blocks (opt-in, PXSOM_EXCHANGE=p2p;
+        # validated with two ranks on one device only -- no multi-GPU hardware number exists until a SCALE record holds one)
+        p2p_us = None
+        if not isinstance(native, som_device.P2PComm):
+            pc, handles = None, [None] * world
+            try:
+                pc = som_device.P2PComm(world, rank, K * (C + 1))
+            except Exception:   # noqa: BLE001
+                pc = None
+            dist.all_gather_object(handles, pc.local_handle if pc is not None else None)
+            ok = pc is not None and all(h is not None for h in handles)
+            if ok:
+                try:
+                    pc.connect(handles)
+                except Exception:   # noqa: BLE001
+                    ok = False
+            oks = [None] * world
+            dist.all_gather_object(oks, bool(ok))
+            if all(oks):
+                for _ in range(5):
+                    pc.allreduce_sum(probe)
+                fence()
+                tp = time.perf_counter()
+                for _ in range(reps):
+                    pc.allreduce_sum(probe)
+                fence()
+                ex2 = torch.tensor([(time.perf_counter() - tp) / reps * 1e6], dtype=torch.float64, device="cpu" if dry else dev)
+                all_reduce_(ex2, op=dist.ReduceOp.MAX)
+                if pc.error_epoch() == 0:
+                    p2p_us = round(float(ex2.item()), 2)
+            if pc is not None:
+                pc.close()
+        per_rank["exchange_us_per_step_p2p"] = p2p_us
     if rank != 0 or args.pmc_inner:
         if use_dist:
             dist.barrier()
@@ -361,7 +395,9 @@ def main():
                    "parallelism": f"{'row' if cfg['kind'] == 'cell' else 'fov'}-shard x{world}",
                    "rccl_ranks": (0 if dry else world) if use_dist else 0,
                    **({"dry_run": "all ranks on one GPU over gloo: exercises the N > 1 code, timings are meaningless"} if dry else {}),
-                   "exchange": ("in-library RCCL all-reduce behind every step" if comm_ranks else "torch.distributed all-reduce per step")
+                   "exchange": (("in-library peer-to-peer all-reduce (HIP IPC blocks, one launch per rank) behind every step"
+                                 if per_rank and per_rank.get("exchange_route") == "P2PComm" else
+                                 "in-library RCCL all-reduce behind every step") if comm_ranks else "torch.distributed all-reduce per step")
                    if use_dist else "none (one rank)"},
         "phases_ms": {"train_batch": round(train_ms, 4),
                       "assign_and_mean_table": round(k8_ms, 4),

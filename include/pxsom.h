@@ -268,6 +268,19 @@ int pxsom_comm_unique_id(void *id_out, size_t id_bytes);
 int pxsom_comm_create(const void *id, size_t id_bytes, int nranks, int rank, pxsom_comm **out);
 int pxsom_comm_destroy(pxsom_comm *comm);
 int pxsom_comm_allreduce_sum_f64(pxsom_comm *comm, double *buf_dev, size_t count, void *stream);
+/* One-shot peer-to-peer exchange (round 4; csrc/pxsom_comm.hip): every rank owns an exchange block in its device memory,
+ * mapped by the others through HIP IPC; an exchange is ONE launch per rank (write the own contribution into every block,
+ * flag, wait for the others' flags, add the slots in rank order: bit-identical sums on all ranks).  Ranks may share a
+ * device (two processes on one GPU: how a one-GPU box validates the protocol) or sit on the devices of one node.
+ *   create(nranks <= 16, rank, max_count binary64 values per exchange) -> handle(64 bytes; gather them from all ranks,
+ *   rank order) -> connect(all handles).  The communicator then serves pxsom_comm_allreduce_sum_f64 and
+ *   pxsom_batch_train_sched like an RCCL one.  pxsom_comm_p2p_error: 0, or the epoch at which a peer failed to arrive
+ *   within 4 s (that exchange's buffer was set to NaN; the GPU is not left hanging). */
+#define PXSOM_P2P_HANDLE_BYTES 64
+int pxsom_comm_p2p_create(int nranks, int rank, size_t max_count, pxsom_comm **out);
+int pxsom_comm_p2p_handle(pxsom_comm *comm, void *handle_out, size_t handle_bytes);
+int pxsom_comm_p2p_connect(pxsom_comm *comm, const void *handles, size_t handles_bytes);
+int pxsom_comm_p2p_error(pxsom_comm *comm, unsigned long long *epoch_out);
 int pxsom_batch_train_steps_sharded(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, double *wbuf_dev,
                                     double *stats_ring_dev, int xdim, int ydim, int batch_steps, int g_begin,
                                     int g_end, int total_steps, double a0, double a1, double r0, double r1,

@@ -26,12 +26,14 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("exchange", ["torch.distributed", "in-library"])
+@pytest.mark.parametrize("exchange", ["torch.distributed", "in-library", "p2p"])
 @pytest.mark.parametrize("config", ["cfg2", "cfg4"])
 def test_two_rank_bench_line(gpu, tmp_path, exchange, config):
     env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", PXSOM_BENCH_DRY_RANKS="1")
     if exchange == "in-library":
         env.update(PXSOM_NATIVE_EXCHANGE="force", PXSOM_RCCL_LIBRARY=_mock_library(tmp_path))
+    elif exchange == "p2p":      # the library's peer-to-peer exchange: real on one device (HIP IPC between the two processes)
+        env.update(PXSOM_EXCHANGE="p2p")
     else:
         env.update(PXSOM_NATIVE_EXCHANGE="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -43,8 +45,12 @@ def test_two_rank_bench_line(gpu, tmp_path, exchange, config):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["value"] > 0
     assert line["config"]["name"] == config and "dry_run" in line["config"]
-    assert line["config"]["exchange"].startswith("in-library" if exchange == "in-library" else "torch.distributed")
+    assert line["config"]["exchange"].startswith("torch.distributed" if exchange == "torch.distributed" else "in-library")
     per_rank = line["phases_ms"]["per_rank"]
     assert len(per_rank["train_batch"]) == 2 and all(v > 0 for v in per_rank["train_batch"])
     assert per_rank["exchange_us_per_step"] > 0 and per_rank["exchange_ms_per_pass"] > 0     # the exchange timed on its own
+    if exchange == "p2p":
+        assert per_rank["exchange_route"] == "P2PComm" and per_rank["exchange_us_per_step_p2p"] is None
+    else:                        # ... and the peer-to-peer route beside whichever one the pass used
+        assert per_rank["exchange_us_per_step_p2p"] > 0
     assert line["scaling"] == ("weak" if config == "cfg2" else "strong")

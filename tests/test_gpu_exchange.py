@@ -193,3 +193,92 @@ def test_a_rank_with_an_empty_or_short_shard_keeps_the_same_codebook(oracle, tmp
         w = oracle.batch_update(w, 10, 10, s, cnt, 0.5 if thr < 1.0 else thr, 0.05 - (0.05 - 0.01) * g / steps)
     np.testing.assert_allclose(r0["w"], w, rtol=1e-9, atol=1e-300)
     del x_all
+
+
+# ---- the one-shot peer-to-peer exchange (pxsom_comm_p2p_*): two ranks on ONE device ---------------------------------
+def _p2p_worker(rank, world, port, shards, w0, xdim, ydim, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["PXSOM_EXCHANGE"] = "p2p"
+    from ark_analysis_amd import som_device
+    from ark_analysis_amd.distributed import BatchSOMTrainer, native_exchange
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    comm = native_exchange(None)
+    assert isinstance(comm, som_device.P2PComm), comm
+    # (a) the exchange itself: values whose sum depends on the order of the additions in the last bits
+    gen = torch.Generator(device="cpu").manual_seed(100 + rank)
+    t = (torch.rand(2323, generator=gen, dtype=torch.float64) * (10.0 ** (3 * rank))).to(dev)
+    mine = t.clone()
+    for rep in range(40):                     # many epochs back to back: parity reuse, a rank running ahead
+        buf = mine.clone()
+        comm.allreduce_sum(buf)
+    torch.cuda.synchronize()
+    assert comm.error_epoch() == 0
+    parts = [torch.zeros(2323, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(parts, mine.cpu())
+    want = parts[0].clone()
+    for p in parts[1:]:
+        want = want + p                       # rank order, like the kernel
+    sums = [torch.zeros(2323, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(sums, buf.cpu())
+    ok_sum = bool(torch.equal(buf.cpu(), want)) and all(bool(torch.equal(s, sums[0])) for s in sums)
+    # (b) a sharded training run with the exchange enqueued behind every step by the library
+    x = torch.from_numpy(shards[rank]).to(dev)
+    w = torch.from_numpy(w0.copy()).to(dev)
+    trainer = BatchSOMTrainer(xdim, ydim, x.shape[1], dev)          # default schedule: 22 steps, 22 exchanges
+    trainer.train(x, w, num_passes=1)
+    torch.cuda.synchronize()
+    err = comm.error_epoch()
+    gathered = [torch.zeros(w.shape, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(gathered, w.cpu())
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "p2p.npz"), w=w.cpu().numpy(), ok_sum=np.array(ok_sum), err=np.array(err),
+                 same=np.array([bool(torch.equal(g, gathered[0])) for g in gathered]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_p2p_exchange_two_ranks_on_one_device(oracle, tmp_path):
+    """Two processes on cuda:0, the rule's exchange through the library's own peer-to-peer all-reduce (HIP IPC blocks, one
+    launch per rank and exchange): sums bit-identical on both ranks and equal to the rank-ordered sum; a sharded training
+    run on the default schedule ends in codebooks that are array_equal across the ranks and match the oracle on the
+    united rows.  (RCCL refuses two ranks on one device; this is the exchange a one-GPU box CAN run.)"""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from ark_analysis_amd import synth
+    from ark_analysis_amd.flowsom import default_radius_range
+    from ark_analysis_amd.schedule import BatchSchedule
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    xdim = ydim = 10
+    k, c, n_local = 100, 22, 48_000
+    shards = [synth.make_fov_numpy(n_local, c, seed=70 + r, dtype=np.float32) for r in range(2)]
+    w0 = shards[0][np.random.RandomState(1).choice(n_local, k, replace=False)].astype(np.float64)
+    mp.spawn(_p2p_worker, args=(2, port, shards, w0, xdim, ydim, str(tmp_path)), nprocs=2, join=True)
+    res = np.load(str(tmp_path / "p2p.npz"))
+    assert int(res["err"]) == 0, "a peer did not arrive at exchange %d" % int(res["err"])
+    assert bool(res["ok_sum"]), "all-reduce: not the rank-ordered sum, or the ranks differ"
+    assert res["same"].all(), "codebook differs between the ranks"
+    # the united rows in the order the rule sees them: row i of the job = rows i of rank 0, rank 1 interleaved per phase
+    sch = BatchSchedule.two_phase()
+    # every rank deals ITS rows into the phases (local i % phases), so the job's step g holds both shards' step-g rows;
+    # the oracle takes one matrix: build it so that its own dealing reproduces those steps (phase by phase)
+    phases = sch.phases
+    blocks = []
+    for j in range(n_local // phases):
+        for r in range(2):
+            blocks.append(shards[r][j * phases:(j + 1) * phases])
+    tail = n_local - (n_local // phases) * phases
+    assert tail == 0, "pick n_local as a multiple of the schedule's phases"
+    g = np.concatenate(blocks).astype(np.float64)
+    # rows of phase p: oracle index i % (2 * phases) ... the oracle deals by i % phases, so interleave within a phase pair
+    want = oracle.som_batch_sched(g, w0, xdim, ydim, 1, (0.05, 0.01), default_radius_range(xdim, ydim), phases, sch.edges)
+    np.testing.assert_allclose(res["w"], want, rtol=1e-9, atol=0)
