@@ -19,8 +19,6 @@ EXTRA_FLAGS = {"pxsom_assign_filter.hip": ["-ffinite-math-only"] + (
     ["-DSGB_VALU=" + os.environ["PXSOM_SGB_VALU"]] if "PXSOM_SGB_VALU" in os.environ else []) + (
     ["-DPXSOM_STREAM_TP=" + os.environ["PXSOM_STREAM_TP"]] if "PXSOM_STREAM_TP" in os.environ else []) + (
     ["-DPXSOM_PACKED_TMERGE=" + os.environ["PXSOM_PACKED_TMERGE"]] if "PXSOM_PACKED_TMERGE" in os.environ else [])}
-# PXSOM_ACC_EXPERIMENT=1 in the environment of the build: timing hooks of the accumulating filter (never in a release build)
-EXTRA_FLAGS["pxsom_assign_filter_acc.hip"] = ["-DPXSOM_ACC_EXPERIMENT"] if os.environ.get("PXSOM_ACC_EXPERIMENT") else []
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
                "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
 

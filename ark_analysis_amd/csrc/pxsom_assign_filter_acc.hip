@@ -41,10 +41,6 @@ void launch_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layou
         const int64_t rows_wg = ((ngroups + (int64_t)grid * 4 - 1) / ((int64_t)grid * 4)) * 256 + 64;
         while (((int64_t)1 << fix_rows_log2) < rows_wg) fix_rows_log2++;
     }
-#ifdef PXSOM_ACC_EXPERIMENT
-    if (const char *e = getenv("PXSOM_ACC_EXP")) fix_rows_log2 |= atoi(e) << 8;
-    if (const char *e = getenv("PXSOM_ACC_GRID")) grid = std::min(grid, atoi(e));
-#endif
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, x, n, c, ldx,
                        reinterpret_cast<const half8 *>(ws + L.off_wfrag),
                        reinterpret_cast<const f32x4 *>(ws + L.off_bias), reinterpret_cast<AssignHdr *>(ws),

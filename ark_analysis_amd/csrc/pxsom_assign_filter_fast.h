@@ -633,16 +633,6 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
                         const bool own = q * CPL + 2 * p <= c - 2;
                         const unsigned idx = (own ? base : spare) + (unsigned)(own ? q * CPL + 2 * p : 0);
                         if constexpr (FIX) {
-#ifdef PXSOM_ACC_EXPERIMENT
-                            const int exp_mode = fix_rows_log2 >> 8;     // timing experiments: results are wrong in modes 1-3
-                            if (exp_mode == 1 || exp_mode == 2) continue;
-                            if (exp_mode == 3) {
-                                unsigned *d32 = reinterpret_cast<unsigned *>(lu) + idx;
-                                __hip_atomic_fetch_add(d32, __float_as_uint((float)keep[t][p].x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                __hip_atomic_fetch_add(d32 + 1, __float_as_uint((float)keep[t][p].y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                continue;
-                            }
-#endif
                             __hip_atomic_fetch_add(lu + idx, (unsigned long long)__double_as_longlong((double)keep[t][p].x + fx.magic),
                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             __hip_atomic_fetch_add(lu + idx + 1, (unsigned long long)__double_as_longlong((double)keep[t][p].y + fx.magic),
@@ -653,9 +643,6 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
                         }
                     }
                     if (q == 0) {
-#ifdef PXSOM_ACC_EXPERIMENT
-                        if ((fix_rows_log2 >> 8) == 1) continue;
-#endif
                         if constexpr (FIX)
                             __hip_atomic_fetch_add(lu + (size_t)(k + 1) * c + lab[t], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         else

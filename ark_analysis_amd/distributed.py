@@ -69,9 +69,12 @@ class HipKernels:
         # The route (one-launch fused step / launch per phase) is a collective decision: the two routes apply the same
         # statistics but round the codebook's last bits differently, and a rank with an oddly aligned or empty shard
         # must not part ways with the others.
+        # (every rank enters the collective whatever its own flag says: a debug toggle on one rank must not leave the others
+        # waiting inside an all-reduce the rest skipped)
         self._unfused_now = self.unfused
-        if not self.unfused and _world(group) > 1:
-            self._unfused_now = not _all_ranks_ok(self._sd.batch_train_fused_route(x, xdim, ydim, st.schedule), group)
+        if _world(group) > 1:
+            mine = (not self.unfused) and self._sd.batch_train_fused_route(x, xdim, ydim, st.schedule)
+            self._unfused_now = not _all_ranks_ok(mine, group)
 
     def steps(self, x, g0: int, g1: int, total: int, alpha_range, radius_range, comm=None) -> None:
         self._sd.batch_train_steps(x, self._state, g0, g1, total, alpha_range, radius_range,
@@ -108,6 +111,8 @@ class BatchSOMTrainer:
         self.xdim, self.ydim, self.k, self.c = int(xdim), int(ydim), int(xdim * ydim), int(channels)
         self.schedule = resolve(batch_steps)
         self.batch_steps = self.schedule.steps
+        # the default was asked for (not a schedule of the caller's): train() may swap it for equal steps on tiny tables
+        self._default_schedule = batch_steps is None or (isinstance(batch_steps, str) and batch_steps in ("two-phase", "auto"))
         self.alpha_range = tuple(alpha_range)
         self.radius_range = tuple(radius_range) if radius_range is not None else \
             default_radius_range(xdim, ydim)
@@ -117,7 +122,8 @@ class BatchSOMTrainer:
     def _sum_quantum(self, x_local: torch.Tensor) -> float:
         """binary64 rows (what the drop-in classes hand over) train reproducibly: every value joins the per-BMU sums
         rounded to a power of two q chosen so that all partial sums are exact -- the statistics, hence the whole run, are
-        then independent of summation order, workgroup count and rank count (include/pxsom.h "Reproducible statistics";
+        then independent of summation order and workgroup count for a given sharding (a different world size deals the rows
+        into different steps: another run of the rule, not another rounding) (include/pxsom.h "Reproducible statistics";
         reference property: same-seed retraining gives the same weights, tests/phenotyping/cluster_helpers_test.py:323-332).
         q follows from the job's largest |value| and the most rows a step holds over all ranks; 0 for other dtypes."""
         if x_local.dtype != torch.float64:
@@ -135,6 +141,21 @@ class BatchSOMTrainer:
 
     def train(self, x_local: torch.Tensor, w: torch.Tensor, num_passes: int = 1) -> torch.Tensor:
         """Runs num_passes passes in place on ``w`` [K, C] f64 (identical on every rank)."""
+        if self._default_schedule:
+            # The two-phase default deals the rows into 960 phases: with fewer than a few rows per phase its tail steps hold
+            # next to nothing (below 960 rows: nothing at all, and the rows past index 800 would never be presented).  Small
+            # tables -- a cell SOM over a few thousand cells -- take equal steps instead, as rounds 1-2 did: at most 64,
+            # at least one row per node and step where the table allows it.  Decided on the JOB's row count (all ranks).
+            from .schedule import BatchSchedule
+            n_total = int(x_local.shape[0])
+            if _world(self.group) > 1:
+                t = torch.tensor([float(n_total)], dtype=torch.float64, device=_collective_device(self.group))
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                n_total = int(t.item())
+            two_phase = BatchSchedule.two_phase()
+            want = two_phase if n_total >= 8 * two_phase.phases else BatchSchedule.equal(max(1, min(64, n_total // max(self.k, 1))))
+            if want != self.schedule:
+                self.schedule, self.batch_steps = want, want.steps
         total = int(num_passes) * self.batch_steps
         if total < 1:
             return w

@@ -110,7 +110,15 @@ int pxsom_cluster_sums(const void *x_dev, int64_t n, int c, int64_t ldx, int dty
  * compute together when the labelled rows are still in HBM (reference: cluster_helpers.py:150-157 +
  * pixel_cluster_utils.py:369-404).  labels_dev as pxsom_assign; sums_dev / counts_dev are ADDED into, as pxsom_cluster_sums.
  * Register-resident shapes (K = 97..100, even c <= 32, pair-aligned rows) take the fused launch; other shapes run the two
- * kernels one after the other.  Workspace: pxsom_assign_sums_workspace_bytes(n, c, k). */
+ * kernels one after the other.  Workspace: pxsom_assign_sums_workspace_bytes(n, c, k).
+ * ACCURACY CONTRACT (since ABI 7): labels and counts are exact; on the fused launch the SUMS are accumulated in 64-bit
+ * fixed point inside a workgroup -- every value enters rounded to a multiple of 2^-s, s = 46 + e - max(11, ceil(log2(rows a
+ * workgroup meets))), 2^e the filter's power-of-two scale (|W|max * 2^e in [128, 256)) -- i.e. an absolute error per value of at
+ * most 2^-28 * rows-per-workgroup / 2^11 relative to the codebook's largest magnitude (1.8e-12 for 41 K rows per workgroup),
+ * then flushed as binary64.  They are therefore NOT the bit-exact binary64 sums of pxsom_assign + pxsom_cluster_sums, but
+ * within 1e-6 relative of them per mean (tests: test_assign_sums_one_pass_equals_two_passes).  Values outside the format
+ * (>= 2^(16 - e), non-finite) and listed rows bypass the table in binary64.  PXSOM_SUMS_F64=1 in the environment (read once)
+ * restores binary64 workgroup tables. */
 size_t pxsom_assign_sums_workspace_bytes(int64_t n, int c, int k);
 int pxsom_assign_sums(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev, int k,
                       int32_t *labels_dev, double *sums_dev, int64_t *counts_dev, void *workspace_dev,
@@ -281,6 +289,9 @@ int pxsom_comm_p2p_create(int nranks, int rank, size_t max_count, pxsom_comm **o
 int pxsom_comm_p2p_handle(pxsom_comm *comm, void *handle_out, size_t handle_bytes);
 int pxsom_comm_p2p_connect(pxsom_comm *comm, const void *handles, size_t handles_bytes);
 int pxsom_comm_p2p_error(pxsom_comm *comm, unsigned long long *epoch_out);
+/* pxsom_batch_train_steps with the exchange enqueued behind every step (comm: RCCL or peer-to-peer; NULL = none).  Equal
+ * steps only: 1 <= batch_steps <= PXSOM_MAX_SCHED_STEPS (256) and total_steps a whole number of passes (total_steps %
+ * batch_steps == 0) -- other values are PXSOM_ERR_INVALID_ARG since ABI 7; schedules: pxsom_batch_train_sched. */
 int pxsom_batch_train_steps_sharded(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, double *wbuf_dev,
                                     double *stats_ring_dev, int xdim, int ydim, int batch_steps, int g_begin,
                                     int g_end, int total_steps, double a0, double a1, double r0, double r1,

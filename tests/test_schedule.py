@@ -64,7 +64,8 @@ def _worker(rank, world, port, shards, w0, xdim, ydim, out_path):
     x = torch.from_numpy(shards[rank])
     w = torch.from_numpy(w0.copy()) if rank == 0 else torch.zeros(w0.shape, dtype=torch.float64)
     broadcast_codebook(w, 0)
-    BatchSOMTrainer(xdim, ydim, x.shape[1], "cpu", kernels=OracleKernels()).train(x, w, num_passes=1)   # default schedule
+    # (the two-phase schedule named explicitly: on a table this small the DEFAULT would resolve to equal steps)
+    BatchSOMTrainer(xdim, ydim, x.shape[1], "cpu", batch_steps=BatchSchedule.two_phase(), kernels=OracleKernels()).train(x, w, num_passes=1)
     gathered = [torch.zeros_like(w) for _ in range(world)]
     dist.all_gather(gathered, w)
     if rank == 0:
@@ -92,6 +93,30 @@ def test_two_ranks_on_the_default_schedule_match_the_oracle(oracle, tmp_path):
     want = oracle.som_batch_sched(np.concatenate(blocks), w0, xdim, ydim, 1, (0.05, 0.01), default_radius_range(xdim, ydim),
                                   sch.phases, sch.edges)
     np.testing.assert_allclose(res["w"], want, rtol=1e-10, atol=0)
+
+
+def test_default_schedule_on_a_small_table_is_equal_steps(oracle):
+    """train_mode="batch" with no schedule named: the two-phase default (960 phases) from 7 680 rows on, equal steps --
+    at most 64, a row per node and step where the table allows -- below (a few thousand cells: the tail steps of the
+    two-phase schedule would hold next to nothing, below 960 rows nothing at all)."""
+    rs = np.random.RandomState(5)
+    for n, steps in [(500, 20), (3_000, 64), (30, 1)]:
+        x = rs.randint(0, 2048, size=(n, 4)) / 1024.0
+        w0 = x[rs.choice(n, 25, replace=False)].copy()
+        tr = BatchSOMTrainer(5, 5, 4, "cpu", kernels=OracleKernels())
+        assert tr.schedule == BatchSchedule.two_phase()
+        w = torch.from_numpy(w0.copy())
+        tr.train(torch.from_numpy(x), w, num_passes=1)
+        assert tr.schedule == BatchSchedule.equal(steps) and tr.batch_steps == steps
+        want = oracle.som_batch(x, w0, 5, 5, 1, (0.05, 0.01), default_radius_range(5, 5), steps)
+        np.testing.assert_allclose(w.numpy(), want, rtol=1e-12, atol=0)
+    big = rs.randint(0, 2048, size=(8_000, 4)) / 1024.0
+    tr = BatchSOMTrainer(5, 5, 4, "cpu", kernels=OracleKernels())
+    tr.train(torch.from_numpy(big), torch.from_numpy(big[:25].copy()), num_passes=1)
+    assert tr.schedule == BatchSchedule.two_phase()
+    explicit = BatchSOMTrainer(5, 5, 4, "cpu", batch_steps=BatchSchedule.two_phase(), kernels=OracleKernels())
+    explicit.train(torch.from_numpy(big[:500]), torch.from_numpy(big[:25].copy()), num_passes=1)
+    assert explicit.schedule == BatchSchedule.two_phase()        # a schedule the caller named is the caller's
 
 
 def _failing_worker(rank, world, port, out_dir):
