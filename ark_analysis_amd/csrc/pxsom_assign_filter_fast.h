@@ -130,8 +130,9 @@ template <typename T, bool FIX = false>
 __device__ __forceinline__ void exact_row_accumulate(const T *__restrict__ x, int64_t row, int c, int64_t ldx,
                                                      const double *wt, int k, int32_t *__restrict__ labels,
                                                      double *ls, int lane, const FixPoint *fx = nullptr,
-                                                     double *stats = nullptr)
+                                                     double *stats = nullptr, int cs = 0)
 {
+    if (cs == 0) cs = c;   // row stride of the workgroup's table (acc_stride: padded to an odd number of words)
     const double xa = (double)x[row * ldx + (lane < c ? lane : 0)];   // c <= 32 here: lane j holds channel j
     const unsigned xlo = (unsigned)__double_as_longlong(xa), xhi = (unsigned)(__double_as_longlong(xa) >> 32);
     const int n0 = lane, n1 = lane + 64;
@@ -185,19 +186,19 @@ __device__ __forceinline__ void exact_row_accumulate(const T *__restrict__ x, in
             unsigned long long *lu = reinterpret_cast<unsigned long long *>(ls);
             if (__ballot(!fits) == 0ull) {
                 if (lane < c)
-                    __hip_atomic_fetch_add(lu + (size_t)win * c + lane, (unsigned long long)__double_as_longlong(xa + fx->magic),
+                    __hip_atomic_fetch_add(lu + (size_t)win * cs + lane, (unsigned long long)__double_as_longlong(xa + fx->magic),
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (lane == 0)
-                    __hip_atomic_fetch_add(lu + (size_t)(k + 1) * c + win, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(lu + (size_t)(k + 1) * cs + win, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else {
                 if (lane < c) __hip_atomic_fetch_add(stats + (size_t)win * c + lane, xa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (lane == 0) __hip_atomic_fetch_add(stats + (size_t)k * c + win, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         } else {
             if (lane < c)
-                __hip_atomic_fetch_add(ls + (size_t)win * c + lane, xa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(ls + (size_t)win * cs + lane, xa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (lane == 0)
-                __hip_atomic_fetch_add(ls + (size_t)(k + 1) * c + win, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(ls + (size_t)(k + 1) * cs + win, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
 }
@@ -205,6 +206,11 @@ __device__ __forceinline__ void exact_row_accumulate(const T *__restrict__ x, in
 
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+
+// Row stride of the accumulating filter's workgroup table, in 8-byte words: the channel count padded to an ODD number.  The 64
+// lanes of one ds_add hit words label * stride + (lane group) * CPL + 2 p (+ 1) for 16 unrelated labels: with the natural
+// stride 22 the labels spread over only 8 of the 16 double-word bank pairs (gcd(22, 16) = 2), with 23 over all of them.
+__host__ __device__ inline int acc_stride(int c) { return c | 1; }
 
 // SGB_VALU > 0 forces a 1-MFMA : SGB_VALU-VALU cadence with sched_group_barrier.  Measured (bench.py,
 // filter kernel): 0 -> 0.237 ms, 3 -> 0.252, 5 -> 0.249, 8 -> 0.247: the compiler's own order wins.
@@ -233,7 +239,8 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
     // ACC: table [(k+1)*c sums | (k+1) counts]; row k is a spare one that takes the adds of rows / channel slots that must
     // not count (listed rows, rows a previous group owns, clamped channel slots): the accumulation has no branch
     double *ls = reinterpret_cast<double *>(acc_smem);
-    double *wt = ls + (((size_t)(k + 1) * (c + 1) + 1) & ~(size_t)1);   // [c][k] transposed codebook (ACC only); 16-byte aligned
+    const int cs = acc_stride(c);   // table row stride (words)
+    double *wt = ls + (((size_t)(k + 1) * (cs + 1) + 1) & ~(size_t)1);   // [c][k] transposed codebook (ACC only); 16-byte aligned
     // ACC: rows the filter is not sure of wait in a per-workgroup queue and are settled after the group loop by
     // whichever wave is free (a mini-batch lists 0..6 rows per wave early in training: the slowest wave set the pace)
     constexpr unsigned kAmbQueue = 256;
@@ -276,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
         __syncthreads();
         prep_body<256, 128>(wrow, k, c, hdr_l, frag_l, bias_l, NB, 1, CPL, idx_bits, node_bits, nullptr, nullptr, 0, 0, true);
         __syncthreads();
-        for (int e = threadIdx.x; e < (k + 1) * (c + 1); e += 256) ls[e] = 0.0;   // (the first add comes after the loads' wait)
+        for (int e = threadIdx.x; e < (k + 1) * (cs + 1); e += 256) ls[e] = 0.0;   // (the first add comes after the loads' wait)
         __syncthreads();
         wfrag = frag_l;
         bias = bias_l;
@@ -627,7 +634,7 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
                 for (int t = 0; t < kTilesPerIter; t++) lab[t] = (unsigned)__shfl((int)mine, t * 16 + pix);
 #pragma unroll
                 for (int t = 0; t < kTilesPerIter; t++) {
-                    const unsigned base = lab[t] * (unsigned)c, spare = (unsigned)k * (unsigned)c;
+                    const unsigned base = lab[t] * (unsigned)cs, spare = (unsigned)k * (unsigned)cs;
 #pragma unroll
                     for (int p = 0; p < NP; p++) {
                         const bool own = q * CPL + 2 * p <= c - 2;
@@ -644,9 +651,9 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
                     }
                     if (q == 0) {
                         if constexpr (FIX)
-                            __hip_atomic_fetch_add(lu + (size_t)(k + 1) * c + lab[t], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(lu + (size_t)(k + 1) * cs + lab[t], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         else
-                            __hip_atomic_fetch_add(ls + (size_t)(k + 1) * c + lab[t], 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(ls + (size_t)(k + 1) * cs + lab[t], 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
             }
@@ -664,7 +671,7 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
                 while (late) {
                     const int src = __builtin_ctzll(late);
                     late &= late - 1;
-                    exact_row_accumulate<T, FIX>(x, row0 + src, c, ldx, wt, k, labels, ls, lane, &fx, stats);
+                    exact_row_accumulate<T, FIX>(x, row0 + src, c, ldx, wt, k, labels, ls, lane, &fx, stats, cs);
                 }
             } else {
                 unsigned base = 0;
@@ -685,15 +692,15 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
         __syncthreads();   // every wave is through its groups: the queue is complete
         const unsigned queued = *amb_n < kAmbQueue ? *amb_n : kAmbQueue;   // rows past the end were settled at once
         for (unsigned i = threadIdx.x >> 6; i < queued; i += 4)
-            exact_row_accumulate<T, FIX>(x, amb_q[i], c, ldx, wt, k, labels, ls, lane, &fx, stats);
+            exact_row_accumulate<T, FIX>(x, amb_q[i], c, ldx, wt, k, labels, ls, lane, &fx, stats, cs);
         __syncthreads();
         if constexpr (FIX) {
             int node = (int)threadIdx.x / c, j = (int)threadIdx.x - node * c;   // element e <-> (node, channel), no division per element
             const int dnode = 256 / c, dj = 256 % c;
             for (int e = threadIdx.x; e < k * c; e += 256) {
-                const unsigned long long cnt = lu[(size_t)(k + 1) * c + node];
+                const unsigned long long cnt = lu[(size_t)(k + 1) * cs + node];
                 if (cnt) {
-                    const long long units = (long long)(lu[e] - cnt * fx.mbits);
+                    const long long units = (long long)(lu[(size_t)node * cs + j] - cnt * fx.mbits);
                     if (units) __hip_atomic_fetch_add(stats + e, (double)units * fx.unit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 node += dnode;
@@ -704,13 +711,25 @@ __global__ __launch_bounds__(256, 2) void bmu_filter_fast(
                 }
             }
             for (int e = threadIdx.x; e < k; e += 256) {
-                const unsigned long long cnt = lu[(size_t)(k + 1) * c + e];
+                const unsigned long long cnt = lu[(size_t)(k + 1) * cs + e];
                 if (cnt) __hip_atomic_fetch_add(stats + (size_t)k * c + e, (double)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         } else {
-            for (int e = threadIdx.x; e < k * c + k; e += 256) {
-                const double v = ls[e < k * c ? e : e + c + 0];   // counts sit behind the spare row
+            int node = (int)threadIdx.x / c, j = (int)threadIdx.x - node * c;
+            const int dnode = 256 / c, dj = 256 % c;
+            for (int e = threadIdx.x; e < k * c; e += 256) {
+                const double v = ls[(size_t)node * cs + j];
                 if (v != 0.0) __hip_atomic_fetch_add(stats + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                node += dnode;
+                j += dj;
+                if (j >= c) {
+                    j -= c;
+                    node++;
+                }
+            }
+            for (int e = threadIdx.x; e < k; e += 256) {
+                const double v = ls[(size_t)(k + 1) * cs + e];   // counts sit behind the spare row
+                if (v != 0.0) __hip_atomic_fetch_add(stats + (size_t)k * c + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }

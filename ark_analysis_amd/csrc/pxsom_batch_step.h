@@ -21,9 +21,11 @@ struct StepHdr {
 #pragma clang fp contract(off)
 // One listed row settled by a whole wave: lanes <-> nodes lane and lane + 64, the row's values read from LDS
 // (one address for the wave: a broadcast), distances exactly as the oracle forms them.
+// (cs: row stride of the table in words -- c, or c padded to an odd number against LDS bank conflicts: table_stride())
 __device__ __forceinline__ void exact_row_from_lds(const double *xr, int c, const double *wt, double *ls, int lane,
-                                                   double qmagic)
+                                                   double qmagic, int cs = 0)
 {
+    if (cs == 0) cs = c;
     const int n0 = lane, n1 = lane + 64;
     const int c1 = n1 < kK ? n1 : kK - 1;
     double d0 = 0.0, d1 = 0.0;
@@ -64,9 +66,9 @@ __device__ __forceinline__ void exact_row_from_lds(const double *xr, int c, cons
     const int win = (int)pxsom::wave_min_u32(best == smin ? (unsigned)bestk : 0xffffffffu);
     if (win != 0x7fffffff) {   // 0x7fffffff: no finite distance (NaN row): label 0, not accumulated
         if (lane < c)
-            __hip_atomic_fetch_add(ls + (size_t)win * c + lane, qround(xr[lane], qmagic), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(ls + (size_t)win * cs + lane, qround(xr[lane], qmagic), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (lane == 0)
-            __hip_atomic_fetch_add(ls + (size_t)kK * c + win, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(ls + (size_t)kK * cs + win, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
 #pragma clang fp contract(fast)

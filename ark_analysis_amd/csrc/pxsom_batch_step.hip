@@ -38,6 +38,10 @@ constexpr int kStepThreads = 512, kStepWaves = 8;
 // move (36.0 / 33.1 us before and after: the LDS serialisation is not what holds them) and every step paid for clearing and
 // adding up the copies (tail step 11.4 -> 12.1 us): one table.
 __host__ __device__ inline int table_copies(int c) { return (void)c, 1; }
+// Row stride of the table in 8-byte words: the channel count padded to an ODD number.  The 64 lanes of one ds_add_f64 hit words
+// node * stride + (lane group) * CPL + 2 p for 16 unrelated nodes: with stride 22 the nodes spread over 8 of the 16 double-word
+// bank pairs (gcd(22, 16) = 2), with 23 over all of them (the one-pass kernel's acc_stride: same reason).
+__host__ __device__ inline int table_stride(int c) { return c | 1; }
 
 // LDS carve-up (bytes from the start of the dynamic segment)
 struct StepLds {
@@ -47,7 +51,7 @@ __host__ __device__ inline StepLds step_lds(int c)
 {
     StepLds L;
     size_t o = 0;
-    L.ls = o;    o += ((size_t)kK * c + kK) * 8 * table_copies(c);   // copies x table [K*c sums | K counts]
+    L.ls = o;    o += ((size_t)kK * table_stride(c) + kK) * 8 * table_copies(c);   // copies x table [K x stride sums | K counts]
     L.wt = o;    o += (size_t)c * kK * 8;                 // codebook, transposed [c][K]
     L.tl = o;    o += (size_t)kK * (c + 1) * 8;           // window-sum scratch; later the queue of listed rows
     L.key = o;   o += (size_t)kK * 8;
@@ -92,7 +96,8 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
     // ---- P0: everything that does not depend on the codebook is requested first --------------------------
     // rows of this wave's tiles (rows past the end re-read the last row and are ignored afterwards)
     P2 raw[TPW][NP];
-    const size_t tstride = (size_t)kK * c + kK;      // doubles per copy of the statistics table
+    const int cs = table_stride(c);
+    const size_t tstride = (size_t)kK * cs + kK;     // doubles per copy of the statistics table
     const int ncopies = table_copies(c);
     const unsigned group_w = (unsigned)sa.group_w;
     const double qmagic = sizeof(T) == 8 ? sa.qmagic : 0.0;
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
         if (blk < nblocks) load_rows(blk);
         PXSOM_PHASE(9);
         // (while those are in flight) clear the table and this workgroup's slice of the next buffer
-        for (int e = tid; e < (kK * c + kK) * ncopies; e += kStepThreads) ls[e] = 0.0;
+        for (int e = tid; e < (kK * cs + kK) * ncopies; e += kStepThreads) ls[e] = 0.0;
         if (tid == 0) {
             hdr->q_n = 0u;
             hdr->bad = 0;
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
         load_centring();
         if (blk < nblocks) load_rows(blk);
         PXSOM_PHASE(9);
-        for (int e = tid; e < (kK * c + kK) * ncopies; e += kStepThreads) ls[e] = 0.0;
+        for (int e = tid; e < (kK * cs + kK) * ncopies; e += kStepThreads) ls[e] = 0.0;
         if (tid == 0) {
             hdr->q_n = 0u;
             hdr->bad = 0;
@@ -508,7 +513,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
             const unsigned real = wb == (unsigned)(kNB - 1) ? 16u * wb + 4u * wr + wq : 16u * wb + 4u * wq + wr;
             if (valid && !amb) {
                 double *tab = ls + (size_t)(pix & (ncopies - 1)) * tstride;
-                double *dst = tab + (size_t)real * c + q * CPL;
+                double *dst = tab + (size_t)real * cs + q * CPL;
 #pragma unroll
                 for (int p = 0; p < NP; p++) {
                     if (q * CPL + 2 * p <= c - 2) {   // clamped slots re-read the last pair: not theirs
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
                     }
                 }
                 if (q == 0)
-                    __hip_atomic_fetch_add(tab + (size_t)kK * c + real, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(tab + (size_t)kK * cs + real, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             // listed rows: values into the queue (all four lanes of a pixel agree on amb and on the slot)
             const unsigned mask16 = (unsigned)(__ballot(amb) & 0xffffull);
@@ -558,7 +563,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    exact_row_from_lds(slot, c, wt, ls + (size_t)(wv & (ncopies - 1)) * tstride, lane, qmagic);
+                    exact_row_from_lds(slot, c, wt, ls + (size_t)(wv & (ncopies - 1)) * tstride, lane, qmagic, cs);
                     __builtin_amdgcn_wave_barrier();
                 }
             }
@@ -567,7 +572,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
         __syncthreads();   // every wave is through its tiles: the queue is complete
         const unsigned queued = hdr->q_n < (unsigned)kQueueRows ? hdr->q_n : (unsigned)kQueueRows;
         for (unsigned i = wv; i < queued; i += kStepWaves)
-            exact_row_from_lds(qrows + (size_t)i * c, c, wt, ls + (size_t)(wv & (ncopies - 1)) * tstride, lane, qmagic);
+            exact_row_from_lds(qrows + (size_t)i * c, c, wt, ls + (size_t)(wv & (ncopies - 1)) * tstride, lane, qmagic, cs);
         __syncthreads();
         if (blk + gridDim.x < nblocks && tid == 0) hdr->q_n = 0u;
         PXSOM_PHASE(17);
@@ -584,8 +589,10 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
         for (int it = 0; it < span; it += kStepThreads) {
             if (e >= span) e -= span;
             if (e < total) {
-                double v = ls[e];
-                for (int j = 1; j < ncopies; j++) v += ls[e + (size_t)j * tstride];
+                const int node = e / c;                                              // e -> (node, channel) | count
+                const int le = e < kK * c ? node * cs + (e - node * c) : kK * cs + (e - kK * c);
+                double v = ls[le];
+                for (int j = 1; j < ncopies; j++) v += ls[le + (size_t)j * tstride];
                 if (v != 0.0) __hip_atomic_fetch_add(stats + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             e += kStepThreads;
