@@ -609,7 +609,35 @@ def main():
             wd = torch.from_numpy(oracle_w).to(dev)
             lab_gpu, _ = som_device.assign(x_all[:n_s], wd)
             labels_equal = bool(np.array_equal(lab_gpu.cpu().numpy(), lab_cpu))
+            # The reference's own process-parallel mode beside it (cluster_pixels(multiprocess=True, batch_size=5),
+            # pixel_som_clustering.py:140, :257-271): min(5, cores) worker processes, one FOV table each, the oracle's BMU
+            # search + per-cluster sums; training stays the sequential loop it is.  Workers are fresh interpreters (numpy +
+            # the oracle library only); the span is first compute start -> last compute end.
+            mp_field = None
+            try:
+                procs_n = min(5, os.cpu_count() or 1, f_s)
+                with tempfile.TemporaryDirectory(prefix="pxsom_cpu_mp_") as td:
+                    np.save(os.path.join(td, "w.npy"), oracle_w)
+                    for f in range(procs_n):
+                        np.save(os.path.join(td, "x%d.npy" % f), x_all[f * P:(f + 1) * P].cpu().numpy())
+                    code = ("import sys, time, numpy as np; sys.path.insert(0, %r); from tests import oracle_binding as ob; "
+                            "w = np.load(sys.argv[1]); x = np.load(sys.argv[2]).astype(np.float64); t0 = time.time(); "
+                            "lab, _ = ob.map_data_to_nodes(w, x, column_major_copy=True); ob.cluster_sums(x, lab, w.shape[0]); "
+                            "print(t0, time.time())" % os.path.dirname(os.path.abspath(__file__)))
+                    ps = [subprocess.Popen([sys.executable, "-c", code, os.path.join(td, "w.npy"), os.path.join(td, "x%d.npy" % f)],
+                                           stdout=subprocess.PIPE, text=True) for f in range(procs_n)]
+                    spans = [tuple(float(v) for v in p_.communicate(timeout=600)[0].split()) for p_ in ps]
+                span = max(e for _, e in spans) - min(b for b, _ in spans)
+                label_rate = procs_n * P / span                                   # pixels / s with procs_n workers
+                mp_s = t_train + n_all / label_rate
+                mp_field = {"processes": procs_n, "value": round(n_all / mp_s / 1e6, 4), "unit": "Mpx/s",
+                            "labelling_Mpx_per_s": round(label_rate / 1e6, 3),
+                            "sample": f"{procs_n} worker processes x 1 FOV table each ({span:.2f} s for {procs_n * P} pixels), "
+                                      f"training as above ({t_train:.2f} s, sequential by construction)"}
+            except Exception as err:   # noqa: BLE001 -- a baseline, not the product: say so and go on
+                mp_field = {"error": str(err)[:200]}
             out["cpu_baseline"] = {
+                "multiprocess": mp_field,
                 "value": round(n_all / cpu_s / 1e6, 4), "unit": "Mpx/s", "cores": 1,
                 "host_cores": os.cpu_count(), "kind": "port",
                 "sample": f"oracle online FlowSOM training on the full {n_train}-row training subset "
