@@ -146,7 +146,52 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
     };
     // Order of the requests matters: vmcnt retires loads in issue order, so what is needed first is asked for
     // first -- the statistics (pass 1), then the old node values (P3), the step's rows (HBM, slowest) last.
-    if (sa.has_update) {
+    // BMU-only steps (the tail of a pass: thr = 0.5, r = 0): the window of a node is the node itself -- both separable passes
+    // would add +-0 to S[x][y], the same bits -- so thread <-> (node, lane group) asks for ITS words of the statistics directly
+    // (no scratch pass, no barrier before them), and the gain 1 - (1 - alpha)^n with its expm1 and the reciprocal are formed
+    // once per node by the first two waves (lane <-> node) instead of by all seven waves that hold node lanes: the update of
+    // a tail step was binary64 issue on two waves per SIMD (profiles/r03/step_phase_timing.txt: 1.6 us of 9.1).
+    const int upd_r = sa.thr < 0.0 ? -1 : (sa.thr > 1.0e6 ? 1000000 : (int)floor(sa.thr));
+    const bool bmu_only = sa.has_update != 0 && upd_r == 0;
+    double sdir[CPL];   // bmu_only: this thread's words of the statistics
+    if (bmu_only) {
+        double cnt = 0.0;
+        if (tid < 2 * 64) cnt = sa.stats_prev[(size_t)kK * c + (tid < kK ? tid : 0)];
+#pragma unroll
+        for (int i = 0; i < CPL; i++) {
+            const int ch = nq * CPL + i;
+            sdir[i] = sa.stats_prev[(has_node && ch < c) ? (size_t)node * c + ch : 0];
+        }
+#pragma unroll
+        for (int i = 0; i < CPL; i++) {
+            const int ch = nq * CPL + i;
+            wv_[i] = sa.w_in[(has_node && ch < c) ? (size_t)node * c + ch : 0];
+        }
+        load_centring();
+        if (blk < nblocks) load_rows(blk);
+        PXSOM_PHASE(9);
+        for (int e = tid; e < (kK * cs + kK) * ncopies; e += kStepThreads) ls[e] = 0.0;
+        if (tid == 0) {
+            hdr->q_n = 0u;
+            hdr->bad = 0;
+        }
+        if (tid < 64) bias_l[6 * 64 + tid] = f32x4{kNegBig, kNegBig, kNegBig, kNegBig};   // rows of the last block without a node
+        if (sa.stats_zero) {
+            const int per = (sa.zero_count + (int)gridDim.x - 1) / (int)gridDim.x;
+            const int z1 = min(((int)blockIdx.x + 1) * per, sa.zero_count);
+            for (int e = (int)blockIdx.x * per + tid; e < z1; e += kStepThreads) sa.stats_zero[e] = 0.0;
+        }
+        park_centring();
+        if (tid < kK) {   // tl[node] = gain (or -1: no rows, the node stays), tl[K + node] = 1 / n
+#pragma clang fp contract(off)
+            const double den = 0.0 + cnt;
+            tl[tid] = den > 0.0 ? -expm1(den * sa.lg) : -1.0;
+            tl[kK + tid] = den > 0.0 ? 1.0 / den : 0.0;
+        }
+        PXSOM_PHASE(10);
+        PXSOM_PHASE(11);
+        __syncthreads();
+    } else if (sa.has_update) {
         // pass 1 of the separable window sums: thread <-> (grid row gx, column cc); column c carries the counts
         double S[kYD];
         const bool p1 = tid < kXD * NC;
@@ -258,7 +303,10 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
             const int xp = node / kYD, yp = node - xp * kYD;
             const double *nrow = tl + (size_t)(yp * kXD + xp) * NC;
             double inv = 0.0;
-            if (sa.has_update) {
+            if (bmu_only) {
+                gain = tl[node];
+                inv = tl[kK + node];
+            } else if (sa.has_update) {
                 den = nrow[c];
                 // gain = 1 - (1-alpha)^den = -expm1(den * log(1-alpha)); == 1 exactly for wide windows: the node is
                 // then the window mean itself (orc_batch_update)
@@ -273,7 +321,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
                 if (ch < c) {
                     double v = wv_[i];
                     if (gain >= 0.0) {   // (idle channel slots hold whatever word 0 held: never used)
-                        const double num = nrow[ch];
+                        const double num = bmu_only ? 0.0 + sdir[i] : nrow[ch];
                         v = gain == 1.0 ? num * inv : v + gain * (num * inv - v);
                     }
                     wv_[i] = v;
@@ -372,9 +420,11 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
                 ee &= __shfl_xor(ee, 2);
                 return ee != 0;
             };
+            // (BMU-only steps do not look for duplicates: the first of two equal nodes takes all their rows and moves away
+            // within a step; until then their rows are listed and settled exactly -- the labels do not depend on the mask)
             int hit = 0x7fffffff;
 #pragma unroll 5
-            for (int prev = nq; prev < kK; prev += 4) hit = min(hit, (prev < node && key[prev] == kkey) ? prev : 0x7fffffff);
+            for (int prev = nq; prev < (bmu_only ? 0 : kK); prev += 4) hit = min(hit, (prev < node && key[prev] == kkey) ? prev : 0x7fffffff);
             hit = min(hit, __shfl_xor(hit, 1));
             hit = min(hit, __shfl_xor(hit, 2));
             bool dup = false;
