@@ -618,18 +618,20 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
                 }
             }
         }
-        PXSOM_PHASE(16);
-        __syncthreads();   // every wave is through its tiles: the queue is complete
+    }
+    // the listed rows of ALL rounds are settled together, by whichever wave is free: a round no longer ends in two barriers
+    // (the queue keeps the rows' values; what does not fit was settled on the spot)
+    PXSOM_PHASE(16);
+    __syncthreads();   // every wave is through its tiles: the queue is complete
+    {
         const unsigned queued = hdr->q_n < (unsigned)kQueueRows ? hdr->q_n : (unsigned)kQueueRows;
         for (unsigned i = wv; i < queued; i += kStepWaves)
             exact_row_from_lds(qrows + (size_t)i * c, c, wt, ls + (size_t)(wv & (ncopies - 1)) * tstride, lane, qmagic, cs);
         __syncthreads();
-        if (blk + gridDim.x < nblocks && tid == 0) hdr->q_n = 0u;
         PXSOM_PHASE(17);
 #ifdef PXSOM_PHASE_TIMING
         if (tid == 0 && blockIdx.x == 0) g_phase_ticks[21] = (long long)queued;
 #endif
-        if (blk + gridDim.x < nblocks) __syncthreads();
     }
     // ---- P9: flush.  Every workgroup starts at a different offset, so that the workgroups of a launch (which all
     // get here at about the same time) do not queue up on the same few addresses.
