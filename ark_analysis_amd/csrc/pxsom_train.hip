@@ -1739,22 +1739,35 @@ __global__ __launch_bounds__(256) void centring_vector_kernel(const double *__re
                                                               double *__restrict__ zero_out, int zero_count)
 {
     for (int e = threadIdx.x; e < zero_count; e += 256) zero_out[e] = 0.0;   // the first step's statistics buffer (no memset launch)
-    const int j = threadIdx.x >> 1, part = threadIdx.x & 1;   // 2 adjacent lanes share a channel (c <= 128)
+    // `parts` adjacent lanes share a channel (8 for c <= 32, 2 for c <= 128): each sums every parts-th node with its loads in
+    // flight eight at a time -- a lane walking 50 nodes one L2 round trip after the other made this launch 16 us
+    const int cp = c <= 32 ? 32 : (c <= 64 ? 64 : 128), parts = 256 / cp;
+    const int j = threadIdx.x / parts, part = threadIdx.x % parts;
     double sum = 0.0;
-    if (j < c)
-        for (int node = part; node < k; node += 2) sum += w[(size_t)node * c + j];
-    sum += __shfl_xor(sum, 1);
+    if (j < c) {
+        for (int n0 = part; n0 < k; n0 += 8 * parts) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = n0 + u * parts < k ? w[(size_t)(n0 + u * parts) * c + j] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; u++) sum += v[u];
+        }
+    }
+    for (int d = 1; d < parts; d *= 2) sum += __shfl_xor(sum, d);
     float m = (float)(sum / (double)k);
     if (!(j < c && fabsf(m) <= 3.0e38f)) m = 0.f;   // a non-finite codebook: not centred (every row is listed anyway)
-    if (part == 0) mu32[j] = m;
+    if (part == 0 && j < pxsom_bmu::kFilterMaxChannels) mu32[j] = m;
     // word 128: the vector's norm (the steps cap their power-of-two scale with it: pxsom_batch_step.hip)
     __shared__ float s_m[pxsom_bmu::kFilterMaxChannels];
-    if (part == 0) s_m[j] = m;
+    if (threadIdx.x < pxsom_bmu::kFilterMaxChannels) s_m[threadIdx.x] = 0.f;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double n2 = 0.0;
-        for (int i = 0; i < pxsom_bmu::kFilterMaxChannels; i++) n2 += (double)s_m[i] * (double)s_m[i];
-        mu32[pxsom_bmu::kFilterMaxChannels] = (float)sqrt(n2);
+    if (part == 0 && j < pxsom_bmu::kFilterMaxChannels) s_m[j] = m;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const double a = (double)s_m[threadIdx.x], b = (double)s_m[threadIdx.x + 64];
+        double n2 = a * a + b * b;
+        for (int d = 1; d < 64; d *= 2) n2 += __shfl_xor(n2, d);
+        if (threadIdx.x == 0) mu32[pxsom_bmu::kFilterMaxChannels] = (float)sqrt(n2);
     }
 }
 
