@@ -20,7 +20,7 @@ EXTRA_FLAGS = {"pxsom_assign_filter.hip": ["-ffinite-math-only"] + (
     ["-DPXSOM_STREAM_TP=" + os.environ["PXSOM_STREAM_TP"]] if "PXSOM_STREAM_TP" in os.environ else []) + (
     ["-DPXSOM_PACKED_TMERGE=" + os.environ["PXSOM_PACKED_TMERGE"]] if "PXSOM_PACKED_TMERGE" in os.environ else [])}
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-               "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
+               "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"] + os.environ.get("PXSOM_HIPCC_EXTRA", "").split()   # (ablation builds)
 
 
 def _hipcc() -> str:

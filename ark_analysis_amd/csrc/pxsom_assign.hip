@@ -34,10 +34,14 @@ namespace {
 // the list's length; the latter settles a row in about 0.4 ps x K x C on the whole chip: they meet near 2.25e6 / C
 // rows (measured: 100 K rows at C = 22, 22 K at C = 100).
 // PXSOM_SCREEN_MIN_ROWS overrides it (the tests send short lists through the screened kernel as well).
-static unsigned screen_min_rows(int c)
+// Codebooks whose binary32 copy the screened kernel stages in LDS (12 .. 64 KB): its lane groups share the nodes of a short
+// batch, and the crossover drops to 8 K rows (measured on config 4, 100 x 100: pass 2.68 / 2.70 / 2.64 / 2.91 ms with the
+// crossover at 22.5 K / 2 K / 8 K / 512 rows).
+static unsigned screen_min_rows(int c, bool w32_in_lds)
 {
     if (const char *forced = getenv("PXSOM_SCREEN_MIN_ROWS")) return (unsigned)strtoul(forced, nullptr, 10);
-    return (unsigned)(2250000 / (c > 0 ? c : 1));
+    const unsigned by_width = (unsigned)(2250000 / (c > 0 ? c : 1));
+    return w32_in_lds ? std::min(by_width, 8192u) : by_width;
 }
 
 // NT threads in ONE workgroup: 256, or 1024 for codebooks of more than 128 nodes (every phase is a loop over
@@ -276,6 +280,10 @@ __global__ __launch_bounds__(256) void bmu_exact_kernel(const T *__restrict__ x,
 //          smallest distance and, among equal ones, the smallest node: the oracle's first strict minimum.
 // ------------------------------------------------------------------------------------------------
 constexpr int kPairCap = 512;
+// timing ablations (scripts/jobs/r4_exact_ablate.sh; wrong labels): 1 = pairs not evaluated, 2 = no node walk, 4 = no reference distance
+#ifndef PXSOM_SCREEN_ABLATE
+#define PXSOM_SCREEN_ABLATE 0
+#endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void wave_lds_sync()
@@ -284,7 +292,10 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
-template <typename T, int CB, int NU>   // c <= 8 * CB = Layout::cp32; NU nodes' codebook rows requested together
+// WLDS: the binary32 codebook copy is staged in LDS and read as broadcasts.  The scalar cache (16 KB) serves a small table
+// at a few cycles per load; a table that does not fit it (config 4: 100 x 104 floats = 42 KB) turns every 64-byte scalar
+// load into an L2 round trip the wave waits for -- seven per node, 465 us for a batch of 64 rows.
+template <typename T, int CB, int NU, bool WLDS>   // c <= 8 * CB = Layout::cp32; NU nodes' codebook rows requested together
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CB <= 3 || (sizeof(T) <= 4 && CB <= 5)) ? 4 : 2)))
 void bmu_exact_screened_kernel(const T *__restrict__ x, int c, int64_t ldx,
                                                                  const double *__restrict__ w,
@@ -301,16 +312,49 @@ void bmu_exact_screened_kernel(const T *__restrict__ x, int c, int64_t ldx,
     __shared__ long long s_row[4][64];
     constexpr bool kNarrow = sizeof(T) <= 4;   // binary16 / binary32 rows: a NaN / Inf shows in the binary32 copy
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const unsigned nbatches = (count + 63) / 64;
+    if (blockIdx.x * 16u >= count) return;   // uniform per workgroup: no batch for it even at four rows per wave
+    extern __shared__ __attribute__((aligned(16))) float s_w32[];
+    if constexpr (WLDS) {
+        const int words4 = k * (8 * CB) / 4;
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(w32);
+        for (int e0 = threadIdx.x; e0 < words4; e0 += 4 * 256) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = src[e0 + u * 256 < words4 ? e0 + u * 256 : 0];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (e0 + u * 256 < words4) reinterpret_cast<f32x4 *>(s_w32)[e0 + u * 256] = v[u];
+        }
+        __syncthreads();
+    }
     const double u24 = 0x1p-24;
     const bool blind = hdr->force_exact != 0 || !(hdr->scale > 0.f);
     const double wn = blind ? 0.0 : (double)hdr->wn_raw;   // (uncentred: the bound is on rounding x and w themselves)
     const double eta = (double)(c + 4) * u24;
     const unsigned long long kInitD = (unsigned long long)__double_as_longlong(DBL_MAX);
 
-    // every wave works through batches of 64 listed rows on its own
-    for (unsigned bt = blockIdx.x * 4 + wv; bt < nbatches; bt += gridDim.x * 4) {
-        const unsigned e = bt * 64 + lane;
+    // A wave takes 64 / G listed rows at a time and G lane groups share the nodes among them (group g: nodes
+    // [g * kper, (g + 1) * kper)): a batch costs 1 / G of the node walk, so a list too short to give every wave of the
+    // launch 64 rows still spreads over all of them, and a long one ends in a short last round.  G is the power of two
+    // that minimises rounds x (1 / G + fixed part); the LDS copy is what lets the groups read different nodes (the
+    // scalar path reads one node for the whole wave: G = 1).
+    const unsigned nwaves = gridDim.x * 4;
+    int G = 1;
+    if constexpr (WLDS) {
+        float best = 3.0e38f;
+        for (int g = 1; g <= 16; g *= 2) {
+            const unsigned nb = (count * (unsigned)g + 63u) / 64u;
+            const float cost = (float)((nb + nwaves - 1) / nwaves) * (1.0f / (float)g + 0.24f);
+            if (cost < best) { best = cost; G = g; }
+        }
+    }
+    const int rpw = 64 / G, kper = (k + G - 1) / G;
+    const int grp = lane / rpw, slot = lane % rpw;
+    const int node_lo = grp * kper, node_hi = min(k, node_lo + kper);
+    const unsigned nbatches_g = (count + (unsigned)rpw - 1) / (unsigned)rpw;
+
+    for (unsigned bt = blockIdx.x * 4 + wv; bt < nbatches_g; bt += nwaves) {
+        const unsigned e = bt * (unsigned)rpw + (unsigned)slot;
         const bool valid = e < count;
         const int64_t row = amb_list[valid ? e : count - 1];
         const T *rp = x + row * ldx;
@@ -320,9 +364,7 @@ void bmu_exact_screened_kernel(const T *__restrict__ x, int c, int64_t ldx,
             const float v = (float)rp[j < c ? j : c - 1];
             xv[j] = j < c ? v : 0.f;
         }
-        s_bestd[wv][lane] = kInitD;
-        s_bestk[wv][lane] = 0x7fffffff;
-        s_row[wv][lane] = row;
+        if (grp == 0) s_row[wv][slot] = row;
         float n2 = 0.f;
         bool finite_x = true;
 #pragma unroll
@@ -333,20 +375,47 @@ void bmu_exact_screened_kernel(const T *__restrict__ x, int c, int64_t ldx,
         int ref = labels[row] - 1;
         if ((unsigned)ref >= (unsigned)k) ref = 0;
         wave_lds_sync();
-        // the oracle's distance of one listed row to one node (rows re-read from memory: they are in L2)
-        auto oracle_distance = [&](int node, int64_t r) __attribute__((always_inline)) {
+        // the oracle's distance of the listed row in slot `rl` to one node.  binary16 / binary32 rows: xv IS the row (the
+        // conversion to binary32 is exact), so the value comes out of the registers of lane rl (group 0 holds slot rl in
+        // lane rl; ds_bpermute: no memory traffic); binary64 rows are re-read (L2)
+        auto oracle_distance = [&](int node, int rl, int64_t r) __attribute__((always_inline)) {
 #pragma clang fp contract(off)
             const double *wk = w + (size_t)node * c;
-            const T *rq = x + r * ldx;
             double acc = 0.0;
+            if constexpr (kNarrow) {
+                // eight codebook values requested together; a channel past c adds an exact +0.0 (no branch per channel:
+                // the compiler turns one into a load -> wait -> add chain of a hundred round trips)
+#pragma unroll
+                for (int j0 = 0; j0 < 8 * CB; j0 += 8) {
+                    double wv8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) wv8[u] = wk[j0 + u < c ? j0 + u : 0];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const float xj = __shfl(xv[j0 + u], rl, 64);
+                        double t = (double)xj - wv8[u];
+                        t = j0 + u < c ? t : 0.0;
+                        acc += t * t;
+                    }
+                }
+            } else {
+                const T *rq = x + r * ldx;
 #pragma unroll(CB >= 16 ? 4 : 8)
-            for (int j = 0; j < c; j++) {
-                const double t = (double)rq[j] - wk[j];
-                acc += t * t;
+                for (int j = 0; j < c; j++) {
+                    const double t = (double)rq[j] - wk[j];
+                    acc += t * t;
+                }
             }
             return sqrt(acc);
         };
-        const double dref = oracle_distance(ref, row);
+        const double dref = (PXSOM_SCREEN_ABLATE & 4) ? 1.0 : oracle_distance(ref, lane, row);   // (every group for its own copy of the row: same value)
+        // the reference node's distance is the row's first candidate (the pairs below leave that node out)
+        if (grp == 0) {
+            const bool seeded = dref < DBL_MAX;   // NaN / Inf never replace the oracle's DBL_MAX
+            s_bestd[wv][slot] = seeded ? (unsigned long long)__double_as_longlong(dref) : kInitD;
+            s_bestk[wv][slot] = seeded ? ref : 0x7fffffff;
+        }
+        wave_lds_sync();
         // rows with a NaN / Inf keep label 0 in the oracle (no distance is ever below DBL_MAX): nothing to evaluate
         const bool skip = !valid || (kNarrow && !finite_x);
         float thr = __builtin_inff();
@@ -359,12 +428,13 @@ void bmu_exact_screened_kernel(const T *__restrict__ x, int c, int64_t ldx,
 
         unsigned npairs = 0;
         auto flush = [&]() __attribute__((always_inline)) {
+            if (PXSOM_SCREEN_ABLATE & 1) npairs = 0;
             for (unsigned p0 = 0; p0 < npairs; p0 += 64) {
                 const unsigned p = p0 + lane;
                 const bool on = p < npairs;
                 const unsigned pr = s_pairs[wv][on ? p : 0];
                 const int rl = (int)(pr >> 16), node = (int)(pr & 0xffffu);
-                const double dist = oracle_distance(node, s_row[wv][rl]);
+                const double dist = oracle_distance(node, rl, kNarrow ? 0 : s_row[wv][rl]);
                 const bool ok = on && dist < DBL_MAX;          // NaN / Inf never replace the oracle's DBL_MAX
                 const unsigned long long bits = (unsigned long long)__double_as_longlong(dist);
                 const unsigned long long before = s_bestd[wv][rl];
@@ -379,21 +449,21 @@ void bmu_exact_screened_kernel(const T *__restrict__ x, int c, int64_t ldx,
             }
             npairs = 0;
         };
-        for (int node = 0; node < k; node += NU) {
+        for (int i = 0; i < ((PXSOM_SCREEN_ABLATE & 2) ? 0 : kper); i += NU) {
             float d[NU];
             {
 #pragma clang fp contract(fast)
 #pragma unroll
                 for (int u = 0; u < NU; u++) {
-                    const int nd = node + u < k ? node + u : k - 1;
-                    const float *wr = w32 + (size_t)nd * (8 * CB);   // rows are zero-padded to 8 * CB channels
+                    const int nd = node_lo + i + u < k ? node_lo + i + u : k - 1;
+                    const float *wr = (WLDS ? s_w32 : w32) + (size_t)nd * (8 * CB);   // rows are zero-padded to 8 * CB channels
                     f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};   // independent chains
 #pragma unroll
-                    for (int i = 0; i < 4 * CB; i++) {
-                        const f32x2 wv2 = {wr[2 * i], wr[2 * i + 1]};
-                        const f32x2 xx = {xv[2 * i], xv[2 * i + 1]};
+                    for (int q = 0; q < 4 * CB; q++) {
+                        const f32x2 wv2 = {wr[2 * q], wr[2 * q + 1]};
+                        const f32x2 xx = {xv[2 * q], xv[2 * q + 1]};
                         const f32x2 t = xx - wv2;
-                        acc[i & 3] = t * t + acc[i & 3];
+                        acc[q & 3] = t * t + acc[q & 3];
                     }
                     const f32x2 sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
                     d[u] = sum.x + sum.y;
@@ -401,11 +471,12 @@ void bmu_exact_screened_kernel(const T *__restrict__ x, int c, int64_t ldx,
             }
 #pragma unroll
             for (int u = 0; u < NU; u++) {
-                const bool flag = !skip && node + u < k && !(d[u] > thr);   // a NaN stays in: binary64 decides
+                const int nd = node_lo + i + u;
+                const bool flag = !skip && nd < node_hi && nd != ref && !(d[u] > thr);   // a NaN stays in: binary64 decides
                 const unsigned long long m = __ballot(flag);
                 if (m) {
                     const unsigned ahead = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    if (flag) s_pairs[wv][npairs + ahead] = ((unsigned)lane << 16) | (unsigned)(node + u);
+                    if (flag) s_pairs[wv][npairs + ahead] = ((unsigned)slot << 16) | (unsigned)nd;
                     npairs += (unsigned)__popcll(m);
                     if (npairs > (unsigned)(kPairCap - 64)) {
                         wave_lds_sync();
@@ -416,8 +487,8 @@ void bmu_exact_screened_kernel(const T *__restrict__ x, int c, int64_t ldx,
         }
         wave_lds_sync();
         flush();
-        if (valid) {
-            const int win = s_bestk[wv][lane];
+        if (valid && grp == 0) {
+            const int win = s_bestk[wv][slot];
             labels[row] = win == 0x7fffffff ? 0 : win + 1;
         }
         wave_lds_sync();
@@ -641,7 +712,10 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
     // or two rounds (workgroups without rows leave at once)
     int egrid = (int)std::min<int64_t>((n + 31) / 32, (int64_t)cus * 4);
     if (egrid < 1) egrid = 1;
-    const unsigned screened_from = screen_min_rows(c);
+    // the binary32 codebook copy: scalar cache while it fits it, LDS up to 64 KB (two workgroups per CU), L2 beyond
+    const size_t w32_bytes = (size_t)k * L.cp32 * sizeof(float);
+    const bool w32_lds = w32_bytes > 12 * 1024 && w32_bytes <= 64 * 1024;
+    const unsigned screened_from = screen_min_rows(c, w32_lds);
     hipLaunchKernelGGL(bmu_exact_kernel<T>, dim3(egrid), dim3(256), use_lds ? wt_bytes : 0, st, x, c, ldx, w,
                        k, reinterpret_cast<const AssignHdr *>(ws),
                        reinterpret_cast<const unsigned *>(ws + L.off_list), labels, use_lds,
@@ -651,12 +725,19 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
         void (*kern)(const T *, int, int64_t, const double *, const float *, int, const AssignHdr *, const unsigned *, int32_t *,
                      unsigned) = nullptr;
         switch (L.cp32 / 8) {
-#define PXSOM_SCREENED(CB) case CB: kern = bmu_exact_screened_kernel<T, CB, (CB <= 3 ? 4 : CB <= 6 ? 2 : 1)>; break;
+#define PXSOM_SCREENED(CB)                                                                                  \
+    case CB:                                                                                                \
+        kern = w32_lds ? bmu_exact_screened_kernel<T, CB, (CB <= 3 ? 4 : CB <= 6 ? 2 : 1), true>            \
+                       : bmu_exact_screened_kernel<T, CB, (CB <= 3 ? 4 : CB <= 6 ? 2 : 1), false>;          \
+        break;
             PXSOM_SCREENED(2) PXSOM_SCREENED(3) PXSOM_SCREENED(4) PXSOM_SCREENED(5) PXSOM_SCREENED(6) PXSOM_SCREENED(8)
             PXSOM_SCREENED(10) PXSOM_SCREENED(13) PXSOM_SCREENED(16)
 #undef PXSOM_SCREENED
         }
-        hipLaunchKernelGGL(kern, dim3(cus * 4), dim3(256), 0, st, x, c, ldx, w, reinterpret_cast<const float *>(ws + L.off_w32), k,
+        // every workgroup resident at once (the kernel sizes its batches by the waves of the launch)
+        const int cb = L.cp32 / 8, by_regs = (cb <= 3 || (sizeof(T) <= 4 && cb <= 5)) ? 4 : 2;
+        const int by_lds = w32_lds ? (int)std::max<size_t>(1, (160 * 1024) / (w32_bytes + 12 * 1024)) : by_regs;
+        hipLaunchKernelGGL(kern, dim3(cus * std::min(by_regs, by_lds)), dim3(256), w32_lds ? w32_bytes : 0, st, x, c, ldx, w, reinterpret_cast<const float *>(ws + L.off_w32), k,
                            reinterpret_cast<const AssignHdr *>(ws), reinterpret_cast<const unsigned *>(ws + L.off_list), labels,
                            screened_from);
         PXSOM_LAUNCH_CHECK("bmu_exact_screened_kernel");

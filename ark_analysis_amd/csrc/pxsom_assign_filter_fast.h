@@ -217,6 +217,9 @@ __host__ __device__ inline int acc_stride(int c) { return c | 1; }
 #ifndef SGB_VALU
 #define SGB_VALU 0
 #endif
+#ifndef PXSOM_FAST_WGS
+#define PXSOM_FAST_WGS 2
+#endif
 #ifndef PXSOM_FINE_BLOCKS
 #define PXSOM_FINE_BLOCKS 2
 #endif
@@ -229,7 +232,7 @@ __host__ __device__ inline int acc_stride(int c) { return c | 1; }
 // FIX (with ACC; pxsom_assign_sums): the workgroup's table is 64-bit fixed point (FixPoint above), fix_rows_log2 =
 // ceil(log2(rows a workgroup can meet)).
 template <typename T, int CPL, int NB, int RU, int MODE, bool ACC, bool FIX = false, bool TWO = true>
-__global__ __launch_bounds__(256, 2) void bmu_filter_fast(
+__global__ __launch_bounds__(256, PXSOM_FAST_WGS) void bmu_filter_fast(
     const T *__restrict__ x, int64_t n, int c, int64_t ldx, const half8 *__restrict__ wfrag,
     const f32x4 *__restrict__ bias, AssignHdr *hdr, unsigned *__restrict__ amb_list,
     int32_t *__restrict__ labels, int k, double *__restrict__ stats, const double *__restrict__ wcodes,

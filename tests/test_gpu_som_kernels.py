@@ -140,6 +140,8 @@ def test_assign_identical_codebook_rows(gpu, oracle):
     (40_000, 22, 100, np.float32),     # config 2's codebook
     (30_000, 40, 400, np.float16),     # config 5's
     (30_000, 100, 100, np.float32),    # config 4's
+    (2_500, 100, 100, np.float32),     # ... a short list: sixteen lane groups share the nodes of four rows per wave
+    (1_500, 40, 400, np.float16),      # config 5's, short list
     (20_000, 7, 97, np.float64),       # odd channel count, binary64 rows
     (12_000, 128, 225, np.float32),    # the widest rows
     (9_000, 3, 1024, np.float32),      # the largest codebook
@@ -176,7 +178,7 @@ def test_long_exact_lists_are_screened_and_stay_bit_exact(gpu, oracle, monkeypat
     if pattern != "ties":          # (coarse-grid ties list thousands of rows for most shapes, not for all)
         # (the filters centre rows and codebook: an offset blob is no longer "every row near-tied" for them -- the rows no
         # shortcut survives remain)
-        assert sd.last_exact_rows(sd.assign.last_workspace) >= (2048 if pattern == "crowded" else 256)
+        assert sd.last_exact_rows(sd.assign.last_workspace) >= (min(2048, n // 2) if pattern == "crowded" else 256)
     want, _ = oracle.map_data_to_nodes(w, x.astype(np.float64))
     np.testing.assert_array_equal(got, want)
     monkeypatch.delenv("PXSOM_SCREEN_MIN_ROWS")        # and the default split between the two exact kernels
