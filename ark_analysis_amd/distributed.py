@@ -209,6 +209,26 @@ def _all_ranks_ok(ok: bool, group) -> bool:
     return bool(flag.item())
 
 
+def _exchange_verified(comm, group) -> bool:
+    """One all-reduce of a known payload through a communicator that was just made, before any training step depends on it:
+    every rank contributes ``j * (rank + 1) + rank / 4`` (exact in binary64, so the sum is the same bits in any order) and
+    checks the closed form.  The verdict is agreed (MIN over the ranks): a route whose first run on this hardware returns
+    anything else -- or raises -- is dropped by all ranks together, and the caller falls back."""
+    ok = True
+    try:
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        base = torch.arange(2300, dtype=torch.float64, device=dev)
+        got = base * float(rank + 1) + 0.25 * rank
+        comm.allreduce_sum(got)
+        torch.cuda.synchronize()
+        want = base * (world * (world + 1) / 2.0) + 0.25 * (world * (world - 1) / 2.0)
+        ok = bool(torch.equal(got, want))
+    except Exception:      # noqa: BLE001 -- agreed below
+        ok = False
+    return _all_ranks_ok(ok, group)
+
+
 def _group_key(group):
     """What identifies a process group for the communicator cache: its global ranks (an ``id()`` can be reused once the
     group object is collected)."""
@@ -246,7 +266,10 @@ def native_exchange(group=None):
                 err = e
                 comm.close()
                 comm = None
-        if not _all_ranks_ok(comm is not None, group):
+        usable = _all_ranks_ok(comm is not None, group)
+        if usable and not _exchange_verified(comm, group):
+            usable, err = False, "its first all-reduce did not return the expected sums"
+        if not usable:
             if comm is not None:
                 comm.close()
             comm = None
@@ -272,7 +295,10 @@ def native_exchange(group=None):
                 comm = som_device.RankComm(box[0], world, rank)
             except Exception as e:
                 err = e
-            if not _all_ranks_ok(comm is not None, group):
+            usable = _all_ranks_ok(comm is not None, group)
+            if usable and not _exchange_verified(comm, group):
+                usable, err = False, "its first all-reduce did not return the expected sums"
+            if not usable:
                 if comm is not None:
                     comm.close()
                 comm = None

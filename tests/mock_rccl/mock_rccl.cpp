@@ -92,6 +92,8 @@ __attribute__((visibility("default"))) ncclResult_t ncclAllReduce(const void *se
     for (int r = 0; r < c->nranks; r++)
         for (size_t i = 0; i < count; i++) total[i] += c->seg->buf[r][i];
     barrier(c);   // everybody has read: the slots may be overwritten by the next call
+    // fault injection (tests/test_gpu_exchange.py): a collective library whose sums are off by one in the first word
+    if (count && getenv("MOCK_RCCL_WRONG_SUM")) total[0] += 1.0;
     if (hipMemcpy(recvbuff, total.data(), count * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
         return ncclUnhandledCudaError;
     return ncclSuccess;

@@ -282,3 +282,50 @@ def test_p2p_exchange_two_ranks_on_one_device(oracle, tmp_path):
     # rows of phase p: oracle index i % (2 * phases) ... the oracle deals by i % phases, so interleave within a phase pair
     want = oracle.som_batch_sched(g, w0, xdim, ydim, 1, (0.05, 0.01), default_radius_range(xdim, ydim), phases, sch.edges)
     np.testing.assert_allclose(res["w"], want, rtol=1e-9, atol=0)
+
+
+def _native_exchange_worker(rank, world, lib_path, port, out_path, wrong):
+    os.environ.update(PXSOM_RCCL_LIBRARY=lib_path, PXSOM_NATIVE_EXCHANGE="force", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if wrong:
+        os.environ["MOCK_RCCL_WRONG_SUM"] = "1"
+    import warnings
+    import torch as th
+    import torch.distributed as dist
+    from ark_analysis_amd import distributed
+    th.cuda.set_device(0)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        comm = distributed.native_exchange(None)
+    verdict = "none" if comm is None else type(comm).__name__
+    if comm is not None:        # a communicator that passed its first all-reduce serves the next one as well
+        t = th.full((64,), float(rank + 1), dtype=th.float64, device="cuda")
+        comm.allreduce_sum(t)
+        th.cuda.synchronize()
+        assert float(t[0]) == world * (world + 1) / 2
+    with open(out_path % rank, "w") as f:
+        f.write(verdict + "|" + ";".join(str(w.message) for w in caught))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("wrong", [False, True])
+def test_a_communicator_is_checked_before_it_is_trusted(tmp_path, wrong):
+    """`distributed.native_exchange` runs one all-reduce of a known payload through a communicator it has just made; a
+    collective library that returns other sums (here: the stand-in library with an off-by-one first word) is dropped by
+    both ranks together -- the run all-reduces through torch.distributed instead -- and rank 0 says why."""
+    import socket
+    import torch.multiprocessing as mp
+    lib_path = _mock_library(tmp_path)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "verdict%d.txt")
+    mp.spawn(_native_exchange_worker, args=(2, lib_path, port, out, wrong), nprocs=2, join=True)
+    v0, v1 = open(out % 0).read(), open(out % 1).read()
+    if wrong:
+        assert v0.startswith("none|") and v1.startswith("none|")
+        assert "did not return the expected sums" in v0
+    else:
+        assert v0.startswith("RankComm|") and v1.startswith("RankComm|")
