@@ -142,6 +142,7 @@ def test_assign_identical_codebook_rows(gpu, oracle):
     (30_000, 100, 100, np.float32),    # config 4's
     (2_500, 100, 100, np.float32),     # ... a short list: sixteen lane groups share the nodes of four rows per wave
     (1_500, 40, 400, np.float16),      # config 5's, short list
+    (6_000, 100, 100, np.float64),     # binary64 rows with the LDS-staged copy (rows re-read, not taken from registers)
     (20_000, 7, 97, np.float64),       # odd channel count, binary64 rows
     (12_000, 128, 225, np.float32),    # the widest rows
     (9_000, 3, 1024, np.float32),      # the largest codebook
