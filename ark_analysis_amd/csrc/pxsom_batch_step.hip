@@ -633,21 +633,21 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
         if (tid == 0 && blockIdx.x == 0) g_phase_ticks[21] = (long long)queued;
 #endif
     }
-    // ---- P9: flush.  Every workgroup starts at a different offset, so that the workgroups of a launch (which all
-    // get here at about the same time) do not queue up on the same few addresses.
+    // ---- P9: flush.  Every workgroup starts at a different WORD (blockIdx * 97 mod the table's length), so that the workgroups
+    // of a launch -- which all get here at about the same time -- are spread over the whole buffer instead of queueing up on the
+    // same few cache lines (five starting points, as it was until round 4, left 14 - 25 workgroups of a small step on each:
+    // scripts/ubench/flush_replicas.hip issues 69 x 2 300 atomics in under 1 us this way)
     {
-        const int total = kK * c + kK, span = (total + kStepThreads - 1) / kStepThreads * kStepThreads;
-        int e = tid + (int)((blockIdx.x * 7u) % (unsigned)(span / kStepThreads)) * kStepThreads;
-        for (int it = 0; it < span; it += kStepThreads) {
-            if (e >= span) e -= span;
-            if (e < total) {
-                const int node = e / c;                                              // e -> (node, channel) | count
-                const int le = e < kK * c ? node * cs + (e - node * c) : kK * cs + (e - kK * c);
-                double v = ls[le];
-                for (int j = 1; j < ncopies; j++) v += ls[le + (size_t)j * tstride];
-                if (v != 0.0) __hip_atomic_fetch_add(stats + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            e += kStepThreads;
+        const int total = kK * c + kK;
+        const int shift = (int)((blockIdx.x * 97u) % (unsigned)total);
+        for (int e0 = tid; e0 < total; e0 += kStepThreads) {
+            int e = e0 + shift;
+            if (e >= total) e -= total;
+            const int node = e / c;                                              // e -> (node, channel) | count
+            const int le = e < kK * c ? node * cs + (e - node * c) : kK * cs + (e - kK * c);
+            double v = ls[le];
+            for (int j = 1; j < ncopies; j++) v += ls[le + (size_t)j * tstride];
+            if (v != 0.0) __hip_atomic_fetch_add(stats + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     PXSOM_PHASE(18);
