@@ -181,6 +181,12 @@ int launch_batch_step(const T *x, int64_t n, int c, int64_t ldx, double *stats, 
 // pending update + codebook preparation for the generic BMU search in one launch (pxsom_batch_step.hip); returns
 // false when the shape is not covered (then *rc is untouched and the caller takes the launch-per-phase route)
 bool launch_update_prepare(const StepArgs &sa, int xdim, int ydim, int c, char *ws, const Layout &L, hipStream_t st, int *rc);
+// One launch per BMU-only step for codebooks of up to 128 nodes x 128 channels (pxsom_batch_step_wide.hip)
+template <typename T>
+bool step_wide_shape(int c, int k);
+int64_t step_wide_max_rows();
+template <typename T>
+int launch_batch_step_wide(const T *x, int64_t n, int c, int64_t ldx, int k, double *stats, const StepArgs &sa, hipStream_t st);
 // the streamed filter on packed-K fragments (pxsom_assign_filter.hip)
 void launch_filter_packed(const _Float16 *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels, hipStream_t st);
 // rows the packed kernel can read: 16-byte aligned rows of binary16

@@ -1,0 +1,462 @@
+// pxsom_batch_step_wide.hip -- ONE launch per BMU-only mini-batch step for codebooks the register-resident step kernel
+// (pxsom_batch_step.hip: 10 x 10 grid, C <= 32) cannot hold: any grid of up to 128 nodes, up to 128 channels, binary32 or
+// binary64 rows (the cell SOM: 100 nodes x 100 pixel-cluster counts, reference cell_som_clustering.py:8-75; a pixel SOM on a
+// grid other than 10 x 10, pixel_som_clustering.py:16-21).
+//
+// Which steps: those whose pending update has its threshold pinned at 0.5 -- a node's window is the node itself, so the grid's
+// shape does not enter -- and that are small enough for their statistics to go to HBM with one device-scope atomic per value
+// (<= kWideMaxRows rows).  On the default schedule these are the 16 steps of the tail, each of which otherwise costs four or
+// five dependent launches (update + prepare, search, exact, screened exact, sums: ~78 us on config 4 against ~25 us of work).
+//
+// A workgroup (512 threads) takes 64 rows, each of its first four waves one 16-row tile:
+//   P0  requests: the counts and sums of step g-1, W_{g-1};
+//   P1  the pending update, element-wise and coalesced, in the arithmetic of orc_som_batch_sched (gain = -expm1(den lg), mean =
+//       S (1/den), w + gain (mean - w), no contraction); W_g into LDS (row stride padded to an odd number of words), workgroup 0
+//       writes it to HBM;
+//   P2  centred norms, maxima, the power-of-two scale, A-fragments (binary16 hi / lo of (W - mu) scale) and biases in LDS;
+//   P3  search: the K7 filter on v_mfma_f32_16x16x32_f16 with the three-term split, top-2 with the node id in the low mantissa
+//       bits, rigorous tolerance (pxsom_assign_filter_fast.h); a row the filter vouches for adds itself to the step's statistics
+//       in HBM, the others wait in a queue;
+//   P4  the queue is settled by whichever wave is free, exactly as the oracle does (binary64, j ascending, no contraction, sqrt,
+//       first strict minimum) against the LDS copy of W_g;
+//   and every workgroup clears its share of the next step's statistics buffer.
+// Equal nodes need no special case: their scores tie, the row is listed, the exact path takes the first of them.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdlib>
+
+#include "pxsom_assign.h"
+#include "pxsom_assign_filter_fast.h"
+#include "pxsom_wave.h"
+
+namespace pxsom_bmu {
+namespace {
+
+// (a workgroup's listed rows are settled by all eight waves, a row at a time: four search tiles per workgroup, not eight, keep
+// that tail short and spread a small step over twice as many CUs)
+constexpr int kWideThreads = 512, kWideWaves = 8, kWideSearchWaves = 4, kWideRowsPerWg = kWideSearchWaves * 16;
+constexpr int64_t kWideMaxRows = 16384;   // (beyond: the launch-per-phase route's LDS tables beat one atomic per value)
+constexpr int kWideMaxNodes = 128;
+
+struct WideShape {
+    int nb, nch, cpl, cs;
+    size_t off_frag, off_bias, off_misc, total;
+};
+inline WideShape wide_shape(int c, int k)
+{
+    WideShape s;
+    s.nb = (k + 15) / 16;
+    s.nch = (c + 31) / 32;
+    s.cpl = (c + 4 * s.nch - 1) / (4 * s.nch);
+    s.cs = c | 1;
+    s.off_frag = pxsom::align_up((size_t)k * s.cs * sizeof(double), 16);
+    s.off_bias = s.off_frag + (size_t)s.nb * 2 * s.nch * 64 * sizeof(half8);
+    s.off_misc = s.off_bias + (size_t)s.nb * 64 * sizeof(f32x4);
+    // misc: gain[k] | inv[k] | nrm[k] (binary64) | red[3 * waves] | mu_s[128] (binary32) | queue[128] (int64) | control words
+    s.total = s.off_misc + (size_t)(3 * kWideMaxNodes + 3 * kWideWaves) * sizeof(double) + 128 * sizeof(float) +
+              kWideRowsPerWg * (sizeof(long long) + sizeof(int)) + 64;
+    return s;
+}
+
+struct WideCtl {
+    unsigned q_n;
+    int bad;
+};
+
+template <typename T>
+__device__ __forceinline__ double wide_value(T v, double qmagic)
+{
+    if constexpr (sizeof(T) == 8) return qround((double)v, qmagic);
+    else return (double)v;
+}
+
+#pragma clang fp contract(off)
+// Listed rows settled by a whole wave, TWO at a time (their chains run side by side and share every codebook value read from
+// LDS): lanes <-> nodes lane and lane + 64 (k <= 128), a row's channels held by the lanes (lane l: channels l and l + 64) and
+// broadcast with v_readlane, W_g from LDS (row stride cs, odd: no bank conflicts between the lanes' nodes), distances exactly
+// as the oracle forms them (binary64, j ascending, no contraction, sqrt, first strict minimum).  The winner takes the row into
+// the step's statistics.
+template <typename T>
+__device__ __forceinline__ void wide_exact_rows(const T *xr0, const T *xr1, bool two, int c, int k, const double *wl, int cs, int lane,
+                                                double qmagic, double *stats)
+{
+    const double xa0 = lane < c ? (double)xr0[lane] : 0.0, xb0 = lane + 64 < c ? (double)xr0[lane + 64] : 0.0;
+    const double xa1 = lane < c ? (double)xr1[lane] : 0.0, xb1 = lane + 64 < c ? (double)xr1[lane + 64] : 0.0;
+    const int n0 = lane < k ? lane : k - 1, n1 = lane + 64 < k ? lane + 64 : k - 1;
+    const double *w0 = wl + (size_t)n0 * cs, *w1 = wl + (size_t)n1 * cs;
+    double d00 = 0.0, d01 = 0.0, d10 = 0.0, d11 = 0.0;   // d<row><node half>
+    auto span = [&](int j0, int j1, double va0, double va1, int off) {   // channels [j0, j1), held by lanes j - off
+        int j = j0;
+        for (; j + 4 <= j1; j += 4) {   // the LDS reads of a trip are issued together; sums stay in j order
+            double wa[4], wb[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                wa[u] = w0[j + u];
+                wb[u] = w1[j + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const double x0 = pxsom::readlane_f64(va0, j + u - off), x1 = pxsom::readlane_f64(va1, j + u - off);
+                const double t00 = x0 - wa[u], t01 = x0 - wb[u], t10 = x1 - wa[u], t11 = x1 - wb[u];
+                d00 += t00 * t00;
+                d01 += t01 * t01;
+                d10 += t10 * t10;
+                d11 += t11 * t11;
+            }
+        }
+        for (; j < j1; j++) {
+            const double x0 = pxsom::readlane_f64(va0, j - off), x1 = pxsom::readlane_f64(va1, j - off);
+            const double wa = w0[j], wb = w1[j];
+            const double t00 = x0 - wa, t01 = x0 - wb, t10 = x1 - wa, t11 = x1 - wb;
+            d00 += t00 * t00;
+            d01 += t01 * t01;
+            d10 += t10 * t10;
+            d11 += t11 * t11;
+        }
+    };
+    span(0, c < 64 ? c : 64, xa0, xa1, 0);
+    if (c > 64) span(64, c, xb0, xb1, 64);
+    auto settle = [&](double d0, double d1, const T *xr) {
+        double best = DBL_MAX;
+        int bestk = 0x7fffffff;
+        const double s0 = sqrt(d0), s1 = sqrt(d1);
+        if (lane < k && s0 < best) {
+            best = s0;
+            bestk = lane;
+        }
+        if (lane + 64 < k && s1 < best) {
+            best = s1;
+            bestk = lane + 64;
+        }
+        const double smin = pxsom::wave_min_f64(best);
+        const int win = (int)pxsom::wave_min_u32(best == smin ? (unsigned)bestk : 0xffffffffu);
+        if (win != 0x7fffffff) {   // 0x7fffffff: no finite distance (NaN row): not accumulated, as in the oracle
+            if (lane < c)
+                __hip_atomic_fetch_add(stats + (size_t)win * c + lane, wide_value<T>(xr[lane], qmagic), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane + 64 < c)
+                __hip_atomic_fetch_add(stats + (size_t)win * c + lane + 64, wide_value<T>(xr[lane + 64], qmagic), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_fetch_add(stats + (size_t)k * c + win, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    settle(d00, d01, xr0);
+    if (two) settle(d10, d11, xr1);
+}
+#pragma clang fp contract(fast)
+
+template <typename T, int NCH>
+__global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *__restrict__ x, int64_t n, int c, int64_t ldx, int k,
+                                                                       double *__restrict__ stats, StepArgs sa, WideShape ws)
+{
+    extern __shared__ __attribute__((aligned(16))) char wide_smem[];
+    double *wl = reinterpret_cast<double *>(wide_smem);                                   // W_g [k][cs]
+    half8 *frag = reinterpret_cast<half8 *>(wide_smem + ws.off_frag);                     // [nb][2 nch][64]
+    f32x4 *biasl = reinterpret_cast<f32x4 *>(wide_smem + ws.off_bias);                    // [nb][64]
+    double *gain_l = reinterpret_cast<double *>(wide_smem + ws.off_misc);                 // [128]
+    double *inv_l = gain_l + kWideMaxNodes, *nrm_l = inv_l + kWideMaxNodes;               // [128] each
+    double *red = nrm_l + kWideMaxNodes;                                                  // [3 waves]
+    float *mu_s = reinterpret_cast<float *>(red + 3 * kWideWaves);                        // [128]
+    long long *queue = reinterpret_cast<long long *>(mu_s + 128);                         // [128]
+    int *lab_l = reinterpret_cast<int *>(queue + kWideRowsPerWg);                         // [rows per workgroup]
+    WideCtl *ctl = reinterpret_cast<WideCtl *>(lab_l + kWideRowsPerWg);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int cs = ws.cs, nb = ws.nb, cpl = ws.cpl;
+    const int kc = k * c;
+
+    // ---- P0 / P1: the pending update (threshold 0.5: a node's window is the node)
+    if (tid == 0) {
+        ctl->q_n = 0u;
+        ctl->bad = 0;
+    }
+    if (tid < kWideMaxNodes) {
+        const double den = tid < k ? sa.stats_prev[(size_t)kc + tid] : 0.0;
+        gain_l[tid] = den > 0.0 ? -expm1(den * sa.lg) : -1.0;
+        inv_l[tid] = den > 0.0 ? 1.0 / den : 0.0;
+    }
+    if (sa.stats_zero) {
+        const int zper = (sa.zero_count + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int z1 = min(((int)blockIdx.x + 1) * zper, sa.zero_count);
+        for (int e = (int)blockIdx.x * zper + tid; e < z1; e += kWideThreads) sa.stats_zero[e] = 0.0;
+    }
+    __syncthreads();
+    {
+#pragma clang fp contract(off)
+        for (int e0 = tid; e0 < kc; e0 += 4 * kWideThreads) {   // four elements' loads in flight per thread
+            double wo[4], sv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int e = e0 + u * kWideThreads < kc ? e0 + u * kWideThreads : 0;
+                wo[u] = sa.w_in[e];
+                sv[u] = sa.stats_prev[e];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int e = e0 + u * kWideThreads;
+                if (e < kc) {
+                    const int node = e / c, j = e - node * c;
+                    const double gain = gain_l[node];
+                    double v = wo[u];
+                    if (gain >= 0.0) {
+                        const double mean = sv[u] * inv_l[node];
+                        v = gain == 1.0 ? mean : v + gain * (mean - v);
+                    }
+                    wl[(size_t)node * cs + j] = v;
+                    if (sa.w_out && blockIdx.x == 0) sa.w_out[e] = v;
+                }
+            }
+        }
+    }
+    if (tid < 128) mu_s[tid] = (sa.mu32 && tid < c) ? sa.mu32[tid] : 0.f;   // (unscaled until the scale is known)
+    const float mu_norm = sa.mu32 ? sa.mu32[kFilterMaxChannels] : 0.f;
+    __syncthreads();
+
+    // ---- P2: centred norms, maxima, scale; fragments and biases
+    {
+        const int node = tid >> 2, part = tid & 3;
+        double nrm = 0.0, mymax = 0.0;
+        bool bad = false;
+        if (node < k) {
+            for (int j = part; j < c; j += 4) {
+                const double v = wl[(size_t)node * cs + j];
+                bad |= !(fabs(v) <= DBL_MAX);
+                const double vc = v - (double)mu_s[j];
+                nrm += vc * vc;
+                mymax = fmax(mymax, fabs(vc));
+            }
+        }
+        nrm += __shfl_xor(nrm, 1);
+        nrm += __shfl_xor(nrm, 2);
+        if (node < k && part == 0) nrm_l[node] = nrm;
+        if (bad) ctl->bad = 1;
+        const double wmax = -pxsom::wave_min_f64(-(mymax == mymax ? mymax : 0.0));
+        const double nmax = -pxsom::wave_min_f64(-((node < k && nrm == nrm) ? nrm : 0.0));
+        if (lane == 0) {
+            red[wv] = wmax;
+            red[kWideWaves + wv] = nmax;
+        }
+    }
+    __syncthreads();
+    double maxabs = red[0], wn2max = red[kWideWaves];
+#pragma unroll
+    for (int i = 1; i < kWideWaves; i++) {
+        maxabs = fmax(maxabs, red[i]);
+        wn2max = fmax(wn2max, red[kWideWaves + i]);
+    }
+    int sexp = 0;
+    if (maxabs > 0.0 && maxabs <= DBL_MAX) {
+        int ex;
+        frexp(maxabs, &ex);
+        sexp = 8 - ex;
+        if (mu_norm > 0.f) {   // a codebook collapsed onto the centring vector must not blow the scale up (pxsom_batch_step.hip P4)
+            int exn;
+            frexpf(mu_norm, &exn);
+            if (sexp > 8 - exn + 6) sexp = 8 - exn + 6;
+        }
+        sexp = max(-100, min(100, sexp));
+    }
+    const double scale_d = ldexp(1.0, sexp);
+    const bool badw = ctl->bad != 0 || !(wn2max * scale_d * scale_d <= 1.0e30);
+    const float scale = (float)scale_d;
+    const float wn_max = badw ? 0.f : (float)(sqrt(wn2max) * scale_d * (1.0 + 1e-6));
+    const bool force_exact = badw;
+    const float x_limit = 60000.0f;
+    // A-fragments: frag[(b * 2 nch + 2 h) * 64 + lane] hi, + 1: lo; lane (q << 4 | m) <-> node 16 b + m, slot i of lane group q in
+    // chunk h <-> channel h * 4 cpl + q * cpl + i
+    for (int f = tid; f < nb * NCH * 64; f += kWideThreads) {
+        const int fl = f & 63, h = (f >> 6) % NCH, b = (f >> 6) / NCH;
+        const int m = fl & 15, q = fl >> 4, node = 16 * b + m;
+        half8 fhi, flo;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int ch = h * 4 * cpl + q * cpl + i;
+            float W = 0.f;
+            if (i < cpl && ch < c && node < k) W = (float)((wl[(size_t)node * cs + ch] - (double)mu_s[ch]) * scale_d);
+            const _Float16 hi = (_Float16)W;
+            fhi[i] = hi;
+            flo[i] = (_Float16)(W - (float)hi);
+        }
+        frag[(size_t)(b * 2 * NCH + 2 * h) * 64 + fl] = fhi;
+        frag[(size_t)(b * 2 * NCH + 2 * h + 1) * 64 + fl] = flo;
+    }
+    for (int f = tid; f < nb * 64; f += kWideThreads) {
+        const int fl = f & 63, b = f >> 6, q = fl >> 4;
+        f32x4 bv;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int node = 16 * b + 4 * q + r;
+            bv[r] = node < k ? (float)(-0.5 * nrm_l[node] * scale_d * scale_d) : kNegBig;
+        }
+        biasl[(size_t)b * 64 + fl] = bv;
+    }
+    __syncthreads();   // (everybody has read the unscaled centring vector)
+    if (tid < 128) mu_s[tid] = (float)((double)mu_s[tid] * scale_d);
+    __syncthreads();
+
+    // ---- P3: search.  Lane (q, pix) holds, for chunk h, channels h * 4 cpl + q * cpl + i of row pix of the wave's tile
+    const int pix = lane & 15, q = lane >> 4;
+    constexpr unsigned idx_mask = 31u;   // (b * 4 + r): the lane group travels beside the score, not inside it
+    for (int64_t blk = blockIdx.x; blk * kWideRowsPerWg < n; blk += gridDim.x) {
+        if (wv < kWideSearchWaves) {
+            const int64_t row = blk * kWideRowsPerWg + wv * 16 + pix;
+            const bool valid = row < n;
+            const T *xr = x + (valid ? row : n - 1) * ldx;
+            T raw[NCH][8];
+#pragma unroll
+            for (int h = 0; h < NCH; h++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int ch = h * 4 * cpl + q * cpl + i;
+                    raw[h][i] = xr[(i < cpl && ch < c) ? ch : 0];
+                }
+            half8 bh[NCH], bl[NCH];
+            float ss = 0.f;
+#pragma unroll
+            for (int h = 0; h < NCH; h++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int ch = h * 4 * cpl + q * cpl + i;
+                    float xs = 0.f;
+                    if (i < cpl && ch < c) {
+                        if constexpr (sizeof(T) == 8) xs = (float)__builtin_fma((double)raw[h][i], scale_d, -(double)mu_s[ch]);
+                        else xs = fmaf((float)raw[h][i], scale, -mu_s[ch]);
+                    }
+                    const _Float16 hi = (_Float16)xs;
+                    bh[h][i] = hi;
+                    bl[h][i] = (_Float16)(xs - (float)hi);
+                    ss = fmaf((float)hi, (float)hi, ss);
+                }
+            float m1 = kNegBig, m2 = kNegBig;
+            for (int b = 0; b < nb; b++) {
+                f32x4 acc = biasl[(size_t)b * 64 + lane];
+#pragma unroll
+                for (int h = 0; h < NCH; h++) {
+                    const half8 whi = frag[(size_t)(b * 2 * NCH + 2 * h) * 64 + lane], wlo = frag[(size_t)(b * 2 * NCH + 2 * h + 1) * 64 + lane];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, bh[h], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, bl[h], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, bh[h], acc, 0, 0, 0);
+                }
+                top2_quad(m1, m2, pack_idx(acc[0], (unsigned)(b * 4 + 0), idx_mask), pack_idx(acc[1], (unsigned)(b * 4 + 1), idx_mask),
+                          pack_idx(acc[2], (unsigned)(b * 4 + 2), idx_mask), pack_idx(acc[3], (unsigned)(b * 4 + 3), idx_mask));
+            }
+            // merge the four lane groups of a pixel (every lane of the pixel ends up with the result); wq: the group the best
+            // score came from (on equal scores either: such a row is listed)
+            float f1 = m1, f2 = m2;
+            unsigned wq = (unsigned)q;
+            {
+                const F2 e1 = xchg16(f1), e2 = xchg16(f2), e3 = xchg16(ss);
+                const float best = fmaxf(e1.a, e1.b);
+                if (best != f1) wq ^= 1u;      // the partner group's score won (q ^ 1: neither has merged before)
+                f1 = best;
+                f2 = fmaxf(fmaxf(fminf(e1.a, e1.b), e2.a), e2.b);
+                ss = e3.a + e3.b;
+            }
+            {
+                const F2 e1 = xchg32(f1), e2 = xchg32(f2), e3 = xchg32(ss), eq = xchg32(__uint_as_float(wq));
+                const float best = fmaxf(e1.a, e1.b);
+                const unsigned qa = __float_as_uint(eq.a), qb = __float_as_uint(eq.b);
+                if (best != f1) wq = qa == wq ? qb : qa;   // the other half's winner
+                f1 = best;
+                f2 = fmaxf(fmaxf(fminf(e1.a, e1.b), e2.a), e2.b);
+                ss = e3.a + e3.b;
+            }
+            const float xn = __builtin_amdgcn_sqrtf(ss) * 1.001f;
+            const bool finite_n = (__float_as_uint(ss) & 0x7f800000u) != 0x7f800000u;
+            const float tol = sa.tol_rel * (xn * wn_max + 0.5f * wn_max * wn_max) + sa.tol_abs * (xn + wn_max);
+            const bool amb = !((f1 - f2) > tol) || !(xn < x_limit) || !finite_n || force_exact;
+            const unsigned id = __float_as_uint(f1) & idx_mask;
+            const int node = (int)(16u * (id >> 2) + 4u * wq + (id & 3u));
+            // vouched rows go into the statistics after the barrier, shared out over all eight waves (below); a listed row waits
+            // in the queue
+            if (q == 0) lab_l[wv * 16 + pix] = (valid && !amb) ? node : -1;
+            if (valid && amb && q == 0) queue[atomicAdd(&ctl->q_n, 1u)] = row;
+
+        }
+        // ---- P4: vouched rows into the statistics, a row at a time with lanes <-> channels: the 64 atomics of an instruction fall
+        // into consecutive words (7 cache lines per 100-channel row).  (Adding from the registers that hold the tile for the
+        // search -- lane (q, pix) its own channel slots of row pix -- is one cache line PER LANE and atomic: measured 180 us per
+        // 8 300-row step on config 4 against 78 us for the five launches this kernel replaces.)  Then the listed rows of this
+        // block, by whichever wave is free.
+        __syncthreads();
+        {
+            int labs[kWideRowsPerWg / kWideWaves];
+            T va[kWideRowsPerWg / kWideWaves], vb[kWideRowsPerWg / kWideWaves];
+#pragma unroll
+            for (int u = 0; u < kWideRowsPerWg / kWideWaves; u++) {   // all the rows' loads first (L2: the tile was just read)
+                const int r = wv + u * kWideWaves;
+                labs[u] = lab_l[r];
+                va[u] = vb[u] = (T)0;
+                if (labs[u] >= 0) {
+                    const T *xq = x + (blk * kWideRowsPerWg + r) * ldx;
+                    va[u] = xq[lane < c ? lane : 0];
+                    vb[u] = xq[lane + 64 < c ? lane + 64 : 0];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kWideRowsPerWg / kWideWaves; u++) {
+                if (labs[u] >= 0) {
+                    double *dst = stats + (size_t)labs[u] * c;
+                    if (lane < c) __hip_atomic_fetch_add(dst + lane, wide_value<T>(va[u], sa.qmagic), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane + 64 < c)
+                        __hip_atomic_fetch_add(dst + lane + 64, wide_value<T>(vb[u], sa.qmagic), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 0) __hip_atomic_fetch_add(stats + (size_t)kc + labs[u], 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        const unsigned queued = ctl->q_n;
+        for (unsigned i = 2 * wv; i < queued; i += 2 * kWideWaves) {
+            const bool two = i + 1 < queued;
+            wide_exact_rows<T>(x + queue[i] * ldx, x + queue[two ? i + 1 : i] * ldx, two, c, k, wl, cs, lane, sa.qmagic, stats);
+        }
+        __syncthreads();
+        if (tid == 0) ctl->q_n = 0u;
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+// shapes the kernel covers (a codebook whose LDS copy + fragments fit one CU)
+template <typename T>
+bool step_wide_shape(int c, int k)
+{
+    if (sizeof(T) < 4 || c < 1 || c > kFilterMaxChannels || k < 1 || k > kWideMaxNodes) return false;
+    return wide_shape(c, k).total <= 150 * 1024;
+}
+template bool step_wide_shape<float>(int, int);
+template bool step_wide_shape<double>(int, int);
+template bool step_wide_shape<_Float16>(int, int);
+
+int64_t step_wide_max_rows() { return kWideMaxRows; }
+
+// One BMU-only step: the pending update of sa (threshold 0.5), the search of the n rows x[i * ldx], their statistics added to
+// `stats` (cleared by an earlier step), sa.stats_zero cleared, W_g to sa.w_out.
+template <typename T>
+int launch_batch_step_wide(const T *x, int64_t n, int c, int64_t ldx, int k, double *stats, const StepArgs &sa, hipStream_t st)
+{
+    const WideShape ws = wide_shape(c, k);
+    void (*kern)(const T *, int64_t, int, int64_t, int, double *, StepArgs, WideShape) = nullptr;
+    switch (ws.nch) {
+        case 1: kern = batch_step_wide_kernel<T, 1>; break;
+        case 2: kern = batch_step_wide_kernel<T, 2>; break;
+        case 3: kern = batch_step_wide_kernel<T, 3>; break;
+        default: kern = batch_step_wide_kernel<T, 4>; break;
+    }
+    static pxsom::PerDevice<size_t> raised_on[4];
+    size_t &raised = raised_on[ws.nch - 1].here();
+    if (raised < ws.total) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws.total);
+        if (e != hipSuccess)
+            return pxsom::fail(PXSOM_ERR_HIP, "wide step kernel: cannot raise the LDS limit to %zu bytes: %s", ws.total, hipGetErrorString(e));
+        raised = ws.total;
+    }
+    const int64_t blocks = std::max<int64_t>((n + kWideRowsPerWg - 1) / kWideRowsPerWg, 1);
+    const int grid = (int)std::min<int64_t>(blocks, (int64_t)pxsom::device_cu_count());
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWideThreads), ws.total, st, x, n, c, ldx, k, stats, sa, ws);
+    PXSOM_LAUNCH_CHECK("batch_step_wide_kernel");
+    return PXSOM_OK;
+}
+template int launch_batch_step_wide<float>(const float *, int64_t, int, int64_t, int, double *, const StepArgs &, hipStream_t);
+template int launch_batch_step_wide<double>(const double *, int64_t, int, int64_t, int, double *, const StepArgs &, hipStream_t);
+
+}  // namespace pxsom_bmu

@@ -1898,6 +1898,33 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
             if (comm && (rc = pxsom::comm_allreduce_sum_f64(comm, s_cur, nstats, st))) return rc;
             continue;
         }
+        // BMU-only steps (threshold pinned at 0.5) of codebooks up to 128 nodes x 128 channels: ONE launch (update, fragments,
+        // search, exact settle, statistics: pxsom_batch_step_wide.hip) instead of the four or five below
+        if constexpr (sizeof(T) >= 4) {
+            static const bool wide_off = getenv("PXSOM_STEP_WIDE") != nullptr && getenv("PXSOM_STEP_WIDE")[0] == '0';   // A/B hook
+            if (!(flags & PXSOM_TRAIN_UNFUSED) && !wide_off && gg > 0 && thr == 0.5 && rows <= pxsom_bmu::step_wide_max_rows() &&
+                pxsom_bmu::step_wide_shape<T>(c, k)) {
+                pxsom_bmu::StepArgs sa;
+                sa.w_in = w_prev;
+                sa.w_out = w_cur;
+                sa.stats_prev = s_prev;
+                sa.stats_zero = s_next;
+                sa.zero_count = (int)nstats;
+                sa.has_update = 1;
+                sa.thr = thr;
+                sa.lg = log1p(-alpha);
+                sa.mu32 = (centred_run && !no_centre) ? mu32 : nullptr;
+                // (5 index bits in the scores, three-term split, centred rows)
+                sa.tol_rel = (float)(2.5 * (ldexp(1.0, -(23 - 5)) + (3.0 * c + 2.0) * ldexp(1.0, -24) + ldexp(1.0, -19) + ldexp(1.0, -23) +
+                                            ldexp(1.0, -24)));
+                sa.tol_abs = fused_tol_abs;
+                sa.qmagic = qmagic;
+                int rc = pxsom_bmu::launch_batch_step_wide<T>(xv, rows, c, ldv, k, s_cur, sa, st);
+                if (rc) return rc;
+                if (comm && (rc = pxsom::comm_allreduce_sum_f64(comm, s_cur, nstats, st))) return rc;
+                continue;
+            }
+        }
         // codebooks the all-in-one kernel cannot hold (K = 400, or C > 32): ONE launch applies the pending update and
         // prepares the assign workspace for W_g (copy + update + clears + prep before), then search / exact / sums
         if (!(flags & PXSOM_TRAIN_UNFUSED)) {

@@ -635,6 +635,54 @@ def test_batch_train_steps_statistics_match_oracle_per_step(gpu, oracle):
         w_prev, s_prev, cnt_prev = w_g, s, cnt
 
 
+@pytest.mark.parametrize("xdim,ydim,c,dtype", [(10, 10, 100, np.float32), (12, 10, 22, np.float32), (8, 16, 40, np.float32),
+                                               (7, 5, 9, np.float64), (3, 1, 128, np.float32), (11, 11, 2, np.float32)])
+def test_wide_bmu_only_steps_match_the_oracle_per_step(gpu, oracle, xdim, ydim, c, dtype):
+    """Grids other than 10 x 10 / rows wider than 32 channels (up to 128 nodes x 128 channels): the steps whose pending update has
+    its threshold pinned at 0.5 run as ONE launch (csrc/pxsom_batch_step_wide.hip).  Step by step: the codebook a step derives
+    == orc_batch_update of the previous one, its statistics == orc_cluster_sums of the oracle's BMUs for that codebook (ties,
+    duplicate nodes and repeated rows included), and the launch-per-phase route gives the same bits."""
+    k, n, m = xdim * ydim, 12_000, 8
+    x = synth.make_fov_numpy(n, c, seed=15, dtype=np.float32).astype(dtype)
+    x[100:110] = x[100]                  # repeated rows
+    w0 = _codebook(x.astype(np.float64), k, seed=4)
+    if k > 3:
+        w0[k - 1] = w0[1]                # a duplicate node
+    xd = torch.from_numpy(x).to(gpu)
+    rr = (1.5, 0.0)                      # the threshold drops under 1 (pinned at 0.5) from the fifth step on
+    states = [sd.BatchTrainState(n, c, xdim, ydim, m, gpu) for _ in range(2)]
+    for st in states:
+        st.wbuf[0].copy_(torch.from_numpy(w0))
+    from ark_analysis_amd.distributed import batch_schedule
+    bmu_only = 0
+    w_prev = None
+    for g in range(m):
+        sd.batch_train_steps(xd, states[0], g, g + 1, m, (0.05, 0.01), rr)
+        sd.batch_train_steps(xd, states[1], g, g + 1, m, (0.05, 0.01), rr, unfused=True)
+        w_g = states[0].wbuf[g % 2].cpu().numpy()
+        if g > 0:
+            thr, alpha = batch_schedule(g - 1, m, (0.05, 0.01), rr)
+            bmu_only += thr == 0.5
+            want_w = oracle.batch_update(w_prev, xdim, ydim, s_prev, cnt_prev, thr, alpha)
+            np.testing.assert_allclose(w_g, want_w, rtol=1e-12, atol=0)
+        rows = x[g::m].astype(np.float64)
+        lab, _ = oracle.map_data_to_nodes(w_g, rows)
+        s, cnt = oracle.cluster_sums(rows, lab, k)
+        ring = states[0].ring[g % 3].cpu().numpy()
+        np.testing.assert_array_equal(ring[k * c:], cnt.astype(np.float64))
+        if dtype == np.float64:          # binary64 rows: the order of the atomic additions leaves 1e-16 noise
+            np.testing.assert_allclose(ring[: k * c].reshape(k, c), s, rtol=1e-12, atol=1e-12)
+            states[1].wbuf.copy_(states[0].wbuf)
+            states[1].ring.copy_(states[0].ring)
+        else:
+            np.testing.assert_array_equal(ring[: k * c].reshape(k, c), s)
+            assert torch.equal(states[0].wbuf[g % 2], states[1].wbuf[g % 2]), f"codebook of step {g} differs from the launch-per-phase route"
+            assert torch.equal(states[0].ring[g % 3], states[1].ring[g % 3]), f"statistics of step {g} differ"
+        assert float(states[0].ring[(g + 1) % 3].abs().max()) == 0.0, "next statistics buffer not cleared"
+        w_prev, s_prev, cnt_prev = w_g, s, cnt
+    assert bmu_only >= 3
+
+
 def test_assign_full_size_sampled_against_oracle(gpu, oracle):
     """BASELINE config 2 size on one GPU (10 x 1024^2 x 22 fp32, K=100): rows are independent, so
     the oracle on a random sample of rows must agree exactly; plus idempotence and range."""
