@@ -1,5 +1,5 @@
 // pxsom_batch_step_wide.hip -- ONE launch per BMU-only mini-batch step for codebooks the register-resident step kernel
-// (pxsom_batch_step.hip: 10 x 10 grid, C <= 32) cannot hold: any grid of up to 128 nodes, up to 128 channels, binary32 or
+// (pxsom_batch_step.hip: 10 x 10 grid, C <= 32) cannot hold: any grid of up to 256 nodes, up to 128 channels, binary32 or
 // binary64 rows (the cell SOM: 100 nodes x 100 pixel-cluster counts, reference cell_som_clustering.py:8-75; a pixel SOM on a
 // grid other than 10 x 10, pixel_som_clustering.py:16-21).
 //
@@ -37,10 +37,10 @@ namespace {
 // that tail short and spread a small step over twice as many CUs)
 constexpr int kWideThreads = 512, kWideWaves = 8, kWideSearchWaves = 4, kWideRowsPerWg = kWideSearchWaves * 16;
 constexpr int64_t kWideMaxRows = 16384;   // (beyond: the launch-per-phase route's LDS tables beat one atomic per value)
-constexpr int kWideMaxNodes = 128;
+constexpr int kWideMaxNodes = 256;
 
 struct WideShape {
-    int nb, nch, cpl, cs;
+    int nb, nch, cpl, cs, kp;   // kp: k rounded up to a multiple of 64 (per-node arrays, node slots of the exact path)
     size_t off_frag, off_bias, off_misc, total;
 };
 inline WideShape wide_shape(int c, int k)
@@ -50,11 +50,12 @@ inline WideShape wide_shape(int c, int k)
     s.nch = (c + 31) / 32;
     s.cpl = (c + 4 * s.nch - 1) / (4 * s.nch);
     s.cs = c | 1;
+    s.kp = (k + 63) & ~63;
     s.off_frag = pxsom::align_up((size_t)k * s.cs * sizeof(double), 16);
     s.off_bias = s.off_frag + (size_t)s.nb * 2 * s.nch * 64 * sizeof(half8);
     s.off_misc = s.off_bias + (size_t)s.nb * 64 * sizeof(f32x4);
     // misc: gain[k] | inv[k] | nrm[k] (binary64) | red[3 * waves] | mu_s[128] (binary32) | queue[128] (int64) | control words
-    s.total = s.off_misc + (size_t)(3 * kWideMaxNodes + 3 * kWideWaves) * sizeof(double) + 128 * sizeof(float) +
+    s.total = s.off_misc + (size_t)(3 * s.kp + 3 * kWideWaves) * sizeof(double) + 128 * sizeof(float) +
               kWideRowsPerWg * (sizeof(long long) + sizeof(int)) + 64;
     return s;
 }
@@ -73,61 +74,64 @@ __device__ __forceinline__ double wide_value(T v, double qmagic)
 
 #pragma clang fp contract(off)
 // Listed rows settled by a whole wave, TWO at a time (their chains run side by side and share every codebook value read from
-// LDS): lanes <-> nodes lane and lane + 64 (k <= 128), a row's channels held by the lanes (lane l: channels l and l + 64) and
+// LDS): lanes <-> nodes lane, lane + 64, ... (k <= 256), a row's channels held by the lanes (lane l: channels l and l + 64) and
 // broadcast with v_readlane, W_g from LDS (row stride cs, odd: no bank conflicts between the lanes' nodes), distances exactly
 // as the oracle forms them (binary64, j ascending, no contraction, sqrt, first strict minimum).  The winner takes the row into
 // the step's statistics.
-template <typename T>
+template <typename T, int NS>   // NS: node slots per lane (k <= 64 NS)
 __device__ __forceinline__ void wide_exact_rows(const T *xr0, const T *xr1, bool two, int c, int k, const double *wl, int cs, int lane,
                                                 double qmagic, double *stats)
 {
     const double xa0 = lane < c ? (double)xr0[lane] : 0.0, xb0 = lane + 64 < c ? (double)xr0[lane + 64] : 0.0;
     const double xa1 = lane < c ? (double)xr1[lane] : 0.0, xb1 = lane + 64 < c ? (double)xr1[lane + 64] : 0.0;
-    const int n0 = lane < k ? lane : k - 1, n1 = lane + 64 < k ? lane + 64 : k - 1;
-    const double *w0 = wl + (size_t)n0 * cs, *w1 = wl + (size_t)n1 * cs;
-    double d00 = 0.0, d01 = 0.0, d10 = 0.0, d11 = 0.0;   // d<row><node half>
+    const double *wn[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) wn[s] = wl + (size_t)(lane + 64 * s < k ? lane + 64 * s : k - 1) * cs;
+    double d0[NS], d1[NS];   // row 0 / row 1, node slot s
+#pragma unroll
+    for (int s = 0; s < NS; s++) d0[s] = d1[s] = 0.0;
     auto span = [&](int j0, int j1, double va0, double va1, int off) {   // channels [j0, j1), held by lanes j - off
         int j = j0;
         for (; j + 4 <= j1; j += 4) {   // the LDS reads of a trip are issued together; sums stay in j order
-            double wa[4], wb[4];
+            double wv4[NS][4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                wa[u] = w0[j + u];
-                wb[u] = w1[j + u];
-            }
+            for (int s = 0; s < NS; s++)
+#pragma unroll
+                for (int u = 0; u < 4; u++) wv4[s][u] = wn[s][j + u];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const double x0 = pxsom::readlane_f64(va0, j + u - off), x1 = pxsom::readlane_f64(va1, j + u - off);
-                const double t00 = x0 - wa[u], t01 = x0 - wb[u], t10 = x1 - wa[u], t11 = x1 - wb[u];
-                d00 += t00 * t00;
-                d01 += t01 * t01;
-                d10 += t10 * t10;
-                d11 += t11 * t11;
+#pragma unroll
+                for (int s = 0; s < NS; s++) {
+                    const double t0 = x0 - wv4[s][u], t1 = x1 - wv4[s][u];
+                    d0[s] += t0 * t0;
+                    d1[s] += t1 * t1;
+                }
             }
         }
         for (; j < j1; j++) {
             const double x0 = pxsom::readlane_f64(va0, j - off), x1 = pxsom::readlane_f64(va1, j - off);
-            const double wa = w0[j], wb = w1[j];
-            const double t00 = x0 - wa, t01 = x0 - wb, t10 = x1 - wa, t11 = x1 - wb;
-            d00 += t00 * t00;
-            d01 += t01 * t01;
-            d10 += t10 * t10;
-            d11 += t11 * t11;
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                const double wj = wn[s][j];
+                const double t0 = x0 - wj, t1 = x1 - wj;
+                d0[s] += t0 * t0;
+                d1[s] += t1 * t1;
+            }
         }
     };
     span(0, c < 64 ? c : 64, xa0, xa1, 0);
     if (c > 64) span(64, c, xb0, xb1, 64);
-    auto settle = [&](double d0, double d1, const T *xr) {
+    auto settle = [&](const double *d, const T *xr) {
         double best = DBL_MAX;
         int bestk = 0x7fffffff;
-        const double s0 = sqrt(d0), s1 = sqrt(d1);
-        if (lane < k && s0 < best) {
-            best = s0;
-            bestk = lane;
-        }
-        if (lane + 64 < k && s1 < best) {
-            best = s1;
-            bestk = lane + 64;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {   // slots in ascending node order: the first strict minimum of this lane's nodes
+            const double ds = sqrt(d[s]);
+            if (lane + 64 * s < k && ds < best) {
+                best = ds;
+                bestk = lane + 64 * s;
+            }
         }
         const double smin = pxsom::wave_min_f64(best);
         const int win = (int)pxsom::wave_min_u32(best == smin ? (unsigned)bestk : 0xffffffffu);
@@ -140,8 +144,8 @@ __device__ __forceinline__ void wide_exact_rows(const T *xr0, const T *xr1, bool
             if (lane == 0) __hip_atomic_fetch_add(stats + (size_t)k * c + win, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
-    settle(d00, d01, xr0);
-    if (two) settle(d10, d11, xr1);
+    settle(d0, xr0);
+    if (two) settle(d1, xr1);
 }
 #pragma clang fp contract(fast)
 
@@ -153,9 +157,9 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
     double *wl = reinterpret_cast<double *>(wide_smem);                                   // W_g [k][cs]
     half8 *frag = reinterpret_cast<half8 *>(wide_smem + ws.off_frag);                     // [nb][2 nch][64]
     f32x4 *biasl = reinterpret_cast<f32x4 *>(wide_smem + ws.off_bias);                    // [nb][64]
-    double *gain_l = reinterpret_cast<double *>(wide_smem + ws.off_misc);                 // [128]
-    double *inv_l = gain_l + kWideMaxNodes, *nrm_l = inv_l + kWideMaxNodes;               // [128] each
-    double *red = nrm_l + kWideMaxNodes;                                                  // [3 waves]
+    double *gain_l = reinterpret_cast<double *>(wide_smem + ws.off_misc);                 // [kp]
+    double *inv_l = gain_l + ws.kp, *nrm_l = inv_l + ws.kp;                               // [kp] each
+    double *red = nrm_l + ws.kp;                                                          // [3 waves]
     float *mu_s = reinterpret_cast<float *>(red + 3 * kWideWaves);                        // [128]
     long long *queue = reinterpret_cast<long long *>(mu_s + 128);                         // [128]
     int *lab_l = reinterpret_cast<int *>(queue + kWideRowsPerWg);                         // [rows per workgroup]
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
         ctl->q_n = 0u;
         ctl->bad = 0;
     }
-    if (tid < kWideMaxNodes) {
+    if (tid < ws.kp) {
         const double den = tid < k ? sa.stats_prev[(size_t)kc + tid] : 0.0;
         gain_l[tid] = den > 0.0 ? -expm1(den * sa.lg) : -1.0;
         inv_l[tid] = den > 0.0 ? 1.0 / den : 0.0;
@@ -213,24 +217,28 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
 
     // ---- P2: centred norms, maxima, scale; fragments and biases
     {
-        const int node = tid >> 2, part = tid & 3;
-        double nrm = 0.0, mymax = 0.0;
+        const int part = tid & 3;
+        double mymax = 0.0, mynrm = 0.0;
         bool bad = false;
-        if (node < k) {
-            for (int j = part; j < c; j += 4) {
-                const double v = wl[(size_t)node * cs + j];
-                bad |= !(fabs(v) <= DBL_MAX);
-                const double vc = v - (double)mu_s[j];
-                nrm += vc * vc;
-                mymax = fmax(mymax, fabs(vc));
+        for (int node = tid >> 2; node < ws.kp; node += kWideThreads / 4) {   // (uniform trip count: the shuffles need every lane)
+            double nrm = 0.0;
+            if (node < k) {
+                for (int j = part; j < c; j += 4) {
+                    const double v = wl[(size_t)node * cs + j];
+                    bad |= !(fabs(v) <= DBL_MAX);
+                    const double vc = v - (double)mu_s[j];
+                    nrm += vc * vc;
+                    mymax = fmax(mymax, fabs(vc));
+                }
             }
+            nrm += __shfl_xor(nrm, 1);
+            nrm += __shfl_xor(nrm, 2);
+            if (node < k && part == 0) nrm_l[node] = nrm;
+            if (node < k && nrm == nrm) mynrm = fmax(mynrm, nrm);
         }
-        nrm += __shfl_xor(nrm, 1);
-        nrm += __shfl_xor(nrm, 2);
-        if (node < k && part == 0) nrm_l[node] = nrm;
         if (bad) ctl->bad = 1;
         const double wmax = -pxsom::wave_min_f64(-(mymax == mymax ? mymax : 0.0));
-        const double nmax = -pxsom::wave_min_f64(-((node < k && nrm == nrm) ? nrm : 0.0));
+        const double nmax = -pxsom::wave_min_f64(-mynrm);
         if (lane == 0) {
             red[wv] = wmax;
             red[kWideWaves + wv] = nmax;
@@ -295,7 +303,7 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
 
     // ---- P3: search.  Lane (q, pix) holds, for chunk h, channels h * 4 cpl + q * cpl + i of row pix of the wave's tile
     const int pix = lane & 15, q = lane >> 4;
-    constexpr unsigned idx_mask = 31u;   // (b * 4 + r): the lane group travels beside the score, not inside it
+    const unsigned idx_mask = nb > 8 ? 63u : 31u;   // (b * 4 + r): the lane group travels beside the score, not inside it
     for (int64_t blk = blockIdx.x; blk * kWideRowsPerWg < n; blk += gridDim.x) {
         if (wv < kWideSearchWaves) {
             const int64_t row = blk * kWideRowsPerWg + wv * 16 + pix;
@@ -406,7 +414,9 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
         const unsigned queued = ctl->q_n;
         for (unsigned i = 2 * wv; i < queued; i += 2 * kWideWaves) {
             const bool two = i + 1 < queued;
-            wide_exact_rows<T>(x + queue[i] * ldx, x + queue[two ? i + 1 : i] * ldx, two, c, k, wl, cs, lane, sa.qmagic, stats);
+            const T *xa = x + queue[i] * ldx, *xb = x + queue[two ? i + 1 : i] * ldx;
+            if (k <= 128) wide_exact_rows<T, 2>(xa, xb, two, c, k, wl, cs, lane, sa.qmagic, stats);
+            else wide_exact_rows<T, 4>(xa, xb, two, c, k, wl, cs, lane, sa.qmagic, stats);
         }
         __syncthreads();
         if (tid == 0) ctl->q_n = 0u;

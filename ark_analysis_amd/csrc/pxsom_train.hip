@@ -1914,8 +1914,8 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
                 sa.thr = thr;
                 sa.lg = log1p(-alpha);
                 sa.mu32 = (centred_run && !no_centre) ? mu32 : nullptr;
-                // (5 index bits in the scores, three-term split, centred rows)
-                sa.tol_rel = (float)(2.5 * (ldexp(1.0, -(23 - 5)) + (3.0 * c + 2.0) * ldexp(1.0, -24) + ldexp(1.0, -19) + ldexp(1.0, -23) +
+                // (5 index bits in the scores -- 6 from 129 nodes on --, three-term split, centred rows)
+                sa.tol_rel = (float)(2.5 * (ldexp(1.0, -(23 - (k > 128 ? 6 : 5))) + (3.0 * c + 2.0) * ldexp(1.0, -24) + ldexp(1.0, -19) + ldexp(1.0, -23) +
                                             ldexp(1.0, -24)));
                 sa.tol_abs = fused_tol_abs;
                 sa.qmagic = qmagic;

@@ -636,9 +636,10 @@ def test_batch_train_steps_statistics_match_oracle_per_step(gpu, oracle):
 
 
 @pytest.mark.parametrize("xdim,ydim,c,dtype", [(10, 10, 100, np.float32), (12, 10, 22, np.float32), (8, 16, 40, np.float32),
-                                               (7, 5, 9, np.float64), (3, 1, 128, np.float32), (11, 11, 2, np.float32)])
+                                               (7, 5, 9, np.float64), (3, 1, 128, np.float32), (11, 11, 2, np.float32),
+                                               (12, 12, 22, np.float32), (16, 16, 8, np.float32), (13, 15, 30, np.float64)])
 def test_wide_bmu_only_steps_match_the_oracle_per_step(gpu, oracle, xdim, ydim, c, dtype):
-    """Grids other than 10 x 10 / rows wider than 32 channels (up to 128 nodes x 128 channels): the steps whose pending update has
+    """Grids other than 10 x 10 / rows wider than 32 channels (up to 256 nodes x 128 channels): the steps whose pending update has
     its threshold pinned at 0.5 run as ONE launch (csrc/pxsom_batch_step_wide.hip).  Step by step: the codebook a step derives
     == orc_batch_update of the previous one, its statistics == orc_cluster_sums of the oracle's BMUs for that codebook (ties,
     duplicate nodes and repeated rows included), and the launch-per-phase route gives the same bits."""
