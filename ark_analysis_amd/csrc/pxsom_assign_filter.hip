@@ -669,7 +669,21 @@ void launch_packed(const _Float16 *x, int64_t n, int c, int64_t ldx, char *ws, c
     AssignHdr *hd = reinterpret_cast<AssignHdr *>(ws);
     unsigned *al = reinterpret_cast<unsigned *>(ws + L.off_list);
     const int cus = pxsom::device_cu_count();
-    if (lds <= 150 * 1024 && lds > 64 * 1024) {          // one workgroup per CU: a big one (two waves per SIMD on one LDS copy)
+    // one workgroup per CU (the codebook's fragments take 64 .. 150 KB of its LDS): 1024 threads -- four waves per SIMD on one
+    // LDS copy; measured on config 5's shape (4.2 M rows x 40 binary16, 400 nodes) 0.332 ms against 0.370 with 512 threads:
+    // matrix and vector instructions of a SIMD overlap between waves, not inside one.  PXSOM_PACKED_BD=512: the old launch.
+    static const int big_bd = getenv("PXSOM_PACKED_BD") ? atoi(getenv("PXSOM_PACKED_BD")) : 1024;
+    if (lds <= 150 * 1024 && lds > 64 * 1024 && big_bd == 1024) {
+        auto kern = bmu_filter_packed_kernel<NPK, 4, true, 1024>;
+        static pxsom::PerDevice<bool> raised_on;
+        bool &raised = raised_on.here();
+        if (!raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            raised = true;
+        }
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((ngroups + 15) / 16, cus));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, st, x, n, c, ldx, wf, bi, hd, al, labels);
+    } else if (lds <= 150 * 1024 && lds > 64 * 1024) {          // one workgroup per CU: a big one (two waves per SIMD on one LDS copy)
         auto kern = bmu_filter_packed_kernel<NPK, 4, true, 512>;
         static pxsom::PerDevice<bool> raised_on;
         bool &raised = raised_on.here();

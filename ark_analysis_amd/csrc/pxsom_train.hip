@@ -664,7 +664,7 @@ __global__ __launch_bounds__(256) void batch_update_kernel(double *w, int xdim, 
 template <typename T>
 struct TableAdd {
     static constexpr bool kFixed = false;
-    static __device__ __forceinline__ void add(double *ls, size_t slot, T v, double *)
+    static __device__ __forceinline__ void add(double *ls, size_t slot, T v, double *, size_t = 0)
     {
         __hip_atomic_fetch_add(ls + slot, (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -673,12 +673,12 @@ struct TableAdd {
 template <>
 struct TableAdd<_Float16> {
     static constexpr bool kFixed = true;
-    static __device__ __forceinline__ void add(double *ls, size_t slot, _Float16 v, double *global_sums)
+    static __device__ __forceinline__ void add(double *ls, size_t slot, _Float16 v, double *global_sums, size_t global_slot)
     {
         const unsigned b = __builtin_bit_cast(unsigned short, v);
         const unsigned e = (b >> 10) & 31u, m = b & 1023u;
         if (e == 31u) {   // inf / NaN
-            __hip_atomic_fetch_add(global_sums + slot, (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(global_sums + global_slot, (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
         const unsigned long long q = e ? (unsigned long long)(1024u + m) << (e - 1u) : (unsigned long long)m;
@@ -699,14 +699,16 @@ template <typename T, bool COUNT_F64, int NT>
 __global__ __launch_bounds__(NT) void cluster_sums_kernel(const T *__restrict__ x, int64_t n, int c,
                                                            int64_t ldx, const int32_t *__restrict__ labels,
                                                            int k, double *sums, unsigned long long *counts,
-                                                           int64_t rows_per_block, int use_lds, double qmagic)
+                                                           int64_t rows_per_block, int use_lds, double qmagic, int cs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double *ls = reinterpret_cast<double *>(smem_raw);                 // [k*c] + kSumsSpare slots nobody reads
-    unsigned *lc = reinterpret_cast<unsigned *>(ls + (size_t)k * c + kSumsSpare);   // [k]
+    // table row stride cs (words): c, or c padded to an odd number -- the lanes of a ds_add hit rows of unrelated labels, and with
+    // an even stride those fall on a fraction of the banks (c = 40: stride 80 dwords, four bank groups in all)
+    double *ls = reinterpret_cast<double *>(smem_raw);                 // [k*cs] + kSumsSpare slots nobody reads
+    unsigned *lc = reinterpret_cast<unsigned *>(ls + (size_t)k * cs + kSumsSpare);   // [k]
     const int tid = threadIdx.x;
     if (use_lds) {
-        for (int e = tid; e < k * c + kSumsSpare; e += NT) ls[e] = 0.0;
+        for (int e = tid; e < k * cs + kSumsSpare; e += NT) ls[e] = 0.0;
         for (int e = tid; e < k; e += NT) lc[e] = 0u;
         __syncthreads();
     }
@@ -771,8 +773,8 @@ __global__ __launch_bounds__(NT) void cluster_sums_kernel(const T *__restrict__ 
                             plain = (reach & 0x80008000u) == 0u;
                             if (plain) {
                                 const bool ok_a = (unsigned)lab_a[u] < (unsigned)k, ok_b = (unsigned)lab_b[u] < (unsigned)k;
-                                const int base_a = ok_a ? lab_a[u] * c + ch0[u] : k * c;
-                                const int base_b = ok_b ? lab_b[u] * c + ch0[u] - c : k * c;
+                                const int base_a = ok_a ? lab_a[u] * cs + ch0[u] : k * cs;
+                                const int base_b = ok_b ? lab_b[u] * cs + ch0[u] - c : k * cs;
                                 unsigned long long *table = reinterpret_cast<unsigned long long *>(ls);
 #pragma unroll
                                 for (int i = 0; i < VEC; i++) {
@@ -793,7 +795,7 @@ __global__ __launch_bounds__(NT) void cluster_sums_kernel(const T *__restrict__ 
                                 const int lb = wrapped ? lab_b[u] : lab_a[u];
                                 const int ch = ch0[u] + i - (wrapped ? c : 0);
                                 if (lb >= 0 && lb < k) {
-                                    TableAdd<T>::add(ls, (size_t)lb * c + ch, val[u][i], sums);
+                                    TableAdd<T>::add(ls, (size_t)lb * cs + ch, val[u][i], sums, (size_t)lb * c + ch);
                                     if (ch == 0) atomicAdd(&lc[lb], 1u);
                                 }
                             }
@@ -836,7 +838,7 @@ __global__ __launch_bounds__(NT) void cluster_sums_kernel(const T *__restrict__ 
                     for (int i = 0; i < VEC; i++) {
                         const int lb = lab[u][i];
                         if (lb >= 0 && lb < k) {
-                            TableAdd<T>::add(ls, (size_t)lb * c + chn[u][i], val[u][i], sums);
+                            TableAdd<T>::add(ls, (size_t)lb * cs + chn[u][i], val[u][i], sums, (size_t)lb * c + chn[u][i]);
                             if (chn[u][i] == 0) atomicAdd(&lc[lb], 1u);
                         }
                     }
@@ -846,7 +848,7 @@ __global__ __launch_bounds__(NT) void cluster_sums_kernel(const T *__restrict__ 
                 const int64_t row = e / c;
                 const int ch = (int)(e - row * c), lb = labels[r0 + row] - 1;
                 if (lb >= 0 && lb < k) {
-                    TableAdd<T>::add(ls, (size_t)lb * c + ch, xb[e], sums);
+                    TableAdd<T>::add(ls, (size_t)lb * cs + ch, xb[e], sums, (size_t)lb * c + ch);
                     if (ch == 0) atomicAdd(&lc[lb], 1u);
                 }
             }
@@ -881,7 +883,7 @@ __global__ __launch_bounds__(NT) void cluster_sums_kernel(const T *__restrict__ 
                 if constexpr (sizeof(T) == 8) v[u] = pxsom_bmu::qround(v[u], qmagic);   // binary64 rows of a reproducible run
                 if (lab[u] >= 0 && lab[u] < k) {
                     if (use_lds) {
-                        TableAdd<T>::add(ls, (size_t)lab[u] * c + cc[u], v[u], sums);
+                        TableAdd<T>::add(ls, (size_t)lab[u] * cs + cc[u], v[u], sums, (size_t)lab[u] * c + cc[u]);
                         if (cc[u] == 0) atomicAdd(&lc[lab[u]], 1u);
                     } else {
                         __hip_atomic_fetch_add(&sums[(size_t)lab[u] * c + cc[u]], (double)v[u], __ATOMIC_RELAXED,
@@ -900,9 +902,17 @@ __global__ __launch_bounds__(NT) void cluster_sums_kernel(const T *__restrict__ 
     }
     if (use_lds) {
         __syncthreads();
+        int node = tid / c, j = tid - node * c;   // element e <-> (node, channel), advanced without a division per element
+        const int dnode = NT / c, dj = NT % c;
         for (int e = tid; e < k * c; e += NT) {
-            const double v = TableAdd<T>::value(ls, e);
+            const double v = TableAdd<T>::value(ls, (size_t)node * cs + j);
             if (v != 0.0) __hip_atomic_fetch_add(&sums[e], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            node += dnode;
+            j += dj;
+            if (j >= c) {
+                j -= c;
+                node++;
+            }
         }
         for (int e = tid; e < k; e += NT)
             if (lc[e]) {
@@ -1270,7 +1280,10 @@ int cluster_sums_typed(const T *x, int64_t n, int c, int64_t ldx, const int32_t 
             }
         }
     }
-    const size_t lds = ((size_t)k * c + kSumsSpare) * 8 + (size_t)k * 4;
+    // table row stride: odd when the padded table still fits (bank spread of the LDS atomics), else c
+    const size_t lds_odd = ((size_t)k * (c | 1) + kSumsSpare) * 8 + (size_t)k * 4;
+    const int cs = lds_odd <= 150 * 1024 ? (c | 1) : c;
+    const size_t lds = ((size_t)k * cs + kSumsSpare) * 8 + (size_t)k * 4;
     const int use_lds = lds <= 150 * 1024;
     const int cus = pxsom::device_cu_count();
     // small inputs are latency-bound per workgroup, so they are spread wide: 64 rows per workgroup (measured on
@@ -1289,7 +1302,7 @@ int cluster_sums_typed(const T *x, int64_t n, int c, int64_t ldx, const int32_t 
         PXSOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(wide ? 1024 : 256), use_lds ? lds : 0, st, x, n, c, ldx, labels, k,
-                       sums, reinterpret_cast<unsigned long long *>(counts), rows_per_block, use_lds, qmagic);
+                       sums, reinterpret_cast<unsigned long long *>(counts), rows_per_block, use_lds, qmagic, cs);
     PXSOM_LAUNCH_CHECK("cluster_sums_kernel");
     return PXSOM_OK;
 }
