@@ -185,8 +185,9 @@ bool launch_update_prepare(const StepArgs &sa, int xdim, int ydim, int c, char *
 template <typename T>
 bool step_wide_shape(int c, int k);
 int64_t step_wide_max_rows();
+bool step_wide_windowed(int xdim, int ydim, int c);
 template <typename T>
-int launch_batch_step_wide(const T *x, int64_t n, int c, int64_t ldx, int k, double *stats, const StepArgs &sa, hipStream_t st);
+int launch_batch_step_wide(const T *x, int64_t n, int c, int64_t ldx, int xdim, int ydim, double *stats, const StepArgs &sa, hipStream_t st);
 // the streamed filter on packed-K fragments (pxsom_assign_filter.hip)
 void launch_filter_packed(const _Float16 *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels, hipStream_t st);
 // rows the packed kernel can read: 16-byte aligned rows of binary16

@@ -49,7 +49,7 @@ inline WideShape wide_shape(int c, int k)
     s.nb = (k + 15) / 16;
     s.nch = (c + 31) / 32;
     s.cpl = (c + 4 * s.nch - 1) / (4 * s.nch);
-    s.cs = c | 1;
+    s.cs = (c + 1) | 1;   // W_g row stride, words: odd, and wide enough for [c sums | count] rows while the window sums are formed
     s.kp = (k + 63) & ~63;
     s.off_frag = pxsom::align_up((size_t)k * s.cs * sizeof(double), 16);
     s.off_bias = s.off_frag + (size_t)s.nb * 2 * s.nch * 64 * sizeof(half8);
@@ -151,7 +151,7 @@ __device__ __forceinline__ void wide_exact_rows(const T *xr0, const T *xr1, bool
 
 template <typename T, int NCH>
 __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *__restrict__ x, int64_t n, int c, int64_t ldx, int k,
-                                                                       double *__restrict__ stats, StepArgs sa, WideShape ws)
+                                                                       double *__restrict__ stats, StepArgs sa, WideShape ws, int xd, int yd)
 {
     extern __shared__ __attribute__((aligned(16))) char wide_smem[];
     double *wl = reinterpret_cast<double *>(wide_smem);                                   // W_g [k][cs]
@@ -168,23 +168,27 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
     const int cs = ws.cs, nb = ws.nb, cpl = ws.cpl;
     const int kc = k * c;
 
-    // ---- P0 / P1: the pending update (threshold 0.5: a node's window is the node)
+    // ---- P0 / P1: the pending update.  Threshold 0.5: a node's window is the node.  Threshold >= 1 (grids up to 16 x 16, k c <=
+    // 16 384): the Chebyshev window sums, separably and in the oracle's order (orc_batch_update: per grid row the window's
+    // columns ascending, then the rows ascending) in the W_g region of LDS, node k = x * yd + y as everywhere.
     if (tid == 0) {
         ctl->q_n = 0u;
         ctl->bad = 0;
     }
-    if (tid < ws.kp) {
-        const double den = tid < k ? sa.stats_prev[(size_t)kc + tid] : 0.0;
-        gain_l[tid] = den > 0.0 ? -expm1(den * sa.lg) : -1.0;
-        inv_l[tid] = den > 0.0 ? 1.0 / den : 0.0;
-    }
+    const int r = !sa.has_update ? 0 : (sa.thr > 1.0e6 ? 1000000 : (sa.thr >= 1.0 ? (int)floor(sa.thr) : 0));
     if (sa.stats_zero) {
         const int zper = (sa.zero_count + (int)gridDim.x - 1) / (int)gridDim.x;
         const int z1 = min(((int)blockIdx.x + 1) * zper, sa.zero_count);
         for (int e = (int)blockIdx.x * zper + tid; e < z1; e += kWideThreads) sa.stats_zero[e] = 0.0;
     }
-    __syncthreads();
-    {
+    if (r == 0) {
+        if (tid < ws.kp) {
+            const double den = (tid < k && sa.has_update) ? sa.stats_prev[(size_t)kc + tid] : 0.0;
+            gain_l[tid] = den > 0.0 ? -expm1(den * sa.lg) : -1.0;
+            inv_l[tid] = den > 0.0 ? 1.0 / den : 0.0;
+        }
+        __syncthreads();
+        {
 #pragma clang fp contract(off)
         for (int e0 = tid; e0 < kc; e0 += 4 * kWideThreads) {   // four elements' loads in flight per thread
             double wo[4], sv[4];
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
             for (int u = 0; u < 4; u++) {
                 const int e = e0 + u * kWideThreads < kc ? e0 + u * kWideThreads : 0;
                 wo[u] = sa.w_in[e];
-                sv[u] = sa.stats_prev[e];
+                sv[u] = sa.has_update ? sa.stats_prev[e] : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -208,6 +212,71 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
                     wl[(size_t)node * cs + j] = v;
                     if (sa.w_out && blockIdx.x == 0) sa.w_out[e] = v;
                 }
+            }
+        }
+        }
+    } else {
+#pragma clang fp contract(off)
+        constexpr int kMaxE = 32, kMaxD = 16;           // elements of W per thread; grid side (checked by the host)
+        const int nc = c + 1;
+        double wold[kMaxE];
+#pragma unroll
+        for (int u = 0; u < kMaxE; u++) wold[u] = sa.w_in[tid + kWideThreads * u < kc ? tid + kWideThreads * u : 0];
+        for (int e = tid; e < k * nc; e += kWideThreads) {   // statistics rows [c sums | count] into LDS
+            const int node = e / nc, cc = e - node * nc;
+            wl[(size_t)node * cs + cc] = cc < c ? sa.stats_prev[(size_t)node * c + cc] : sa.stats_prev[(size_t)kc + node];
+        }
+        __syncthreads();
+        // along y: line (x, cc); then along x: line (y, cc).  A line is read into registers, its window sums written back.
+        auto pass = [&](int nlines_major, int len, int stride, bool along_y) {
+            for (int line = tid; line < nlines_major * nc; line += kWideThreads) {
+                const int major = line / nc, cc = line - major * nc;
+                double *base = wl + (along_y ? (size_t)major * yd * cs : (size_t)major * cs) + cc;
+                double v[kMaxD];
+#pragma unroll
+                for (int i = 0; i < kMaxD; i++) v[i] = i < len ? base[(size_t)i * stride] : 0.0;
+#pragma unroll
+                for (int p = 0; p < kMaxD; p++) {
+                    if (p < len) {
+                        double t = 0.0;
+#pragma unroll
+                        for (int i = 0; i < kMaxD; i++)
+                            if (i < len && i >= p - r && i <= p + r) t += v[i];
+                        base[(size_t)p * stride] = t;
+                    }
+                }
+            }
+        };
+        pass(xd, yd, cs, true);
+        __syncthreads();
+        pass(yd, xd, yd * cs, false);
+        __syncthreads();
+        if (tid < ws.kp) {
+            const double den = tid < k ? wl[(size_t)tid * cs + c] : 0.0;
+            gain_l[tid] = den > 0.0 ? -expm1(den * sa.lg) : -1.0;
+            inv_l[tid] = den > 0.0 ? 1.0 / den : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kMaxE; u++) {   // new node values into registers: every read of the window sums comes first
+            const int e = tid + kWideThreads * u;
+            if (e < kc) {
+                const int node = e / c, j = e - node * c;
+                const double gain = gain_l[node];
+                if (gain >= 0.0) {
+                    const double mean = wl[(size_t)node * cs + j] * inv_l[node];
+                    wold[u] = gain == 1.0 ? mean : wold[u] + gain * (mean - wold[u]);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kMaxE; u++) {
+            const int e = tid + kWideThreads * u;
+            if (e < kc) {
+                const int node = e / c, j = e - node * c;
+                wl[(size_t)node * cs + j] = wold[u];
+                if (sa.w_out && blockIdx.x == 0) sa.w_out[e] = wold[u];
             }
         }
     }
@@ -438,14 +507,18 @@ template bool step_wide_shape<double>(int, int);
 template bool step_wide_shape<_Float16>(int, int);
 
 int64_t step_wide_max_rows() { return kWideMaxRows; }
+// steps with a window (threshold >= 1) and the first step of a run (no pending update): the grid's sides and the codebook's
+// size are bounded by what a thread keeps in registers while the window sums are formed
+bool step_wide_windowed(int xdim, int ydim, int c) { return xdim <= 16 && ydim <= 16 && (int64_t)xdim * ydim * c <= 32 * kWideThreads; }
 
-// One BMU-only step: the pending update of sa (threshold 0.5), the search of the n rows x[i * ldx], their statistics added to
+// One step: the pending update of sa (has_update == 0: none), the search of the n rows x[i * ldx], their statistics added to
 // `stats` (cleared by an earlier step), sa.stats_zero cleared, W_g to sa.w_out.
 template <typename T>
-int launch_batch_step_wide(const T *x, int64_t n, int c, int64_t ldx, int k, double *stats, const StepArgs &sa, hipStream_t st)
+int launch_batch_step_wide(const T *x, int64_t n, int c, int64_t ldx, int xdim, int ydim, double *stats, const StepArgs &sa, hipStream_t st)
 {
+    const int k = xdim * ydim;
     const WideShape ws = wide_shape(c, k);
-    void (*kern)(const T *, int64_t, int, int64_t, int, double *, StepArgs, WideShape) = nullptr;
+    void (*kern)(const T *, int64_t, int, int64_t, int, double *, StepArgs, WideShape, int, int) = nullptr;
     switch (ws.nch) {
         case 1: kern = batch_step_wide_kernel<T, 1>; break;
         case 2: kern = batch_step_wide_kernel<T, 2>; break;
@@ -462,11 +535,11 @@ int launch_batch_step_wide(const T *x, int64_t n, int c, int64_t ldx, int k, dou
     }
     const int64_t blocks = std::max<int64_t>((n + kWideRowsPerWg - 1) / kWideRowsPerWg, 1);
     const int grid = (int)std::min<int64_t>(blocks, (int64_t)pxsom::device_cu_count());
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWideThreads), ws.total, st, x, n, c, ldx, k, stats, sa, ws);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWideThreads), ws.total, st, x, n, c, ldx, k, stats, sa, ws, xdim, ydim);
     PXSOM_LAUNCH_CHECK("batch_step_wide_kernel");
     return PXSOM_OK;
 }
-template int launch_batch_step_wide<float>(const float *, int64_t, int, int64_t, int, double *, const StepArgs &, hipStream_t);
-template int launch_batch_step_wide<double>(const double *, int64_t, int, int64_t, int, double *, const StepArgs &, hipStream_t);
+template int launch_batch_step_wide<float>(const float *, int64_t, int, int64_t, int, int, double *, const StepArgs &, hipStream_t);
+template int launch_batch_step_wide<double>(const double *, int64_t, int, int64_t, int, int, double *, const StepArgs &, hipStream_t);
 
 }  // namespace pxsom_bmu

@@ -1911,19 +1911,21 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
             if (comm && (rc = pxsom::comm_allreduce_sum_f64(comm, s_cur, nstats, st))) return rc;
             continue;
         }
-        // BMU-only steps (threshold pinned at 0.5) of codebooks up to 128 nodes x 128 channels: ONE launch (update, fragments,
-        // search, exact settle, statistics: pxsom_batch_step_wide.hip) instead of the four or five below
+        // small steps (<= 16 K rows) of codebooks up to 256 nodes x 128 channels: ONE launch (update, fragments, search, exact
+        // settle, statistics: pxsom_batch_step_wide.hip) instead of the four or five below -- the BMU-only steps (threshold
+        // pinned at 0.5) on any grid, the windowed ones on grids up to 16 x 16
         if constexpr (sizeof(T) >= 4) {
             static const bool wide_off = getenv("PXSOM_STEP_WIDE") != nullptr && getenv("PXSOM_STEP_WIDE")[0] == '0';   // A/B hook
-            if (!(flags & PXSOM_TRAIN_UNFUSED) && !wide_off && gg > 0 && thr == 0.5 && rows <= pxsom_bmu::step_wide_max_rows() &&
-                pxsom_bmu::step_wide_shape<T>(c, k)) {
+            const bool bmu_only = gg > 0 && thr == 0.5;
+            if (!(flags & PXSOM_TRAIN_UNFUSED) && !wide_off && rows <= pxsom_bmu::step_wide_max_rows() && pxsom_bmu::step_wide_shape<T>(c, k) &&
+                (bmu_only || pxsom_bmu::step_wide_windowed(xdim, ydim, c))) {
                 pxsom_bmu::StepArgs sa;
-                sa.w_in = w_prev;
-                sa.w_out = w_cur;
+                sa.w_in = gg > 0 ? w_prev : w_cur;
+                sa.w_out = gg > 0 ? w_cur : nullptr;
                 sa.stats_prev = s_prev;
                 sa.stats_zero = s_next;
                 sa.zero_count = (int)nstats;
-                sa.has_update = 1;
+                sa.has_update = gg > 0 ? 1 : 0;
                 sa.thr = thr;
                 sa.lg = log1p(-alpha);
                 sa.mu32 = (centred_run && !no_centre) ? mu32 : nullptr;
@@ -1932,7 +1934,7 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
                                             ldexp(1.0, -24)));
                 sa.tol_abs = fused_tol_abs;
                 sa.qmagic = qmagic;
-                int rc = pxsom_bmu::launch_batch_step_wide<T>(xv, rows, c, ldv, k, s_cur, sa, st);
+                int rc = pxsom_bmu::launch_batch_step_wide<T>(xv, rows, c, ldv, xdim, ydim, s_cur, sa, st);
                 if (rc) return rc;
                 if (comm && (rc = pxsom::comm_allreduce_sum_f64(comm, s_cur, nstats, st))) return rc;
                 continue;
