@@ -198,10 +198,10 @@ int pxsom_batch_update_prepare(double *w_dev, int xdim, int ydim, int c, double 
  * all-reduce) pxsom_batch_train_finish applies the last pending update: w_out_dev [k, c] receives W_total.
  * Register-resident shapes (10 x 10 grid, even c <= 32, rows 2-element aligned) take ONE launch per step: the
  * pending update of step g-1 and the codebook preparation run at the head of step g's BMU search in every
- * workgroup; other shapes run update / prepare / search / exact / sums launches per step -- except the steps whose
- * pending update has its threshold pinned at 0.5 (a node's window is the node: the grid's shape does not enter), which
- * take ONE launch as well for binary32 / binary64 rows, codebooks of up to 256 nodes x 128 channels that fit a CU's LDS
- * and steps of up to 16 384 rows (csrc/pxsom_batch_step_wide.hip).  Same results either way (PXSOM_TRAIN_UNFUSED forces
+ * workgroup; other shapes run update / prepare / search / exact / sums launches per step -- except steps of up to
+ * 16 384 binary32 / binary64 rows on codebooks of up to 256 nodes x 128 channels that fit a CU's LDS, which take ONE
+ * launch as well (csrc/pxsom_batch_step_wide.hip): the steps whose pending update has its threshold pinned at 0.5 on any
+ * grid (a node's window is the node), the others on grids up to 16 x 16.  Same results either way (PXSOM_TRAIN_UNFUSED forces
  * the launch-per-phase route for every step).  Oracle of record: oracle/pxsom_oracle.c orc_som_batch. */
 #define PXSOM_TRAIN_UNFUSED 1
 /* Opt-in (round 4, experimental): the BMU-only steps at the end of a single-rank call (neighbourhood threshold pinned at
