@@ -1917,8 +1917,9 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
         if constexpr (sizeof(T) >= 4) {
             static const bool wide_off = getenv("PXSOM_STEP_WIDE") != nullptr && getenv("PXSOM_STEP_WIDE")[0] == '0';   // A/B hook
             const bool bmu_only = gg > 0 && thr == 0.5;
+            static const int64_t win_cap = getenv("PXSOM_STEP_WIDE_WINCAP") ? atoll(getenv("PXSOM_STEP_WIDE_WINCAP")) : 4096;   // tuning hook
             if (!(flags & PXSOM_TRAIN_UNFUSED) && !wide_off && rows <= pxsom_bmu::step_wide_max_rows() && pxsom_bmu::step_wide_shape<T>(c, k) &&
-                (bmu_only || pxsom_bmu::step_wide_windowed(xdim, ydim, c))) {
+                (bmu_only || (rows <= win_cap && pxsom_bmu::step_wide_windowed(xdim, ydim, c)))) {
                 pxsom_bmu::StepArgs sa;
                 sa.w_in = gg > 0 ? w_prev : w_cur;
                 sa.w_out = gg > 0 ? w_cur : nullptr;

@@ -201,7 +201,7 @@ int pxsom_batch_update_prepare(double *w_dev, int xdim, int ydim, int c, double 
  * workgroup; other shapes run update / prepare / search / exact / sums launches per step -- except steps of up to
  * 16 384 binary32 / binary64 rows on codebooks of up to 256 nodes x 128 channels that fit a CU's LDS, which take ONE
  * launch as well (csrc/pxsom_batch_step_wide.hip): the steps whose pending update has its threshold pinned at 0.5 on any
- * grid (a node's window is the node), the others on grids up to 16 x 16.  Same results either way (PXSOM_TRAIN_UNFUSED forces
+ * grid (a node's window is the node), the others -- up to 4 096 rows -- on grids up to 16 x 16.  Same results either way (PXSOM_TRAIN_UNFUSED forces
  * the launch-per-phase route for every step).  Oracle of record: oracle/pxsom_oracle.c orc_som_batch. */
 #define PXSOM_TRAIN_UNFUSED 1
 /* Opt-in (round 4, experimental): the BMU-only steps at the end of a single-rank call (neighbourhood threshold pinned at
