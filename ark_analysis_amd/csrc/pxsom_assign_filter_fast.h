@@ -6,6 +6,7 @@
 #pragma once
 #include <cfloat>
 #include <cmath>
+#include <type_traits>
 
 #include "pxsom_assign.h"
 #include "pxsom_prep.h"
@@ -249,6 +250,13 @@ __global__ __launch_bounds__(256, PXSOM_FAST_WGS) void bmu_filter_fast(
     constexpr unsigned kAmbQueue = 256;
     int64_t *amb_q = nullptr;
     unsigned *amb_n = nullptr;
+    // ACC, round 4: rows the FIRST stage cannot vouch for wait in a queue of their wave and are searched in full 64 at a time
+    // (full tiles, behind the group loop's body) instead of inside the trip that met them, where a tile was searched again for
+    // one or two rows of its sixteen: the second stage inside the trip was 12 % of the one-pass kernel's time in execution and
+    // 10 % in what its code did to the trip's schedule (profiles/r04/acc_stage2_ablation.txt)
+    constexpr unsigned kS1Queue = 256;
+    int64_t *s1_q = nullptr;
+    unsigned s1_n = 0u;   // wave-uniform
     if constexpr (ACC) {
         // Every workgroup prepares the codebook for itself (no prep launch in front of a mini-batch step):
         // row-major copy in LDS -> prep_body -> fragments / bias / constants in LDS, read below exactly as
@@ -260,6 +268,7 @@ __global__ __launch_bounds__(256, PXSOM_FAST_WGS) void bmu_filter_fast(
         AssignHdr *hdr_l = reinterpret_cast<AssignHdr *>(bias_l + NB * 64);
         amb_q = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(hdr_l) + kHdrBytes);   // [kAmbQueue]
         amb_n = reinterpret_cast<unsigned *>(amb_q + kAmbQueue);
+        s1_q = reinterpret_cast<int64_t *>(amb_n + 4) + (size_t)(threadIdx.x >> 6) * kS1Queue;   // this wave's
         if (threadIdx.x == 0) *amb_n = 0u;
         // element e = tid + 256 u  <->  (node, channel), advanced without a division per element
         int node = (int)threadIdx.x / c, j = (int)threadIdx.x - node * c;
@@ -393,7 +402,13 @@ __global__ __launch_bounds__(256, PXSOM_FAST_WGS) void bmu_filter_fast(
     if (g < ngroups) load_group(g, rows_a);
     // one trip: group g's rows are in `raw`; the next group's go to `nxt` (the same set for the plain filter, whose rows are
     // dead once converted)
-    auto trip = [&](RowSet &raw, RowSet &nxt) {
+    // QUEUED (ACC only): `raw` holds 64 rows gathered from the wave's queue (full_rows of them are real, lane <-> queue slot);
+    // FULL: every tile takes the three-term search; otherwise raw is group g and, with ACC, only stage 1 runs here.
+    // mode 0: a group trip (ACC: stage 1 only, the rows it cannot vouch for are deferred); 1 (ACC): the wave's queue, 64 rows in full
+    auto trip = [&](RowSet &raw, RowSet &nxt, auto mode_tag, unsigned full_rows) {
+        constexpr int kMode = decltype(mode_tag)::value;
+        constexpr bool FULL = kMode != 0, QUEUED = kMode == 1;
+        constexpr bool DEFER = ACC && !FULL;
         RowSet &keep = raw;
         half8 bh[kTilesPerIter];
         float ss[kTilesPerIter];
@@ -442,7 +457,7 @@ __global__ __launch_bounds__(256, PXSOM_FAST_WGS) void bmu_filter_fast(
             }
             return bl;
         };
-        {
+        if constexpr (!QUEUED) {
             int64_t gnext = g + nwaves;
             if (gnext > ngroups - 1) gnext = ngroups - 1;  // harmless re-read on the last trip
             load_group(gnext, nxt);
@@ -485,7 +500,34 @@ __global__ __launch_bounds__(256, PXSOM_FAST_WGS) void bmu_filter_fast(
             float m1[kTilesPerIter], m2[kTilesPerIter];
 #pragma unroll
             for (int t = 0; t < kTilesPerIter; t++) m1[t] = m2[t] = kNegBig;
-            if (!direct) {
+            if constexpr (FULL) {
+                // every tile in full: the three-term search, two node blocks' chains side by side
+#pragma unroll
+                for (int t = 0; t < kTilesPerIter; t++) {
+                    const half8 bl = low_halves(t);
+#pragma unroll
+                    for (int b = 0; b < NB; b += 2) {
+                        f32x4 acc[2];
+#pragma unroll
+                        for (int u = 0; u < 2; u++)
+                            if (b + u < NB) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b + u < NB ? b + u : b][0], bh[t], breg[b + u < NB ? b + u : b], 0, 0, 0);
+#pragma unroll
+                        for (int u = 0; u < 2; u++)
+                            if (b + u < NB) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b + u < NB ? b + u : b][0], bl, acc[u], 0, 0, 0);
+#pragma unroll
+                        for (int u = 0; u < 2; u++)
+                            if (b + u < NB) {
+                                half8 wl;
+                                if constexpr (kLowInRegs) wl = wreg[b + u < NB ? b + u : b][1];
+                                else wl = wlow[((b + u) * 2 + 1) * 64 + lane];
+                                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh[t], acc[u], 0, 0, 0);
+                            }
+#pragma unroll
+                        for (int u = 0; u < 2; u++)
+                            if (b + u < NB) absorb(m1[t], m2[t], acc[u], b + u);
+                    }
+                }
+            } else if (DEFER || !direct) {
 #pragma unroll
                 for (int b = 0; b < NB; b++) {
                     f32x4 acc[kTilesPerIter];
@@ -537,9 +579,11 @@ __global__ __launch_bounds__(256, PXSOM_FAST_WGS) void bmu_filter_fast(
                 const float tol = trel * (xn * wn_max + 0.5f * wn_max * wn_max) + tol_abs * (xn + wn_max);
                 return ((unsigned)!((b1 - b2) > tol) | unfit) != 0u;
             };
-            my_amb = direct || unsure(a1, a2, tol_rel_coarse);
+            if constexpr (FULL) my_amb = unsure(a1, a2, tol_rel);
+            else if constexpr (DEFER) my_amb = unsure(a1, a2, tol_rel_coarse);
+            else my_amb = direct || unsure(a1, a2, tol_rel_coarse);
             my_m1 = a1;
-            {
+            if constexpr (!ACC) {
                 // Stage 2: the full three-term search for the tiles that hold a row stage 1 could not vouch for (lane row t
                 // owns tile t's rows: 16 ballot bits per tile).  One tile at a time, two node blocks' chains side by side;
                 // the four lane groups of a pixel are merged in place and lane row t takes the result.
@@ -610,13 +654,21 @@ __global__ __launch_bounds__(256, PXSOM_FAST_WGS) void bmu_filter_fast(
                 __builtin_amdgcn_sched_group_barrier(0x002, SGB_VALU, 0);  // VALU
             }
         }
-        // lane (q, pix) owns row row0 + q*16 + pix == row0 + lane
-        int64_t row0 = g * 64;
-        if (row0 > n - 64) row0 = n - 64;
-        const int64_t row = row0 + lane;
-        // rows of a shifted last group that the previous group already covered are not listed again
-        // (a row listed twice would be accumulated twice by the exact kernel)
-        my_amb = my_amb && row >= g * 64;
+        // lane (q, pix) owns row row0 + q*16 + pix == row0 + lane (FULL: the row in slot `lane` of the wave's queue)
+        int64_t row0 = 0, row;
+        bool own;
+        if constexpr (QUEUED) {
+            row = s1_q[lane < (int)full_rows ? lane : 0];
+            own = lane < (int)full_rows;
+        } else {
+            row0 = g * 64;
+            if (row0 > n - 64) row0 = n - 64;
+            row = row0 + lane;
+            // rows of a shifted last group that the previous group already covered are not listed again
+            // (a row listed twice would be accumulated twice by the exact kernel)
+            own = row >= g * 64;
+        }
+        my_amb = my_amb && own;
         {
             // id (q, b, r) -> node: 16 b + 4 q + r, the last block's 4x4 (q, r) grid transposed (node_of_row)
             const unsigned id = __float_as_uint(my_m1) & node_mask;
@@ -625,13 +677,14 @@ __global__ __launch_bounds__(256, PXSOM_FAST_WGS) void bmu_filter_fast(
             // ACC: rows of the shifted last group that the group before it owns are left alone -- that group may
             // already have settled them exactly inside this launch, and a late provisional store would undo it
             // (plain filter: the rewrite is harmless, the exact kernel runs in a launch of its own afterwards)
-            if (!ACC || row >= g * 64) labels[row] = (int)real + 1;
+            // (a row that waits for the full search keeps no provisional label: the search's store is the only one)
+            if (!ACC || (own && !(DEFER && my_amb))) labels[row] = (int)real + 1;
             if constexpr (ACC) {
                 // lane (q, pix) holds channels q*CPL.. of rows (t, pix), t = 0..3; their labels sit in lanes (t, pix).
                 // Listed rows and rows a previous group already added go to the spare row k, clamped channel slots
                 // (they re-read the row's last valid pair) too: straight-line code, the four label exchanges in flight
                 // together.
-                const unsigned mine = (my_amb || row < g * 64) ? (unsigned)k : real;
+                const unsigned mine = (my_amb || !own) ? (unsigned)k : real;
                 unsigned lab[kTilesPerIter];
 #pragma unroll
                 for (int t = 0; t < kTilesPerIter; t++) lab[t] = (unsigned)__shfl((int)mine, t * 16 + pix);
@@ -662,7 +715,12 @@ __global__ __launch_bounds__(256, PXSOM_FAST_WGS) void bmu_filter_fast(
             }
         }
         unsigned long long mask = __ballot(my_amb);
-        if (mask) {
+        if constexpr (DEFER) {
+            if (mask) {   // into the wave's queue, behind what it holds (room for two trips' rows is checked by the group loop)
+                if (my_amb) s1_q[s1_n + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = row;
+                s1_n += (unsigned)__popcll(mask);
+            }
+        } else if (mask) {
             if constexpr (ACC) {
                 unsigned base = 0;
                 if (lane == 0) base = atomicAdd(amb_n, (unsigned)__popcll(mask));
@@ -674,7 +732,8 @@ __global__ __launch_bounds__(256, PXSOM_FAST_WGS) void bmu_filter_fast(
                 while (late) {
                     const int src = __builtin_ctzll(late);
                     late &= late - 1;
-                    exact_row_accumulate<T, FIX>(x, row0 + src, c, ldx, wt, k, labels, ls, lane, &fx, stats, cs);
+                    const int64_t rsrc = QUEUED ? s1_q[src] : row0 + src;
+                    exact_row_accumulate<T, FIX>(x, rsrc, c, ldx, wt, k, labels, ls, lane, &fx, stats, cs);
                 }
             } else {
                 unsigned base = 0;
@@ -684,12 +743,52 @@ __global__ __launch_bounds__(256, PXSOM_FAST_WGS) void bmu_filter_fast(
             }
         }
     };
+    // ACC: the rows stage 1 left in the wave's queue, 64 at a time (`all`: the rest too), each batch gathered into a row set of
+    // its own and searched in full
+    // (every place the queue is emptied at comes behind a trip that read rows_b -- or behind the last trip of all: rows_b is free)
+    RowSet &rows_q = rows_b;
+    auto drain = [&](bool all) {
+        while (s1_n >= 64u || (all && s1_n > 0u)) {
+            const unsigned cnt = s1_n < 64u ? s1_n : 64u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int t = 0; t < kTilesPerIter; t++) {
+                const int slot = t * 16 + pix;
+                const T *rp = x + s1_q[slot < (int)cnt ? slot : 0] * ldx;
+#pragma unroll
+                for (int p = 0; p < NP; p++) {
+                    int ch = q * CPL + 2 * p;
+                    if (ch > c - 2) ch = c - 2;
+                    rows_q[t][p] = *reinterpret_cast<const P2 *>(rp + ch);
+                }
+            }
+            trip(rows_q, rows_q, std::integral_constant<int, 1>{}, cnt);
+            __builtin_amdgcn_wave_barrier();
+            if (s1_n > 64u && lane < (int)(s1_n - 64u)) {   // what came in behind the batch moves to the front
+                const int64_t moved = s1_q[64 + lane];
+                s1_q[lane] = moved;
+            }
+            s1_n -= cnt;
+        }
+    };
+    // (the full search stays OUT of the loop that streams the groups: that loop runs until the wave's queue could overflow within
+    // two more trips -- on ordinary data never -- and the queue is emptied between two runs of it.  A fall-back that searches a
+    // wave's groups in full straight away once most of its rows fail stage 1 -- crowded nodes -- was measured on the same box:
+    // it takes a codebook with node pairs 1e-2 apart from 1.65 to 1.20 ms and costs the ordinary case 0.260 -> 0.270 ms for
+    // being there; not kept.)
     while (g < ngroups) {
-        trip(rows_a, rows_b);
-        g += nwaves;
-        if (g >= ngroups) break;
-        trip(rows_b, rows_a);
-        g += nwaves;
+        while (g < ngroups && (!ACC || s1_n <= kS1Queue - 128u)) {
+            trip(rows_a, rows_b, std::integral_constant<int, 0>{}, 0u);
+            g += nwaves;
+            if (g >= ngroups) break;
+            trip(rows_b, rows_a, std::integral_constant<int, 0>{}, 0u);
+            g += nwaves;
+        }
+        if constexpr (ACC) {
+            drain(true);   // (the one place the full search is instantiated)
+        }
     }
     if constexpr (ACC) {
         __syncthreads();   // every wave is through its groups: the queue is complete
