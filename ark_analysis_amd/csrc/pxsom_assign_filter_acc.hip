@@ -17,7 +17,7 @@ void launch_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layou
     auto kern = bmu_filter_fast<T, CPL, 7, 1, 0, true, FIX>;
     // table (first the row-major codebook prep reads) | transposed codebook | fragments | bias | header copy | listed-row queue:
     // 62 KB at k = 100, c = 22 -- two workgroups per CU
-    const size_t lds = ((((size_t)(L.k + 1) * (acc_stride(c) + 1) + 1) & ~(size_t)1) + (size_t)L.k * c) * sizeof(double) +
+    const size_t lds = ((((size_t)(L.k + 1) * (acc_stride(c) + 1) + 1) & ~(size_t)1) + (PXSOM_FAST_WGS < 3 ? (size_t)L.k * c : 0)) * sizeof(double) +
                        (size_t)7 * 2 * 64 * sizeof(half8) + (size_t)7 * 64 * sizeof(f32x4) + kHdrBytes +
                        256 * sizeof(int64_t) + 16 +   // + queue of listed rows and its counter
                        4 * 256 * sizeof(int64_t);    // + the four waves' queues of rows that wait for the full search

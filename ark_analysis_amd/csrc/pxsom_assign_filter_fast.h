@@ -131,8 +131,11 @@ template <typename T, bool FIX = false>
 __device__ __forceinline__ void exact_row_accumulate(const T *__restrict__ x, int64_t row, int c, int64_t ldx,
                                                      const double *wt, int k, int32_t *__restrict__ labels,
                                                      double *ls, int lane, const FixPoint *fx = nullptr,
-                                                     double *stats = nullptr, int cs = 0)
+                                                     double *stats = nullptr, int cs = 0, int wsj = 0, int wsn = 1)
 {
+    // codebook element (channel j, node) at wt[j * wsj + node * wsn]: the transposed LDS copy (wsj = k, wsn = 1: the default) or
+    // the row-major codebook where it lies in HBM / L2 (wsj = 1, wsn = c)
+    if (wsj == 0) wsj = k;
     if (cs == 0) cs = c;   // row stride of the workgroup's table (acc_stride: padded to an odd number of words)
     const double xa = (double)x[row * ldx + (lane < c ? lane : 0)];   // c <= 32 here: lane j holds channel j
     const unsigned xlo = (unsigned)__double_as_longlong(xa), xhi = (unsigned)(__double_as_longlong(xa) >> 32);
@@ -148,8 +151,8 @@ __device__ __forceinline__ void exact_row_accumulate(const T *__restrict__ x, in
         double wa[4], wb[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            wa[u] = wt[(size_t)(j + u) * k + c0];
-            wb[u] = wt[(size_t)(j + u) * k + c1];
+            wa[u] = wt[(size_t)(j + u) * wsj + (size_t)c0 * wsn];
+            wb[u] = wt[(size_t)(j + u) * wsj + (size_t)c1 * wsn];
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -161,7 +164,7 @@ __device__ __forceinline__ void exact_row_accumulate(const T *__restrict__ x, in
     }
     for (; j < c; j++) {
         const double xj = channel(j);
-        const double t0 = xj - wt[(size_t)j * k + c0], t1 = xj - wt[(size_t)j * k + c1];
+        const double t0 = xj - wt[(size_t)j * wsj + (size_t)c0 * wsn], t1 = xj - wt[(size_t)j * wsj + (size_t)c1 * wsn];
         d0 += t0 * t0;
         d1 += t1 * t1;
     }
@@ -245,6 +248,10 @@ __global__ __launch_bounds__(256, PXSOM_FAST_WGS) void bmu_filter_fast(
     double *ls = reinterpret_cast<double *>(acc_smem);
     const int cs = acc_stride(c);   // table row stride (words)
     double *wt = ls + (((size_t)(k + 1) * (cs + 1) + 1) & ~(size_t)1);   // [c][k] transposed codebook (ACC only); 16-byte aligned
+    // three workgroups per CU (PXSOM_FAST_WGS = 3): no room for that copy -- the listed rows read the codebook where it lies
+    constexpr bool kWtInLds = PXSOM_FAST_WGS < 3;
+    const double *wx = kWtInLds ? wt : wcodes;
+    const int wsj = kWtInLds ? k : 1, wsn = kWtInLds ? 1 : c;
     // ACC: rows the filter is not sure of wait in a per-workgroup queue and are settled after the group loop by
     // whichever wave is free (a mini-batch lists 0..6 rows per wave early in training: the slowest wave set the pace)
     constexpr unsigned kAmbQueue = 256;
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(256, PXSOM_FAST_WGS) void bmu_filter_fast(
         // the plain filter reads them from the workspace.
         // the row-major copy prep_body reads lives in the table's storage (needed before the first row is added only)
         double *wrow = ls;                                                           // [k][c]
-        half8 *frag_l = reinterpret_cast<half8 *>(wt + (size_t)k * c);               // [NB][2][64]
+        half8 *frag_l = reinterpret_cast<half8 *>(wt + (kWtInLds ? (size_t)k * c : 0));   // [NB][2][64]
         f32x4 *bias_l = reinterpret_cast<f32x4 *>(frag_l + NB * 2 * 64);             // [NB][64]
         AssignHdr *hdr_l = reinterpret_cast<AssignHdr *>(bias_l + NB * 64);
         amb_q = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(hdr_l) + kHdrBytes);   // [kAmbQueue]
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(256, PXSOM_FAST_WGS) void bmu_filter_fast(
                 const int e = e0 + u * 256;
                 if (e < k * c) {
                     wrow[e] = v[u];
-                    wt[j * k + node] = v[u];
+                    if constexpr (kWtInLds) wt[j * k + node] = v[u];
                 }
                 node += dnode;
                 j += dj;
@@ -733,7 +740,7 @@ __global__ __launch_bounds__(256, PXSOM_FAST_WGS) void bmu_filter_fast(
                     const int src = __builtin_ctzll(late);
                     late &= late - 1;
                     const int64_t rsrc = QUEUED ? s1_q[src] : row0 + src;
-                    exact_row_accumulate<T, FIX>(x, rsrc, c, ldx, wt, k, labels, ls, lane, &fx, stats, cs);
+                    exact_row_accumulate<T, FIX>(x, rsrc, c, ldx, wx, k, labels, ls, lane, &fx, stats, cs, wsj, wsn);
                 }
             } else {
                 unsigned base = 0;
@@ -794,7 +801,7 @@ __global__ __launch_bounds__(256, PXSOM_FAST_WGS) void bmu_filter_fast(
         __syncthreads();   // every wave is through its groups: the queue is complete
         const unsigned queued = *amb_n < kAmbQueue ? *amb_n : kAmbQueue;   // rows past the end were settled at once
         for (unsigned i = threadIdx.x >> 6; i < queued; i += 4)
-            exact_row_accumulate<T, FIX>(x, amb_q[i], c, ldx, wt, k, labels, ls, lane, &fx, stats, cs);
+            exact_row_accumulate<T, FIX>(x, amb_q[i], c, ldx, wx, k, labels, ls, lane, &fx, stats, cs, wsj, wsn);
         __syncthreads();
         if constexpr (FIX) {
             int node = (int)threadIdx.x / c, j = (int)threadIdx.x - node * c;   // element e <-> (node, channel), no division per element
