@@ -224,6 +224,9 @@ __host__ __device__ inline int acc_stride(int c) { return c | 1; }
 #ifndef PXSOM_FAST_WGS
 #define PXSOM_FAST_WGS 2
 #endif
+#ifndef PXSOM_PLAIN_WGS
+#define PXSOM_PLAIN_WGS 2
+#endif
 #ifndef PXSOM_FINE_BLOCKS
 #define PXSOM_FINE_BLOCKS 2
 #endif
@@ -236,7 +239,7 @@ __host__ __device__ inline int acc_stride(int c) { return c | 1; }
 // FIX (with ACC; pxsom_assign_sums): the workgroup's table is 64-bit fixed point (FixPoint above), fix_rows_log2 =
 // ceil(log2(rows a workgroup can meet)).
 template <typename T, int CPL, int NB, int RU, int MODE, bool ACC, bool FIX = false, bool TWO = true>
-__global__ __launch_bounds__(256, PXSOM_FAST_WGS) void bmu_filter_fast(
+__global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void bmu_filter_fast(
     const T *__restrict__ x, int64_t n, int c, int64_t ldx, const half8 *__restrict__ wfrag,
     const f32x4 *__restrict__ bias, AssignHdr *hdr, unsigned *__restrict__ amb_list,
     int32_t *__restrict__ labels, int k, double *__restrict__ stats, const double *__restrict__ wcodes,
@@ -257,13 +260,17 @@ __global__ __launch_bounds__(256, PXSOM_FAST_WGS) void bmu_filter_fast(
     constexpr unsigned kAmbQueue = 256;
     int64_t *amb_q = nullptr;
     unsigned *amb_n = nullptr;
-    // ACC, round 4: rows the FIRST stage cannot vouch for wait in a queue of their wave and are searched in full 64 at a time
+    // Round 4: rows the FIRST stage cannot vouch for wait in a queue of their wave and are searched in full 64 at a time
     // (full tiles, behind the group loop's body) instead of inside the trip that met them, where a tile was searched again for
     // one or two rows of its sixteen: the second stage inside the trip was 12 % of the one-pass kernel's time in execution and
     // 10 % in what its code did to the trip's schedule (profiles/r04/acc_stage2_ablation.txt)
     constexpr unsigned kS1Queue = 256;
     int64_t *s1_q = nullptr;
     unsigned s1_n = 0u;   // wave-uniform
+    if constexpr (!ACC) {   // (the plain filter has no dynamic LDS: its waves' queues are a static array)
+        __shared__ long long s1_plain[4 * kS1Queue];
+        s1_q = reinterpret_cast<int64_t *>(s1_plain) + (size_t)(threadIdx.x >> 6) * kS1Queue;
+    }
     if constexpr (ACC) {
         // Every workgroup prepares the codebook for itself (no prep launch in front of a mini-batch step):
         // row-major copy in LDS -> prep_body -> fragments / bias / constants in LDS, read below exactly as
@@ -316,9 +323,6 @@ __global__ __launch_bounds__(256, PXSOM_FAST_WGS) void bmu_filter_fast(
     static_assert(NB <= 8, "7-bit packed node index");
     const float scale = hdr->scale, wn_max = hdr->wn_max, tol_rel = hdr->tol_rel,
                 tol_abs = hdr->tol_abs, x_limit = hdr->x_limit, tol_rel_coarse = hdr->tol_rel_coarse;
-    // two-stage search (TWO): tiles searched in full / tiles seen so far by this wave, and its verdict on the codebook
-    unsigned fine_tiles = 0, seen_tiles = 0;
-    bool direct = false;
     const bool force_exact = hdr->force_exact != 0;
     FixPoint fx = {};
     if constexpr (FIX) fx = make_fixpoint(hdr->fix_exp, fix_rows_log2 & 255);
@@ -409,13 +413,13 @@ __global__ __launch_bounds__(256, PXSOM_FAST_WGS) void bmu_filter_fast(
     if (g < ngroups) load_group(g, rows_a);
     // one trip: group g's rows are in `raw`; the next group's go to `nxt` (the same set for the plain filter, whose rows are
     // dead once converted)
-    // QUEUED (ACC only): `raw` holds 64 rows gathered from the wave's queue (full_rows of them are real, lane <-> queue slot);
+    // QUEUED: `raw` holds 64 rows gathered from the wave's queue (full_rows of them are real, lane <-> queue slot);
     // FULL: every tile takes the three-term search; otherwise raw is group g and, with ACC, only stage 1 runs here.
-    // mode 0: a group trip (ACC: stage 1 only, the rows it cannot vouch for are deferred); 1 (ACC): the wave's queue, 64 rows in full
+    // mode 0: a group trip (stage 1 only, the rows it cannot vouch for are deferred); 1: the wave's queue, 64 rows in full
     auto trip = [&](RowSet &raw, RowSet &nxt, auto mode_tag, unsigned full_rows) {
         constexpr int kMode = decltype(mode_tag)::value;
         constexpr bool FULL = kMode != 0, QUEUED = kMode == 1;
-        constexpr bool DEFER = ACC && !FULL;
+        constexpr bool DEFER = !FULL && MODE != 1;   // (MODE 1: the microbenchmark's stream-only trip)
         RowSet &keep = raw;
         half8 bh[kTilesPerIter];
         float ss[kTilesPerIter];
@@ -502,8 +506,7 @@ __global__ __launch_bounds__(256, PXSOM_FAST_WGS) void bmu_filter_fast(
             float tm1[kTilesPerIter], tm2[kTilesPerIter];
             // Stage 1: Wh*Xh alone, all four tiles' chains side by side -- a third of the MFMAs.  Its bound is the full one
             // with the two dropped cross terms charged to it (2^-10 |X'||W'|: AssignHdr::tol_rel_coarse); a row whose top-2
-            // gap clears THAT tolerance is as sure as any.  The others' tiles are searched again below.  (A wave that has
-            // given up on stage 1 -- `direct` -- leaves every row unsure here.)
+            // gap clears THAT tolerance is as sure as any.  The others wait in the wave's queue for the full search.
             float m1[kTilesPerIter], m2[kTilesPerIter];
 #pragma unroll
             for (int t = 0; t < kTilesPerIter; t++) m1[t] = m2[t] = kNegBig;
@@ -534,7 +537,7 @@ __global__ __launch_bounds__(256, PXSOM_FAST_WGS) void bmu_filter_fast(
                             if (b + u < NB) absorb(m1[t], m2[t], acc[u], b + u);
                     }
                 }
-            } else if (DEFER || !direct) {
+            } else {
 #pragma unroll
                 for (int b = 0; b < NB; b++) {
                     f32x4 acc[kTilesPerIter];
@@ -587,67 +590,8 @@ __global__ __launch_bounds__(256, PXSOM_FAST_WGS) void bmu_filter_fast(
                 return ((unsigned)!((b1 - b2) > tol) | unfit) != 0u;
             };
             if constexpr (FULL) my_amb = unsure(a1, a2, tol_rel);
-            else if constexpr (DEFER) my_amb = unsure(a1, a2, tol_rel_coarse);
-            else my_amb = direct || unsure(a1, a2, tol_rel_coarse);
+            else my_amb = unsure(a1, a2, tol_rel_coarse);
             my_m1 = a1;
-            if constexpr (!ACC) {
-                // Stage 2: the full three-term search for the tiles that hold a row stage 1 could not vouch for (lane row t
-                // owns tile t's rows: 16 ballot bits per tile).  One tile at a time, two node blocks' chains side by side;
-                // the four lane groups of a pixel are merged in place and lane row t takes the result.
-                const unsigned long long um = __ballot(my_amb);
-                if (um) {
-                    unsigned redone = 0;
-#pragma unroll
-                    for (int t = 0; t < kTilesPerIter; t++) {
-                        if ((um >> (16 * t)) & 0xffffull) {
-                            redone++;
-                            const half8 bl = low_halves(t);
-                            float m1 = kNegBig, m2 = kNegBig;
-#pragma unroll
-                            for (int b = 0; b < NB; b += PXSOM_FINE_BLOCKS) {
-                                constexpr int kPair = PXSOM_FINE_BLOCKS;   // node blocks whose chains run side by side
-                                f32x4 acc[kPair];
-#pragma unroll
-                                for (int u = 0; u < kPair; u++)
-                                    if (b + u < NB) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b + u < NB ? b + u : b][0], bh[t], breg[b + u < NB ? b + u : b], 0, 0, 0);
-#pragma unroll
-                                for (int u = 0; u < kPair; u++)
-                                    if (b + u < NB) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b + u < NB ? b + u : b][0], bl, acc[u], 0, 0, 0);
-#pragma unroll
-                                for (int u = 0; u < kPair; u++)
-                                    if (b + u < NB) {
-                                        half8 wl;
-                                        if constexpr (kLowInRegs) wl = wreg[b + u < NB ? b + u : b][1];
-                                        else wl = wlow[((b + u) * 2 + 1) * 64 + lane];
-                                        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh[t], acc[u], 0, 0, 0);
-                                    }
-#pragma unroll
-                                for (int u = 0; u < kPair; u++)
-                                    if (b + u < NB) absorb(m1, m2, acc[u], b + u);
-                            }
-                            float f1 = __uint_as_float(__float_as_uint(m1) | ((unsigned)q << 5)), f2 = m2;
-                            {
-                                const F2 e1 = xchg16(f1), e2 = xchg16(f2);
-                                f1 = fmaxf(e1.a, e1.b);
-                                f2 = fmaxf(fmaxf(fminf(e1.a, e1.b), e2.a), e2.b);
-                            }
-                            {
-                                const F2 e1 = xchg32(f1), e2 = xchg32(f2);
-                                f1 = fmaxf(e1.a, e1.b);
-                                f2 = fmaxf(fmaxf(fminf(e1.a, e1.b), e2.a), e2.b);
-                            }
-                            if (q == t) {
-                                my_amb = unsure(f1, f2, tol_rel);
-                                my_m1 = f1;
-                            }
-                        }
-                    }
-                    fine_tiles += redone;
-                }
-                seen_tiles += kTilesPerIter;
-                // a codebook whose rows mostly need stage 2 (crowded nodes, early training steps): this wave stops trying stage 1
-                if (seen_tiles >= 16u && fine_tiles * 2u > seen_tiles) direct = true;
-            }
         }
 
         // Both waves of a SIMD run this same stream, so MFMA bursts and VALU stretches would line up
@@ -685,7 +629,9 @@ __global__ __launch_bounds__(256, PXSOM_FAST_WGS) void bmu_filter_fast(
             // already have settled them exactly inside this launch, and a late provisional store would undo it
             // (plain filter: the rewrite is harmless, the exact kernel runs in a launch of its own afterwards)
             // (a row that waits for the full search keeps no provisional label: the search's store is the only one)
-            if (!ACC || (own && !(DEFER && my_amb))) labels[row] = (int)real + 1;
+            // (nor does a row of a shifted last group that the group before it owns: that group's wave may have searched it in
+            // full already)
+            if (own && !(DEFER && my_amb)) labels[row] = (int)real + 1;
             if constexpr (ACC) {
                 // lane (q, pix) holds channels q*CPL.. of rows (t, pix), t = 0..3; their labels sit in lanes (t, pix).
                 // Listed rows and rows a previous group already added go to the spare row k, clamped channel slots
@@ -750,7 +696,7 @@ __global__ __launch_bounds__(256, PXSOM_FAST_WGS) void bmu_filter_fast(
             }
         }
     };
-    // ACC: the rows stage 1 left in the wave's queue, 64 at a time (`all`: the rest too), each batch gathered into a row set of
+    // the rows stage 1 left in the wave's queue, 64 at a time (`all`: the rest too), each batch gathered into a row set of
     // its own and searched in full
     // (every place the queue is emptied at comes behind a trip that read rows_b -- or behind the last trip of all: rows_b is free)
     RowSet &rows_q = rows_b;
@@ -773,9 +719,15 @@ __global__ __launch_bounds__(256, PXSOM_FAST_WGS) void bmu_filter_fast(
             }
             trip(rows_q, rows_q, std::integral_constant<int, 1>{}, cnt);
             __builtin_amdgcn_wave_barrier();
-            if (s1_n > 64u && lane < (int)(s1_n - 64u)) {   // what came in behind the batch moves to the front
-                const int64_t moved = s1_q[64 + lane];
-                s1_q[lane] = moved;
+            // what came in behind the batch moves to the front, 64 entries at a time in ascending order (up to 192 entries:
+            // the queue holds two trips' worth beyond the level the group loop stops at)
+            for (unsigned i = (unsigned)lane; i + 64u < s1_n; i += 64u) {
+                const int64_t moved = s1_q[64u + i];
+                __builtin_amdgcn_wave_barrier();
+                s1_q[i] = moved;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
             s1_n -= cnt;
         }
@@ -786,16 +738,14 @@ __global__ __launch_bounds__(256, PXSOM_FAST_WGS) void bmu_filter_fast(
     // it takes a codebook with node pairs 1e-2 apart from 1.65 to 1.20 ms and costs the ordinary case 0.260 -> 0.270 ms for
     // being there; not kept.)
     while (g < ngroups) {
-        while (g < ngroups && (!ACC || s1_n <= kS1Queue - 128u)) {
+        while (g < ngroups && s1_n <= kS1Queue - 128u) {
             trip(rows_a, rows_b, std::integral_constant<int, 0>{}, 0u);
             g += nwaves;
             if (g >= ngroups) break;
             trip(rows_b, rows_a, std::integral_constant<int, 0>{}, 0u);
             g += nwaves;
         }
-        if constexpr (ACC) {
-            drain(true);   // (the one place the full search is instantiated)
-        }
+        if constexpr (MODE != 1) drain(true);   // (the one place the full search is instantiated)
     }
     if constexpr (ACC) {
         __syncthreads();   // every wave is through its groups: the queue is complete

@@ -781,6 +781,30 @@ def test_relabel_matches_numpy(gpu):
             np.testing.assert_array_equal(got2.cpu().numpy(), want[1:])
 
 
+@pytest.mark.parametrize("apart", [3e-3, 1e-3, 3e-4, 1e-6])
+def test_deferred_full_search_on_codebooks_of_close_node_pairs(gpu, oracle, apart):
+    """The register-resident filters (labels only, and labels + tables in one pass) keep the rows their first stage cannot
+    vouch for in a queue per wave and search them in full 64 at a time.  Codebooks whose nodes come in pairs `apart` (relative)
+    from each other make that the fate of a third to all of the rows -- queues that fill between two drains, batches behind
+    batches: labels equal the oracle's, twice in a row, and the one-pass tables count every row once."""
+    n, c, k = 1_200_000, 22, 100
+    x = synth.make_fov_numpy(n, c, seed=33, dtype=np.float32)
+    rs = np.random.RandomState(9)
+    half = _codebook(x.astype(np.float64), k // 2, seed=6)
+    w = np.concatenate([half, half * (1.0 + apart * rs.uniform(0.5, 1.5, size=half.shape))])
+    xd, wd = torch.from_numpy(x).to(gpu), torch.from_numpy(np.ascontiguousarray(w)).to(gpu)
+    la, _ = sd.assign(xd, wd)
+    lb, _ = sd.assign(xd, wd)
+    assert torch.equal(la, lb)
+    want, _ = oracle.map_data_to_nodes(w, x.astype(np.float64))
+    np.testing.assert_array_equal(la.cpu().numpy(), want)
+    l1, s1, c1 = sd.assign_sums(xd, wd)
+    np.testing.assert_array_equal(l1.cpu().numpy(), want)
+    np.testing.assert_array_equal(c1.cpu().numpy(), np.bincount(want - 1, minlength=k))
+    s2, _ = sd.cluster_sums(xd, la, k)
+    np.testing.assert_allclose(s1.cpu().numpy(), s2.cpu().numpy(), rtol=1e-6, atol=1e-6 * float(np.abs(s2.cpu().numpy()).max()))
+
+
 @pytest.mark.parametrize("n,c,k,dtype", [(300_000, 22, 100, np.float32), (50_001, 8, 100, np.float32), (70_000, 16, 100, np.float16),
                                          (20_000, 22, 100, np.float64), (30_000, 40, 400, np.float16), (9_000, 7, 30, np.float32)])
 def test_assign_sums_one_pass_equals_two_passes(gpu, oracle, n, c, k, dtype):
