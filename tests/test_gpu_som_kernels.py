@@ -781,14 +781,15 @@ def test_relabel_matches_numpy(gpu):
             np.testing.assert_array_equal(got2.cpu().numpy(), want[1:])
 
 
-@pytest.mark.parametrize("apart", [3e-3, 1e-3, 3e-4, 1e-6])
-def test_deferred_full_search_on_codebooks_of_close_node_pairs(gpu, oracle, apart):
+@pytest.mark.parametrize("apart,dtype", [(3e-3, np.float32), (1e-3, np.float32), (3e-4, np.float32), (1e-6, np.float32),
+                                         (1e-3, np.float16), (3e-4, np.float64)])
+def test_deferred_full_search_on_codebooks_of_close_node_pairs(gpu, oracle, apart, dtype):
     """The register-resident filters (labels only, and labels + tables in one pass) keep the rows their first stage cannot
     vouch for in a queue per wave and search them in full 64 at a time.  Codebooks whose nodes come in pairs `apart` (relative)
     from each other make that the fate of a third to all of the rows -- queues that fill between two drains, batches behind
     batches: labels equal the oracle's, twice in a row, and the one-pass tables count every row once."""
     n, c, k = 1_200_000, 22, 100
-    x = synth.make_fov_numpy(n, c, seed=33, dtype=np.float32)
+    x = synth.make_fov_numpy(n, c, seed=33, dtype=np.float32).astype(dtype)
     rs = np.random.RandomState(9)
     half = _codebook(x.astype(np.float64), k // 2, seed=6)
     w = np.concatenate([half, half * (1.0 + apart * rs.uniform(0.5, 1.5, size=half.shape))])
