@@ -1032,6 +1032,9 @@ int launch_step(const T *x, int64_t n, int c, int64_t ldx, double *stats, const 
             if (small_tpw != 1 && small_tpw != 2 && small_tpw != 4) small_tpw = 1;
         }
         if (blocks1 <= slots && blocks1 >= 8 * small_tpw) tpw = small_tpw;
+        // binary64 rows (the drop-in classes' tables): four tiles per wave spill 182 VGPRs, and more rounds of one tile cost
+        // less than that -- measured on 1 M x 22, default schedule: pass 0.520 ms (by size) / 0.487 (two) / 0.474 (one)
+        if (sizeof(T) == 8) tpw = 1;
     }
     const int64_t rows_per_wg = (int64_t)kStepWaves * 16 * tpw;
     // a step larger than one block per slot: the fewest rounds, spread evenly (853 blocks -> 214 workgroups x 4, not 256 x 3.3)
