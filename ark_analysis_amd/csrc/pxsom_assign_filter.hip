@@ -673,7 +673,7 @@ void launch_packed(const _Float16 *x, int64_t n, int c, int64_t ldx, char *ws, c
     // LDS copy; measured on config 5's shape (4.2 M rows x 40 binary16, 400 nodes) 0.332 ms against 0.370 with 512 threads:
     // matrix and vector instructions of a SIMD overlap between waves, not inside one.  PXSOM_PACKED_BD=512: the old launch.
     static const int big_bd = getenv("PXSOM_PACKED_BD") ? atoi(getenv("PXSOM_PACKED_BD")) : 1024;
-    if (lds <= 150 * 1024 && lds > 64 * 1024 && big_bd == 1024) {
+    if (lds <= 150 * 1024 && lds > 64 * 1024 && big_bd == 1024 && NPK <= 4) {   // (five chunks and more spill at 128 VGPRs)
         auto kern = bmu_filter_packed_kernel<NPK, 4, true, 1024>;
         static pxsom::PerDevice<bool> raised_on;
         bool &raised = raised_on.here();
