@@ -409,7 +409,9 @@ void launch_filter_variant(const T *x, int64_t n, int c, int64_t ldx, char *ws, 
     // streamed codebook (NB == 0): every fragment read serves TP tiles.  Measured (filter, ms, fragments from
     // L1 / L2): C = 40, K = 400, 4.2 M rows: TP 1 / 2 / 4 = 1.27 / 0.83 / 0.75; C = 100, K = 100, 1 M rows:
     // 0.244 / 0.188 / 0.257 (four channel chunks x four tiles of fragments no longer fit the register file)
-    constexpr int TP = (NB > 0) ? 2 : (PXSOM_STREAM_TP > 0 ? PXSOM_STREAM_TP : (NCH <= 2 ? 4 : 2));
+    // (round 4, four chunks: one tile per read spills 16 dwords instead of 52 and is as fast on 1 M rows, faster on the small
+    // steps of a training pass -- config 4's step 2.97 -> 2.89 ms)
+    constexpr int TP = (NB > 0) ? 2 : (PXSOM_STREAM_TP > 0 ? PXSOM_STREAM_TP : (NCH <= 2 ? 4 : (NCH == 3 ? 2 : 1)));
     const int64_t ngroups = (n + 63) / 64;
     if constexpr (LDSW) {
         if (lds > 64 * 1024) {   // one workgroup per CU: make it a big one
