@@ -65,7 +65,10 @@ __host__ __device__ inline StepLds step_lds(int c)
     return L;
 }
 
-template <typename T, int CPL, int TPW>
+// BMU: the launch is a BMU-only step (pending update with its threshold pinned at 0.5) and the windowed update is compiled out --
+// the same instructions run either way on such a step, but the kernel that also CONTAINS the windowed update takes 10.6 us
+// per step where this one takes 9.3 (profiles/r04/step_bmu_only_specialisation.txt).
+template <typename T, int CPL, int TPW, bool BMU = false>
 __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__restrict__ x, int64_t n, int c, int64_t ldx,
                                                                   double *__restrict__ stats, StepArgs sa)
 {
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
     // once per node by the first two waves (lane <-> node) instead of by all seven waves that hold node lanes: the update of
     // a tail step was binary64 issue on two waves per SIMD (profiles/r03/step_phase_timing.txt: 1.6 us of 9.1).
     const int upd_r = sa.thr < 0.0 ? -1 : (sa.thr > 1.0e6 ? 1000000 : (int)floor(sa.thr));
-    const bool bmu_only = sa.has_update != 0 && upd_r == 0;
+    const bool bmu_only = BMU || (sa.has_update != 0 && upd_r == 0);
     double sdir[CPL];   // bmu_only: this thread's words of the statistics
     if (bmu_only) {
         double cnt = 0.0;
@@ -997,10 +1000,13 @@ int launch_step(const T *x, int64_t n, int c, int64_t ldx, double *stats, const 
     auto k1 = batch_step_kernel<T, CPL, 1>;
     auto k2 = batch_step_kernel<T, CPL, 2>;
     auto k4 = batch_step_kernel<T, CPL, 4>;
+    auto k1b = batch_step_kernel<T, CPL, 1, true>;
+    auto k2b = batch_step_kernel<T, CPL, 2, true>;
     static pxsom::PerDevice<size_t> attr_lds_on;
     size_t &attr_lds = attr_lds_on.here();
     if (attr_lds < lds) {
-        for (const void *fn : {reinterpret_cast<const void *>(k1), reinterpret_cast<const void *>(k2), reinterpret_cast<const void *>(k4)}) {
+        for (const void *fn : {reinterpret_cast<const void *>(k1), reinterpret_cast<const void *>(k2), reinterpret_cast<const void *>(k4),
+                               reinterpret_cast<const void *>(k1b), reinterpret_cast<const void *>(k2b)}) {
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess)
                 return pxsom::fail(PXSOM_ERR_HIP, "batch step kernel: cannot raise the LDS limit to %zu bytes: %s", lds,
@@ -1041,7 +1047,10 @@ int launch_step(const T *x, int64_t n, int c, int64_t ldx, double *stats, const 
     const int64_t nblocks = std::max<int64_t>((n + rows_per_wg - 1) / rows_per_wg, 1);
     const int64_t rounds = (nblocks + slots - 1) / slots;
     const int grid = (int)((nblocks + rounds - 1) / rounds);
-    hipLaunchKernelGGL(tpw == 1 ? k1 : (tpw == 2 ? k2 : k4), dim3(grid), dim3(kStepThreads), lds, st, x, n, c, ldx, stats, sa);
+    // (the kernel's own test of the pending update's threshold, made here: a BMU-only step takes the specialised kernel)
+    const bool bmu = sa.has_update != 0 && sa.thr >= 0.0 && sa.thr < 1.0;
+    auto kern = tpw == 1 ? (bmu ? k1b : k1) : (tpw == 2 ? (bmu ? k2b : k2) : k4);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kStepThreads), lds, st, x, n, c, ldx, stats, sa);
     PXSOM_LAUNCH_CHECK("batch_step_kernel");
     return PXSOM_OK;
 }
