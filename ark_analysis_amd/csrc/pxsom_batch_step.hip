@@ -65,10 +65,11 @@ __host__ __device__ inline StepLds step_lds(int c)
     return L;
 }
 
-// BMU: the launch is a BMU-only step (pending update with its threshold pinned at 0.5) and the windowed update is compiled out --
-// the same instructions run either way on such a step, but the kernel that also CONTAINS the windowed update takes 10.6 us
-// per step where this one takes 9.3 (profiles/r04/step_bmu_only_specialisation.txt).
-template <typename T, int CPL, int TPW, bool BMU = false>
+// BMU: the launch is a BMU-only step (pending update with its threshold pinned at 0.5) and the windowed update is compiled out;
+// !BMU: the other way round.  The same instructions run on a step whichever kernel it takes, but a kernel that CONTAINS both
+// updates takes 10.6 us per BMU-only step where the specialised one takes 9.3, and 0.2 - 1.4 us more per windowed step
+// (profiles/r04/step_bmu_only_specialisation.txt).
+template <typename T, int CPL, int TPW, bool BMU>
 __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__restrict__ x, int64_t n, int c, int64_t ldx,
                                                                   double *__restrict__ stats, StepArgs sa)
 {
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
     // once per node by the first two waves (lane <-> node) instead of by all seven waves that hold node lanes: the update of
     // a tail step was binary64 issue on two waves per SIMD (profiles/r03/step_phase_timing.txt: 1.6 us of 9.1).
     const int upd_r = sa.thr < 0.0 ? -1 : (sa.thr > 1.0e6 ? 1000000 : (int)floor(sa.thr));
-    const bool bmu_only = BMU || (sa.has_update != 0 && upd_r == 0);
+    constexpr bool bmu_only = BMU;   // (the launch picks the kernel by the pending update's threshold: launch_step)
     double sdir[CPL];   // bmu_only: this thread's words of the statistics
     if (bmu_only) {
         double cnt = 0.0;
@@ -997,9 +998,9 @@ int launch_step(const T *x, int64_t n, int c, int64_t ldx, double *stats, const 
                 hipStream_t st)
 {
     const size_t lds = step_lds(c).total;
-    auto k1 = batch_step_kernel<T, CPL, 1>;
-    auto k2 = batch_step_kernel<T, CPL, 2>;
-    auto k4 = batch_step_kernel<T, CPL, 4>;
+    auto k1 = batch_step_kernel<T, CPL, 1, false>;
+    auto k2 = batch_step_kernel<T, CPL, 2, false>;
+    auto k4 = batch_step_kernel<T, CPL, 4, false>;
     auto k1b = batch_step_kernel<T, CPL, 1, true>;
     auto k2b = batch_step_kernel<T, CPL, 2, true>;
     static pxsom::PerDevice<size_t> attr_lds_on;
@@ -1042,13 +1043,14 @@ int launch_step(const T *x, int64_t n, int c, int64_t ldx, double *stats, const 
         // less than that -- measured on 1 M x 22, default schedule: pass 0.520 ms (by size) / 0.487 (two) / 0.474 (one)
         if (sizeof(T) == 8) tpw = 1;
     }
+    // (the kernel's own test of the pending update's threshold, made here: a BMU-only step takes the specialised kernel)
+    const bool bmu = sa.has_update != 0 && sa.thr >= 0.0 && sa.thr < 1.0;
+    if (bmu && tpw == 4) tpw = 2;   // (BMU-only steps that large do not occur on the default schedule: two tiles, more rounds)
     const int64_t rows_per_wg = (int64_t)kStepWaves * 16 * tpw;
     // a step larger than one block per slot: the fewest rounds, spread evenly (853 blocks -> 214 workgroups x 4, not 256 x 3.3)
     const int64_t nblocks = std::max<int64_t>((n + rows_per_wg - 1) / rows_per_wg, 1);
     const int64_t rounds = (nblocks + slots - 1) / slots;
     const int grid = (int)((nblocks + rounds - 1) / rounds);
-    // (the kernel's own test of the pending update's threshold, made here: a BMU-only step takes the specialised kernel)
-    const bool bmu = sa.has_update != 0 && sa.thr >= 0.0 && sa.thr < 1.0;
     auto kern = tpw == 1 ? (bmu ? k1b : k1) : (tpw == 2 ? (bmu ? k2b : k2) : k4);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kStepThreads), lds, st, x, n, c, ldx, stats, sa);
     PXSOM_LAUNCH_CHECK("batch_step_kernel");
