@@ -280,10 +280,6 @@ __global__ __launch_bounds__(256) void bmu_exact_kernel(const T *__restrict__ x,
 //          smallest distance and, among equal ones, the smallest node: the oracle's first strict minimum.
 // ------------------------------------------------------------------------------------------------
 constexpr int kPairCap = 512;
-// timing ablations (scripts/jobs/r4_exact_ablate.sh; wrong labels): 1 = pairs not evaluated, 2 = no node walk, 4 = no reference distance
-#ifndef PXSOM_SCREEN_ABLATE
-#define PXSOM_SCREEN_ABLATE 0
-#endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void wave_lds_sync()
@@ -408,7 +404,7 @@ void bmu_exact_screened_kernel(const T *__restrict__ x, int c, int64_t ldx,
             }
             return sqrt(acc);
         };
-        const double dref = (PXSOM_SCREEN_ABLATE & 4) ? 1.0 : oracle_distance(ref, lane, row);   // (every group for its own copy of the row: same value)
+        const double dref = oracle_distance(ref, lane, row);   // (every group for its own copy of the row: same value)
         // the reference node's distance is the row's first candidate (the pairs below leave that node out)
         if (grp == 0) {
             const bool seeded = dref < DBL_MAX;   // NaN / Inf never replace the oracle's DBL_MAX
@@ -428,7 +424,6 @@ void bmu_exact_screened_kernel(const T *__restrict__ x, int c, int64_t ldx,
 
         unsigned npairs = 0;
         auto flush = [&]() __attribute__((always_inline)) {
-            if (PXSOM_SCREEN_ABLATE & 1) npairs = 0;
             for (unsigned p0 = 0; p0 < npairs; p0 += 64) {
                 const unsigned p = p0 + lane;
                 const bool on = p < npairs;
@@ -449,7 +444,7 @@ void bmu_exact_screened_kernel(const T *__restrict__ x, int c, int64_t ldx,
             }
             npairs = 0;
         };
-        for (int i = 0; i < ((PXSOM_SCREEN_ABLATE & 2) ? 0 : kper); i += NU) {
+        for (int i = 0; i < kper; i += NU) {
             float d[NU];
             {
 #pragma clang fp contract(fast)

@@ -1,4 +1,4 @@
-# where the screened exact kernel's time goes on config 4's lists: ablation builds (labels wrong, timing only) -> gpurun_out/r4_exact/ablate.txt
+# where the screened exact kernel's time went on config 4's lists: ablation builds (hooks removed from the tree since; labels wrong, timing only) -> gpurun_out/r4_exact/ablate.txt
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/r4_exact
 OUT=$R/gpurun_out/r4_exact/ablate.txt
