@@ -39,6 +39,28 @@ struct AssignHdr {
 };
 static_assert(sizeof(AssignHdr) <= kHdrBytes, "workspace header");
 
+// Gain of the batch rule, 1 - (1 - alpha)^den for a whole den >= 1 (a window's row count), with q = 1 - alpha rounded once on
+// the host: binary exponentiation in plain binary64 products, low bit first -- no libm call, so orc_batch_gain
+// (oracle/pxsom_oracle.c, the same statements) and every kernel return the same bits whatever maths library either side
+// links.  Every intermediate is held at or above 2^-200: anything below 2^-54 leaves the gain at exactly 1 (the node then IS
+// the window mean, orc_batch_update), so the floor changes no result and no product ever reaches the subnormal range.
+__host__ __device__ inline double batch_gain(double den, double q)
+{
+#pragma clang fp contract(off)
+    const double tiny = 0x1p-200;
+    unsigned long long m = (unsigned long long)den;
+    double p = 1.0, b = q;
+    while (m) {
+        double t = p * b;
+        t = t < tiny ? tiny : t;
+        p = (m & 1ull) ? t : p;
+        m >>= 1;
+        b = b * b;
+        b = b < tiny ? tiny : b;
+    }
+    return 1.0 - p;
+}
+
 // the pending update a fused mini-batch step applies at its head, and its housekeeping (pxsom_batch_step.hip)
 struct StepArgs {
     const double *w_in;        // [k, c] codebook the pending update applies to (W_{g-1}, or W_0 when has_update == 0)
@@ -47,7 +69,7 @@ struct StepArgs {
     double *stats_zero;        // buffer cleared for step g+1 (NULL: none)
     int zero_count;
     int has_update;
-    double thr, lg;            // schedule of the pending update (step g-1): window threshold, log(1 - alpha)
+    double thr, q;             // schedule of the pending update (step g-1): window threshold, 1 - alpha (batch_gain)
     float tol_rel, tol_abs;    // filter tolerance coefficients (depend on c only: computed on the host)
     // two-level row view of a scheduled step (fused kernel only): row f of the step is
     // x[(f / group_w) * group_stride + (f % group_w) * ldx] -- group_w consecutive rows (the phases the step
@@ -62,18 +84,18 @@ struct StepArgs {
 };
 
 // The BMU-only tail of a training pass as ONE persistent launch (pxsom_batch_tail.hip): every step's row view, its
-// pending update's log(1 - alpha), and where the state the per-step route would leave behind goes.
+// pending update's 1 - alpha, and where the state the per-step route would leave behind goes.
 constexpr int kMaxTailSteps = 64;
 struct TailStep {
     int e0, width;             // the step takes the phases [e0, e0 + width): rows (f / width) * phases + e0 + f % width
     long long rows;            // rows of the step (>= 1)
-    double lg;                 // log(1 - alpha) of the update applied at the HEAD of this step (statistics of the step before)
+    double q;                  // 1 - alpha of the update applied at the HEAD of this step (statistics of the step before)
 };
 struct TailArgs {
     int nsteps, phases;
     int first_has_update;      // 0: the run starts here (W_in is searched as it is)
-    int final_update;          // 1: the last step's statistics are applied as well (lg_final) and the result goes to w_final
-    double lg_final;
+    int final_update;          // 1: the last step's statistics are applied as well (q_final) and the result goes to w_final
+    double q_final;
     const double *stats_first; // [k*c sums | k counts] of the step before the first one (ring slot; first_has_update)
     const double *w_in;        // [k, c] codebook the first update applies to
     double *w_last;            // [k, c] receives the codebook the LAST step searched with (wbuf slot of that step)

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
     // first -- the statistics (pass 1), then the old node values (P3), the step's rows (HBM, slowest) last.
     // BMU-only steps (the tail of a pass: thr = 0.5, r = 0): the window of a node is the node itself -- both separable passes
     // would add +-0 to S[x][y], the same bits -- so thread <-> (node, lane group) asks for ITS words of the statistics directly
-    // (no scratch pass, no barrier before them), and the gain 1 - (1 - alpha)^n with its expm1 and the reciprocal are formed
+    // (no scratch pass, no barrier before them), and the gain 1 - (1 - alpha)^n with its chain of products and the reciprocal are formed
     // once per node by the first two waves (lane <-> node) instead of by all seven waves that hold node lanes: the update of
     // a tail step was binary64 issue on two waves per SIMD (profiles/r03/step_phase_timing.txt: 1.6 us of 9.1).
     const int upd_r = sa.thr < 0.0 ? -1 : (sa.thr > 1.0e6 ? 1000000 : (int)floor(sa.thr));
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
         if (tid < kK) {   // tl[node] = gain (or -1: no rows, the node stays), tl[K + node] = 1 / n
 #pragma clang fp contract(off)
             const double den = 0.0 + cnt;
-            tl[tid] = den > 0.0 ? -expm1(den * sa.lg) : -1.0;
+            tl[tid] = den > 0.0 ? batch_gain(den, sa.q) : -1.0;
             tl[kK + tid] = den > 0.0 ? 1.0 / den : 0.0;
         }
         PXSOM_PHASE(10);
@@ -312,10 +312,10 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
                 inv = tl[kK + node];
             } else if (sa.has_update) {
                 den = nrow[c];
-                // gain = 1 - (1-alpha)^den = -expm1(den * log(1-alpha)); == 1 exactly for wide windows: the node is
+                // gain = 1 - (1-alpha)^den (batch_gain); == 1 exactly for wide windows: the node is
                 // then the window mean itself (orc_batch_update)
                 if (den > 0.0) {
-                    gain = -expm1(den * sa.lg);
+                    gain = batch_gain(den, sa.q);
                     inv = 1.0 / den;
                 }
             }
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
         if (tid < K) {
             const int xp = tid / YD, yp = tid - xp * YD;
             const double den = tl[(size_t)(yp * XD + xp) * NC + c];
-            gain_l[tid] = den > 0.0 ? -expm1(den * sa.lg) : -1.0;
+            gain_l[tid] = den > 0.0 ? batch_gain(den, sa.q) : -1.0;
             tl[(size_t)(yp * XD + xp) * NC + c] = den > 0.0 ? 1.0 / den : 0.0;     // the count column now holds 1/den
         }
         PXSOM_PHASE(4);

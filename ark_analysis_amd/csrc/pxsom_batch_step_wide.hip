@@ -10,7 +10,7 @@
 //
 // A workgroup (512 threads) takes 64 rows, each of its first four waves one 16-row tile:
 //   P0  requests: the counts and sums of step g-1, W_{g-1};
-//   P1  the pending update, element-wise and coalesced, in the arithmetic of orc_som_batch_sched (gain = -expm1(den lg), mean =
+//   P1  the pending update, element-wise and coalesced, in the arithmetic of orc_som_batch_sched (gain = batch_gain(den, 1 - alpha), mean =
 //       S (1/den), w + gain (mean - w), no contraction); W_g into LDS (row stride padded to an odd number of words), workgroup 0
 //       writes it to HBM;
 //   P2  centred norms, maxima, the power-of-two scale, A-fragments (binary16 hi / lo of (W - mu) scale) and biases in LDS;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
     if (r == 0) {
         if (tid < ws.kp) {
             const double den = (tid < k && sa.has_update) ? sa.stats_prev[(size_t)kc + tid] : 0.0;
-            gain_l[tid] = den > 0.0 ? -expm1(den * sa.lg) : -1.0;
+            gain_l[tid] = den > 0.0 ? batch_gain(den, sa.q) : -1.0;
             inv_l[tid] = den > 0.0 ? 1.0 / den : 0.0;
         }
         __syncthreads();
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
         __syncthreads();
         if (tid < ws.kp) {
             const double den = tid < k ? wl[(size_t)tid * cs + c] : 0.0;
-            gain_l[tid] = den > 0.0 ? -expm1(den * sa.lg) : -1.0;
+            gain_l[tid] = den > 0.0 ? batch_gain(den, sa.q) : -1.0;
             inv_l[tid] = den > 0.0 ? 1.0 / den : 0.0;
         }
         __syncthreads();

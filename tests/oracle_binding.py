@@ -48,6 +48,8 @@ def lib():
         L.orc_batch_update.restype = None
         L.orc_batch_update.argtypes = [c_dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_dp, c_i64p,
                                        ctypes.c_double, ctypes.c_double]
+        L.orc_batch_gain.restype = ctypes.c_double
+        L.orc_batch_gain.argtypes = [ctypes.c_double, ctypes.c_double]
         L.orc_som_batch.restype = ctypes.c_int
         L.orc_som_batch.argtypes = [c_dp, ctypes.c_int64, ctypes.c_int, c_dp, ctypes.c_int, ctypes.c_int,
                                     ctypes.c_double, ctypes.c_double, ctypes.c_double,
@@ -194,6 +196,11 @@ def batch_update(codes, xdim, ydim, sums, counts, thr, alpha):
     lib().orc_batch_update(_dp(codes), int(xdim), int(ydim), px, _dp(sums), counts.ctypes.data_as(c_i64p),
                            float(thr), float(alpha))
     return codes
+
+
+def batch_gain(den, q):
+    """1 - q^den of the batch rule (orc_batch_gain: binary exponentiation in plain binary64 products)."""
+    return float(lib().orc_batch_gain(float(den), float(q)))
 
 
 def som_batch(data, codes, xdim, ydim, rlen, alpha_range, radius_range, M):

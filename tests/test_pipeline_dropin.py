@@ -71,9 +71,9 @@ def test_pixel_pipeline_batch_mode_matches_fixture(som_backend, tmp_path, capsys
     pixel_som_clustering.generate_som_avg_files(FOVS, CHANS, td, obj, data_dir="pixel_mat_data")
     assert capsys.readouterr().out == str(g["stdout"])
     assert list(obj.weights.columns) == CHANS
-    # batch rule on binary64 tables: the statistics are exact sums of quantised rows (order-free), what is left between
-    # device and oracle is expm1 against libm's: 1e-9
-    np.testing.assert_allclose(obj.weights.values, g["weights"], rtol=1e-9, atol=0)
+    # batch rule on binary64 tables: the statistics are exact sums of quantised rows (order-free) and the gain is a chain of
+    # plain products on both sides (batch_gain, round 5): the oracle's codebook bit for bit
+    np.testing.assert_array_equal(obj.weights.values, g["weights"])
     np.testing.assert_array_equal(read_dataframe(os.path.join(td, "pixel_som_weights.feather")).values,
                                   obj.weights.values)
     from tests import oracle_binding as ob
