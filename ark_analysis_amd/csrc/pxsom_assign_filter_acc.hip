@@ -6,6 +6,7 @@
 #include <cstdlib>
 
 #include "pxsom_assign_filter_fast.h"
+#include "pxsom_assign_onepass.h"
 
 namespace pxsom_bmu {
 namespace {
@@ -49,6 +50,44 @@ void launch_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layou
                        fix_rows_log2);
 }
 
+// the four-waves-per-SIMD one-pass kernel (pxsom_assign_onepass.h): fixed-point tables, binary32 / binary16 rows, C <= 24
+template <typename T, int CPL>
+void launch_onepass(const T *x, int64_t n, int c, int64_t ldx, const Layout &L, int32_t *labels, double *stats, const double *w,
+                    hipStream_t st)
+{
+    auto kern = bmu_onepass_kernel<T, CPL>;
+    const size_t lds = onepass_lds_bytes(L.k, c);
+    static pxsom::PerDevice<int> bpc_on;   // (one per instantiation)
+    int &bpc = bpc_on.here();
+    if (bpc == 0) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        int nbk = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, kern, kOneThreads, lds) != hipSuccess || nbk < 1) nbk = 1;
+        bpc = nbk > 4 ? 4 : nbk;
+    }
+    const int64_t nunits = (n + 31) / 32;
+    // at least two 32-row units per wave where the launch is small (fewer workgroups pay the prologue and the flush)
+    int grid = (int)std::min<int64_t>((nunits + 2 * kOneWaves - 1) / (2 * kOneWaves), (int64_t)pxsom::device_cu_count() * bpc);
+    if (grid < 1) grid = 1;
+    int fix_rows_log2 = 0;
+    {
+        const int64_t rows_wg = ((nunits + (int64_t)grid * kOneWaves - 1) / ((int64_t)grid * kOneWaves)) * (32 * kOneWaves) + 32;
+        while (((int64_t)1 << fix_rows_log2) < rows_wg) fix_rows_log2++;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kOneThreads), lds, st, x, n, c, ldx, labels, L.k, stats, w, L.idx_bits, L.node_bits,
+                       fix_rows_log2);
+}
+
+// PXSOM_ONEPASS=1 takes the three-waves-per-SIMD kernel (opt-in: measured slower; read once)
+bool onepass_enabled()
+{
+    static const bool on = [] {
+        const char *e = std::getenv("PXSOM_ONEPASS");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
+
 }  // namespace
 
 template <typename T>
@@ -58,6 +97,17 @@ void launch_filter_fast_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws,
 #define PXSOM_ACC(CPL)                                                            \
     (fixed ? launch_acc<T, CPL, true>(x, n, c, ldx, ws, L, labels, stats, w, st)  \
            : launch_acc<T, CPL, false>(x, n, c, ldx, ws, L, labels, stats, w, st))
+    if constexpr (sizeof(T) <= 4) {
+        if (fixed && L.cpl <= 6 && onepass_enabled()) {
+            if (L.cpl == 6)
+                launch_onepass<T, 6>(x, n, c, ldx, L, labels, stats, w, st);
+            else if (L.cpl == 4)
+                launch_onepass<T, 4>(x, n, c, ldx, L, labels, stats, w, st);
+            else
+                launch_onepass<T, 2>(x, n, c, ldx, L, labels, stats, w, st);
+            return;
+        }
+    }
     if (L.cpl == 6)
         PXSOM_ACC(6);
     else if (L.cpl == 8)

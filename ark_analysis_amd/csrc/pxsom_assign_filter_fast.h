@@ -638,12 +638,22 @@ __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void b
                 // (they re-read the row's last valid pair) too: straight-line code, the four label exchanges in flight
                 // together.
                 const unsigned mine = (my_amb || !own) ? (unsigned)k : real;
+                // Round 5: the four labels travel through v_permlane16/32_swap (VALU) instead of four ds_bpermute, whose
+                // results waited in the LDS queue behind the trip's own atomics: swapping a value with itself hands every lane
+                // {even row's, odd row's} of its pair of lane rows, then {lower half's, upper half's} of the wave.
                 unsigned lab[kTilesPerIter];
-#pragma unroll
-                for (int t = 0; t < kTilesPerIter; t++) lab[t] = (unsigned)__shfl((int)mine, t * 16 + pix);
+                {
+                    const uint2v r16 = __builtin_amdgcn_permlane16_swap(mine, mine, false, false);   // rows 0, 1: {L0, L1}; rows 2, 3: {L2, L3}
+                    const uint2v e32 = __builtin_amdgcn_permlane32_swap(r16[0], r16[0], false, false);   // {L0, L2} in every lane
+                    const uint2v o32 = __builtin_amdgcn_permlane32_swap(r16[1], r16[1], false, false);   // {L1, L3}
+                    lab[0] = e32[0];
+                    lab[1] = o32[0];
+                    lab[2] = e32[1];
+                    lab[3] = o32[1];
+                }
 #pragma unroll
                 for (int t = 0; t < kTilesPerIter; t++) {
-                    const unsigned base = lab[t] * (unsigned)cs, spare = (unsigned)k * (unsigned)cs;
+                    const unsigned base = __umul24(lab[t], (unsigned)cs), spare = __umul24((unsigned)k, (unsigned)cs);   // (v_mul_lo_u32 runs at quarter rate)
 #pragma unroll
                     for (int p = 0; p < NP; p++) {
                         const bool own = q * CPL + 2 * p <= c - 2;

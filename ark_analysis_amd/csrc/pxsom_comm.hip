@@ -122,7 +122,11 @@ __global__ __launch_bounds__(1024) void p2p_allreduce_kernel(P2PArgs a, double *
     }
     __syncthreads();
     if (s_timeout) {
-        if (tid == 0) __hip_atomic_store(&mine->error, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tid == 0) {   // the FIRST exchange that timed out stays on record (a later one must not overwrite it)
+            unsigned long long none = 0ull;
+            (void)__hip_atomic_compare_exchange_strong(&mine->error, &none, a.epoch, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         for (size_t e = tid; e < count; e += 1024) buf[e] = __builtin_nan("");
         return;
     }
@@ -232,16 +236,16 @@ PXSOM_EXPORT int pxsom_comm_p2p_create(int nranks, int rank, size_t max_count, p
     c->max_count = max_count;
     const size_t bytes = sizeof(P2PBlock) + (size_t)2 * nranks * max_count * sizeof(double);
     // fine-grained device memory: peers write into it and this rank reads it while kernels run
+    // (no coarse-grained fall-back: kernels of other devices poll and write this block while this device's kernels run, which
+    // only fine-grained memory keeps coherent -- without it the communicator is not made and the caller takes another route)
     hipError_t e = hipExtMallocWithFlags(reinterpret_cast<void **>(&c->block), bytes, hipDeviceMallocFinegrained);
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        e = hipMalloc(reinterpret_cast<void **>(&c->block), bytes);
-    }
-    if (e != hipSuccess) {
         delete c;
-        return pxsom::hip_fail(e, "pxsom_comm_p2p_create: exchange block");
+        return pxsom::hip_fail(e, "pxsom_comm_p2p_create: fine-grained exchange block");
     }
     e = hipMemset(c->block, 0, bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();   // the block is clear before its handle can reach a peer
     if (e != hipSuccess) {
         (void)hipFree(c->block);
         delete c;

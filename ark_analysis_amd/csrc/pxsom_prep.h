@@ -95,7 +95,8 @@ __device__ __forceinline__ void prep_body(const double *wl, int k, int c, Assign
     // any vector would do for the ranking, the mean keeps the centred norms (what the error bound is relative to) small.
     // NT / 128 adjacent lanes share a channel.
     if (center) {
-        constexpr int per = NT / kFilterMaxChannels;
+        // (a power of two of lanes per channel, whatever NT: workgroups of 768 threads use four, their last 256 threads idle)
+        constexpr int per = NT / kFilterMaxChannels >= 8 ? 8 : (NT / kFilterMaxChannels >= 4 ? 4 : (NT / kFilterMaxChannels >= 2 ? 2 : 1));
         const int j = tid / per, part = tid % per;
         double sum = 0.0;
         if (j < c)

@@ -66,15 +66,23 @@ class HipKernels:
             self._rings = [st.ring[i] for i in range(3)]     # views made once: ring(g) sits in the per-step loop
         st.wbuf[0].copy_(w)
         st.quantum = float(quantum)
-        # The route (one-launch fused step / launch per phase) is a collective decision: the two routes apply the same
-        # statistics but round the codebook's last bits differently, and a rank with an oddly aligned or empty shard
-        # must not part ways with the others.
+        # The route (one-launch fused step / launch per phase) is a collective decision: a rank with an oddly aligned or
+        # empty shard must not part ways with the others.
         # (every rank enters the collective whatever its own flag says: a debug toggle on one rank must not leave the others
         # waiting inside an all-reduce the rest skipped)
         self._unfused_now = self.unfused
         if _world(group) > 1:
+            # launch-per-phase everywhere only where the ranks DISAGREE (some could take the one-launch 10 x 10 step, some
+            # not -- an oddly aligned or empty shard), or where a rank asked for it.  Where no rank can take the fused step
+            # (cell SOMs, other grids) nothing is forced: the library picks among the wide one-launch step and the
+            # launch-per-phase route per step, which give the same bits (tests/test_gpu_schedule.py,
+            # test_wide_bmu_only_steps_match_the_oracle_per_step).
             mine = (not self.unfused) and self._sd.batch_train_fused_route(x, xdim, ydim, st.schedule)
-            self._unfused_now = not _all_ranks_ok(mine, group)
+            flags = torch.tensor([1 if mine else 0, 0 if mine else -1, 0 if self.unfused else 1], dtype=torch.int32,
+                                 device=_collective_device(group))
+            dist.all_reduce(flags, op=dist.ReduceOp.MIN, group=group)
+            all_fused, any_fused, nobody_asked = bool(flags[0].item()), flags[1].item() == 0, bool(flags[2].item())
+            self._unfused_now = (not nobody_asked) or (any_fused and not all_fused)
 
     def steps(self, x, g0: int, g1: int, total: int, alpha_range, radius_range, comm=None) -> None:
         self._sd.batch_train_steps(x, self._state, g0, g1, total, alpha_range, radius_range,
@@ -172,7 +180,16 @@ class BatchSOMTrainer:
             comm = kern.exchange(self.group) if hasattr(kern, "exchange") else None
             if comm is not None:     # step launches and their all-reduces back to back on one stream, one call
                 kern.steps(x_local, 0, total, total, self.alpha_range, self.radius_range, comm=comm)
-            else:
+                if not _exchange_completed(comm, self.group):
+                    # A peer did not arrive at an exchange in time (the one-shot peer-to-peer route bounds its wait: the late
+                    # rank's statistics turned to NaN there and that step was dropped on that rank only -- the replicas have
+                    # parted).  Agreed by all ranks: the route is retired and the pass runs again from W_0 (``w`` still holds
+                    # it: finish has not run) with the statistics all-reduced through torch.distributed.
+                    _retire_native_exchange(self.group, "a peer was late for an exchange")
+                    kern.begin(x_local, w, self.xdim, self.ydim, self.schedule, group=self.group, quantum=quantum) \
+                        if isinstance(kern, HipKernels) else kern.begin(x_local, w, self.xdim, self.ydim, self.schedule, quantum=quantum)
+                    comm = None
+            if comm is None:
                 for g in range(total):
                     kern.steps(x_local, g, g + 1, total, self.alpha_range, self.radius_range)
                     all_reduce_(kern.ring(g), group=self.group)
@@ -227,6 +244,34 @@ def _exchange_verified(comm, group) -> bool:
     except Exception:      # noqa: BLE001 -- agreed below
         ok = False
     return _all_ranks_ok(ok, group)
+
+
+def _exchange_completed(comm, group) -> bool:
+    """After a run of steps through an in-library communicator: did every exchange complete on every rank?  Only the
+    peer-to-peer route can say no (``error_epoch``: the first exchange a peer missed); the verdict is agreed (MIN)."""
+    ok = True
+    if hasattr(comm, "error_epoch"):
+        try:
+            torch.cuda.synchronize()
+            ok = comm.error_epoch() == 0
+        except Exception:      # noqa: BLE001 -- agreed below
+            ok = False
+    return _all_ranks_ok(ok, group)
+
+
+def _retire_native_exchange(group, why: str) -> None:
+    """Drops the group's in-library communicator for the rest of the process (every rank calls this at the same point)."""
+    import warnings
+    key = _group_key(group)
+    comm = _native_comms.get(key)
+    if comm is not None:
+        try:
+            comm.close()
+        except Exception:      # noqa: BLE001
+            pass
+    _native_comms[key] = None
+    if dist.get_rank(group) == 0:
+        warnings.warn("in-library exchange retired (%s): all-reducing through torch.distributed" % why)
 
 
 def _group_key(group):

@@ -231,6 +231,10 @@ int pxsom_batch_train_finish(const double *wbuf_dev, const double *stats_ring_de
  * over the whole run, g in [0, num_passes * steps_per_pass); the call with g_begin == 0 must come first on a workspace
  * (it clears ring[0] and, for shapes outside the fused kernel with steps wider than one phase, gathers the rows into
  * step order inside the workspace -- one extra read + write of the matrix per run).  Every rank runs the same steps.
+ * The WORKSPACE IS RUN STATE, like wbuf and the ring: the g_begin == 0 call also leaves the run's centring vector (the
+ * mean of W_0 per channel and its norm, read by every later step's filter) in it, so the calls of one run must be given
+ * the same, untouched workspace; a later call on a fresh or foreign workspace would centre on whatever bytes it finds
+ * (results stay exact -- every label is settled against the binary64 codebook -- but most rows would be listed).
  * Oracle of record: oracle/pxsom_oracle.c orc_som_batch_sched.  Reference call replaced: cluster_helpers.py:98-116. */
 /* Reproducible statistics for binary64 rows (sum_quantum > 0; ignored for binary32 / binary16 rows).  The per-BMU sums
  * of a step are floating-point additions in whatever order the workgroups and ranks deliver them; for binary64 rows that
