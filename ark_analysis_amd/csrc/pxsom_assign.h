@@ -193,6 +193,10 @@ void launch_filter_fast_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws,
                             double *stats, const double *w, hipStream_t st, bool fixed = false);
 template <typename T>
 bool filter_fast_path(const T *x, int64_t n, int c, int64_t ldx, const Layout &L);
+// labels only on binary64 rows of the fast path's shapes, self-contained (pxsom_assign_filter_acc.hip / pxsom_assign_onepass.h)
+bool onepass_labels_route(size_t elem_bytes);
+void launch_onepass_labels(const double *x, int64_t n, int c, int64_t ldx, const Layout &L, int32_t *labels, const double *w,
+                           hipStream_t st);
 // fused mini-batch step (pxsom_batch_step.hip): which shapes it covers, and its launch
 template <typename T>
 bool step_fused_shape(const T *x, int64_t n, int c, int64_t ldx, int xdim, int ydim, int64_t group_stride = 0);

@@ -670,6 +670,26 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
         }
         return PXSOM_OK;
     }
+    if constexpr (sizeof(T) == 8) {
+        // binary64 rows of the register-resident shapes (what the drop-in classes label): one self-contained launch of the
+        // two-tile kernel -- prepares the codebook itself and settles its listed rows inside (round 5: no spills, unlike
+        // bmu_filter_fast<double>); the workspace only records that no row was listed
+        if (!prepared && !stats && onepass_labels_route(sizeof(T)) && filter_fast_path<T>(x, n, c, ldx, L)) {
+            PXSOM_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(unsigned), st));
+            pxsom::Prof *prof1 = pxsom::current_prof();
+            pxsom::prof_mark(prof1, st, true, n);
+            launch_onepass_labels(x, n, c, ldx, L, labels, w, st);
+            pxsom::prof_mark(prof1, st, false, n);
+            PXSOM_LAUNCH_CHECK("bmu_onepass_kernel");
+            if (dist) {
+                int dgrid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)pxsom::device_cu_count() * 8);
+                if (dgrid < 1) dgrid = 1;
+                hipLaunchKernelGGL(bmu_dist_kernel<T>, dim3(dgrid), dim3(256), 0, st, x, n, c, ldx, w, labels, dist);
+                PXSOM_LAUNCH_CHECK("bmu_dist_kernel");
+            }
+            return PXSOM_OK;
+        }
+    }
     if (!prepared && !stats) {  // prepared: pxsom_batch_update_prepare did this; stats: the accumulating filter
                                  // prepares the codebook inside its own launch
         const size_t stage_bytes = (size_t)k * c * sizeof(double);

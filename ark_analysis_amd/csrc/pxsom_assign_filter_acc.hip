@@ -50,31 +50,32 @@ void launch_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layou
                        fix_rows_log2);
 }
 
-// the four-waves-per-SIMD one-pass kernel (pxsom_assign_onepass.h): fixed-point tables, binary32 / binary16 rows, C <= 24
-template <typename T, int CPL>
+// the one-pass kernel with two tiles per trip (pxsom_assign_onepass.h): fixed-point tables
+template <typename T, int CPL, bool TABLE = true>
 void launch_onepass(const T *x, int64_t n, int c, int64_t ldx, const Layout &L, int32_t *labels, double *stats, const double *w,
                     hipStream_t st)
 {
-    auto kern = bmu_onepass_kernel<T, CPL>;
-    const size_t lds = onepass_lds_bytes(L.k, c);
+    constexpr int kThreads = sizeof(T) == 8 ? 512 : kOneThreads, kWpe = sizeof(T) == 8 ? 2 : PXSOM_ONE_WPE, kWaves = kThreads / 64;
+    auto kern = bmu_onepass_kernel<T, CPL, kThreads, kWpe, TABLE>;
+    const size_t lds = onepass_lds_bytes(L.k, c, kThreads);
     static pxsom::PerDevice<int> bpc_on;   // (one per instantiation)
     int &bpc = bpc_on.here();
     if (bpc == 0) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         int nbk = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, kern, kOneThreads, lds) != hipSuccess || nbk < 1) nbk = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, kern, kThreads, lds) != hipSuccess || nbk < 1) nbk = 1;
         bpc = nbk > 4 ? 4 : nbk;
     }
     const int64_t nunits = (n + 31) / 32;
     // at least two 32-row units per wave where the launch is small (fewer workgroups pay the prologue and the flush)
-    int grid = (int)std::min<int64_t>((nunits + 2 * kOneWaves - 1) / (2 * kOneWaves), (int64_t)pxsom::device_cu_count() * bpc);
+    int grid = (int)std::min<int64_t>((nunits + 2 * kWaves - 1) / (2 * kWaves), (int64_t)pxsom::device_cu_count() * bpc);
     if (grid < 1) grid = 1;
     int fix_rows_log2 = 0;
     {
-        const int64_t rows_wg = ((nunits + (int64_t)grid * kOneWaves - 1) / ((int64_t)grid * kOneWaves)) * (32 * kOneWaves) + 32;
+        const int64_t rows_wg = ((nunits + (int64_t)grid * kWaves - 1) / ((int64_t)grid * kWaves)) * (32 * kWaves) + 32;
         while (((int64_t)1 << fix_rows_log2) < rows_wg) fix_rows_log2++;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kOneThreads), lds, st, x, n, c, ldx, labels, L.k, stats, w, L.idx_bits, L.node_bits,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, x, n, c, ldx, labels, L.k, stats, w, L.idx_bits, L.node_bits,
                        fix_rows_log2);
 }
 
@@ -88,6 +89,16 @@ bool onepass_enabled()
     return on;
 }
 
+// binary64 rows: on unless PXSOM_ONEPASS_F64=0 (same-box A/B against bmu_filter_fast<double>)
+bool onepass_f64_enabled()
+{
+    static const bool on = [] {
+        const char *e = std::getenv("PXSOM_ONEPASS_F64");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 }  // namespace
 
 template <typename T>
@@ -97,16 +108,21 @@ void launch_filter_fast_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws,
 #define PXSOM_ACC(CPL)                                                            \
     (fixed ? launch_acc<T, CPL, true>(x, n, c, ldx, ws, L, labels, stats, w, st)  \
            : launch_acc<T, CPL, false>(x, n, c, ldx, ws, L, labels, stats, w, st))
-    if constexpr (sizeof(T) <= 4) {
-        if (fixed && L.cpl <= 6 && onepass_enabled()) {
-            if (L.cpl == 6)
-                launch_onepass<T, 6>(x, n, c, ldx, L, labels, stats, w, st);
-            else if (L.cpl == 4)
-                launch_onepass<T, 4>(x, n, c, ldx, L, labels, stats, w, st);
-            else
-                launch_onepass<T, 2>(x, n, c, ldx, L, labels, stats, w, st);
-            return;
+    // binary64 rows (what the drop-in classes hold): the two-tile kernel is the one without spills; binary32 / binary16: opt-in
+    if (fixed && (sizeof(T) == 8 ? onepass_f64_enabled() : (L.cpl <= 6 && onepass_enabled()))) {
+        if constexpr (sizeof(T) == 8) {
+            if (L.cpl == 8) {
+                launch_onepass<T, 8>(x, n, c, ldx, L, labels, stats, w, st);
+                return;
+            }
         }
+        if (L.cpl == 6)
+            launch_onepass<T, 6>(x, n, c, ldx, L, labels, stats, w, st);
+        else if (L.cpl == 4)
+            launch_onepass<T, 4>(x, n, c, ldx, L, labels, stats, w, st);
+        else
+            launch_onepass<T, 2>(x, n, c, ldx, L, labels, stats, w, st);
+        return;
     }
     if (L.cpl == 6)
         PXSOM_ACC(6);
@@ -117,6 +133,22 @@ void launch_filter_fast_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws,
     else
         PXSOM_ACC(2);
 #undef PXSOM_ACC
+}
+
+// pxsom_assign on binary64 rows of the register-resident shapes: labels only, in the two-tile kernel (no workspace, no list,
+// no exact launch behind it; bmu_filter_fast<double, ACC = false> keeps four tiles of binary64 rows in flight and spills).
+bool onepass_labels_route(size_t elem_bytes) { return elem_bytes == 8 && onepass_f64_enabled(); }
+void launch_onepass_labels(const double *x, int64_t n, int c, int64_t ldx, const Layout &L, int32_t *labels, const double *w,
+                           hipStream_t st)
+{
+    if (L.cpl == 8)
+        launch_onepass<double, 8, false>(x, n, c, ldx, L, labels, nullptr, w, st);
+    else if (L.cpl == 6)
+        launch_onepass<double, 6, false>(x, n, c, ldx, L, labels, nullptr, w, st);
+    else if (L.cpl == 4)
+        launch_onepass<double, 4, false>(x, n, c, ldx, L, labels, nullptr, w, st);
+    else
+        launch_onepass<double, 2, false>(x, n, c, ldx, L, labels, nullptr, w, st);
 }
 
 template void launch_filter_fast_acc<float>(const float *, int64_t, int, int64_t, char *, const Layout &, int32_t *,

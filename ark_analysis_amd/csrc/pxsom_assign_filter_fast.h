@@ -127,7 +127,8 @@ __device__ __forceinline__ FixPoint make_fixpoint(int scale_exp, int rows_log2)
     return f;
 }
 
-template <typename T, bool FIX = false>
+// (ADD = false: the label only -- the labels-only mode of the two-tile kernel, pxsom_assign_onepass.h)
+template <typename T, bool FIX = false, bool ADD = true>
 __device__ __forceinline__ void exact_row_accumulate(const T *__restrict__ x, int64_t row, int c, int64_t ldx,
                                                      const double *wt, int k, int32_t *__restrict__ labels,
                                                      double *ls, int lane, const FixPoint *fx = nullptr,
@@ -182,7 +183,7 @@ __device__ __forceinline__ void exact_row_accumulate(const T *__restrict__ x, in
     const double smin = pxsom::wave_min_f64(best);
     const int win = (int)pxsom::wave_min_u32(best == smin ? (unsigned)bestk : 0xffffffffu);
     if (lane == 0) labels[row] = win == 0x7fffffff ? 0 : win + 1;   // no finite distance (NaN row): label 0
-    if (win != 0x7fffffff) {
+    if (ADD && win != 0x7fffffff) {
         if constexpr (FIX) {
             // a listed row may hold values the table's format cannot (it was listed for its size, perhaps): such a row
             // goes straight to the global binary64 statistics

@@ -1,19 +1,24 @@
-// pxsom_assign_onepass.h -- labels + per-cluster fixed-point tables in one pass (pxsom_assign_sums / pxsom_assign_means),
-// the kernel built for FOUR waves per SIMD (round 5).  Same arithmetic contract as bmu_filter_fast<ACC, FIX>
-// (pxsom_assign_filter_fast.h): two-stage register-resident search on v_mfma_f32_16x16x32_f16, rows the first stage cannot
-// vouch for searched in full from a queue of their wave, rows the full search cannot vouch for settled in the oracle's
-// binary64 arithmetic inside the launch, every vouched row added to a 64-bit fixed-point table in LDS.  What differs is the
-// shape, chosen so that the streaming trip fits 128 VGPRs (bmu_filter_fast needs 251: two waves per SIMD, issue-bound at
-// ~55 % VALU utilisation, profiles/r04/pmc_issue.txt):
-//   * two 16-row tiles per trip instead of four: row sets, fp16 operands, accumulators and the top-2 state halve;
-//   * the bias -|W'|^2 / 2 rides in the MFMA's spare k-slots (C <= 24 leaves slots 6, 7 of every lane group free): three
-//     binary16 parts of the bias against constant multipliers on the row side, the accumulator starts from the inline
-//     constant 0 and the 28 bias registers are gone; a fourth spare slot masks duplicate nodes (-65504 x 65504);
-//   * workgroups of 512 threads, two per CU (16 waves per CU): one table per eight waves;
+// pxsom_assign_onepass.h -- the register-resident BMU search with TWO 16-row tiles per trip (round 5): labels + per-cluster
+// fixed-point tables in one pass (pxsom_assign_sums / pxsom_assign_means), or labels alone (pxsom_assign on binary64 rows).
+// Same arithmetic contract as bmu_filter_fast (pxsom_assign_filter_fast.h): two-stage search on v_mfma_f32_16x16x32_f16, rows the
+// first stage cannot vouch for searched in full from a queue of their wave, rows the full search cannot vouch for settled in
+// the oracle's binary64 arithmetic inside the launch, every vouched row added to a 64-bit fixed-point table in LDS.  What
+// differs is the shape:
+//   * two tiles per trip instead of four: row sets, fp16 operands, accumulators and the top-2 state halve;
+//   * C <= 24: the bias -|W'|^2 / 2 rides in the MFMA's spare k-slots 6, 7 of every lane group -- three binary16 parts of the
+//     bias against constant multipliers on the row side, the accumulator starts from the inline constant 0 and the 28 bias
+//     registers are gone; a fourth spare slot masks duplicate nodes (-65504 x 65504).  C = 26..32: bias registers as before;
 //   * with two tiles the transposing merge leaves tile 0's rows in the even lane rows and tile 1's in the odd ones, twice over:
-//     the labels a lane needs for its table adds come from ONE v_permlane16_swap instead of four ds_bpermute behind the
-//     LDS unit's atomics.
-// Covers binary32 / binary16 rows, K in (96, 100], even C <= 24; everything else stays on bmu_filter_fast.
+//     the labels a lane needs for its table adds come from ONE v_permlane16_swap (no LDS round trip behind the atomics);
+//   * self-contained: every workgroup prepares the codebook itself, no workspace, no list, no launch behind it.
+// Where it is used (pxsom_assign_filter_acc.hip, pxsom_assign.hip) and what was measured (profiles/r05/):
+//   * BINARY64 ROWS -- what the drop-in classes hold -- by default (512 threads, 256 VGPRs, no spills: bmu_filter_fast keeps four
+//     tiles of binary64 rows in flight and spills 28 - 138 VGPRs).  4 M x 22 rows: labels + mean table 0.285 -> 0.183 ms,
+//     labels 0.220 -> 0.167 ms = 4.4 TB/s of rows (f64_assign_probe.txt); PXSOM_ONEPASS_F64=0: the old kernels (same-box A/B).
+//   * binary32 / binary16 rows, C <= 24: opt-in (PXSOM_ONEPASS=1; 768 threads x 1 per CU, three waves per SIMD at 168 VGPRs) --
+//     built to test whether a third wave per SIMD lifts the issue-bound one-pass kernel: it does not, 0.297 ms against 0.262
+//     for bmu_filter_fast<ACC, FIX> on the bench matrix; the timing builds below (PXSOM_ONE_ABL) put the table adds at 0.08 ms
+//     of it, a third of that LDS bank conflicts (onepass_three_waves_ablation.txt).
 #pragma once
 #include "pxsom_assign_filter_fast.h"
 
@@ -30,29 +35,34 @@ namespace {
 #define PXSOM_ONE_WPE 3
 #endif
 constexpr int kOneThreads = PXSOM_ONE_THREADS;   // 768 x 1 per CU: three waves per SIMD (168 VGPRs); 512 x 2: four (128)
-constexpr int kOneWaves = kOneThreads / 64;
 constexpr int kOneTiles = 2;          // 16-row tiles per trip
 constexpr int kOneNB = 7;             // node blocks (K in (96, 100])
 constexpr unsigned kOneS1Queue = 128; // rows a wave can hold back for the full search
 constexpr unsigned kOneAmbQueue = 256;
 
 // dynamic LDS of one workgroup (bytes) at k nodes, c channels
-__host__ __device__ inline size_t onepass_lds_bytes(int k, int c)
+__host__ __device__ inline size_t onepass_lds_bytes(int k, int c, int threads)
 {
+    const int kOneWaves = threads / 64;
     const size_t table = (((size_t)(k + 1) * (acc_stride(c) + 1) + 1) & ~(size_t)1) * sizeof(double);
     return table + (size_t)k * c * sizeof(double) + (size_t)kOneNB * 2 * 64 * sizeof(half8) + (size_t)kOneNB * 64 * sizeof(f32x4) +
            kHdrBytes + kOneAmbQueue * sizeof(int64_t) + 16 + (size_t)kOneWaves * kOneS1Queue * sizeof(int64_t);
 }
 
-template <typename T, int CPL>
-__global__ __launch_bounds__(kOneThreads, PXSOM_ONE_WPE) void bmu_onepass_kernel(const T *__restrict__ x, int64_t n, int c, int64_t ldx,
+// THREADS x WPE: 768 x 3 (one workgroup per CU, three waves per SIMD, 168 VGPRs) for binary32 / binary16 rows; 512 x 2 (256 VGPRs)
+// for binary64 rows, whose row sets take twice the registers -- for them this kernel is the spill-free one (bmu_filter_fast
+// keeps four tiles of binary64 rows in flight: 28 - 138 spilled VGPRs).
+// TABLE = false: labels only (pxsom_assign on binary64 rows): no table, no flush, listed rows settled for their label alone.
+template <typename T, int CPL, int THREADS, int WPE, bool TABLE = true>
+__global__ __launch_bounds__(THREADS, WPE) void bmu_onepass_kernel(const T *__restrict__ x, int64_t n, int c, int64_t ldx,
                                                                      int32_t *__restrict__ labels, int k,
                                                                      double *__restrict__ stats,
                                                                      const double *__restrict__ wcodes, int idx_bits,
                                                                      int node_bits, int fix_rows_log2)
 {
-    static_assert(CPL == 2 || CPL == 4 || CPL == 6, "slots 6, 7 of a lane group must be free for the bias");
-    static_assert(sizeof(T) <= 4, "binary32 / binary16 rows");
+    // FOLD: the bias rides in the spare k-slots 6, 7 of every lane group (C <= 24); C = 26..32 fills the slots: bias registers
+    constexpr bool FOLD = CPL <= 6;
+    constexpr int kOneThreads = THREADS, kOneWaves = THREADS / 64;
     constexpr int NB = kOneNB, NP = CPL / 2;
     extern __shared__ __attribute__((aligned(16))) char one_smem[];
     double *ls = reinterpret_cast<double *>(one_smem);
@@ -101,7 +111,7 @@ __global__ __launch_bounds__(kOneThreads, PXSOM_ONE_WPE) void bmu_onepass_kernel
         // bits -- what is lost is below 2^-33 |bias| + 2^-39); a masked node (duplicate of an earlier one, or past k) gets
         // -65504 against the multiplier 65504: -4.29e9, under every score a row inside the filter's range can have
         // (>= -(|X'| + |W'|)^2 / 2 > -1.9e9)
-        for (int f = tid; f < NB * 64; f += kOneThreads) {
+        for (int f = tid; f < (FOLD ? NB * 64 : 0); f += kOneThreads) {
             const int lane = f & 63, b = f >> 6, q = lane >> 4, m = lane & 15;
             const float bv = bias_l[b * 64 + ((m >> 2) << 4)][m & 3];
             _Float16 s6 = (_Float16)0, s7 = (_Float16)0;
@@ -124,13 +134,15 @@ __global__ __launch_bounds__(kOneThreads, PXSOM_ONE_WPE) void bmu_onepass_kernel
             fr[6] = s6;
             fr[7] = s7;
         }
-        for (int e = tid; e < (k + 1) * (cs + 1); e += kOneThreads) ls[e] = 0.0;
+        if constexpr (TABLE)
+            for (int e = tid; e < (k + 1) * (cs + 1); e += kOneThreads) ls[e] = 0.0;
         __syncthreads();
     }
     constexpr unsigned idx_mask = 127u, node_mask = 127u;
     const float scale = hdr->scale, wn_max = hdr->wn_max, tol_abs = hdr->tol_abs, x_limit = hdr->x_limit;
     // the bias goes through the MFMA's accumulation as three more products: four more roundings charged to both tolerances
-    const float tol_rel = hdr->tol_rel + 2.5f * 4.f * 5.9604645e-8f, tol_rel_coarse = hdr->tol_rel_coarse + 2.5f * 4.f * 5.9604645e-8f;
+    const float tol_fold = FOLD ? 2.5f * 4.f * 5.9604645e-8f : 0.f;
+    const float tol_rel = hdr->tol_rel + tol_fold, tol_rel_coarse = hdr->tol_rel_coarse + tol_fold;
     const bool force_exact = hdr->force_exact != 0;
     const FixPoint fx = make_fixpoint(hdr->fix_exp, fix_rows_log2 & 255);
     unsigned long long *lu = reinterpret_cast<unsigned long long *>(ls);
@@ -143,8 +155,12 @@ __global__ __launch_bounds__(kOneThreads, PXSOM_ONE_WPE) void bmu_onepass_kernel
     const int64_t nunits = (n + 31) / 32;
 
     half8 wreg[NB];
+    f32x4 breg[FOLD ? 1 : NB];
 #pragma unroll
-    for (int b = 0; b < NB; b++) wreg[b] = frag_l[(b * 2) * 64 + lane];
+    for (int b = 0; b < NB; b++) {
+        wreg[b] = frag_l[(b * 2) * 64 + lane];
+        if constexpr (!FOLD) breg[b] = bias_l[b * 64 + lane];
+    }
     const half8 *wlow = frag_l;
     // the row side of the bias slots: pair 3 of every fp16 operand
     half2_t bias_mul;
@@ -182,10 +198,15 @@ __global__ __launch_bounds__(kOneThreads, PXSOM_ONE_WPE) void bmu_onepass_kernel
                     const half2_t h = __builtin_bit_cast(half2_t, v);
                     raw[t][p].x = h[0];
                     raw[t][p].y = h[1];
-                } else {
+                } else if constexpr (sizeof(T) == 4) {
                     const uint2v v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)loff[p], soff, 0);
                     raw[t][p].x = __uint_as_float(v[0]);
                     raw[t][p].y = __uint_as_float(v[1]);
+                } else {
+                    typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+                    const uint4v v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)loff[p], soff, 0);
+                    raw[t][p].x = __longlong_as_double(((long long)v[1] << 32) | v[0]);
+                    raw[t][p].y = __longlong_as_double(((long long)v[3] << 32) | v[2]);
                 }
             }
         }
@@ -201,15 +222,21 @@ __global__ __launch_bounds__(kOneThreads, PXSOM_ONE_WPE) void bmu_onepass_kernel
         constexpr bool FULL = decltype(mode_tag)::value != 0;
         half8 bh[kOneTiles];
         float ss[kOneTiles];
+        // x' = fl(x * scale - mu_s): one rounding (binary64 rows: formed in binary64, then rounded once more)
         auto centred = [&](int t, int p, float &xs0, float &xs1) {
-            xs0 = fmaf((float)raw[t][p].x, scale, -mus[p][0]);
-            xs1 = fmaf((float)raw[t][p].y, scale, -mus[p][1]);
+            if constexpr (sizeof(T) == 8) {
+                xs0 = (float)__builtin_fma((double)raw[t][p].x, (double)scale, -(double)mus[p][0]);
+                xs1 = (float)__builtin_fma((double)raw[t][p].y, (double)scale, -(double)mus[p][1]);
+            } else {
+                xs0 = fmaf((float)raw[t][p].x, scale, -mus[p][0]);
+                xs1 = fmaf((float)raw[t][p].y, scale, -mus[p][1]);
+            }
         };
 #pragma unroll
         for (int t = 0; t < kOneTiles; t++) {
             float acc2 = 0.f;
 #pragma unroll
-            for (int p = 0; p < 3; p++) {
+            for (int p = 0; p < (FOLD ? 3 : 4); p++) {
                 half2_t h2 = {(_Float16)0, (_Float16)0};
                 if (p < NP) {
                     float xs0, xs1;
@@ -221,8 +248,10 @@ __global__ __launch_bounds__(kOneThreads, PXSOM_ONE_WPE) void bmu_onepass_kernel
                 bh[t][2 * p] = h2[0];
                 bh[t][2 * p + 1] = h2[1];
             }
-            bh[t][6] = bias_mul[0];
-            bh[t][7] = bias_mul[1];
+            if constexpr (FOLD) {
+                bh[t][6] = bias_mul[0];
+                bh[t][7] = bias_mul[1];
+            }
             ss[t] = acc2;
         }
         if constexpr (!FULL) {
@@ -267,7 +296,7 @@ __global__ __launch_bounds__(kOneThreads, PXSOM_ONE_WPE) void bmu_onepass_kernel
                 }
 #pragma unroll
                 for (int b = 0; b < NB; b++) {
-                    f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b], bh[t], zero4, 0, 0, 0);
+                    f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b], bh[t], FOLD ? zero4 : breg[FOLD ? 0 : b], 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b], bl, acc, 0, 0, 0);   // (bl's bias slots are zero)
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlow[(b * 2 + 1) * 64 + lane], bh[t], acc, 0, 0, 0);   // (Wl's too)
                     absorb(m1[t], m2[t], acc, b);
@@ -278,7 +307,8 @@ __global__ __launch_bounds__(kOneThreads, PXSOM_ONE_WPE) void bmu_onepass_kernel
             for (int b = 0; b < NB; b++) {
                 f32x4 acc[kOneTiles];
 #pragma unroll
-                for (int t = 0; t < kOneTiles; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b], bh[t], zero4, 0, 0, 0);
+                for (int t = 0; t < kOneTiles; t++)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b], bh[t], FOLD ? zero4 : breg[FOLD ? 0 : b], 0, 0, 0);
 #pragma unroll
                 for (int t = 0; t < kOneTiles; t++) absorb(m1[t], m2[t], acc[t], b);
             }
@@ -336,7 +366,7 @@ __global__ __launch_bounds__(kOneThreads, PXSOM_ONE_WPE) void bmu_onepass_kernel
 #if PXSOM_ONE_ABL & 1
         if (real == 0x7fffffffu) lu[real] = (unsigned long long)raw[0][0].x;   // (timing build: no table adds)
 #else
-        {
+        if constexpr (TABLE) {
             // lane (q, pix) holds channels q CPL.. of rows (t, pix), t = 0, 1; tile t's labels sit in the lane rows of its parity:
             // one swap of the value with itself hands every lane {even row's, odd row's} = {tile 0's, tile 1's}.  Unsure rows,
             // rows another trip owns and clamped channel slots go to the spare table row k: no branch.
@@ -391,7 +421,7 @@ __global__ __launch_bounds__(kOneThreads, PXSOM_ONE_WPE) void bmu_onepass_kernel
                 const int src = __builtin_ctzll(late);
                 late &= late - 1;
                 const int64_t rsrc = s1_q[s1_n - full_rows + (unsigned)src];   // (lanes q < 2: lane == slot)
-                exact_row_accumulate<T, true>(x, rsrc, c, ldx, wt, k, labels, ls, lane, &fx, stats, cs, k, 1);
+                exact_row_accumulate<T, true, TABLE>(x, rsrc, c, ldx, wt, k, labels, ls, lane, &fx, stats, cs, k, 1);
             }
         }
     };
@@ -435,10 +465,10 @@ __global__ __launch_bounds__(kOneThreads, PXSOM_ONE_WPE) void bmu_onepass_kernel
     {
         const unsigned queued = *amb_n < kOneAmbQueue ? *amb_n : kOneAmbQueue;   // rows past the end were settled at once
         for (unsigned i = (unsigned)(tid >> 6); i < queued; i += kOneWaves)
-            exact_row_accumulate<T, true>(x, amb_q[i], c, ldx, wt, k, labels, ls, lane, &fx, stats, cs, k, 1);
+            exact_row_accumulate<T, true, TABLE>(x, amb_q[i], c, ldx, wt, k, labels, ls, lane, &fx, stats, cs, k, 1);
     }
     __syncthreads();
-    {
+    if constexpr (TABLE) {
         int node = tid / c, j = tid - node * c;   // element e <-> (node, channel), no division per element
         const int dnode = kOneThreads / c, dj = kOneThreads % c;
         for (int e = tid; e < k * c; e += kOneThreads) {

@@ -380,6 +380,7 @@ def main():
     flops_assign = 2.0 * K * C                         # algorithmic flops per row (x . W^T)
     achieved_tf = flops_assign * n_all / (kern_avg_ms * 1e-3) / 1e12 if kern_launches else 0.0
     mfma_bound = K > 128                               # register-resident filter: HBM; streamed K=400 filter: matrix + VALU pipes
+    fast_route = C % 2 == 0 and C <= 32 and 96 < K <= 100   # the register-resident kernels' shapes (csrc/pxsom_assign_filter.hip filter_fast_path)
     out = {
         "metric": "M pixels/sec SOM train+assign, 22-ch 1024^2 FOVs, 100-node SOM",
         "value": round(value, 1), "unit": "Mpx/s", "n_gpus": world, "steps": args.steps,
@@ -411,7 +412,8 @@ def main():
                       "rows_per_launch": n_all, "launches_timed": kern_launches,
                       "note": "K = 400 nodes: 400 scores per row put the streamed filter on the matrix + VALU pipes, not on HBM"}
                      if mfma_bound else
-                     {"kernel": "bmu_filter_kernel" if (not args.one_pass) else
+                     {"kernel": ("bmu_filter_fast (labels only; the K8 kernel follows)" if fast_route else "bmu_filter_kernel (streamed filter; exact rows and the K8 kernel follow)")
+                      if (not args.one_pass) or not fast_route else
                       "bmu_filter_fast<ACC> (labels + per-cluster table in one pass; replaces the filter and the K8 kernel)",
                       "bound": "hbm", "achieved": round(achieved, 1),
                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -419,7 +421,9 @@ def main():
                       "pixels_per_launch": n_all, "launches_timed": kern_launches}),
         "roofline_step": {"bound": "hbm", "bytes_per_pixel": round(bytes_step, 2), "achieved": round(step_gbs, 1),
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_gbs / HBM_PEAK_GBS, 4),
-                          "note": "whole step per GPU: SURVEY 8(d) algorithmic bytes / ms_per_step"},
+                          "note": "whole step per GPU: SURVEY 8(d) algorithmic bytes / ms_per_step; the training subset (%.0f MB) is the same "
+                                  "rows in every timed repeat and fits the 256 MB MALL -- its steps are latency chains, not bandwidth "
+                                  "(profiles/r04/assign_sums_size_probe.txt)" % (n_train * C * esize / 1e6)},
     }
 
     # ---- HBM traffic and matrix-pipe utilisation of the filter kernel: PMC passes of a short run of this script
