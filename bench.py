@@ -349,17 +349,26 @@ def main():
             oks = [None] * world
             dist.all_gather_object(oks, bool(ok))
             if all(oks):
-                for _ in range(5):
-                    pc.allreduce_sum(probe)
+                # ONE exchange first, checked on every rank: peer mappings that do not work across devices show up as a
+                # bounded wait (4 s) + NaN there, and the timed run of 55 more such waits is not started
+                pc.allreduce_sum(probe)
                 fence()
-                tp = time.perf_counter()
-                for _ in range(reps):
-                    pc.allreduce_sum(probe)
-                fence()
-                ex2 = torch.tensor([(time.perf_counter() - tp) / reps * 1e6], dtype=torch.float64, device="cpu" if dry else dev)
-                all_reduce_(ex2, op=dist.ReduceOp.MAX)
-                if pc.error_epoch() == 0:
-                    p2p_us = round(float(ex2.item()), 2)
+                firsts = [None] * world
+                dist.all_gather_object(firsts, bool(pc.error_epoch() == 0 and torch.isfinite(probe).all().item()))
+                probe.zero_()
+                if all(firsts):
+                    for _ in range(4):
+                        pc.allreduce_sum(probe)
+                    fence()
+                    tp = time.perf_counter()
+                    for _ in range(reps):
+                        pc.allreduce_sum(probe)
+                    fence()
+                    ex2 = torch.tensor([(time.perf_counter() - tp) / reps * 1e6], dtype=torch.float64, device="cpu" if dry else dev)
+                    all_reduce_(ex2, op=dist.ReduceOp.MAX)
+                    if pc.error_epoch() == 0:
+                        p2p_us = round(float(ex2.item()), 2)
+                    probe.zero_()
             if pc is not None:
                 pc.close()
         per_rank["exchange_us_per_step_p2p"] = p2p_us
