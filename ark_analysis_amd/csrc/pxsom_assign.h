@@ -44,9 +44,16 @@ static_assert(sizeof(AssignHdr) <= kHdrBytes, "workspace header");
 // (oracle/pxsom_oracle.c, the same statements) and every kernel return the same bits whatever maths library either side
 // links.  Every intermediate is held at or above 2^-200: anything below 2^-54 leaves the gain at exactly 1 (the node then IS
 // the window mean, orc_batch_update), so the floor changes no result and no product ever reaches the subnormal range.
-__host__ __device__ inline double batch_gain(double den, double q)
+// `sat` (batch_gain_saturation(q), formed once per step on the host): every den >= sat has gain exactly 1 -- the loop would
+// multiply by a square of q that is itself at or below 2^-60 -- so the loop is skipped for the wide windows of a pass's first steps
+// (18 - 20 dependent trips per node there: 6.5 us of a 0.34 ms pass, profiles/r05/gain_cost.txt).  Result-neutral by construction.
+__host__ __device__ inline double batch_gain(double den, double q, double sat)
 {
 #pragma clang fp contract(off)
+#ifdef PXSOM_GAIN_TIMING_EXPM1   // (timing build only: what the chain of products costs a pass against one library call)
+    return -expm1(den * log(q));
+#endif
+    if (den >= sat) return 1.0;
     const double tiny = 0x1p-200;
     unsigned long long m = (unsigned long long)den;
     double p = 1.0, b = q;
@@ -61,6 +68,21 @@ __host__ __device__ inline double batch_gain(double den, double q)
     return 1.0 - p;
 }
 
+// The smallest power of two D whose square-chain value q^D (the loop's own b) is at or below 2^-60, or 2^62 when there is none
+// (q >= 1): a den >= D has a set bit at or above log2 D, the loop multiplies p <= 1 by that b or a smaller one, and 1 - p is 1.
+__host__ __device__ inline double batch_gain_saturation(double q)
+{
+#pragma clang fp contract(off)
+    const double tiny = 0x1p-200;
+    double b = q, d = 1.0;
+    while (b > 0x1p-60 && d < 0x1p62) {
+        b = b * b;
+        b = b < tiny ? tiny : b;
+        d = d * 2.0;
+    }
+    return b <= 0x1p-60 ? d : 0x1p62;
+}
+
 // the pending update a fused mini-batch step applies at its head, and its housekeeping (pxsom_batch_step.hip)
 struct StepArgs {
     const double *w_in;        // [k, c] codebook the pending update applies to (W_{g-1}, or W_0 when has_update == 0)
@@ -70,6 +92,7 @@ struct StepArgs {
     int zero_count;
     int has_update;
     double thr, q;             // schedule of the pending update (step g-1): window threshold, 1 - alpha (batch_gain)
+    double sat = 0x1p62;       // batch_gain_saturation(q)
     float tol_rel, tol_abs;    // filter tolerance coefficients (depend on c only: computed on the host)
     // two-level row view of a scheduled step (fused kernel only): row f of the step is
     // x[(f / group_w) * group_stride + (f % group_w) * ldx] -- group_w consecutive rows (the phases the step
@@ -90,12 +113,13 @@ struct TailStep {
     int e0, width;             // the step takes the phases [e0, e0 + width): rows (f / width) * phases + e0 + f % width
     long long rows;            // rows of the step (>= 1)
     double q;                  // 1 - alpha of the update applied at the HEAD of this step (statistics of the step before)
+    double sat;                // batch_gain_saturation(q)
 };
 struct TailArgs {
     int nsteps, phases;
     int first_has_update;      // 0: the run starts here (W_in is searched as it is)
     int final_update;          // 1: the last step's statistics are applied as well (q_final) and the result goes to w_final
-    double q_final;
+    double q_final, sat_final;
     const double *stats_first; // [k*c sums | k counts] of the step before the first one (ring slot; first_has_update)
     const double *w_in;        // [k, c] codebook the first update applies to
     double *w_last;            // [k, c] receives the codebook the LAST step searched with (wbuf slot of that step)

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
         if (tid < kK) {   // tl[node] = gain (or -1: no rows, the node stays), tl[K + node] = 1 / n
 #pragma clang fp contract(off)
             const double den = 0.0 + cnt;
-            tl[tid] = den > 0.0 ? batch_gain(den, sa.q) : -1.0;
+            tl[tid] = den > 0.0 ? batch_gain(den, sa.q, sa.sat) : -1.0;
             tl[kK + tid] = den > 0.0 ? 1.0 / den : 0.0;
         }
         PXSOM_PHASE(10);
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
                 // gain = 1 - (1-alpha)^den (batch_gain); == 1 exactly for wide windows: the node is
                 // then the window mean itself (orc_batch_update)
                 if (den > 0.0) {
-                    gain = batch_gain(den, sa.q);
+                    gain = batch_gain(den, sa.q, sa.sat);
                     inv = 1.0 / den;
                 }
             }
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
         if (tid < K) {
             const int xp = tid / YD, yp = tid - xp * YD;
             const double den = tl[(size_t)(yp * XD + xp) * NC + c];
-            gain_l[tid] = den > 0.0 ? batch_gain(den, sa.q) : -1.0;
+            gain_l[tid] = den > 0.0 ? batch_gain(den, sa.q, sa.sat) : -1.0;
             tl[(size_t)(yp * XD + xp) * NC + c] = den > 0.0 ? 1.0 / den : 0.0;     // the count column now holds 1/den
         }
         PXSOM_PHASE(4);

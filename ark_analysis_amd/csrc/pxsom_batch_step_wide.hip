@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
     if (r == 0) {
         if (tid < ws.kp) {
             const double den = (tid < k && sa.has_update) ? sa.stats_prev[(size_t)kc + tid] : 0.0;
-            gain_l[tid] = den > 0.0 ? batch_gain(den, sa.q) : -1.0;
+            gain_l[tid] = den > 0.0 ? batch_gain(den, sa.q, sa.sat) : -1.0;
             inv_l[tid] = den > 0.0 ? 1.0 / den : 0.0;
         }
         __syncthreads();
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
         __syncthreads();
         if (tid < ws.kp) {
             const double den = tid < k ? wl[(size_t)tid * cs + c] : 0.0;
-            gain_l[tid] = den > 0.0 ? batch_gain(den, sa.q) : -1.0;
+            gain_l[tid] = den > 0.0 ? batch_gain(den, sa.q, sa.sat) : -1.0;
             inv_l[tid] = den > 0.0 ? 1.0 / den : 0.0;
         }
         __syncthreads();

@@ -410,7 +410,7 @@ __global__ __launch_bounds__(kTailThreads) void batch_tail_kernel(const T *__res
                     const double den = 0.0 + tl[ic * NC + c];
                     if (den > 0.0) {
                         // gain = 1 - (1-alpha)^den (batch_gain; orc_batch_update)
-                        const double gain = batch_gain(den, S.q), inv = 1.0 / den;
+                        const double gain = batch_gain(den, S.q, S.sat), inv = 1.0 / den;
                         const double num = 0.0 + tl[ic * NC + jc];
                         v = gain == 1.0 ? num * inv : v + gain * (num * inv - v);
                     }
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(kTailThreads) void batch_tail_kernel(const T *__res
             if (ta.final_update) {
                 const double den = 0.0 + tl[i * NC + c];
                 if (den > 0.0) {
-                    const double gain = batch_gain(den, ta.q_final), inv = 1.0 / den;
+                    const double gain = batch_gain(den, ta.q_final, ta.sat_final), inv = 1.0 / den;
                     const double num = 0.0 + tl[i * NC + j];
                     v = gain == 1.0 ? num * inv : v + gain * (num * inv - v);
                 }

@@ -578,7 +578,7 @@ __global__ __launch_bounds__(CH * L > 40 ? 512 : 256) void som_online_split_kern
 __global__ __launch_bounds__(256) void batch_update_kernel(double *w, int xdim, int ydim, int c,
                                                            const double *__restrict__ sums,
                                                            const double *__restrict__ counts,
-                                                           double thr, double q, int stage,
+                                                           double thr, double q, double sat, int stage,
                                                            double *__restrict__ zero_out, int zero_count,
                                                            const double *w_src = nullptr)
 {
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(256) void batch_update_kernel(double *w, int xdim, 
         }
         if (den > 0.0) {
             // 1 - (1-alpha)^den by binary exponentiation, 1 - alpha formed on the host (batch_gain; orc_batch_update)
-            const double gain = pxsom_bmu::batch_gain(den, q), inv = 1.0 / den;
+            const double gain = pxsom_bmu::batch_gain(den, q, sat), inv = 1.0 / den;
             // gain == 1 exactly (wide windows): the node is the window mean itself, so nodes sharing a window are
             // bit-identical (and masked as duplicates by prep) instead of one ulp apart (orc_batch_update)
             w[(size_t)k * c + j] = gain == 1.0 ? num * inv : wv + gain * (num * inv - wv);
@@ -1400,7 +1400,7 @@ PXSOM_EXPORT int pxsom_batch_update(double *w_dev, int xdim, int ydim, int c, co
     const size_t stage_bytes = (size_t)K * (c + 1) * sizeof(double);
     const int stage = stage_bytes <= 60 * 1024;
     hipLaunchKernelGGL(batch_update_kernel, dim3(K), dim3(256), stage ? stage_bytes : 0, st, w_dev, xdim, ydim, c,
-                       sums_dev, counts_dev, thr, 1.0 - alpha, stage, (double *)nullptr, 0);
+                       sums_dev, counts_dev, thr, 1.0 - alpha, pxsom_bmu::batch_gain_saturation(1.0 - alpha), stage, (double *)nullptr, 0);
     PXSOM_LAUNCH_CHECK("batch_update_kernel");
     return PXSOM_OK;
 }
@@ -1616,7 +1616,7 @@ PXSOM_EXPORT int pxsom_batch_update_prepare(double *w_dev, int xdim, int ydim, i
     const size_t stage_bytes = (size_t)nstats * sizeof(double);
     const int stage = stage_bytes <= 60 * 1024;
     hipLaunchKernelGGL(batch_update_kernel, dim3(k), dim3(256), stage ? stage_bytes : 0, st, w_dev, xdim, ydim, c,
-                       stats_dev, stats_dev + (size_t)k * c, thr, 1.0 - alpha, stage, other ? stats_next_dev : nullptr,
+                       stats_dev, stats_dev + (size_t)k * c, thr, 1.0 - alpha, pxsom_bmu::batch_gain_saturation(1.0 - alpha), stage, other ? stats_next_dev : nullptr,
                        other ? nstats : 0);
     PXSOM_LAUNCH_CHECK("batch_update_kernel");
     if (!other) PXSOM_HIP_TRY(hipMemsetAsync(stats_dev, 0, stage_bytes, st));
@@ -1897,6 +1897,7 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
             sa.has_update = gg > 0 ? 1 : 0;
             sa.thr = thr;
             sa.q = 1.0 - alpha;
+            sa.sat = pxsom_bmu::batch_gain_saturation(sa.q);
             sa.tol_rel = fused_tol_rel;
             sa.tol_abs = fused_tol_abs;
             sa.mu32 = no_centre ? nullptr : mu32;
@@ -1929,6 +1930,7 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
                 sa.has_update = gg > 0 ? 1 : 0;
                 sa.thr = thr;
                 sa.q = 1.0 - alpha;
+            sa.sat = pxsom_bmu::batch_gain_saturation(sa.q);
                 sa.mu32 = (centred_run && !no_centre) ? mu32 : nullptr;
                 // (5 index bits in the scores -- 6 from 129 nodes on --, three-term split, centred rows)
                 sa.tol_rel = (float)(2.5 * (ldexp(1.0, -(23 - (k > 128 ? 6 : 5))) + (3.0 * c + 2.0) * ldexp(1.0, -24) + ldexp(1.0, -19) + ldexp(1.0, -23) +
@@ -1955,6 +1957,7 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
             sa.has_update = gg > 0 ? 1 : 0;
             sa.thr = thr;
             sa.q = 1.0 - alpha;
+            sa.sat = pxsom_bmu::batch_gain_saturation(sa.q);
             // the generic filter is centred on the run's vector too (binary32 / binary64 rows): + 2^-24, the rounding of
             // x' = fl(x * scale - mu_s)
             sa.mu32 = (centred_run && !no_centre && npk == 0) ? mu32 : nullptr;
@@ -1991,6 +1994,7 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
         ta.first_has_update = g_tail > 0 ? 1 : 0;
         ta.final_update = 0;
         ta.q_final = 1.0;
+        ta.sat_final = 0x1p62;
         ta.stats_first = ring + (size_t)((g_tail + 2) % 3) * nstats;
         ta.w_in = g_tail > 0 ? wbuf + (size_t)((g_tail + 1) % 2) * nw : wbuf + (size_t)(g_tail % 2) * nw;
         ta.w_last = wbuf + (size_t)((g_end - 1) % 2) * nw;
@@ -2011,6 +2015,7 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
             double thr = 0.0, alpha = 0.0;
             if (gg > 0) batch_schedule(sc.pos(gg - 1), span, a0, a1, r0, r1, &thr, &alpha);
             ts.q = 1.0 - alpha;
+            ts.sat = pxsom_bmu::batch_gain_saturation(ts.q);
         }
         int rc = pxsom_bmu::launch_batch_tail<T>(x, c, ldx, ta, st);
         if (rc) return rc;
@@ -2117,7 +2122,7 @@ int finish_at(const double *wbuf_dev, const double *stats_ring_dev, int xdim, in
     const size_t stage_bytes = (size_t)k * (c + 1) * sizeof(double);
     const int stage = stage_bytes <= 60 * 1024;
     hipLaunchKernelGGL(batch_update_kernel, dim3(k), dim3(256), stage ? stage_bytes : 0, st, w_out_dev, xdim, ydim, c, s_last,
-                       s_last + nw, thr, 1.0 - alpha, stage, (double *)nullptr, 0, w_last);
+                       s_last + nw, thr, 1.0 - alpha, pxsom_bmu::batch_gain_saturation(1.0 - alpha), stage, (double *)nullptr, 0, w_last);
     PXSOM_LAUNCH_CHECK("batch_update_kernel");
     return PXSOM_OK;
 }

@@ -43,7 +43,7 @@ int main(int argc, char **argv)
             sa.stats_prev = dring + ((g + 2) % 3) * ns; sa.stats_zero = dring + ((g + 1) % 3) * ns;
             sa.zero_count = (int)ns; sa.has_update = g > 0;
             double thr = 6.0 - 6.0 * (g > 0 ? g - 1 : 0) / M; if (thr < 1) thr = 0.5;
-            sa.thr = thr; sa.q = 1.0 - (0.05 - 0.04 * (g > 0 ? g - 1 : 0) / M);
+            sa.thr = thr; sa.q = 1.0 - (0.05 - 0.04 * (g > 0 ? g - 1 : 0) / M); sa.sat = pxsom_bmu::batch_gain_saturation(sa.q);
             sa.tol_rel = (float)(2.5 * (ldexp(1.0, -16) + (3.0 * c + 2.0) * ldexp(1.0, -24) + ldexp(1.0, -19) + ldexp(1.0, -23)));
             sa.tol_abs = (float)(2.5 * ldexp(1.0, -24) * sqrt((double)c));
             const int64_t rows = (n - g + M - 1) / M;

@@ -39,7 +39,7 @@ int main(int argc, char **argv)
         hipMemcpy(dwbuf + nw, w.data(), nw * 8, hipMemcpyHostToDevice);
         hipMemset(dring, 0, 3 * ns * 8);
         TailArgs ta;
-        ta.nsteps = 16; ta.phases = 960; ta.first_has_update = 0; ta.final_update = 0; ta.q_final = 1.0;
+        ta.nsteps = 16; ta.phases = 960; ta.first_has_update = 0; ta.final_update = 0; ta.q_final = 1.0; ta.sat_final = 0x1p62;
         ta.stats_first = dring; ta.w_in = dwbuf; ta.w_last = dwbuf + nw; ta.stats_last = dring + ns; ta.stats_zero = dring + 2 * ns;
         ta.w_final = nullptr; ta.scratch = scratch;
         ta.tol_rel = (float)(2.5 * (ldexp(1.0, -16) + (3.0 * c + 2.0) * ldexp(1.0, -24) + ldexp(1.0, -19) + ldexp(1.0, -23) + ldexp(1.0, -24)));
@@ -47,7 +47,7 @@ int main(int argc, char **argv)
         ta.mu32 = dmu; ta.qmagic = 0.0;
         for (int s = 0; s < 16; s++) {
             ta.st[s].e0 = 800 + 8 * s; ta.st[s].width = s == 15 ? 40 : 8;
-            ta.st[s].rows = (n / 960) * ta.st[s].width; ta.st[s].q = 1.0 - 0.015;
+            ta.st[s].rows = (n / 960) * ta.st[s].width; ta.st[s].q = 1.0 - 0.015; ta.st[s].sat = pxsom_bmu::batch_gain_saturation(ta.st[s].q);
         }
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0, 0);

@@ -25,7 +25,7 @@ int main()
         for (double thr : {11.0, 5.5, 0.5}) {
             StepArgs sa;
             sa.w_in = dw; sa.w_out = dw2; sa.stats_prev = ds; sa.stats_zero = dz; sa.zero_count = (int)st.size(); sa.has_update = 1;
-            sa.thr = thr; sa.q = 1.0 - 0.04; sa.tol_rel = 1e-5f; sa.tol_abs = 1e-6f;
+            sa.thr = thr; sa.q = 1.0 - 0.04; sa.sat = pxsom_bmu::batch_gain_saturation(sa.q); sa.tol_rel = 1e-5f; sa.tol_abs = 1e-6f;
             int rc = 0;
             for (int rep = 0; rep < 3; rep++) {
                 bool ok = launch_update_prepare(sa, xd, xd, c, ws, L, 0, &rc);

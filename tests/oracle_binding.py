@@ -50,6 +50,8 @@ def lib():
                                        ctypes.c_double, ctypes.c_double]
         L.orc_batch_gain.restype = ctypes.c_double
         L.orc_batch_gain.argtypes = [ctypes.c_double, ctypes.c_double]
+        L.orc_batch_gain_saturation.restype = ctypes.c_double
+        L.orc_batch_gain_saturation.argtypes = [ctypes.c_double]
         L.orc_som_batch.restype = ctypes.c_int
         L.orc_som_batch.argtypes = [c_dp, ctypes.c_int64, ctypes.c_int, c_dp, ctypes.c_int, ctypes.c_int,
                                     ctypes.c_double, ctypes.c_double, ctypes.c_double,
@@ -201,6 +203,11 @@ def batch_update(codes, xdim, ydim, sums, counts, thr, alpha):
 def batch_gain(den, q):
     """1 - q^den of the batch rule (orc_batch_gain: binary exponentiation in plain binary64 products)."""
     return float(lib().orc_batch_gain(float(den), float(q)))
+
+
+def batch_gain_saturation(q):
+    """Smallest power of two D from which on 1 - q^den is exactly 1 by construction (orc_batch_gain_saturation)."""
+    return float(lib().orc_batch_gain_saturation(float(q)))
 
 
 def som_batch(data, codes, xdim, ydim, rlen, alpha_range, radius_range, M):
