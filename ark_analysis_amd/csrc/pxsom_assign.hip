@@ -674,7 +674,7 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
         // binary64 rows of the register-resident shapes (what the drop-in classes label): one self-contained launch of the
         // two-tile kernel -- prepares the codebook itself and settles its listed rows inside (round 5: no spills, unlike
         // bmu_filter_fast<double>); the workspace only records that no row was listed
-        if (!prepared && !stats && onepass_labels_route(sizeof(T)) && filter_fast_path<T>(x, n, c, ldx, L)) {
+        if (!stats && onepass_labels_route(sizeof(T)) && filter_fast_path<T>(x, n, c, ldx, L)) {   // (prepared or not: it prepares itself)
             PXSOM_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(unsigned), st));
             pxsom::Prof *prof1 = pxsom::current_prof();
             pxsom::prof_mark(prof1, st, true, n);

@@ -986,15 +986,22 @@ void launch_filter_any(const T *x, int64_t n, int c, int64_t ldx, char *ws, cons
         launch_filter_fast_acc<T>(x, n, c, ldx, ws, L, labels, stats, w, st, fixed);
         return;
     }
-    if (fast_ok && L.cpl == 6)       // C = 18..24 (BASELINE.json configs 2/3: C = 22)
-        launch_fast<T, 6, 7, 1>(x, n, c, ldx, ws, L, labels, st);
-    else if (fast_ok && L.cpl == 8)  // C = 26..32
-        launch_fast<T, 8, 7, 1>(x, n, c, ldx, ws, L, labels, st);
-    else if (fast_ok && L.cpl == 4)  // C = 10..16
-        launch_fast<T, 4, 7, 1>(x, n, c, ldx, ws, L, labels, st);
-    else if (fast_ok && L.cpl == 2)  // C <= 8 (config 1)
-        launch_fast<T, 2, 7, 1>(x, n, c, ldx, ws, L, labels, st);
-    else if (L.nch == 1)
+    // (binary64 rows of these shapes never get here: assign_typed hands them to the two-tile kernel, pxsom_assign_onepass.h --
+    // bmu_filter_fast<double> spilled and is not built any more)
+    if constexpr (sizeof(T) != 8) {
+        if (fast_ok) {
+            if (L.cpl == 6)       // C = 18..24 (BASELINE.json configs 2/3: C = 22)
+                launch_fast<T, 6, 7, 1>(x, n, c, ldx, ws, L, labels, st);
+            else if (L.cpl == 8)  // C = 26..32
+                launch_fast<T, 8, 7, 1>(x, n, c, ldx, ws, L, labels, st);
+            else if (L.cpl == 4)  // C = 10..16
+                launch_fast<T, 4, 7, 1>(x, n, c, ldx, ws, L, labels, st);
+            else                  // C <= 8 (config 1)
+                launch_fast<T, 2, 7, 1>(x, n, c, ldx, ws, L, labels, st);
+            return;
+        }
+    }
+    if (L.nch == 1)
         vec2 ? launch_filter<T, 1, 0, 0, true>(x, n, c, ldx, ws, L, labels, st)
              : launch_filter<T, 1, 0, 0, false>(x, n, c, ldx, ws, L, labels, st);
     else if (L.nch == 2)

@@ -51,12 +51,12 @@ void launch_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layou
 }
 
 // the one-pass kernel with two tiles per trip (pxsom_assign_onepass.h): fixed-point tables
-template <typename T, int CPL, bool TABLE = true>
+template <typename T, int CPL, int TMODE = 1>
 void launch_onepass(const T *x, int64_t n, int c, int64_t ldx, const Layout &L, int32_t *labels, double *stats, const double *w,
                     hipStream_t st)
 {
     constexpr int kThreads = sizeof(T) == 8 ? 512 : kOneThreads, kWpe = sizeof(T) == 8 ? 2 : PXSOM_ONE_WPE, kWaves = kThreads / 64;
-    auto kern = bmu_onepass_kernel<T, CPL, kThreads, kWpe, TABLE>;
+    auto kern = bmu_onepass_kernel<T, CPL, kThreads, kWpe, TMODE>;
     const size_t lds = onepass_lds_bytes(L.k, c, kThreads);
     static pxsom::PerDevice<int> bpc_on;   // (one per instantiation)
     int &bpc = bpc_on.here();
@@ -89,16 +89,6 @@ bool onepass_enabled()
     return on;
 }
 
-// binary64 rows: on unless PXSOM_ONEPASS_F64=0 (same-box A/B against bmu_filter_fast<double>)
-bool onepass_f64_enabled()
-{
-    static const bool on = [] {
-        const char *e = std::getenv("PXSOM_ONEPASS_F64");
-        return !(e && e[0] == '0');
-    }();
-    return on;
-}
-
 }  // namespace
 
 template <typename T>
@@ -108,14 +98,24 @@ void launch_filter_fast_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws,
 #define PXSOM_ACC(CPL)                                                            \
     (fixed ? launch_acc<T, CPL, true>(x, n, c, ldx, ws, L, labels, stats, w, st)  \
            : launch_acc<T, CPL, false>(x, n, c, ldx, ws, L, labels, stats, w, st))
-    // binary64 rows (what the drop-in classes hold): the two-tile kernel is the one without spills; binary32 / binary16: opt-in
-    if (fixed && (sizeof(T) == 8 ? onepass_f64_enabled() : (L.cpl <= 6 && onepass_enabled()))) {
-        if constexpr (sizeof(T) == 8) {
-            if (L.cpl == 8) {
-                launch_onepass<T, 8>(x, n, c, ldx, L, labels, stats, w, st);
-                return;
-            }
-        }
+    // binary64 rows (what the drop-in classes hold) ALWAYS take the two-tile kernel -- fixed-point or binary64 tables --: it is the
+    // one without spills (bmu_filter_fast kept four tiles of binary64 rows in flight and spilled 28 - 138 VGPRs; its binary64
+    // instantiations are gone).  binary32 / binary16 rows, C <= 24, fixed-point tables: opt-in (measured slower).
+    if constexpr (sizeof(T) == 8) {
+#define PXSOM_ONE64(CPL) (fixed ? launch_onepass<T, CPL, 1>(x, n, c, ldx, L, labels, stats, w, st) \
+                                : launch_onepass<T, CPL, 2>(x, n, c, ldx, L, labels, stats, w, st))
+        if (L.cpl == 8)
+            PXSOM_ONE64(8);
+        else if (L.cpl == 6)
+            PXSOM_ONE64(6);
+        else if (L.cpl == 4)
+            PXSOM_ONE64(4);
+        else
+            PXSOM_ONE64(2);
+#undef PXSOM_ONE64
+        return;
+    } else {
+    if (fixed && L.cpl <= 6 && onepass_enabled()) {
         if (L.cpl == 6)
             launch_onepass<T, 6>(x, n, c, ldx, L, labels, stats, w, st);
         else if (L.cpl == 4)
@@ -132,23 +132,24 @@ void launch_filter_fast_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws,
         PXSOM_ACC(4);
     else
         PXSOM_ACC(2);
+    }
 #undef PXSOM_ACC
 }
 
 // pxsom_assign on binary64 rows of the register-resident shapes: labels only, in the two-tile kernel (no workspace, no list,
 // no exact launch behind it; bmu_filter_fast<double, ACC = false> keeps four tiles of binary64 rows in flight and spills).
-bool onepass_labels_route(size_t elem_bytes) { return elem_bytes == 8 && onepass_f64_enabled(); }
+bool onepass_labels_route(size_t elem_bytes) { return elem_bytes == 8; }
 void launch_onepass_labels(const double *x, int64_t n, int c, int64_t ldx, const Layout &L, int32_t *labels, const double *w,
                            hipStream_t st)
 {
     if (L.cpl == 8)
-        launch_onepass<double, 8, false>(x, n, c, ldx, L, labels, nullptr, w, st);
+        launch_onepass<double, 8, 0>(x, n, c, ldx, L, labels, nullptr, w, st);
     else if (L.cpl == 6)
-        launch_onepass<double, 6, false>(x, n, c, ldx, L, labels, nullptr, w, st);
+        launch_onepass<double, 6, 0>(x, n, c, ldx, L, labels, nullptr, w, st);
     else if (L.cpl == 4)
-        launch_onepass<double, 4, false>(x, n, c, ldx, L, labels, nullptr, w, st);
+        launch_onepass<double, 4, 0>(x, n, c, ldx, L, labels, nullptr, w, st);
     else
-        launch_onepass<double, 2, false>(x, n, c, ldx, L, labels, nullptr, w, st);
+        launch_onepass<double, 2, 0>(x, n, c, ldx, L, labels, nullptr, w, st);
 }
 
 template void launch_filter_fast_acc<float>(const float *, int64_t, int, int64_t, char *, const Layout &, int32_t *,

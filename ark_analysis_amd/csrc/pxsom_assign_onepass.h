@@ -52,8 +52,10 @@ __host__ __device__ inline size_t onepass_lds_bytes(int k, int c, int threads)
 // THREADS x WPE: 768 x 3 (one workgroup per CU, three waves per SIMD, 168 VGPRs) for binary32 / binary16 rows; 512 x 2 (256 VGPRs)
 // for binary64 rows, whose row sets take twice the registers -- for them this kernel is the spill-free one (bmu_filter_fast
 // keeps four tiles of binary64 rows in flight: 28 - 138 spilled VGPRs).
-// TABLE = false: labels only (pxsom_assign on binary64 rows): no table, no flush, listed rows settled for their label alone.
-template <typename T, int CPL, int THREADS, int WPE, bool TABLE = true>
+// TMODE: 1 = 64-bit fixed-point tables (pxsom_assign_sums / means); 2 = binary64 tables, ds_add_f64 (pxsom_batch_accumulate: the
+// batch rule's statistics as its tests pin them); 0 = labels only (pxsom_assign): no table, no flush, listed rows settled for
+// their label alone.
+template <typename T, int CPL, int THREADS, int WPE, int TMODE = 1>
 __global__ __launch_bounds__(THREADS, WPE) void bmu_onepass_kernel(const T *__restrict__ x, int64_t n, int c, int64_t ldx,
                                                                      int32_t *__restrict__ labels, int k,
                                                                      double *__restrict__ stats,
@@ -64,6 +66,7 @@ __global__ __launch_bounds__(THREADS, WPE) void bmu_onepass_kernel(const T *__re
     constexpr bool FOLD = CPL <= 6;
     constexpr int kOneThreads = THREADS, kOneWaves = THREADS / 64;
     constexpr int NB = kOneNB, NP = CPL / 2;
+    constexpr bool TABLE = TMODE != 0, FIXT = TMODE == 1;
     extern __shared__ __attribute__((aligned(16))) char one_smem[];
     double *ls = reinterpret_cast<double *>(one_smem);
     const int cs = acc_stride(c);
@@ -392,13 +395,23 @@ __global__ __launch_bounds__(THREADS, WPE) void bmu_onepass_kernel(const T *__re
 #if PXSOM_ONE_ABL & 16     // (timing build: half of the adds)
                     if (p & 1) continue;
 #endif
-                    __hip_atomic_fetch_add(lu + idx, (unsigned long long)__double_as_longlong((double)raw[t][p].x + fx.magic),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(lu + idx + 1, (unsigned long long)__double_as_longlong((double)raw[t][p].y + fx.magic),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if constexpr (FIXT) {
+                        __hip_atomic_fetch_add(lu + idx, (unsigned long long)__double_as_longlong((double)raw[t][p].x + fx.magic),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(lu + idx + 1, (unsigned long long)__double_as_longlong((double)raw[t][p].y + fx.magic),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else {
+                        __hip_atomic_fetch_add(ls + idx, (double)raw[t][p].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(ls + idx + 1, (double)raw[t][p].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
 #endif
                 }
-                if (q == 0) __hip_atomic_fetch_add(lu + (size_t)(k + 1) * cs + lab, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (q == 0) {
+                    if constexpr (FIXT)
+                        __hip_atomic_fetch_add(lu + (size_t)(k + 1) * cs + lab, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else
+                        __hip_atomic_fetch_add(ls + (size_t)(k + 1) * cs + lab, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
         }
 #endif
@@ -421,7 +434,7 @@ __global__ __launch_bounds__(THREADS, WPE) void bmu_onepass_kernel(const T *__re
                 const int src = __builtin_ctzll(late);
                 late &= late - 1;
                 const int64_t rsrc = s1_q[s1_n - full_rows + (unsigned)src];   // (lanes q < 2: lane == slot)
-                exact_row_accumulate<T, true, TABLE>(x, rsrc, c, ldx, wt, k, labels, ls, lane, &fx, stats, cs, k, 1);
+                exact_row_accumulate<T, FIXT, TABLE>(x, rsrc, c, ldx, wt, k, labels, ls, lane, &fx, stats, cs, k, 1);
             }
         }
     };
@@ -465,10 +478,28 @@ __global__ __launch_bounds__(THREADS, WPE) void bmu_onepass_kernel(const T *__re
     {
         const unsigned queued = *amb_n < kOneAmbQueue ? *amb_n : kOneAmbQueue;   // rows past the end were settled at once
         for (unsigned i = (unsigned)(tid >> 6); i < queued; i += kOneWaves)
-            exact_row_accumulate<T, true, TABLE>(x, amb_q[i], c, ldx, wt, k, labels, ls, lane, &fx, stats, cs, k, 1);
+            exact_row_accumulate<T, FIXT, TABLE>(x, amb_q[i], c, ldx, wt, k, labels, ls, lane, &fx, stats, cs, k, 1);
     }
     __syncthreads();
-    if constexpr (TABLE) {
+    if constexpr (TMODE == 2) {
+        int node = tid / c, j = tid - node * c;
+        const int dnode = kOneThreads / c, dj = kOneThreads % c;
+        for (int e = tid; e < k * c; e += kOneThreads) {
+            const double v = ls[(size_t)node * cs + j];
+            if (v != 0.0) __hip_atomic_fetch_add(stats + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            node += dnode;
+            j += dj;
+            if (j >= c) {
+                j -= c;
+                node++;
+            }
+        }
+        for (int e = tid; e < k; e += kOneThreads) {
+            const double v = ls[(size_t)(k + 1) * cs + e];   // counts sit behind the spare row
+            if (v != 0.0) __hip_atomic_fetch_add(stats + (size_t)k * c + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if constexpr (FIXT) {
         int node = tid / c, j = tid - node * c;   // element e <-> (node, channel), no division per element
         const int dnode = kOneThreads / c, dj = kOneThreads % c;
         for (int e = tid; e < k * c; e += kOneThreads) {
