@@ -41,12 +41,12 @@ static_assert(sizeof(AssignHdr) <= kHdrBytes, "workspace header");
 
 // Gain of the batch rule, 1 - (1 - alpha)^den for a whole den >= 1 (a window's row count), with q = 1 - alpha rounded once on
 // the host: binary exponentiation in plain binary64 products, low bit first -- no libm call, so orc_batch_gain
-// (oracle/pxsom_oracle.c, the same statements) and every kernel return the same bits whatever maths library either side
-// links.  Every intermediate is held at or above 2^-200: anything below 2^-54 leaves the gain at exactly 1 (the node then IS
-// the window mean, orc_batch_update), so the floor changes no result and no product ever reaches the subnormal range.
-// `sat` (batch_gain_saturation(q), formed once per step on the host): every den >= sat has gain exactly 1 -- the loop would
-// multiply by a square of q that is itself at or below 2^-60 -- so the loop is skipped for the wide windows of a pass's first steps
-// (18 - 20 dependent trips per node there: 6.5 us of a 0.34 ms pass, profiles/r05/gain_cost.txt).  Result-neutral by construction.
+// (oracle/pxsom_oracle.c, the same statements) and every kernel return the same bits whatever maths library either side links.
+// `sat` = batch_gain_saturation(q), formed once per step on the host: a den >= sat has gain exactly 1 (the loop would multiply
+// p <= 1 by a square of q that is itself at or below 2^-60), so such windows -- the wide ones of a pass's first steps -- skip the
+// loop; below sat every factor is above 2^-60 and the product above 2^-120: no intermediate ever reaches the subnormal range.
+// The loop is kept to a handful of instructions per bit (32-bit counter: a step holds fewer than 2^31 rows, sat <= den else):
+// it runs on one or two waves of a latency-bound step kernel, where a wave issues one instruction every ~3.6 ns.
 __host__ __device__ inline double batch_gain(double den, double q, double sat)
 {
 #pragma clang fp contract(off)
@@ -54,16 +54,22 @@ __host__ __device__ inline double batch_gain(double den, double q, double sat)
     return -expm1(den * log(q));
 #endif
     if (den >= sat) return 1.0;
-    const double tiny = 0x1p-200;
-    unsigned long long m = (unsigned long long)den;
+    if (den >= 0x1p31) {         // (only without a saturation point below 2^31: alpha below ~1e-8)
+        unsigned long long m = (unsigned long long)den;
+        double p = 1.0, b = q;
+        while (m) {
+            p = (m & 1ull) ? p * b : p;
+            m >>= 1;
+            b = b * b;
+        }
+        return 1.0 - p;
+    }
+    unsigned m = (unsigned)den;
     double p = 1.0, b = q;
     while (m) {
-        double t = p * b;
-        t = t < tiny ? tiny : t;
-        p = (m & 1ull) ? t : p;
+        p = (m & 1u) ? p * b : p;
         m >>= 1;
         b = b * b;
-        b = b < tiny ? tiny : b;
     }
     return 1.0 - p;
 }
@@ -73,11 +79,9 @@ __host__ __device__ inline double batch_gain(double den, double q, double sat)
 __host__ __device__ inline double batch_gain_saturation(double q)
 {
 #pragma clang fp contract(off)
-    const double tiny = 0x1p-200;
     double b = q, d = 1.0;
     while (b > 0x1p-60 && d < 0x1p62) {
         b = b * b;
-        b = b < tiny ? tiny : b;
         d = d * 2.0;
     }
     return b <= 0x1p-60 ? d : 0x1p62;

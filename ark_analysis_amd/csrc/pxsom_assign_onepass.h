@@ -375,6 +375,11 @@ __global__ __launch_bounds__(THREADS, WPE) void bmu_onepass_kernel(const T *__re
             // rows another trip owns and clamped channel slots go to the spare table row k: no branch.
             const unsigned mine = (my_amb || !counted) ? (unsigned)k : real;
             const uint2v lr = __builtin_amdgcn_permlane16_swap(mine, mine, false, false);
+            // where the last pair of the last lane group lies past the row's end (c < 4 CPL) its sixteen lanes -- one per row of
+            // the tile, whose adds would go to the spare row -- carry the row's COUNT in the first of their two adds: no separate
+            // count instruction (as bmu_filter_fast since round 5)
+            const bool fold = c < 4 * CPL;                      // (wave-uniform)
+            const bool cnt_lane = fold && q == 3;
 #pragma unroll
             for (int t = 0; t < kOneTiles; t++) {
                 const unsigned lab = lr[t];
@@ -395,18 +400,20 @@ __global__ __launch_bounds__(THREADS, WPE) void bmu_onepass_kernel(const T *__re
 #if PXSOM_ONE_ABL & 16     // (timing build: half of the adds)
                     if (p & 1) continue;
 #endif
+                    const bool counts_here = p == NP - 1 && cnt_lane;
+                    const unsigned idx0 = counts_here ? (unsigned)(k + 1) * (unsigned)cs + lab : idx;
                     if constexpr (FIXT) {
-                        __hip_atomic_fetch_add(lu + idx, (unsigned long long)__double_as_longlong((double)raw[t][p].x + fx.magic),
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const unsigned long long v0 = (unsigned long long)__double_as_longlong((double)raw[t][p].x + fx.magic);
+                        __hip_atomic_fetch_add(lu + idx0, counts_here ? 1ull : v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         __hip_atomic_fetch_add(lu + idx + 1, (unsigned long long)__double_as_longlong((double)raw[t][p].y + fx.magic),
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     } else {
-                        __hip_atomic_fetch_add(ls + idx, (double)raw[t][p].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(ls + idx0, counts_here ? 1.0 : (double)raw[t][p].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         __hip_atomic_fetch_add(ls + idx + 1, (double)raw[t][p].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
 #endif
                 }
-                if (q == 0) {
+                if (!fold && q == 0) {
                     if constexpr (FIXT)
                         __hip_atomic_fetch_add(lu + (size_t)(k + 1) * cs + lab, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     else
