@@ -31,7 +31,7 @@ def _hipcc() -> str:
 
 
 HEADERS = ["pxsom_common.h", "pxsom_assign.h", "pxsom_wave.h", "pxsom_assign_filter_fast.h", "pxsom_batch_step.h", "pxsom_prep.h",
-           "pxsom_sums.h", "pxsom_assign_onepass.h"]
+           "pxsom_sums.h", "pxsom_assign_onepass.h", "pxsom_xch.h"]
 STAMP_PATH = SO_PATH + ".srchash"
 
 

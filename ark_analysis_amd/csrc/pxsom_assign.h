@@ -108,6 +108,14 @@ struct StepArgs {
     double qmagic = 0.0;
     // centring vector of the one-launch step's filter: c binary32 values in HBM (AssignHdr::mu_s before scaling); NULL: zeros
     const float *mu32 = nullptr;
+    // The rule's exchange INSIDE the launch (round 5; fused kernel on a peer-to-peer communicator, pxsom_xch.h): xch_wait != 0 --
+    // the pending update's statistics are the sum, in rank order, of the ranks' slots of that epoch in THIS rank's block (the
+    // step waits for their flags: bounded, then NaN + the block's error word); xch_signal != 0 -- the last workgroup through the
+    // flush copies this rank's statistics into its slot of EVERY rank's block and raises the flag of that epoch.
+    char *const *xch_peers = nullptr;
+    unsigned *xch_ticket = nullptr;
+    int xch_nranks = 0, xch_rank = 0;
+    unsigned long long xch_max_count = 0, xch_wait = 0, xch_signal = 0;
 };
 
 // The BMU-only tail of a training pass as ONE persistent launch (pxsom_batch_tail.hip): every step's row view, its

@@ -2,6 +2,7 @@
 // (pxsom_batch_tail.hip) share: the grid the register-resident training kernels are built for, and the exact path of a
 // listed row whose values sit in LDS.
 #pragma once
+#include "pxsom_xch.h"
 #include <cfloat>
 #include <cmath>
 

@@ -69,7 +69,9 @@ __host__ __device__ inline StepLds step_lds(int c)
 // !BMU: the other way round.  The same instructions run on a step whichever kernel it takes, but a kernel that CONTAINS both
 // updates takes 10.6 us per BMU-only step where the specialised one takes 9.3, and 0.2 - 1.4 us more per windowed step
 // (profiles/r04/step_bmu_only_specialisation.txt).
-template <typename T, int CPL, int TPW, bool BMU>
+// EXCH (round 5): the instantiation for ranks of a sharded run on a peer-to-peer communicator -- the rule's exchange runs inside
+// the launch (StepArgs::xch_*): no all-reduce launch between two steps.
+template <typename T, int CPL, int TPW, bool BMU, bool EXCH = false>
 __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__restrict__ x, int64_t n, int c, int64_t ldx,
                                                                   double *__restrict__ stats, StepArgs sa)
 {
@@ -155,16 +157,63 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
     // (no scratch pass, no barrier before them), and the gain 1 - (1 - alpha)^n with its chain of products and the reciprocal are formed
     // once per node by the first two waves (lane <-> node) instead of by all seven waves that hold node lanes: the update of
     // a tail step was binary64 issue on two waves per SIMD (profiles/r03/step_phase_timing.txt: 1.6 us of 9.1).
+    // word e of the pending update's statistics: this rank's buffer, or -- EXCH with a wait epoch -- the sum of the ranks' slots
+    // in rank order, starting from +0.0 (the same additions p2p_allreduce_kernel makes: the same bits on every rank)
+    char *xch_mine = nullptr;
+    const int xch_parity = (int)(sa.xch_wait & 1ull);
+    if constexpr (EXCH) {
+        if (sa.xch_wait) {
+            xch_mine = sa.xch_peers[sa.xch_rank];
+            __shared__ int s_xch_late;
+            if (tid == 0) s_xch_late = 0;
+            __syncthreads();
+            if (tid < sa.xch_nranks) {
+                pxsom::P2PBlock *blk_mine = reinterpret_cast<pxsom::P2PBlock *>(xch_mine);
+                const long long t0 = (long long)wall_clock64();   // 100 MHz
+                while (__hip_atomic_load(&blk_mine->flags[xch_parity][tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != sa.xch_wait) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if ((long long)wall_clock64() - t0 > 400000000ll) {   // 4 s, as the separate exchange
+                        s_xch_late = 1;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+            if (s_xch_late) {   // a peer never arrived: nothing to apply -- poison the codebook and record the epoch (first one kept)
+                if (blockIdx.x == 0 && sa.w_out)
+                    for (int e = tid; e < kK * c; e += kStepThreads) sa.w_out[e] = __builtin_nan("");
+                if (tid == 0 && blockIdx.x == 0) {
+                    unsigned long long none = 0ull;
+                    (void)__hip_atomic_compare_exchange_strong(&reinterpret_cast<pxsom::P2PBlock *>(xch_mine)->error, &none, sa.xch_wait,
+                                                               __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                return;
+            }
+        }
+    }
+    auto stat = [&](size_t e) -> double {
+        if constexpr (EXCH) {
+            if (xch_mine) {
+                double acc = 0.0;
+                for (int p = 0; p < sa.xch_nranks; p++)
+                    acc += __hip_atomic_load(pxsom::p2p_slot(xch_mine, xch_parity, p, sa.xch_nranks, (size_t)sa.xch_max_count) + e,
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return acc;
+            }
+        }
+        return sa.stats_prev[e];
+    };
     const int upd_r = sa.thr < 0.0 ? -1 : (sa.thr > 1.0e6 ? 1000000 : (int)floor(sa.thr));
     constexpr bool bmu_only = BMU;   // (the launch picks the kernel by the pending update's threshold: launch_step)
     double sdir[CPL];   // bmu_only: this thread's words of the statistics
     if (bmu_only) {
         double cnt = 0.0;
-        if (tid < 2 * 64) cnt = sa.stats_prev[(size_t)kK * c + (tid < kK ? tid : 0)];
+        if (tid < 2 * 64) cnt = stat((size_t)kK * c + (tid < kK ? tid : 0));
 #pragma unroll
         for (int i = 0; i < CPL; i++) {
             const int ch = nq * CPL + i;
-            sdir[i] = sa.stats_prev[(has_node && ch < c) ? (size_t)node * c + ch : 0];
+            sdir[i] = stat((has_node && ch < c) ? (size_t)node * c + ch : 0);
         }
 #pragma unroll
         for (int i = 0; i < CPL; i++) {
@@ -202,7 +251,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
         const int gx = p1 ? tid / NC : 0, cc = p1 ? tid - gx * NC : 0;
 #pragma unroll
         for (int y = 0; y < kYD; y++)   // branch-free: idle threads re-read a valid word
-            S[y] = sa.stats_prev[cc < c ? (size_t)(gx * kYD + y) * c + cc : (size_t)kK * c + gx * kYD + y];
+            S[y] = stat(cc < c ? (size_t)(gx * kYD + y) * c + cc : (size_t)kK * c + gx * kYD + y);
 #pragma unroll
         for (int i = 0; i < CPL; i++) {
             const int ch = nq * CPL + i;
@@ -655,6 +704,35 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
         }
     }
     PXSOM_PHASE(18);
+    if constexpr (EXCH) {
+        if (sa.xch_signal) {
+            // the last workgroup through the flush hands this rank's statistics to every rank
+            __shared__ int s_xch_last;
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned t = __hip_atomic_fetch_add(sa.xch_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                s_xch_last = t == gridDim.x - 1u;
+                if (s_xch_last) __hip_atomic_store(sa.xch_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            if (s_xch_last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                const int parity = (int)(sa.xch_signal & 1ull), total = kK * c + kK;
+                for (int e = tid; e < total; e += kStepThreads) {
+                    const double v = __hip_atomic_load(stats + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int p = 0; p < sa.xch_nranks; p++)
+                        __hip_atomic_store(pxsom::p2p_slot(sa.xch_peers[p], parity, sa.xch_rank, sa.xch_nranks, (size_t)sa.xch_max_count) + e, v,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                __threadfence_system();
+                __syncthreads();
+                if (tid < sa.xch_nranks)
+                    __hip_atomic_store(&reinterpret_cast<pxsom::P2PBlock *>(sa.xch_peers[tid])->flags[parity][sa.xch_rank], sa.xch_signal,
+                                       __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
 #ifdef PXSOM_PHASE_TIMING
     __builtin_amdgcn_s_waitcnt(0);
     PXSOM_PHASE(19);
@@ -1003,11 +1081,18 @@ int launch_step(const T *x, int64_t n, int c, int64_t ldx, double *stats, const 
     auto k4 = batch_step_kernel<T, CPL, 4, false>;
     auto k1b = batch_step_kernel<T, CPL, 1, true>;
     auto k2b = batch_step_kernel<T, CPL, 2, true>;
+    auto x1 = batch_step_kernel<T, CPL, 1, false, true>;     // the exchange inside the launch (sharded runs, peer-to-peer blocks)
+    auto x2 = batch_step_kernel<T, CPL, 2, false, true>;
+    auto x4 = batch_step_kernel<T, CPL, 4, false, true>;
+    auto x1b = batch_step_kernel<T, CPL, 1, true, true>;
+    auto x2b = batch_step_kernel<T, CPL, 2, true, true>;
     static pxsom::PerDevice<size_t> attr_lds_on;
     size_t &attr_lds = attr_lds_on.here();
     if (attr_lds < lds) {
         for (const void *fn : {reinterpret_cast<const void *>(k1), reinterpret_cast<const void *>(k2), reinterpret_cast<const void *>(k4),
-                               reinterpret_cast<const void *>(k1b), reinterpret_cast<const void *>(k2b)}) {
+                               reinterpret_cast<const void *>(k1b), reinterpret_cast<const void *>(k2b), reinterpret_cast<const void *>(x1),
+                               reinterpret_cast<const void *>(x2), reinterpret_cast<const void *>(x4), reinterpret_cast<const void *>(x1b),
+                               reinterpret_cast<const void *>(x2b)}) {
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess)
                 return pxsom::fail(PXSOM_ERR_HIP, "batch step kernel: cannot raise the LDS limit to %zu bytes: %s", lds,
@@ -1052,6 +1137,7 @@ int launch_step(const T *x, int64_t n, int c, int64_t ldx, double *stats, const 
     const int64_t rounds = (nblocks + slots - 1) / slots;
     const int grid = (int)((nblocks + rounds - 1) / rounds);
     auto kern = tpw == 1 ? (bmu ? k1b : k1) : (tpw == 2 ? (bmu ? k2b : k2) : k4);
+    if (sa.xch_peers) kern = tpw == 1 ? (bmu ? x1b : x1) : (tpw == 2 ? (bmu ? x2b : x2) : x4);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kStepThreads), lds, st, x, n, c, ldx, stats, sa);
     PXSOM_LAUNCH_CHECK("batch_step_kernel");
     return PXSOM_OK;

@@ -16,6 +16,7 @@
 #include <cstring>
 
 #include "pxsom_common.h"
+#include "pxsom_xch.h"
 
 namespace {
 
@@ -59,12 +60,8 @@ int rccl_fail(const char *what, ncclResult_t r)
 //      order, so the result is bit-identical on all ranks (an RCCL ring promises that only per algorithm and size).
 // Epoch parity alternates, so a rank running ahead writes the other half of the block; it cannot lap a slow rank by two
 // epochs because its own step 3 of the epoch in between needs that rank's flag.
-constexpr int kP2PMaxRanks = 16;
-struct P2PBlock {           // head of a rank's exchange block
-    unsigned long long flags[2][kP2PMaxRanks];
-    unsigned long long error;
-    unsigned long long pad[7];
-};
+using pxsom::kP2PMaxRanks;
+using pxsom::P2PBlock;
 struct P2PArgs {
     char *peer[kP2PMaxRanks];   // every rank's block as mapped here (peer[rank] = the own one)
     int nranks, rank;
@@ -81,14 +78,12 @@ struct pxsom_comm {
     char *peer[kP2PMaxRanks] = {};               // mapped blocks
     size_t max_count = 0;
     unsigned long long epoch = 0;
+    char *dev_table = nullptr;                   // [nranks] peer pointers + the fused steps' ticket word, in device memory (connect)
 };
 
 namespace {
 
-__device__ __forceinline__ double *p2p_slot(char *block, int parity, int src, int nranks, size_t max_count)
-{
-    return reinterpret_cast<double *>(block + sizeof(P2PBlock)) + ((size_t)parity * nranks + src) * max_count;
-}
+using pxsom::p2p_slot;
 
 __global__ __launch_bounds__(1024) void p2p_allreduce_kernel(P2PArgs a, double *__restrict__ buf, size_t count)
 {
@@ -159,6 +154,23 @@ int p2p_allreduce(pxsom_comm *c, double *buf, size_t count, hipStream_t st)
 }  // namespace
 
 namespace pxsom {
+
+// The rule's exchange inside the step launches (pxsom_batch_step.hip, EXCH instantiations): hands the training loop the blocks
+// and reserves the epochs of `exchanges` fused exchanges (the next separate all-reduce continues behind them).
+bool comm_fused_begin(pxsom_comm *c, int exchanges, size_t count, FusedXch *out)
+{
+    if (!c || !c->p2p || !c->dev_table || count > c->max_count || exchanges < 0) return false;
+    for (int p = 0; p < c->nranks; p++)
+        if (!c->peer[p]) return false;
+    out->peers = reinterpret_cast<char *const *>(c->dev_table);
+    out->ticket = reinterpret_cast<unsigned *>(c->dev_table + kP2PMaxRanks * sizeof(char *));
+    out->nranks = c->nranks;
+    out->rank = c->rank;
+    out->max_count = c->max_count;
+    out->epoch_base = c->epoch;
+    c->epoch += (unsigned long long)exchanges;
+    return true;
+}
 
 // used by the training loop (pxsom_train.hip)
 int comm_allreduce_sum_f64(pxsom_comm *c, double *buf, size_t count, hipStream_t st)
@@ -280,6 +292,13 @@ PXSOM_EXPORT int pxsom_comm_p2p_connect(pxsom_comm *c, const void *handles, size
         if (e != hipSuccess) return pxsom::hip_fail(e, "pxsom_comm_p2p_connect: hipIpcOpenMemHandle");
         c->peer[p] = static_cast<char *>(ptr);
     }
+    // the table the fused step kernels read (pxsom_xch.h FusedXch): peer pointers, then the ticket word
+    if (!c->dev_table) {
+        PXSOM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->dev_table), (kP2PMaxRanks + 1) * sizeof(char *)));
+        char *host[kP2PMaxRanks + 1] = {};
+        for (int p = 0; p < c->nranks; p++) host[p] = c->peer[p];
+        PXSOM_HIP_TRY(hipMemcpy(c->dev_table, host, sizeof(host), hipMemcpyHostToDevice));
+    }
     return PXSOM_OK;
 }
 
@@ -301,6 +320,7 @@ PXSOM_EXPORT int pxsom_comm_destroy(pxsom_comm *c)
         for (int p = 0; p < c->nranks; p++)
             if (p != c->rank && c->peer[p]) (void)hipIpcCloseMemHandle(c->peer[p]);
         if (c->block) (void)hipFree(c->block);
+        if (c->dev_table) (void)hipFree(c->dev_table);
         delete c;
         return PXSOM_OK;
     }

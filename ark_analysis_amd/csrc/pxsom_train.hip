@@ -11,6 +11,7 @@
 //                       (pixel_cluster_utils.py:369-404) and is the accumulation half of the batch rule.
 //   pxsom_batch_update  the batch rule's codebook update (oracle of record: orc_batch_update).
 #include <algorithm>
+#include <cstring>
 #include <cfloat>
 #include <vector>
 #include <cmath>
@@ -19,6 +20,7 @@
 #include "pxsom_common.h"
 #include "pxsom_sums.h"
 #include "pxsom_wave.h"
+#include "pxsom_xch.h"
 
 namespace {
 
@@ -1874,6 +1876,18 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
             if (g_end - g >= 2 && g_end - g <= pxsom_bmu::kMaxTailSteps) g_tail = g;
         }
     }
+    // The exchange inside the step launches (round 5; PXSOM_EXCHANGE=fused, a peer-to-peer communicator, the fused 10 x 10 step):
+    // step gg's last workgroup hands this rank's statistics to every rank, step gg + 1 adds the ranks' slots in rank order while
+    // it applies the pending update -- no all-reduce launch between two steps.  The last step of the call keeps the separate
+    // all-reduce: the next call (or the final update) reads the ring.  Every rank takes the same decision (same environment,
+    // same communicator kind, agreed route).
+    pxsom::FusedXch fxch;
+    bool fused_xch = false;
+    {
+        static const bool fused_env = getenv("PXSOM_EXCHANGE") != nullptr && strcmp(getenv("PXSOM_EXCHANGE"), "fused") == 0;
+        if (comm && fused_shape && fused_env && g_tail - g_begin >= 2)
+            fused_xch = pxsom::comm_fused_begin(comm, g_tail - g_begin - 1, nstats, &fxch);
+    }
     for (int gg = g_begin; gg < g_tail; gg++) {
         const int g = gg % sc.steps;
         const int64_t rows = sc.rows(n, g);
@@ -1904,12 +1918,22 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
             sa.group_w = wd > 1 ? wd : 1;
             sa.group_stride = (int64_t)sc.phases * ldx;
             sa.qmagic = qmagic;
+            if (fused_xch) {
+                const int i = gg - g_begin;                       // the exchange behind step gg has epoch base + i + 1
+                sa.xch_peers = fxch.peers;
+                sa.xch_ticket = fxch.ticket;
+                sa.xch_nranks = fxch.nranks;
+                sa.xch_rank = fxch.rank;
+                sa.xch_max_count = fxch.max_count;
+                sa.xch_wait = i > 0 ? fxch.epoch_base + (unsigned long long)i : 0ull;
+                sa.xch_signal = gg + 1 < g_tail ? fxch.epoch_base + (unsigned long long)i + 1ull : 0ull;
+            }
             // (an empty step -- a rank whose shard is shorter than the schedule -- still launches: the update, the
             // clearing of the next buffer and W_g are the kernel's, and every rank must take the same route)
             int rc = pxsom_bmu::launch_batch_step<T>(x + (size_t)sc.e0(g) * ldx, rows, c, wd > 1 ? ldx : ldx * sc.phases,
                                                      s_cur, sa, tpw, st);
             if (rc) return rc;
-            if (comm && (rc = pxsom::comm_allreduce_sum_f64(comm, s_cur, nstats, st))) return rc;
+            if (comm && (!fused_xch || gg + 1 == g_tail) && (rc = pxsom::comm_allreduce_sum_f64(comm, s_cur, nstats, st))) return rc;
             continue;
         }
         // small steps (<= 16 K rows) of codebooks up to 256 nodes x 128 channels: ONE launch (update, fragments, search, exact

@@ -294,7 +294,10 @@ def native_exchange(group=None):
     # PXSOM_EXCHANGE=p2p (opt-in, round 4): the one-shot peer-to-peer exchange over HIP IPC blocks instead of RCCL -- one launch
     # per step and rank, bit-identical sums; validated with two ranks on ONE device (tests/test_gpu_exchange.py), no
     # multi-GPU hardware run exists yet, hence not the default.  Any backend: the handles travel as host objects.
-    if wanted != "0" and os.environ.get("PXSOM_EXCHANGE", "rccl") == "p2p" and torch.cuda.is_available():
+    # PXSOM_EXCHANGE=fused (round 5): the same blocks, and the fused 10 x 10 step runs the exchange INSIDE its launch (the last
+    # workgroup of a step writes to every rank, the next step's prologue adds the slots: csrc/pxsom_batch_step.hip); other
+    # shapes and the last step of a call keep the one-launch exchange.
+    if wanted != "0" and os.environ.get("PXSOM_EXCHANGE", "rccl") in ("p2p", "fused") and torch.cuda.is_available():
         from . import som_device
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         err = None

@@ -405,7 +405,9 @@ def main():
                    "parallelism": f"{'row' if cfg['kind'] == 'cell' else 'fov'}-shard x{world}",
                    "rccl_ranks": (0 if dry else world) if use_dist else 0,
                    **({"dry_run": "all ranks on one GPU over gloo: exercises the N > 1 code, timings are meaningless"} if dry else {}),
-                   "exchange": (("in-library peer-to-peer all-reduce (HIP IPC blocks, one launch per rank) behind every step"
+                   "exchange": ((("in-library peer-to-peer exchange INSIDE the step launches (HIP IPC blocks; last workgroup writes, next step's prologue adds)"
+                                  if os.environ.get("PXSOM_EXCHANGE") == "fused" and cfg["kind"] != "cell" else
+                                  "in-library peer-to-peer all-reduce (HIP IPC blocks, one launch per rank) behind every step")
                                  if per_rank and per_rank.get("exchange_route") == "P2PComm" else
                                  "in-library RCCL all-reduce behind every step") if comm_ranks else "torch.distributed all-reduce per step")
                    if use_dist else "none (one rank)"},

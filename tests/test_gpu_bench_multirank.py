@@ -26,14 +26,14 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("exchange", ["torch.distributed", "in-library", "p2p"])
+@pytest.mark.parametrize("exchange", ["torch.distributed", "in-library", "p2p", "fused"])
 @pytest.mark.parametrize("config", ["cfg2", "cfg4"])
 def test_two_rank_bench_line(gpu, tmp_path, exchange, config):
     env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", PXSOM_BENCH_DRY_RANKS="1")
     if exchange == "in-library":
         env.update(PXSOM_NATIVE_EXCHANGE="force", PXSOM_RCCL_LIBRARY=_mock_library(tmp_path))
-    elif exchange == "p2p":      # the library's peer-to-peer exchange: real on one device (HIP IPC between the two processes)
-        env.update(PXSOM_EXCHANGE="p2p")
+    elif exchange in ("p2p", "fused"):   # the library's peer-to-peer exchange: real on one device (HIP IPC between the two processes);
+        env.update(PXSOM_EXCHANGE=exchange)   # "fused": inside the 10 x 10 step's own launch (config 2; config 4 keeps the one-launch exchange)
     else:
         env.update(PXSOM_NATIVE_EXCHANGE="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -49,7 +49,7 @@ def test_two_rank_bench_line(gpu, tmp_path, exchange, config):
     per_rank = line["phases_ms"]["per_rank"]
     assert len(per_rank["train_batch"]) == 2 and all(v > 0 for v in per_rank["train_batch"])
     assert per_rank["exchange_us_per_step"] > 0 and per_rank["exchange_ms_per_pass"] > 0     # the exchange timed on its own
-    if exchange == "p2p":
+    if exchange in ("p2p", "fused"):
         assert per_rank["exchange_route"] == "P2PComm" and per_rank["exchange_us_per_step_p2p"] is None
     else:                        # ... and the peer-to-peer route beside whichever one the pass used
         assert per_rank["exchange_us_per_step_p2p"] > 0

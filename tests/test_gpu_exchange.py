@@ -196,12 +196,12 @@ def test_a_rank_with_an_empty_or_short_shard_keeps_the_same_codebook(oracle, tmp
 
 
 # ---- the one-shot peer-to-peer exchange (pxsom_comm_p2p_*): two ranks on ONE device ---------------------------------
-def _p2p_worker(rank, world, port, shards, w0, xdim, ydim, out_dir):
+def _p2p_worker(rank, world, port, shards, w0, xdim, ydim, out_dir, route="p2p"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    os.environ["PXSOM_EXCHANGE"] = "p2p"
+    os.environ["PXSOM_EXCHANGE"] = route
     from ark_analysis_amd import som_device
     from ark_analysis_amd.distributed import BatchSOMTrainer, native_exchange
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -236,7 +236,7 @@ def _p2p_worker(rank, world, port, shards, w0, xdim, ydim, out_dir):
     gathered = [torch.zeros(w.shape, dtype=torch.float64) for _ in range(world)]
     dist.all_gather(gathered, w.cpu())
     if rank == 0:
-        np.savez(os.path.join(out_dir, "p2p.npz"), w=w.cpu().numpy(), ok_sum=np.array(ok_sum), err=np.array(err),
+        np.savez(os.path.join(out_dir, route + ".npz"), w=w.cpu().numpy(), ok_sum=np.array(ok_sum), err=np.array(err),
                  same=np.array([bool(torch.equal(g, gathered[0])) for g in gathered]))
     dist.barrier()
     dist.destroy_process_group()
@@ -282,6 +282,35 @@ def test_p2p_exchange_two_ranks_on_one_device(oracle, tmp_path):
     # rows of phase p: oracle index i % (2 * phases) ... the oracle deals by i % phases, so interleave within a phase pair
     want = oracle.som_batch_sched(g, w0, xdim, ydim, 1, (0.05, 0.01), default_radius_range(xdim, ydim), phases, sch.edges)
     np.testing.assert_allclose(res["w"], want, rtol=1e-9, atol=0)
+
+
+def test_fused_exchange_two_ranks_on_one_device(oracle, tmp_path):
+    """The exchange INSIDE the step launches (PXSOM_EXCHANGE=fused: the last workgroup of a step writes this rank's statistics
+    into every rank's block, the next step adds the slots in rank order while it applies the update), two processes on cuda:0:
+    no peer late, codebooks array_equal across the ranks AND array_equal to the run with the one-launch exchange behind every
+    step (the same additions in the same order), on a schedule with steps of one, two and four tiles per wave."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from ark_analysis_amd import synth
+    xdim = ydim = 10
+    k, c, n_local = 100, 22, 96_000
+    shards = [synth.make_fov_numpy(n_local, c, seed=170 + r, dtype=np.float32) for r in range(2)]
+    w0 = shards[1][np.random.RandomState(2).choice(n_local, k, replace=False)].astype(np.float64)
+    got = {}
+    for route in ("fused", "p2p"):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        mp.spawn(_p2p_worker, args=(2, port, shards, w0, xdim, ydim, str(tmp_path), route), nprocs=2, join=True)
+        res = np.load(str(tmp_path / (route + ".npz")))
+        assert int(res["err"]) == 0, "%s: a peer did not arrive at exchange %d" % (route, int(res["err"]))
+        assert res["same"].all(), route + ": codebook differs between the ranks"
+        assert np.isfinite(res["w"]).all(), route
+        got[route] = res["w"]
+    assert np.array_equal(got["fused"], got["p2p"]), "largest difference %.3g" % float(np.abs(got["fused"] - got["p2p"]).max())
 
 
 def _native_exchange_worker(rank, world, lib_path, port, out_path, wrong):
