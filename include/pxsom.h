@@ -290,7 +290,12 @@ int pxsom_comm_allreduce_sum_f64(pxsom_comm *comm, double *buf_dev, size_t count
  *   create(nranks <= 16, rank, max_count binary64 values per exchange) -> handle(64 bytes; gather them from all ranks,
  *   rank order) -> connect(all handles).  The communicator then serves pxsom_comm_allreduce_sum_f64 and
  *   pxsom_batch_train_sched like an RCCL one.  pxsom_comm_p2p_error: 0, or the epoch at which a peer failed to arrive
- *   within 4 s (that exchange's buffer was set to NaN; the GPU is not left hanging). */
+ *   within 4 s (that exchange's buffer was set to NaN; the GPU is not left hanging; the FIRST such epoch stays on record).
+ * Round 5: with PXSOM_EXCHANGE=fused in the environment of every rank, pxsom_batch_train_sched on such a communicator runs the
+ * exchange INSIDE the launches of the fused 10 x 10 step (the last workgroup of a step writes this rank's statistics into every
+ * block, the next step adds the slots in rank order while it applies the update: the same bits as the one-launch exchange, one
+ * launch per step); a peer that is late there turns the codebook to NaN and sets the same error word.  The last step of a call
+ * and every other shape keep the one-launch exchange. */
 #define PXSOM_P2P_HANDLE_BYTES 64
 int pxsom_comm_p2p_create(int nranks, int rank, size_t max_count, pxsom_comm **out);
 int pxsom_comm_p2p_handle(pxsom_comm *comm, void *handle_out, size_t handle_bytes);
