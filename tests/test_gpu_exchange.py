@@ -313,6 +313,31 @@ def test_fused_exchange_two_ranks_on_one_device(oracle, tmp_path):
     assert np.array_equal(got["fused"], got["p2p"]), "largest difference %.3g" % float(np.abs(got["fused"] - got["p2p"]).max())
 
 
+@pytest.mark.parametrize("c,rows", [(100, (30_000, 9_600)), (22, (61_440, 7_680))])
+def test_uneven_shards_end_in_equal_codebooks(tmp_path, c, rows):
+    """Ranks with shards of very different lengths take different kernel routes for the same step -- the wide one-launch step up
+    to 16 K local rows, the launch-per-phase route beyond (cell SOM, 100 columns); one or more tiles per wave in the fused step
+    (22 columns) -- and apply the same all-reduced statistics locally: the replicas stay equal only if the routes' updates are
+    bit-identical (the advisor's round-4 finding).  Two processes on cuda:0, peer-to-peer exchange, default schedule."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from ark_analysis_amd import synth
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    k = 100
+    shards = [synth.make_fov_numpy(rows[r], c, seed=270 + r, dtype=np.float32) for r in range(2)]
+    w0 = shards[0][np.random.RandomState(3).choice(rows[0], k, replace=False)].astype(np.float64)
+    mp.spawn(_p2p_worker, args=(2, port, shards, w0, 10, 10, str(tmp_path)), nprocs=2, join=True)
+    res = np.load(str(tmp_path / "p2p.npz"))
+    assert int(res["err"]) == 0
+    assert np.isfinite(res["w"]).all()
+    assert res["same"].all(), "codebook differs between the ranks"
+
+
 def _native_exchange_worker(rank, world, lib_path, port, out_path, wrong):
     os.environ.update(PXSOM_RCCL_LIBRARY=lib_path, PXSOM_NATIVE_EXCHANGE="force", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if wrong:
