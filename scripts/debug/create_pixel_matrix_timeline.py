@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from ark_analysis_amd import flowsom, fov_tables, image_io
 from ark_analysis_amd.phenotyping import pixel_cluster_utils, pixie_preprocessing as pp
 ap = argparse.ArgumentParser(); ap.add_argument("--fovs", type=int, default=6); args = ap.parse_args()
+if "PXSOM_SWITCH" in os.environ: sys.setswitchinterval(float(os.environ["PXSOM_SWITCH"]))   # GIL hand-over interval (default 5 ms)
 root = tempfile.mkdtemp(prefix="pxsom_pre_")
 tiff_dir, seg_dir = os.path.join(root, "tiffs"), os.path.join(root, "seg")
 os.makedirs(os.path.join(root, "pixel_output_dir")); os.mkdir(seg_dir)
