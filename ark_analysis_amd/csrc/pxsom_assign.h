@@ -1,6 +1,7 @@
 // pxsom_assign.h -- declarations shared by the BMU-assignment translation units.
 #pragma once
 #include <algorithm>
+#include <cmath>
 
 #include "pxsom_common.h"
 
@@ -38,6 +39,39 @@ struct AssignHdr {
     float tol_rel_coarse; // tol_rel of the register-resident filter's first stage (Wh*Xh alone)
 };
 static_assert(sizeof(AssignHdr) <= kHdrBytes, "workspace header");
+
+// The accumulation terms of the filter's |score - exact| bound (DESIGN.md "K7 error bound"), in units of 2^-24, after what
+// v_mfma_f32_16x16x32_f16 was measured to do (round 5, profiles/r05/mfma_rounding.txt): an instruction takes its 32 slots as four
+// groups of eight in slot order; inside a group every product is cut below 2^-24 of the group's largest product, the cut products are
+// summed exactly, and the sum joins the accumulator within 2 x 2^-24 of the larger of the two (measured: 1.03 - 1.4).  So a chain of
+// `terms` products per channel (Wh*Xh, Wh*Xl, Wl*Xh: 3; binary16 rows: 2; a first stage on Wh*Xh alone: 1) over NCH = ceil(C / 32)
+// instructions each commits
+//   * 4 NCH terms group additions, each within 2 x 2^-24 of the running magnitude |X'||W'| (1 + 2^-10) + |W'|^2 / 2
+//     (+ 2: the bias the chain starts from and the rounding of |X'|^2)                                       -> filter_accum_units
+//   * cuts of at most 8 x 2^-24 x max |x'_j w'_j| <= 8 x 2^-24 x |X'|_2 max|w'| per group of the Wh*Xh instructions (the cross terms'
+//     groups are 2^-11 of that: the factor 1 + 2^-10), with max|w'| < 256 by the choice of the scale (every prep makes the
+//     largest magnitude of the scaled codebook lie in [128, 256), or lists every row)                    -> filter_cut_abs (x |X'|)
+// in place of one 2^-24 of the running magnitude per product (3C + 2), which is what round-to-nearest additions in slot order
+// would commit and what the unit does not do.
+// (-DPXSOM_TOL_SLOTWISE=1, timing builds: the bound of rounds 1 - 4, one rounding per product)
+#ifndef PXSOM_TOL_SLOTWISE
+#define PXSOM_TOL_SLOTWISE 0
+#endif
+__host__ __device__ inline double filter_accum_units(int c, int terms)
+{
+    if (PXSOM_TOL_SLOTWISE) return (double)terms * c + 2.0;
+    const int nch = (c + 31) / 32;
+    return 2.0 * (4.0 * nch * terms) * (1.0 + 0x1p-10) + 2.0;
+}
+__host__ __device__ inline double filter_cut_abs(int c)
+{
+    if (PXSOM_TOL_SLOTWISE) return 0.0;
+    const int nch = (c + 31) / 32;
+    // (1 + 2^-9: the cross terms' groups, 2^-11 of the Wh*Xh ones, and the roundings of the two high parts)
+    return 8.0 * (4.0 * nch) * (1.0 + 0x1p-9) * 256.0 * 0x1p-24;
+}
+// the absolute coefficient every filter multiplies by |X'| + |W'|max: binary16 subnormal floor + the cuts
+__host__ __device__ inline double filter_tol_abs(int c) { return 2.5 * (0x1p-24 * sqrt((double)c) + filter_cut_abs(c)); }
 
 // Gain of the batch rule, 1 - (1 - alpha)^den for a whole den >= 1 (a window's row count), with q = 1 - alpha rounded once on
 // the host: binary exponentiation in plain binary64 products, low bit first -- no libm call, so orc_batch_gain

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_kernel(
     // (a centred workspace -- binary32 / binary64 rows only, pxsom_assign.hip -- keeps the full split: x * scale - mu_s is not
     // a binary16 number)
     const bool lo_needed = sizeof(T) != 2 || scale < 1.f || hdr->centred != 0;
-    if (!lo_needed) tol_rel -= 2.5f * ((float)c * 0x1p-24f + (0x1p-19f - 0x1p-21f));
+    if (!lo_needed) tol_rel -= 2.5f * ((float)(filter_accum_units(c, 3) - filter_accum_units(c, 2)) * 0x1p-24f + (0x1p-19f - 0x1p-21f));
 
     const int lane = threadIdx.x & 63;
     const int pix = lane & 15, q = lane >> 4;
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_packed_kerne
     constexpr unsigned idx_mask = 3u;
     const float scale = hdr->scale, wn_max = hdr->wn_max, tol_abs = hdr->tol_abs, x_limit = hdr->x_limit;
     // binary16 rows without the Xl terms: the bound of the streamed kernel (see there)
-    const float tol_rel = hdr->tol_rel - 2.5f * ((float)c * 0x1p-24f + (0x1p-19f - 0x1p-21f));
+    const float tol_rel = hdr->tol_rel - 2.5f * ((float)(filter_accum_units(c, 3) - filter_accum_units(c, 2)) * 0x1p-24f + (0x1p-19f - 0x1p-21f));
     const bool force_exact = hdr->force_exact != 0 || scale < 1.f;
     const int lane = threadIdx.x & 63;
     const int pix = lane & 15, q = lane >> 4;
@@ -686,7 +686,7 @@ __global__ __launch_bounds__(BD, 1) void bmu_filter_packed2_kernel(
     const int nb = hdr->nb;
     constexpr unsigned idx_mask = 3u;
     const float scale = hdr->scale, wn_max = hdr->wn_max, tol_abs = hdr->tol_abs, x_limit = hdr->x_limit;
-    const float tol_rel = hdr->tol_rel - 2.5f * ((float)c * 0x1p-24f + (0x1p-19f - 0x1p-21f));
+    const float tol_rel = hdr->tol_rel - 2.5f * ((float)(filter_accum_units(c, 3) - filter_accum_units(c, 2)) * 0x1p-24f + (0x1p-19f - 0x1p-21f));
     const float tol_rel1 = tol_rel + 2.5f * 0x1p-11f;     // stage 1: the dropped Wl.Xh term
     const bool force_exact = hdr->force_exact != 0 || scale < 1.f;
     const int lane = threadIdx.x & 63;

@@ -437,7 +437,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
             if (e < -100) e = -100;
         }
         const double scale = ldexp(1.0, e);
-        const bool badw = hdr->bad != 0 || !(wn2max * scale * scale <= 1.0e30);
+        const bool badw = hdr->bad != 0 || !(wn2max * scale * scale <= 1.0e30) || !(maxabs * scale < 256.0);   // (256: filter_cut_abs)
         fscale = (float)scale;
         // rounded up by a hair; NaN / Inf / huge codebook: every row takes the exact path
         wn_max = badw ? 0.f : (float)(sqrt(wn2max) * scale * (1.0 + 1e-6));
@@ -948,7 +948,7 @@ __global__ __launch_bounds__(kUpdThreads) void batch_update_prep_kernel(StepArgs
     }
     const double scale = ldexp(1.0, e);
     __syncthreads();
-    const bool badw = flags[0] != 0 || !(wn2max * scale * scale <= 1.0e30);
+    const bool badw = flags[0] != 0 || !(wn2max * scale * scale <= 1.0e30) || !(maxabs * scale < 256.0);   // (256: filter_cut_abs)
     if (tid == 0 && blockIdx.x == 0) {
         hdr_g->amb_count = 0;
         hdr_g->scale = (float)scale;

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
         sexp = max(-100, min(100, sexp));
     }
     const double scale_d = ldexp(1.0, sexp);
-    const bool badw = ctl->bad != 0 || !(wn2max * scale_d * scale_d <= 1.0e30);
+    const bool badw = ctl->bad != 0 || !(wn2max * scale_d * scale_d <= 1.0e30) || !(maxabs * scale_d < 256.0);   // (256: filter_cut_abs)
     const float scale = (float)scale_d;
     const float wn_max = badw ? 0.f : (float)(sqrt(wn2max) * scale_d * (1.0 + 1e-6));
     const bool force_exact = badw;

@@ -462,7 +462,7 @@ __global__ __launch_bounds__(kTailThreads) void batch_tail_kernel(const T *__res
         }
         __syncthreads();
         TAIL_STAMP(5);
-        float fscale, wn_max;
+        float fscale, wn_max, abs_up;
         bool force_exact;
         double scale_next;
         {
@@ -478,6 +478,9 @@ __global__ __launch_bounds__(kTailThreads) void batch_tail_kernel(const T *__res
             fscale = (float)scale;
             wn_max = badw ? 0.f : (float)(sqrt(wn2max) * scale * (1.0 + 1e-6));
             force_exact = badw;
+            // tol_abs holds the cuts inside an MFMA's groups for a scaled codebook below 256 (filter_cut_abs); this step's fragments
+            // carry the previous codebook's scale, so the largest magnitude may have left that range: scale the term with it
+            abs_up = fmaxf(1.f, (float)(maxabs * scale * (1.0 / 256.0) * (1.0 + 1e-6)));
             scale_next = scale_for(maxabs, mu_norm);
         }
         TAIL_STAMP(6);
@@ -583,7 +586,7 @@ __global__ __launch_bounds__(kTailThreads) void batch_tail_kernel(const T *__res
                     s2 = es.a + es.b;
                 }
                 const float xn = __builtin_amdgcn_sqrtf(s2) * 1.001f;
-                const float tol = tol_rel * (xn * wn_max + 0.5f * wn_max * wn_max) + tol_abs * (xn + wn_max);
+                const float tol = tol_rel * (xn * wn_max + 0.5f * wn_max * wn_max) + tol_abs * abs_up * (xn + wn_max);
                 const unsigned nonfinite = (unsigned)((__float_as_uint(s2) & 0x7f800000u) == 0x7f800000u);
                 const long long row = ((long long)(j0 + t) * Wt + u) * 16 + pix;
                 const bool valid = row < S.rows;

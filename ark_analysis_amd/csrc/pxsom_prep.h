@@ -190,26 +190,27 @@ __device__ __forceinline__ void prep_body(const double *wl, int k, int c, Assign
     const double scale = ldexp(1.0, e);
     PXSOM_PHASE_ANY(3);
     if (tid == 0) {
-        const bool badw = s_bad != 0 || !(wn2max * scale * scale <= 1.0e30);
+        // (maxabs * scale < 256 is what filter_cut_abs counts on: it fails only where the exponent clamp above bit)
+        const bool badw = s_bad != 0 || !(wn2max * scale * scale <= 1.0e30) || !(maxabs * scale < 256.0);
         hdr->amb_count = 0;
         hdr->scale = (float)scale;
         // rounded up by a hair; an infinite wn_max makes every row take the exact path
         hdr->wn_max = badw ? 0.f : (float)(sqrt(wn2max) * scale * (1.0 + 1e-6));
         hdr->force_exact = badw ? 1 : 0;  // NaN/Inf/huge codebook: every row takes the exact path
         // coefficient of the rigorous |filter - exact| bound, see DESIGN.md "K7 error bound":
-        //   index packing 2^-(23-idx_bits) (idx_bits low mantissa bits replaced), fp32 accumulation
-        //   (3C+2)*2^-24, split residual 2^-19,
+        //   index packing 2^-(23-idx_bits) (idx_bits low mantissa bits replaced), the matrix unit's group additions
+        //   filter_accum_units * 2^-24 (the cuts inside its groups: tol_abs), split residual 2^-19,
         //   f64->f32 input rounding 2^-23;  tol = 2 * 1.25 * E
         //   centred filter: + 2^-24, the rounding of x' = fl(x * scale - mu_s) (one fused operation)
         const double coef = ldexp(1.0, -(23 - idx_bits)) +
-                            (3.0 * c + 2.0) * ldexp(1.0, -24) + ldexp(1.0, -19) + ldexp(1.0, -23) + (center ? ldexp(1.0, -24) : 0.0);
+                            filter_accum_units(c, 3) * ldexp(1.0, -24) + ldexp(1.0, -19) + ldexp(1.0, -23) + (center ? ldexp(1.0, -24) : 0.0);
         hdr->tol_rel = (float)(2.5 * coef);
         // first stage of the register-resident filter: Wh*Xh alone.  |X'.W' - Xh.Wh| <= (2^-11 + 2^-11 (1 + 2^-11)) |X'||W'|
         // (binary16 unit roundoff 2^-11 on either factor), C products + the bias in the fp32 accumulation
-        const double coef_c = ldexp(1.0, -10) + ldexp(1.0, -20) + ldexp(1.0, -(23 - idx_bits)) + (1.0 * c + 2.0) * ldexp(1.0, -24) +
+        const double coef_c = ldexp(1.0, -10) + ldexp(1.0, -20) + ldexp(1.0, -(23 - idx_bits)) + filter_accum_units(c, 1) * ldexp(1.0, -24) +
                               ldexp(1.0, -23) + (center ? ldexp(1.0, -24) : 0.0);
         hdr->tol_rel_coarse = (float)(2.5 * coef_c);
-        hdr->tol_abs = (float)(2.5 * ldexp(1.0, -24) * sqrt((double)c));  // fp16 subnormal floor
+        hdr->tol_abs = (float)filter_tol_abs(c);  // fp16 subnormal floor + the cuts inside the groups of an MFMA (pxsom_assign.h)
         hdr->x_limit = 60000.0f;
         hdr->nb = nb;
         hdr->nch = nch;

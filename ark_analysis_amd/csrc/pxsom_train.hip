@@ -1850,9 +1850,9 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
     }
     // coefficients of the fused kernels' rigorous |score - exact| bound (DESIGN.md "K7 error bound"; 7 index bits packed
     // into the scores): tol = 2 * 1.25 * E (+ 2^-24: the rounding of the centred row, x' = fl(x * scale - mu_s))
-    const float fused_tol_rel = (float)(2.5 * (ldexp(1.0, -(23 - 7)) + (3.0 * c + 2.0) * ldexp(1.0, -24) + ldexp(1.0, -19) +
+    const float fused_tol_rel = (float)(2.5 * (ldexp(1.0, -(23 - 7)) + pxsom_bmu::filter_accum_units(c, 3) * ldexp(1.0, -24) + ldexp(1.0, -19) +
                                                ldexp(1.0, -23) + ldexp(1.0, -24)));
-    const float fused_tol_abs = (float)(2.5 * ldexp(1.0, -24) * sqrt((double)c));
+    const float fused_tol_abs = (float)pxsom_bmu::filter_tol_abs(c);
     static const bool no_centre = getenv("PXSOM_STEP_NO_CENTRE") != nullptr;   // timing hook
     // Opt-in (PXSOM_TRAIN_PERSISTENT_TAIL): the BMU-only steps at the end of the call (threshold pinned at 0.5: a node's
     // window is the node) as ONE persistent launch on one XCD (pxsom_batch_tail.hip) -- single rank only: the all-reduce of
@@ -1957,7 +1957,7 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
             sa.sat = pxsom_bmu::batch_gain_saturation(sa.q);
                 sa.mu32 = (centred_run && !no_centre) ? mu32 : nullptr;
                 // (5 index bits in the scores -- 6 from 129 nodes on --, three-term split, centred rows)
-                sa.tol_rel = (float)(2.5 * (ldexp(1.0, -(23 - (k > 128 ? 6 : 5))) + (3.0 * c + 2.0) * ldexp(1.0, -24) + ldexp(1.0, -19) + ldexp(1.0, -23) +
+                sa.tol_rel = (float)(2.5 * (ldexp(1.0, -(23 - (k > 128 ? 6 : 5))) + pxsom_bmu::filter_accum_units(c, 3) * ldexp(1.0, -24) + ldexp(1.0, -19) + ldexp(1.0, -23) +
                                             ldexp(1.0, -24)));
                 sa.tol_abs = fused_tol_abs;
                 sa.qmagic = qmagic;
@@ -1985,9 +1985,9 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
             // the generic filter is centred on the run's vector too (binary32 / binary64 rows): + 2^-24, the rounding of
             // x' = fl(x * scale - mu_s)
             sa.mu32 = (centred_run && !no_centre && npk == 0) ? mu32 : nullptr;
-            sa.tol_rel = (float)(2.5 * (ldexp(1.0, -(23 - L.idx_bits)) + (3.0 * c + 2.0) * ldexp(1.0, -24) + ldexp(1.0, -19) +
+            sa.tol_rel = (float)(2.5 * (ldexp(1.0, -(23 - L.idx_bits)) + pxsom_bmu::filter_accum_units(c, 3) * ldexp(1.0, -24) + ldexp(1.0, -19) +
                                         ldexp(1.0, -23) + (sa.mu32 ? ldexp(1.0, -24) : 0.0)));
-            sa.tol_abs = (float)(2.5 * ldexp(1.0, -24) * sqrt((double)c));
+            sa.tol_abs = (float)pxsom_bmu::filter_tol_abs(c);
             int rc = PXSOM_OK;
             if (pxsom_bmu::launch_update_prepare(sa, xdim, ydim, c, ws, L, st, &rc)) {
                 if (rc) return rc;
