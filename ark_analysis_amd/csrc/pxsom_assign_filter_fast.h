@@ -239,6 +239,12 @@ __host__ __device__ inline int acc_stride(int c) { return c | 1; }
 // mini-batch step needs no exact-kernel launch.  One pass over x, one launch.
 // FIX (with ACC; pxsom_assign_sums): the workgroup's table is 64-bit fixed point (FixPoint above), fix_rows_log2 =
 // ceil(log2(rows a workgroup can meet)).
+#ifndef PXSOM_ADD_SCAN       // one-pass kernel: tiles whose neighbouring rows mostly share their label are summed along the row axis first
+#define PXSOM_ADD_SCAN 1
+#endif
+#ifndef PXSOM_ADD_SCAN_MIN   // ... from this many agreeing neighbour pairs of a tile's 60 on (52: runs of eight rows and longer)
+#define PXSOM_ADD_SCAN_MIN 52
+#endif
 template <typename T, int CPL, int NB, int RU, int MODE, bool ACC, bool FIX = false, bool TWO = true>
 __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void bmu_filter_fast(
     const T *__restrict__ x, int64_t n, int c, int64_t ldx, const half8 *__restrict__ wfrag,
@@ -268,6 +274,7 @@ __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void b
     constexpr unsigned kS1Queue = 256;
     int64_t *s1_q = nullptr;
     unsigned s1_n = 0u;   // wave-uniform
+    bool scan_trip = false;   // wave-uniform: this trip's rows are summed along the row axis before they touch the table (ACC + FIX, see there)
     if constexpr (!ACC) {   // (the plain filter has no dynamic LDS: its waves' queues are a static array)
         __shared__ long long s1_plain[4 * kS1Queue];
         s1_q = reinterpret_cast<int64_t *>(s1_plain) + (size_t)(threadIdx.x >> 6) * kS1Queue;
@@ -659,6 +666,74 @@ __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void b
                 const bool fold = c < 4 * CPL;                      // (wave-uniform)
                 const bool cnt_lane = fold && q == 3;
                 const unsigned cnt_base = (unsigned)(k + 1) * (unsigned)cs;
+                // (scan_trip was decided a trip ago, on that trip's last tile -- labels that agreed there agree next door -- so the branch
+                // below does not wait for a vector compare of this trip's labels)
+                const bool scan_now = scan_trip;
+                if constexpr (FIX && PXSOM_ADD_SCAN) {
+                    const unsigned nx3 = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)lab[kTilesPerIter - 1], 0x101 /* row_shl:1 */, 0xf, 0xf, false);
+                    // agreeing neighbour pairs of that tile's 60 (15 per lane row, the four lane rows alike)
+                    scan_trip = fold && __popcll(__ballot(nx3 == lab[kTilesPerIter - 1])) >= PXSOM_ADD_SCAN_MIN;
+                }
+                // Round 5: neighbouring rows that share their label (what images do and the synthetic FOVs do not: the 16 rows of
+                // one ds_add then hit the same words and the instruction is served lane after lane -- 0.30 -> 0.84 ms on rows in
+                // runs of 16 equal labels, profiles/r05/label_coherence.txt).  Where most neighbours agree (a wave-uniform count)
+                // the tile's rows are first summed along the row axis: inclusive prefix sums P of the fixed-point words over the 16
+                // lanes of a lane row (v_add_co / v_addc on row_shr operands, two instructions per step and word), and only the
+                // LAST row e of every run of equal labels touches the table: + P[e] to its own label, - P[e] to the label of the
+                // run that follows (whose own last row adds its P, which contains P[e]): the telescoped sums are the runs' sums,
+                // in the same modular 64-bit arithmetic as the plain adds, so the table ends bit-identical.
+                                if constexpr (FIX && PXSOM_ADD_SCAN)
+                if (__builtin_expect(scan_now, 0)) {   // (out of line: the plain adds below stay one block behind the search)
+#pragma unroll
+                    for (int t = 0; t < kTilesPerIter; t++) {
+                        const unsigned base = __umul24(lab[t], (unsigned)cs), spare = __umul24((unsigned)k, (unsigned)cs);
+                        const unsigned nxt = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)lab[t], 0x101 /* row_shl:1 */, 0xf, 0xf, false);
+                        const bool last = pix == 15;
+                        const bool ends = last || nxt != lab[t];
+                        unsigned lo[2 * NP], hi[2 * NP];
+#pragma unroll
+                        for (int p = 0; p < NP; p++) {
+                            const unsigned long long bx = (unsigned long long)__double_as_longlong((double)keep[t][p].x + fx.magic);
+                            const unsigned long long by = (unsigned long long)__double_as_longlong((double)keep[t][p].y + fx.magic);
+                            const unsigned long long b0 = (p == NP - 1 && cnt_lane) ? 1ull : bx;   // (the count lane's first word counts rows)
+                            lo[2 * p] = (unsigned)b0;
+                            hi[2 * p] = (unsigned)(b0 >> 32);
+                            lo[2 * p + 1] = (unsigned)by;
+                            hi[2 * p + 1] = (unsigned)(by >> 32);
+                        }
+#define PXSOM_SCAN_STEP(SHR)                                                                                                         \
+_Pragma("unroll") for (int j = 0; j < 2 * NP; j++)                                                                                \
+    asm volatile("v_add_co_u32_dpp %0, vcc, %0, %0 row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"               \
+                 "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:1"                \
+                 : "+v"(lo[j]), "+v"(hi[j])::"vcc");
+                        PXSOM_SCAN_STEP(1)
+                        PXSOM_SCAN_STEP(2)
+                        PXSOM_SCAN_STEP(4)
+                        PXSOM_SCAN_STEP(8)
+#undef PXSOM_SCAN_STEP
+                        if (ends) {
+                            const unsigned base_n = __umul24(nxt < (unsigned)k ? nxt : (unsigned)k, (unsigned)cs);
+#pragma unroll
+                            for (int p = 0; p < NP; p++) {
+                                const bool own = q * CPL + 2 * p <= c - 2;
+                                const unsigned off = (unsigned)(own ? q * CPL + 2 * p : 0);
+                                const bool counts_here = p == NP - 1 && cnt_lane;
+                                const unsigned ip = (own ? base : spare) + off, in = (own ? base_n : spare) + off;
+                                const unsigned ip0 = counts_here ? cnt_base + lab[t] : ip;
+                                const unsigned in0 = counts_here ? cnt_base + (nxt < (unsigned)k ? nxt : (unsigned)k) : in;
+                                const unsigned long long p0 = ((unsigned long long)hi[2 * p] << 32) | lo[2 * p];
+                                const unsigned long long p1 = ((unsigned long long)hi[2 * p + 1] << 32) | lo[2 * p + 1];
+                                __hip_atomic_fetch_add(lu + ip0, p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                __hip_atomic_fetch_add(lu + ip + 1, p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                if (!last) {
+                                    __hip_atomic_fetch_add(lu + in0, 0ull - p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    __hip_atomic_fetch_add(lu + in + 1, 0ull - p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                }
+                            }
+                        }
+                    }
+                }
+                if (__builtin_expect(!scan_now, 1))
 #pragma unroll
                 for (int t = 0; t < kTilesPerIter; t++) {
                     const unsigned base = __umul24(lab[t], (unsigned)cs), spare = __umul24((unsigned)k, (unsigned)cs);   // (v_mul_lo_u32 runs at quarter rate)

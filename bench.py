@@ -507,6 +507,18 @@ def main():
                                   "node pairs 1e-2 apart": timed_assign(near),
                                   "note": "labels of all rows, bit-equal to the oracle in every case (tests); time follows the rows the "
                                           "filter lists for the exact binary64 path"}
+        # Neighbouring rows that share their label -- what images look like and the synthetic FOVs do not: the same rows in runs of
+        # 64 equal labels (sorted by label, the runs shuffled).  The 16 rows of one LDS atomic then hit the same table words; the
+        # one-pass kernel sums such tiles along the row axis first (scripts/debug/label_coherence_probe.py has the other run lengths).
+        order = torch.argsort(labels.long(), stable=True)
+        runs = n_all // 64
+        idx = (torch.randperm(runs, device=dev).unsqueeze(1) * 64 + torch.arange(64, device=dev).unsqueeze(0)).reshape(-1)
+        x_keep = x_all
+        x_all = x_all[order[idx]].contiguous()
+        del order, idx
+        out["operating_range"]["rows in runs of 64 equal labels"] = timed_assign(w)
+        x_all = x_keep
+        del x_keep
 
     if args.config == "cfg5":
         # "+ consensus meta-cluster" (BASELINE.json configs[4]): Ward on the K x C mean table on the host (the

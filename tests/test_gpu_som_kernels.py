@@ -845,6 +845,42 @@ def test_assign_sums_one_pass_equals_two_passes(gpu, oracle, n, c, k, dtype):
     np.testing.assert_allclose(s3.cpu().numpy(), s1.cpu().numpy(), rtol=1e-13, atol=0)
 
 
+@pytest.mark.parametrize("run", [1000, 64, 16, 9, 5])
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+def test_assign_sums_on_label_coherent_rows(gpu, oracle, run, dtype):
+    """Rows whose neighbours share their label (what images look like; the synthetic FOVs do not): the one-pass kernel sums such
+    tiles along the row axis before they touch its table (prefix sums over the 16 rows of a tile, one add and one subtraction per
+    run of equal labels).  Labels against the oracle; counts bit for bit and means within the fixed-point bound against the
+    two-pass tables -- with runs longer than, equal to and shorter than a tile, runs that straddle tiles, listed rows (duplicate
+    nodes, an oversized row) inside the runs, and the table equal from run to run."""
+    n, c, k = 70_000, 22, 100
+    x = synth.make_fov_numpy(n, c, seed=95, dtype=np.float32)
+    w = _codebook(x.astype(np.float64), k, seed=6)
+    w[k - 1] = w[7]                                    # duplicate nodes: their rows are listed, inside the runs
+    first, _ = oracle.map_data_to_nodes(w, x.astype(np.float64))
+    order = np.argsort(first, kind="stable")
+    pieces = n // run
+    perm = np.random.RandomState(3).permutation(pieces)
+    idx = (perm[:, None] * run + np.arange(run)[None, :]).reshape(-1)
+    x = np.ascontiguousarray(x[order][np.concatenate([idx, np.arange(pieces * run, n)])]).astype(dtype)
+    if dtype != np.float16:
+        x[4_000, 0] = 5.0e4                            # a row the filter lists for its size, in the middle of a run
+    xd, wd = torch.from_numpy(x).to(gpu), torch.from_numpy(w).to(gpu)
+    l2, _ = sd.assign(xd, wd)
+    s2, c2 = sd.cluster_sums(xd, l2, k)
+    l1, s1, c1 = sd.assign_sums(xd, wd)
+    want, _ = oracle.map_data_to_nodes(w, x.astype(np.float64))
+    np.testing.assert_array_equal(l1.cpu().numpy(), want)
+    assert torch.equal(l1, l2) and torch.equal(c1, c2)
+    cnt = np.maximum(c2.cpu().numpy(), 1)[:, None].astype(np.float64)
+    mean1, mean2 = s1.cpu().numpy() / cnt, s2.cpu().numpy() / cnt
+    wmax = float(np.abs(w).max())
+    assert np.all(np.abs(mean1 - mean2) <= 1e-6 * np.abs(mean2) + 1e-10 * wmax), float(np.abs(mean1 - mean2).max())
+    l3, s3, c3 = sd.assign_sums(xd, wd)
+    assert torch.equal(l3, l1) and torch.equal(c3, c1)
+    np.testing.assert_allclose(s3.cpu().numpy(), s1.cpu().numpy(), rtol=1e-13, atol=0)
+
+
 @pytest.mark.parametrize("n", [2_000, 20_000, 150_000])
 def test_assign_sums_small_launch_large_vouched_value(gpu, oracle, n):
     """A row the filter VOUCHES for may hold values up to 2^16 / scale -- a hundred times the codebook's largest entry.
