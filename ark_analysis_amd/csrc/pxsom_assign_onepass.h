@@ -78,6 +78,7 @@ __global__ __launch_bounds__(THREADS, WPE) void bmu_onepass_kernel(const T *__re
     unsigned *amb_n = reinterpret_cast<unsigned *>(amb_q + kOneAmbQueue);
     int64_t *s1_q = reinterpret_cast<int64_t *>(amb_n + 4) + (size_t)(threadIdx.x >> 6) * kOneS1Queue;   // this wave's
     unsigned s1_n = 0u;   // wave-uniform
+    bool scan_trip = false;   // wave-uniform: this trip's tiles are summed along the row axis before they touch the table (see the adds)
     const int tid = threadIdx.x;
     {
         // the codebook: row-major copy (in the table's storage, free until the first add) for prep_body, transposed copy for the
@@ -380,6 +381,67 @@ __global__ __launch_bounds__(THREADS, WPE) void bmu_onepass_kernel(const T *__re
             // count instruction (as bmu_filter_fast since round 5)
             const bool fold = c < 4 * CPL;                      // (wave-uniform)
             const bool cnt_lane = fold && q == 3;
+            // Label-coherent rows (images): as bmu_filter_fast's adds (pxsom_assign_filter_fast.h, round 5) -- where most neighbours of a
+            // tile agree, inclusive prefix sums of the fixed-point words along the tile's 16 rows, then one add and one subtraction per
+            // run of equal labels; decided a trip ahead on the last tile's labels, the table bit-identical either way.
+            const bool scan_now = scan_trip;
+            if constexpr (FIXT && PXSOM_ADD_SCAN) {
+                const unsigned nxl = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)lr[kOneTiles - 1], 0x101 /* row_shl:1 */, 0xf, 0xf, false);
+                scan_trip = fold && __popcll(__ballot(nxl == lr[kOneTiles - 1])) >= PXSOM_ADD_SCAN_MIN;
+            }
+            if constexpr (FIXT && PXSOM_ADD_SCAN)
+            if (__builtin_expect(scan_now, 0)) {
+#pragma unroll
+                for (int t = 0; t < kOneTiles; t++) {
+                    const unsigned lab = lr[t];
+                    const unsigned base = __umul24(lab, (unsigned)cs), spare = __umul24((unsigned)k, (unsigned)cs);
+                    const unsigned nxt = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)lab, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
+                    const bool last = pix == 15;
+                    const bool ends = last || nxt != lab;
+                    unsigned lo[2 * NP], hi[2 * NP];
+#pragma unroll
+                    for (int p = 0; p < NP; p++) {
+                        const unsigned long long bx = (unsigned long long)__double_as_longlong((double)raw[t][p].x + fx.magic);
+                        const unsigned long long by = (unsigned long long)__double_as_longlong((double)raw[t][p].y + fx.magic);
+                        const unsigned long long b0 = (p == NP - 1 && cnt_lane) ? 1ull : bx;   // (the count lane's first word counts rows)
+                        lo[2 * p] = (unsigned)b0;
+                        hi[2 * p] = (unsigned)(b0 >> 32);
+                        lo[2 * p + 1] = (unsigned)by;
+                        hi[2 * p + 1] = (unsigned)(by >> 32);
+                    }
+#define PXSOM_SCAN_STEP(SHR)                                                                                                         \
+    _Pragma("unroll") for (int j = 0; j < 2 * NP; j++)                                                                                \
+        asm volatile("v_add_co_u32_dpp %0, vcc, %0, %0 row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"               \
+                     "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:1"                \
+                     : "+v"(lo[j]), "+v"(hi[j])::"vcc");
+                    PXSOM_SCAN_STEP(1)
+                    PXSOM_SCAN_STEP(2)
+                    PXSOM_SCAN_STEP(4)
+                    PXSOM_SCAN_STEP(8)
+#undef PXSOM_SCAN_STEP
+                    if (ends) {
+                        const unsigned nlab = nxt < (unsigned)k ? nxt : (unsigned)k;
+                        const unsigned base_n = __umul24(nlab, (unsigned)cs), cnt_base = (unsigned)(k + 1) * (unsigned)cs;
+#pragma unroll
+                        for (int p = 0; p < NP; p++) {
+                            const bool real_slot = q * CPL + 2 * p <= c - 2;
+                            const unsigned off = (unsigned)(real_slot ? q * CPL + 2 * p : 0);
+                            const bool counts_here = p == NP - 1 && cnt_lane;
+                            const unsigned ip = (real_slot ? base : spare) + off, in = (real_slot ? base_n : spare) + off;
+                            const unsigned ip0 = counts_here ? cnt_base + lab : ip, in0 = counts_here ? cnt_base + nlab : in;
+                            const unsigned long long p0 = ((unsigned long long)hi[2 * p] << 32) | lo[2 * p];
+                            const unsigned long long p1 = ((unsigned long long)hi[2 * p + 1] << 32) | lo[2 * p + 1];
+                            __hip_atomic_fetch_add(lu + ip0, p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(lu + ip + 1, p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (!last) {
+                                __hip_atomic_fetch_add(lu + in0, 0ull - p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                __hip_atomic_fetch_add(lu + in + 1, 0ull - p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                        }
+                    }
+                }
+            }
+            if (__builtin_expect(!scan_now, 1))
 #pragma unroll
             for (int t = 0; t < kOneTiles; t++) {
                 const unsigned lab = lr[t];

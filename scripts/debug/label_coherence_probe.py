@@ -9,6 +9,9 @@ from ark_analysis_amd import synth, som_device as sd
 dev = torch.device("cuda:0")
 n, c, k = 10 << 20, 22, 100
 x = synth.make_fov_torch(n, c, seed=7, device=dev)
+if len(sys.argv) > 1 and sys.argv[1] == "f64":     # what the drop-in classes hold (the two-tile kernel, pxsom_assign_onepass.h)
+    n = 4 << 20
+    x = x[:n].double().contiguous()
 w = x[torch.randperm(n, device=dev)[:k]].double().contiguous()
 for _ in range(3):   # a few Lloyd steps: a codebook like a trained one
     lab, _ = sd.assign(x, w)

@@ -846,13 +846,14 @@ def test_assign_sums_one_pass_equals_two_passes(gpu, oracle, n, c, k, dtype):
 
 
 @pytest.mark.parametrize("run", [1000, 64, 16, 9, 5])
-@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+@pytest.mark.parametrize("dtype", [np.float32, np.float16, np.float64])
 def test_assign_sums_on_label_coherent_rows(gpu, oracle, run, dtype):
     """Rows whose neighbours share their label (what images look like; the synthetic FOVs do not): the one-pass kernel sums such
     tiles along the row axis before they touch its table (prefix sums over the 16 rows of a tile, one add and one subtraction per
     run of equal labels).  Labels against the oracle; counts bit for bit and means within the fixed-point bound against the
     two-pass tables -- with runs longer than, equal to and shorter than a tile, runs that straddle tiles, listed rows (duplicate
-    nodes, an oversized row) inside the runs, and the table equal from run to run."""
+    nodes, an oversized row) inside the runs, and the table equal from run to run.  binary64 rows take the two-tile kernel
+    (pxsom_assign_onepass.h), which carries the same adds."""
     n, c, k = 70_000, 22, 100
     x = synth.make_fov_numpy(n, c, seed=95, dtype=np.float32)
     w = _codebook(x.astype(np.float64), k, seed=6)
