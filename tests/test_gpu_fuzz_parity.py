@@ -116,6 +116,20 @@ def test_fuzz_assign_and_sums(oracle):
         # codebook's largest magnitude; 2^-28 covers workgroups of up to 2 K rows
         wmax = float(np.abs(w[np.isfinite(w)]).max()) if np.isfinite(w).any() else 0.0
         _assert_sums_close(oracle, s2.cpu().numpy(), ws, host, want, k, tag + " (one pass)", per_row=wmax * 2.0 ** -28)
+        if host.shape[0] >= 64 and rs.rand() < 0.3:
+            # the same rows with neighbours that share their label (what images look like): runs of equal labels, shuffled --
+            # the one-pass kernels sum such tiles along the row axis before they touch their tables
+            order = np.argsort(want, kind="stable")
+            run = int(rs.choice([3, 8, 16, 40, 1000]))
+            pieces = max(1, host.shape[0] // run)
+            perm = rs.permutation(pieces)
+            idx = np.concatenate([(perm[:, None] * run + np.arange(run)[None, :]).reshape(-1), np.arange(pieces * run, host.shape[0])])
+            idx = order[idx[idx < host.shape[0]]]
+            xs = x[torch.from_numpy(idx).cuda()].contiguous()
+            lab3, s3, c3 = som_device.assign_sums(xs, torch.from_numpy(w).cuda())
+            assert np.array_equal(lab3.cpu().numpy(), want[idx]), tag + " (one pass, runs of %d)" % run
+            assert np.array_equal(c3.cpu().numpy(), wc), tag + " (one pass, runs of %d)" % run
+            _assert_sums_close(oracle, s3.cpu().numpy(), ws, host, want, k, tag + " (one pass, runs of %d)" % run, per_row=wmax * 2.0 ** -28)
 
 
 def test_fuzz_batch_training(oracle):
