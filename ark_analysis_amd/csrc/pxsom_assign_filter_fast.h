@@ -736,7 +736,12 @@ _Pragma("unroll") for (int j = 0; j < 2 * NP; j++)                              
                 if (__builtin_expect(!scan_now, 1))
 #pragma unroll
                 for (int t = 0; t < kTilesPerIter; t++) {
+#ifdef PXSOM_TIMING_REPLICA   // (timing build ONLY, results are wrong: rows of odd pix add into a second table laid over the codebook copy)
+                    const unsigned base = __umul24(lab[t], (unsigned)cs) + ((pix & 1) ? (unsigned)(((k + 1) * (cs + 1) + 1) & ~1) : 0u),
+                                   spare = __umul24((unsigned)k, (unsigned)cs);
+#else
                     const unsigned base = __umul24(lab[t], (unsigned)cs), spare = __umul24((unsigned)k, (unsigned)cs);   // (v_mul_lo_u32 runs at quarter rate)
+#endif
 #pragma unroll
                     for (int p = 0; p < NP; p++) {
                         const bool own = q * CPL + 2 * p <= c - 2;
