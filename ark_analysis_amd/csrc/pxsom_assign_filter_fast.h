@@ -668,8 +668,10 @@ __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void b
                 const unsigned cnt_base = (unsigned)(k + 1) * (unsigned)cs;
                 // (scan_trip was decided a trip ago, on that trip's last tile -- labels that agreed there agree next door -- so the branch
                 // below does not wait for a vector compare of this trip's labels)
-                const bool scan_now = scan_trip;
-                if constexpr (FIX && PXSOM_ADD_SCAN) {
+                // (rows that come out of the wave's queue are not neighbours -- and the idle lanes of a short batch all carry the spare
+                // label: such a trip neither takes the decision nor makes the next one)
+                const bool scan_now = QUEUED ? false : scan_trip;
+                if constexpr (FIX && PXSOM_ADD_SCAN && !QUEUED) {
                     const unsigned nx3 = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)lab[kTilesPerIter - 1], 0x101 /* row_shl:1 */, 0xf, 0xf, false);
                     // agreeing neighbour pairs of that tile's 60 (15 per lane row, the four lane rows alike)
                     scan_trip = fold && __popcll(__ballot(nx3 == lab[kTilesPerIter - 1])) >= PXSOM_ADD_SCAN_MIN;

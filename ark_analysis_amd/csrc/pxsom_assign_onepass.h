@@ -384,8 +384,10 @@ __global__ __launch_bounds__(THREADS, WPE) void bmu_onepass_kernel(const T *__re
             // Label-coherent rows (images): as bmu_filter_fast's adds (pxsom_assign_filter_fast.h, round 5) -- where most neighbours of a
             // tile agree, inclusive prefix sums of the fixed-point words along the tile's 16 rows, then one add and one subtraction per
             // run of equal labels; decided a trip ahead on the last tile's labels, the table bit-identical either way.
-            const bool scan_now = scan_trip;
-            if constexpr (FIXT && PXSOM_ADD_SCAN) {
+            // (rows out of the wave's queue are not neighbours, the idle lanes of a short batch all carry the spare label: such a trip
+            // neither takes the decision nor makes the next one)
+            const bool scan_now = FULL ? false : scan_trip;
+            if constexpr (FIXT && PXSOM_ADD_SCAN && !FULL) {
                 const unsigned nxl = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)lr[kOneTiles - 1], 0x101 /* row_shl:1 */, 0xf, 0xf, false);
                 scan_trip = fold && __popcll(__ballot(nxl == lr[kOneTiles - 1])) >= PXSOM_ADD_SCAN_MIN;
             }
