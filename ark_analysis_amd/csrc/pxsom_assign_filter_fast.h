@@ -242,8 +242,8 @@ __host__ __device__ inline int acc_stride(int c) { return c | 1; }
 #ifndef PXSOM_ADD_SCAN       // one-pass kernel: tiles whose neighbouring rows mostly share their label are summed along the row axis first
 #define PXSOM_ADD_SCAN 1
 #endif
-#ifndef PXSOM_ADD_SCAN_MIN   // ... from this many agreeing neighbour pairs of a tile's 60 on (52: runs of eight rows and longer)
-#define PXSOM_ADD_SCAN_MIN 52
+#ifndef PXSOM_ADD_SCAN_MIN   // ... from this many agreeing neighbour pairs of a tile's 60 on (47: runs of five rows and longer; runs of four cost the same either way)
+#define PXSOM_ADD_SCAN_MIN 47
 #endif
 template <typename T, int CPL, int NB, int RU, int MODE, bool ACC, bool FIX = false, bool TWO = true>
 __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void bmu_filter_fast(
