@@ -880,6 +880,11 @@ def test_assign_sums_on_label_coherent_rows(gpu, oracle, run, dtype):
     l3, s3, c3 = sd.assign_sums(xd, wd)
     assert torch.equal(l3, l1) and torch.equal(c3, c1)
     np.testing.assert_allclose(s3.cpu().numpy(), s1.cpu().numpy(), rtol=1e-13, atol=0)
+    # the two-pass sums kernel on the same rows (groups of rows that all carry one label are added up across the lane slots first)
+    so, co = oracle.cluster_sums(x.astype(np.float64), want, k)
+    np.testing.assert_array_equal(c2.cpu().numpy(), co)
+    mag, _ = oracle.cluster_sums(np.abs(x.astype(np.float64)), want, k)
+    assert np.all(np.abs(s2.cpu().numpy() - so) <= 1e-12 * mag), float(np.abs(s2.cpu().numpy() - so).max())
 
 
 @pytest.mark.parametrize("n", [2_000, 20_000, 150_000])
