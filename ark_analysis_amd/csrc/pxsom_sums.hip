@@ -124,13 +124,6 @@ __global__ __launch_bounds__(256) void cluster_sums_pairs_kernel(const T *__rest
             }
             return __ballot(cl && lab != k && lane < RL);
         };
-        // a group whose rows ALL carry one label (neighbouring rows that share their label: what images look like, round 5): bit
-        // set for every row of such a group.  Its rows are added up across the lane slots first and applied once.
-        auto uniform_mask = [&](int lab) -> unsigned long long {
-            if (RPI == 1) return 0ull;
-            const int base = lane / RPI * RPI;
-            return __ballot(__shfl(lab, base) == lab && lane < RL);
-        };
         bits_t val[U];
         int lv_cur[NL], lv_nxt[NL], lv_far[NL];   // labels two tiles ahead, requested before the tile's values
         load_labels(0, lv_cur);
@@ -145,13 +138,12 @@ __global__ __launch_bounds__(256) void cluster_sums_pairs_kernel(const T *__rest
         unsigned tile_off = TR * gstep / RPI;
         for (int rel0 = 0; rel0 < lim; rel0 += TR, tile_off += TR * gstep / RPI) {
             load_labels(rel0 + 2 * TR, lv_far);
-            unsigned long long cm[NL], um[NL];
+            unsigned long long cm[NL];
             int row_bytes[NL];
 #pragma unroll
             for (int i = 0; i < NL; i++) {
                 if (lv_cur[i] < k) atomicAdd(&cnt[lv_cur[i]], 1u);
                 cm[i] = clash_mask(lv_cur[i]);
-                um[i] = uniform_mask(lv_cur[i]);
                 row_bytes[i] = (int)__umul24(lv_cur[i], c * 8);
             }
             int word[U];
@@ -170,16 +162,6 @@ __global__ __launch_bounds__(256) void cluster_sums_pairs_kernel(const T *__rest
                 off += gstep;
                 if (!((cm[g * RPI / RL] >> (g * RPI % RL)) & ((1ull << RPI) - 1))) {
                     *wp = *wp + v;
-                } else if (((um[g * RPI / RL] >> (g * RPI % RL)) & ((1ull << RPI) - 1)) == ((1ull << RPI) - 1)) {
-                    // one label for the whole group: lane slot s holds row s's pair -- slot 0 collects the group's sum and applies it
-                    d2 t = v;
-#pragma unroll
-                    for (int s = 1; s < RPI; s++) {
-                        const int src = (lane + s * pairs) & 63;   // (every lane takes part in every exchange; only slot 0's sums are used)
-                        t[0] += __shfl(v[0], src);
-                        t[1] += __shfl(v[1], src);
-                    }
-                    if (slot == 0) *wp = *wp + t;
                 } else {
                     // one row at a time.  The fences keep the RPI predicated updates apart: to the compiler they
                     // are mutually exclusive branches of one thread, which it may fold into a single update

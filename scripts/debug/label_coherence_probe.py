@@ -51,7 +51,7 @@ print("rows as generated:            labels + mean table %.3f ms, labels only %.
 for name, idx in (("sorted by label", order), ("runs of 256 equal labels", runs(256)), ("runs of 64", runs(64)), ("runs of 16", runs(16)), ("runs of 8", runs(8)), ("runs of 6", runs(6)), ("runs of 5", runs(5)), ("runs of 4", runs(4)), ("runs of 2", runs(2))):
     xs = x[idx].contiguous()
     ms, means = timed(xs, "assign_means")
-    ok = torch.allclose(means, base_means, rtol=1e-9 if xs.shape[0] == n else 1e-4, atol=0)
+    ok = torch.allclose(means, base_means, rtol=1e-9, atol=0) if xs.shape[0] == n else "n/a (a few rows left out)"
     print("%-28s  labels + mean table %.3f ms, labels only %.3f ms, sums kernel alone %.3f ms  (means equal to the unsorted run's within 1e-9: %s)"
           % (name + ":", ms, timed(xs, "assign")[0], timed(xs, "cluster_sums")[0], ok))
     del xs
