@@ -737,6 +737,7 @@ __global__ __launch_bounds__(NT) void cluster_sums_kernel(const T *__restrict__ 
                 // s_waitcnt right behind it: one serialised L2 round trip per vector, which held this kernel at a
                 // quarter of the LDS atomic rate)
                 const int64_t last_row = r1 - r0 - 1;
+                const bool rows_of_vectors = c % VEC == 0;   // (wave-uniform)
                 for (int64_t v0 = tid; v0 < nvec; v0 += 4 * NT) {
                     T val[4][VEC];
                     int lab_a[4], lab_b[4], ch0[4];
@@ -757,6 +758,52 @@ __global__ __launch_bounds__(NT) void cluster_sums_kernel(const T *__restrict__ 
                             vch -= c;
                             vrow++;
                         }
+                    }
+                    // Round 5: rows of a whole number of vectors (c % VEC == 0: 40 binary16 channels, 100 binary32 columns): a vector lies
+                    // in ONE row, so its eight (four) adds go to consecutive words of one table row -- no per-element choice between two
+                    // labels, no test for zero (a zero adds nothing), the element's place in the instruction's offset field.  Timing builds
+                    // had shown what bounds this kernel: not HBM (0.353 ms of 0.402 without its loads), not the LDS atomics (0.364 without
+                    // them), but the dozen vector instructions per ELEMENT around them (profiles/r05/sums_loads_in_flight.txt).
+                    if (rows_of_vectors) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const bool ok_a = (unsigned)lab_a[u] < (unsigned)k;
+                            const int base = ok_a ? lab_a[u] * cs + ch0[u] : k * cs;
+                            bool plain = true;
+                            if constexpr (TableAdd<T>::kFixed) {
+                                unsigned raw[4], reach = 0u;
+                                __builtin_memcpy(raw, val[u], 16);
+#pragma unroll
+                                for (int d = 0; d < 4; d++) reach |= (raw[d] & 0x7fff7fffu) + 0x04000400u;
+                                plain = (reach & 0x80008000u) == 0u;   // (no Inf / NaN among the eight)
+                                if (plain) {
+                                    unsigned long long *tp = reinterpret_cast<unsigned long long *>(ls) + base;
+#pragma unroll
+                                    for (int i = 0; i < VEC; i++) {
+                                        const double shifted = (double)val[u][i] + 0x1.8p+28;
+                                        __hip_atomic_fetch_add(tp + i, (unsigned long long)__double_as_longlong(shifted) - 0x41B8000000000000ull,
+                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    }
+                                }
+                            } else {
+                                if (ok_a) {
+                                    double *tp = ls + base;
+#pragma unroll
+                                    for (int i = 0; i < VEC; i++)
+                                        __hip_atomic_fetch_add(tp + i, (double)val[u][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                }
+                            }
+                            if (plain) {
+                                if (ok_a && ch0[u] == 0) atomicAdd(&lc[lab_a[u]], 1u);
+                            } else if (ok_a) {
+#pragma unroll
+                                for (int i = 0; i < VEC; i++) {
+                                    TableAdd<T>::add(ls, (size_t)lab_a[u] * cs + ch0[u] + i, val[u][i], sums, (size_t)lab_a[u] * c + ch0[u] + i);
+                                    if (ch0[u] + i == 0) atomicAdd(&lc[lab_a[u]], 1u);
+                                }
+                            }
+                        }
+                        continue;
                     }
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
