@@ -748,7 +748,9 @@ __global__ __launch_bounds__(NT) void cluster_sums_kernel(const T *__restrict__ 
                         const u4 raw = *reinterpret_cast<const u4 *>(xb + VEC * (ok ? v : nvec - 1));
                         __builtin_memcpy(val[u], &raw, 16);
                         const int64_t row = vrow < last_row ? vrow : last_row, row2 = vrow + 1 < last_row ? vrow + 1 : last_row;
-                        const int la = labels[r0 + row] - 1, lb2 = labels[r0 + row2] - 1;
+                        // (rows of whole vectors never look at the second label: its load is the third of every four vector-memory
+                        // instructions of this loop)
+                        const int la = labels[r0 + row] - 1, lb2 = rows_of_vectors ? -1 : labels[r0 + row2] - 1;
                         lab_a[u] = ok ? la : -1;
                         lab_b[u] = (ok && vrow + 1 <= last_row) ? lb2 : -1;
                         ch0[u] = vch;
