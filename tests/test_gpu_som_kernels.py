@@ -706,6 +706,35 @@ def test_assign_full_size_sampled_against_oracle(gpu, oracle):
     assert int(cnt.sum()) == n
 
 
+def test_mean_table_full_size_does_not_depend_on_the_row_order(gpu, oracle):
+    """BASELINE config 2 size (10 x 1024^2 x 22 fp32, K = 100), labels + mean table in one pass: the same rows as generated,
+    sorted by label and in shuffled runs of 7 equal labels -- the orders that send the table adds through the plain path, the
+    row-axis path and a mixture of both -- give the same counts bit for bit, labels that are the permutation of each other,
+    tables within the fixed-point bound; a sample of the sorted order against the oracle."""
+    n, c, k = 10 * 1024 * 1024, 22, 100
+    x = synth.make_fov_torch(n, c, seed=1001, device=gpu)
+    wd = x[torch.randperm(n, device=gpu)[:k]].to(torch.float64).contiguous()
+    l0, s0, c0 = sd.assign_sums(x, wd)
+    assert int(c0.sum()) == n
+    order = torch.argsort(l0.long(), stable=True)
+    run = 7
+    pieces = n // run
+    idx7 = (torch.randperm(pieces, device=gpu).unsqueeze(1) * run + torch.arange(run, device=gpu).unsqueeze(0)).reshape(-1)
+    idx7 = torch.cat([order[idx7], order[pieces * run:]])
+    wmax = float(wd.abs().max())
+    for idx in (order, idx7):
+        xs = x[idx].contiguous()
+        l1, s1, c1 = sd.assign_sums(xs, wd)
+        assert torch.equal(l1, l0[idx]) and torch.equal(c1, c0)
+        cnt = c0.clamp(min=1).to(torch.float64).unsqueeze(1)
+        err = ((s1 - s0) / cnt).abs()
+        assert bool((err <= 1e-6 * (s0 / cnt).abs() + 1e-10 * wmax).all()), float(err.max())
+        del xs
+    pick = torch.randperm(n, device=gpu)[:100_000]
+    want, _ = oracle.map_data_to_nodes(wd.cpu().numpy(), x[order[pick]].double().cpu().numpy())
+    np.testing.assert_array_equal(l0[order[pick]].cpu().numpy(), want)
+
+
 def test_cell_som_shape_full_size_properties(gpu, oracle):
     """BASELINE config 4 (cell SOM: 1e6 cells x 100 features, 10x10 SOM) at full size: batch training leaves a
     finite codebook whose every mini-batch statistic accounts for every row; labels of a random sample equal
