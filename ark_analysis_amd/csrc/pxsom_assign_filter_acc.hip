@@ -11,14 +11,14 @@
 namespace pxsom_bmu {
 namespace {
 
-template <typename T, int CPL, bool FIX>
+template <typename T, int CPL, bool FIX, bool FOLD = true>
 void launch_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels, double *stats,
                 const double *w, hipStream_t st)
 {
-    auto kern = bmu_filter_fast<T, CPL, 7, 1, 0, true, FIX>;
+    auto kern = bmu_filter_fast<T, CPL, 7, 1, 0, true, FIX, FOLD>;
     // table (first the row-major codebook prep reads) | transposed codebook | fragments | bias | header copy | listed-row queue:
-    // 62 KB at k = 100, c = 22 -- two workgroups per CU
-    const size_t lds = ((((size_t)(L.k + 1) * (acc_stride(c) + 1) + 1) & ~(size_t)1) + (PXSOM_FAST_WGS < 3 ? (size_t)L.k * c : 0)) * sizeof(double) +
+    // 63 KB at k = 100, c = 22 -- two workgroups per CU
+    const size_t lds = (acc_table_words(L.k, c, CPL, FIX) + (PXSOM_FAST_WGS < 3 ? (size_t)L.k * c : 0)) * sizeof(double) +
                        (size_t)7 * 2 * 64 * sizeof(half8) + (size_t)7 * 64 * sizeof(f32x4) + kHdrBytes +
                        256 * sizeof(int64_t) + 16 +   // + queue of listed rows and its counter
                        4 * 256 * sizeof(int64_t);    // + the four waves' queues of rows that wait for the full search
@@ -79,28 +79,22 @@ void launch_onepass(const T *x, int64_t n, int c, int64_t ldx, const Layout &L, 
                        fix_rows_log2);
 }
 
-// PXSOM_ONEPASS=1 takes the three-waves-per-SIMD kernel (opt-in: measured slower; read once)
-bool onepass_enabled()
-{
-    static const bool on = [] {
-        const char *e = std::getenv("PXSOM_ONEPASS");
-        return e && e[0] == '1';
-    }();
-    return on;
-}
-
 }  // namespace
 
 template <typename T>
 void launch_filter_fast_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels,
                             double *stats, const double *w, hipStream_t st, bool fixed)
 {
-#define PXSOM_ACC(CPL)                                                            \
-    (fixed ? launch_acc<T, CPL, true>(x, n, c, ldx, ws, L, labels, stats, w, st)  \
+    // (fixed-point tables: the kernel that finds a slot past the row's end to count the rows in, c < 4 CPL, or the one that counts
+    // them with an instruction of its own)
+#define PXSOM_ACC(CPL)                                                                                           \
+    (fixed ? (c < 4 * CPL ? launch_acc<T, CPL, true, true>(x, n, c, ldx, ws, L, labels, stats, w, st)            \
+                          : launch_acc<T, CPL, true, false>(x, n, c, ldx, ws, L, labels, stats, w, st))          \
            : launch_acc<T, CPL, false>(x, n, c, ldx, ws, L, labels, stats, w, st))
     // binary64 rows (what the drop-in classes hold) ALWAYS take the two-tile kernel -- fixed-point or binary64 tables --: it is the
     // one without spills (bmu_filter_fast kept four tiles of binary64 rows in flight and spilled 28 - 138 VGPRs; its binary64
-    // instantiations are gone).  binary32 / binary16 rows, C <= 24, fixed-point tables: opt-in (measured slower).
+    // instantiations are gone).  On binary32 / binary16 rows it was measured slower (0.297 against 0.262 ms, profiles/r05) and is
+    // not built for them.
     if constexpr (sizeof(T) == 8) {
 #define PXSOM_ONE64(CPL) (fixed ? launch_onepass<T, CPL, 1>(x, n, c, ldx, L, labels, stats, w, st) \
                                 : launch_onepass<T, CPL, 2>(x, n, c, ldx, L, labels, stats, w, st))
@@ -115,15 +109,6 @@ void launch_filter_fast_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws,
 #undef PXSOM_ONE64
         return;
     } else {
-    if (fixed && L.cpl <= 6 && onepass_enabled()) {
-        if (L.cpl == 6)
-            launch_onepass<T, 6>(x, n, c, ldx, L, labels, stats, w, st);
-        else if (L.cpl == 4)
-            launch_onepass<T, 4>(x, n, c, ldx, L, labels, stats, w, st);
-        else
-            launch_onepass<T, 2>(x, n, c, ldx, L, labels, stats, w, st);
-        return;
-    }
     if (L.cpl == 6)
         PXSOM_ACC(6);
     else if (L.cpl == 8)

@@ -54,6 +54,13 @@ __device__ __forceinline__ F2 xchg32(float v)
     return {__uint_as_float(r[0]), __uint_as_float(r[1])};
 }
 
+// max / min of two scores as ONE v_med3_f32 against +-3e38.  Where the default FP semantics hold (the accumulating variants) a
+// plain fmaxf on a score whose low bits were just replaced by an index costs a quieting v_max_f32 x, x, x in front of it (the
+// compiler cannot know the bit pattern is no signalling NaN); the median has no such clause.  Scores are finite and below 3e38 in
+// magnitude on every row whose label the filter vouches for (the others are caught by their norm).
+__device__ __forceinline__ float max_of(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, -kNegBig); }
+__device__ __forceinline__ float min_of(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, kNegBig); }
+
 // running top-2 (m1 >= m2) absorbs two values per update:
 //   m1' = max3(m1, a, b);   m2' = max(med3(m1, a, b), m2)
 __device__ __forceinline__ void top2_pair(float &m1, float &m2, float a, float b)
@@ -132,8 +139,11 @@ template <typename T, bool FIX = false, bool ADD = true>
 __device__ __forceinline__ void exact_row_accumulate(const T *__restrict__ x, int64_t row, int c, int64_t ldx,
                                                      const double *wt, int k, int32_t *__restrict__ labels,
                                                      double *ls, int lane, const FixPoint *fx = nullptr,
-                                                     double *stats = nullptr, int cs = 0, int wsj = 0, int wsn = 1)
+                                                     double *stats = nullptr, int cs = 0, int wsj = 0, int wsn = 1,
+                                                     int cnt_word = -1, unsigned long long cnt_inc = 1ull)
 {
+    // cnt_word >= 0 (round 6, the one-pass kernel's table): a row's count lives in word cnt_word of its table row and grows by
+    // cnt_inc per row; otherwise in the region behind the spare row, by one
     // codebook element (channel j, node) at wt[j * wsj + node * wsn]: the transposed LDS copy (wsj = k, wsn = 1: the default) or
     // the row-major codebook where it lies in HBM / L2 (wsj = 1, wsn = c)
     if (wsj == 0) wsj = k;
@@ -194,7 +204,8 @@ __device__ __forceinline__ void exact_row_accumulate(const T *__restrict__ x, in
                     __hip_atomic_fetch_add(lu + (size_t)win * cs + lane, (unsigned long long)__double_as_longlong(xa + fx->magic),
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (lane == 0)
-                    __hip_atomic_fetch_add(lu + (size_t)(k + 1) * cs + win, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(lu + (cnt_word >= 0 ? (size_t)win * cs + cnt_word : (size_t)(k + 1) * cs + win), cnt_inc,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else {
                 if (lane < c) __hip_atomic_fetch_add(stats + (size_t)win * c + lane, xa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (lane == 0) __hip_atomic_fetch_add(stats + (size_t)k * c + win, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -216,6 +227,24 @@ typedef unsigned uint2v __attribute__((ext_vector_type(2)));
 // lanes of one ds_add hit words label * stride + (lane group) * CPL + 2 p (+ 1) for 16 unrelated labels: with the natural
 // stride 22 the labels spread over only 8 of the 16 double-word bank pairs (gcd(22, 16) = 2), with 23 over all of them.
 __host__ __device__ inline int acc_stride(int c) { return c | 1; }
+// Round 6, the fixed-point table of the one-pass kernel (FIX): a table row is 4 CPL + 1 words -- slot (lane group q, pair p,
+// element e) of a lane IS word q CPL + 2 p + e of its row's table row, whatever c: words 0 .. c-1 are the channels, word c takes
+// the slot that lies just past the row's end and is the row COUNT (below), the words behind it take the other slots past the end
+// and are never read.  One address per tile and lane (label x stride + lane base, the pairs ride in the instruction's offset
+// field), no select between a label's row and the spare one per pair, no count address: 4 address instructions per 64 rows
+// instead of 36 + 20.  The stride stays odd (25 words at CPL = 6): the 16 labels of a ds_add spread over all bank pairs.
+__host__ __device__ inline int acc_stride_fix(int cpl) { return 4 * cpl + 1; }
+__host__ __device__ inline size_t acc_table_words(int k, int c, int cpl, bool fix)
+{
+    return fix ? (((size_t)(k + 1) * acc_stride_fix(cpl) + 1) & ~(size_t)1) : (((size_t)(k + 1) * (acc_stride(c) + 1) + 1) & ~(size_t)1);
+}
+// a * inverse(a) == 1 modulo 2^64 for odd a (Newton: the correct low bits double per step, a itself has three)
+__host__ __device__ inline unsigned long long inverse_mod_2_64(unsigned long long a)
+{
+    unsigned long long x = a;
+    for (int i = 0; i < 5; i++) x *= 2ull - a * x;
+    return x;
+}
 
 // SGB_VALU > 0 forces a 1-MFMA : SGB_VALU-VALU cadence with sched_group_barrier.  Measured (bench.py,
 // filter kernel): 0 -> 0.237 ms, 3 -> 0.252, 5 -> 0.249, 8 -> 0.247: the compiler's own order wins.
@@ -245,7 +274,9 @@ __host__ __device__ inline int acc_stride(int c) { return c | 1; }
 #ifndef PXSOM_ADD_SCAN_MIN   // ... from this many agreeing neighbour pairs of a tile's 60 on (47: runs of five rows and longer; runs of four cost the same either way)
 #define PXSOM_ADD_SCAN_MIN 47
 #endif
-template <typename T, int CPL, int NB, int RU, int MODE, bool ACC, bool FIX = false, bool TWO = true>
+// FOLD (FIX only): some slots of the last lane groups lie past the row's end (c < 4 CPL) -- the one at channel c then carries
+// the row count; without such a slot (c == 4 CPL) the count takes an instruction of its own.
+template <typename T, int CPL, int NB, int RU, int MODE, bool ACC, bool FIX = false, bool FOLD = true>
 __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void bmu_filter_fast(
     const T *__restrict__ x, int64_t n, int c, int64_t ldx, const half8 *__restrict__ wfrag,
     const f32x4 *__restrict__ bias, AssignHdr *hdr, unsigned *__restrict__ amb_list,
@@ -256,8 +287,8 @@ __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void b
     // ACC: table [(k+1)*c sums | (k+1) counts]; row k is a spare one that takes the adds of rows / channel slots that must
     // not count (listed rows, rows a previous group owns, clamped channel slots): the accumulation has no branch
     double *ls = reinterpret_cast<double *>(acc_smem);
-    const int cs = acc_stride(c);   // table row stride (words)
-    double *wt = ls + (((size_t)(k + 1) * (cs + 1) + 1) & ~(size_t)1);   // [c][k] transposed codebook (ACC only); 16-byte aligned
+    const int cs = FIX ? acc_stride_fix(CPL) : acc_stride(c);   // table row stride (words)
+    double *wt = ls + acc_table_words(k, c, CPL, FIX);   // [c][k] transposed codebook (ACC only); 16-byte aligned
     // three workgroups per CU (PXSOM_FAST_WGS = 3): no room for that copy -- the listed rows read the codebook where it lies
     constexpr bool kWtInLds = PXSOM_FAST_WGS < 3;
     const double *wx = kWtInLds ? wt : wcodes;
@@ -317,7 +348,7 @@ __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void b
         __syncthreads();
         prep_body<256, 128>(wrow, k, c, hdr_l, frag_l, bias_l, NB, 1, CPL, idx_bits, node_bits, nullptr, nullptr, 0, 0, true);
         __syncthreads();
-        for (int e = threadIdx.x; e < (k + 1) * (cs + 1); e += 256) ls[e] = 0.0;   // (the first add comes after the loads' wait)
+        for (int e = threadIdx.x; e < (int)acc_table_words(k, c, CPL, FIX); e += 256) ls[e] = 0.0;   // (the first add comes after the loads' wait)
         __syncthreads();
         wfrag = frag_l;
         bias = bias_l;
@@ -333,7 +364,15 @@ __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void b
                 tol_abs = hdr->tol_abs, x_limit = hdr->x_limit, tol_rel_coarse = hdr->tol_rel_coarse;
     const bool force_exact = hdr->force_exact != 0;
     FixPoint fx = {};
-    if constexpr (FIX) fx = make_fixpoint(hdr->fix_exp, fix_rows_log2 & 255);
+    if constexpr (FIX) {
+        fx = make_fixpoint(hdr->fix_exp, fix_rows_log2 & 255);
+        // Round 6: the magic number is one unit larger, so its bit pattern B is ODD.  Every slot of every vouched row then adds
+        // bits(v + M) = B + round(v 2^s) to its word, the slots past the row's end (their loads return 0) B itself: the word at
+        // channel c holds n B modulo 2^64 after n rows -- which is both what the flush subtracts from every channel word of the
+        // row and, times the inverse of B modulo 2^64, the count n.  No lane adds anything but what it loaded.
+        fx.magic += fx.unit;
+        fx.mbits += 1ull;
+    }
     unsigned long long *lu = reinterpret_cast<unsigned long long *>(ls);
 
     const int lane = threadIdx.x & 63;
@@ -360,12 +399,16 @@ __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void b
 
     // byte offset of this lane's pair p inside a 16-row tile (channel slots past c re-read the
     // row's last valid pair: their codebook slots are zero)
+    // (ACC + FIX: such a pair's offset lies past the end of every group's buffer instead -- the load returns zeros, which is what
+    // the pair's table slots must add; its MFMA slots meet zero codebook entries either way)
     unsigned loff[NP];
 #pragma unroll
     for (int p = 0; p < NP; p++) {
         int ch = q * CPL + 2 * p;
-        if (ch > c - 2) ch = c - 2;
+        const bool past = ch > c - 2;
+        if (past) ch = c - 2;
         loff[p] = (unsigned)((pix * ldx + ch) * (int64_t)sizeof(T));
+        if (ACC && FIX && past) loff[p] = 0x80000000u;
     }
     const int64_t tile_bytes = 16 * ldx * (int64_t)sizeof(T);
     // centring vector of this lane's channels, scaled (zeros when the workspace was prepared without it)
@@ -499,7 +542,7 @@ __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void b
                     const float p0 = pack_idx(acc[0], (unsigned)(b * 4 + 0), idx_mask);
                     if (RU == 1) {
                         m2 = __builtin_amdgcn_fmed3f(m1, m2, p0);
-                        m1 = fmaxf(m1, p0);
+                        m1 = max_of(m1, p0);
                     } else {
                         const float p1 = pack_idx(acc[1], (unsigned)(b * 4 + 1), idx_mask);
                         top2_pair(m1, m2, p0, p1);
@@ -580,8 +623,8 @@ __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void b
                     rs = __builtin_amdgcn_permlane16_swap(__float_as_uint(xs), __float_as_uint(ys), false, false);
                 }
                 const float a = __uint_as_float(r1[0]), b = __uint_as_float(r1[1]);
-                o1 = fmaxf(a, b);
-                o2 = fmaxf(fmaxf(fminf(a, b), __uint_as_float(r2[0])), __uint_as_float(r2[1]));
+                o1 = max_of(a, b);
+                o2 = fmaxf(fmaxf(min_of(a, b), __uint_as_float(r2[0])), __uint_as_float(r2[1]));
                 os = __uint_as_float(rs[0]) + __uint_as_float(rs[1]);
             };
             float p1, p2, ps, q1, q2, qs, a1, a2, s2;
@@ -659,111 +702,103 @@ __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void b
                     lab[2] = e32[1];
                     lab[3] = o32[1];
                 }
-                // Round 5: where the last pair of the last lane group lies past the row's end (c < 4 CPL: 22 channels on six per
-                // lane) its sixteen lanes -- one per row of the tile, idle until now: their adds went to the spare row -- carry the
-                // row's COUNT in the first of their two adds: the separate count instruction (16 active lanes) per tile is gone,
-                // 24 LDS atomics per 64 rows instead of 28.
-                const bool fold = c < 4 * CPL;                      // (wave-uniform)
-                const bool cnt_lane = fold && q == 3;
-                const unsigned cnt_base = (unsigned)(k + 1) * (unsigned)cs;
-                // (scan_trip was decided a trip ago, on that trip's last tile -- labels that agreed there agree next door -- so the branch
-                // below does not wait for a vector compare of this trip's labels)
-                // (rows that come out of the wave's queue are not neighbours -- and the idle lanes of a short batch all carry the spare
-                // label: such a trip neither takes the decision nor makes the next one)
-                const bool scan_now = QUEUED ? false : scan_trip;
-                if constexpr (FIX && PXSOM_ADD_SCAN && !QUEUED) {
-                    const unsigned nx3 = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)lab[kTilesPerIter - 1], 0x101 /* row_shl:1 */, 0xf, 0xf, false);
-                    // agreeing neighbour pairs of that tile's 60 (15 per lane row, the four lane rows alike)
-                    scan_trip = fold && __popcll(__ballot(nx3 == lab[kTilesPerIter - 1])) >= PXSOM_ADD_SCAN_MIN;
-                }
-                // Round 5: neighbouring rows that share their label (what images do and the synthetic FOVs do not: the 16 rows of
-                // one ds_add then hit the same words and the instruction is served lane after lane -- 0.30 -> 0.84 ms on rows in
-                // runs of 16 equal labels, profiles/r05/label_coherence.txt).  Where most neighbours agree (a wave-uniform count)
-                // the tile's rows are first summed along the row axis: inclusive prefix sums P of the fixed-point words over the 16
-                // lanes of a lane row (v_add_co / v_addc on row_shr operands, two instructions per step and word), and only the
-                // LAST row e of every run of equal labels touches the table: + P[e] to its own label, - P[e] to the label of the
-                // run that follows (whose own last row adds its P, which contains P[e]): the telescoped sums are the runs' sums,
-                // in the same modular 64-bit arithmetic as the plain adds, so the table ends bit-identical.
-                                if constexpr (FIX && PXSOM_ADD_SCAN)
-                if (__builtin_expect(scan_now, 0)) {   // (out of line: the plain adds below stay one block behind the search)
+                if constexpr (FIX) {
+                    // Round 6: every slot of a lane adds what the lane loaded for it to ITS word of the row's table row
+                    // (acc_stride_fix): address = label x stride + lane base, the pairs in the offset field.  Listed rows and rows
+                    // a previous group owns carry the spare label k.  The slot at channel c (FOLD: it exists) loaded zeros and so
+                    // adds the bare bit pattern of the magic number: the row count, see where fx is made.
+                    const unsigned cs8 = (unsigned)cs * 8u;
+                    char *const lane_base = reinterpret_cast<char *>(lu) + (unsigned)(q * CPL) * 8u;
+                    auto table_row = [&](unsigned label) { return reinterpret_cast<unsigned long long *>(lane_base + __umul24(label, cs8)); };
+                    auto slot_bits = [&](float v) { return (unsigned long long)__double_as_longlong((double)v + fx.magic); };
+                    // (scan_trip was decided a trip ago, on that trip's last tile -- labels that agreed there agree next door -- so the
+                    // branch below does not wait for a vector compare of this trip's labels; rows that come out of the wave's queue
+                    // are not neighbours -- and the idle lanes of a short batch all carry the spare label: such a trip neither takes
+                    // the decision nor makes the next one)
+                    const bool scan_now = QUEUED ? false : scan_trip;
+                    if constexpr (FOLD && PXSOM_ADD_SCAN && !QUEUED) {
+                        const unsigned nx3 = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)lab[kTilesPerIter - 1], 0x101 /* row_shl:1 */, 0xf, 0xf, false);
+                        // agreeing neighbour pairs of that tile's 60 (15 per lane row, the four lane rows alike)
+                        scan_trip = __popcll(__ballot(nx3 == lab[kTilesPerIter - 1])) >= PXSOM_ADD_SCAN_MIN;
+                    }
+                    // Round 5: neighbouring rows that share their label (what images do and the synthetic FOVs do not: the 16 rows of
+                    // one ds_add then hit the same words and the instruction is served lane after lane -- 0.30 -> 0.84 ms on rows in
+                    // runs of 16 equal labels, profiles/r05/label_coherence.txt).  Where most neighbours agree (a wave-uniform count)
+                    // the tile's rows are first summed along the row axis: inclusive prefix sums P of the fixed-point words over the 16
+                    // lanes of a lane row (v_add_co / v_addc on row_shr operands, two instructions per step and word), and only the
+                    // LAST row e of every run of equal labels touches the table: + P[e] to its own label, - P[e] to the label of the
+                    // run that follows (whose own last row adds its P, which contains P[e]): the telescoped sums are the runs' sums,
+                    // in the same modular 64-bit arithmetic as the plain adds, so the table ends bit-identical.  (The count word is a
+                    // slot like any other.)
+                    if constexpr (FOLD && PXSOM_ADD_SCAN)
+                    if (__builtin_expect(scan_now, 0)) {   // (out of line: the plain adds below stay one block behind the search)
 #pragma unroll
-                    for (int t = 0; t < kTilesPerIter; t++) {
-                        const unsigned base = __umul24(lab[t], (unsigned)cs), spare = __umul24((unsigned)k, (unsigned)cs);
-                        const unsigned nxt = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)lab[t], 0x101 /* row_shl:1 */, 0xf, 0xf, false);
-                        const bool last = pix == 15;
-                        const bool ends = last || nxt != lab[t];
-                        unsigned lo[2 * NP], hi[2 * NP];
+                        for (int t = 0; t < kTilesPerIter; t++) {
+                            const unsigned nxt = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)lab[t], 0x101 /* row_shl:1 */, 0xf, 0xf, false);
+                            const bool last = pix == 15;
+                            const bool ends = last || nxt != lab[t];
+                            unsigned lo[2 * NP], hi[2 * NP];
 #pragma unroll
-                        for (int p = 0; p < NP; p++) {
-                            const unsigned long long bx = (unsigned long long)__double_as_longlong((double)keep[t][p].x + fx.magic);
-                            const unsigned long long by = (unsigned long long)__double_as_longlong((double)keep[t][p].y + fx.magic);
-                            const unsigned long long b0 = (p == NP - 1 && cnt_lane) ? 1ull : bx;   // (the count lane's first word counts rows)
-                            lo[2 * p] = (unsigned)b0;
-                            hi[2 * p] = (unsigned)(b0 >> 32);
-                            lo[2 * p + 1] = (unsigned)by;
-                            hi[2 * p + 1] = (unsigned)(by >> 32);
-                        }
+                            for (int p = 0; p < NP; p++) {
+                                const unsigned long long bx = slot_bits((float)keep[t][p].x), by = slot_bits((float)keep[t][p].y);
+                                lo[2 * p] = (unsigned)bx;
+                                hi[2 * p] = (unsigned)(bx >> 32);
+                                lo[2 * p + 1] = (unsigned)by;
+                                hi[2 * p + 1] = (unsigned)(by >> 32);
+                            }
 #define PXSOM_SCAN_STEP(SHR)                                                                                                         \
 _Pragma("unroll") for (int j = 0; j < 2 * NP; j++)                                                                                \
     asm volatile("v_add_co_u32_dpp %0, vcc, %0, %0 row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"               \
                  "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:1"                \
                  : "+v"(lo[j]), "+v"(hi[j])::"vcc");
-                        PXSOM_SCAN_STEP(1)
-                        PXSOM_SCAN_STEP(2)
-                        PXSOM_SCAN_STEP(4)
-                        PXSOM_SCAN_STEP(8)
+                            PXSOM_SCAN_STEP(1)
+                            PXSOM_SCAN_STEP(2)
+                            PXSOM_SCAN_STEP(4)
+                            PXSOM_SCAN_STEP(8)
 #undef PXSOM_SCAN_STEP
-                        if (ends) {
-                            const unsigned base_n = __umul24(nxt < (unsigned)k ? nxt : (unsigned)k, (unsigned)cs);
+                            if (ends) {
+                                unsigned long long *const mine_row = table_row(lab[t]);
+                                unsigned long long *const next_row = table_row(nxt < (unsigned)k ? nxt : (unsigned)k);
 #pragma unroll
-                            for (int p = 0; p < NP; p++) {
-                                const bool own = q * CPL + 2 * p <= c - 2;
-                                const unsigned off = (unsigned)(own ? q * CPL + 2 * p : 0);
-                                const bool counts_here = p == NP - 1 && cnt_lane;
-                                const unsigned ip = (own ? base : spare) + off, in = (own ? base_n : spare) + off;
-                                const unsigned ip0 = counts_here ? cnt_base + lab[t] : ip;
-                                const unsigned in0 = counts_here ? cnt_base + (nxt < (unsigned)k ? nxt : (unsigned)k) : in;
-                                const unsigned long long p0 = ((unsigned long long)hi[2 * p] << 32) | lo[2 * p];
-                                const unsigned long long p1 = ((unsigned long long)hi[2 * p + 1] << 32) | lo[2 * p + 1];
-                                __hip_atomic_fetch_add(lu + ip0, p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                __hip_atomic_fetch_add(lu + ip + 1, p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                if (!last) {
-                                    __hip_atomic_fetch_add(lu + in0, 0ull - p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                    __hip_atomic_fetch_add(lu + in + 1, 0ull - p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                for (int j = 0; j < 2 * NP; j++) {
+                                    const unsigned long long pj = ((unsigned long long)hi[j] << 32) | lo[j];
+                                    __hip_atomic_fetch_add(mine_row + j, pj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    if (!last) __hip_atomic_fetch_add(next_row + j, 0ull - pj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                                 }
                             }
                         }
                     }
-                }
-                if (__builtin_expect(!scan_now, 1))
+                    if (__builtin_expect(!scan_now, 1))
 #pragma unroll
-                for (int t = 0; t < kTilesPerIter; t++) {
-#ifdef PXSOM_TIMING_REPLICA   // (timing build ONLY, results are wrong: rows of odd pix add into a second table laid over the codebook copy)
-                    const unsigned base = __umul24(lab[t], (unsigned)cs) + ((pix & 1) ? (unsigned)(((k + 1) * (cs + 1) + 1) & ~1) : 0u),
-                                   spare = __umul24((unsigned)k, (unsigned)cs);
-#else
-                    const unsigned base = __umul24(lab[t], (unsigned)cs), spare = __umul24((unsigned)k, (unsigned)cs);   // (v_mul_lo_u32 runs at quarter rate)
-#endif
+                    for (int t = 0; t < kTilesPerIter; t++) {
+                        unsigned long long *const row_words = table_row(lab[t]);
 #pragma unroll
-                    for (int p = 0; p < NP; p++) {
-                        const bool own = q * CPL + 2 * p <= c - 2;
-                        unsigned idx = (own ? base : spare) + (unsigned)(own ? q * CPL + 2 * p : 0);
-                        const bool counts_here = p == NP - 1 && cnt_lane;
-                        const unsigned idx0 = counts_here ? cnt_base + lab[t] : idx;
-                        if constexpr (FIX) {
-                            const unsigned long long v0 = (unsigned long long)__double_as_longlong((double)keep[t][p].x + fx.magic);
-                            __hip_atomic_fetch_add(lu + idx0, counts_here ? 1ull : v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            __hip_atomic_fetch_add(lu + idx + 1, (unsigned long long)__double_as_longlong((double)keep[t][p].y + fx.magic),
-                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        } else {
+                        for (int p = 0; p < NP; p++) {
+                            __hip_atomic_fetch_add(row_words + 2 * p, slot_bits((float)keep[t][p].x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(row_words + 2 * p + 1, slot_bits((float)keep[t][p].y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        if constexpr (!FOLD)   // (c == 4 CPL: no slot past the row's end -- the first lane group counts the row)
+                            if (q == 0) __hip_atomic_fetch_add(row_words + c, fx.mbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                } else {
+                    // binary64 tables (the training steps' statistics): a label's row or the spare one per pair, the count in the
+                    // idle lanes' first add where there are any (c < 4 CPL) and by an instruction of its own otherwise
+                    const bool fold = c < 4 * CPL;                      // (wave-uniform)
+                    const bool cnt_lane = fold && q == 3;
+                    const unsigned cnt_base = (unsigned)(k + 1) * (unsigned)cs;
+#pragma unroll
+                    for (int t = 0; t < kTilesPerIter; t++) {
+                        const unsigned base = __umul24(lab[t], (unsigned)cs), spare = __umul24((unsigned)k, (unsigned)cs);   // (v_mul_lo_u32 runs at quarter rate)
+#pragma unroll
+                        for (int p = 0; p < NP; p++) {
+                            const bool own = q * CPL + 2 * p <= c - 2;
+                            unsigned idx = (own ? base : spare) + (unsigned)(own ? q * CPL + 2 * p : 0);
+                            const bool counts_here = p == NP - 1 && cnt_lane;
+                            const unsigned idx0 = counts_here ? cnt_base + lab[t] : idx;
                             __hip_atomic_fetch_add(ls + idx0, counts_here ? 1.0 : (double)keep[t][p].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             __hip_atomic_fetch_add(ls + idx + 1, (double)keep[t][p].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
-                    }
-                    if (!fold && q == 0) {
-                        if constexpr (FIX)
-                            __hip_atomic_fetch_add(lu + (size_t)(k + 1) * cs + lab[t], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        else
+                        if (!fold && q == 0)
                             __hip_atomic_fetch_add(ls + (size_t)(k + 1) * cs + lab[t], 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
@@ -788,7 +823,7 @@ _Pragma("unroll") for (int j = 0; j < 2 * NP; j++)                              
                     const int src = __builtin_ctzll(late);
                     late &= late - 1;
                     const int64_t rsrc = QUEUED ? s1_q[src] : row0 + src;
-                    exact_row_accumulate<T, FIX>(x, rsrc, c, ldx, wx, k, labels, ls, lane, &fx, stats, cs, wsj, wsn);
+                    exact_row_accumulate<T, FIX>(x, rsrc, c, ldx, wx, k, labels, ls, lane, &fx, stats, cs, wsj, wsn, FIX ? c : -1, FIX ? fx.mbits : 1ull);
                 }
             } else {
                 unsigned base = 0;
@@ -817,6 +852,8 @@ _Pragma("unroll") for (int j = 0; j < 2 * NP; j++)                              
                     int ch = q * CPL + 2 * p;
                     if (ch > c - 2) ch = c - 2;
                     rows_q[t][p] = *reinterpret_cast<const P2 *>(rp + ch);
+                    if constexpr (ACC && FIX)   // (a pair past the row's end holds zeros, as the group loads deliver it)
+                        if (q * CPL + 2 * p > c - 2) rows_q[t][p] = P2{};
                 }
             }
             trip(rows_q, rows_q, std::integral_constant<int, 1>{}, cnt);
@@ -853,15 +890,17 @@ _Pragma("unroll") for (int j = 0; j < 2 * NP; j++)                              
         __syncthreads();   // every wave is through its groups: the queue is complete
         const unsigned queued = *amb_n < kAmbQueue ? *amb_n : kAmbQueue;   // rows past the end were settled at once
         for (unsigned i = threadIdx.x >> 6; i < queued; i += 4)
-            exact_row_accumulate<T, FIX>(x, amb_q[i], c, ldx, wx, k, labels, ls, lane, &fx, stats, cs, wsj, wsn);
+            exact_row_accumulate<T, FIX>(x, amb_q[i], c, ldx, wx, k, labels, ls, lane, &fx, stats, cs, wsj, wsn, FIX ? c : -1, FIX ? fx.mbits : 1ull);
         __syncthreads();
         if constexpr (FIX) {
             int node = (int)threadIdx.x / c, j = (int)threadIdx.x - node * c;   // element e <-> (node, channel), no division per element
             const int dnode = 256 / c, dj = 256 % c;
+            // word c of a table row holds n B modulo 2^64 for the n rows of the label (B: the magic number's odd bit pattern) -- the
+            // very amount those rows put on top of their values in every channel word
             for (int e = threadIdx.x; e < k * c; e += 256) {
-                const unsigned long long cnt = lu[(size_t)(k + 1) * cs + node];
-                if (cnt) {
-                    const long long units = (long long)(lu[(size_t)node * cs + j] - cnt * fx.mbits);
+                const unsigned long long nb = lu[(size_t)node * cs + c];
+                if (nb) {
+                    const long long units = (long long)(lu[(size_t)node * cs + j] - nb);
                     if (units) __hip_atomic_fetch_add(stats + e, (double)units * fx.unit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 node += dnode;
@@ -871,8 +910,9 @@ _Pragma("unroll") for (int j = 0; j < 2 * NP; j++)                              
                     node++;
                 }
             }
+            const unsigned long long binv = inverse_mod_2_64(fx.mbits);
             for (int e = threadIdx.x; e < k; e += 256) {
-                const unsigned long long cnt = lu[(size_t)(k + 1) * cs + e];
+                const unsigned long long cnt = lu[(size_t)e * cs + c] * binv;
                 if (cnt) __hip_atomic_fetch_add(stats + (size_t)k * c + e, (double)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         } else {

@@ -1,6 +1,5 @@
 """Kernel routes that an environment switch selects (read once per process by libpxsom): each runs a parity check against the
 oracle in a process of its own, so that the switched-off defaults and the opt-in experiments stay correct, not just compiled.
-  PXSOM_ONEPASS=1       binary32 / binary16 rows through the two-tile one-pass kernel at three waves per SIMD (opt-in)
   (PXSOM_TRAIN_UNFUSED=1 only labels the binary64 cases: they take the two-tile kernel whatever the environment says)
   PXSOM_PACKED_TWO=1    packed-K filter in two stages (opt-in)"""
 import os
@@ -44,7 +43,6 @@ print("ok")
 
 
 @pytest.mark.parametrize("switch,cases", [
-    ("PXSOM_ONEPASS=1", [("float32", 20_011, 22, 100), ("float16", 9_000, 16, 99), ("float32", 70, 4, 97), ("float32", 33_000, 24, 100)]),
     ("PXSOM_TRAIN_UNFUSED=1", [("float64", 20_011, 22, 100), ("float64", 5_000, 32, 100), ("float64", 64, 2, 100), ("float64", 12_345, 8, 98)]),
     ("PXSOM_PACKED_TWO=1", [("float16", 30_000, 40, 400), ("float16", 7_001, 64, 256)]),
 ])
