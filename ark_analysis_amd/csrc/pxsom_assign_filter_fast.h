@@ -363,6 +363,12 @@ __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void b
     const float scale = hdr->scale, wn_max = hdr->wn_max, tol_rel = hdr->tol_rel,
                 tol_abs = hdr->tol_abs, x_limit = hdr->x_limit, tol_rel_coarse = hdr->tol_rel_coarse;
     const bool force_exact = hdr->force_exact != 0;
+    const unsigned long long force_m = force_exact ? ~0ull : 0ull;
+    // (the coefficients a shade up, the range bound a shade down: the fused form never vouches for a row the term-by-term one listed)
+    const float tol_a = (tol_rel * wn_max + tol_abs) * 1.0011f, tol_b = (0.5f * tol_rel * wn_max * wn_max + tol_abs * wn_max) * 1.0001f;
+    const float tol_a_coarse = (tol_rel_coarse * wn_max + tol_abs) * 1.0011f,
+                tol_b_coarse = (0.5f * tol_rel_coarse * wn_max * wn_max + tol_abs * wn_max) * 1.0001f;
+    const unsigned s2_limit_bits = __float_as_uint(fminf((x_limit / 1.001f) * (x_limit / 1.001f) * 0.9999f, 3.0e38f));
     FixPoint fx = {};
     if constexpr (FIX) {
         fx = make_fixpoint(hdr->fix_exp, fix_rows_log2 & 255);
@@ -380,9 +386,12 @@ __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void b
     // ACC: groups are dealt workgroup-major (wave 0 of every workgroup first), so a mini-batch of a few hundred
     // groups spreads over all CUs -- and so do the rows its workgroups have to settle exactly
     const int wv_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t wave = ACC ? (int64_t)wv_in_block * gridDim.x + blockIdx.x : (int64_t)blockIdx.x * 4 + wv_in_block;
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
-    const int64_t ngroups = (n + 63) / 64;
+    // (group numbers are 32-bit -- the launchers refuse 2^37 rows and more --: their clamps and the loop tests stay on the scalar
+    // unit, which has no 64-bit ordered compare)
+    const int wave = ACC ? wv_in_block * (int)gridDim.x + (int)blockIdx.x : (int)blockIdx.x * 4 + wv_in_block;
+    const int nwaves = (int)gridDim.x * 4;
+    const int ngroups = (int)((n + 63) / 64);
+    const int last_shift = (int)((int64_t)ngroups * 64 - n);   // the last group is shifted back by this many rows (0: it is full)
 
     // the low fragments serve stage 2 only (a tile in nine on a trained codebook): the accumulating variant, which is
     // short of registers, leaves them in its LDS copy
@@ -429,10 +438,9 @@ __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void b
     // Buffer loads: the 64-row group is a descriptor of its own (base = x + row0*ldx*sizeof(T), built
     // from wave-uniform values on the scalar unit), the tile offset rides in soffset and the lane offset in
     // voffset -- no per-load VALU address arithmetic.
-    auto load_group = [&](int64_t g, RowSet &raw) {
+    auto load_group = [&](int g, RowSet &raw) {
         if constexpr (MODE >= 2) g = wave;
-        int64_t row0 = g * 64;
-        if (row0 > n - 64) row0 = n - 64;
+        const int64_t row0 = (int64_t)g * 64 - (g == ngroups - 1 ? last_shift : 0);
         const char *gb = reinterpret_cast<const char *>(x) + row0 * ldx * (int64_t)sizeof(T);
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<char *>(gb), (short)0, (int)(64 * ldx * (int64_t)sizeof(T)), 0x00020000);
@@ -460,7 +468,7 @@ __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void b
         }
     };
 
-    int64_t g = wave;
+    int g = wave;
     if (g < ngroups) load_group(g, rows_a);
     // one trip: group g's rows are in `raw`; the next group's go to `nxt` (the same set for the plain filter, whose rows are
     // dead once converted)
@@ -520,13 +528,15 @@ __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void b
             return bl;
         };
         if constexpr (!QUEUED) {
-            int64_t gnext = g + nwaves;
+            int gnext = g + nwaves;
             if (gnext > ngroups - 1) gnext = ngroups - 1;  // harmless re-read on the last trip
             load_group(gnext, nxt);
         }
 
         float my_m1 = 0.f;
-        bool my_amb = false;
+        // rows this trip cannot vouch for, as a lane mask: the tests below are vector compares whose results ARE such masks, and the
+        // logic between them, the test "any?" and the rows' places in the queue then run on the scalar unit
+        unsigned long long amb_m = 0ull;
         if constexpr (MODE == 1) {
             float acc = 0.f;
 #pragma unroll
@@ -631,17 +641,15 @@ __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void b
             merge(tm1[0], tm1[1], tm2[0], tm2[1], ss[0], ss[1], false, p1, p2, ps);
             merge(tm1[2], tm1[3], tm2[2], tm2[3], ss[2], ss[3], false, q1, q2, qs);
             merge(p1, q1, p2, q2, ps, qs, true, a1, a2, s2);
-            // |Xh| <= |X| (1 + 2^-11): folded into the 1.001 factor with the sqrt's ulp
-            const float xn = __builtin_amdgcn_sqrtf(s2) * 1.001f;
+            // tol = trel (|X| wn_max + wn_max^2 / 2) + tol_abs (|X| + wn_max) with |X| <= 1.001 sqrt(s2) (|Xh| <= |X| (1 + 2^-11) and
+            // the sqrt's ulp), as ONE fused multiply-add on sqrt(s2): tol_a, tol_b below.  A row is unfit for the filter when
+            // 1.001 sqrt(s2) >= x_limit or s2 is not finite: one unsigned compare of the bit pattern of s2 (a sum of squares: never
+            // negative; an infinity or a NaN of either sign compares above every finite bound) against that of x_limit^2 scaled down.
             unsigned sbits = __float_as_uint(s2);
-            asm("" : "+v"(sbits));  // opaque copy: keeps the exponent test under finite-math
-            const unsigned unfit = (unsigned)!(xn < x_limit) | (unsigned)((sbits & 0x7f800000u) == 0x7f800000u) | (unsigned)force_exact;
-            auto unsure = [&](float b1, float b2, float trel) {
-                const float tol = trel * (xn * wn_max + 0.5f * wn_max * wn_max) + tol_abs * (xn + wn_max);
-                return ((unsigned)!((b1 - b2) > tol) | unfit) != 0u;
-            };
-            if constexpr (FULL) my_amb = unsure(a1, a2, tol_rel);
-            else my_amb = unsure(a1, a2, tol_rel_coarse);
+            asm("" : "+v"(sbits));  // opaque copy: keeps the test on the bits under finite-math
+            const unsigned long long unfit_m = __builtin_amdgcn_uicmp(sbits, s2_limit_bits, 35 /* unsigned >= */) | force_m;
+            const float tol = fmaf(__builtin_amdgcn_sqrtf(s2), FULL ? tol_a : tol_a_coarse, FULL ? tol_b : tol_b_coarse);
+            amb_m = ~__builtin_amdgcn_fcmpf(a1 - a2, tol, 2 /* ordered > */) | unfit_m;
             my_m1 = a1;
         }
 
@@ -658,19 +666,20 @@ __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void b
         }
         // lane (q, pix) owns row row0 + q*16 + pix == row0 + lane (FULL: the row in slot `lane` of the wave's queue)
         int64_t row0 = 0, row;
-        bool own;
+        unsigned long long own_m;
         if constexpr (QUEUED) {
             row = s1_q[lane < (int)full_rows ? lane : 0];
-            own = lane < (int)full_rows;
+            own_m = full_rows >= 64u ? ~0ull : (1ull << full_rows) - 1ull;
         } else {
-            row0 = g * 64;
-            if (row0 > n - 64) row0 = n - 64;
-            row = row0 + lane;
             // rows of a shifted last group that the previous group already covered are not listed again
             // (a row listed twice would be accumulated twice by the exact kernel)
-            own = row >= g * 64;
+            const int shift = g == ngroups - 1 ? last_shift : 0;
+            row0 = (int64_t)g * 64 - shift;
+            row = row0 + lane;
+            own_m = ~0ull << shift;
         }
-        my_amb = my_amb && own;
+        amb_m &= own_m;
+        const bool my_amb = __builtin_amdgcn_inverse_ballot_w64(amb_m);
         {
             // id (q, b, r) -> node: 16 b + 4 q + r, the last block's 4x4 (q, r) grid transposed (node_of_row)
             const unsigned id = __float_as_uint(my_m1) & node_mask;
@@ -682,13 +691,16 @@ __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void b
             // (a row that waits for the full search keeps no provisional label: the search's store is the only one)
             // (nor does a row of a shifted last group that the group before it owns: that group's wave may have searched it in
             // full already)
-            if (own && !(DEFER && my_amb)) labels[row] = (int)real + 1;
+            if (__builtin_amdgcn_inverse_ballot_w64(DEFER ? own_m & ~amb_m : own_m)) {
+                if constexpr (QUEUED) labels[row] = (int)real + 1;
+                else (labels + row0)[lane] = (int)real + 1;   // (scalar base + the lane's constant offset: no 64-bit vector address)
+            }
             if constexpr (ACC) {
                 // lane (q, pix) holds channels q*CPL.. of rows (t, pix), t = 0..3; their labels sit in lanes (t, pix).
                 // Listed rows and rows a previous group already added go to the spare row k, clamped channel slots
                 // (they re-read the row's last valid pair) too: straight-line code, the four label exchanges in flight
                 // together.
-                const unsigned mine = (my_amb || !own) ? (unsigned)k : real;
+                const unsigned mine = __builtin_amdgcn_inverse_ballot_w64(amb_m | ~own_m) ? (unsigned)k : real;
                 // Round 5: the four labels travel through v_permlane16/32_swap (VALU) instead of four ds_bpermute, whose
                 // results waited in the LDS queue behind the trip's own atomics: swapping a value with itself hands every lane
                 // {even row's, odd row's} of its pair of lane rows, then {lower half's, upper half's} of the wave.
@@ -804,7 +816,7 @@ _Pragma("unroll") for (int j = 0; j < 2 * NP; j++)                              
                 }
             }
         }
-        unsigned long long mask = __ballot(my_amb);
+        const unsigned long long mask = amb_m;
         if constexpr (DEFER) {
             if (mask) {   // into the wave's queue, behind what it holds (room for two trips' rows is checked by the group loop)
                 if (my_amb) s1_q[s1_n + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = row;
