@@ -137,6 +137,9 @@ struct StepArgs {
     // takes) out of every `phases` rows; group_w == 1: a plain strided view (ldx is then ignored)
     int group_w = 1;
     int64_t group_stride = 0;
+    // f / group_w without a division in the kernel (launch_step fills them): (f * group_magic) >> (32 + group_shift) for f < 2^31
+    unsigned group_magic = 0;
+    int group_shift = 0;
     // binary64 rows enter the statistics rounded to multiples of the run's quantum q (include/pxsom.h "Reproducible
     // statistics"): qmagic = 1.5 * 2^52 * q, (v + qmagic) - qmagic is that rounding; 0: off
     double qmagic = 0.0;

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
             if (group_w == 1u) {
                 rp = x + row * ldx;
             } else {   // a scheduled step: group_w consecutive rows out of every `phases` (rows per step < 2^32: host check)
-                const unsigned grp = (unsigned)row / group_w, sub = (unsigned)row - grp * group_w;
+                const unsigned grp = __umulhi((unsigned)row, sa.group_magic) >> sa.group_shift, sub = (unsigned)row - grp * group_w;
                 rp = x + (int64_t)grp * sa.group_stride + (int64_t)sub * ldx;
             }
 #pragma unroll
@@ -386,25 +386,33 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
                     mymax = fmax(mymax, fabs(vc));
                     // duplicate key: the bit pattern rotated by a channel-dependent amount, xor-ed up (no multiplies:
                     // integer multiplies run at quarter rate; a key match is verified channel by channel anyway)
-                    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-                    const int rot = (7 * ch + 1) & 63;
-                    kkey ^= (bits << rot) | (bits >> ((64 - rot) & 63));
+                    if constexpr (!BMU) {   // (BMU-only steps do not look for duplicates: no key)
+                        const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+                        const int rot = (7 * ch + 1) & 63;
+                        kkey ^= (bits << rot) | (bits >> ((64 - rot) & 63));
+                    }
                 }
             }
         }
         // the 4 lanes of a node are adjacent: butterfly over the quad (same order for every node, so bit-identical
         // rows get bit-identical norms and keys)
         nrm += __shfl_xor(nrm, 1);
-        kkey ^= __shfl_xor(kkey, 1);
         nrm += __shfl_xor(nrm, 2);
-        kkey ^= __shfl_xor(kkey, 2);
-        if (has_node && nq == 0) key[node] = kkey;
+        if constexpr (!BMU) {
+            kkey ^= __shfl_xor(kkey, 1);
+            kkey ^= __shfl_xor(kkey, 2);
+            if (has_node && nq == 0) key[node] = kkey;
+        }
         if (bad) hdr->bad = 1;   // NaN / Inf in the codebook: every row takes the exact path
-        const double wmax = -pxsom::wave_min_f64(-mymax);
-        const double nmax = -pxsom::wave_min_f64(-((has_node && nrm == nrm) ? nrm : 0.0));
+        // the two maxima only steer the scale (the exponent of the largest magnitude) and the norm bound (rounded up by a hair
+        // below): binary32 roundings of them, reduced as unsigned integers -- non-negative binary32 numbers order like their bit
+        // patterns, infinities included --, a third of the instructions of two binary64 reductions.  (A magnitude that rounds up
+        // to the next power of two halves the scale: the scaled maximum then lies just below 128 instead of just below 256.)
+        const unsigned wbits = ~pxsom::wave_min_u32(~__float_as_uint((float)mymax));
+        const unsigned nbits = ~pxsom::wave_min_u32(~__float_as_uint((has_node && nrm == nrm) ? (float)nrm : 0.f));
         if (lane == 0) {
-            red[wv] = wmax;
-            red[kStepWaves + wv] = nmax;
+            red[wv] = (double)__uint_as_float(wbits);
+            red[kStepWaves + wv] = (double)__uint_as_float(nbits) * (1.0 + 0x1p-23);
         }
     }
     PXSOM_PHASE(12);
@@ -508,7 +516,10 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
     // ---- P7: BMU search of this workgroup's rows -------------------------------------------------------------
     const float tol_rel = sa.tol_rel, tol_abs = sa.tol_abs, x_limit = 60000.0f;
     double *qrows = tl;   // the window-sum scratch is free now: [kQueueRows][c]
-    constexpr unsigned idx_mask = 127u;
+    // Round 6: a score carries the 5 bits (b, r) of its place in the lane; WHICH of the four lanes of a pixel held the winner
+    // travels beside the scores through the merge (a compare + select per level) instead of in two more mantissa bits: the
+    // packing term of the tolerance is 2^-18 instead of 2^-16 -- its largest term -- and a crowded codebook lists 2.5 x fewer rows
+    constexpr unsigned idx_mask = 31u;
     float mus[NP][2];   // the centring vector at this lane's channels, scaled (a binary32 value times a power of two: exact)
 #pragma unroll
     for (int p = 0; p < NP; p++) {
@@ -575,7 +586,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
                 } else {   // last block: only accumulator register 0 holds real nodes (K = 100)
                     const float p0 = pack_idx(acc[t][0], (unsigned)(b * 4 + 0), idx_mask);
                     m2[t] = __builtin_amdgcn_fmed3f(m1[t], m2[t], p0);
-                    m1[t] = fmaxf(m1[t], p0);
+                    m1[t] = max_of(m1[t], p0);
                 }
             }
         }
@@ -590,17 +601,24 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
 #pragma unroll
         for (int t = 0; t < TPW; t++) {
             // merge of the 4 lane groups that share a pixel: afterwards all four hold the pixel's top-2
-            float a1 = __uint_as_float(__float_as_uint(m1[t]) | ((unsigned)q << 5)), a2 = m2[t], s2 = ss[t];
+            // (v_permlane16/32_swap of a value with itself hands BOTH lanes of a pair {the even lane row's, the odd one's} resp.
+            // {the lower half's, the upper half's} in that order: the comparison below gives both the same answer)
+            float a1 = m1[t], a2 = m2[t], s2 = ss[t];
+            unsigned wq;   // lane group (0..3) that held the winner
             {
                 const F2 e1 = xchg16(a1), e2 = xchg16(a2), es = xchg16(s2);
-                a1 = fmaxf(e1.a, e1.b);
-                a2 = fmaxf(fmaxf(fminf(e1.a, e1.b), e2.a), e2.b);
+                wq = e1.a >= e1.b ? 0u : 1u;
+                a1 = max_of(e1.a, e1.b);
+                a2 = fmaxf(fmaxf(min_of(e1.a, e1.b), e2.a), e2.b);
                 s2 = es.a + es.b;
             }
             {
                 const F2 e1 = xchg32(a1), e2 = xchg32(a2), es = xchg32(s2);
-                a1 = fmaxf(e1.a, e1.b);
-                a2 = fmaxf(fmaxf(fminf(e1.a, e1.b), e2.a), e2.b);
+                const unsigned mine = wq | ((unsigned)q & 2u);   // (the upper half's lane groups are 2 and 3)
+                const auto eq = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
+                wq = e1.a >= e1.b ? eq[0] : eq[1];
+                a1 = max_of(e1.a, e1.b);
+                a2 = fmaxf(fmaxf(min_of(e1.a, e1.b), e2.a), e2.b);
                 s2 = es.a + es.b;
             }
             // |Xh| <= |X| (1 + 2^-11): folded into the 1.001 factor with the sqrt's ulp
@@ -612,7 +630,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
             const bool amb = valid && ((!((a1 - a2) > tol)) || !(xn < x_limit) || nonfinite != 0u || force_exact);
             // id (q, b, r) -> node: 16 b + 4 q + r, the last block's 4x4 (q, r) grid transposed (node_of_row)
             const unsigned id = __float_as_uint(a1) & idx_mask;
-            const unsigned wq = id >> 5, wb = (id >> 2) & 7u, wr = id & 3u;
+            const unsigned wb = id >> 2, wr = id & 3u;
             const unsigned real = wb == (unsigned)(kNB - 1) ? 16u * wb + 4u * wr + wq : 16u * wb + 4u * wq + wr;
             if (valid && !amb) {
                 double *tab = ls + (size_t)(pix & (ncopies - 1)) * tstride;
@@ -690,18 +708,39 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
     // of a launch -- which all get here at about the same time -- are spread over the whole buffer instead of queueing up on the
     // same few cache lines (five starting points, as it was until round 4, left 14 - 25 workgroups of a small step on each:
     // scripts/ubench/flush_replicas.hip issues 69 x 2 300 atomics in under 1 us this way)
+    // Round 6: element -> (node, channel) by ONE division per thread, then advanced by additions (the division per element --
+    // ~30 vector instructions on every wave, five times over -- was most of the 1.7 us this phase took on a tail step:
+    // profiles/r06/step_phase_timing.txt); the LDS reads of a thread are issued before its first atomic.
     {
-        const int total = kK * c + kK;
-        const int shift = (int)((blockIdx.x * 97u) % (unsigned)total);
-        for (int e0 = tid; e0 < total; e0 += kStepThreads) {
-            int e = e0 + shift;
-            if (e >= total) e -= total;
-            const int node = e / c;                                              // e -> (node, channel) | count
-            const int le = e < kK * c ? node * cs + (e - node * c) : kK * cs + (e - kK * c);
-            double v = ls[le];
-            for (int j = 1; j < ncopies; j++) v += ls[le + (size_t)j * tstride];
-            if (v != 0.0) __hip_atomic_fetch_add(stats + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int nsums = kK * c;
+        int e = (tid + (int)((blockIdx.x * 97u) % (unsigned)nsums)) % nsums;   // this thread's first word of the sums, staggered
+        int node = e / c, j = e - node * c;
+        const int dnode = kStepThreads / c, dj = kStepThreads - dnode * c;      // (wave-uniform: scalar unit)
+        constexpr int kMaxTrips = (kK * 32 + kStepThreads - 1) / kStepThreads;  // c <= 32
+        double v[kMaxTrips];
+        int at[kMaxTrips];
+#pragma unroll
+        for (int u = 0; u < kMaxTrips; u++) {
+            const bool on = tid + u * kStepThreads < nsums;
+            v[u] = on ? ls[node * cs + j] : 0.0;
+            at[u] = e;
+            e += kStepThreads;
+            node += dnode;
+            j += dj;
+            if (j >= c) {
+                j -= c;
+                node++;
+            }
+            if (e >= nsums) {   // past the end of the sums: around to their first word
+                e -= nsums;
+                node -= kK;
+            }
         }
+        const double cntv = tid < kK ? ls[kK * cs + tid] : 0.0;
+#pragma unroll
+        for (int u = 0; u < kMaxTrips; u++)
+            if (v[u] != 0.0) __hip_atomic_fetch_add(stats + at[u], v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cntv != 0.0) __hip_atomic_fetch_add(stats + nsums + tid, cntv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     PXSOM_PHASE(18);
     if constexpr (EXCH) {
@@ -1138,7 +1177,24 @@ int launch_step(const T *x, int64_t n, int c, int64_t ldx, double *stats, const 
     const int grid = (int)((nblocks + rounds - 1) / rounds);
     auto kern = tpw == 1 ? (bmu ? k1b : k1) : (tpw == 2 ? (bmu ? k2b : k2) : k4);
     if (sa.xch_peers) kern = tpw == 1 ? (bmu ? x1b : x1) : (tpw == 2 ? (bmu ? x2b : x2) : x4);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kStepThreads), lds, st, x, n, c, ldx, stats, sa);
+    // row f of a scheduled step -> f / group_w by a multiplication: m = floor(2^(31 + s) / w) + 1 with 2^(s-1) < w <= 2^s is exact
+    // for f < 2^31 (step_fused_shape: a step holds fewer than 2^31 rows... 2^32 by the shape test, 2^31 here)
+    StepArgs sk = sa;
+    {
+        const unsigned w = (unsigned)std::max(sa.group_w, 1);
+        int s = 0;
+        while (((uint64_t)1 << s) < w) s++;
+        if (s == 0) {   // w == 1: f itself
+            sk.group_magic = 0x80000000u;
+            sk.group_shift = 0;
+            // (mulhi(f, 2^31) = f >> 1: not f -- the kernel's plain-view branch is taken for w == 1, the fields are unused)
+        } else {
+            sk.group_magic = (unsigned)((((uint64_t)1 << (31 + s)) / w) + 1u);
+            sk.group_shift = s - 1;
+        }
+        if (n >= ((int64_t)1 << 31)) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "batch step: %lld rows in one step (limit 2^31)", (long long)n);
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kStepThreads), lds, st, x, n, c, ldx, stats, sk);
     PXSOM_LAUNCH_CHECK("batch_step_kernel");
     return PXSOM_OK;
 }

@@ -1897,10 +1897,14 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
         int rc = launch_gather<T>(x, n, c, ldx, xg, sc, st);
         if (rc) return rc;
     }
-    // coefficients of the fused kernels' rigorous |score - exact| bound (DESIGN.md "K7 error bound"; 7 index bits packed
-    // into the scores): tol = 2 * 1.25 * E (+ 2^-24: the rounding of the centred row, x' = fl(x * scale - mu_s))
-    const float fused_tol_rel = (float)(2.5 * (ldexp(1.0, -(23 - 7)) + pxsom_bmu::filter_accum_units(c, 3) * ldexp(1.0, -24) + ldexp(1.0, -19) +
-                                               ldexp(1.0, -23) + ldexp(1.0, -24)));
+    // coefficients of the fused kernels' rigorous |score - exact| bound (DESIGN.md "K7 error bound"): tol = 2 * 1.25 * E (+ 2^-24:
+    // the rounding of the centred row, x' = fl(x * scale - mu_s)).  Index bits packed into the scores: 5 in the one-launch step
+    // (round 6: the lane group travels beside the scores), 7 in the persistent tail.
+    auto fused_tol = [&](int bits) {
+        return (float)(2.5 * (ldexp(1.0, -(23 - bits)) + pxsom_bmu::filter_accum_units(c, 3) * ldexp(1.0, -24) + ldexp(1.0, -19) + ldexp(1.0, -23) +
+                              ldexp(1.0, -24)));
+    };
+    const float fused_tol_rel = fused_tol(5), tail_tol_rel = fused_tol(7);
     const float fused_tol_abs = (float)pxsom_bmu::filter_tol_abs(c);
     static const bool no_centre = getenv("PXSOM_STEP_NO_CENTRE") != nullptr;   // timing hook
     // Opt-in (PXSOM_TRAIN_PERSISTENT_TAIL): the BMU-only steps at the end of the call (threshold pinned at 0.5: a node's
@@ -2075,7 +2079,7 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
         ta.stats_zero = ring + (size_t)(g_end % 3) * nstats;
         ta.w_final = nullptr;
         ta.scratch = ws + tw.off_tail;
-        ta.tol_rel = fused_tol_rel;
+        ta.tol_rel = tail_tol_rel;
         ta.tol_abs = fused_tol_abs;
         ta.mu32 = no_centre ? nullptr : mu32;
         ta.qmagic = qmagic;
