@@ -708,39 +708,21 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
     // of a launch -- which all get here at about the same time -- are spread over the whole buffer instead of queueing up on the
     // same few cache lines (five starting points, as it was until round 4, left 14 - 25 workgroups of a small step on each:
     // scripts/ubench/flush_replicas.hip issues 69 x 2 300 atomics in under 1 us this way)
-    // Round 6: element -> (node, channel) by ONE division per thread, then advanced by additions (the division per element --
-    // ~30 vector instructions on every wave, five times over -- was most of the 1.7 us this phase took on a tail step:
-    // profiles/r06/step_phase_timing.txt); the LDS reads of a thread are issued before its first atomic.
+    // (Round 6: the division per element is not what this phase waits for -- with one division per thread and the LDS reads in
+    // front of the atomics it takes 2.0 us on a tail step against 1.7: 69 workgroups x ~1 650 binary64 atomics on the same 144
+    // cache lines are served by the memory-side atomic unit at its own pace; profiles/r06/step_phase_timing.txt)
     {
-        const int nsums = kK * c;
-        int e = (tid + (int)((blockIdx.x * 97u) % (unsigned)nsums)) % nsums;   // this thread's first word of the sums, staggered
-        int node = e / c, j = e - node * c;
-        const int dnode = kStepThreads / c, dj = kStepThreads - dnode * c;      // (wave-uniform: scalar unit)
-        constexpr int kMaxTrips = (kK * 32 + kStepThreads - 1) / kStepThreads;  // c <= 32
-        double v[kMaxTrips];
-        int at[kMaxTrips];
-#pragma unroll
-        for (int u = 0; u < kMaxTrips; u++) {
-            const bool on = tid + u * kStepThreads < nsums;
-            v[u] = on ? ls[node * cs + j] : 0.0;
-            at[u] = e;
-            e += kStepThreads;
-            node += dnode;
-            j += dj;
-            if (j >= c) {
-                j -= c;
-                node++;
-            }
-            if (e >= nsums) {   // past the end of the sums: around to their first word
-                e -= nsums;
-                node -= kK;
-            }
+        const int total = kK * c + kK;
+        const int shift = (int)((blockIdx.x * 97u) % (unsigned)total);
+        for (int e0 = tid; e0 < total; e0 += kStepThreads) {
+            int e = e0 + shift;
+            if (e >= total) e -= total;
+            const int node = e / c;                                              // e -> (node, channel) | count
+            const int le = e < kK * c ? node * cs + (e - node * c) : kK * cs + (e - kK * c);
+            double v = ls[le];
+            for (int j = 1; j < ncopies; j++) v += ls[le + (size_t)j * tstride];
+            if (v != 0.0) __hip_atomic_fetch_add(stats + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        const double cntv = tid < kK ? ls[kK * cs + tid] : 0.0;
-#pragma unroll
-        for (int u = 0; u < kMaxTrips; u++)
-            if (v[u] != 0.0) __hip_atomic_fetch_add(stats + at[u], v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cntv != 0.0) __hip_atomic_fetch_add(stats + nsums + tid, cntv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     PXSOM_PHASE(18);
     if constexpr (EXCH) {
