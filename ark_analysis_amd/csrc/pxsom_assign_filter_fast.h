@@ -420,6 +420,8 @@ __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void b
         if (ACC && FIX && past) loff[p] = 0x80000000u;
     }
     const int64_t tile_bytes = 16 * ldx * (int64_t)sizeof(T);
+    // (Round 6, measured and not kept: a lane's first two pairs as ONE 16-byte load where both lie inside the row -- 8 requests per
+    // group instead of 12 -- kernel 0.256 ms against 0.235 on the same box, interleaved; profiles/r06/experiments.txt)
     // centring vector of this lane's channels, scaled (zeros when the workspace was prepared without it)
     float mus[NP][2];
 #pragma unroll
