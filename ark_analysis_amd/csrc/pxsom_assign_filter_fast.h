@@ -482,6 +482,9 @@ __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void b
         constexpr bool FULL = kMode != 0, QUEUED = kMode == 1;
         constexpr bool DEFER = !FULL && MODE != 1;   // (MODE 1: the microbenchmark's stream-only trip)
         RowSet &keep = raw;
+        // (Round 6, measured neutral and not kept: the next group's loads at the very head of the trip behind a scheduling barrier --
+        // the compiler sinks them behind the first three MFMAs --: 0.2341 / 0.2348 / 0.2345 / 0.2327 ms against 0.2352 / 0.2348 /
+        // 0.2347 / 0.2339, interleaved on one box.  The trip does not wait for its rows.)
         half8 bh[kTilesPerIter];
         float ss[kTilesPerIter];
         // x' = fl(x * scale - mu_s): one rounding (binary64 rows: formed in binary64, then rounded once more)
