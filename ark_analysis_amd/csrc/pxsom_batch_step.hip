@@ -161,13 +161,22 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
     // in rank order, starting from +0.0 (the same additions p2p_allreduce_kernel makes: the same bits on every rank)
     char *xch_mine = nullptr;
     const int xch_parity = (int)(sa.xch_wait & 1ull);
+    // Round 6 (advisor, round 5): a workgroup that meets a late peer does NOT leave the launch -- it records the epoch in the
+    // block's error word (first one kept; ANY workgroup, not only the first), searches no rows, poisons the codebook it would
+    // hand on, and still takes its ticket at the end, marked late: the last workgroup through the ticket then resets it and
+    // raises this rank's flag of the next epoch over slots full of NaN -- the peers fail fast and loud instead of waiting four
+    // seconds in every later step of the call, and no ticket count survives into the next launch.
+    bool xch_late = false;
     if constexpr (EXCH) {
         if (sa.xch_wait) {
             xch_mine = sa.xch_peers[sa.xch_rank];
             __shared__ int s_xch_late;
-            if (tid == 0) s_xch_late = 0;
+            // (an epoch already on record: a peer was late earlier in this call -- every later step would wait its four seconds
+            // for the same peer; it is late at once instead)
+            if (tid == 0)
+                s_xch_late = __hip_atomic_load(&reinterpret_cast<pxsom::P2PBlock *>(xch_mine)->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0ull;
             __syncthreads();
-            if (tid < sa.xch_nranks) {
+            if (tid < sa.xch_nranks && !s_xch_late) {
                 pxsom::P2PBlock *blk_mine = reinterpret_cast<pxsom::P2PBlock *>(xch_mine);
                 const long long t0 = (long long)wall_clock64();   // 100 MHz
                 while (__hip_atomic_load(&blk_mine->flags[xch_parity][tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != sa.xch_wait) {
@@ -180,15 +189,13 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
             }
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-            if (s_xch_late) {   // a peer never arrived: nothing to apply -- poison the codebook and record the epoch (first one kept)
-                if (blockIdx.x == 0 && sa.w_out)
-                    for (int e = tid; e < kK * c; e += kStepThreads) sa.w_out[e] = __builtin_nan("");
-                if (tid == 0 && blockIdx.x == 0) {
+            if (s_xch_late) {   // a peer never arrived: nothing to apply -- record the epoch (first one kept)
+                xch_late = true;
+                if (tid == 0) {
                     unsigned long long none = 0ull;
                     (void)__hip_atomic_compare_exchange_strong(&reinterpret_cast<pxsom::P2PBlock *>(xch_mine)->error, &none, sa.xch_wait,
                                                                __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
-                return;
             }
         }
     }
@@ -377,6 +384,8 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
                         const double num = bmu_only ? 0.0 + sdir[i] : nrow[ch];
                         v = gain == 1.0 ? num * inv : v + gain * (num * inv - v);
                     }
+                    if constexpr (EXCH)
+                        if (xch_late) v = __builtin_nan("");   // (the statistics it would have applied are not all there)
                     wv_[i] = v;
                     wt[(size_t)ch * kK + node] = v;
                     if (blockIdx.x == 0 && sa.w_out && (sa.has_update || sa.w_out != sa.w_in)) sa.w_out[(size_t)node * c + ch] = v;
@@ -528,6 +537,8 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
         mus[p][0] = mu_l[ch] * fscale;
         mus[p][1] = mu_l[ch + 1] * fscale;
     }
+    if constexpr (EXCH)
+        if (xch_late) blk = nblocks;   // (a poisoned codebook would send every row to the exact path: the pass is repeated anyway)
     for (; blk < nblocks; blk += gridDim.x) {
         half8 bh[TPW], bl[TPW];
         float ss[TPW];
@@ -731,9 +742,13 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
             __shared__ int s_xch_last;
             __threadfence();
             __syncthreads();
+            // the ticket counts the workgroups in its low 16 bits (a grid holds at most 2 x 256) and the late ones above them
+            __shared__ int s_xch_poison;
             if (tid == 0) {
-                const unsigned t = __hip_atomic_fetch_add(sa.xch_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-                s_xch_last = t == gridDim.x - 1u;
+                const unsigned mine = 1u + (xch_late ? 0x10000u : 0u);
+                const unsigned t = __hip_atomic_fetch_add(sa.xch_ticket, mine, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                s_xch_last = (t & 0xffffu) == gridDim.x - 1u;
+                s_xch_poison = ((t + mine) >> 16) != 0u;
                 if (s_xch_last) __hip_atomic_store(sa.xch_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
@@ -741,7 +756,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 const int parity = (int)(sa.xch_signal & 1ull), total = kK * c + kK;
                 for (int e = tid; e < total; e += kStepThreads) {
-                    const double v = __hip_atomic_load(stats + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const double v = s_xch_poison ? __builtin_nan("") : __hip_atomic_load(stats + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     for (int p = 0; p < sa.xch_nranks; p++)
                         __hip_atomic_store(pxsom::p2p_slot(sa.xch_peers[p], parity, sa.xch_rank, sa.xch_nranks, (size_t)sa.xch_max_count) + e, v,
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

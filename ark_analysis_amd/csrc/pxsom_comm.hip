@@ -102,10 +102,12 @@ __global__ __launch_bounds__(1024) void p2p_allreduce_kernel(P2PArgs a, double *
     }
     // 3. everybody's contribution has arrived in MY block
     P2PBlock *mine = reinterpret_cast<P2PBlock *>(a.peer[a.rank]);
+    // (an exchange already on record as timed out: the peer that missed it will miss this one's epoch too -- a run of exchanges
+    // enqueued back to back must not wait four seconds in each of them)
     __shared__ int s_timeout;
-    if (tid == 0) s_timeout = 0;
+    if (tid == 0) s_timeout = __hip_atomic_load(&mine->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0ull;
     __syncthreads();
-    if (tid < a.nranks) {
+    if (tid < a.nranks && !s_timeout) {
         const long long t0 = (long long)wall_clock64();   // 100 MHz
         while (__hip_atomic_load(&mine->flags[parity][tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != a.epoch) {
             __builtin_amdgcn_s_sleep(8);

@@ -71,6 +71,7 @@ class HipKernels:
         # (every rank enters the collective whatever its own flag says: a debug toggle on one rank must not leave the others
         # waiting inside an all-reduce the rest skipped)
         self._unfused_now = self.unfused
+        self.route_agreement = None
         if _world(group) > 1:
             # launch-per-phase everywhere only where the ranks DISAGREE (some could take the one-launch 10 x 10 step, some
             # not -- an oddly aligned or empty shard), or where a rank asked for it.  Where no rank can take the fused step
@@ -78,11 +79,14 @@ class HipKernels:
             # launch-per-phase route per step, which give the same bits (tests/test_gpu_schedule.py,
             # test_wide_bmu_only_steps_match_the_oracle_per_step).
             mine = (not self.unfused) and self._sd.batch_train_fused_route(x, xdim, ydim, st.schedule)
-            flags = torch.tensor([1 if mine else 0, 0 if mine else -1, 0 if self.unfused else 1], dtype=torch.int32,
+            # one MIN-reduce carries "all", "any" and "nobody asked": [1 if mine] is 1 only when every rank can take the fused step,
+            # [-1 if mine] is -1 as soon as ONE rank can, [1 unless this rank asked for the launch-per-phase route]
+            flags = torch.tensor([1 if mine else 0, -1 if mine else 0, 0 if self.unfused else 1], dtype=torch.int32,
                                  device=_collective_device(group))
             dist.all_reduce(flags, op=dist.ReduceOp.MIN, group=group)
-            all_fused, any_fused, nobody_asked = bool(flags[0].item()), flags[1].item() == 0, bool(flags[2].item())
+            all_fused, any_fused, nobody_asked = bool(flags[0].item()), flags[1].item() == -1, bool(flags[2].item())
             self._unfused_now = (not nobody_asked) or (any_fused and not all_fused)
+            self.route_agreement = {"all_fused": all_fused, "any_fused": any_fused, "unfused_now": self._unfused_now}
 
     def steps(self, x, g0: int, g1: int, total: int, alpha_range, radius_range, comm=None) -> None:
         self._sd.batch_train_steps(x, self._state, g0, g1, total, alpha_range, radius_range,

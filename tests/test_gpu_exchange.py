@@ -338,6 +338,141 @@ def test_uneven_shards_end_in_equal_codebooks(tmp_path, c, rows):
     assert res["same"].all(), "codebook differs between the ranks"
 
 
+def _mixed_route_worker(rank, world, port, shards, w0, out_dir, route):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PXSOM_EXCHANGE=route)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from ark_analysis_amd.distributed import BatchSOMTrainer
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    x = torch.from_numpy(shards[rank]).to(dev)
+    if rank == 1:                                   # the same rows behind an ODD row stride: not the fused step's shape
+        wide = torch.zeros((x.shape[0], x.shape[1] + 1), dtype=x.dtype, device=dev)
+        wide[:, :x.shape[1]] = x
+        x = wide[:, :x.shape[1]]
+    w = torch.from_numpy(w0.copy()).to(dev)
+    trainer = BatchSOMTrainer(10, 10, x.shape[1], dev)
+    trainer.train(x, w, num_passes=1)
+    torch.cuda.synchronize()
+    gathered = [torch.zeros(w.shape, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(gathered, w.cpu())
+    agreement = dict(trainer.kernels.route_agreement)
+    np.savez(os.path.join(out_dir, "mixed_%s_%d.npz" % (route, rank)), w=w.cpu().numpy(),
+             same=np.array([bool(torch.equal(g, gathered[0])) for g in gathered]),
+             flags=np.array([agreement["all_fused"], agreement["any_fused"], agreement["unfused_now"]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("route", ["p2p", "fused"])
+def test_one_misaligned_shard_sends_every_rank_to_the_launch_per_phase_route(oracle, tmp_path, route):
+    """Round 5's advice: rank 0 can take the one-launch 10 x 10 step, rank 1 cannot (odd row stride).  The route is a collective
+    decision -- `any but not all` must be detected (it was not: the second flag of the MIN-reduce could never differ from the
+    first) and every rank must then run the launch-per-phase steps, or one rank would wait inside the fused step's in-kernel
+    exchange for a peer that exchanges through the separate launch.  Both ranks report the same verdict, end with array_equal
+    codebooks, and the codebook matches the oracle on the united rows."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from ark_analysis_amd import synth
+    from ark_analysis_amd.flowsom import default_radius_range
+    from ark_analysis_amd.schedule import BatchSchedule
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    k, c, n_local = 100, 22, 19_200
+    shards = [synth.make_fov_numpy(n_local, c, seed=370 + r, dtype=np.float32) for r in range(2)]
+    w0 = shards[0][np.random.RandomState(5).choice(n_local, k, replace=False)].astype(np.float64)
+    mp.spawn(_mixed_route_worker, args=(2, port, shards, w0, str(tmp_path), route), nprocs=2, join=True)
+    res = [np.load(str(tmp_path / ("mixed_%s_%d.npz" % (route, r)))) for r in range(2)]
+    for r in res:
+        assert list(r["flags"]) == [False, True, True], list(r["flags"])   # not all, but some: launch per phase everywhere
+        assert r["same"].all(), "codebook differs between the ranks"
+    sch = BatchSchedule.two_phase()
+    phases = sch.phases
+    assert n_local % phases == 0
+    blocks = [shards[r][j * phases:(j + 1) * phases] for j in range(n_local // phases) for r in range(2)]
+    want = oracle.som_batch_sched(np.concatenate(blocks).astype(np.float64), w0, 10, 10, 1, (0.05, 0.01), default_radius_range(10, 10),
+                                  phases, sch.edges)
+    np.testing.assert_allclose(res[0]["w"], want, rtol=1e-9, atol=0)
+
+
+def _late_peer_worker(rank, world, port, shards, w0, out_dir, route):
+    import time
+    import warnings
+
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PXSOM_EXCHANGE=route)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from ark_analysis_amd import som_device
+    from ark_analysis_amd.distributed import BatchSOMTrainer
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    x = torch.from_numpy(shards[rank]).to(dev)
+    w = torch.from_numpy(w0.copy()).to(dev)
+    if rank == 1:       # rank 1 reaches the run of steps six seconds after rank 0: past the exchanges' four-second bound
+        real, held = som_device.batch_train_steps, []
+
+        def held_back(*a, **k):
+            if not held:
+                held.append(1)
+                time.sleep(6.0)
+            return real(*a, **k)
+        som_device.batch_train_steps = held_back
+    trainer = BatchSOMTrainer(10, 10, x.shape[1], dev)
+    t0 = time.time()
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        trainer.train(x, w, num_passes=1)
+        torch.cuda.synchronize()
+    took = time.time() - t0
+    gathered = [torch.zeros(w.shape, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(gathered, w.cpu())
+    np.savez(os.path.join(out_dir, "late_%s_%d.npz" % (route, rank)), w=w.cpu().numpy(), took=np.array(took),
+             same=np.array([bool(torch.equal(g, gathered[0])) for g in gathered]),
+             retired=np.array(any("retired" in str(c.message) for c in caught)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("route", ["fused", "p2p"])
+def test_a_late_peer_is_noticed_and_the_pass_repeated(oracle, tmp_path, route):
+    """A rank that reaches its run of steps after the exchanges' four-second bound: the waiting rank records the epoch, is late
+    at once in every later step of the call (no cascade of timeouts: the call returns in seconds, not steps x 4 s), still raises
+    its own flags -- over NaN slots on the in-kernel route -- and the ranks agree to retire the route and run the pass again
+    through torch.distributed: equal, finite codebooks that match the oracle on the united rows (round 5's advice)."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from ark_analysis_amd import synth
+    from ark_analysis_amd.flowsom import default_radius_range
+    from ark_analysis_amd.schedule import BatchSchedule
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    k, c, n_local = 100, 22, 19_200
+    shards = [synth.make_fov_numpy(n_local, c, seed=470 + r, dtype=np.float32) for r in range(2)]
+    w0 = shards[1][np.random.RandomState(6).choice(n_local, k, replace=False)].astype(np.float64)
+    mp.spawn(_late_peer_worker, args=(2, port, shards, w0, str(tmp_path), route), nprocs=2, join=True)
+    res = [np.load(str(tmp_path / ("late_%s_%d.npz" % (route, r)))) for r in range(2)]
+    assert bool(res[0]["retired"]), "rank 0 did not report the retired route"
+    for r in res:
+        assert r["same"].all() and np.isfinite(r["w"]).all()
+        assert float(r["took"]) < 40.0, float(r["took"])       # one or two timeouts, not one per step
+    sch = BatchSchedule.two_phase()
+    phases = sch.phases
+    blocks = [shards[r][j * phases:(j + 1) * phases] for j in range(n_local // phases) for r in range(2)]
+    want = oracle.som_batch_sched(np.concatenate(blocks).astype(np.float64), w0, 10, 10, 1, (0.05, 0.01), default_radius_range(10, 10),
+                                  phases, sch.edges)
+    np.testing.assert_allclose(res[0]["w"], want, rtol=1e-9, atol=0)
+
+
 def _native_exchange_worker(rank, world, lib_path, port, out_path, wrong):
     os.environ.update(PXSOM_RCCL_LIBRARY=lib_path, PXSOM_NATIVE_EXCHANGE="force", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if wrong:
