@@ -83,6 +83,7 @@ SYMBOLS = {
     "pxsom_comm_p2p_handle": (_i32, [_vp, _vp, _sz]),
     "pxsom_comm_p2p_connect": (_i32, [_vp, _vp, _sz]),
     "pxsom_comm_p2p_error": (_i32, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
+    "pxsom_comm_p2p_set_fused": (_i32, [_vp, _i32]),
 }
 
 _lib = None

@@ -79,6 +79,7 @@ struct pxsom_comm {
     size_t max_count = 0;
     unsigned long long epoch = 0;
     char *dev_table = nullptr;                   // [nranks] peer pointers + the fused steps' ticket word, in device memory (connect)
+    bool fused = false;                          // pxsom_comm_p2p_set_fused: the fused 10 x 10 step exchanges inside its launch
 };
 
 namespace {
@@ -161,7 +162,7 @@ namespace pxsom {
 // and reserves the epochs of `exchanges` fused exchanges (the next separate all-reduce continues behind them).
 bool comm_fused_begin(pxsom_comm *c, int exchanges, size_t count, FusedXch *out)
 {
-    if (!c || !c->p2p || !c->dev_table || count > c->max_count || exchanges < 0) return false;
+    if (!c || !c->p2p || !c->fused || !c->dev_table || count > c->max_count || exchanges < 0) return false;
     for (int p = 0; p < c->nranks; p++)
         if (!c->peer[p]) return false;
     out->peers = reinterpret_cast<char *const *>(c->dev_table);
@@ -312,6 +313,13 @@ PXSOM_EXPORT int pxsom_comm_p2p_error(pxsom_comm *c, unsigned long long *epoch_o
     P2PBlock head;
     PXSOM_HIP_TRY(hipMemcpy(&head, c->block, sizeof(head), hipMemcpyDeviceToHost));
     *epoch_out = head.error;
+    return PXSOM_OK;
+}
+
+PXSOM_EXPORT int pxsom_comm_p2p_set_fused(pxsom_comm *c, int on)
+{
+    if (!c || !c->p2p) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_comm_p2p_set_fused: not a peer-to-peer communicator");
+    c->fused = on != 0;
     return PXSOM_OK;
 }
 

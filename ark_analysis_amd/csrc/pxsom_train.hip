@@ -1929,7 +1929,7 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
             if (g_end - g >= 2 && g_end - g <= pxsom_bmu::kMaxTailSteps) g_tail = g;
         }
     }
-    // The exchange inside the step launches (round 5; PXSOM_EXCHANGE=fused, a peer-to-peer communicator, the fused 10 x 10 step):
+    // The exchange inside the step launches (round 5; a peer-to-peer communicator with pxsom_comm_p2p_set_fused, the fused 10 x 10 step):
     // step gg's last workgroup hands this rank's statistics to every rank, step gg + 1 adds the ranks' slots in rank order while
     // it applies the pending update -- no all-reduce launch between two steps.  The last step of the call keeps the separate
     // all-reduce: the next call (or the final update) reads the ring.  Every rank takes the same decision (same environment,
@@ -1937,8 +1937,7 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
     pxsom::FusedXch fxch;
     bool fused_xch = false;
     {
-        static const bool fused_env = getenv("PXSOM_EXCHANGE") != nullptr && strcmp(getenv("PXSOM_EXCHANGE"), "fused") == 0;
-        if (comm && fused_shape && fused_env && g_tail - g_begin >= 2)
+        if (comm && fused_shape && g_tail - g_begin >= 2)   // (false unless the communicator is peer-to-peer with its fused switch on)
             fused_xch = pxsom::comm_fused_begin(comm, g_tail - g_begin - 1, nstats, &fxch);
     }
     for (int gg = g_begin; gg < g_tail; gg++) {

@@ -19,6 +19,7 @@ steps in 22 dependent launches).  pxsom_batch_train_sched runs the step loop ins
 register-resident shapes a step is ONE launch (the update of step g-1 and the codebook preparation sit at the head of
 step g's BMU search).  Oracle of record: oracle/pxsom_oracle.c (orc_som_batch_sched).
 """
+import time
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -284,40 +285,82 @@ def _group_key(group):
     return tuple(sorted(dist.get_process_group_ranks(group))) if group is not None else None
 
 
-def native_exchange(group=None):
-    """libpxsom's own RCCL communicator over the ranks of ``group`` (see HipKernels.exchange).  Collective: every
-    rank of the group calls it at the same point.  Two agreed phases, so that a rank that cannot take part
-    (no RCCL to bind, id not drawn) never leaves the others waiting inside ncclCommInitRank."""
+# Which in-library exchange a multi-rank job takes:
+#   "auto" (default)  both routes are made and checked; each runs a short timed series of the rule's own all-reduce ([K C + K]
+#                     binary64 words); the peer-to-peer route INSIDE the step launches is taken when its one-launch form measured
+#                     at most FLIP_RATIO of RCCL's time per exchange (MAX over the ranks: every rank computes the same verdict),
+#                     RCCL otherwise.  A route that cannot be made, fails its first checked exchange or times out is not a candidate.
+#   "rccl" | "p2p" | "fused"   that route (falling back as before when it cannot be made).
+# Set by set_exchange_route() or PXSOM_EXCHANGE in the environment of every rank.
+FLIP_RATIO = 0.7
+_route = None
+exchange_report = {}      # group key -> what was measured and chosen (bench.py prints it)
+
+
+def set_exchange_route(route: Optional[str]) -> None:
+    """"auto" | "rccl" | "p2p" | "fused" | None (= environment / default).  Call it on every rank, before the first training run."""
+    global _route
+    if route not in (None, "auto", "rccl", "p2p", "fused"):
+        raise ValueError("exchange route: auto, rccl, p2p or fused")
+    _route = route
+
+
+def _exchange_route() -> str:
     import os
-    import warnings
-    key = _group_key(group)
-    if key in _native_comms:
-        return _native_comms[key]
-    comm = None
-    wanted = os.environ.get("PXSOM_NATIVE_EXCHANGE", "1")     # "0": never; "force": on any backend (tests: gloo group
-    # PXSOM_EXCHANGE=p2p (opt-in, round 4): the one-shot peer-to-peer exchange over HIP IPC blocks instead of RCCL -- one launch
-    # per step and rank, bit-identical sums; validated with two ranks on ONE device (tests/test_gpu_exchange.py), no
-    # multi-GPU hardware run exists yet, hence not the default.  Any backend: the handles travel as host objects.
-    # PXSOM_EXCHANGE=fused (round 5): the same blocks, and the fused 10 x 10 step runs the exchange INSIDE its launch (the last
-    # workgroup of a step writes to every rank, the next step's prologue adds the slots: csrc/pxsom_batch_step.hip); other
-    # shapes and the last step of a call keep the one-launch exchange.
-    if wanted != "0" and os.environ.get("PXSOM_EXCHANGE", "rccl") in ("p2p", "fused") and torch.cuda.is_available():
-        from . import som_device
-        rank, world = dist.get_rank(group), dist.get_world_size(group)
-        err = None
+    route = _route or os.environ.get("PXSOM_EXCHANGE", "auto")
+    return route if route in ("auto", "rccl", "p2p", "fused") else "auto"
+
+
+def _make_p2p(group):
+    """A connected, checked peer-to-peer communicator, or (None, why) -- agreed by all ranks."""
+    from . import som_device
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    comm, err = None, None
+    try:
+        comm = som_device.P2PComm(world, rank, 1 << 18)
+    except Exception as e:          # noqa: BLE001 -- agreed below: all ranks fall back together
+        err = e
+    if _all_ranks_ok(comm is not None, group):
+        box = [None] * world
+        dist.all_gather_object(box, comm.local_handle, group=group)
         try:
-            comm = som_device.P2PComm(world, rank, 1 << 18)
-        except Exception as e:          # noqa: BLE001 -- agreed below: all ranks fall back together
+            comm.connect(box)
+        except Exception as e:      # noqa: BLE001
             err = e
-        if _all_ranks_ok(comm is not None, group):
-            box = [None] * world
-            dist.all_gather_object(box, comm.local_handle, group=group)
-            try:
-                comm.connect(box)
-            except Exception as e:      # noqa: BLE001
-                err = e
-                comm.close()
-                comm = None
+            comm.close()
+            comm = None
+    elif comm is not None:
+        comm.close()
+        comm = None
+    usable = _all_ranks_ok(comm is not None, group)
+    if usable and not _exchange_verified(comm, group):
+        usable, err = False, "its first all-reduce did not return the expected sums"
+    if usable and not _all_ranks_ok(comm.error_epoch() == 0, group):
+        usable, err = False, "a peer was late for its first all-reduce"
+    if not usable:
+        if comm is not None:
+            comm.close()
+        return None, err
+    return comm, None
+
+
+def _make_rccl(group):
+    from . import som_device
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    comm, uid, err = None, None, None
+    try:
+        som_device.RankComm.bind()
+        if rank == 0:
+            uid = som_device.RankComm.unique_id()
+    except Exception as e:          # agreed below: all ranks fall back together
+        err = e
+    if _all_ranks_ok(err is None, group):
+        box = [uid]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        try:
+            comm = som_device.RankComm(box[0], world, rank)
+        except Exception as e:      # noqa: BLE001
+            err = e
         usable = _all_ranks_ok(comm is not None, group)
         if usable and not _exchange_verified(comm, group):
             usable, err = False, "its first all-reduce did not return the expected sums"
@@ -325,37 +368,88 @@ def native_exchange(group=None):
             if comm is not None:
                 comm.close()
             comm = None
-            if rank == 0:
-                warnings.warn("peer-to-peer exchange unavailable (%s): falling back" % err)
-        else:
-            _native_comms[key] = comm
-            return comm
-    if wanted != "0" and (dist.get_backend(group) == "nccl" or wanted == "force"):   # + a stand-in collective library)
-        from . import som_device
-        rank, world = dist.get_rank(group), dist.get_world_size(group)
-        uid, err = None, None
-        try:
-            som_device.RankComm.bind()
-            if rank == 0:
-                uid = som_device.RankComm.unique_id()
-        except Exception as e:          # agreed below: all ranks fall back together
-            err = e
-        if _all_ranks_ok(err is None, group):
-            box = [uid]
-            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            try:
-                comm = som_device.RankComm(box[0], world, rank)
-            except Exception as e:
-                err = e
-            usable = _all_ranks_ok(comm is not None, group)
-            if usable and not _exchange_verified(comm, group):
-                usable, err = False, "its first all-reduce did not return the expected sums"
-            if not usable:
-                if comm is not None:
-                    comm.close()
-                comm = None
-        if comm is None and rank == 0:
-            warnings.warn("in-library RCCL exchange unavailable (%s): all-reducing through torch.distributed" % err)
+    return comm, err
+
+
+def _exchange_us(comm, group, words: int = 2300, reps: int = 40) -> float:
+    """Microseconds per all-reduce of ``words`` binary64 values through ``comm``, back to back on this stream: MAX over the ranks
+    (the same number on every rank); inf where an exchange failed."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    probe = torch.zeros(words, dtype=torch.float64, device=dev)
+    ok = True
+    us = float("inf")
+    try:
+        for _ in range(6):
+            comm.allreduce_sum(probe)
+        torch.cuda.synchronize()
+        dist.barrier(group=group)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            comm.allreduce_sum(probe)
+        torch.cuda.synchronize()
+        us = (time.perf_counter() - t0) / reps * 1e6
+        if hasattr(comm, "error_epoch") and comm.error_epoch() != 0:
+            ok = False
+        if not bool(torch.isfinite(probe).all().item()):
+            ok = False
+    except Exception:      # noqa: BLE001 -- agreed below
+        ok = False
+    t = torch.tensor([us if ok else float("inf")], dtype=torch.float64, device=_collective_device(group))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())
+
+
+def native_exchange(group=None):
+    """libpxsom's own communicator over the ranks of ``group`` (see HipKernels.exchange): RCCL, or the one-shot peer-to-peer
+    exchange over HIP IPC blocks -- on the fused 10 x 10 step inside the step launches.  Collective: every rank of the group calls
+    it at the same point.  Every phase is agreed, so that a rank that cannot take part (no RCCL to bind, a block that cannot be
+    mapped) never leaves the others waiting.  The route: see ``set_exchange_route``; what was measured and chosen is kept in
+    ``exchange_report``."""
+    import os
+    import warnings
+    key = _group_key(group)
+    if key in _native_comms:
+        return _native_comms[key]
+    wanted = os.environ.get("PXSOM_NATIVE_EXCHANGE", "1")     # "0": never; "force": on any backend (tests: gloo group
+    route = _exchange_route()                                  # + a stand-in collective library)
+    rank = dist.get_rank(group)
+    report = {"route_asked": route}
+    comm = None
+    if wanted != "0" and torch.cuda.is_available():
+        on_rccl_backend = dist.get_backend(group) == "nccl"
+        p2p = rccl = None
+        if route in ("p2p", "fused") or (route == "auto" and on_rccl_backend):
+            p2p, why = _make_p2p(group)
+            if p2p is None:
+                report["p2p"] = "unavailable: %s" % why
+                if rank == 0 and route != "auto":
+                    warnings.warn("peer-to-peer exchange unavailable (%s): falling back" % why)
+        if route in ("p2p", "fused") and p2p is not None:
+            comm = p2p
+            comm.set_fused(route == "fused")
+        elif on_rccl_backend or wanted == "force":
+            rccl, why = _make_rccl(group)
+            if rccl is None:
+                report["rccl"] = "unavailable: %s" % why
+            if rccl is not None and p2p is not None:          # auto: both work -- the faster one, by the rule of FLIP_RATIO
+                report["rccl_us_per_exchange"] = round(_exchange_us(rccl, group), 2)
+                report["p2p_us_per_exchange"] = round(_exchange_us(p2p, group), 2)
+                take_p2p = report["p2p_us_per_exchange"] <= FLIP_RATIO * report["rccl_us_per_exchange"]
+                report["rule"] = "peer-to-peer inside the step launches when its one-launch exchange takes <= %.2f x RCCL's" % FLIP_RATIO
+                comm, other = (p2p, rccl) if take_p2p else (rccl, p2p)
+                other.close()
+                if take_p2p:
+                    comm.set_fused(True)
+            elif rccl is not None:
+                comm = rccl
+            elif p2p is not None:                             # auto without a working RCCL binding
+                comm = p2p
+                comm.set_fused(True)
+            if comm is None and rank == 0:
+                warnings.warn("in-library exchange unavailable (%s): all-reducing through torch.distributed" % why)
+    report["route_taken"] = ("torch.distributed" if comm is None else
+                             ("p2p-fused" if getattr(comm, "fused", False) else "p2p") if hasattr(comm, "error_epoch") else "rccl")
+    exchange_report[key] = report
     _native_comms[key] = comm
     return comm
 

@@ -247,6 +247,7 @@ class P2PComm:
                     "pxsom_comm_p2p_create")
         self.handle = box
         self.nranks, self.rank, self.max_count = int(nranks), int(rank), int(max_count)
+        self.fused = False
         mine = ctypes.create_string_buffer(P2P_HANDLE_BYTES)
         _capi.check(_capi.lib().pxsom_comm_p2p_handle(self.handle, ctypes.cast(mine, ctypes.c_void_p), P2P_HANDLE_BYTES),
                     "pxsom_comm_p2p_handle")
@@ -269,6 +270,11 @@ class P2PComm:
             raise ValueError("the exchange reduces contiguous float64 buffers")
         rc = _capi.lib().pxsom_comm_allreduce_sum_f64(self.handle, t.data_ptr(), t.numel(), _capi.stream_ptr())
         _capi.check(rc, "pxsom_comm_allreduce_sum_f64")
+
+    def set_fused(self, on: bool) -> None:
+        """The fused 10 x 10 training step runs the exchange inside its own launch (every rank: the same value)."""
+        _capi.check(_capi.lib().pxsom_comm_p2p_set_fused(self.handle, 1 if on else 0), "pxsom_comm_p2p_set_fused")
+        self.fused = bool(on)
 
     def error_epoch(self) -> int:
         """0, or the number of the first exchange a peer did not arrive at in time (its result was NaN)."""

@@ -310,8 +310,16 @@ def main():
         dist.all_gather(gathered, mine)
         per_rank = {"train_batch": [round(float(g[0]), 4) for g in gathered],
                     "assign_and_mean_table": [round(float(g[1]), 4) for g in gathered]}
+        from ark_analysis_amd import distributed as _dm
         from ark_analysis_amd.distributed import native_exchange
         native = native_exchange(None)                                     # (made once per group: cached by now)
+        # replicas: every rank must hold the same codebook bit for bit after the timed passes
+        wcpu = w.detach().cpu()
+        copies = [torch.zeros_like(wcpu) for _ in range(world)]
+        dist.all_gather(copies, wcpu)
+        per_rank["codebooks_equal"] = bool(all(torch.equal(cp, copies[0]) for cp in copies)) and bool(torch.isfinite(wcpu).all())
+        per_rank["kernel_route_agreement"] = getattr(trainer.kernels, "route_agreement", None)
+        per_rank["exchange_decision"] = _dm.exchange_report.get(None)
         comm_ranks = world if native is not None else 0
         assert dist.get_world_size() == args.gpus, "process group size and --gpus disagree"
         # the rule's only exchange, timed on its own after the timed region: one [K*C + K] binary64 all-reduce per step, back
@@ -330,10 +338,11 @@ def main():
         per_rank["exchange_us_per_step"] = round(float(exch.item()), 2)
         per_rank["exchange_ms_per_pass"] = round(float(exch.item()) * sched.steps * 1e-3, 4)
         per_rank["exchange_route"] = type(native).__name__ if native is not None else "torch.distributed"
+        per_rank["exchange_fused"] = bool(getattr(native, "fused", False))
         # the other in-library route beside it: the one-shot peer-to-peer exchange over HIP IPC blocks (opt-in, PXSOM_EXCHANGE=p2p;
         # validated with two ranks on one device only -- no multi-GPU hardware number exists until a SCALE record holds one)
-        p2p_us = None
-        if not isinstance(native, som_device.P2PComm):
+        p2p_us = (_dm.exchange_report.get(None) or {}).get("p2p_us_per_exchange")    # ("auto": both routes were timed when the communicator was made)
+        if not isinstance(native, som_device.P2PComm) and p2p_us is None:
             pc, handles = None, [None] * world
             try:
                 pc = som_device.P2PComm(world, rank, K * (C + 1))
@@ -406,7 +415,7 @@ def main():
                    "rccl_ranks": (0 if dry else world) if use_dist else 0,
                    **({"dry_run": "all ranks on one GPU over gloo: exercises the N > 1 code, timings are meaningless"} if dry else {}),
                    "exchange": ((("in-library peer-to-peer exchange INSIDE the step launches (HIP IPC blocks; last workgroup writes, next step's prologue adds)"
-                                  if os.environ.get("PXSOM_EXCHANGE") == "fused" and cfg["kind"] != "cell" else
+                                  if per_rank.get("exchange_fused") and cfg["kind"] != "cell" else
                                   "in-library peer-to-peer all-reduce (HIP IPC blocks, one launch per rank) behind every step")
                                  if per_rank and per_rank.get("exchange_route") == "P2PComm" else
                                  "in-library RCCL all-reduce behind every step") if comm_ranks else "torch.distributed all-reduce per step")

@@ -291,16 +291,18 @@ int pxsom_comm_allreduce_sum_f64(pxsom_comm *comm, double *buf_dev, size_t count
  *   rank order) -> connect(all handles).  The communicator then serves pxsom_comm_allreduce_sum_f64 and
  *   pxsom_batch_train_sched like an RCCL one.  pxsom_comm_p2p_error: 0, or the epoch at which a peer failed to arrive
  *   within 4 s (that exchange's buffer was set to NaN; the GPU is not left hanging; the FIRST such epoch stays on record).
- * Round 5: with PXSOM_EXCHANGE=fused in the environment of every rank, pxsom_batch_train_sched on such a communicator runs the
+ * pxsom_comm_p2p_set_fused(comm, 1) (ABI 9; EVERY rank, same value): pxsom_batch_train_sched on such a communicator runs the
  * exchange INSIDE the launches of the fused 10 x 10 step (the last workgroup of a step writes this rank's statistics into every
  * block, the next step adds the slots in rank order while it applies the update: the same bits as the one-launch exchange, one
- * launch per step); a peer that is late there turns the codebook to NaN and sets the same error word.  The last step of a call
- * and every other shape keep the one-launch exchange. */
+ * launch per step); a peer that is late there turns the codebook to NaN, sets the same error word, and this rank still raises
+ * its flags (over NaN slots) so that nobody waits for it.  The last step of a call and every other shape keep the one-launch
+ * exchange.  The switch is a property of the communicator (no process-wide state). */
 #define PXSOM_P2P_HANDLE_BYTES 64
 int pxsom_comm_p2p_create(int nranks, int rank, size_t max_count, pxsom_comm **out);
 int pxsom_comm_p2p_handle(pxsom_comm *comm, void *handle_out, size_t handle_bytes);
 int pxsom_comm_p2p_connect(pxsom_comm *comm, const void *handles, size_t handles_bytes);
 int pxsom_comm_p2p_error(pxsom_comm *comm, unsigned long long *epoch_out);
+int pxsom_comm_p2p_set_fused(pxsom_comm *comm, int on);
 /* pxsom_batch_train_steps with the exchange enqueued behind every step (comm: RCCL or peer-to-peer; NULL = none).  Equal
  * steps only: 1 <= batch_steps <= PXSOM_MAX_SCHED_STEPS (256) and total_steps a whole number of passes (total_steps %
  * batch_steps == 0) -- other values are PXSOM_ERR_INVALID_ARG since ABI 7; schedules: pxsom_batch_train_sched. */

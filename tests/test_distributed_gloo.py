@@ -7,6 +7,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -52,22 +53,25 @@ def _worker(rank, world, port, shards, w0, xdim, ydim, m, out_path):
     dist.destroy_process_group()
 
 
-def test_two_rank_batch_training_matches_single_process_oracle(oracle, tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_two_rank_batch_training_matches_single_process_oracle(oracle, tmp_path, world):
+    """FOV-sharded batch training over `world` ranks (gloo, CPU; 8 = the node the scaling bench runs on): replicas equal, the
+    codebook that of ONE process on the united rows, the all-reduced cluster tables those of the united rows."""
     from ark_analysis_amd.flowsom import default_radius_range
     xdim = ydim = 5
     k, c, m, n_local = 25, 6, 8, 400
     rs = np.random.RandomState(0)
-    shards = [rs.gamma(0.8, 0.4, size=(n_local, c)) for _ in range(2)]
+    shards = [rs.gamma(0.8, 0.4, size=(n_local, c)) for _ in range(world)]
     w0 = shards[0][rs.choice(n_local, k, replace=False)].copy()
     out = str(tmp_path / "rank0.npz")
-    mp.spawn(_worker, args=(2, _free_port(), shards, w0, xdim, ydim, m, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), shards, w0, xdim, ydim, m, out), nprocs=world, join=True)
     res = np.load(out)
-    assert res["same"].all(), "codebook differs between ranks"
+    assert res["same"].all() and len(res["same"]) == world, "codebook differs between ranks"
     # single-process equivalent: interleave the shards in blocks of m rows so that global row i % m
-    # selects exactly the union of both ranks' local mini-batch (i % m)
+    # selects exactly the union of all ranks' local mini-batch (i % m)
     blocks = []
     for j in range(n_local // m):
-        for r in range(2):
+        for r in range(world):
             blocks.append(shards[r][j * m:(j + 1) * m])
     g = np.concatenate(blocks)
     want = oracle.som_batch(g, w0, xdim, ydim, 2, (0.05, 0.01), default_radius_range(xdim, ydim), m)

@@ -54,3 +54,38 @@ def test_two_rank_bench_line(gpu, tmp_path, exchange, config):
     else:                        # ... and the peer-to-peer route beside whichever one the pass used
         assert per_rank["exchange_us_per_step_p2p"] > 0
     assert line["scaling"] == ("weak" if config == "cfg2" else "strong")
+
+
+@pytest.mark.parametrize("config,exchange", [("cfg2", "torch.distributed"), ("cfg3", "fused"), ("cfg4", "p2p")])
+def test_eight_rank_bench_line(gpu, tmp_path, config, exchange):
+    """The driver's `--gpus 8` launch with all eight ranks on device 0 (gloo; one FOV resp. 125 000 cells per rank): ONE line,
+    every per-rank list eight long, the replicas' codebooks equal bit for bit after the timed passes, the kernel route agreed by
+    all ranks (config 4 at eight ranks is the 125 K-cell shard: wide one-launch steps where a step holds at most 16 K rows, launch
+    per phase beyond -- the same bits either way), the exchange route the line names is the one asked for."""
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", PXSOM_BENCH_DRY_RANKS="1")
+    if exchange == "torch.distributed":
+        env.update(PXSOM_NATIVE_EXCHANGE="0")
+    else:
+        env.update(PXSOM_EXCHANGE=exchange)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--config", config, "--fovs-per-gpu", "1", "--no-pmc", "--no-cpu-baseline", "--no-online", "--no-operating-range"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=str(tmp_path))
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert res.returncode == 0 and len(lines) == 1, res.stdout[-2000:] + res.stderr[-4000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["value"] > 0 and line["config"]["name"] == config
+    per_rank = line["phases_ms"]["per_rank"]
+    assert len(per_rank["train_batch"]) == 8 and len(per_rank["assign_and_mean_table"]) == 8
+    assert all(v > 0 for v in per_rank["train_batch"])
+    assert per_rank["codebooks_equal"] is True
+    agreed = per_rank["kernel_route_agreement"]
+    assert agreed is not None and agreed["unfused_now"] is False
+    if config == "cfg4":
+        assert agreed["all_fused"] is False and agreed["any_fused"] is False      # no rank has the 10 x 10 x <= 32 step: nothing forced
+        assert line["config"]["rows_per_gpu"] == 125_000 and line["scaling"] == "strong"
+    else:
+        assert agreed["all_fused"] is True
+    assert per_rank["exchange_route"] == ("torch.distributed" if exchange == "torch.distributed" else "P2PComm")
+    assert per_rank["exchange_fused"] is (exchange == "fused")
+    assert per_rank["exchange_decision"]["route_taken"] == {"torch.distributed": "torch.distributed", "fused": "p2p-fused", "p2p": "p2p"}[exchange]
