@@ -12,7 +12,7 @@ import subprocess
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 SO_PATH = os.path.join(_PKG, "libpxsom.so")
-SOURCES = ["pxsom_api.hip", "pxsom_assign.hip", "pxsom_assign_filter.hip", "pxsom_assign_filter_acc.hip", "pxsom_batch_step.hip", "pxsom_batch_step_wide.hip", "pxsom_batch_tail.hip", "pxsom_train.hip",
+SOURCES = ["pxsom_api.hip", "pxsom_assign.hip", "pxsom_assign_filter.hip", "pxsom_assign_filter_acc.hip", "pxsom_batch_step.hip", "pxsom_batch_step_wide.hip", "pxsom_train.hip",
            "pxsom_pre.hip", "pxsom_sums.hip", "pxsom_comm.hip"]
 # per-file extra flags: the filter works on provably finite scores (see the file header)
 EXTRA_FLAGS = {"pxsom_assign_filter.hip": ["-ffinite-math-only"] + (

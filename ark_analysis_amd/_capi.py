@@ -23,7 +23,7 @@ _STATUS = {0: "PXSOM_OK", -1: "PXSOM_ERR_INVALID_ARG", -2: "PXSOM_ERR_UNSUPPORTE
 # every symbol include/pxsom.h declares: (restype, argtypes)
 _vp, _i32, _i64, _f64, _sz = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double,
                               ctypes.c_size_t)
-ABI_VERSION = 8  # include/pxsom.h PXSOM_ABI_VERSION
+ABI_VERSION = 9  # include/pxsom.h PXSOM_ABI_VERSION
 
 SYMBOLS = {
     "pxsom_abi_version": (_i32, []),
@@ -35,6 +35,7 @@ SYMBOLS = {
     "pxsom_host_glibc_rand_fill": (_i32, [ctypes.c_uint32, _i64, _vp]),
     "pxsom_assign_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "pxsom_assign": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "pxsom_assign_ex": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _sz, _i32, _vp]),
     "pxsom_assign_last_exact_rows": (_i32, [_vp, _vp, ctypes.POINTER(ctypes.c_int64)]),
     "pxsom_cluster_sums": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _i32, _vp, _vp, _vp]),
     "pxsom_train_online": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _i32, _i32, _i32, _f64, _f64,

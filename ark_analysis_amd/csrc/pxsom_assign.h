@@ -155,36 +155,6 @@ struct StepArgs {
     unsigned long long xch_max_count = 0, xch_wait = 0, xch_signal = 0;
 };
 
-// The BMU-only tail of a training pass as ONE persistent launch (pxsom_batch_tail.hip): every step's row view, its
-// pending update's 1 - alpha, and where the state the per-step route would leave behind goes.
-constexpr int kMaxTailSteps = 64;
-struct TailStep {
-    int e0, width;             // the step takes the phases [e0, e0 + width): rows (f / width) * phases + e0 + f % width
-    long long rows;            // rows of the step (>= 1)
-    double q;                  // 1 - alpha of the update applied at the HEAD of this step (statistics of the step before)
-    double sat;                // batch_gain_saturation(q)
-};
-struct TailArgs {
-    int nsteps, phases;
-    int first_has_update;      // 0: the run starts here (W_in is searched as it is)
-    int final_update;          // 1: the last step's statistics are applied as well (q_final) and the result goes to w_final
-    double q_final, sat_final;
-    const double *stats_first; // [k*c sums | k counts] of the step before the first one (ring slot; first_has_update)
-    const double *w_in;        // [k, c] codebook the first update applies to
-    double *w_last;            // [k, c] receives the codebook the LAST step searched with (wbuf slot of that step)
-    double *stats_last;        // receives the last step's statistics (ring slot of that step)
-    double *stats_zero;        // ring slot of the step after the last one: cleared
-    double *w_final;           // final_update: [k, c]
-    char *scratch;             // tail_scratch_bytes(c): control words, member tables, published codebook
-    float tol_rel, tol_abs;
-    const float *mu32;         // centring vector (kFilterMaxChannels words + its norm) or NULL
-    double qmagic;
-    TailStep st[kMaxTailSteps];
-};
-size_t tail_scratch_bytes(int c);
-template <typename T>
-int launch_batch_tail(const T *x, int c, int64_t ldx, const TailArgs &ta, hipStream_t st);
-
 // round-half-even to the quantum behind qmagic (exact while |v| < 2^51 q)
 __device__ __forceinline__ double qround(double v, double qmagic) { return qmagic != 0.0 ? (v + qmagic) - qmagic : v; }
 

@@ -33,13 +33,13 @@ namespace {
 // bmu_exact_kernel (a wave per row or four: latency).  A wave of the former walks all K nodes at ~1 us each whatever
 // the list's length; the latter settles a row in about 0.4 ps x K x C on the whole chip: they meet near 2.25e6 / C
 // rows (measured: 100 K rows at C = 22, 22 K at C = 100).
-// PXSOM_SCREEN_MIN_ROWS overrides it (the tests send short lists through the screened kernel as well).
+// pxsom_assign_ex(..., PXSOM_ASSIGN_SCREEN_ALL_LISTS) sends every list there (the tests' route to that kernel on short lists).
 // Codebooks whose binary32 copy the screened kernel stages in LDS (12 .. 64 KB): its lane groups share the nodes of a short
 // batch, and the crossover drops to 8 K rows (measured on config 4, 100 x 100: pass 2.68 / 2.70 / 2.64 / 2.91 ms with the
 // crossover at 22.5 K / 2 K / 8 K / 512 rows).
-static unsigned screen_min_rows(int c, bool w32_in_lds)
+static unsigned screen_min_rows(int c, bool w32_in_lds, bool all_lists)
 {
-    if (const char *forced = getenv("PXSOM_SCREEN_MIN_ROWS")) return (unsigned)strtoul(forced, nullptr, 10);
+    if (all_lists) return 1u;
     const unsigned by_width = (unsigned)(2250000 / (c > 0 ? c : 1));
     return w32_in_lds ? std::min(by_width, 8192u) : by_width;
 }
@@ -637,7 +637,7 @@ static int prep_stage(size_t stage_bytes)
 template <typename T>
 int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int k, int32_t *labels,
                  double *dist, char *ws, const Layout &L_in, hipStream_t st, double *stats = nullptr,
-                 bool prepared = false, bool fixed = false)
+                 bool prepared = false, bool fixed = false, bool screen_all = false)
 {
     // binary16 rows of a wide codebook: packed-K fragments (pxsom_assign.h packed_k).  `prepared`: the caller's layout
     // says what the workspace holds.
@@ -730,7 +730,7 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
     // the binary32 codebook copy: scalar cache while it fits it, LDS up to 64 KB (two workgroups per CU), L2 beyond
     const size_t w32_bytes = (size_t)k * L.cp32 * sizeof(float);
     const bool w32_lds = w32_bytes > 12 * 1024 && w32_bytes <= 64 * 1024;
-    const unsigned screened_from = screen_min_rows(c, w32_lds);
+    const unsigned screened_from = screen_min_rows(c, w32_lds, screen_all);
     hipLaunchKernelGGL(bmu_exact_kernel<T>, dim3(egrid), dim3(256), use_lds ? wt_bytes : 0, st, x, c, ldx, w,
                        k, reinterpret_cast<const AssignHdr *>(ws),
                        reinterpret_cast<const unsigned *>(ws + L.off_list), labels, use_lds,
@@ -779,6 +779,13 @@ PXSOM_EXPORT int pxsom_assign(const void *x_dev, int64_t n, int c, int64_t ldx, 
                               const double *w_dev, int k, int32_t *labels_dev, double *dist_dev,
                               void *workspace_dev, size_t workspace_bytes, void *stream)
 {
+    return pxsom_assign_ex(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, dist_dev, workspace_dev, workspace_bytes, 0, stream);
+}
+
+PXSOM_EXPORT int pxsom_assign_ex(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype,
+                                 const double *w_dev, int k, int32_t *labels_dev, double *dist_dev,
+                                 void *workspace_dev, size_t workspace_bytes, int flags, void *stream)
+{
     if (n < 0 || n > 0x7fffffffLL)
         return pxsom::fail(PXSOM_ERR_INVALID_ARG, "pxsom_assign: n=%lld outside [0, 2^31)", (long long)n);
     if (c < 1 || c > PXSOM_MAX_CHANNELS)
@@ -799,7 +806,9 @@ PXSOM_EXPORT int pxsom_assign(const void *x_dev, int64_t n, int c, int64_t ldx, 
         PXSOM_HIP_TRY(hipMemsetAsync(ws, 0, kHdrBytes, st));
         return PXSOM_OK;
     }
-    PXSOM_DISPATCH_DTYPE(dtype, x_dev, xp, assign_typed<T>(xp, n, c, ldx, w_dev, k, labels_dev, dist_dev, ws, L, st));
+    const bool screen_all = (flags & PXSOM_ASSIGN_SCREEN_ALL_LISTS) != 0;
+    PXSOM_DISPATCH_DTYPE(dtype, x_dev, xp,
+                         assign_typed<T>(xp, n, c, ldx, w_dev, k, labels_dev, dist_dev, ws, L, st, nullptr, false, false, screen_all));
 }
 
 int pxsom_bmu::assign_accumulate(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev,

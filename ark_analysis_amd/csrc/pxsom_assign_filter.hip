@@ -29,6 +29,10 @@
 #ifndef PXSOM_PACKED_TMERGE
 #define PXSOM_PACKED_TMERGE 1
 #endif
+#ifndef PXSOM_FILTER_MODE
+#define PXSOM_FILTER_MODE 0
+#endif
+
 namespace pxsom_bmu {
 namespace {
 
@@ -378,12 +382,8 @@ template <typename T, int CPL, int NB, int RU>
 void launch_fast(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels,
                  hipStream_t st)
 {
-    auto kern = bmu_filter_fast<T, CPL, NB, RU, 0, false>;
-    if constexpr (NB == 7 && CPL == 6 && sizeof(T) == 4) {  // microbench hook (headline shape only)
-        const char *m = getenv("PXSOM_FILTER_MODE");
-        if (m && m[0] == '1') kern = bmu_filter_fast<T, CPL, NB, RU, 1, false>;
-        if (m && m[0] == '2') kern = bmu_filter_fast<T, CPL, NB, RU, 2, false>;
-    }
+    // (timing builds: -DPXSOM_FILTER_MODE=1 streams the rows without MFMA / top-2, 2 re-reads one cache-hot group)
+    auto kern = bmu_filter_fast<T, CPL, NB, RU, PXSOM_FILTER_MODE, false>;
     static pxsom::PerDevice<int> bpc_on;
     int &bpc = bpc_on.here();
     if (bpc == 0) {
@@ -664,218 +664,10 @@ __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_packed_kerne
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Packed-K filter in TWO STAGES (round 5; the wide codebooks' version of what bmu_filter_fast does for K = 100).  The packed
-// run of a node block is [Wh(0..C) | Wl(0..C)] against [Xh | Xh]; its first ceil(C / 32) MFMAs hold all of Wh, so
-//   stage 1: those MFMAs alone (the Wl slot groups of the last one zeroed on the row side): Wh*Xh, 2 MFMAs per block instead
-//            of 3 at C = 40, a row is vouched for if its top-2 gap clears the tolerance with the dropped term charged to it
-//            (|Wl.Xh| <= 2^-11 |W'||X'|: binary16 unit roundoff on W');
-//   stage 2: the rows stage 1 cannot vouch for wait in a queue of their wave (LDS, behind the fragments) and are searched
-//            64 at a time with all NPK MFMAs -- full tiles, outside the loop that streams the groups; what is still unsure
-//            there goes to the exact list as before.
-// One workgroup per CU on the codebook's LDS copy (BD = 1024 or 512 threads), four tiles per trip, transposing merge.  Labels identical to the one-stage kernel's by construction: both
-// only ever vouch for a row whose winner is certain, everything else is settled exactly.
-// ------------------------------------------------------------------------------------------------
-constexpr unsigned kPackedQueue = 192;   // rows a wave can hold back (a trip adds at most 64, a batch takes 64)
-template <int NPK, int BD>
-__global__ __launch_bounds__(BD, 1) void bmu_filter_packed2_kernel(
-    const _Float16 *__restrict__ x, int64_t n, int c, int64_t ldx, const half8 *__restrict__ wfrag,
-    const f32x4 *__restrict__ bias, AssignHdr *hdr, unsigned *__restrict__ amb_list, int32_t *__restrict__ labels)
-{
-    constexpr int TP = kTilesPerIter;
-    const int nb = hdr->nb;
-    constexpr unsigned idx_mask = 3u;
-    const float scale = hdr->scale, wn_max = hdr->wn_max, tol_abs = hdr->tol_abs, x_limit = hdr->x_limit;
-    const float tol_rel = hdr->tol_rel - 2.5f * ((float)(filter_accum_units(c, 3) - filter_accum_units(c, 2)) * 0x1p-24f + (0x1p-19f - 0x1p-21f));
-    const float tol_rel1 = tol_rel + 2.5f * 0x1p-11f;     // stage 1: the dropped Wl.Xh term
-    const bool force_exact = hdr->force_exact != 0 || scale < 1.f;
-    const int lane = threadIdx.x & 63;
-    const int pix = lane & 15, q = lane >> 4;
-    constexpr int WV = BD / 64;
-    const int wv = threadIdx.x >> 6;
-    const int64_t wave = (int64_t)blockIdx.x * WV + wv;
-    const int64_t nwaves = (int64_t)gridDim.x * WV;
-    const int64_t ngroups = (n + 63) / 64;
-
-    extern __shared__ __attribute__((aligned(16))) char filt_smem[];
-    half8 *lfrag = reinterpret_cast<half8 *>(filt_smem);
-    f32x4 *lbias = reinterpret_cast<f32x4 *>(lfrag + (size_t)nb * NPK * 64);
-    unsigned *s1_q = reinterpret_cast<unsigned *>(lbias + (size_t)nb * 64) + (size_t)wv * kPackedQueue;   // this wave's
-    unsigned s1_n = 0u;   // wave-uniform
-    {
-        const int nf = nb * NPK * 64;
-        for (int i0 = threadIdx.x; i0 < nf; i0 += 4 * BD) {
-            half8 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) v[u] = wfrag[i0 + u * BD < nf ? i0 + u * BD : 0];
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-                if (i0 + u * BD < nf) lfrag[i0 + u * BD] = v[u];
-        }
-        for (int i = threadIdx.x; i < nb * 64; i += BD) lbias[i] = bias[i];
-        __syncthreads();
-    }
-    const int g8 = c / 8;
-    const int n1 = (g8 + 3) / 4;    // MFMAs of a block that hold Wh
-    int choff[NPK];
-    bool first_term[NPK];
-#pragma unroll
-    for (int m = 0; m < NPK; m++) {
-        const int sg = 4 * m + q, term = sg / g8;
-        choff[m] = term < 2 ? 8 * (sg - term * g8) : -1;
-        first_term[m] = term == 0;
-    }
-    const _Float16 hscale = (_Float16)scale;   // a power of two in [1, 2^15]: exact
-
-    // one trip over 64 rows: the group g (stage 1) or `count` rows from the end of the wave's queue (all NPK MFMAs)
-    auto trip = [&](auto full_tag, int64_t g, unsigned count) {
-        constexpr bool FULL = decltype(full_tag)::value;
-        half8 bx[TP][NPK];
-        float ss[TP];
-#pragma unroll
-        for (int u = 0; u < TP; u++) {
-            int64_t row;
-            if constexpr (FULL) {
-                const unsigned slot = (unsigned)(u * 16 + pix);
-                row = (int64_t)s1_q[s1_n - count + (slot < count ? slot : 0u)];
-            } else {
-                row = g * 64 + u * 16 + pix;
-                if (row > n - 1) row = n - 1;
-            }
-            const _Float16 *rp = x + row * ldx;
-            float acc2 = 0.f;
-#pragma unroll
-            for (int m = 0; m < NPK; m++) {
-                half8 v = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
-                if (choff[m] >= 0 && (FULL || first_term[m])) v = *reinterpret_cast<const half8 *>(rp + choff[m]);
-                v = v * hscale;
-                if (first_term[m]) {   // |X|^2 from the first term's groups: every channel once
-#pragma unroll
-                    for (int i = 0; i < 8; i += 2) {
-                        const half2_t h2 = {v[i], v[i + 1]};
-                        acc2 = __builtin_amdgcn_fdot2(h2, h2, acc2, false);
-                    }
-                }
-                bx[u][m] = v;     // (stage 1: the Wl slot groups stay zero on the row side)
-            }
-            ss[u] = acc2;
-        }
-        float m1[TP], m2[TP];
-        int bsel[TP];
-#pragma unroll
-        for (int u = 0; u < TP; u++) {
-            m1[u] = m2[u] = kNegBig;
-            bsel[u] = 0;
-        }
-        for (int b = 0; b < nb; b++) {
-            f32x4 acc[TP];
-            const f32x4 bv = lbias[b * 64 + lane];
-#pragma unroll
-            for (int u = 0; u < TP; u++) acc[u] = bv;
-#pragma unroll
-            for (int m = 0; m < NPK; m++) {
-                if (FULL || m < n1) {
-                    const half8 wf = lfrag[(b * NPK + m) * 64 + lane];
-#pragma unroll
-                    for (int u = 0; u < TP; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, bx[u][m], acc[u], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < TP; u++) {
-                const float before = m1[u];
-                consume(m1[u], m2[u], acc[u], 0, idx_mask);
-                bsel[u] = m1[u] != before ? b : bsel[u];
-            }
-        }
-        // transposing merge of the four tiles (as the one-stage kernel): lane row q ends with tile q's merged result
-        float a1[TP], a2[TP], s2[TP];
-        int node[TP];
-#pragma unroll
-        for (int u = 0; u < TP; u++) {
-            a1[u] = m1[u];
-            a2[u] = m2[u];
-            s2[u] = ss[u];
-            const unsigned bb = (unsigned)bsel[u], r = __float_as_uint(a1[u]) & idx_mask;
-            node[u] = (int)((int)bb == nb - 1 ? (bb << 4) | (r << 2) | (unsigned)q : (bb << 4) | ((unsigned)q << 2) | r);
-        }
-        auto tmerge = [&](int xi, int yi, bool wide) {   // tiles xi, yi -> slot xi
-            uint2v r1, r2, rs, rn;
-            if (wide) {
-                r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a1[xi]), __float_as_uint(a1[yi]), false, false);
-                r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a2[xi]), __float_as_uint(a2[yi]), false, false);
-                rs = __builtin_amdgcn_permlane32_swap(__float_as_uint(s2[xi]), __float_as_uint(s2[yi]), false, false);
-                rn = __builtin_amdgcn_permlane32_swap((unsigned)node[xi], (unsigned)node[yi], false, false);
-            } else {
-                r1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(a1[xi]), __float_as_uint(a1[yi]), false, false);
-                r2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(a2[xi]), __float_as_uint(a2[yi]), false, false);
-                rs = __builtin_amdgcn_permlane16_swap(__float_as_uint(s2[xi]), __float_as_uint(s2[yi]), false, false);
-                rn = __builtin_amdgcn_permlane16_swap((unsigned)node[xi], (unsigned)node[yi], false, false);
-            }
-            const float ea = __uint_as_float(r1[0]), eb = __uint_as_float(r1[1]);
-            const int na = (int)rn[0], nb_ = (int)rn[1];
-            const bool take_b = eb > ea || (eb == ea && nb_ < na);
-            a2[xi] = fmaxf(fmaxf(fminf(ea, eb), __uint_as_float(r2[0])), __uint_as_float(r2[1]));
-            a1[xi] = take_b ? eb : ea;
-            node[xi] = take_b ? nb_ : na;
-            s2[xi] = __uint_as_float(rs[0]) + __uint_as_float(rs[1]);
-        };
-        tmerge(0, 1, false);
-        tmerge(2, 3, false);
-        tmerge(0, 2, true);
-        const float xn = __builtin_amdgcn_sqrtf(s2[0]) * 1.000001f;
-        const float trel = FULL ? tol_rel : tol_rel1;
-        const float tol = trel * (xn * wn_max + 0.5f * wn_max * wn_max) + tol_abs * (xn + wn_max);
-        unsigned sbits = __float_as_uint(s2[0]);
-        asm volatile("" : "+v"(sbits));
-        const bool nonfinite = (sbits & 0x7f800000u) == 0x7f800000u;
-        const bool unsure = !((a1[0] - a2[0]) > tol) || !(xn < x_limit) || nonfinite || force_exact;
-        int64_t row;
-        bool valid;
-        if constexpr (FULL) {
-            valid = (unsigned)lane < count;
-            row = (int64_t)s1_q[s1_n - count + (valid ? (unsigned)lane : 0u)];
-        } else {
-            row = g * 64 + lane;
-            valid = row < n;
-        }
-        const bool push = valid && unsure;
-        // a row that waits for the full search keeps no provisional label (the search's store is the only one); a row on the
-        // exact list keeps the full search's proposal, which the exact kernel replaces
-        if (valid && (FULL || !unsure)) labels[row] = node[0] + 1;
-        const unsigned long long mask = __ballot(push);
-        if (mask) {
-            if constexpr (FULL) {
-                unsigned base = 0;
-                if (lane == 0) base = atomicAdd(&hdr->amb_count, (unsigned)__popcll(mask));
-                base = __shfl(base, 0);
-                if (push) amb_list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned)row;
-            } else {
-                if (push) s1_q[s1_n + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = (unsigned)row;
-                s1_n += (unsigned)__popcll(mask);
-            }
-        }
-    };
-    auto drain = [&](bool all) {
-        while (s1_n >= 64u || (all && s1_n > 0u)) {
-            const unsigned cnt = s1_n < 64u ? s1_n : 64u;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            trip(std::integral_constant<bool, true>{}, 0, cnt);
-            __builtin_amdgcn_wave_barrier();
-            s1_n -= cnt;     // (taken from the END of the queue: nothing to move)
-        }
-    };
-    int64_t g = wave;
-    while (g < ngroups) {
-        while (g < ngroups && s1_n <= kPackedQueue - 64u) {
-            trip(std::integral_constant<bool, false>{}, g, 0u);
-            g += nwaves;
-        }
-        drain(g >= ngroups);
-    }
-}
-
+// (Round 5 built a two-stage form of this kernel -- the Wh MFMAs alone first, the rows they cannot vouch for searched in full from
+// per-wave queues --: bit-equal labels, 0.397 ms against 0.330 for the one-stage kernel on config 5's shape, since with 400 nodes too
+// many rows' top-2 gaps lie inside the 2^-11 |X'||W'| the dropped Wl term costs; profiles/r05/packed_filter_experiments.txt.  It has no
+// shape where it wins and was removed in round 6.)
 template <int NPK>
 void launch_packed(const _Float16 *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels, hipStream_t st)
 {
@@ -888,28 +680,9 @@ void launch_packed(const _Float16 *x, int64_t n, int c, int64_t ldx, char *ws, c
     const int cus = pxsom::device_cu_count();
     // one workgroup per CU (the codebook's fragments take 64 .. 150 KB of its LDS): 1024 threads -- four waves per SIMD on one
     // LDS copy; measured on config 5's shape (4.2 M rows x 40 binary16, 400 nodes) 0.332 ms against 0.370 with 512 threads:
-    // matrix and vector instructions of a SIMD overlap between waves, not inside one.  PXSOM_PACKED_BD=512: the old launch.
-    static const int big_bd = getenv("PXSOM_PACKED_BD") ? atoi(getenv("PXSOM_PACKED_BD")) : 1024;
-    // two stages (round 5): the Wh MFMAs alone first.  Opt-in (PXSOM_PACKED_TWO=1): measured SLOWER on config 5's shape -- 0.397 ms
-    // against 0.330 for the one-stage kernel on 4.2 M x 40 rows, same box (profiles/r05/packed_filter_experiments.txt): with 400
-    // nodes the top-2 gap of too many rows is inside the 2^-11 |X'||W'| the dropped Wl term costs, and they pay both stages
-    static const bool two_stage = getenv("PXSOM_PACKED_TWO") && getenv("PXSOM_PACKED_TWO")[0] == '1';
-    const size_t lds2 = lds + (size_t)16 * kPackedQueue * sizeof(unsigned);
-    if constexpr (NPK <= 4)   // (five MFMAs per block and more spill at the 128 VGPRs of a 1024-thread workgroup: never launched, not built)
-    if (two_stage && lds <= 140 * 1024 && lds > 64 * 1024 && big_bd == 1024 && (c / 8 + 3) / 4 < NPK) {
-        auto kern = bmu_filter_packed2_kernel<NPK, 1024>;
-        static pxsom::PerDevice<bool> raised_on;
-        bool &raised = raised_on.here();
-        if (!raised) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            raised = true;
-        }
-        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((ngroups + 15) / 16, cus));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds2, st, x, n, c, ldx, wf, bi, hd, al, labels);
-        return;
-    }
+    // matrix and vector instructions of a SIMD overlap between waves, not inside one.
     if constexpr (NPK <= 4)
-    if (lds <= 150 * 1024 && lds > 64 * 1024 && big_bd == 1024) {   // (five chunks and more spill at 128 VGPRs)
+    if (lds <= 150 * 1024 && lds > 64 * 1024) {   // (five chunks and more spill at 128 VGPRs)
         auto kern = bmu_filter_packed_kernel<NPK, 4, true, 1024>;
         static pxsom::PerDevice<bool> raised_on;
         bool &raised = raised_on.here();

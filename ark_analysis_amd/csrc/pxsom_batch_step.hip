@@ -1141,25 +1141,14 @@ int launch_step(const T *x, int64_t n, int c, int64_t ldx, double *stats, const 
     // 4 -- a round costs ~3.5 us whatever it holds, and the search itself runs at a fraction of the filter kernel's rate
     // workgroup slots: one per CU.  (Two fit -- 77 KB of LDS, <= 128 VGPRs each -- and were measured on the two-phase
     // schedule's large steps: SLOWER, pass 0.505 -> 0.574 ms; a step's time grows with the number of workgroups that flush
-    // their tables into the same 18 KB of statistics.  PXSOM_STEP_WGS_PER_CU=2 reproduces it.)
-    static int wgs_per_cu = 0;
-    if (wgs_per_cu == 0) {
-        const char *e = getenv("PXSOM_STEP_WGS_PER_CU");
-        wgs_per_cu = e ? atoi(e) : 1;
-        if (wgs_per_cu < 1 || wgs_per_cu > 2) wgs_per_cu = 1;
-    }
-    const int64_t cus = pxsom::device_cu_count(), slots = cus * wgs_per_cu;
+    // their tables into the same 18 KB of statistics.)
+    const int64_t cus = pxsom::device_cu_count(), slots = cus;
     int tpw = tiles_per_wave == 2 ? 2 : (tiles_per_wave == 4 ? 4 : 1);
     if (tiles_per_wave <= 0) {
         const int64_t blocks1 = (n + kStepWaves * 16 - 1) / (kStepWaves * 16);
         tpw = blocks1 <= slots ? 1 : (blocks1 <= 2 * slots ? 2 : 4);
-        static int small_tpw = 0;      // tuning hook: tiles per wave of the steps that fit one round (PXSOM_STEP_TPW_SMALL)
-        if (small_tpw == 0) {
-            const char *e = getenv("PXSOM_STEP_TPW_SMALL");
-            small_tpw = e ? atoi(e) : 1;
-            if (small_tpw != 1 && small_tpw != 2 && small_tpw != 4) small_tpw = 1;
-        }
-        if (blocks1 <= slots && blocks1 >= 8 * small_tpw) tpw = small_tpw;
+        // (steps that fit one round keep ONE tile per wave: with two, half as many workgroups flush their tables -- fewer
+        // atomics -- but search twice as long: pass 0.336 against 0.325 ms, profiles/r06/experiments.txt)
         // binary64 rows (the drop-in classes' tables): four tiles per wave spill 182 VGPRs, and more rounds of one tile cost
         // less than that -- measured on 1 M x 22, default schedule: pass 0.520 ms (by size) / 0.487 (two) / 0.474 (one)
         if (sizeof(T) == 8) tpw = 1;
@@ -1224,13 +1213,8 @@ bool launch_update_prepare(const StepArgs &sa, int xdim, int ydim, int c, char *
     double *wt_out = L.has_wt() ? reinterpret_cast<double *>(ws + L.off_wt) : nullptr;
     // workgroups: each redoes the update, the output (duplicates, fragments, bias, copies) is shared out by node
     // blocks -- 4 blocks of 16 nodes each at K = 400 (7 workgroups), 2 at K = 100 (4 workgroups)
-    static int share = -1;
-    if (share < 0) {
-        const char *e = getenv("PXSOM_UPDATE_SHARE");
-        share = !(e && e[0] == '0');
-    }
     const int bper = xdim == 10 ? 2 : 4;
-    const int grid = share ? (L.nb + bper - 1) / bper : 1;
+    const int grid = (L.nb + bper - 1) / bper;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kUpdThreads), lds, st, sa, c, reinterpret_cast<AssignHdr *>(ws),
                        reinterpret_cast<half8 *>(ws + L.off_wfrag), reinterpret_cast<f32x4 *>(ws + L.off_bias), wt_out, L.nb,
                        L.nch, L.cpl, L.idx_bits, pl, reinterpret_cast<float *>(ws + L.off_w32), L.cp32, L.npk);

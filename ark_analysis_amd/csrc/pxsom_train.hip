@@ -1521,13 +1521,8 @@ PXSOM_EXPORT int pxsom_assign_sums(const void *x_dev, int64_t n, int c, int64_t 
     double *scratch = reinterpret_cast<double *>(reinterpret_cast<char *>(workspace_dev) + assign_ws);
     PXSOM_HIP_TRY(hipMemsetAsync(scratch, 0, (size_t)k * (c + 1) * sizeof(double), st));
     bool fused = false;
-    static int fixed = -1;   // PXSOM_SUMS_F64=1: binary64 workgroup tables (the round-2 form) instead of fixed point
-    if (fixed < 0) {
-        const char *e = getenv("PXSOM_SUMS_F64");
-        fixed = !(e && e[0] == '1');
-    }
     rc = pxsom_bmu::assign_accumulate(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, scratch, workspace_dev, assign_ws, st,
-                                      &fused, fixed != 0);
+                                      &fused, true);
     if (rc) return rc;
     if (fused) {
         hipLaunchKernelGGL(stats_to_tables_kernel, dim3((k * (c + 1) + 255) / 256), dim3(256), 0, st, scratch, k, c, sums_dev,
@@ -1836,7 +1831,7 @@ __global__ __launch_bounds__(256) void centring_vector_kernel(const double *__re
 }
 
 struct TrainWs {
-    size_t assign_ws, off_labels, off_mu, off_gather, off_tail, total;
+    size_t assign_ws, off_labels, off_mu, off_gather, total;
 };
 inline TrainWs train_ws(int64_t n, int c, int k, size_t esize, const Sched &sc)
 {
@@ -1846,9 +1841,7 @@ inline TrainWs train_ws(int64_t n, int c, int k, size_t esize, const Sched &sc)
     w.off_labels = pxsom::align_up(w.assign_ws, 256);
     w.off_mu = w.off_labels + pxsom::align_up((size_t)(rmax > 0 ? rmax : 1) * sizeof(int32_t), 256);
     w.off_gather = w.off_mu + 1024;   // 129 floats: the run's centring vector (c <= 128) and its norm
-    w.off_tail = w.off_gather + (sc.any_wide() ? pxsom::align_up((size_t)(n > 0 ? n : 1) * c * esize, 256) : 0);
-    // the persistent BMU-only tail's scratch (control words, member tables, published codebook: pxsom_batch_tail.hip)
-    w.total = w.off_tail + ((k == 100 && c <= 32) ? pxsom_bmu::tail_scratch_bytes(c) : 0);
+    w.total = w.off_gather + (sc.any_wide() ? pxsom::align_up((size_t)(n > 0 ? n : 1) * c * esize, 256) : 0);
     return w;
 }
 }  // namespace
@@ -1871,12 +1864,7 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
     int32_t *labels = reinterpret_cast<int32_t *>(ws + tw.off_labels);
     T *xg = reinterpret_cast<T *>(ws + tw.off_gather);
     const int64_t span = (int64_t)num_passes * sc.phases;
-    static int tpw = -1;   // 16-row tiles per wave of the fused step: 0 = by step size (launch_step), PXSOM_STEP_TPW = 1 / 2 / 4 forces
-    if (tpw < 0) {
-        const char *e = getenv("PXSOM_STEP_TPW");
-        tpw = e ? atoi(e) : 0;
-        if (tpw != 1 && tpw != 2 && tpw != 4) tpw = 0;
-    }
+    constexpr int tpw = 0;   // 16-row tiles per wave of the fused step: by step size (launch_step)
     // which route a step takes (one decision per run: every step of a shape shares it, and so do all ranks -- the fused
     // kernel needs rows >= 1, which a rank with a short shard may not have, so empty steps are allowed there)
     const bool fused_shape = !(flags & PXSOM_TRAIN_UNFUSED) &&
@@ -1899,36 +1887,14 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
     }
     // coefficients of the fused kernels' rigorous |score - exact| bound (DESIGN.md "K7 error bound"): tol = 2 * 1.25 * E (+ 2^-24:
     // the rounding of the centred row, x' = fl(x * scale - mu_s)).  Index bits packed into the scores: 5 in the one-launch step
-    // (round 6: the lane group travels beside the scores), 7 in the persistent tail.
-    auto fused_tol = [&](int bits) {
-        return (float)(2.5 * (ldexp(1.0, -(23 - bits)) + pxsom_bmu::filter_accum_units(c, 3) * ldexp(1.0, -24) + ldexp(1.0, -19) + ldexp(1.0, -23) +
-                              ldexp(1.0, -24)));
-    };
-    const float fused_tol_rel = fused_tol(5), tail_tol_rel = fused_tol(7);
+    // (round 6: the lane group travels beside the scores).
+    const float fused_tol_rel = (float)(2.5 * (ldexp(1.0, -(23 - 5)) + pxsom_bmu::filter_accum_units(c, 3) * ldexp(1.0, -24) + ldexp(1.0, -19) +
+                                               ldexp(1.0, -23) + ldexp(1.0, -24)));
     const float fused_tol_abs = (float)pxsom_bmu::filter_tol_abs(c);
-    static const bool no_centre = getenv("PXSOM_STEP_NO_CENTRE") != nullptr;   // timing hook
-    // Opt-in (PXSOM_TRAIN_PERSISTENT_TAIL): the BMU-only steps at the end of the call (threshold pinned at 0.5: a node's
-    // window is the node) as ONE persistent launch on one XCD (pxsom_batch_tail.hip) -- single rank only: the all-reduce of
-    // a sharded run sits between the steps.  Not the default: 12.2 us per step against 12.0 us for the launches (config 2).
-    int g_tail = g_end;
-    {
-        static const bool tail_env = getenv("PXSOM_TRAIN_TAIL") != nullptr && getenv("PXSOM_TRAIN_TAIL")[0] == '1';
-        if (fused_shape && !comm && (tail_env || (flags & PXSOM_TRAIN_PERSISTENT_TAIL))) {
-            int g = g_end;
-            while (g > g_begin) {
-                const int gg = g - 1;
-                if (gg > 0) {
-                    double thr = 0.0, alpha = 0.0;
-                    batch_schedule(sc.pos(gg - 1), span, a0, a1, r0, r1, &thr, &alpha);
-                    if (thr != 0.5) break;
-                }
-                const int64_t rows = sc.rows(n, gg % sc.steps);
-                if (rows < 1 || rows >= (int64_t)1 << 31 || sc.width(gg % sc.steps) < 1) break;
-                g--;
-            }
-            if (g_end - g >= 2 && g_end - g <= pxsom_bmu::kMaxTailSteps) g_tail = g;
-        }
-    }
+    constexpr bool no_centre = false;
+    // (Rounds 4 - 5 carried an opt-in persistent launch for the BMU-only tail on one XCD, pxsom_batch_tail.hip: 12.2 us per step
+    // against 9.8 for the launches, profiles/r04/tail_phase_timing.txt; removed in round 6 with its flag.)
+    const int g_tail = g_end;
     // The exchange inside the step launches (round 5; a peer-to-peer communicator with pxsom_comm_p2p_set_fused, the fused 10 x 10 step):
     // step gg's last workgroup hands this rank's statistics to every rank, step gg + 1 adds the ranks' slots in rank order while
     // it applies the pending update -- no all-reduce launch between two steps.  The last step of the call keeps the separate
@@ -1992,10 +1958,9 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
         // settle, statistics: pxsom_batch_step_wide.hip) instead of the four or five below -- the BMU-only steps (threshold
         // pinned at 0.5) on any grid, the windowed ones on grids up to 16 x 16
         if constexpr (sizeof(T) >= 4) {
-            static const bool wide_off = getenv("PXSOM_STEP_WIDE") != nullptr && getenv("PXSOM_STEP_WIDE")[0] == '0';   // A/B hook
             const bool bmu_only = gg > 0 && thr == 0.5;
-            static const int64_t win_cap = getenv("PXSOM_STEP_WIDE_WINCAP") ? atoll(getenv("PXSOM_STEP_WIDE_WINCAP")) : 4096;   // tuning hook
-            if (!(flags & PXSOM_TRAIN_UNFUSED) && !wide_off && rows <= pxsom_bmu::step_wide_max_rows() && pxsom_bmu::step_wide_shape<T>(c, k) &&
+            constexpr int64_t win_cap = 4096;   // (windowed steps beyond ~4 K rows run as fast on the launch-per-phase route: profiles/r04)
+            if (!(flags & PXSOM_TRAIN_UNFUSED) && rows <= pxsom_bmu::step_wide_max_rows() && pxsom_bmu::step_wide_shape<T>(c, k) &&
                 (bmu_only || (rows <= win_cap && pxsom_bmu::step_wide_windowed(xdim, ydim, c)))) {
                 pxsom_bmu::StepArgs sa;
                 sa.w_in = gg > 0 ? w_prev : w_cur;
@@ -2062,39 +2027,6 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
         int rc = batch_accumulate_impl(xv, rows, c, ldv, dtype, w_cur, k, labels, s_cur, ws, assign_ws, 0, st, qmagic);
         if (rc) return rc;
         if (comm && (rc = pxsom::comm_allreduce_sum_f64(comm, s_cur, nstats, st))) return rc;
-    }
-    if (g_tail < g_end) {
-        pxsom_bmu::TailArgs ta;
-        ta.nsteps = g_end - g_tail;
-        ta.phases = sc.phases;
-        ta.first_has_update = g_tail > 0 ? 1 : 0;
-        ta.final_update = 0;
-        ta.q_final = 1.0;
-        ta.sat_final = 0x1p62;
-        ta.stats_first = ring + (size_t)((g_tail + 2) % 3) * nstats;
-        ta.w_in = g_tail > 0 ? wbuf + (size_t)((g_tail + 1) % 2) * nw : wbuf + (size_t)(g_tail % 2) * nw;
-        ta.w_last = wbuf + (size_t)((g_end - 1) % 2) * nw;
-        ta.stats_last = ring + (size_t)((g_end - 1) % 3) * nstats;
-        ta.stats_zero = ring + (size_t)(g_end % 3) * nstats;
-        ta.w_final = nullptr;
-        ta.scratch = ws + tw.off_tail;
-        ta.tol_rel = tail_tol_rel;
-        ta.tol_abs = fused_tol_abs;
-        ta.mu32 = no_centre ? nullptr : mu32;
-        ta.qmagic = qmagic;
-        for (int gg = g_tail; gg < g_end; gg++) {
-            const int g = gg % sc.steps;
-            pxsom_bmu::TailStep &ts = ta.st[gg - g_tail];
-            ts.e0 = sc.e0(g);
-            ts.width = sc.width(g);
-            ts.rows = sc.rows(n, g);
-            double thr = 0.0, alpha = 0.0;
-            if (gg > 0) batch_schedule(sc.pos(gg - 1), span, a0, a1, r0, r1, &thr, &alpha);
-            ts.q = 1.0 - alpha;
-            ts.sat = pxsom_bmu::batch_gain_saturation(ts.q);
-        }
-        int rc = pxsom_bmu::launch_batch_tail<T>(x, c, ldx, ta, st);
-        if (rc) return rc;
     }
     (void)ws_bytes;
     return PXSOM_OK;

@@ -47,8 +47,9 @@ class AssignWorkspace:
 
 def assign(x: torch.Tensor, w: torch.Tensor, labels: Optional[torch.Tensor] = None,
            dists: Optional[torch.Tensor] = None, want_dists: bool = False,
-           workspace: Optional[AssignWorkspace] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """BMU labels (int32, 1-based) of every row of ``x`` against codebook ``w`` [K, C] f64."""
+           workspace: Optional[AssignWorkspace] = None, screen_all_lists: bool = False) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """BMU labels (int32, 1-based) of every row of ``x`` against codebook ``w`` [K, C] f64.  ``screen_all_lists``: every list of
+    rows for the exact path takes the long-list (screened) kernel whatever its length (PXSOM_ASSIGN_SCREEN_ALL_LISTS; same labels)."""
     n, c, ldx, dt = _matrix_args(x)
     w = _codebook(w)
     k = w.shape[0]
@@ -60,10 +61,11 @@ def assign(x: torch.Tensor, w: torch.Tensor, labels: Optional[torch.Tensor] = No
         dists = torch.empty(n, dtype=torch.float64, device=x.device)
     if workspace is None or not workspace.fits(n, c, k):
         workspace = AssignWorkspace(n, c, k, x.device)
-    rc = _capi.lib().pxsom_assign(x.data_ptr(), n, c, ldx, dt, w.data_ptr(), k, labels.data_ptr(),
-                                  dists.data_ptr() if dists is not None else None,
-                                  workspace.buf.data_ptr(), workspace.bytes, _capi.stream_ptr())
-    _capi.check(rc, "pxsom_assign")
+    rc = _capi.lib().pxsom_assign_ex(x.data_ptr(), n, c, ldx, dt, w.data_ptr(), k, labels.data_ptr(),
+                                     dists.data_ptr() if dists is not None else None,
+                                     workspace.buf.data_ptr(), workspace.bytes, ASSIGN_SCREEN_ALL_LISTS if screen_all_lists else 0,
+                                     _capi.stream_ptr())
+    _capi.check(rc, "pxsom_assign_ex")
     assign.last_workspace = workspace
     return labels, dists
 
@@ -94,7 +96,7 @@ def cluster_sums(x: torch.Tensor, labels: torch.Tensor, k: int,
 
 
 TRAIN_UNFUSED = 1  # include/pxsom.h PXSOM_TRAIN_UNFUSED
-TRAIN_PERSISTENT_TAIL = 2  # include/pxsom.h PXSOM_TRAIN_PERSISTENT_TAIL
+ASSIGN_SCREEN_ALL_LISTS = 1  # include/pxsom.h PXSOM_ASSIGN_SCREEN_ALL_LISTS
 
 
 class BatchTrainState:
@@ -150,13 +152,11 @@ def batch_train_fused_route(x: torch.Tensor, xdim: int, ydim: int, schedule) -> 
 
 
 def batch_train_steps(x: torch.Tensor, state: BatchTrainState, g_begin: int, g_end: int, total_steps: int,
-                      alpha_range, radius_range, unfused: bool = False, comm: "RankComm" = None,
-                      persistent_tail: bool = False) -> None:
+                      alpha_range, radius_range, unfused: bool = False, comm: "RankComm" = None) -> None:
     """Mini-batch steps [g_begin, g_end) of a batch training run of ``total_steps`` = passes x steps per pass, launched
     back to back by the library (``state.wbuf[0]`` holds W_0 before step 0; see include/pxsom.h).  ``comm``: the
     statistics of every step are sum-all-reduced over its ranks right behind the step's launch (every rank makes the
-    same call).  ``persistent_tail`` (opt-in, single rank): the BMU-only steps at the end of the call run as one
-    persistent launch on one XCD (csrc/pxsom_batch_tail.hip; same codebook bit for bit, not faster yet)."""
+    same call)."""
     n, c, ldx, dt = _matrix_args(x)
     if not state.fits(n, c, state.xdim, state.ydim, state.schedule, x.dtype):
         raise ValueError("batch-training state does not fit this matrix")
@@ -167,7 +167,7 @@ def batch_train_steps(x: torch.Tensor, state: BatchTrainState, g_begin: int, g_e
         x.data_ptr(), n, c, ldx, dt, state.wbuf.data_ptr(), state.ring.data_ptr(), state.xdim, state.ydim,
         sch.phases, state.edges.ctypes.data, sch.steps, int(g_begin), int(g_end), int(total_steps) // sch.steps,
         float(alpha_range[0]), float(alpha_range[1]), float(radius_range[0]), float(radius_range[1]), float(state.quantum),
-        state.ws.data_ptr(), state.ws_bytes, (TRAIN_UNFUSED if unfused else 0) | (TRAIN_PERSISTENT_TAIL if persistent_tail else 0),
+        state.ws.data_ptr(), state.ws_bytes, TRAIN_UNFUSED if unfused else 0,
         comm.handle if comm is not None else None, _capi.stream_ptr())
     _capi.check(rc, "pxsom_batch_train_sched")
 

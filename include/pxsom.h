@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PXSOM_ABI_VERSION 8
+#define PXSOM_ABI_VERSION 9
 
 typedef enum pxsom_status {
     PXSOM_OK = 0,
@@ -91,6 +91,14 @@ size_t pxsom_assign_workspace_bytes(int64_t n, int c, int k);
 int pxsom_assign(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev,
                  int k, int32_t *labels_dev, double *dist_dev, void *workspace_dev,
                  size_t workspace_bytes, void *stream);
+/* pxsom_assign with flags (ABI 9).  PXSOM_ASSIGN_SCREEN_ALL_LISTS: every list of rows for the exact path goes through the
+ * long-list kernel (binary32 screening, binary64 for the surviving nodes), whatever its length -- by default lists shorter than
+ * ~2.25e6 / c rows take the wave-per-row kernel.  Same labels either way; the flag exists so that the long-list kernel can be
+ * exercised on small inputs (a per-call argument: the library reads no environment variables). */
+#define PXSOM_ASSIGN_SCREEN_ALL_LISTS 1
+int pxsom_assign_ex(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev,
+                    int k, int32_t *labels_dev, double *dist_dev, void *workspace_dev,
+                    size_t workspace_bytes, int flags, void *stream);
 
 /* Number of rows the last pxsom_assign on this workspace sent to the exact binary64 path
  * (diagnostic; synchronises the stream). */
@@ -117,8 +125,8 @@ int pxsom_cluster_sums(const void *x_dev, int64_t n, int c, int64_t ldx, int dty
  * most 2^-28 * rows-per-workgroup / 2^11 relative to the codebook's largest magnitude (1.8e-12 for 41 K rows per workgroup),
  * then flushed as binary64.  They are therefore NOT the bit-exact binary64 sums of pxsom_assign + pxsom_cluster_sums, but
  * within 1e-6 relative of them per mean (tests: test_assign_sums_one_pass_equals_two_passes).  Values outside the format
- * (>= 2^(16 - e), non-finite) and listed rows bypass the table in binary64.  PXSOM_SUMS_F64=1 in the environment (read once)
- * restores binary64 workgroup tables. */
+ * (>= 2^(16 - e), non-finite) and listed rows bypass the table in binary64.  (ABI 9: the environment switch PXSOM_SUMS_F64 is
+ * gone -- the library reads no environment variable; exact binary64 tables: pxsom_assign + pxsom_cluster_sums.) */
 size_t pxsom_assign_sums_workspace_bytes(int64_t n, int c, int k);
 int pxsom_assign_sums(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev, int k,
                       int32_t *labels_dev, double *sums_dev, int64_t *counts_dev, void *workspace_dev,
@@ -204,12 +212,8 @@ int pxsom_batch_update_prepare(double *w_dev, int xdim, int ydim, int c, double 
  * grid (a node's window is the node), the others -- up to 4 096 rows -- on grids up to 16 x 16.  Same results either way (PXSOM_TRAIN_UNFUSED forces
  * the launch-per-phase route for every step).  Oracle of record: oracle/pxsom_oracle.c orc_som_batch. */
 #define PXSOM_TRAIN_UNFUSED 1
-/* Opt-in (round 4, experimental): the BMU-only steps at the end of a single-rank call (neighbourhood threshold pinned at
- * 0.5) run as ONE persistent launch whose workgroups all sit on one XCD and synchronise through that XCD's L2
- * (csrc/pxsom_batch_tail.hip: same rule, same state left behind, bit-equal codebooks -- tests/test_gpu_schedule.py).
- * Measured on config 2: 12.2 us per step against 12.0 us for the launch-per-step route (profiles/r04/tail_phase_timing.txt),
- * so it is NOT the default; the environment variable PXSOM_TRAIN_TAIL=1 turns it on for every call. */
-#define PXSOM_TRAIN_PERSISTENT_TAIL 2
+/* (flag value 2 was PXSOM_TRAIN_PERSISTENT_TAIL in ABI 6 - 8: an opt-in persistent launch for the BMU-only tail, measured slower
+ * than the launches it replaced and removed in ABI 9; the bit is ignored.) */
 size_t pxsom_batch_train_workspace_bytes(int64_t n, int batch_steps, int c, int k);
 int pxsom_batch_train_steps(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, double *wbuf_dev,
                             double *stats_ring_dev, int xdim, int ydim, int batch_steps, int g_begin, int g_end,

@@ -25,7 +25,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/pxsom.h but not exported"
     assert set(declared) == set(_capi.SYMBOLS), "ctypes prototype table and header disagree"
-    assert lib.pxsom_abi_version() == _capi.ABI_VERSION == 8
+    assert lib.pxsom_abi_version() == _capi.ABI_VERSION == 9
 
 
 def test_argument_validation_without_gpu():

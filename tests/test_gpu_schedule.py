@@ -236,7 +236,7 @@ TAIL_HEAVY = BatchSchedule.two_phase(head_steps=2, tail_steps=9, head_ratio=0.5,
 
 
 @pytest.mark.parametrize("c,dtype,n,sch,passes", [
-    (22, np.float32, 120_007, None, 1),            # the default schedule: 6 launches + one 16-step persistent launch
+    (22, np.float32, 120_007, None, 1),            # the default schedule: 22 one-launch steps
     (22, np.float32, 20_011, TAIL_HEAVY, 1),
     (16, np.float16, 31_000, SMALL_TWO_PHASE, 2),  # two passes: the tail is the end of the second
     (32, np.float64, 12_000, TAIL_HEAVY, 1),       # binary64 rows (rounded to the run's quantum), widest fused rows
@@ -247,10 +247,12 @@ TAIL_HEAVY = BatchSchedule.two_phase(head_steps=2, tail_steps=9, head_ratio=0.5,
     (8, np.float32, 2_500, SMALL_TWO_PHASE, 1),
     (2, np.float32, 4_001, TAIL_HEAVY, 1),
 ])
-def test_persistent_tail_equals_the_launch_per_step_route(gpu, oracle, c, dtype, n, sch, passes):
-    """The BMU-only tail as one persistent launch on one XCD (csrc/pxsom_batch_tail.hip; opt-in) against the launch-per-step
-    route: the codebook and the state left behind (W of the last step, its statistics, the cleared next buffer) bit for
-    bit on data whose sums are exact, and the run against orc_som_batch_sched."""
+def test_one_launch_steps_equal_the_launch_per_phase_route_and_the_oracle(gpu, oracle, c, dtype, n, sch, passes):
+    """(Rounds 4 - 5: test_persistent_tail_equals_the_launch_per_step_route -- the opt-in persistent tail kernel it pinned was
+    removed in round 6; its six cases stay.)  The one-launch fused steps against the launch-per-phase route
+    (PXSOM_TRAIN_UNFUSED: update, prepare, search, exact and sums kernels per step): the codebook and the state left behind (W
+    of the last step, its statistics, the cleared next buffer) bit for bit on data whose sums are exact, and the run against
+    orc_som_batch_sched."""
     xdim = ydim = 10
     k = 100
     sch = BatchSchedule.two_phase() if sch is None else sch
@@ -260,17 +262,17 @@ def test_persistent_tail_equals_the_launch_per_step_route(gpu, oracle, c, dtype,
     x = synth.make_fov_numpy(max(n, 2 * k), c, seed=51, dtype=np.float32)[:n]
     x = (np.round(x.astype(np.float64) * 4096.0) / 4096.0).astype(dtype)
     w0 = _codebook(synth.make_fov_numpy(4 * k, c, seed=52, dtype=np.float64), k, seed=7)
-    w0[k - 2] = w0[3]                                    # a duplicate node: not masked out by the tail's filter
+    w0[k - 2] = w0[3]                                    # a duplicate node: not masked out by the BMU-only steps' filter
     xd = torch.from_numpy(x).to(gpu)
     rr = default_radius_range(xdim, ydim)
     total = passes * sch.steps
     quantum = sd.exact_sum_quantum(float(np.abs(x).max()), n) if dtype == np.float64 else 0.0
     outs = []
-    for tail in (True, False):
+    for unfused in (False, True):
         st = sd.BatchTrainState(n, c, xdim, ydim, sch, gpu, dtype=xd.dtype)
         st.quantum = quantum
         st.wbuf[0].copy_(torch.from_numpy(w0))
-        sd.batch_train_steps(xd, st, 0, total, total, (0.05, 0.01), rr, persistent_tail=tail)
+        sd.batch_train_steps(xd, st, 0, total, total, (0.05, 0.01), rr, unfused=unfused)
         w = torch.empty((k, c), dtype=torch.float64, device=gpu)
         sd.batch_train_finish(st, total, total, (0.05, 0.01), rr, w)
         outs.append((w, st.wbuf.clone(), st.ring.clone()))

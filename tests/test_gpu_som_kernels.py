@@ -21,10 +21,10 @@ def _codebook(x, k, seed=3):
     return np.ascontiguousarray(x[idx].astype(np.float64))
 
 
-def _gpu_assign(gpu, x, w, want_dists=False):
+def _gpu_assign(gpu, x, w, want_dists=False, screen_all_lists=False):
     xd = torch.from_numpy(x).to(gpu)
     wd = torch.from_numpy(w).to(gpu)
-    labels, dists = sd.assign(xd, wd, want_dists=want_dists)
+    labels, dists = sd.assign(xd, wd, want_dists=want_dists, screen_all_lists=screen_all_lists)
     torch.cuda.synchronize()
     return labels.cpu().numpy(), (dists.cpu().numpy() if dists is not None else None)
 
@@ -148,12 +148,11 @@ def test_assign_identical_codebook_rows(gpu, oracle):
     (9_000, 3, 1024, np.float32),      # the largest codebook
 ])
 @pytest.mark.parametrize("pattern", ["crowded", "ties", "wild"])
-def test_long_exact_lists_are_screened_and_stay_bit_exact(gpu, oracle, monkeypatch, n, c, k, dtype, pattern):
+def test_long_exact_lists_are_screened_and_stay_bit_exact(gpu, oracle, n, c, k, dtype, pattern):
     """Thousands of listed rows (crowded codebooks, discrete data, non-finite and out-of-range rows) through the
     screened exact kernel (binary32 screening against the distance of the filter's proposal, binary64 only for
     the surviving nodes): labels equal the oracle's, first-minimum ties and label 0 for non-finite rows included.
-    The kernel takes over from 2.25e6 / C listed rows; ``PXSOM_SCREEN_MIN_ROWS`` sends these lists there too."""
-    monkeypatch.setenv("PXSOM_SCREEN_MIN_ROWS", "1")
+    The kernel takes over from 2.25e6 / C listed rows; PXSOM_ASSIGN_SCREEN_ALL_LISTS (pxsom_assign_ex) sends these lists there too."""
     rs = np.random.RandomState(n + c + k)
     if pattern == "crowded":       # node pairs 1e-3 .. 1e-9 apart, a duplicated node, rows around them
         half = rs.rand((k + 1) // 2, c)
@@ -175,15 +174,14 @@ def test_long_exact_lists_are_screened_and_stay_bit_exact(gpu, oracle, monkeypat
     with np.errstate(over="ignore"):
         x = np.ascontiguousarray(x.astype(dtype))
     w = np.ascontiguousarray(w.astype(np.float64))
-    got, _ = _gpu_assign(gpu, x, w)
+    got, _ = _gpu_assign(gpu, x, w, screen_all_lists=True)
     if pattern != "ties":          # (coarse-grid ties list thousands of rows for most shapes, not for all)
         # (the filters centre rows and codebook: an offset blob is no longer "every row near-tied" for them -- the rows no
         # shortcut survives remain)
         assert sd.last_exact_rows(sd.assign.last_workspace) >= (min(2048, n // 2) if pattern == "crowded" else 256)
     want, _ = oracle.map_data_to_nodes(w, x.astype(np.float64))
     np.testing.assert_array_equal(got, want)
-    monkeypatch.delenv("PXSOM_SCREEN_MIN_ROWS")        # and the default split between the two exact kernels
-    got, _ = _gpu_assign(gpu, x, w)
+    got, _ = _gpu_assign(gpu, x, w)                    # and the default split between the two exact kernels
     np.testing.assert_array_equal(got, want)
 
 
