@@ -78,7 +78,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
+    ap.add_argument("--config", choices=["cfg1"] + sorted(CONFIGS), default="cfg2",
+                    help="cfg1: BASELINE.json configs[0] -- one 512x512x8 FOV through train_pixel_som -> cluster_pixels -> "
+                         "generate_som_avg_files (the Python plumbing, HIP path beside the oracle-backed CPU path; one GPU)")
     ap.add_argument("--fovs-per-gpu", type=int, default=None)
     ap.add_argument("--batch-steps", default="two-phase",
                     help="training schedule: 'two-phase' (default: 6 large steps while the radius is >= 1, 16 in "
@@ -182,8 +184,124 @@ def pmc_passes(argv_inner, kernel_substr="bmu_filter"):
     return out
 
 
+def run_cfg1(args):
+    """BASELINE.json configs[0] ("cfg1 additionally times the full Python plumbing"): ONE synthetic FOV of
+    512 x 512 x 8 channels as the reference stores it (binary64 feather tables: full + 10 % subset + normalisation file) through
+    the drop-in functions train_pixel_som -> cluster_pixels -> generate_som_avg_files -- file in, labelled file + weights + CSV out
+    -- on the HIP path (`steps` repeats on fresh directories), and ONCE with the oracle standing in for the device entry points
+    (the `cpu_baseline` leg: what the reference's own route costs on this box's host cores with pyFlowSOM's arithmetic restated in
+    C).  Labels, codebook and mean table of the two legs are compared."""
+    import shutil
+
+    import pandas as pd
+
+    from ark_analysis_amd import fov_tables
+    from ark_analysis_amd.phenotyping import pixel_som_clustering
+    _capi.require_gpu()
+    side, c = 512, 8
+    n = side * side
+    chans = ["chan%d" % i for i in range(c)]
+    fovs = ["fov0"]
+    x = synth.make_fov_numpy(n, c, seed=501, dtype=np.float64)
+    sub = np.sort(np.random.RandomState(7).choice(n, n // 10, replace=False))
+
+    def make_dirs():
+        root = tempfile.mkdtemp(prefix="pxsom_cfg1_")
+        os.mkdir(os.path.join(root, "pixel_mat_data"))
+        os.mkdir(os.path.join(root, "pixel_mat_subsetted"))
+        df = pd.DataFrame(x, columns=chans)
+        df["fov"] = "fov0"
+        df["row_index"] = np.repeat(np.arange(side), side)
+        df["column_index"] = np.tile(np.arange(side), side)
+        df["label"] = 0
+        fov_tables.write_dataframe(df, os.path.join(root, "pixel_mat_data", "fov0.feather"))
+        fov_tables.write_dataframe(df.iloc[sub], os.path.join(root, "pixel_mat_subsetted", "fov0.feather"))
+        fov_tables.write_dataframe(pd.DataFrame(np.ones((1, c)), columns=chans), os.path.join(root, "post_rowsum_chan_norm.feather"))
+        return root
+
+    def run(root, **train_kw):
+        stamps = [time.perf_counter()]
+        with contextlib.redirect_stdout(io.StringIO()):
+            som = pixel_som_clustering.train_pixel_som(fovs, chans, root, num_passes=1, seed=42, **train_kw)
+            stamps.append(time.perf_counter())
+            pixel_som_clustering.cluster_pixels(fovs, root, som)
+            stamps.append(time.perf_counter())
+            pixel_som_clustering.generate_som_avg_files(fovs, chans, root, som, data_dir="pixel_mat_data")
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        stamps.append(time.perf_counter())
+        labels = fov_tables.read_dataframe(os.path.join(root, "pixel_mat_data", "fov0.feather"))["pixel_som_cluster"].values
+        avg = pd.read_csv(os.path.join(root, "pixel_channel_avg_som_cluster.csv"))
+        return np.diff(stamps), np.asarray(som.weights.values), labels, avg
+
+    import contextlib
+    import io
+    legs = {}
+    for mode, kw in (("online", {}), ("batch", {"train_mode": "batch"})):     # reference order (exact) / the throughput rule
+        times = []
+        for i in range(args.warmup + args.steps):
+            root = make_dirs()
+            try:
+                t, w, lab, avg = run(root, **kw)
+            finally:
+                shutil.rmtree(root, ignore_errors=True)
+            if i >= args.warmup:
+                times.append(t)
+        legs[mode] = (np.mean(np.asarray(times), axis=0), w, lab, avg)
+    line = {"metric": "M pixels/sec SOM train+assign through the drop-in pipeline functions, 1 FOV 512x512x8ch, 100-node SOM",
+            "unit": "Mpx/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "1 synthetic FOV 512x512x8ch, 10x10 SOM via train_pixel_som -> cluster_pixels -> generate_som_avg_files "
+                                   "on binary64 feather tables (BASELINE.json configs[0]: the plumbing config)", "name": "cfg1",
+                       "rows": n, "channels": c, "som_nodes": 100, "train_rows": int(len(sub)), "num_passes": 1}}
+    t_on, t_ba = legs["online"][0], legs["batch"][0]
+    line["value"] = round(n / float(np.sum(t_on)) / 1e6, 3)
+    line["ms_per_step"] = round(float(np.sum(t_on)) * 1e3, 2)
+    line["phases_ms"] = {"train_mode_online (reference order, exact)": {"train_pixel_som": round(t_on[0] * 1e3, 2), "cluster_pixels": round(t_on[1] * 1e3, 2),
+                                                                         "generate_som_avg_files": round(t_on[2] * 1e3, 2)},
+                         "train_mode_batch": {"train_pixel_som": round(t_ba[0] * 1e3, 2), "cluster_pixels": round(t_ba[1] * 1e3, 2),
+                                              "generate_som_avg_files": round(t_ba[2] * 1e3, 2), "Mpx_per_s": round(n / float(np.sum(t_ba)) / 1e6, 3)}}
+    line["roofline"] = None     # host-side plumbing (feather I/O, DataFrames): no kernel of this run is priced against a roofline
+    if not args.no_cpu_baseline:
+        # the same three calls with the oracle behind ark_analysis_amd.flowsom (test infrastructure, used here as the CPU baseline only)
+        from tests import oracle_backend
+        from ark_analysis_amd import flowsom
+        saved = {}
+
+        def patch(mod, name, value):
+            saved.setdefault((mod, name), getattr(mod, name))
+            setattr(mod, name, value)
+        oracle_backend.install(patch)
+        try:
+            root = make_dirs()
+            try:
+                t_cpu, w_cpu, lab_cpu, avg_cpu = run(root)
+            finally:
+                shutil.rmtree(root, ignore_errors=True)
+        finally:
+            for (mod, name), value in saved.items():
+                setattr(mod, name, value)
+        del flowsom
+        w_on, lab_on, avg_on = legs["online"][1], legs["online"][2], legs["online"][3]
+        line["cpu_baseline"] = {"value": round(n / float(np.sum(t_cpu)) / 1e6, 4), "unit": "Mpx/s", "cores": 1, "kind": "port",
+                                "sample": "the whole config (1 FOV: 26 214 training rows x 1 pass in the reference's order, 262 144 rows labelled), "
+                                          "same three calls, oracle/pxsom_oracle.c behind ark_analysis_amd.flowsom; once",
+                                "phases_ms": {"train_pixel_som": round(t_cpu[0] * 1e3, 2), "cluster_pixels": round(t_cpu[1] * 1e3, 2),
+                                              "generate_som_avg_files": round(t_cpu[2] * 1e3, 2)},
+                                "gpu_codebook_bit_equal": bool(np.array_equal(w_on, w_cpu)),
+                                "gpu_labels_equal": bool(np.array_equal(lab_on, lab_cpu)),
+                                "gpu_mean_table_max_rel_err": float(np.max(np.abs(avg_on[chans].values - avg_cpu[chans].values) /
+                                                                     np.maximum(np.abs(avg_cpu[chans].values), 1e-300))),
+                                "speedup_whole_pipeline": round(float(np.sum(t_cpu)) / float(np.sum(t_on)), 2)}
+    print(json.dumps(line))
+
+
 def main():
     args = parse()
+    if args.config == "cfg1":
+        if args.gpus != 1:
+            raise SystemExit("bench.py: cfg1 is the one-FOV plumbing config (one GPU)")
+        return run_cfg1(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
