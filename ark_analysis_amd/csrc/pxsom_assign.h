@@ -121,6 +121,19 @@ __host__ __device__ inline double batch_gain_saturation(double q)
     return b <= 0x1p-60 ? d : 0x1p62;
 }
 
+// Fixed-point workgroup tables (pxsom_assign_sums / pxsom_assign_means) and what becomes of the statistics buffer they are
+// flushed into: the LAST workgroup through the flush (a ticket behind the statistics, cleared with them) turns [k c sums | k counts]
+// into the caller's tables inside the same launch -- no finishing launch behind a 0.22 ms kernel (round 6).  `done` tells the caller
+// whether the kernel that ran does this (the two-tile kernel for binary64 rows does not: the finishing kernel is launched).
+struct FinishTables {
+    double *sums = nullptr;        // [k, c]
+    long long *counts = nullptr;   // [k]
+    double *means = nullptr;       // [k, c] or NULL
+    int overwrite = 0;             // 0: added into sums / counts (pxsom_assign_sums); 1: overwritten, means formed (pxsom_assign_means)
+    unsigned *ticket = nullptr;    // one word behind the statistics, zero at launch
+    bool done = false;
+};
+
 // the pending update a fused mini-batch step applies at its head, and its housekeeping (pxsom_batch_step.hip)
 struct StepArgs {
     const double *w_in;        // [k, c] codebook the pending update applies to (W_{g-1}, or W_0 when has_update == 0)
@@ -229,11 +242,11 @@ __host__ __device__ inline int node_of_row(int b, int m, int nb)
 // [k*c sums | k counts] for every row it does not list
 template <typename T>
 void launch_filter_any(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L,
-                       int32_t *labels, double *stats, const double *w, hipStream_t st, bool fixed = false);
+                       int32_t *labels, double *stats, const double *w, hipStream_t st, FinishTables *fin = nullptr);
 // the accumulating variant (pxsom_assign_filter_acc.hip): also settles its listed rows itself
 template <typename T>
 void launch_filter_fast_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels,
-                            double *stats, const double *w, hipStream_t st, bool fixed = false);
+                            double *stats, const double *w, hipStream_t st, FinishTables *fin = nullptr);
 template <typename T>
 bool filter_fast_path(const T *x, int64_t n, int c, int64_t ldx, const Layout &L);
 // labels only on binary64 rows of the fast path's shapes, self-contained (pxsom_assign_filter_acc.hip / pxsom_assign_onepass.h)
@@ -268,11 +281,12 @@ inline bool packed_rows_ok(const T *x, int64_t ldx)
 
 // pxsom_assign with the batch rule's accumulation fused in (pxsom_assign.hip).  *fused = false: the shape
 // is outside the fused path, nothing was done, the caller runs assign + cluster sums separately.
-// fixed: the workgroup tables are 64-bit fixed point (pxsom_assign_sums: sums within 2^-38 of the codebook's largest
-// magnitude per value instead of the exact binary64 sums the batch rule's tests pin; 3.4x the LDS atomic rate)
+// fin != NULL: the workgroup tables are 64-bit fixed point (pxsom_assign_sums: sums within 2^-38 of the codebook's largest
+// magnitude per value instead of the exact binary64 sums the batch rule's tests pin; 3.4x the LDS atomic rate), and the launch may
+// finish the caller's tables itself (FinishTables)
 int assign_accumulate(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev, int k,
                       int32_t *labels_dev, double *stats_dev, void *workspace_dev, size_t workspace_bytes,
-                      hipStream_t st, bool *fused, bool fixed = false);
+                      hipStream_t st, bool *fused, FinishTables *fin = nullptr);
 int assign_prepared(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev, int k,
                     int32_t *labels_dev, void *workspace_dev, size_t workspace_bytes, hipStream_t st, int npk = 0);
 int prepare_only(const double *w_dev, int c, int k, void *workspace_dev, size_t workspace_bytes,

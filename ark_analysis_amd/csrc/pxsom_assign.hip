@@ -637,7 +637,7 @@ static int prep_stage(size_t stage_bytes)
 template <typename T>
 int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int k, int32_t *labels,
                  double *dist, char *ws, const Layout &L_in, hipStream_t st, double *stats = nullptr,
-                 bool prepared = false, bool fixed = false, bool screen_all = false)
+                 bool prepared = false, FinishTables *fin = nullptr, bool screen_all = false)
 {
     // binary16 rows of a wide codebook: packed-K fragments (pxsom_assign.h packed_k).  `prepared`: the caller's layout
     // says what the workspace holds.
@@ -712,9 +712,9 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
     pxsom::prof_mark(prof, st, true, n);
     if constexpr (sizeof(T) == 2) {
         if (L.npk > 0) launch_filter_packed(x, n, c, ldx, ws, L, labels, st);
-        else launch_filter_any<T>(x, n, c, ldx, ws, L, labels, stats, w, st, fixed);
+        else launch_filter_any<T>(x, n, c, ldx, ws, L, labels, stats, w, st, fin);
     } else {
-        launch_filter_any<T>(x, n, c, ldx, ws, L, labels, stats, w, st, fixed);
+        launch_filter_any<T>(x, n, c, ldx, ws, L, labels, stats, w, st, fin);
     }
     pxsom::prof_mark(prof, st, false, n);
     PXSOM_LAUNCH_CHECK("bmu_filter_kernel");
@@ -808,12 +808,12 @@ PXSOM_EXPORT int pxsom_assign_ex(const void *x_dev, int64_t n, int c, int64_t ld
     }
     const bool screen_all = (flags & PXSOM_ASSIGN_SCREEN_ALL_LISTS) != 0;
     PXSOM_DISPATCH_DTYPE(dtype, x_dev, xp,
-                         assign_typed<T>(xp, n, c, ldx, w_dev, k, labels_dev, dist_dev, ws, L, st, nullptr, false, false, screen_all));
+                         assign_typed<T>(xp, n, c, ldx, w_dev, k, labels_dev, dist_dev, ws, L, st, nullptr, false, nullptr, screen_all));
 }
 
 int pxsom_bmu::assign_accumulate(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev,
                                  int k, int32_t *labels_dev, double *stats_dev, void *workspace_dev,
-                                 size_t workspace_bytes, hipStream_t st, bool *fused, bool fixed)
+                                 size_t workspace_bytes, hipStream_t st, bool *fused, FinishTables *fin)
 {
     *fused = false;
     if (n < 64 || n > 0x7fffffffLL || c < 1 || c > PXSOM_MAX_CHANNELS || k < 1 || k > PXSOM_MAX_NODES || ldx < c ||
@@ -826,7 +826,7 @@ int pxsom_bmu::assign_accumulate(const void *x_dev, int64_t n, int c, int64_t ld
     PXSOM_DISPATCH_DTYPE(dtype, x_dev, xp,
                          (filter_fast_path<T>(xp, n, c, ldx, L)
                               ? (*fused = true, assign_typed<T>(xp, n, c, ldx, w_dev, k, labels_dev, nullptr, ws, L, st,
-                                                                stats_dev, false, fixed))
+                                                                stats_dev, false, fin))
                               : PXSOM_OK));
 }
 

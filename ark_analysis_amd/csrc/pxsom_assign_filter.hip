@@ -398,7 +398,7 @@ void launch_fast(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layo
                        reinterpret_cast<const half8 *>(ws + L.off_wfrag),
                        reinterpret_cast<const f32x4 *>(ws + L.off_bias), reinterpret_cast<AssignHdr *>(ws),
                        reinterpret_cast<unsigned *>(ws + L.off_list), labels, L.k, (double *)nullptr,
-                       (const double *)nullptr, 0, 0, 0);
+                       (const double *)nullptr, 0, 0, 0, FinishTables{});
 }
 
 template <typename T, int NCH, int CPL, int NB, bool VEC2, bool LDSW>
@@ -751,12 +751,12 @@ bool filter_fast_path(const T *x, int64_t n, int c, int64_t ldx, const Layout &L
 
 template <typename T>
 void launch_filter_any(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L,
-                       int32_t *labels, double *stats, const double *w, hipStream_t st, bool fixed)
+                       int32_t *labels, double *stats, const double *w, hipStream_t st, FinishTables *fin)
 {
     const bool vec2 = (c % 2 == 0) && (ldx % 2 == 0) && (reinterpret_cast<uintptr_t>(x) % (2 * sizeof(T)) == 0);
     const bool fast_ok = filter_fast_path<T>(x, n, c, ldx, L);
     if (fast_ok && stats) {   // batch-rule variant (its own translation unit: default FP semantics)
-        launch_filter_fast_acc<T>(x, n, c, ldx, ws, L, labels, stats, w, st, fixed);
+        launch_filter_fast_acc<T>(x, n, c, ldx, ws, L, labels, stats, w, st, fin);
         return;
     }
     // (binary64 rows of these shapes never get here: assign_typed hands them to the two-tile kernel, pxsom_assign_onepass.h --
@@ -789,11 +789,11 @@ void launch_filter_any(const T *x, int64_t n, int c, int64_t ldx, char *ws, cons
 }
 
 template void launch_filter_any<float>(const float *, int64_t, int, int64_t, char *, const Layout &, int32_t *,
-                                       double *, const double *, hipStream_t, bool);
+                                       double *, const double *, hipStream_t, FinishTables *);
 template void launch_filter_any<double>(const double *, int64_t, int, int64_t, char *, const Layout &, int32_t *,
-                                        double *, const double *, hipStream_t, bool);
+                                        double *, const double *, hipStream_t, FinishTables *);
 template void launch_filter_any<_Float16>(const _Float16 *, int64_t, int, int64_t, char *, const Layout &, int32_t *,
-                                          double *, const double *, hipStream_t, bool);
+                                          double *, const double *, hipStream_t, FinishTables *);
 void launch_filter_packed(const _Float16 *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels, hipStream_t st)
 {
     switch (L.npk) {   // ceil(2 c / 32) for c = 40 .. 128 (c % 8 == 0)

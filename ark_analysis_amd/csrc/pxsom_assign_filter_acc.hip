@@ -13,7 +13,7 @@ namespace {
 
 template <typename T, int CPL, bool FIX, bool FOLD = true>
 void launch_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels, double *stats,
-                const double *w, hipStream_t st)
+                const double *w, hipStream_t st, FinishTables *fin = nullptr)
 {
     auto kern = bmu_filter_fast<T, CPL, 7, 1, 0, true, FIX, FOLD>;
     // table (first the row-major codebook prep reads) | transposed codebook | fragments | bias | header copy | listed-row queue:
@@ -47,7 +47,8 @@ void launch_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layou
                        reinterpret_cast<const half8 *>(ws + L.off_wfrag),
                        reinterpret_cast<const f32x4 *>(ws + L.off_bias), reinterpret_cast<AssignHdr *>(ws),
                        reinterpret_cast<unsigned *>(ws + L.off_list), labels, L.k, stats, w, L.idx_bits, L.node_bits,
-                       fix_rows_log2);
+                       fix_rows_log2, (FIX && fin) ? *fin : FinishTables{});
+    if (FIX && fin && fin->ticket) fin->done = true;
 }
 
 // the one-pass kernel with two tiles per trip (pxsom_assign_onepass.h): fixed-point tables
@@ -83,13 +84,14 @@ void launch_onepass(const T *x, int64_t n, int c, int64_t ldx, const Layout &L, 
 
 template <typename T>
 void launch_filter_fast_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels,
-                            double *stats, const double *w, hipStream_t st, bool fixed)
+                            double *stats, const double *w, hipStream_t st, FinishTables *fin)
 {
+    const bool fixed = fin != nullptr;
     // (fixed-point tables: the kernel that finds a slot past the row's end to count the rows in, c < 4 CPL, or the one that counts
     // them with an instruction of its own)
 #define PXSOM_ACC(CPL)                                                                                           \
-    (fixed ? (c < 4 * CPL ? launch_acc<T, CPL, true, true>(x, n, c, ldx, ws, L, labels, stats, w, st)            \
-                          : launch_acc<T, CPL, true, false>(x, n, c, ldx, ws, L, labels, stats, w, st))          \
+    (fixed ? (c < 4 * CPL ? launch_acc<T, CPL, true, true>(x, n, c, ldx, ws, L, labels, stats, w, st, fin)       \
+                          : launch_acc<T, CPL, true, false>(x, n, c, ldx, ws, L, labels, stats, w, st, fin))     \
            : launch_acc<T, CPL, false>(x, n, c, ldx, ws, L, labels, stats, w, st))
     // binary64 rows (what the drop-in classes hold) ALWAYS take the two-tile kernel -- fixed-point or binary64 tables --: it is the
     // one without spills (bmu_filter_fast kept four tiles of binary64 rows in flight and spilled 28 - 138 VGPRs; its binary64
@@ -138,10 +140,10 @@ void launch_onepass_labels(const double *x, int64_t n, int c, int64_t ldx, const
 }
 
 template void launch_filter_fast_acc<float>(const float *, int64_t, int, int64_t, char *, const Layout &, int32_t *,
-                                            double *, const double *, hipStream_t, bool);
+                                            double *, const double *, hipStream_t, FinishTables *);
 template void launch_filter_fast_acc<double>(const double *, int64_t, int, int64_t, char *, const Layout &, int32_t *,
-                                             double *, const double *, hipStream_t, bool);
+                                             double *, const double *, hipStream_t, FinishTables *);
 template void launch_filter_fast_acc<_Float16>(const _Float16 *, int64_t, int, int64_t, char *, const Layout &,
-                                               int32_t *, double *, const double *, hipStream_t, bool);
+                                               int32_t *, double *, const double *, hipStream_t, FinishTables *);
 
 }  // namespace pxsom_bmu

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void b
     const T *__restrict__ x, int64_t n, int c, int64_t ldx, const half8 *__restrict__ wfrag,
     const f32x4 *__restrict__ bias, AssignHdr *hdr, unsigned *__restrict__ amb_list,
     int32_t *__restrict__ labels, int k, double *__restrict__ stats, const double *__restrict__ wcodes,
-    int idx_bits, int node_bits, int fix_rows_log2 = 0)
+    int idx_bits, int node_bits, int fix_rows_log2 = 0, FinishTables fin = FinishTables{})
 {
     extern __shared__ __attribute__((aligned(16))) char acc_smem[];
     // ACC: table [(k+1)*c sums | (k+1) counts]; row k is a spare one that takes the adds of rows / channel slots that must
@@ -931,6 +931,45 @@ _Pragma("unroll") for (int j = 0; j < 2 * NP; j++)                              
             for (int e = threadIdx.x; e < k; e += 256) {
                 const unsigned long long cnt = lu[(size_t)e * cs + c] * binv;
                 if (cnt) __hip_atomic_fetch_add(stats + (size_t)k * c + e, (double)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // Round 6: the last workgroup through its flush turns the statistics into the caller's tables (a ticket: release by
+            // every workgroup behind its own atomics, acquire by the last one before it reads them all) -- the finishing launch
+            // behind this kernel is gone
+            if (fin.ticket) {
+                __shared__ int s_last_wg;
+                __threadfence();
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    const unsigned t = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                    s_last_wg = t == gridDim.x - 1u;
+                }
+                __syncthreads();
+                if (s_last_wg) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    int node = (int)threadIdx.x / c, j = (int)threadIdx.x - node * c;
+                    for (int e = threadIdx.x; e < k * c; e += 256) {
+                        const double s = __hip_atomic_load(stats + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (fin.overwrite) {
+                            const double cnt = __hip_atomic_load(stats + (size_t)k * c + node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            fin.sums[e] = s;
+                            if (fin.means) fin.means[e] = s / (cnt > 0.0 ? cnt : 1.0);
+                        } else {
+                            fin.sums[e] += s;
+                        }
+                        node += dnode;
+                        j += dj;
+                        if (j >= c) {
+                            j -= c;
+                            node++;
+                        }
+                    }
+                    for (int e = threadIdx.x; e < k; e += 256) {
+                        const long long cnt = (long long)__hip_atomic_load(stats + (size_t)k * c + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (fin.overwrite) fin.counts[e] = cnt;
+                        else fin.counts[e] += cnt;
+                    }
+                    if (threadIdx.x == 0) __hip_atomic_store(fin.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         } else {
             int node = (int)threadIdx.x / c, j = (int)threadIdx.x - node * c;

@@ -1499,7 +1499,8 @@ __global__ __launch_bounds__(256) void tables_to_means_kernel(const double *__re
 PXSOM_EXPORT size_t pxsom_assign_sums_workspace_bytes(int64_t n, int c, int k)
 {
     const size_t a = pxsom_assign_workspace_bytes(n, c, k);
-    return a ? pxsom::align_up(a, 256) + pxsom::align_up((size_t)k * (c + 1) * sizeof(double), 256) : 0;
+    // (+ 256: the ticket word of the launch that finishes the tables itself, pxsom_bmu::FinishTables)
+    return a ? pxsom::align_up(a, 256) + pxsom::align_up((size_t)k * (c + 1) * sizeof(double), 256) + 256 : 0;
 }
 
 PXSOM_EXPORT int pxsom_assign_sums(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev, int k,
@@ -1519,11 +1520,17 @@ PXSOM_EXPORT int pxsom_assign_sums(const void *x_dev, int64_t n, int c, int64_t 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const size_t assign_ws = pxsom::align_up(pxsom_assign_workspace_bytes(n, c, k), 256);
     double *scratch = reinterpret_cast<double *>(reinterpret_cast<char *>(workspace_dev) + assign_ws);
-    PXSOM_HIP_TRY(hipMemsetAsync(scratch, 0, (size_t)k * (c + 1) * sizeof(double), st));
+    const size_t stats_bytes = pxsom::align_up((size_t)k * (c + 1) * sizeof(double), 256);
+    PXSOM_HIP_TRY(hipMemsetAsync(scratch, 0, stats_bytes + 256, st));   // statistics + the finishing launch's ticket
     bool fused = false;
+    pxsom_bmu::FinishTables fin;
+    fin.sums = sums_dev;
+    fin.counts = reinterpret_cast<long long *>(counts_dev);
+    fin.ticket = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(scratch) + stats_bytes);
     rc = pxsom_bmu::assign_accumulate(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, scratch, workspace_dev, assign_ws, st,
-                                      &fused, true);
+                                      &fused, &fin);
     if (rc) return rc;
+    if (fused && fin.done) return PXSOM_OK;   // the last workgroup of the launch added the statistics into the tables
     if (fused) {
         hipLaunchKernelGGL(stats_to_tables_kernel, dim3((k * (c + 1) + 255) / 256), dim3(256), 0, st, scratch, k, c, sums_dev,
                            reinterpret_cast<long long *>(counts_dev));
@@ -1552,13 +1559,21 @@ PXSOM_EXPORT int pxsom_assign_means(const void *x_dev, int64_t n, int c, int64_t
     const size_t assign_ws = pxsom::align_up(pxsom_assign_workspace_bytes(n, c, k), 256);
     double *scratch = reinterpret_cast<double *>(reinterpret_cast<char *>(workspace_dev) + assign_ws);
     const unsigned fgrid = (unsigned)((k * (c + 1) + 255) / 256);
-    PXSOM_HIP_TRY(hipMemsetAsync(scratch, 0, (size_t)k * (c + 1) * sizeof(double), st));
+    const size_t stats_bytes = pxsom::align_up((size_t)k * (c + 1) * sizeof(double), 256);
+    PXSOM_HIP_TRY(hipMemsetAsync(scratch, 0, stats_bytes + 256, st));   // statistics + the finishing launch's ticket
     bool fused = false;
+    pxsom_bmu::FinishTables fin;
+    fin.sums = sums_dev;
+    fin.counts = reinterpret_cast<long long *>(counts_dev);
+    fin.means = means_dev;
+    fin.overwrite = 1;
+    fin.ticket = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(scratch) + stats_bytes);
     if (n > 0) {
         rc = pxsom_bmu::assign_accumulate(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, scratch, workspace_dev, assign_ws, st, &fused,
-                                          true);
+                                          &fin);
         if (rc) return rc;
     }
+    if (fused && fin.done) return PXSOM_OK;   // the last workgroup of the launch wrote the three tables
     if (fused || n == 0) {   // one launch writes the three tables
         hipLaunchKernelGGL(stats_to_means_kernel, dim3(fgrid), dim3(256), 0, st, scratch, k, c, sums_dev,
                            reinterpret_cast<long long *>(counts_dev), means_dev);
