@@ -932,20 +932,21 @@ _Pragma("unroll") for (int j = 0; j < 2 * NP; j++)                              
                 const unsigned long long cnt = lu[(size_t)e * cs + c] * binv;
                 if (cnt) __hip_atomic_fetch_add(stats + (size_t)k * c + e, (double)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            // Round 6: the last workgroup through its flush turns the statistics into the caller's tables (a ticket: release by
-            // every workgroup behind its own atomics, acquire by the last one before it reads them all) -- the finishing launch
-            // behind this kernel is gone
+            // Round 6: the last workgroup through its flush turns the statistics into the caller's tables -- the finishing launch
+            // behind this kernel is gone.  The statistics only ever see device-scope atomics, which are performed at the memory
+            // side: a wave whose vmcnt has drained knows its adds are in, and the last workgroup reads them with device-scope
+            // atomic loads.  NO release fence: at agent scope that is a write-back of the XCD's whole L2 -- 40 MB of freshly
+            // written labels -- by every one of 512 workgroups (measured: kernel 0.22 -> 0.31 ms).
             if (fin.ticket) {
                 __shared__ int s_last_wg;
-                __threadfence();
+                __builtin_amdgcn_s_waitcnt(0);
                 __syncthreads();
                 if (threadIdx.x == 0) {
-                    const unsigned t = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned t = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     s_last_wg = t == gridDim.x - 1u;
                 }
                 __syncthreads();
                 if (s_last_wg) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     int node = (int)threadIdx.x / c, j = (int)threadIdx.x - node * c;
                     for (int e = threadIdx.x; e < k * c; e += 256) {
                         const double s = __hip_atomic_load(stats + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
