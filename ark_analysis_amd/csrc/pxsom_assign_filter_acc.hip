@@ -16,34 +16,36 @@ void launch_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layou
                 const double *w, hipStream_t st, FinishTables *fin = nullptr)
 {
     auto kern = bmu_filter_fast<T, CPL, 7, 1, 0, true, FIX, FOLD>;
+    constexpr int kThreads = fast_threads(true, FIX), kWaves = kThreads / 64;   // (FIX: one workgroup of 512 threads per CU)
     // table (first the row-major codebook prep reads) | transposed codebook | fragments | bias | header copy | listed-row queue:
     // 63 KB at k = 100, c = 22 -- two workgroups per CU
     const size_t lds = (acc_table_words(L.k, c, CPL, FIX) + (PXSOM_FAST_WGS < 3 ? (size_t)L.k * c : 0)) * sizeof(double) +
                        (size_t)7 * 2 * 64 * sizeof(half8) + (size_t)7 * 64 * sizeof(f32x4) + kHdrBytes +
                        256 * sizeof(int64_t) + 16 +   // + queue of listed rows and its counter
-                       4 * 256 * sizeof(int64_t);    // + the four waves' queues of rows that wait for the full search
+                       (size_t)kWaves * 256 * sizeof(int64_t);    // + the waves' queues of rows that wait for the full search
     static pxsom::PerDevice<int> bpc_on;   // (one per instantiation)
     int &bpc = bpc_on.here();
     if (bpc == 0) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   128 * 1024);
         int nbk = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, kern, 256, lds) != hipSuccess || nbk < 1) nbk = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, kern, kThreads, lds) != hipSuccess || nbk < 1) nbk = 1;
         bpc = nbk > 8 ? 8 : nbk;
     }
     const int64_t ngroups = (n + 63) / 64;
     // two 64-row groups per workgroup when the launch is small (groups are dealt workgroup-major): measured on
     // the 256-group mini-batches of config 2, training pass 1.63 / 1.59 / 1.50 ms for 4 / 1 / 2 groups per workgroup
     // (fewer workgroups share the exact rows among fewer waves; more pay the prologue and the flush more often)
-    int grid = (int)std::min<int64_t>((ngroups + 1) / 2, (int64_t)pxsom::device_cu_count() * bpc);
+    constexpr int kGroupsPerWg = kWaves / 2;   // (half a group per wave at least)
+    int grid = (int)std::min<int64_t>((ngroups + kGroupsPerWg - 1) / kGroupsPerWg, (int64_t)pxsom::device_cu_count() * bpc);
     if (grid < 1) grid = 1;
-    // FIX: ceil(log2(rows one workgroup can meet)) -- 4 waves x 64 rows per round of the grid, shifted last group included
+    // FIX: ceil(log2(rows one workgroup can meet)) -- its waves x 64 rows per round of the grid, shifted last group included
     int fix_rows_log2 = 0;
     {
-        const int64_t rows_wg = ((ngroups + (int64_t)grid * 4 - 1) / ((int64_t)grid * 4)) * 256 + 64;
+        const int64_t rows_wg = ((ngroups + (int64_t)grid * kWaves - 1) / ((int64_t)grid * kWaves)) * (64 * kWaves) + 64;
         while (((int64_t)1 << fix_rows_log2) < rows_wg) fix_rows_log2++;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, x, n, c, ldx,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, x, n, c, ldx,
                        reinterpret_cast<const half8 *>(ws + L.off_wfrag),
                        reinterpret_cast<const f32x4 *>(ws + L.off_bias), reinterpret_cast<AssignHdr *>(ws),
                        reinterpret_cast<unsigned *>(ws + L.off_list), labels, L.k, stats, w, L.idx_bits, L.node_bits,

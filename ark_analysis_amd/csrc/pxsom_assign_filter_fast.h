@@ -268,6 +268,16 @@ __host__ __device__ inline unsigned long long inverse_mod_2_64(unsigned long lon
 // mini-batch step needs no exact-kernel launch.  One pass over x, one launch.
 // FIX (with ACC; pxsom_assign_sums): the workgroup's table is 64-bit fixed point (FixPoint above), fix_rows_log2 =
 // ceil(log2(rows a workgroup can meet)).
+// Round 6: the one-pass kernel (ACC + FIX) runs as ONE workgroup of 512 threads per CU instead of two of 256 -- the same two waves
+// per SIMD on one table, one codebook copy and one set of fragments: half as many workgroups prepare the codebook and flush 2 300
+// binary64 atomics each into the same 144 cache lines of statistics at the launch's end (the fixed ~25 us of a 0.22 ms launch):
+// 0.2311 - 0.2323 ms against 0.2406 - 0.2416 on one box (profiles/r06/experiments.txt).  -DPXSOM_ONE_WG=0: two workgroups of 256.
+// (Also measured, not kept: the wave's first group requested before the prologue instead of behind it -- 0.2245 - 0.2283 against
+// 0.2221 - 0.2257 ms.)
+#ifndef PXSOM_ONE_WG
+#define PXSOM_ONE_WG 1
+#endif
+__host__ __device__ constexpr int fast_threads(bool acc, bool fix) { return (acc && fix && PXSOM_ONE_WG) ? 512 : 256; }
 #ifndef PXSOM_ADD_SCAN       // one-pass kernel: tiles whose neighbouring rows mostly share their label are summed along the row axis first
 #define PXSOM_ADD_SCAN 1
 #endif
@@ -277,7 +287,7 @@ __host__ __device__ inline unsigned long long inverse_mod_2_64(unsigned long lon
 // FOLD (FIX only): some slots of the last lane groups lie past the row's end (c < 4 CPL) -- the one at channel c then carries
 // the row count; without such a slot (c == 4 CPL) the count takes an instruction of its own.
 template <typename T, int CPL, int NB, int RU, int MODE, bool ACC, bool FIX = false, bool FOLD = true>
-__global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void bmu_filter_fast(
+__global__ __launch_bounds__(fast_threads(ACC, FIX), (ACC && FIX && PXSOM_ONE_WG) ? 1 : (ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS)) void bmu_filter_fast(
     const T *__restrict__ x, int64_t n, int c, int64_t ldx, const half8 *__restrict__ wfrag,
     const f32x4 *__restrict__ bias, AssignHdr *hdr, unsigned *__restrict__ amb_list,
     int32_t *__restrict__ labels, int k, double *__restrict__ stats, const double *__restrict__ wcodes,
@@ -295,6 +305,7 @@ __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void b
     const int wsj = kWtInLds ? k : 1, wsn = kWtInLds ? 1 : c;
     // ACC: rows the filter is not sure of wait in a per-workgroup queue and are settled after the group loop by
     // whichever wave is free (a mini-batch lists 0..6 rows per wave early in training: the slowest wave set the pace)
+    constexpr int kThreads = fast_threads(ACC, FIX), kWaves = kThreads / 64;
     constexpr unsigned kAmbQueue = 256;
     int64_t *amb_q = nullptr;
     unsigned *amb_n = nullptr;
@@ -307,7 +318,7 @@ __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void b
     unsigned s1_n = 0u;   // wave-uniform
     bool scan_trip = false;   // wave-uniform: this trip's rows are summed along the row axis before they touch the table (ACC + FIX, see there)
     if constexpr (!ACC) {   // (the plain filter has no dynamic LDS: its waves' queues are a static array)
-        __shared__ long long s1_plain[4 * kS1Queue];
+        __shared__ long long s1_plain[kWaves * kS1Queue];
         s1_q = reinterpret_cast<int64_t *>(s1_plain) + (size_t)(threadIdx.x >> 6) * kS1Queue;
     }
     if constexpr (ACC) {
@@ -323,16 +334,16 @@ __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void b
         amb_n = reinterpret_cast<unsigned *>(amb_q + kAmbQueue);
         s1_q = reinterpret_cast<int64_t *>(amb_n + 4) + (size_t)(threadIdx.x >> 6) * kS1Queue;   // this wave's
         if (threadIdx.x == 0) *amb_n = 0u;
-        // element e = tid + 256 u  <->  (node, channel), advanced without a division per element
+        // element e = tid + kThreads u  <->  (node, channel), advanced without a division per element
         int node = (int)threadIdx.x / c, j = (int)threadIdx.x - node * c;
-        const int dnode = 256 / c, dj = 256 % c;
-        for (int e0 = threadIdx.x; e0 < k * c; e0 += 8 * 256) {   // 8 L2 loads in flight per thread
+        const int dnode = kThreads / c, dj = kThreads % c;
+        for (int e0 = threadIdx.x; e0 < k * c; e0 += 8 * kThreads) {   // 8 L2 loads in flight per thread
             double v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = wcodes[e0 + u * 256 < k * c ? e0 + u * 256 : 0];
+            for (int u = 0; u < 8; u++) v[u] = wcodes[e0 + u * kThreads < k * c ? e0 + u * kThreads : 0];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                const int e = e0 + u * 256;
+                const int e = e0 + u * kThreads;
                 if (e < k * c) {
                     wrow[e] = v[u];
                     if constexpr (kWtInLds) wt[j * k + node] = v[u];
@@ -346,9 +357,9 @@ __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void b
             }
         }
         __syncthreads();
-        prep_body<256, 128>(wrow, k, c, hdr_l, frag_l, bias_l, NB, 1, CPL, idx_bits, node_bits, nullptr, nullptr, 0, 0, true);
+        prep_body<kThreads, 128>(wrow, k, c, hdr_l, frag_l, bias_l, NB, 1, CPL, idx_bits, node_bits, nullptr, nullptr, 0, 0, true);
         __syncthreads();
-        for (int e = threadIdx.x; e < (int)acc_table_words(k, c, CPL, FIX); e += 256) ls[e] = 0.0;   // (the first add comes after the loads' wait)
+        for (int e = threadIdx.x; e < (int)acc_table_words(k, c, CPL, FIX); e += kThreads) ls[e] = 0.0;   // (the first add comes after the loads' wait)
         __syncthreads();
         wfrag = frag_l;
         bias = bias_l;
@@ -388,8 +399,8 @@ __global__ __launch_bounds__(256, ACC ? PXSOM_FAST_WGS : PXSOM_PLAIN_WGS) void b
     const int wv_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // (group numbers are 32-bit -- the launchers refuse 2^37 rows and more --: their clamps and the loop tests stay on the scalar
     // unit, which has no 64-bit ordered compare)
-    const int wave = ACC ? wv_in_block * (int)gridDim.x + (int)blockIdx.x : (int)blockIdx.x * 4 + wv_in_block;
-    const int nwaves = (int)gridDim.x * 4;
+    const int wave = ACC ? wv_in_block * (int)gridDim.x + (int)blockIdx.x : (int)blockIdx.x * kWaves + wv_in_block;
+    const int nwaves = (int)gridDim.x * kWaves;
     const int ngroups = (int)((n + 63) / 64);
     const int last_shift = (int)((int64_t)ngroups * 64 - n);   // the last group is shifted back by this many rows (0: it is full)
 
@@ -906,15 +917,15 @@ _Pragma("unroll") for (int j = 0; j < 2 * NP; j++)                              
     if constexpr (ACC) {
         __syncthreads();   // every wave is through its groups: the queue is complete
         const unsigned queued = *amb_n < kAmbQueue ? *amb_n : kAmbQueue;   // rows past the end were settled at once
-        for (unsigned i = threadIdx.x >> 6; i < queued; i += 4)
+        for (unsigned i = threadIdx.x >> 6; i < queued; i += kWaves)
             exact_row_accumulate<T, FIX>(x, amb_q[i], c, ldx, wx, k, labels, ls, lane, &fx, stats, cs, wsj, wsn, FIX ? c : -1, FIX ? fx.mbits : 1ull);
         __syncthreads();
         if constexpr (FIX) {
             int node = (int)threadIdx.x / c, j = (int)threadIdx.x - node * c;   // element e <-> (node, channel), no division per element
-            const int dnode = 256 / c, dj = 256 % c;
+            const int dnode = kThreads / c, dj = kThreads % c;
             // word c of a table row holds n B modulo 2^64 for the n rows of the label (B: the magic number's odd bit pattern) -- the
             // very amount those rows put on top of their values in every channel word
-            for (int e = threadIdx.x; e < k * c; e += 256) {
+            for (int e = threadIdx.x; e < k * c; e += kThreads) {
                 const unsigned long long nb = lu[(size_t)node * cs + c];
                 if (nb) {
                     const long long units = (long long)(lu[(size_t)node * cs + j] - nb);
@@ -928,7 +939,7 @@ _Pragma("unroll") for (int j = 0; j < 2 * NP; j++)                              
                 }
             }
             const unsigned long long binv = inverse_mod_2_64(fx.mbits);
-            for (int e = threadIdx.x; e < k; e += 256) {
+            for (int e = threadIdx.x; e < k; e += kThreads) {
                 const unsigned long long cnt = lu[(size_t)e * cs + c] * binv;
                 if (cnt) __hip_atomic_fetch_add(stats + (size_t)k * c + e, (double)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -948,7 +959,7 @@ _Pragma("unroll") for (int j = 0; j < 2 * NP; j++)                              
                 __syncthreads();
                 if (s_last_wg) {
                     int node = (int)threadIdx.x / c, j = (int)threadIdx.x - node * c;
-                    for (int e = threadIdx.x; e < k * c; e += 256) {
+                    for (int e = threadIdx.x; e < k * c; e += kThreads) {
                         const double s = __hip_atomic_load(stats + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (fin.overwrite) {
                             const double cnt = __hip_atomic_load(stats + (size_t)k * c + node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -964,7 +975,7 @@ _Pragma("unroll") for (int j = 0; j < 2 * NP; j++)                              
                             node++;
                         }
                     }
-                    for (int e = threadIdx.x; e < k; e += 256) {
+                    for (int e = threadIdx.x; e < k; e += kThreads) {
                         const long long cnt = (long long)__hip_atomic_load(stats + (size_t)k * c + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (fin.overwrite) fin.counts[e] = cnt;
                         else fin.counts[e] += cnt;
@@ -974,8 +985,8 @@ _Pragma("unroll") for (int j = 0; j < 2 * NP; j++)                              
             }
         } else {
             int node = (int)threadIdx.x / c, j = (int)threadIdx.x - node * c;
-            const int dnode = 256 / c, dj = 256 % c;
-            for (int e = threadIdx.x; e < k * c; e += 256) {
+            const int dnode = kThreads / c, dj = kThreads % c;
+            for (int e = threadIdx.x; e < k * c; e += kThreads) {
                 const double v = ls[(size_t)node * cs + j];
                 if (v != 0.0) __hip_atomic_fetch_add(stats + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 node += dnode;
@@ -985,7 +996,7 @@ _Pragma("unroll") for (int j = 0; j < 2 * NP; j++)                              
                     node++;
                 }
             }
-            for (int e = threadIdx.x; e < k; e += 256) {
+            for (int e = threadIdx.x; e < k; e += kThreads) {
                 const double v = ls[(size_t)(k + 1) * cs + e];   // counts sit behind the spare row
                 if (v != 0.0) __hip_atomic_fetch_add(stats + (size_t)k * c + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
