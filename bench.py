@@ -432,10 +432,10 @@ def main():
         from ark_analysis_amd.distributed import native_exchange
         native = native_exchange(None)                                     # (made once per group: cached by now)
         # replicas: every rank must hold the same codebook bit for bit after the timed passes
-        wcpu = w.detach().cpu()
-        copies = [torch.zeros_like(wcpu) for _ in range(world)]
-        dist.all_gather(copies, wcpu)
-        per_rank["codebooks_equal"] = bool(all(torch.equal(cp, copies[0]) for cp in copies)) and bool(torch.isfinite(wcpu).all())
+        wmine = w.detach().cpu() if dry else w.detach().clone()      # (gloo gathers host tensors, RCCL device tensors)
+        copies = [torch.zeros_like(wmine) for _ in range(world)]
+        dist.all_gather(copies, wmine)
+        per_rank["codebooks_equal"] = bool(all(torch.equal(cp, copies[0]) for cp in copies)) and bool(torch.isfinite(wmine).all().item())
         per_rank["kernel_route_agreement"] = getattr(trainer.kernels, "route_agreement", None)
         per_rank["exchange_decision"] = _dm.exchange_report.get(None)
         comm_ranks = world if native is not None else 0
