@@ -277,6 +277,9 @@ __host__ __device__ inline unsigned long long inverse_mod_2_64(unsigned long lon
 #ifndef PXSOM_ONE_WG
 #define PXSOM_ONE_WG 1
 #endif
+#ifndef PXSOM_TIMING_ABL   // timing builds ONLY (wrong results): 1 = no flush atomics, 2 = listed rows not settled, 4 = no full search of queued rows
+#define PXSOM_TIMING_ABL 0
+#endif
 __host__ __device__ constexpr int fast_threads(bool acc, bool fix) { return (acc && fix && PXSOM_ONE_WG) ? 512 : 256; }
 #ifndef PXSOM_ADD_SCAN       // one-pass kernel: tiles whose neighbouring rows mostly share their label are summed along the row axis first
 #define PXSOM_ADD_SCAN 1
@@ -760,6 +763,46 @@ __global__ __launch_bounds__(fast_threads(ACC, FIX), (ACC && FIX && PXSOM_ONE_WG
                     // slot like any other.)
                     if constexpr (FOLD && PXSOM_ADD_SCAN)
                     if (__builtin_expect(scan_now, 0)) {   // (out of line: the plain adds below stay one block behind the search)
+                        // Round 6: ALL 64 rows of the trip under one label (runs of 64 rows and longer: the inside of a region of
+                        // an image) -- the four tiles' words are first added up inside the lane (a lane holds the same channel slots
+                        // of rows pix, 16 + pix, 32 + pix, 48 + pix), ONE reduction over the 16 lanes of a lane row follows instead
+                        // of four prefix sums, and the last lane of every lane row adds its six words: 36 + 48 vector instructions
+                        // and 6 atomics per 64 rows instead of 192 and 24.  Same modular sums: the table ends bit-identical.
+                        const unsigned lab_first = (unsigned)__builtin_amdgcn_readfirstlane((int)lab[0]);
+                        const bool one_label = __ballot(lab[0] == lab_first && lab[1] == lab_first && lab[2] == lab_first && lab[3] == lab_first) == ~0ull;
+                        if (one_label) {
+                            unsigned lo[2 * NP], hi[2 * NP];
+#pragma unroll
+                            for (int p = 0; p < NP; p++) {
+                                unsigned long long sx = slot_bits((float)keep[0][p].x), sy = slot_bits((float)keep[0][p].y);
+#pragma unroll
+                                for (int t = 1; t < kTilesPerIter; t++) {
+                                    sx += slot_bits((float)keep[t][p].x);
+                                    sy += slot_bits((float)keep[t][p].y);
+                                }
+                                lo[2 * p] = (unsigned)sx;
+                                hi[2 * p] = (unsigned)(sx >> 32);
+                                lo[2 * p + 1] = (unsigned)sy;
+                                hi[2 * p + 1] = (unsigned)(sy >> 32);
+                            }
+#define PXSOM_SCAN_STEP(SHR)                                                                                                         \
+_Pragma("unroll") for (int j = 0; j < 2 * NP; j++)                                                                                \
+    asm volatile("v_add_co_u32_dpp %0, vcc, %0, %0 row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"               \
+                 "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:1"                \
+                 : "+v"(lo[j]), "+v"(hi[j])::"vcc");
+                            PXSOM_SCAN_STEP(1)
+                            PXSOM_SCAN_STEP(2)
+                            PXSOM_SCAN_STEP(4)
+                            PXSOM_SCAN_STEP(8)
+#undef PXSOM_SCAN_STEP
+                            if (pix == 15) {   // (the inclusive prefix sum of the last lane of a lane row is the row's total)
+                                unsigned long long *const one_row = table_row(lab_first);
+#pragma unroll
+                                for (int j = 0; j < 2 * NP; j++)
+                                    __hip_atomic_fetch_add(one_row + j, ((unsigned long long)hi[j] << 32) | lo[j], __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                        } else
 #pragma unroll
                         for (int t = 0; t < kTilesPerIter; t++) {
                             const unsigned nxt = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)lab[t], 0x101 /* row_shl:1 */, 0xf, 0xf, false);
@@ -904,6 +947,10 @@ _Pragma("unroll") for (int j = 0; j < 2 * NP; j++)                              
     // wave's groups in full straight away once most of its rows fail stage 1 -- crowded nodes -- was measured on the same box:
     // it takes a codebook with node pairs 1e-2 apart from 1.65 to 1.20 ms and costs the ordinary case 0.260 -> 0.270 ms for
     // being there; not kept.)
+    // (Round 6, timing builds -DPXSOM_TIMING_ABL: the full search of the queued rows behind a wave's last group costs 9 us of the
+    // 0.22 ms launch -- every wave of the chip runs it at the same moment with the gather's trip to HBM exposed --, the flush 5 us, the
+    // listed rows 2 us.  Emptying the queue two trips early and sending the last trips' unsure rows straight to the exact path was
+    // measured SLOWER: 0.2256 - 0.2311 against 0.2199 - 0.2329 ms, and 10 - 14 % slower on crowded codebooks; not kept.)
     while (g < ngroups) {
         while (g < ngroups && s1_n <= kS1Queue - 128u) {
             trip(rows_a, rows_b, std::integral_constant<int, 0>{}, 0u);
@@ -912,12 +959,14 @@ _Pragma("unroll") for (int j = 0; j < 2 * NP; j++)                              
             trip(rows_b, rows_a, std::integral_constant<int, 0>{}, 0u);
             g += nwaves;
         }
-        if constexpr (MODE != 1) drain(true);   // (the one place the full search is instantiated)
+        if constexpr (MODE != 1 && !(PXSOM_TIMING_ABL & 4)) drain(true);   // (the one place the full search is instantiated)
+        else s1_n = 0u;
     }
     if constexpr (ACC) {
         __syncthreads();   // every wave is through its groups: the queue is complete
         const unsigned queued = *amb_n < kAmbQueue ? *amb_n : kAmbQueue;   // rows past the end were settled at once
         for (unsigned i = threadIdx.x >> 6; i < queued; i += kWaves)
+            if (!(PXSOM_TIMING_ABL & 2))
             exact_row_accumulate<T, FIX>(x, amb_q[i], c, ldx, wx, k, labels, ls, lane, &fx, stats, cs, wsj, wsn, FIX ? c : -1, FIX ? fx.mbits : 1ull);
         __syncthreads();
         if constexpr (FIX) {
@@ -929,7 +978,7 @@ _Pragma("unroll") for (int j = 0; j < 2 * NP; j++)                              
                 const unsigned long long nb = lu[(size_t)node * cs + c];
                 if (nb) {
                     const long long units = (long long)(lu[(size_t)node * cs + j] - nb);
-                    if (units) __hip_atomic_fetch_add(stats + e, (double)units * fx.unit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (units && !(PXSOM_TIMING_ABL & 1)) __hip_atomic_fetch_add(stats + e, (double)units * fx.unit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 node += dnode;
                 j += dj;
