@@ -271,7 +271,9 @@ bool step_wide_windowed(int xdim, int ydim, int c);
 template <typename T>
 int launch_batch_step_wide(const T *x, int64_t n, int c, int64_t ldx, int xdim, int ydim, double *stats, const StepArgs &sa, hipStream_t st);
 // the streamed filter on packed-K fragments (pxsom_assign_filter.hip)
-void launch_filter_packed(const _Float16 *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels, hipStream_t st);
+// (super_blocks: node blocks in super-blocks of four -- the labelling calls; the training steps keep a block index per block)
+void launch_filter_packed(const _Float16 *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels, hipStream_t st,
+                          bool super_blocks);
 // rows the packed kernel can read: 16-byte aligned rows of binary16
 template <typename T>
 inline bool packed_rows_ok(const T *x, int64_t ldx)

@@ -711,7 +711,7 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
     pxsom::Prof *prof = pxsom::current_prof();
     pxsom::prof_mark(prof, st, true, n);
     if constexpr (sizeof(T) == 2) {
-        if (L.npk > 0) launch_filter_packed(x, n, c, ldx, ws, L, labels, st);
+        if (L.npk > 0) launch_filter_packed(x, n, c, ldx, ws, L, labels, st, !prepared);
         else launch_filter_any<T>(x, n, c, ldx, ws, L, labels, stats, w, st, fin);
     } else {
         launch_filter_any<T>(x, n, c, ldx, ws, L, labels, stats, w, st, fin);

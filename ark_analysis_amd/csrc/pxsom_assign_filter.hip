@@ -32,6 +32,9 @@
 #ifndef PXSOM_FILTER_MODE
 #define PXSOM_FILTER_MODE 0
 #endif
+#ifndef PXSOM_PACKED_SUPER   // packed-K filter: node blocks in super-blocks of four (0: a compare + select per block; timing builds)
+#define PXSOM_PACKED_SUPER 1
+#endif
 
 namespace pxsom_bmu {
 namespace {
@@ -463,7 +466,7 @@ void launch_filter_variant(const T *x, int64_t n, int c, int64_t ldx, char *ws, 
 // beside the score, transposing merge, tolerance, exact list) is the streamed kernel's.  A codebook so large that
 // x * scale could lose bits (scale < 1: entries >= 256) sends every row to the exact path instead.
 // ------------------------------------------------------------------------------------------------
-template <int NPK, int TP, bool LDSW, int BD>
+template <int NPK, int TP, bool LDSW, int BD, bool SUPER = false>
 __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_packed_kernel(
     const _Float16 *__restrict__ x, int64_t n, int c, int64_t ldx, const half8 *__restrict__ wfrag,
     const f32x4 *__restrict__ bias, AssignHdr *hdr, unsigned *__restrict__ amb_list, int32_t *__restrict__ labels)
@@ -472,10 +475,17 @@ __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_packed_kerne
     // (Round 5, measured and not kept: the node block packed into the score's low bits beside the register index -- 7 bits -- instead
     // of the per-tile block index kept by a compare + select: the filter went 0.332 -> 0.362 ms on 4.2 M x 40 rows and the 2^-16
     // packing term listed 2.4 x the rows for the exact kernels: profiles/r05/packed_filter_experiments.txt)
-    constexpr unsigned idx_mask = 3u;
+    // Round 6: node blocks in SUPER-BLOCKS of four.  A score carries 4 bits -- which block of its super-block, which accumulator
+    // register --, and the super-block of a tile's best score is kept by ONE compare + select per super-block and tile instead of one
+    // per block (8 + 4 of a block's 51 vector instructions at four tiles).  Packing term of the tolerance: 2^-19 instead of 2^-21
+    // (prep derived the bound for 2 bits: the difference is added here).  SUPER = false for the training steps: the crowded codebooks
+    // of a pass's first steps list 30 % more rows under the wider tolerance and their exact path costs more than the filter gains
+    // (config 5's shape, same box: filter 2.75 -> 2.59 ms per 33.5 M rows, training pass 3.25 -> 3.34 ms; profiles/r06/experiments.txt).
+    constexpr unsigned idx_mask = (PXSOM_PACKED_SUPER && SUPER) ? 15u : 3u;
     const float scale = hdr->scale, wn_max = hdr->wn_max, tol_abs = hdr->tol_abs, x_limit = hdr->x_limit;
     // binary16 rows without the Xl terms: the bound of the streamed kernel (see there)
-    const float tol_rel = hdr->tol_rel - 2.5f * ((float)(filter_accum_units(c, 3) - filter_accum_units(c, 2)) * 0x1p-24f + (0x1p-19f - 0x1p-21f));
+    const float tol_rel = hdr->tol_rel - 2.5f * ((float)(filter_accum_units(c, 3) - filter_accum_units(c, 2)) * 0x1p-24f + (0x1p-19f - 0x1p-21f)) +
+                          ((PXSOM_PACKED_SUPER && SUPER) ? 2.5f * (0x1p-19f - 0x1p-21f) : 0.f);
     const bool force_exact = hdr->force_exact != 0 || scale < 1.f;
     const int lane = threadIdx.x & 63;
     const int pix = lane & 15, q = lane >> 4;
@@ -548,7 +558,8 @@ __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_packed_kerne
                 m1[u] = m2[u] = kNegBig;
                 bsel[u] = 0;
             }
-            for (int b = 0; b < nb; b++) {
+            auto block = [&](int b, auto jtag) {   // node block b; its scores carry (j, r) -- j: its place in the super-block
+                constexpr int J = decltype(jtag)::value;
                 f32x4 acc[TP];
                 const f32x4 bv = LDSW ? lbias[b * 64 + lane] : bias[b * 64 + lane];
 #pragma unroll
@@ -560,10 +571,29 @@ __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_packed_kerne
                     for (int u = 0; u < TP; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, bx[u][m], acc[u], 0, 0, 0);
                 }
 #pragma unroll
-                for (int u = 0; u < TP; u++) {
-                    const float before = m1[u];
-                    consume(m1[u], m2[u], acc[u], 0, idx_mask);
-                    bsel[u] = m1[u] != before ? b : bsel[u];
+                for (int u = 0; u < TP; u++) consume(m1[u], m2[u], acc[u], J, idx_mask);
+            };
+            if constexpr (PXSOM_PACKED_SUPER && SUPER) {
+                for (int sb = 0; sb * 4 < nb; sb++) {
+                    float before[TP];
+#pragma unroll
+                    for (int u = 0; u < TP; u++) before[u] = m1[u];
+                    const int b0 = sb * 4;
+                    block(b0, std::integral_constant<int, 0>{});
+                    if (b0 + 1 < nb) block(b0 + 1, std::integral_constant<int, 1>{});
+                    if (b0 + 2 < nb) block(b0 + 2, std::integral_constant<int, 2>{});
+                    if (b0 + 3 < nb) block(b0 + 3, std::integral_constant<int, 3>{});
+#pragma unroll
+                    for (int u = 0; u < TP; u++) bsel[u] = m1[u] != before[u] ? sb : bsel[u];
+                }
+            } else {
+                for (int b = 0; b < nb; b++) {
+                    float before[TP];
+#pragma unroll
+                    for (int u = 0; u < TP; u++) before[u] = m1[u];
+                    block(b, std::integral_constant<int, 0>{});
+#pragma unroll
+                    for (int u = 0; u < TP; u++) bsel[u] = m1[u] != before[u] ? b : bsel[u];
                 }
             }
             if constexpr (TP == kTilesPerIter && PXSOM_PACKED_TMERGE) {
@@ -579,7 +609,8 @@ __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_packed_kerne
                     a1[u] = m1[u];
                     a2[u] = m2[u];
                     s2[u] = ss[u];
-                    const unsigned bb = (unsigned)bsel[u], r = __float_as_uint(a1[u]) & idx_mask;
+                    const unsigned id = __float_as_uint(a1[u]) & idx_mask, r = id & 3u;
+                    const unsigned bb = (PXSOM_PACKED_SUPER && SUPER) ? (unsigned)bsel[u] * 4u + (id >> 2) : (unsigned)bsel[u];
                     node[u] = (int)((int)bb == nb - 1 ? (bb << 4) | (r << 2) | (unsigned)q : (bb << 4) | ((unsigned)q << 2) | r);
                 }
                 auto tmerge = [&](int x, int y, bool wide) {   // tiles x, y -> slot x
@@ -622,7 +653,8 @@ __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_packed_kerne
                 float a1 = m1[u], a2 = m2[u], s2 = ss[u];
                 int node;
                 {
-                    const unsigned bb = (unsigned)bsel[u], r = __float_as_uint(a1) & idx_mask;
+                    const unsigned id = __float_as_uint(a1) & idx_mask, r = id & 3u;
+                    const unsigned bb = (PXSOM_PACKED_SUPER && SUPER) ? (unsigned)bsel[u] * 4u + (id >> 2) : (unsigned)bsel[u];
                     node = (int)((int)bb == nb - 1 ? (bb << 4) | (r << 2) | (unsigned)q : (bb << 4) | ((unsigned)q << 2) | r);
                 }
                 auto merge_step = [&](bool wide) {
@@ -669,7 +701,8 @@ __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_packed_kerne
 // many rows' top-2 gaps lie inside the 2^-11 |X'||W'| the dropped Wl term costs; profiles/r05/packed_filter_experiments.txt.  It has no
 // shape where it wins and was removed in round 6.)
 template <int NPK>
-void launch_packed(const _Float16 *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels, hipStream_t st)
+void launch_packed(const _Float16 *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels, hipStream_t st,
+                   bool super_blocks)
 {
     const size_t lds = (size_t)L.nb * (NPK + 1) * 1024;       // fragments + bias of the whole codebook
     const int64_t ngroups = (n + 63) / 64;
@@ -683,7 +716,7 @@ void launch_packed(const _Float16 *x, int64_t n, int c, int64_t ldx, char *ws, c
     // matrix and vector instructions of a SIMD overlap between waves, not inside one.
     if constexpr (NPK <= 4)
     if (lds <= 150 * 1024 && lds > 64 * 1024) {   // (five chunks and more spill at 128 VGPRs)
-        auto kern = bmu_filter_packed_kernel<NPK, 4, true, 1024>;
+        auto kern = super_blocks ? bmu_filter_packed_kernel<NPK, 4, true, 1024, true> : bmu_filter_packed_kernel<NPK, 4, true, 1024, false>;
         static pxsom::PerDevice<bool> raised_on;
         bool &raised = raised_on.here();
         if (!raised) {
@@ -794,15 +827,16 @@ template void launch_filter_any<double>(const double *, int64_t, int, int64_t, c
                                         double *, const double *, hipStream_t, FinishTables *);
 template void launch_filter_any<_Float16>(const _Float16 *, int64_t, int, int64_t, char *, const Layout &, int32_t *,
                                           double *, const double *, hipStream_t, FinishTables *);
-void launch_filter_packed(const _Float16 *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels, hipStream_t st)
+void launch_filter_packed(const _Float16 *x, int64_t n, int c, int64_t ldx, char *ws, const Layout &L, int32_t *labels, hipStream_t st,
+                          bool super_blocks)
 {
     switch (L.npk) {   // ceil(2 c / 32) for c = 40 .. 128 (c % 8 == 0)
-        case 3: launch_packed<3>(x, n, c, ldx, ws, L, labels, st); break;
-        case 4: launch_packed<4>(x, n, c, ldx, ws, L, labels, st); break;
-        case 5: launch_packed<5>(x, n, c, ldx, ws, L, labels, st); break;
-        case 6: launch_packed<6>(x, n, c, ldx, ws, L, labels, st); break;
-        case 7: launch_packed<7>(x, n, c, ldx, ws, L, labels, st); break;
-        default: launch_packed<8>(x, n, c, ldx, ws, L, labels, st); break;
+        case 3: launch_packed<3>(x, n, c, ldx, ws, L, labels, st, super_blocks); break;
+        case 4: launch_packed<4>(x, n, c, ldx, ws, L, labels, st, super_blocks); break;
+        case 5: launch_packed<5>(x, n, c, ldx, ws, L, labels, st, super_blocks); break;
+        case 6: launch_packed<6>(x, n, c, ldx, ws, L, labels, st, super_blocks); break;
+        case 7: launch_packed<7>(x, n, c, ldx, ws, L, labels, st, super_blocks); break;
+        default: launch_packed<8>(x, n, c, ldx, ws, L, labels, st, super_blocks); break;
     }
 }
 
