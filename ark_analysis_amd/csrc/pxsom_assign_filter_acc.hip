@@ -19,15 +19,18 @@ void launch_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layou
     constexpr int kThreads = fast_threads(true, FIX), kWaves = kThreads / 64;   // (FIX: one workgroup of 512 threads per CU)
     // table (first the row-major codebook prep reads) | transposed codebook | fragments | bias | header copy | listed-row queue:
     // 63 KB at k = 100, c = 22 -- two workgroups per CU
-    const size_t lds = (acc_table_words(L.k, c, CPL, FIX) + (PXSOM_FAST_WGS < 3 ? (size_t)L.k * c : 0)) * sizeof(double) +
+    const size_t lds = (fast_table_copies(true, FIX, CPL) * acc_table_words(L.k, c, CPL, FIX) + (PXSOM_FAST_WGS < 3 ? (size_t)L.k * c : 0)) * sizeof(double) +
                        (size_t)7 * 2 * 64 * sizeof(half8) + (size_t)7 * 64 * sizeof(f32x4) + kHdrBytes +
                        256 * sizeof(int64_t) + 16 +   // + queue of listed rows and its counter
                        (size_t)kWaves * 256 * sizeof(int64_t);    // + the waves' queues of rows that wait for the full search
     static pxsom::PerDevice<int> bpc_on;   // (one per instantiation)
     int &bpc = bpc_on.here();
     if (bpc == 0) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  128 * 1024);
+        // (what the largest codebook of the shape needs -- 100 nodes, c = 4 CPL --, not the CU's 160 KB: the kernel has static LDS too)
+        const size_t lds_max = (fast_table_copies(true, FIX, CPL) * acc_table_words(100, 4 * CPL, CPL, FIX) + (size_t)100 * 4 * CPL) * sizeof(double) +
+                               (size_t)7 * 2 * 64 * sizeof(half8) + (size_t)7 * 64 * sizeof(f32x4) + kHdrBytes + 256 * sizeof(int64_t) + 16 +
+                               (size_t)kWaves * 256 * sizeof(int64_t);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         int nbk = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, kern, kThreads, lds) != hipSuccess || nbk < 1) nbk = 1;
         bpc = nbk > 8 ? 8 : nbk;

@@ -281,6 +281,18 @@ __host__ __device__ inline unsigned long long inverse_mod_2_64(unsigned long lon
 #define PXSOM_TIMING_ABL 0
 #endif
 __host__ __device__ constexpr int fast_threads(bool acc, bool fix) { return (acc && fix && PXSOM_ONE_WG) ? 512 : 256; }
+// Round 6: with one workgroup per CU there is LDS to spare (70 of 160 KB): the fixed-point table exists in FOUR copies, lane (q, pix)
+// adds into copy pix % 4 -- two rows of a tile that share their label meet in the same words only if they also share pix % 4, and the
+// 16 lanes of an add are served together instead of one after the other (the synthetic order: 16 of 100 labels collide in 72 % of
+// the instructions).  The copy is part of the lane's constant base address: no instruction in the trip; the flush adds the copies up.
+#ifndef PXSOM_TABLE_COPIES
+#define PXSOM_TABLE_COPIES 4
+#endif
+// (eight channels per lane -- C = 26 .. 32 --: two copies, four would not fit 160 KB beside the codebook copy and the fragments)
+__host__ __device__ constexpr int fast_table_copies(bool acc, bool fix, int cpl)
+{
+    return (acc && fix && PXSOM_ONE_WG) ? (cpl <= 6 ? PXSOM_TABLE_COPIES : (PXSOM_TABLE_COPIES < 2 ? PXSOM_TABLE_COPIES : 2)) : 1;
+}
 #ifndef PXSOM_ADD_SCAN       // one-pass kernel: tiles whose neighbouring rows mostly share their label are summed along the row axis first
 #define PXSOM_ADD_SCAN 1
 #endif
@@ -301,7 +313,9 @@ __global__ __launch_bounds__(fast_threads(ACC, FIX), (ACC && FIX && PXSOM_ONE_WG
     // not count (listed rows, rows a previous group owns, clamped channel slots): the accumulation has no branch
     double *ls = reinterpret_cast<double *>(acc_smem);
     const int cs = FIX ? acc_stride_fix(CPL) : acc_stride(c);   // table row stride (words)
-    double *wt = ls + acc_table_words(k, c, CPL, FIX);   // [c][k] transposed codebook (ACC only); 16-byte aligned
+    constexpr int kCopies = fast_table_copies(ACC, FIX, CPL);
+    const size_t table_words = acc_table_words(k, c, CPL, FIX);   // (of one copy)
+    double *wt = ls + kCopies * table_words;   // [c][k] transposed codebook (ACC only); 16-byte aligned
     // three workgroups per CU (PXSOM_FAST_WGS = 3): no room for that copy -- the listed rows read the codebook where it lies
     constexpr bool kWtInLds = PXSOM_FAST_WGS < 3;
     const double *wx = kWtInLds ? wt : wcodes;
@@ -362,7 +376,7 @@ __global__ __launch_bounds__(fast_threads(ACC, FIX), (ACC && FIX && PXSOM_ONE_WG
         __syncthreads();
         prep_body<kThreads, 128>(wrow, k, c, hdr_l, frag_l, bias_l, NB, 1, CPL, idx_bits, node_bits, nullptr, nullptr, 0, 0, true);
         __syncthreads();
-        for (int e = threadIdx.x; e < (int)acc_table_words(k, c, CPL, FIX); e += kThreads) ls[e] = 0.0;   // (the first add comes after the loads' wait)
+        for (int e = threadIdx.x; e < (int)(kCopies * table_words); e += kThreads) ls[e] = 0.0;   // (the first add comes after the loads' wait)
         __syncthreads();
         wfrag = frag_l;
         bias = bias_l;
@@ -739,7 +753,7 @@ __global__ __launch_bounds__(fast_threads(ACC, FIX), (ACC && FIX && PXSOM_ONE_WG
                     // a previous group owns carry the spare label k.  The slot at channel c (FOLD: it exists) loaded zeros and so
                     // adds the bare bit pattern of the magic number: the row count, see where fx is made.
                     const unsigned cs8 = (unsigned)cs * 8u;
-                    char *const lane_base = reinterpret_cast<char *>(lu) + (unsigned)(q * CPL) * 8u;
+                    char *const lane_base = reinterpret_cast<char *>(lu) + (unsigned)(q * CPL) * 8u + (unsigned)(pix & (kCopies - 1)) * (unsigned)(table_words * 8);
                     auto table_row = [&](unsigned label) { return reinterpret_cast<unsigned long long *>(lane_base + __umul24(label, cs8)); };
                     auto slot_bits = [&](float v) { return (unsigned long long)__double_as_longlong((double)v + fx.magic); };
                     // (scan_trip was decided a trip ago, on that trip's last tile -- labels that agreed there agree next door -- so the
@@ -974,10 +988,16 @@ _Pragma("unroll") for (int j = 0; j < 2 * NP; j++)                              
             const int dnode = kThreads / c, dj = kThreads % c;
             // word c of a table row holds n B modulo 2^64 for the n rows of the label (B: the magic number's odd bit pattern) -- the
             // very amount those rows put on top of their values in every channel word
+            auto word_sum = [&](size_t at) {   // a table word over the copies (modular: the order does not matter)
+                unsigned long long t = lu[at];
+#pragma unroll
+                for (int r = 1; r < kCopies; r++) t += lu[(size_t)r * table_words + at];
+                return t;
+            };
             for (int e = threadIdx.x; e < k * c; e += kThreads) {
-                const unsigned long long nb = lu[(size_t)node * cs + c];
+                const unsigned long long nb = word_sum((size_t)node * cs + c);
                 if (nb) {
-                    const long long units = (long long)(lu[(size_t)node * cs + j] - nb);
+                    const long long units = (long long)(word_sum((size_t)node * cs + j) - nb);
                     if (units && !(PXSOM_TIMING_ABL & 1)) __hip_atomic_fetch_add(stats + e, (double)units * fx.unit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 node += dnode;
@@ -989,7 +1009,7 @@ _Pragma("unroll") for (int j = 0; j < 2 * NP; j++)                              
             }
             const unsigned long long binv = inverse_mod_2_64(fx.mbits);
             for (int e = threadIdx.x; e < k; e += kThreads) {
-                const unsigned long long cnt = lu[(size_t)e * cs + c] * binv;
+                const unsigned long long cnt = word_sum((size_t)e * cs + c) * binv;
                 if (cnt) __hip_atomic_fetch_add(stats + (size_t)k * c + e, (double)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             // Round 6: the last workgroup through its flush turns the statistics into the caller's tables -- the finishing launch
