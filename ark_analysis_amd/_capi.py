@@ -60,6 +60,9 @@ SYMBOLS = {
     "pxsom_assign_sums_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "pxsom_assign_sums": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pxsom_assign_means": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pxsom_assign_sums_scratch_bytes": (_sz, [_i32, _i32]),
+    "pxsom_assign_sums_ex": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _sz, _i32, _vp]),
+    "pxsom_assign_means_ex": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp]),
     "pxsom_relabel": (_i32, [_vp, _i64, _vp, _i32, _i32, _vp, _vp]),
     "pxsom_batch_train_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "pxsom_batch_train_steps": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,

@@ -1049,6 +1049,10 @@ _Pragma("unroll") for (int j = 0; j < 2 * NP; j++)                              
                         if (fin.overwrite) fin.counts[e] = cnt;
                         else fin.counts[e] += cnt;
                     }
+                    // ... and leaves the statistics region zero for the next call (include/pxsom.h PXSOM_TABLES_SCRATCH_CLEAN)
+                    __syncthreads();
+                    for (int e = threadIdx.x; e < k * c + k; e += kThreads)
+                        __hip_atomic_store(stats + e, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (threadIdx.x == 0) __hip_atomic_store(fin.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }

@@ -1463,18 +1463,20 @@ PXSOM_EXPORT int pxsom_batch_update(double *w_dev, int xdim, int ydim, int c, co
 // caller's tables.  Other shapes: pxsom_assign, then pxsom_cluster_sums.
 // ------------------------------------------------------------------------------------------------
 namespace {
-__global__ __launch_bounds__(256) void stats_to_tables_kernel(const double *__restrict__ stats, int k, int c, double *sums,
+__global__ __launch_bounds__(256) void stats_to_tables_kernel(double *__restrict__ stats, int k, int c, double *sums,
                                                               long long *counts)
 {
+    // (every element is read by exactly one thread, which clears it: the statistics region is left zero, include/pxsom.h)
     for (int e = blockIdx.x * 256 + threadIdx.x; e < k * c + k; e += gridDim.x * 256) {
         if (e < k * c) sums[e] += stats[e];
         else counts[e - k * c] += (long long)stats[e];
+        stats[e] = 0.0;
     }
 }
 
 // the same, OVERWRITING the caller's tables and forming the means (pxsom_assign_means)
-__global__ __launch_bounds__(256) void stats_to_means_kernel(const double *__restrict__ stats, int k, int c, double *sums,
-                                                             long long *counts, double *means)
+__global__ __launch_bounds__(256) void stats_to_means_kernel(double *__restrict__ stats, int k, int c, double *sums,
+                                                             long long *counts, double *means, int *done)
 {
     for (int e = blockIdx.x * 256 + threadIdx.x; e < k * c + k; e += gridDim.x * 256) {
         if (e < k * c) {
@@ -1484,6 +1486,17 @@ __global__ __launch_bounds__(256) void stats_to_means_kernel(const double *__res
         } else {
             counts[e - k * c] = (long long)stats[e];
         }
+    }
+    // the counts are read by the threads of the sums too: the region is cleared by the LAST workgroup to finish (a ticket in the
+    // word behind the statistics), so that it is left zero (include/pxsom.h)
+    __shared__ int s_last;
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (s_last) {
+        for (int e = threadIdx.x; e < k * c + k; e += 256) stats[e] = 0.0;
+        if (threadIdx.x == 0) *done = 0;
     }
 }
 __global__ __launch_bounds__(256) void tables_to_means_kernel(const double *__restrict__ sums, const long long *__restrict__ counts,
@@ -1496,16 +1509,30 @@ __global__ __launch_bounds__(256) void tables_to_means_kernel(const double *__re
 }
 }  // namespace
 
+PXSOM_EXPORT size_t pxsom_assign_sums_scratch_bytes(int c, int k)
+{
+    if (c < 1 || c > PXSOM_MAX_CHANNELS || k < 1 || k > PXSOM_MAX_NODES) return 0;
+    return pxsom::align_up((size_t)k * (c + 1) * sizeof(double), 256) + 256;
+}
+
 PXSOM_EXPORT size_t pxsom_assign_sums_workspace_bytes(int64_t n, int c, int k)
 {
     const size_t a = pxsom_assign_workspace_bytes(n, c, k);
-    // (+ 256: the ticket word of the launch that finishes the tables itself, pxsom_bmu::FinishTables)
-    return a ? pxsom::align_up(a, 256) + pxsom::align_up((size_t)k * (c + 1) * sizeof(double), 256) + 256 : 0;
+    // [statistics | 256 bytes: the ticket word of the launch that finishes the tables itself] [assign workspace]: the statistics
+    // region sits at the START, where it does not move with n (pxsom_assign_sums_scratch_bytes)
+    return a ? pxsom_assign_sums_scratch_bytes(c, k) + pxsom::align_up(a, 256) : 0;
 }
 
 PXSOM_EXPORT int pxsom_assign_sums(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev, int k,
                                    int32_t *labels_dev, double *sums_dev, int64_t *counts_dev, void *workspace_dev,
                                    size_t workspace_bytes, void *stream)
+{
+    return pxsom_assign_sums_ex(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, sums_dev, counts_dev, workspace_dev, workspace_bytes, 0, stream);
+}
+
+PXSOM_EXPORT int pxsom_assign_sums_ex(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev, int k,
+                                      int32_t *labels_dev, double *sums_dev, int64_t *counts_dev, void *workspace_dev,
+                                      size_t workspace_bytes, int flags, void *stream)
 {
     int rc = check_matrix("pxsom_assign_sums", x_dev, n, c, ldx, dtype);
     if (rc) return rc;
@@ -1518,26 +1545,27 @@ PXSOM_EXPORT int pxsom_assign_sums(const void *x_dev, int64_t n, int c, int64_t 
         return pxsom::fail(PXSOM_ERR_WORKSPACE, "pxsom_assign_sums: workspace %zu < %zu bytes", workspace_bytes, need);
     if (n == 0) return PXSOM_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const size_t assign_ws = pxsom::align_up(pxsom_assign_workspace_bytes(n, c, k), 256);
-    double *scratch = reinterpret_cast<double *>(reinterpret_cast<char *>(workspace_dev) + assign_ws);
-    const size_t stats_bytes = pxsom::align_up((size_t)k * (c + 1) * sizeof(double), 256);
-    PXSOM_HIP_TRY(hipMemsetAsync(scratch, 0, stats_bytes + 256, st));   // statistics + the finishing launch's ticket
+    const size_t scratch_bytes = pxsom_assign_sums_scratch_bytes(c, k), stats_bytes = scratch_bytes - 256;
+    double *scratch = reinterpret_cast<double *>(workspace_dev);
+    void *assign_dev = reinterpret_cast<char *>(workspace_dev) + scratch_bytes;
+    const size_t assign_ws = workspace_bytes - scratch_bytes;
+    if (!(flags & PXSOM_TABLES_SCRATCH_CLEAN)) PXSOM_HIP_TRY(hipMemsetAsync(scratch, 0, scratch_bytes, st));   // statistics + ticket
     bool fused = false;
     pxsom_bmu::FinishTables fin;
     fin.sums = sums_dev;
     fin.counts = reinterpret_cast<long long *>(counts_dev);
     fin.ticket = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(scratch) + stats_bytes);
-    rc = pxsom_bmu::assign_accumulate(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, scratch, workspace_dev, assign_ws, st,
+    rc = pxsom_bmu::assign_accumulate(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, scratch, assign_dev, assign_ws, st,
                                       &fused, &fin);
     if (rc) return rc;
-    if (fused && fin.done) return PXSOM_OK;   // the last workgroup of the launch added the statistics into the tables
+    if (fused && fin.done) return PXSOM_OK;   // the last workgroup of the launch added the statistics into the tables (and cleared them)
     if (fused) {
         hipLaunchKernelGGL(stats_to_tables_kernel, dim3((k * (c + 1) + 255) / 256), dim3(256), 0, st, scratch, k, c, sums_dev,
                            reinterpret_cast<long long *>(counts_dev));
         PXSOM_LAUNCH_CHECK("stats_to_tables_kernel");
         return PXSOM_OK;
     }
-    rc = pxsom_assign(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, nullptr, workspace_dev, assign_ws, stream);
+    rc = pxsom_assign(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, nullptr, assign_dev, assign_ws, stream);
     if (rc) return rc;
     return pxsom_cluster_sums(x_dev, n, c, ldx, dtype, labels_dev, k, sums_dev, counts_dev, stream);
 }
@@ -1545,6 +1573,14 @@ PXSOM_EXPORT int pxsom_assign_sums(const void *x_dev, int64_t n, int c, int64_t 
 PXSOM_EXPORT int pxsom_assign_means(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev, int k,
                                     int32_t *labels_dev, double *sums_dev, int64_t *counts_dev, double *means_dev,
                                     void *workspace_dev, size_t workspace_bytes, void *stream)
+{
+    return pxsom_assign_means_ex(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, sums_dev, counts_dev, means_dev, workspace_dev,
+                                 workspace_bytes, 0, stream);
+}
+
+PXSOM_EXPORT int pxsom_assign_means_ex(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev, int k,
+                                       int32_t *labels_dev, double *sums_dev, int64_t *counts_dev, double *means_dev,
+                                       void *workspace_dev, size_t workspace_bytes, int flags, void *stream)
 {
     int rc = check_matrix("pxsom_assign_means", x_dev, n, c, ldx, dtype);
     if (rc) return rc;
@@ -1556,11 +1592,12 @@ PXSOM_EXPORT int pxsom_assign_means(const void *x_dev, int64_t n, int c, int64_t
     if (!workspace_dev || workspace_bytes < need)
         return pxsom::fail(PXSOM_ERR_WORKSPACE, "pxsom_assign_means: workspace %zu < %zu bytes", workspace_bytes, need);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const size_t assign_ws = pxsom::align_up(pxsom_assign_workspace_bytes(n, c, k), 256);
-    double *scratch = reinterpret_cast<double *>(reinterpret_cast<char *>(workspace_dev) + assign_ws);
+    const size_t scratch_bytes = pxsom_assign_sums_scratch_bytes(c, k), stats_bytes = scratch_bytes - 256;
+    double *scratch = reinterpret_cast<double *>(workspace_dev);
+    void *assign_dev = reinterpret_cast<char *>(workspace_dev) + scratch_bytes;
+    const size_t assign_ws = workspace_bytes - scratch_bytes;
     const unsigned fgrid = (unsigned)((k * (c + 1) + 255) / 256);
-    const size_t stats_bytes = pxsom::align_up((size_t)k * (c + 1) * sizeof(double), 256);
-    PXSOM_HIP_TRY(hipMemsetAsync(scratch, 0, stats_bytes + 256, st));   // statistics + the finishing launch's ticket
+    if (!(flags & PXSOM_TABLES_SCRATCH_CLEAN)) PXSOM_HIP_TRY(hipMemsetAsync(scratch, 0, scratch_bytes, st));   // statistics + ticket
     bool fused = false;
     pxsom_bmu::FinishTables fin;
     fin.sums = sums_dev;
@@ -1569,20 +1606,20 @@ PXSOM_EXPORT int pxsom_assign_means(const void *x_dev, int64_t n, int c, int64_t
     fin.overwrite = 1;
     fin.ticket = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(scratch) + stats_bytes);
     if (n > 0) {
-        rc = pxsom_bmu::assign_accumulate(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, scratch, workspace_dev, assign_ws, st, &fused,
+        rc = pxsom_bmu::assign_accumulate(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, scratch, assign_dev, assign_ws, st, &fused,
                                           &fin);
         if (rc) return rc;
     }
-    if (fused && fin.done) return PXSOM_OK;   // the last workgroup of the launch wrote the three tables
+    if (fused && fin.done) return PXSOM_OK;   // the last workgroup of the launch wrote the three tables (and cleared the statistics)
     if (fused || n == 0) {   // one launch writes the three tables
         hipLaunchKernelGGL(stats_to_means_kernel, dim3(fgrid), dim3(256), 0, st, scratch, k, c, sums_dev,
-                           reinterpret_cast<long long *>(counts_dev), means_dev);
+                           reinterpret_cast<long long *>(counts_dev), means_dev, reinterpret_cast<int *>(fin.ticket));
         PXSOM_LAUNCH_CHECK("stats_to_means_kernel");
         return PXSOM_OK;
     }
     PXSOM_HIP_TRY(hipMemsetAsync(sums_dev, 0, (size_t)k * c * sizeof(double), st));
     PXSOM_HIP_TRY(hipMemsetAsync(counts_dev, 0, (size_t)k * sizeof(int64_t), st));
-    rc = pxsom_assign(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, nullptr, workspace_dev, assign_ws, stream);
+    rc = pxsom_assign(x_dev, n, c, ldx, dtype, w_dev, k, labels_dev, nullptr, assign_dev, assign_ws, stream);
     if (rc) return rc;
     rc = pxsom_cluster_sums(x_dev, n, c, ldx, dtype, labels_dev, k, sums_dev, counts_dev, stream);
     if (rc || !means_dev) return rc;

@@ -73,7 +73,7 @@ def assign(x: torch.Tensor, w: torch.Tensor, labels: Optional[torch.Tensor] = No
 def last_exact_rows(workspace: AssignWorkspace) -> int:
     import ctypes
     out = ctypes.c_int64(0)
-    _capi.check(_capi.lib().pxsom_assign_last_exact_rows(workspace.buf.data_ptr(), _capi.stream_ptr(),
+    _capi.check(_capi.lib().pxsom_assign_last_exact_rows(workspace.buf.data_ptr() + getattr(workspace, "assign_offset", 0), _capi.stream_ptr(),
                                                          ctypes.byref(out)),
                 "pxsom_assign_last_exact_rows")
     return int(out.value)
@@ -564,10 +564,17 @@ class AssignSumsWorkspace:
         if self.bytes == 0:
             raise _capi.PxsomError(f"unsupported assign shape n={n_max} c={c} k={k}")
         self.n_max, self.c, self.k = int(n_max), int(c), int(k)
-        self.buf = torch.empty(self.bytes, dtype=torch.uint8, device=device)
+        # cleared ONCE: the library leaves the statistics region at its head zero after every successful call, and skips its own
+        # clearing launch while ``clean`` says so (PXSOM_TABLES_SCRATCH_CLEAN); a failed call drops the promise
+        self.buf = torch.zeros(self.bytes, dtype=torch.uint8, device=device)
+        self.clean = True
+        self.assign_offset = int(_capi.lib().pxsom_assign_sums_scratch_bytes(int(c), int(k)))   # where the assign workspace begins
 
     def fits(self, n: int, c: int, k: int) -> bool:
         return c == self.c and k == self.k and n <= self.n_max
+
+
+TABLES_SCRATCH_CLEAN = 1  # include/pxsom.h PXSOM_TABLES_SCRATCH_CLEAN
 
 
 def assign_sums(x: torch.Tensor, w: torch.Tensor, labels: Optional[torch.Tensor] = None,
@@ -586,9 +593,11 @@ def assign_sums(x: torch.Tensor, w: torch.Tensor, labels: Optional[torch.Tensor]
         counts = torch.zeros(k, dtype=torch.int64, device=x.device)
     if workspace is None or not workspace.fits(n, c, k):
         workspace = AssignSumsWorkspace(n, c, k, x.device)
-    rc = _capi.lib().pxsom_assign_sums(x.data_ptr(), n, c, ldx, dt, w.data_ptr(), k, labels.data_ptr(), sums.data_ptr(),
-                                       counts.data_ptr(), workspace.buf.data_ptr(), workspace.bytes, _capi.stream_ptr())
-    _capi.check(rc, "pxsom_assign_sums")
+    flags, workspace.clean = (TABLES_SCRATCH_CLEAN if workspace.clean else 0), False
+    rc = _capi.lib().pxsom_assign_sums_ex(x.data_ptr(), n, c, ldx, dt, w.data_ptr(), k, labels.data_ptr(), sums.data_ptr(),
+                                          counts.data_ptr(), workspace.buf.data_ptr(), workspace.bytes, flags, _capi.stream_ptr())
+    _capi.check(rc, "pxsom_assign_sums_ex")
+    workspace.clean = True
     return labels, sums, counts
 
 
@@ -601,7 +610,9 @@ def assign_means(x: torch.Tensor, w: torch.Tensor, labels: torch.Tensor, sums: t
     k = w.shape[0]
     if not workspace.fits(n, c, k):
         raise ValueError("workspace does not fit this matrix")
-    rc = _capi.lib().pxsom_assign_means(x.data_ptr(), n, c, ldx, dt, w.data_ptr(), k, labels.data_ptr(), sums.data_ptr(),
-                                        counts.data_ptr(), means.data_ptr() if means is not None else None,
-                                        workspace.buf.data_ptr(), workspace.bytes, _capi.stream_ptr())
-    _capi.check(rc, "pxsom_assign_means")
+    flags, workspace.clean = (TABLES_SCRATCH_CLEAN if workspace.clean else 0), False
+    rc = _capi.lib().pxsom_assign_means_ex(x.data_ptr(), n, c, ldx, dt, w.data_ptr(), k, labels.data_ptr(), sums.data_ptr(),
+                                           counts.data_ptr(), means.data_ptr() if means is not None else None,
+                                           workspace.buf.data_ptr(), workspace.bytes, flags, _capi.stream_ptr())
+    _capi.check(rc, "pxsom_assign_means_ex")
+    workspace.clean = True

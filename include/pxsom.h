@@ -128,6 +128,20 @@ int pxsom_cluster_sums(const void *x_dev, int64_t n, int c, int64_t ldx, int dty
  * (>= 2^(16 - e), non-finite) and listed rows bypass the table in binary64.  (ABI 9: the environment switch PXSOM_SUMS_F64 is
  * gone -- the library reads no environment variable; exact binary64 tables: pxsom_assign + pxsom_cluster_sums.) */
 size_t pxsom_assign_sums_workspace_bytes(int64_t n, int c, int k);
+/* ABI 9.  The workspace of pxsom_assign_sums / pxsom_assign_means begins with a statistics region of
+ * pxsom_assign_sums_scratch_bytes(c, k) bytes (it does not move with n); the assign workspace follows it (pass
+ * `workspace + scratch bytes` to pxsom_assign_last_exact_rows).  Every successful call LEAVES THAT REGION ZERO.  The _ex forms take
+ * flags: PXSOM_TABLES_SCRATCH_CLEAN -- the caller vouches that the region is zero on entry (it cleared the workspace once when it
+ * allocated it, and every call since returned PXSOM_OK): the call skips its clearing launch (~6 us in front of a 0.22 ms kernel).
+ * After a failed call, clear the region (or drop the flag once). */
+#define PXSOM_TABLES_SCRATCH_CLEAN 1
+size_t pxsom_assign_sums_scratch_bytes(int c, int k);
+int pxsom_assign_sums_ex(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev, int k,
+                         int32_t *labels_dev, double *sums_dev, int64_t *counts_dev, void *workspace_dev,
+                         size_t workspace_bytes, int flags, void *stream);
+int pxsom_assign_means_ex(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev, int k,
+                          int32_t *labels_dev, double *sums_dev, int64_t *counts_dev, double *means_dev, void *workspace_dev,
+                          size_t workspace_bytes, int flags, void *stream);
 int pxsom_assign_sums(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w_dev, int k,
                       int32_t *labels_dev, double *sums_dev, int64_t *counts_dev, void *workspace_dev,
                       size_t workspace_bytes, void *stream);
