@@ -73,6 +73,8 @@ SYMBOLS = {
     "pxsom_batch_train_sched_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32, _vp, _i32]),
     "pxsom_batch_train_sched": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32,
                                        _f64, _f64, _f64, _f64, _f64, _vp, _sz, _i32, _vp, _vp]),
+    "pxsom_batch_train_sched_from": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32,
+                                            _f64, _f64, _f64, _f64, _f64, _vp, _sz, _i32, _vp, _vp]),
     "pxsom_exact_sum_quantum": (_f64, [_f64, _i64]),
     "pxsom_absmax": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _vp]),
     "pxsom_batch_train_sched_finish": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _f64, _f64, _f64, _f64,

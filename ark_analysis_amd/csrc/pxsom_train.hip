@@ -1847,9 +1847,11 @@ int launch_gather(const T *x, int64_t n, int c, int64_t ldx, T *out, const Sched
 // codebook the run starts from, per channel, in binary32.  Any vector keeps the search exact; this one stays close to the
 // nodes' mean for the whole run (they follow the data), so the steps need no reduction of their own for it.
 __global__ __launch_bounds__(256) void centring_vector_kernel(const double *__restrict__ w, int k, int c, float *__restrict__ mu32,
-                                                              double *__restrict__ zero_out, int zero_count)
+                                                              double *__restrict__ zero_out, int zero_count, double *__restrict__ copy_out)
 {
     for (int e = threadIdx.x; e < zero_count; e += 256) zero_out[e] = 0.0;   // the first step's statistics buffer (no memset launch)
+    if (copy_out)   // W_0 handed over by the caller: into the run's codebook buffer (no copy launch in front of the pass)
+        for (int e = threadIdx.x; e < k * c; e += 256) copy_out[e] = w[e];
     // `parts` adjacent lanes share a channel (8 for c <= 32, 2 for c <= 128): each sums every parts-th node with its loads in
     // flight eight at a time -- a lane walking 50 nodes one L2 round trip after the other made this launch 16 us
     const int cp = c <= 32 ? 32 : (c <= 64 ? 64 : 128), parts = 256 / cp;
@@ -1905,7 +1907,8 @@ namespace {
 template <typename T>
 int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, double *wbuf, double *ring, int xdim,
                       int ydim, const Sched &sc, int g_begin, int g_end, int num_passes, double a0, double a1, double r0,
-                      double r1, double sum_quantum, char *ws, size_t ws_bytes, int flags, pxsom_comm *comm, hipStream_t st)
+                      double r1, double sum_quantum, char *ws, size_t ws_bytes, int flags, pxsom_comm *comm, hipStream_t st,
+                      const double *w0 = nullptr)
 {
     // binary64 rows of a reproducible run: (v + qmagic) - qmagic rounds v to a multiple of the quantum
     const double qmagic = (sizeof(T) == 8 && sum_quantum > 0.0) ? 6755399441055744.0 /* 1.5 * 2^52 */ * sum_quantum : 0.0;
@@ -1925,10 +1928,13 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
     // rows of 2-byte floats on the generic route keep the uncentred two-term split (pxsom_assign_filter.hip)
     const bool centred_run = fused_shape || (sizeof(T) != 2 && c <= pxsom_bmu::kFilterMaxChannels && !(flags & PXSOM_TRAIN_UNFUSED));
     if (g_begin == 0) {   // the first step's statistics buffer; every later one is cleared by the step before it
+        // (w0: the codebook the run starts from, where the caller holds it -- copied into wbuf[0] by the launch that is there anyway)
         if (centred_run) {
-            hipLaunchKernelGGL(centring_vector_kernel, dim3(1), dim3(256), 0, st, wbuf, k, c, mu32, ring, (int)nstats);
+            hipLaunchKernelGGL(centring_vector_kernel, dim3(1), dim3(256), 0, st, w0 ? w0 : wbuf, k, c, mu32, ring, (int)nstats,
+                               w0 ? wbuf : (double *)nullptr);
             PXSOM_LAUNCH_CHECK("centring_vector_kernel");
         } else {
+            if (w0) PXSOM_HIP_TRY(hipMemcpyAsync(wbuf, w0, nw * sizeof(double), hipMemcpyDeviceToDevice, st));
             PXSOM_HIP_TRY(hipMemsetAsync(ring, 0, nstats * sizeof(double), st));
         }
     }
@@ -2115,6 +2121,17 @@ PXSOM_EXPORT int pxsom_batch_train_sched(const void *x_dev, int64_t n, int c, in
                                          double r0, double r1, double sum_quantum, void *workspace_dev, size_t workspace_bytes,
                                          int flags, pxsom_comm *comm, void *stream)
 {
+    return pxsom_batch_train_sched_from(x_dev, n, c, ldx, dtype, nullptr, wbuf_dev, stats_ring_dev, xdim, ydim, phases, edges, steps_per_pass,
+                                        g_begin, g_end, num_passes, a0, a1, r0, r1, sum_quantum, workspace_dev, workspace_bytes, flags, comm,
+                                        stream);
+}
+
+PXSOM_EXPORT int pxsom_batch_train_sched_from(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w0_dev,
+                                              double *wbuf_dev, double *stats_ring_dev, int xdim, int ydim, int phases,
+                                              const int32_t *edges, int steps_per_pass, int g_begin, int g_end, int num_passes,
+                                              double a0, double a1, double r0, double r1, double sum_quantum, void *workspace_dev,
+                                              size_t workspace_bytes, int flags, pxsom_comm *comm, void *stream)
+{
     int rc = check_matrix("pxsom_batch_train_sched", x_dev, n, c, ldx, dtype);
     if (rc) return rc;
     {
@@ -2139,7 +2156,7 @@ PXSOM_EXPORT int pxsom_batch_train_sched(const void *x_dev, int64_t n, int c, in
     PXSOM_DISPATCH_DTYPE(dtype, x_dev, xp,
                          train_steps_typed<T>(xp, n, c, ldx, dtype, wbuf_dev, stats_ring_dev, xdim, ydim, sc, g_begin, g_end,
                                               num_passes, a0, a1, r0, r1, sum_quantum, reinterpret_cast<char *>(workspace_dev),
-                                              workspace_bytes, flags, comm, st));
+                                              workspace_bytes, flags, comm, st, g_begin == 0 ? w0_dev : nullptr));
 }
 
 PXSOM_EXPORT int pxsom_batch_train_steps(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, double *wbuf_dev,

@@ -65,7 +65,11 @@ class HipKernels:
         if st is None or not st.fits(n, c, xdim, ydim, schedule, x.dtype) or st.wbuf.device != x.device:
             st = self._state = self._sd.BatchTrainState(n, c, xdim, ydim, schedule, x.device, dtype=x.dtype)
             self._rings = [st.ring[i] for i in range(3)]     # views made once: ring(g) sits in the per-step loop
-        st.wbuf[0].copy_(w)
+        # W_0 stays where the caller holds it: the first run of steps hands it to the library, whose preparing launch copies it into
+        # the state (no copy launch in front of the pass)
+        self._w0 = w if (w.is_cuda and w.dtype == torch.float64 and w.is_contiguous()) else None
+        if self._w0 is None:
+            st.wbuf[0].copy_(w)
         st.quantum = float(quantum)
         # The route (one-launch fused step / launch per phase) is a collective decision: a rank with an oddly aligned or
         # empty shard must not part ways with the others.
@@ -91,7 +95,7 @@ class HipKernels:
 
     def steps(self, x, g0: int, g1: int, total: int, alpha_range, radius_range, comm=None) -> None:
         self._sd.batch_train_steps(x, self._state, g0, g1, total, alpha_range, radius_range,
-                                   unfused=self._unfused_now, comm=comm)
+                                   unfused=self._unfused_now, comm=comm, w0=self._w0 if g0 == 0 else None)
 
     def exchange(self, group=None):
         """The in-library exchange over ``group`` (an RCCL communicator owned by libpxsom, made once per process

@@ -152,24 +152,31 @@ def batch_train_fused_route(x: torch.Tensor, xdim: int, ydim: int, schedule) -> 
 
 
 def batch_train_steps(x: torch.Tensor, state: BatchTrainState, g_begin: int, g_end: int, total_steps: int,
-                      alpha_range, radius_range, unfused: bool = False, comm: "RankComm" = None) -> None:
+                      alpha_range, radius_range, unfused: bool = False, comm: "RankComm" = None,
+                      w0: Optional[torch.Tensor] = None) -> None:
     """Mini-batch steps [g_begin, g_end) of a batch training run of ``total_steps`` = passes x steps per pass, launched
     back to back by the library (``state.wbuf[0]`` holds W_0 before step 0; see include/pxsom.h).  ``comm``: the
     statistics of every step are sum-all-reduced over its ranks right behind the step's launch (every rank makes the
-    same call)."""
+    same call).  ``w0`` (with ``g_begin == 0``): the run's first codebook where the caller holds it -- the launch that prepares the
+    run copies it into ``state.wbuf[0]`` (pxsom_batch_train_sched_from: no copy launch in front of the pass)."""
     n, c, ldx, dt = _matrix_args(x)
+    if w0 is not None:
+        w0 = _codebook(w0)
+        if tuple(w0.shape) != (state.xdim * state.ydim, c):
+            raise ValueError("w0 does not match the state's codebook")
     if not state.fits(n, c, state.xdim, state.ydim, state.schedule, x.dtype):
         raise ValueError("batch-training state does not fit this matrix")
     sch = state.schedule
     if int(total_steps) % sch.steps:
         raise ValueError("total_steps must be a whole number of passes")
-    rc = _capi.lib().pxsom_batch_train_sched(
-        x.data_ptr(), n, c, ldx, dt, state.wbuf.data_ptr(), state.ring.data_ptr(), state.xdim, state.ydim,
+    rc = _capi.lib().pxsom_batch_train_sched_from(
+        x.data_ptr(), n, c, ldx, dt, w0.data_ptr() if (w0 is not None and int(g_begin) == 0) else None,
+        state.wbuf.data_ptr(), state.ring.data_ptr(), state.xdim, state.ydim,
         sch.phases, state.edges.ctypes.data, sch.steps, int(g_begin), int(g_end), int(total_steps) // sch.steps,
         float(alpha_range[0]), float(alpha_range[1]), float(radius_range[0]), float(radius_range[1]), float(state.quantum),
         state.ws.data_ptr(), state.ws_bytes, TRAIN_UNFUSED if unfused else 0,
         comm.handle if comm is not None else None, _capi.stream_ptr())
-    _capi.check(rc, "pxsom_batch_train_sched")
+    _capi.check(rc, "pxsom_batch_train_sched_from")
 
 
 COMM_ID_BYTES = 128  # include/pxsom.h PXSOM_COMM_ID_BYTES

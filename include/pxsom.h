@@ -276,6 +276,14 @@ int pxsom_batch_train_sched(const void *x_dev, int64_t n, int c, int64_t ldx, in
                             int steps_per_pass, int g_begin, int g_end, int num_passes, double a0, double a1, double r0,
                             double r1, double sum_quantum, void *workspace_dev, size_t workspace_bytes, int flags,
                             pxsom_comm *comm, void *stream);
+/* The same with the run's first codebook W_0 handed over where the caller holds it (ABI 9): w0_dev [k, c] or NULL.  With g_begin
+ * == 0 the launch that prepares the run copies it into wbuf_dev[0] itself -- no copy launch in front of a pass of 22 short steps;
+ * w0_dev may be the buffer pxsom_batch_train_sched_finish later writes into.  Ignored when g_begin > 0. */
+int pxsom_batch_train_sched_from(const void *x_dev, int64_t n, int c, int64_t ldx, int dtype, const double *w0_dev, double *wbuf_dev,
+                                 double *stats_ring_dev, int xdim, int ydim, int phases, const int32_t *edges_host,
+                                 int steps_per_pass, int g_begin, int g_end, int num_passes, double a0, double a1, double r0,
+                                 double r1, double sum_quantum, void *workspace_dev, size_t workspace_bytes, int flags,
+                                 pxsom_comm *comm, void *stream);
 int pxsom_batch_train_sched_finish(const double *wbuf_dev, const double *stats_ring_dev, int xdim, int ydim, int c,
                                    int phases, const int32_t *edges_host, int steps_per_pass, int steps_done,
                                    int num_passes, double a0, double a1, double r0, double r1, double *w_out_dev,
