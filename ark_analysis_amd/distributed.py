@@ -156,8 +156,13 @@ class BatchSOMTrainer:
         widest = max(b - a for a, b in zip(self.schedule.edges, self.schedule.edges[1:]))
         return som_device.exact_sum_quantum(vmax, (n_total // self.schedule.phases + world) * max(widest, 1))
 
-    def train(self, x_local: torch.Tensor, w: torch.Tensor, num_passes: int = 1) -> torch.Tensor:
-        """Runs num_passes passes in place on ``w`` [K, C] f64 (identical on every rank)."""
+    def train(self, x_local: torch.Tensor, w: torch.Tensor, num_passes: int = 1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Runs num_passes passes from ``w`` [K, C] f64 (identical on every rank); the result replaces ``w``, or goes to ``out``
+        (same shape and dtype; ``w`` then keeps the first codebook -- a caller that trains from the same start again needs no copy)."""
+        w_first = w
+        if out is not None:
+            if tuple(out.shape) != tuple(w.shape) or out.dtype != w.dtype or out.device != w.device:
+                raise ValueError("out does not match the codebook")
         if self._default_schedule:
             # The two-phase default deals the rows into 960 phases: with fewer than a few rows per phase its tail steps hold
             # next to nothing (below 960 rows: nothing at all, and the rows past index 800 would never be presented).  Small
@@ -175,6 +180,9 @@ class BatchSOMTrainer:
                 self.schedule, self.batch_steps = want, want.steps
         total = int(num_passes) * self.batch_steps
         if total < 1:
+            if out is not None:
+                out.copy_(w)
+                return out
             return w
         if x_local.shape[1] != self.c or tuple(w.shape) != (self.k, self.c):
             raise ValueError(f"matrix [{tuple(x_local.shape)}] / codebook [{tuple(w.shape)}] do not match "
@@ -204,6 +212,7 @@ class BatchSOMTrainer:
                     all_reduce_(kern.ring(g), group=self.group)
         else:
             kern.steps(x_local, 0, total, total, self.alpha_range, self.radius_range)
+        w = w_first if out is None else out
         kern.finish(total, total, self.alpha_range, self.radius_range, w)
         if _world(self.group) > 1:
             # every rank applied the same all-reduced statistics, so the replicas are equal already; the broadcast makes
