@@ -71,6 +71,10 @@ __host__ __device__ inline StepLds step_lds(int c)
 // (profiles/r04/step_bmu_only_specialisation.txt).
 // EXCH (round 5): the instantiation for ranks of a sharded run on a peer-to-peer communicator -- the rule's exchange runs inside
 // the launch (StepArgs::xch_*): no all-reduce launch between two steps.
+#ifdef PXSOM_STEP_COUNT_LISTED   // (counting build only, scripts/dev/listed_per_step.py: rows each launch lists for the exact path)
+__device__ unsigned g_dbg_listed[4096], g_dbg_listed_max[4096], g_dbg_rows[4096], g_dbg_launch;
+__global__ void dbg_next_launch() { g_dbg_launch = g_dbg_launch + 1; }
+#endif
 template <typename T, int CPL, int TPW, bool BMU, bool EXCH = false>
 __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__restrict__ x, int64_t n, int c, int64_t ldx,
                                                                   double *__restrict__ stats, StepArgs sa)
@@ -707,6 +711,14 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
     __syncthreads();   // every wave is through its tiles: the queue is complete
     {
         const unsigned queued = hdr->q_n < (unsigned)kQueueRows ? hdr->q_n : (unsigned)kQueueRows;
+#ifdef PXSOM_STEP_COUNT_LISTED
+        if (tid == 0) {
+            const unsigned slot = *reinterpret_cast<volatile unsigned *>(&g_dbg_launch) & 4095u;
+            atomicAdd(&g_dbg_listed[slot], hdr->q_n);
+            atomicMax(&g_dbg_listed_max[slot], hdr->q_n);
+            if (blockIdx.x == 0) g_dbg_rows[slot] = (unsigned)n;
+        }
+#endif
         for (unsigned i = wv; i < queued; i += kStepWaves)
             exact_row_from_lds(qrows + (size_t)i * c, c, wt, ls + (size_t)(wv & (ncopies - 1)) * tstride, lane, qmagic, cs);
         __syncthreads();
@@ -1180,6 +1192,9 @@ int launch_step(const T *x, int64_t n, int c, int64_t ldx, double *stats, const 
         }
         if (n >= ((int64_t)1 << 31)) return pxsom::fail(PXSOM_ERR_INVALID_ARG, "batch step: %lld rows in one step (limit 2^31)", (long long)n);
     }
+#ifdef PXSOM_STEP_COUNT_LISTED
+    hipLaunchKernelGGL(dbg_next_launch, dim3(1), dim3(1), 0, st);
+#endif
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kStepThreads), lds, st, x, n, c, ldx, stats, sk);
     PXSOM_LAUNCH_CHECK("batch_step_kernel");
     return PXSOM_OK;
@@ -1249,4 +1264,23 @@ PXSOM_INSTANTIATE_STEP(float)
 PXSOM_INSTANTIATE_STEP(double)
 PXSOM_INSTANTIATE_STEP(_Float16)
 
+#ifdef PXSOM_STEP_COUNT_LISTED
+extern "C" __attribute__((visibility("default"))) int pxsom_dbg_listed(unsigned *out, int cap)
+{
+    static unsigned h[3][4096];
+    unsigned nl = 0;
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(&nl, HIP_SYMBOL(g_dbg_launch), 4);
+    (void)hipMemcpyFromSymbol(h[0], HIP_SYMBOL(g_dbg_listed), sizeof(h[0]));
+    (void)hipMemcpyFromSymbol(h[1], HIP_SYMBOL(g_dbg_listed_max), sizeof(h[0]));
+    (void)hipMemcpyFromSymbol(h[2], HIP_SYMBOL(g_dbg_rows), sizeof(h[0]));
+    int m = 0;
+    for (unsigned i = 1; i <= nl && i < 4096 && m + 3 <= cap; i++) {
+        out[m++] = h[2][i];
+        out[m++] = h[0][i];
+        out[m++] = h[1][i];
+    }
+    return m / 3;
+}
+#endif
 }  // namespace pxsom_bmu
