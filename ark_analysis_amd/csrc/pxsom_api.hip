@@ -39,7 +39,7 @@ struct Prof {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     size_t used = 0;
     int64_t min_rows = 0;
-    bool open = false;
+    bool open = false, taken = false;
 };
 
 static thread_local Prof *g_prof = nullptr;
@@ -55,13 +55,23 @@ void prof_mark(Prof *p, hipStream_t st, bool start, int64_t rows)
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
             p->ev.emplace_back(a, b);
         }
-        (void)hipEventRecord(p->ev[p->used].first, st);
-        p->open = true;
+        p->open = true;    // armed: the launch between the two marks takes the pair (prof_take)
+        p->taken = false;
     } else if (p->open) {
-        (void)hipEventRecord(p->ev[p->used].second, st);
-        p->used++;
+        if (p->taken) p->used++;
         p->open = false;
     }
+    (void)st;
+}
+
+bool prof_take(hipEvent_t *start, hipEvent_t *stop)
+{
+    Prof *p = g_prof;
+    if (!p || !p->open || p->taken) return false;
+    *start = p->ev[p->used].first;
+    *stop = p->ev[p->used].second;
+    p->taken = true;
+    return true;
 }
 
 }  // namespace pxsom

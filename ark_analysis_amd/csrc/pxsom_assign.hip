@@ -660,7 +660,7 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
         const int64_t wgrid = std::max<int64_t>(1, std::min<int64_t>((n + 4 * kWideRows - 1) / (4 * kWideRows), (int64_t)wcus * 4));
         pxsom::Prof *wprof = pxsom::current_prof();
         pxsom::prof_mark(wprof, st, true, n);
-        hipLaunchKernelGGL(kern, dim3((unsigned)wgrid), dim3(256), lds, st, x, n, c, ldx, wt, k, labels);
+        PXSOM_TIMED_LAUNCH(kern, dim3((unsigned)wgrid), dim3(256), lds, st, x, n, c, ldx, wt, k, labels);
         pxsom::prof_mark(wprof, st, false, n);
         PXSOM_LAUNCH_CHECK("bmu_wide_kernel");
         if (dist) {

@@ -397,7 +397,7 @@ void launch_fast(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layo
     const int64_t ngroups = (n + 63) / 64;
     int grid = (int)std::min<int64_t>((ngroups + 3) / 4, (int64_t)pxsom::device_cu_count() * bpc);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, x, n, c, ldx,
+    PXSOM_TIMED_LAUNCH(kern, dim3(grid), dim3(256), 0, st, x, n, c, ldx,
                        reinterpret_cast<const half8 *>(ws + L.off_wfrag),
                        reinterpret_cast<const f32x4 *>(ws + L.off_bias), reinterpret_cast<AssignHdr *>(ws),
                        reinterpret_cast<unsigned *>(ws + L.off_list), labels, L.k, (double *)nullptr,
@@ -428,7 +428,7 @@ void launch_filter_variant(const T *x, int64_t n, int c, int64_t ldx, char *ws, 
             }
             int grid = (int)std::min<int64_t>((ngroups + 7) / 8, (int64_t)pxsom::device_cu_count());
             if (grid < 1) grid = 1;
-            hipLaunchKernelGGL(big, dim3(grid), dim3(512), lds, st, x, n, c, ldx,
+            PXSOM_TIMED_LAUNCH(big, dim3(grid), dim3(512), lds, st, x, n, c, ldx,
                                reinterpret_cast<const half8 *>(ws + L.off_wfrag),
                                reinterpret_cast<const f32x4 *>(ws + L.off_bias), reinterpret_cast<AssignHdr *>(ws),
                                reinterpret_cast<unsigned *>(ws + L.off_list), labels);
@@ -451,7 +451,7 @@ void launch_filter_variant(const T *x, int64_t n, int c, int64_t ldx, char *ws, 
     if (lds > 0) blocks_per_cu = std::max(1, std::min<int>(by_regs, (int)((160 * 1024) / lds)));
     int grid = (int)std::min<int64_t>((ngroups + 3) / 4, (int64_t)pxsom::device_cu_count() * blocks_per_cu);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, x, n, c, ldx,
+    PXSOM_TIMED_LAUNCH(kern, dim3(grid), dim3(256), lds, st, x, n, c, ldx,
                        reinterpret_cast<const half8 *>(ws + L.off_wfrag),
                        reinterpret_cast<const f32x4 *>(ws + L.off_bias), reinterpret_cast<AssignHdr *>(ws),
                        reinterpret_cast<unsigned *>(ws + L.off_list), labels);
@@ -724,7 +724,7 @@ void launch_packed(const _Float16 *x, int64_t n, int c, int64_t ldx, char *ws, c
             raised = true;
         }
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((ngroups + 15) / 16, cus));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, st, x, n, c, ldx, wf, bi, hd, al, labels);
+        PXSOM_TIMED_LAUNCH(kern, dim3(grid), dim3(1024), lds, st, x, n, c, ldx, wf, bi, hd, al, labels);
         return;
     }
     if (lds <= 150 * 1024 && lds > 64 * 1024) {          // one workgroup per CU: a big one (two waves per SIMD on one LDS copy)
@@ -736,16 +736,16 @@ void launch_packed(const _Float16 *x, int64_t n, int c, int64_t ldx, char *ws, c
             raised = true;
         }
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((ngroups + 7) / 8, cus));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, x, n, c, ldx, wf, bi, hd, al, labels);
+        PXSOM_TIMED_LAUNCH(kern, dim3(grid), dim3(512), lds, st, x, n, c, ldx, wf, bi, hd, al, labels);
     } else if (lds <= 64 * 1024) {
         auto kern = bmu_filter_packed_kernel<NPK, 4, true, 256>;
         const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / lds)));
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((ngroups + 3) / 4, (int64_t)cus * per_cu));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, x, n, c, ldx, wf, bi, hd, al, labels);
+        PXSOM_TIMED_LAUNCH(kern, dim3(grid), dim3(256), lds, st, x, n, c, ldx, wf, bi, hd, al, labels);
     } else {                                              // fragments from L1 / L2
         auto kern = bmu_filter_packed_kernel<NPK, 4, false, 256>;
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((ngroups + 3) / 4, (int64_t)cus * 2));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, x, n, c, ldx, wf, bi, hd, al, labels);
+        PXSOM_TIMED_LAUNCH(kern, dim3(grid), dim3(256), 0, st, x, n, c, ldx, wf, bi, hd, al, labels);
     }
 }
 

@@ -48,7 +48,7 @@ void launch_acc(const T *x, int64_t n, int c, int64_t ldx, char *ws, const Layou
         const int64_t rows_wg = ((ngroups + (int64_t)grid * kWaves - 1) / ((int64_t)grid * kWaves)) * (64 * kWaves) + 64;
         while (((int64_t)1 << fix_rows_log2) < rows_wg) fix_rows_log2++;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, x, n, c, ldx,
+    PXSOM_TIMED_LAUNCH(kern, dim3(grid), dim3(kThreads), lds, st, x, n, c, ldx,
                        reinterpret_cast<const half8 *>(ws + L.off_wfrag),
                        reinterpret_cast<const f32x4 *>(ws + L.off_bias), reinterpret_cast<AssignHdr *>(ws),
                        reinterpret_cast<unsigned *>(ws + L.off_list), labels, L.k, stats, w, L.idx_bits, L.node_bits,
@@ -81,7 +81,7 @@ void launch_onepass(const T *x, int64_t n, int c, int64_t ldx, const Layout &L, 
         const int64_t rows_wg = ((nunits + (int64_t)grid * kWaves - 1) / ((int64_t)grid * kWaves)) * (32 * kWaves) + 32;
         while (((int64_t)1 << fix_rows_log2) < rows_wg) fix_rows_log2++;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, x, n, c, ldx, labels, L.k, stats, w, L.idx_bits, L.node_bits,
+    PXSOM_TIMED_LAUNCH(kern, dim3(grid), dim3(kThreads), lds, st, x, n, c, ldx, labels, L.k, stats, w, L.idx_bits, L.node_bits,
                        fix_rows_log2);
 }
 

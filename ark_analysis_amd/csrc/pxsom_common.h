@@ -1,6 +1,7 @@
 // pxsom_common.h -- shared host-side plumbing for libpxsom.so (gfx950 only; no other target).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdint>
@@ -79,5 +80,18 @@ struct PerDevice {
 struct Prof;
 Prof *current_prof();
 void prof_mark(Prof *p, hipStream_t st, bool start, int64_t rows);
+// Round 6: the timer's event pair rides ON the dispatch it times (hipExtLaunchKernelGGL's start / stop events: the kernel's own
+// begin and end, what rocprofv3's kernel trace reports) instead of in two marker packets around it -- those made the stream wait
+// at both ends of the launch (~8 us around a 0.21 ms kernel, inside the bench's timed region).  prof_mark(start) arms the pair,
+// the launch between the two marks takes it with PXSOM_TIMED_LAUNCH, prof_mark(end) counts it if it was taken.
+bool prof_take(hipEvent_t *start, hipEvent_t *stop);
+#define PXSOM_TIMED_LAUNCH(kern, grid, block, lds, st, ...)                                           \
+    do {                                                                                              \
+        hipEvent_t pxsom_e0_, pxsom_e1_;                                                              \
+        if (pxsom::prof_take(&pxsom_e0_, &pxsom_e1_))                                                 \
+            hipExtLaunchKernelGGL(kern, grid, block, lds, st, pxsom_e0_, pxsom_e1_, 0, __VA_ARGS__);  \
+        else                                                                                          \
+            hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                              \
+    } while (0)
 
 }  // namespace pxsom
