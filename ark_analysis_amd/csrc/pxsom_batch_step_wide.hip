@@ -4,21 +4,23 @@
 // grid other than 10 x 10, pixel_som_clustering.py:16-21).
 //
 // Which steps: those whose pending update has its threshold pinned at 0.5 -- a node's window is the node itself, so the grid's
-// shape does not enter -- and that are small enough for their statistics to go to HBM with one device-scope atomic per value
-// (<= kWideMaxRows rows).  On the default schedule these are the 16 steps of the tail, each of which otherwise costs four or
+// shape does not enter -- and that are small enough for their statistics to go to HBM with one device-scope atomic per value and
+// workgroup (<= kWideMaxRows rows: every workgroup meets one block of rows).  On the default schedule these are the 16 steps of the tail, each of which otherwise costs four or
 // five dependent launches (update + prepare, search, exact, screened exact, sums: ~78 us on config 4 against ~25 us of work).
 //
-// A workgroup (512 threads) takes 64 rows, each of its first four waves one 16-row tile:
-//   P0  requests: the counts and sums of step g-1, W_{g-1};
+// A workgroup (512 threads) takes 128 rows, each of its eight waves a 16-row tile (round 6; 64 rows on four waves before):
+//   P0  requests: the workgroup's rows (HBM: slowest, used last), the counts and sums of step g-1, W_{g-1};
 //   P1  the pending update, element-wise and coalesced, in the arithmetic of orc_som_batch_sched (gain = batch_gain(den, 1 - alpha), mean =
 //       S (1/den), w + gain (mean - w), no contraction); W_g into LDS (row stride padded to an odd number of words), workgroup 0
 //       writes it to HBM;
 //   P2  centred norms, maxima, the power-of-two scale, A-fragments (binary16 hi / lo of (W - mu) scale) and biases in LDS;
 //   P3  search: the K7 filter on v_mfma_f32_16x16x32_f16 with the three-term split, top-2 with the node id in the low mantissa
-//       bits, rigorous tolerance (pxsom_assign_filter_fast.h); a row the filter vouches for adds itself to the step's statistics
-//       in HBM, the others wait in a queue;
+//       bits, rigorous tolerance (pxsom_assign_filter_fast.h); a row the filter vouches for has its label, the others wait in a
+//       queue;
 //   P4  the queue is settled by whichever wave is free, exactly as the oracle does (binary64, j ascending, no contraction, sqrt,
-//       first strict minimum) against the LDS copy of W_g;
+//       first strict minimum) against the LDS copy of W_g: the rest of the labels;
+//   P5  the rows join the step's statistics in HBM a RUN OF EQUAL LABELS at a time: labels sorted in LDS, a run's rows summed in
+//       registers, one device-scope atomic per (run, channel);
 //   and every workgroup clears its share of the next step's statistics buffer.
 // Equal nodes need no special case: their scores tie, the row is listed, the exact path takes the first of them.
 #include <algorithm>
@@ -30,17 +32,29 @@
 #include "pxsom_assign_filter_fast.h"
 #include "pxsom_wave.h"
 
+#ifndef PXSOM_WIDE_ABL   // timing builds only (results wrong): 1 no statistics of vouched rows, 2 no listed rows, 4 no search at all,
+#define PXSOM_WIDE_ABL 0   // 8 no fragments / biases, 16 no norms
+#endif
+
 namespace pxsom_bmu {
 namespace {
 
-// (a workgroup's listed rows are settled by all eight waves, a row at a time: four search tiles per workgroup, not eight, keep
-// that tail short and spread a small step over twice as many CUs)
-constexpr int kWideThreads = 512, kWideWaves = 8, kWideSearchWaves = 4, kWideRowsPerWg = kWideSearchWaves * 16;
-constexpr int64_t kWideMaxRows = 16384;   // (beyond: the launch-per-phase route's LDS tables beat one atomic per value)
+// Round 6: a workgroup takes 128 rows (eight 16-row tiles) and adds them to the step's statistics ONE VALUE PER RUN OF EQUAL
+// LABELS AND CHANNEL, not one per (row, channel): the rows' labels -- the filter's and the exact path's alike -- are sorted by
+// label in LDS (a counting sort of 128 small integers), each wave takes an eighth of the sorted rows (lanes <-> channels, all its
+// rows requested at once from L2: the tile was just read), sums runs of equal labels in registers and issues a run's atomics
+// when the label changes.  With 64 rows per workgroup and one atomic per value a tail step of config 4 (8 333 rows x 100
+// columns) issued 842 K device-scope atomics and waited 27 of its 58 us for them (timing builds, profiles/r06/experiments.txt).
+constexpr int kWideThreads = 512, kWideWaves = 8, kWideRounds = 1, kWideRowsPerWg = kWideRounds * kWideWaves * 16;
+#ifndef PXSOM_WIDE_MAX_ROWS
+#define PXSOM_WIDE_MAX_ROWS 65536
+#endif
+constexpr int64_t kWideMaxRows = PXSOM_WIDE_MAX_ROWS;   // (beyond: a workgroup meets several blocks of rows, each with atomics of its own: the launch-per-phase route's LDS tables win)
 constexpr int kWideMaxNodes = 256;
 
 struct WideShape {
     int nb, nch, cpl, cs, kp;   // kp: k rounded up to a multiple of 64 (per-node arrays, node slots of the exact path)
+    unsigned cmagic;            // ceil(2^32 / c): e / c == __umulhi(e, cmagic) for e < 2^32 / c (element indices stay below 2^15 c)
     size_t off_frag, off_bias, off_misc, total;
 };
 inline WideShape wide_shape(int c, int k)
@@ -51,18 +65,21 @@ inline WideShape wide_shape(int c, int k)
     s.cpl = (c + 4 * s.nch - 1) / (4 * s.nch);
     s.cs = (c + 1) | 1;   // W_g row stride, words: odd, and wide enough for [c sums | count] rows while the window sums are formed
     s.kp = (k + 63) & ~63;
+    s.cmagic = (unsigned)((0x100000000ull + (unsigned long long)c - 1ull) / (unsigned long long)c);
     s.off_frag = pxsom::align_up((size_t)k * s.cs * sizeof(double), 16);
     s.off_bias = s.off_frag + (size_t)s.nb * 2 * s.nch * 64 * sizeof(half8);
     s.off_misc = s.off_bias + (size_t)s.nb * 64 * sizeof(f32x4);
-    // misc: gain[k] | inv[k] | nrm[k] (binary64) | red[3 * waves] | mu_s[128] (binary32) | queue[128] (int64) | control words
+    // misc: gain[k] | inv[k] | nrm[k] (binary64; after the fragments: the sort's counters, offsets and order) | red[3 * waves] |
+    // mu_s[128] (binary32) | labels[rows] (int) | queue[rows] (unsigned short) | control words
     s.total = s.off_misc + (size_t)(3 * s.kp + 3 * kWideWaves) * sizeof(double) + 128 * sizeof(float) +
-              kWideRowsPerWg * (sizeof(long long) + sizeof(int)) + 64;
+              kWideRowsPerWg * (sizeof(int) + sizeof(unsigned short)) + 64;
     return s;
 }
 
 struct WideCtl {
     unsigned q_n;
     int bad;
+    int sorted_n;   // rows with a label in this block
 };
 
 template <typename T>
@@ -76,11 +93,11 @@ __device__ __forceinline__ double wide_value(T v, double qmagic)
 // Listed rows settled by a whole wave, TWO at a time (their chains run side by side and share every codebook value read from
 // LDS): lanes <-> nodes lane, lane + 64, ... (k <= 256), a row's channels held by the lanes (lane l: channels l and l + 64) and
 // broadcast with v_readlane, W_g from LDS (row stride cs, odd: no bank conflicts between the lanes' nodes), distances exactly
-// as the oracle forms them (binary64, j ascending, no contraction, sqrt, first strict minimum).  The winner takes the row into
-// the step's statistics.
+// as the oracle forms them (binary64, j ascending, no contraction, sqrt, first strict minimum).  The winners (or -2: no finite
+// distance, a NaN row -- not accumulated, as in the oracle) go to *win0 / *win1.
 template <typename T, int NS>   // NS: node slots per lane (k <= 64 NS)
 __device__ __forceinline__ void wide_exact_rows(const T *xr0, const T *xr1, bool two, int c, int k, const double *wl, int cs, int lane,
-                                                double qmagic, double *stats)
+                                                int *win0, int *win1)
 {
     const double xa0 = lane < c ? (double)xr0[lane] : 0.0, xb0 = lane + 64 < c ? (double)xr0[lane + 64] : 0.0;
     const double xa1 = lane < c ? (double)xr1[lane] : 0.0, xb1 = lane + 64 < c ? (double)xr1[lane + 64] : 0.0;
@@ -122,7 +139,7 @@ __device__ __forceinline__ void wide_exact_rows(const T *xr0, const T *xr1, bool
     };
     span(0, c < 64 ? c : 64, xa0, xa1, 0);
     if (c > 64) span(64, c, xb0, xb1, 64);
-    auto settle = [&](const double *d, const T *xr) {
+    auto settle = [&](const double *d) -> int {
         double best = DBL_MAX;
         int bestk = 0x7fffffff;
 #pragma unroll
@@ -135,17 +152,14 @@ __device__ __forceinline__ void wide_exact_rows(const T *xr0, const T *xr1, bool
         }
         const double smin = pxsom::wave_min_f64(best);
         const int win = (int)pxsom::wave_min_u32(best == smin ? (unsigned)bestk : 0xffffffffu);
-        if (win != 0x7fffffff) {   // 0x7fffffff: no finite distance (NaN row): not accumulated, as in the oracle
-            if (lane < c)
-                __hip_atomic_fetch_add(stats + (size_t)win * c + lane, wide_value<T>(xr[lane], qmagic), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (lane + 64 < c)
-                __hip_atomic_fetch_add(stats + (size_t)win * c + lane + 64, wide_value<T>(xr[lane + 64], qmagic), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-            if (lane == 0) __hip_atomic_fetch_add(stats + (size_t)k * c + win, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        return win != 0x7fffffff ? win : -2;
     };
-    settle(d0, xr0);
-    if (two) settle(d1, xr1);
+    const int w0 = settle(d0);
+    if (lane == 0) *win0 = w0;
+    if (two) {
+        const int w1 = settle(d1);
+        if (lane == 0) *win1 = w1;
+    }
 }
 #pragma clang fp contract(fast)
 
@@ -161,12 +175,32 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
     double *inv_l = gain_l + ws.kp, *nrm_l = inv_l + ws.kp;                               // [kp] each
     double *red = nrm_l + ws.kp;                                                          // [3 waves]
     float *mu_s = reinterpret_cast<float *>(red + 3 * kWideWaves);                        // [128]
-    long long *queue = reinterpret_cast<long long *>(mu_s + 128);                         // [128]
-    int *lab_l = reinterpret_cast<int *>(queue + kWideRowsPerWg);                         // [rows per workgroup]
-    WideCtl *ctl = reinterpret_cast<WideCtl *>(lab_l + kWideRowsPerWg);
+    int *lab_l = reinterpret_cast<int *>(mu_s + 128);                                     // [rows per workgroup]: node, -1 listed, -2 none
+    unsigned short *queue = reinterpret_cast<unsigned short *>(lab_l + kWideRowsPerWg);   // [rows per workgroup]: listed rows (local index)
+    WideCtl *ctl = reinterpret_cast<WideCtl *>(queue + kWideRowsPerWg);
+    // (the sort of the labels reuses the gains' words: dead once W_g is formed)
+    int *hist = reinterpret_cast<int *>(gain_l), *start = hist + ws.kp;                   // [kp] each
+    unsigned short *order = reinterpret_cast<unsigned short *>(inv_l);                    // [rows per workgroup] (kp >= 64 binary64 words)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int cs = ws.cs, nb = ws.nb, cpl = ws.cpl;
     const int kc = k * c;
+    // ---- P0: this workgroup's first block of rows is requested before anything else (HBM; the search is the last to need them).
+    // Lane (q, pix) holds, for chunk h, channels h * 4 cpl + q * cpl + i of row pix of the wave's tile.
+    T raw[1][NCH][8];
+    auto request = [&](int64_t blk) {
+        const int64_t row = blk * kWideRowsPerWg + wv * 16 + (lane & 15);
+        const T *xr = x + (row < n ? row : (n > 0 ? n - 1 : 0)) * ldx;
+#pragma unroll
+        for (int h = 0; h < NCH; h++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int ch = h * 4 * cpl + (lane >> 4) * cpl + i;
+                raw[0][h][i] = xr[(i < cpl && ch < c) ? ch : 0];
+            }
+    };
+    constexpr bool kEarly = sizeof(T) < 8;   // (binary64 rows: 64 registers across the update would spill -- requested before the search)
+    if constexpr (kEarly)
+        if (n > 0 && (int64_t)blockIdx.x * kWideRowsPerWg < n && !(PXSOM_WIDE_ABL & 4)) request(blockIdx.x);
 
     // ---- P0 / P1: the pending update.  Threshold 0.5: a node's window is the node.  Threshold >= 1 (grids up to 16 x 16, k c <=
     // 16 384): the Chebyshev window sums, separably and in the oracle's order (orc_batch_update: per grid row the window's
@@ -190,19 +224,20 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
         __syncthreads();
         {
 #pragma clang fp contract(off)
-        for (int e0 = tid; e0 < kc; e0 += 4 * kWideThreads) {   // four elements' loads in flight per thread
-            double wo[4], sv[4];
+        constexpr int kInFlight = 10;   // elements' loads in flight per thread (100 x 100: two trips instead of five)
+        for (int e0 = tid; e0 < kc; e0 += kInFlight * kWideThreads) {
+            double wo[kInFlight], sv[kInFlight];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < kInFlight; u++) {
                 const int e = e0 + u * kWideThreads < kc ? e0 + u * kWideThreads : 0;
                 wo[u] = sa.w_in[e];
                 sv[u] = sa.has_update ? sa.stats_prev[e] : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < kInFlight; u++) {
                 const int e = e0 + u * kWideThreads;
                 if (e < kc) {
-                    const int node = e / c, j = e - node * c;
+                    const int node = (int)__umulhi((unsigned)e, ws.cmagic), j = e - node * c;
                     const double gain = gain_l[node];
                     double v = wo[u];
                     if (gain >= 0.0) {
@@ -261,7 +296,7 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
         for (int u = 0; u < kMaxE; u++) {   // new node values into registers: every read of the window sums comes first
             const int e = tid + kWideThreads * u;
             if (e < kc) {
-                const int node = e / c, j = e - node * c;
+                const int node = (int)__umulhi((unsigned)e, ws.cmagic), j = e - node * c;
                 const double gain = gain_l[node];
                 if (gain >= 0.0) {
                     const double mean = wl[(size_t)node * cs + j] * inv_l[node];
@@ -274,7 +309,7 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
         for (int u = 0; u < kMaxE; u++) {
             const int e = tid + kWideThreads * u;
             if (e < kc) {
-                const int node = e / c, j = e - node * c;
+                const int node = (int)__umulhi((unsigned)e, ws.cmagic), j = e - node * c;
                 wl[(size_t)node * cs + j] = wold[u];
                 if (sa.w_out && blockIdx.x == 0) sa.w_out[e] = wold[u];
             }
@@ -289,7 +324,7 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
         const int part = tid & 3;
         double mymax = 0.0, mynrm = 0.0;
         bool bad = false;
-        for (int node = tid >> 2; node < ws.kp; node += kWideThreads / 4) {   // (uniform trip count: the shuffles need every lane)
+        for (int node = tid >> 2; node < ws.kp && !(PXSOM_WIDE_ABL & 16); node += kWideThreads / 4) {   // (uniform trip count: the shuffles need every lane)
             double nrm = 0.0;
             if (node < k) {
                 for (int j = part; j < c; j += 4) {
@@ -340,7 +375,7 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
     const float x_limit = 60000.0f;
     // A-fragments: frag[(b * 2 nch + 2 h) * 64 + lane] hi, + 1: lo; lane (q << 4 | m) <-> node 16 b + m, slot i of lane group q in
     // chunk h <-> channel h * 4 cpl + q * cpl + i
-    for (int f = tid; f < nb * NCH * 64; f += kWideThreads) {
+    for (int f = tid; f < nb * NCH * 64 && !(PXSOM_WIDE_ABL & 8); f += kWideThreads) {
         const int fl = f & 63, h = (f >> 6) % NCH, b = (f >> 6) / NCH;
         const int m = fl & 15, q = fl >> 4, node = 16 * b + m;
         half8 fhi, flo;
@@ -370,22 +405,17 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
     if (tid < 128) mu_s[tid] = (float)((double)mu_s[tid] * scale_d);
     __syncthreads();
 
-    // ---- P3: search.  Lane (q, pix) holds, for chunk h, channels h * 4 cpl + q * cpl + i of row pix of the wave's tile
+    // ---- P3: search
     const int pix = lane & 15, q = lane >> 4;
     const unsigned idx_mask = nb > 8 ? 63u : 31u;   // (b * 4 + r): the lane group travels beside the score, not inside it
-    for (int64_t blk = blockIdx.x; blk * kWideRowsPerWg < n; blk += gridDim.x) {
-        if (wv < kWideSearchWaves) {
-            const int64_t row = blk * kWideRowsPerWg + wv * 16 + pix;
-            const bool valid = row < n;
-            const T *xr = x + (valid ? row : n - 1) * ldx;
-            T raw[NCH][8];
+    for (int64_t blk = blockIdx.x; blk * kWideRowsPerWg < n && !(PXSOM_WIDE_ABL & 4); blk += gridDim.x) {
+        const int64_t row0 = blk * kWideRowsPerWg;
+        if constexpr (!kEarly) request(blk);
 #pragma unroll
-            for (int h = 0; h < NCH; h++)
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const int ch = h * 4 * cpl + q * cpl + i;
-                    raw[h][i] = xr[(i < cpl && ch < c) ? ch : 0];
-                }
+        for (int rd = 0; rd < kWideRounds; rd++) {
+            const int rl = (rd * kWideWaves + wv) * 16 + pix;   // the row's place in the workgroup's block
+            const bool valid = row0 + rl < n;
+            constexpr int slot = 0;
             half8 bh[NCH], bl[NCH];
             float ss = 0.f;
 #pragma unroll
@@ -395,8 +425,8 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
                     const int ch = h * 4 * cpl + q * cpl + i;
                     float xs = 0.f;
                     if (i < cpl && ch < c) {
-                        if constexpr (sizeof(T) == 8) xs = (float)__builtin_fma((double)raw[h][i], scale_d, -(double)mu_s[ch]);
-                        else xs = fmaf((float)raw[h][i], scale, -mu_s[ch]);
+                        if constexpr (sizeof(T) == 8) xs = (float)__builtin_fma((double)raw[slot][h][i], scale_d, -(double)mu_s[ch]);
+                        else xs = fmaf((float)raw[slot][h][i], scale, -mu_s[ch]);
                     }
                     const _Float16 hi = (_Float16)xs;
                     bh[h][i] = hi;
@@ -443,49 +473,99 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
             const bool amb = !((f1 - f2) > tol) || !(xn < x_limit) || !finite_n || force_exact;
             const unsigned id = __float_as_uint(f1) & idx_mask;
             const int node = (int)(16u * (id >> 2) + 4u * wq + (id & 3u));
-            // vouched rows go into the statistics after the barrier, shared out over all eight waves (below); a listed row waits
-            // in the queue
-            if (q == 0) lab_l[wv * 16 + pix] = (valid && !amb) ? node : -1;
-            if (valid && amb && q == 0) queue[atomicAdd(&ctl->q_n, 1u)] = row;
-
+            // a listed row waits in the queue; every row's label ends up in lab_l (-2: past the end, or a row without a finite distance)
+            if (q == 0) lab_l[rl] = !valid ? -2 : (amb ? -1 : node);
+            if (valid && amb && q == 0) queue[atomicAdd(&ctl->q_n, 1u)] = (unsigned short)rl;
         }
-        // ---- P4: vouched rows into the statistics, a row at a time with lanes <-> channels: the 64 atomics of an instruction fall
-        // into consecutive words (7 cache lines per 100-channel row).  (Adding from the registers that hold the tile for the
-        // search -- lane (q, pix) its own channel slots of row pix -- is one cache line PER LANE and atomic: measured 180 us per
-        // 8 300-row step on config 4 against 78 us for the five launches this kernel replaces.)  Then the listed rows of this
-        // block, by whichever wave is free.
+        if constexpr (kEarly)
+            if ((blk + gridDim.x) * kWideRowsPerWg < n) request(blk + gridDim.x);   // (the next block's rows, if this workgroup has one)
+        // ---- P4: the listed rows of this block, two at a time, by whichever wave is free: their labels join the others'
         __syncthreads();
-        {
-            int labs[kWideRowsPerWg / kWideWaves];
-            T va[kWideRowsPerWg / kWideWaves], vb[kWideRowsPerWg / kWideWaves];
+        const unsigned queued = (PXSOM_WIDE_ABL & 2) ? 0u : ctl->q_n;
+        for (unsigned i = 2 * wv; i < queued; i += 2 * kWideWaves) {
+            const bool two = i + 1 < queued;
+            const int ra = queue[i], rb = queue[two ? i + 1 : i];
+            const T *xa = x + (row0 + ra) * ldx, *xb = x + (row0 + rb) * ldx;
+            if (k <= 128) wide_exact_rows<T, 2>(xa, xb, two, c, k, wl, cs, lane, lab_l + ra, lab_l + rb);
+            else wide_exact_rows<T, 4>(xa, xb, two, c, k, wl, cs, lane, lab_l + ra, lab_l + rb);
+        }
+        for (int i = tid; i < ws.kp; i += kWideThreads) hist[i] = 0;
+        __syncthreads();
+        // ---- P5: the block's rows into the statistics, a label at a time.  Counting sort of the labels (place within a label: the
+        // order the counter's atomics were served in -- the sums are exact, so any order gives the same bits), then wave w takes
+        // the labels w, w + 8, ...: lanes <-> channels l and l + 64, the label's rows eight loads at a time, one atomic per value.
+        int mylab = -1, mypos = 0;
+        if (tid < kWideRowsPerWg) {
+            mylab = lab_l[tid];
+            if (mylab >= 0) mypos = atomicAdd(&hist[mylab], 1);
+        }
+        __syncthreads();
+        if (wv == 0) {   // exclusive prefix sums of the counters: lane l holds the nodes l * NS .. l * NS + NS - 1 (kp = 64 NS <= 256)
+            const int ns = ws.kp >> 6;
+            int mine[4], tot = 0;
 #pragma unroll
-            for (int u = 0; u < kWideRowsPerWg / kWideWaves; u++) {   // all the rows' loads first (L2: the tile was just read)
-                const int r = wv + u * kWideWaves;
-                labs[u] = lab_l[r];
+            for (int u = 0; u < 4; u++) {
+                mine[u] = u < ns ? hist[lane * ns + u] : 0;
+                tot += mine[u];
+            }
+            int incl = tot;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int up = __shfl_up(incl, d);
+                if (lane >= d) incl += up;
+            }
+            int run = incl - tot;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (u < ns) start[lane * ns + u] = run;
+                run += mine[u];
+            }
+            if (lane == 63) ctl->sorted_n = run;
+        }
+        __syncthreads();
+        if (mylab >= 0) order[start[mylab] + mypos] = (unsigned short)tid;
+        __syncthreads();
+        if (!(PXSOM_WIDE_ABL & 1)) {
+            constexpr int kPer = kWideRowsPerWg / kWideWaves;   // sorted rows a wave takes at most
+            const int m = ctl->sorted_n, per = (m + kWideWaves - 1) / kWideWaves;
+            const int p0 = wv * per, p1 = min(m, p0 + per);
+            T va[kPer], vb[kPer];
+            int labs[kPer];
+#pragma unroll
+            for (int u = 0; u < kPer; u++) {
+                labs[u] = -1;
                 va[u] = vb[u] = (T)0;
-                if (labs[u] >= 0) {
-                    const T *xq = x + (blk * kWideRowsPerWg + r) * ldx;
+                if (p0 + u < p1) {
+                    const int r = order[p0 + u];
+                    labs[u] = lab_l[r];
+                    const T *xq = x + (row0 + r) * ldx;
                     va[u] = xq[lane < c ? lane : 0];
                     vb[u] = xq[lane + 64 < c ? lane + 64 : 0];
                 }
             }
+            auto emit = [&](int lab, double s0, double s1, int cnt) {
+                double *dst = stats + (size_t)lab * c;
+                if (lane < c) __hip_atomic_fetch_add(dst + lane, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane + 64 < c) __hip_atomic_fetch_add(dst + lane + 64, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_fetch_add(stats + (size_t)kc + lab, (double)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            };
+            int cur = -1, cnt = 0;
+            double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-            for (int u = 0; u < kWideRowsPerWg / kWideWaves; u++) {
-                if (labs[u] >= 0) {
-                    double *dst = stats + (size_t)labs[u] * c;
-                    if (lane < c) __hip_atomic_fetch_add(dst + lane, wide_value<T>(va[u], sa.qmagic), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (lane + 64 < c)
-                        __hip_atomic_fetch_add(dst + lane + 64, wide_value<T>(vb[u], sa.qmagic), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (lane == 0) __hip_atomic_fetch_add(stats + (size_t)kc + labs[u], 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int u = 0; u < kPer; u++) {
+                if (labs[u] >= 0) {   // (wave-uniform)
+                    if (labs[u] != cur) {
+                        if (cur >= 0) emit(cur, s0, s1, cnt);
+                        cur = labs[u];
+                        s0 = s1 = 0.0;
+                        cnt = 0;
+                    }
+                    s0 += wide_value<T>(va[u], sa.qmagic);
+                    s1 += wide_value<T>(vb[u], sa.qmagic);
+                    cnt++;
                 }
             }
-        }
-        const unsigned queued = ctl->q_n;
-        for (unsigned i = 2 * wv; i < queued; i += 2 * kWideWaves) {
-            const bool two = i + 1 < queued;
-            const T *xa = x + queue[i] * ldx, *xb = x + queue[two ? i + 1 : i] * ldx;
-            if (k <= 128) wide_exact_rows<T, 2>(xa, xb, two, c, k, wl, cs, lane, sa.qmagic, stats);
-            else wide_exact_rows<T, 4>(xa, xb, two, c, k, wl, cs, lane, sa.qmagic, stats);
+            if (cur >= 0) emit(cur, s0, s1, cnt);
         }
         __syncthreads();
         if (tid == 0) ctl->q_n = 0u;
