@@ -35,6 +35,25 @@ int device_cu_count()
     return cached;
 }
 
+static thread_local RowView g_row_view;
+const RowView &current_row_view() { return g_row_view; }
+RowView make_row_view(int gw, int64_t gstride)
+{
+    RowView v;
+    if (gw > 1) {
+        const unsigned w = (unsigned)gw;
+        int s = 0;
+        while (((uint64_t)1 << s) < w) s++;
+        v.gw = gw;
+        v.gstride = gstride;
+        v.magic = (unsigned)((((uint64_t)1 << (31 + s)) / w) + 1u);
+        v.shift = s - 1;
+    }
+    return v;
+}
+RowViewScope::RowViewScope(const RowView &v) : saved(g_row_view) { g_row_view = v; }
+RowViewScope::~RowViewScope() { g_row_view = saved; }
+
 struct Prof {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     size_t used = 0;

@@ -98,7 +98,8 @@ struct ExactRows {
     // row numbers, then the rows themselves (lane j holds channels j and j+64): two dependent HBM/L2
     // round trips, issued for the NEXT batch before the current one is evaluated
     __device__ __forceinline__ void load(const T *__restrict__ x, int c, int64_t ldx,
-                                         const unsigned *__restrict__ amb_list, unsigned e0, unsigned count, int lane)
+                                         const unsigned *__restrict__ amb_list, unsigned e0, unsigned count, int lane,
+                                         const pxsom::RowView &rv)
     {
 #pragma unroll
         for (int u = 0; u < RB; u++) {
@@ -107,7 +108,7 @@ struct ExactRows {
         }
 #pragma unroll
         for (int u = 0; u < RB; u++) {
-            const T *rp = x + rows[u] * ldx;
+            const T *rp = x + rv.offset(rows[u], ldx);
             const double xa = (double)rp[lane < c ? lane : 0];
             const double xb = (double)rp[lane + 64 < c ? lane + 64 : 0];
             x_lo[u][0] = (unsigned)__double_as_longlong(xa);
@@ -127,12 +128,12 @@ __device__ __forceinline__ void exact_rows_loop(const T *__restrict__ x, int c, 
                                                 unsigned count, const unsigned *__restrict__ amb_list,
                                                 int32_t *__restrict__ labels, int use_lds,
                                                 unsigned wave, unsigned nwaves,
-                                                int lane, ExactRows<T, RB> &cur)
+                                                int lane, ExactRows<T, RB> &cur, const pxsom::RowView &rv)
 {
     for (unsigned e0 = wave * RB; e0 < count; e0 += nwaves * RB) {
         ExactRows<T, RB> nxt;
         const unsigned en = e0 + nwaves * RB;
-        if (en < count) nxt.load(x, c, ldx, amb_list, en, count, lane);
+        if (en < count) nxt.load(x, c, ldx, amb_list, en, count, lane, rv);
         double best[RB];
         int bestk[RB];
 #pragma unroll
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256) void bmu_exact_kernel(const T *__restrict__ x,
                                                         const AssignHdr *hdr,
                                                         const unsigned *__restrict__ amb_list,
                                                         int32_t *__restrict__ labels, int use_lds,
-                                                        const double *__restrict__ wt_global, unsigned screened_from)
+                                                        const double *__restrict__ wt_global, unsigned screened_from, pxsom::RowView rv)
 {
     if (hdr->amb_count >= screened_from) return;   // long lists: bmu_exact_screened_kernel (launched beside this one)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -231,9 +232,9 @@ __global__ __launch_bounds__(256) void bmu_exact_kernel(const T *__restrict__ x,
     ExactRows<T, 4> cur4;
     ExactRows<T, 1> cur1;
     if (wide) {
-        if (wave * 4u < count) cur4.load(x, c, ldx, amb_list, wave * 4u, count, lane);
+        if (wave * 4u < count) cur4.load(x, c, ldx, amb_list, wave * 4u, count, lane, rv);
     } else {
-        if (wave < count) cur1.load(x, c, ldx, amb_list, wave, count, lane);
+        if (wave < count) cur1.load(x, c, ldx, amb_list, wave, count, lane, rv);
     }
     if (use_lds) {
         // 8 independent loads in flight per thread (a one-load-per-trip loop pays the L2 latency per trip)
@@ -254,11 +255,11 @@ __global__ __launch_bounds__(256) void bmu_exact_kernel(const T *__restrict__ x,
     }
     PXSOM_PHASE(10);
     if (wide)
-        exact_rows_loop<T, 4, 2, 8>(x, c, ldx, w, wt, k, count, amb_list, labels, use_lds, wave, nwaves, lane, cur4);
+        exact_rows_loop<T, 4, 2, 8>(x, c, ldx, w, wt, k, count, amb_list, labels, use_lds, wave, nwaves, lane, cur4, rv);
     else if (!use_lds && k > 128)
-        exact_rows_loop<T, 1, 8, 4>(x, c, ldx, w, wt, k, count, amb_list, labels, use_lds, wave, nwaves, lane, cur1);
+        exact_rows_loop<T, 1, 8, 4>(x, c, ldx, w, wt, k, count, amb_list, labels, use_lds, wave, nwaves, lane, cur1, rv);
     else
-        exact_rows_loop<T, 1, 2, 8>(x, c, ldx, w, wt, k, count, amb_list, labels, use_lds, wave, nwaves, lane, cur1);
+        exact_rows_loop<T, 1, 2, 8>(x, c, ldx, w, wt, k, count, amb_list, labels, use_lds, wave, nwaves, lane, cur1, rv);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -298,7 +299,7 @@ void bmu_exact_screened_kernel(const T *__restrict__ x, int c, int64_t ldx,
                                                                  const float *__restrict__ w32, int k,
                                                                  const AssignHdr *hdr,
                                                                  const unsigned *__restrict__ amb_list,
-                                                                 int32_t *labels, unsigned min_rows)
+                                                                 int32_t *labels, unsigned min_rows, pxsom::RowView rv)
 {
     const unsigned count = hdr->amb_count;
     if (count < min_rows) return;
@@ -353,7 +354,7 @@ void bmu_exact_screened_kernel(const T *__restrict__ x, int c, int64_t ldx,
         const unsigned e = bt * (unsigned)rpw + (unsigned)slot;
         const bool valid = e < count;
         const int64_t row = amb_list[valid ? e : count - 1];
-        const T *rp = x + row * ldx;
+        const T *rp = x + rv.offset(row, ldx);
         float xv[8 * CB];
 #pragma unroll
         for (int j = 0; j < 8 * CB; j++) {
@@ -395,7 +396,7 @@ void bmu_exact_screened_kernel(const T *__restrict__ x, int c, int64_t ldx,
                     }
                 }
             } else {
-                const T *rq = x + r * ldx;
+                const T *rq = x + rv.offset(r, ldx);
 #pragma unroll(CB >= 16 ? 4 : 8)
                 for (int j = 0; j < c; j++) {
                     const double t = (double)rq[j] - wk[j];
@@ -643,6 +644,10 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
     // says what the workspace holds.
     const int npk = prepared ? L_in.npk : (packed_rows_ok<T>(x, ldx) && !stats ? packed_k(c, k, sizeof(T) == 2) : 0);
     const Layout L = make_layout(n, c, k, npk);
+    // (a scheduled step's rows where they lie, pxsom::RowView: the streamed filters and the exact kernels take views; the
+    // register-resident kernels, the all-exact route of rows wider than 128 and the distance output do not)
+    if (pxsom::row_view_active() && (c > kFilterMaxChannels || L.nch == 1 || dist))
+        return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "assign: a row view on a shape whose kernels do not take views");
     if (c > kFilterMaxChannels) {   // wide rows: no filter, every row in the oracle's arithmetic (section 3c)
         double *wt = reinterpret_cast<double *>(ws + L.off_wt);
         hipLaunchKernelGGL(wide_transpose_kernel, dim3((unsigned)std::min<int64_t>(((int64_t)k * c + 255) / 256, 1024)), dim3(256), 0, st,
@@ -734,11 +739,11 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
     hipLaunchKernelGGL(bmu_exact_kernel<T>, dim3(egrid), dim3(256), use_lds ? wt_bytes : 0, st, x, c, ldx, w,
                        k, reinterpret_cast<const AssignHdr *>(ws),
                        reinterpret_cast<const unsigned *>(ws + L.off_list), labels, use_lds,
-                       reinterpret_cast<const double *>(ws + L.off_wt), screened_from);
+                       reinterpret_cast<const double *>(ws + L.off_wt), screened_from, pxsom::current_row_view());
     PXSOM_LAUNCH_CHECK("bmu_exact_kernel");
     if ((uint64_t)n >= screened_from) {   // (an input shorter than the crossover cannot list that many rows)
         void (*kern)(const T *, int, int64_t, const double *, const float *, int, const AssignHdr *, const unsigned *, int32_t *,
-                     unsigned) = nullptr;
+                     unsigned, pxsom::RowView) = nullptr;
         switch (L.cp32 / 8) {
 #define PXSOM_SCREENED(CB)                                                                                  \
     case CB:                                                                                                \
@@ -754,7 +759,7 @@ int assign_typed(const T *x, int64_t n, int c, int64_t ldx, const double *w, int
         const int by_lds = w32_lds ? (int)std::max<size_t>(1, (160 * 1024) / (w32_bytes + 12 * 1024)) : by_regs;
         hipLaunchKernelGGL(kern, dim3(cus * std::min(by_regs, by_lds)), dim3(256), w32_lds ? w32_bytes : 0, st, x, c, ldx, w, reinterpret_cast<const float *>(ws + L.off_w32), k,
                            reinterpret_cast<const AssignHdr *>(ws), reinterpret_cast<const unsigned *>(ws + L.off_list), labels,
-                           screened_from);
+                           screened_from, pxsom::current_row_view());
         PXSOM_LAUNCH_CHECK("bmu_exact_screened_kernel");
     }
 

@@ -56,7 +56,7 @@ template <typename T, int NCH_T, int CPL_T, int NB_T, bool VEC2, bool PREFETCH, 
 __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_kernel(
     const T *__restrict__ x, int64_t n, int c, int64_t ldx, const half8 *__restrict__ wfrag,
     const f32x4 *__restrict__ bias, AssignHdr *hdr, unsigned *__restrict__ amb_list,
-    int32_t *__restrict__ labels)
+    int32_t *__restrict__ labels, pxsom::RowView rv)
 {
     constexpr int NCH = NCH_T;
     constexpr int NFR = 2 * NCH;  // stored fragments per node block
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_kernel(
     auto load_tile = [&](int64_t g, int t, T(&dst)[NCH][CPLMAX]) {
         int64_t row = g * 64 + t * 16 + pix;
         if (row > n - 1) row = n - 1;
-        const T *rp = x + row * ldx;
+        const T *rp = x + rv.offset(row, ldx);
 #pragma unroll
         for (int h = 0; h < NCH; h++) {
             if constexpr (VEC2) {
@@ -431,7 +431,7 @@ void launch_filter_variant(const T *x, int64_t n, int c, int64_t ldx, char *ws, 
             PXSOM_TIMED_LAUNCH(big, dim3(grid), dim3(512), lds, st, x, n, c, ldx,
                                reinterpret_cast<const half8 *>(ws + L.off_wfrag),
                                reinterpret_cast<const f32x4 *>(ws + L.off_bias), reinterpret_cast<AssignHdr *>(ws),
-                               reinterpret_cast<unsigned *>(ws + L.off_list), labels);
+                               reinterpret_cast<unsigned *>(ws + L.off_list), labels, pxsom::current_row_view());
             return;
         }
     }
@@ -454,7 +454,7 @@ void launch_filter_variant(const T *x, int64_t n, int c, int64_t ldx, char *ws, 
     PXSOM_TIMED_LAUNCH(kern, dim3(grid), dim3(256), lds, st, x, n, c, ldx,
                        reinterpret_cast<const half8 *>(ws + L.off_wfrag),
                        reinterpret_cast<const f32x4 *>(ws + L.off_bias), reinterpret_cast<AssignHdr *>(ws),
-                       reinterpret_cast<unsigned *>(ws + L.off_list), labels);
+                       reinterpret_cast<unsigned *>(ws + L.off_list), labels, pxsom::current_row_view());
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -469,7 +469,8 @@ void launch_filter_variant(const T *x, int64_t n, int c, int64_t ldx, char *ws, 
 template <int NPK, int TP, bool LDSW, int BD, bool SUPER = false>
 __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_packed_kernel(
     const _Float16 *__restrict__ x, int64_t n, int c, int64_t ldx, const half8 *__restrict__ wfrag,
-    const f32x4 *__restrict__ bias, AssignHdr *hdr, unsigned *__restrict__ amb_list, int32_t *__restrict__ labels)
+    const f32x4 *__restrict__ bias, AssignHdr *hdr, unsigned *__restrict__ amb_list, int32_t *__restrict__ labels,
+    pxsom::RowView rv)
 {
     const int nb = hdr->nb;
     // (Round 5, measured and not kept: the node block packed into the score's low bits beside the register index -- 7 bits -- instead
@@ -533,7 +534,7 @@ __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_packed_kerne
             for (int u = 0; u < TP; u++) {
                 int64_t row = g * 64 + (t0 + u) * 16 + pix;
                 if (row > n - 1) row = n - 1;
-                const _Float16 *rp = x + row * ldx;
+                const _Float16 *rp = x + rv.offset(row, ldx);
                 float acc2 = 0.f;
 #pragma unroll
                 for (int m = 0; m < NPK; m++) {
@@ -724,7 +725,7 @@ void launch_packed(const _Float16 *x, int64_t n, int c, int64_t ldx, char *ws, c
             raised = true;
         }
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((ngroups + 15) / 16, cus));
-        PXSOM_TIMED_LAUNCH(kern, dim3(grid), dim3(1024), lds, st, x, n, c, ldx, wf, bi, hd, al, labels);
+        PXSOM_TIMED_LAUNCH(kern, dim3(grid), dim3(1024), lds, st, x, n, c, ldx, wf, bi, hd, al, labels, pxsom::current_row_view());
         return;
     }
     if (lds <= 150 * 1024 && lds > 64 * 1024) {          // one workgroup per CU: a big one (two waves per SIMD on one LDS copy)
@@ -736,16 +737,16 @@ void launch_packed(const _Float16 *x, int64_t n, int c, int64_t ldx, char *ws, c
             raised = true;
         }
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((ngroups + 7) / 8, cus));
-        PXSOM_TIMED_LAUNCH(kern, dim3(grid), dim3(512), lds, st, x, n, c, ldx, wf, bi, hd, al, labels);
+        PXSOM_TIMED_LAUNCH(kern, dim3(grid), dim3(512), lds, st, x, n, c, ldx, wf, bi, hd, al, labels, pxsom::current_row_view());
     } else if (lds <= 64 * 1024) {
         auto kern = bmu_filter_packed_kernel<NPK, 4, true, 256>;
         const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / lds)));
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((ngroups + 3) / 4, (int64_t)cus * per_cu));
-        PXSOM_TIMED_LAUNCH(kern, dim3(grid), dim3(256), lds, st, x, n, c, ldx, wf, bi, hd, al, labels);
+        PXSOM_TIMED_LAUNCH(kern, dim3(grid), dim3(256), lds, st, x, n, c, ldx, wf, bi, hd, al, labels, pxsom::current_row_view());
     } else {                                              // fragments from L1 / L2
         auto kern = bmu_filter_packed_kernel<NPK, 4, false, 256>;
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((ngroups + 3) / 4, (int64_t)cus * 2));
-        PXSOM_TIMED_LAUNCH(kern, dim3(grid), dim3(256), 0, st, x, n, c, ldx, wf, bi, hd, al, labels);
+        PXSOM_TIMED_LAUNCH(kern, dim3(grid), dim3(256), 0, st, x, n, c, ldx, wf, bi, hd, al, labels, pxsom::current_row_view());
     }
 }
 

@@ -165,7 +165,8 @@ __device__ __forceinline__ void wide_exact_rows(const T *xr0, const T *xr1, bool
 
 template <typename T, int NCH>
 __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *__restrict__ x, int64_t n, int c, int64_t ldx, int k,
-                                                                       double *__restrict__ stats, StepArgs sa, WideShape ws, int xd, int yd)
+                                                                       double *__restrict__ stats, StepArgs sa, WideShape ws, int xd, int yd,
+                                                                       pxsom::RowView rv)
 {
     extern __shared__ __attribute__((aligned(16))) char wide_smem[];
     double *wl = reinterpret_cast<double *>(wide_smem);                                   // W_g [k][cs]
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
     T raw[1][NCH][8];
     auto request = [&](int64_t blk) {
         const int64_t row = blk * kWideRowsPerWg + wv * 16 + (lane & 15);
-        const T *xr = x + (row < n ? row : (n > 0 ? n - 1 : 0)) * ldx;
+        const T *xr = x + rv.offset(row < n ? row : (n > 0 ? n - 1 : 0), ldx);
 #pragma unroll
         for (int h = 0; h < NCH; h++)
 #pragma unroll
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
         for (unsigned i = 2 * wv; i < queued; i += 2 * kWideWaves) {
             const bool two = i + 1 < queued;
             const int ra = queue[i], rb = queue[two ? i + 1 : i];
-            const T *xa = x + (row0 + ra) * ldx, *xb = x + (row0 + rb) * ldx;
+            const T *xa = x + rv.offset(row0 + ra, ldx), *xb = x + rv.offset(row0 + rb, ldx);
             if (k <= 128) wide_exact_rows<T, 2>(xa, xb, two, c, k, wl, cs, lane, lab_l + ra, lab_l + rb);
             else wide_exact_rows<T, 4>(xa, xb, two, c, k, wl, cs, lane, lab_l + ra, lab_l + rb);
         }
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
                 if (p0 + u < p1) {
                     const int r = order[p0 + u];
                     labs[u] = lab_l[r];
-                    const T *xq = x + (row0 + r) * ldx;
+                    const T *xq = x + rv.offset(row0 + r, ldx);
                     va[u] = xq[lane < c ? lane : 0];
                     vb[u] = xq[lane + 64 < c ? lane + 64 : 0];
                 }
@@ -598,7 +599,7 @@ int launch_batch_step_wide(const T *x, int64_t n, int c, int64_t ldx, int xdim, 
 {
     const int k = xdim * ydim;
     const WideShape ws = wide_shape(c, k);
-    void (*kern)(const T *, int64_t, int, int64_t, int, double *, StepArgs, WideShape, int, int) = nullptr;
+    void (*kern)(const T *, int64_t, int, int64_t, int, double *, StepArgs, WideShape, int, int, pxsom::RowView) = nullptr;
     switch (ws.nch) {
         case 1: kern = batch_step_wide_kernel<T, 1>; break;
         case 2: kern = batch_step_wide_kernel<T, 2>; break;
@@ -615,7 +616,7 @@ int launch_batch_step_wide(const T *x, int64_t n, int c, int64_t ldx, int xdim, 
     }
     const int64_t blocks = std::max<int64_t>((n + kWideRowsPerWg - 1) / kWideRowsPerWg, 1);
     const int grid = (int)std::min<int64_t>(blocks, (int64_t)pxsom::device_cu_count());
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWideThreads), ws.total, st, x, n, c, ldx, k, stats, sa, ws, xdim, ydim);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWideThreads), ws.total, st, x, n, c, ldx, k, stats, sa, ws, xdim, ydim, pxsom::current_row_view());
     PXSOM_LAUNCH_CHECK("batch_step_wide_kernel");
     return PXSOM_OK;
 }

@@ -74,6 +74,32 @@ struct PerDevice {
     }
 };
 
+// Rows of a scheduled mini-batch step where they lie in the caller's matrix (round 6: the generic training route's kernels read
+// them there; until then every pass began by gathering each step's rows into a copy -- 217 us of config 4's 2.0 ms pass, 800 MB
+// of traffic).  Row f of the step starts at element (f / gw) * gstride + (f % gw) * ldx: gw consecutive rows out of every
+// `phases`; gw <= 1: the plain strided matrix, f * ldx.  A view is set for the calling thread around the launches that take it
+// (RowViewScope); a launch that reads rows and does NOT take views must refuse to run under one (row_view_active()).
+struct RowView {
+    int gw = 1;
+    int64_t gstride = 0;
+    unsigned magic = 0;   // f / gw == __umulhi(f, magic) >> shift for f < 2^31 (as StepArgs::group_magic)
+    int shift = 0;
+    __device__ __forceinline__ int64_t offset(int64_t f, int64_t ldx) const
+    {
+        if (gw <= 1) return f * ldx;
+        const unsigned grp = __umulhi((unsigned)f, magic) >> shift, sub = (unsigned)f - grp * (unsigned)gw;
+        return (int64_t)grp * gstride + (int64_t)sub * ldx;
+    }
+};
+RowView make_row_view(int gw, int64_t gstride);
+const RowView &current_row_view();
+inline bool row_view_active() { return current_row_view().gw > 1; }
+struct RowViewScope {
+    RowView saved;
+    explicit RowViewScope(const RowView &v);
+    ~RowViewScope();
+};
+
 // Optional in-library kernel timer (pxsom_prof_*): HIP event pairs recorded on the launch stream
 // immediately around the dominant kernel of a call, so a caller can report that kernel's
 // duration without a profiler attached.

@@ -22,6 +22,10 @@
 #include "pxsom_wave.h"
 #include "pxsom_xch.h"
 
+#ifndef PXSOM_WIDE_WIN_CAP
+#define PXSOM_WIDE_WIN_CAP 4096
+#endif
+
 namespace {
 
 using pxsom::dpp_f64;
@@ -701,7 +705,7 @@ template <typename T, bool COUNT_F64, int NT>
 __global__ __launch_bounds__(NT) void cluster_sums_kernel(const T *__restrict__ x, int64_t n, int c,
                                                            int64_t ldx, const int32_t *__restrict__ labels,
                                                            int k, double *sums, unsigned long long *counts,
-                                                           int64_t rows_per_block, int use_lds, double qmagic, int cs)
+                                                           int64_t rows_per_block, int use_lds, double qmagic, int cs, pxsom::RowView rv)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     // table row stride cs (words): c, or c padded to an odd number -- the lanes of a ds_add hit rows of unrelated labels, and with
@@ -723,7 +727,11 @@ __global__ __launch_bounds__(NT) void cluster_sums_kernel(const T *__restrict__ 
     if constexpr (sizeof(T) <= 4) {
         // contiguous fp32 / fp16 rows: VEC = 16 / sizeof(T) elements per load
         constexpr int VEC = 16 / (int)sizeof(T);
-        if (use_lds && ldx == c && r0 < r1 && ((reinterpret_cast<uintptr_t>(x) + (size_t)r0 * c * sizeof(T)) & 15) == 0) {
+        // (a scheduled step's rows where they lie, pxsom::RowView: rows of whole vectors only -- the host sees to it --, a vector's
+        // address from its row's place in the caller's matrix instead of from the flat range)
+        const bool viewed = rv.gw > 1;
+        if (use_lds && ldx == c && r0 < r1 &&
+            ((reinterpret_cast<uintptr_t>(x) + (viewed ? (size_t)0 : (size_t)r0 * c * sizeof(T))) & 15) == 0) {
             typedef unsigned u4 __attribute__((ext_vector_type(4)));
             const T *xb = x + r0 * c;
             const int64_t total = (r1 - r0) * c, nvec = total / VEC;
@@ -745,9 +753,9 @@ __global__ __launch_bounds__(NT) void cluster_sums_kernel(const T *__restrict__ 
                     for (int u = 0; u < 4; u++) {
                         const int64_t v = v0 + u * NT;
                         const bool ok = v < nvec;
-                        const u4 raw = *reinterpret_cast<const u4 *>(xb + VEC * (ok ? v : nvec - 1));
-                        __builtin_memcpy(val[u], &raw, 16);
                         const int64_t row = vrow < last_row ? vrow : last_row, row2 = vrow + 1 < last_row ? vrow + 1 : last_row;
+                        const u4 raw = *reinterpret_cast<const u4 *>(viewed ? x + rv.offset(r0 + row, c) + (ok ? vch : 0) : xb + VEC * (ok ? v : nvec - 1));
+                        __builtin_memcpy(val[u], &raw, 16);
                         // (rows of whole vectors never look at the second label: its load is the third of every four vector-memory
                         // instructions of this loop)
                         const int la = labels[r0 + row] - 1, lb2 = rows_of_vectors ? -1 : labels[r0 + row2] - 1;
@@ -1298,6 +1306,19 @@ int launch_sums_private(const T *x, int64_t n, int c, int64_t ldx, const int32_t
     return PXSOM_OK;
 }
 
+// The shapes whose sums kernel reads a scheduled step's rows where they lie (pxsom::RowView): cluster_sums_kernel's flat route
+// with rows of whole 16-byte vectors -- binary32 / binary16 rows, contiguous in the caller's matrix, more than 64 channels (below,
+// large inputs go to the wave-private kernels, which address flat ranges), table in LDS.
+template <typename T>
+bool sums_take_views(const T *x, int c, int64_t ldx, int k)
+{
+    if (sizeof(T) > 4) return false;
+    const int vec = 16 / (int)sizeof(T);
+    const size_t lds_odd = ((size_t)k * (c | 1) + kSumsSpare) * 8 + (size_t)k * 4;
+    return c > 64 && c % vec == 0 && ldx == c && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+           std::min(lds_odd, ((size_t)k * c + kSumsSpare) * 8 + (size_t)k * 4) <= 150 * 1024;
+}
+
 // qmagic != 0 (binary64 rows of a reproducible training run, include/pxsom.h): values are rounded to the run's quantum
 // as they are added; only the atomic kernel knows how.
 template <typename T, bool COUNT_F64 = false>
@@ -1305,6 +1326,8 @@ int cluster_sums_typed(const T *x, int64_t n, int c, int64_t ldx, const int32_t 
                        int64_t *counts, hipStream_t st, double qmagic = 0.0)
 {
     if (sizeof(T) != 8) qmagic = 0.0;
+    if (pxsom::row_view_active() && !sums_take_views<T>(x, c, ldx, k))
+        return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "cluster sums: a row view on a shape whose kernel does not take views");
     // wave-private tables (see cluster_sums_private_kernel): 13 <= c <= 64 (RPI = 64 / c <= 4 rows per
     // instruction, fewer idle lanes than channels), at least two tables per CU, an input big enough to
     // fill them, and a wave's byte range addressable by the 32-bit buffer offsets.  Measured against the
@@ -1353,7 +1376,7 @@ int cluster_sums_typed(const T *x, int64_t n, int c, int64_t ldx, const int32_t 
         PXSOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(wide ? 1024 : 256), use_lds ? lds : 0, st, x, n, c, ldx, labels, k,
-                       sums, reinterpret_cast<unsigned long long *>(counts), rows_per_block, use_lds, qmagic, cs);
+                       sums, reinterpret_cast<unsigned long long *>(counts), rows_per_block, use_lds, qmagic, cs, pxsom::current_row_view());
     PXSOM_LAUNCH_CHECK("cluster_sums_kernel");
     return PXSOM_OK;
 }
@@ -1846,36 +1869,50 @@ int launch_gather(const T *x, int64_t n, int c, int64_t ldx, T *out, const Sched
 // The run's centring vector for the one-launch step's filter (AssignHdr::mu_s, DESIGN.md "K7 centring"): the mean of the
 // codebook the run starts from, per channel, in binary32.  Any vector keeps the search exact; this one stays close to the
 // nodes' mean for the whole run (they follow the data), so the steps need no reduction of their own for it.
-__global__ __launch_bounds__(256) void centring_vector_kernel(const double *__restrict__ w, int k, int c, float *__restrict__ mu32,
-                                                              double *__restrict__ zero_out, int zero_count, double *__restrict__ copy_out)
+__global__ __launch_bounds__(1024) void centring_vector_kernel(const double *__restrict__ w, int k, int c, float *__restrict__ mu32,
+                                                               double *__restrict__ zero_out, int zero_count, double *__restrict__ copy_out)
 {
-    for (int e = threadIdx.x; e < zero_count; e += 256) zero_out[e] = 0.0;   // the first step's statistics buffer (no memset launch)
-    if (copy_out)   // W_0 handed over by the caller: into the run's codebook buffer (no copy launch in front of the pass)
-        for (int e = threadIdx.x; e < k * c; e += 256) copy_out[e] = w[e];
-    // `parts` adjacent lanes share a channel (8 for c <= 32, 2 for c <= 128): each sums every parts-th node with its loads in
-    // flight eight at a time -- a lane walking 50 nodes one L2 round trip after the other made this launch 16 us
-    const int cp = c <= 32 ? 32 : (c <= 64 ? 64 : 128), parts = 256 / cp;
-    const int j = threadIdx.x / parts, part = threadIdx.x % parts;
-    double sum = 0.0;
-    if (j < c) {
-        for (int n0 = part; n0 < k; n0 += 8 * parts) {
-            double v[8];
+    // 1024 threads clear and copy (a 100 x 100 codebook on 256 threads was 40 dependent load -> store trips: 22 us of config 4's
+    // pass), the first 256 form the means
+    for (int e = threadIdx.x; e < zero_count; e += 1024) zero_out[e] = 0.0;   // the first step's statistics buffer (no memset launch)
+    if (copy_out) {   // W_0 handed over by the caller: into the run's codebook buffer (no copy launch in front of the pass)
+        for (int e0 = threadIdx.x; e0 < k * c; e0 += 4 * 1024) {
+            double v[4];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = n0 + u * parts < k ? w[(size_t)(n0 + u * parts) * c + j] : 0.0;
+            for (int u = 0; u < 4; u++) v[u] = w[e0 + u * 1024 < k * c ? e0 + u * 1024 : 0];
 #pragma unroll
-            for (int u = 0; u < 8; u++) sum += v[u];
+            for (int u = 0; u < 4; u++)
+                if (e0 + u * 1024 < k * c) copy_out[e0 + u * 1024] = v[u];
         }
     }
-    for (int d = 1; d < parts; d *= 2) sum += __shfl_xor(sum, d);
-    float m = (float)(sum / (double)k);
-    if (!(j < c && fabsf(m) <= 3.0e38f)) m = 0.f;   // a non-finite codebook: not centred (every row is listed anyway)
-    if (part == 0 && j < pxsom_bmu::kFilterMaxChannels) mu32[j] = m;
-    // word 128: the vector's norm (the steps cap their power-of-two scale with it: pxsom_batch_step.hip)
     __shared__ float s_m[pxsom_bmu::kFilterMaxChannels];
     if (threadIdx.x < pxsom_bmu::kFilterMaxChannels) s_m[threadIdx.x] = 0.f;
     __syncthreads();
-    if (part == 0 && j < pxsom_bmu::kFilterMaxChannels) s_m[j] = m;
+    // `parts` adjacent lanes share a channel (8 for c <= 32, 2 for c <= 128): each sums every parts-th node with its loads in
+    // flight eight at a time -- a lane walking 50 nodes one L2 round trip after the other made this launch 16 us
+    if (threadIdx.x < 256) {
+        const int cp = c <= 32 ? 32 : (c <= 64 ? 64 : 128), parts = 256 / cp;
+        const int j = threadIdx.x / parts, part = threadIdx.x % parts;
+        double sum = 0.0;
+        if (j < c) {
+            for (int n0 = part; n0 < k; n0 += 8 * parts) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = n0 + u * parts < k ? w[(size_t)(n0 + u * parts) * c + j] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; u++) sum += v[u];
+            }
+        }
+        for (int d = 1; d < parts; d *= 2) sum += __shfl_xor(sum, d);
+        float m = (float)(sum / (double)k);
+        if (!(j < c && fabsf(m) <= 3.0e38f)) m = 0.f;   // a non-finite codebook: not centred (every row is listed anyway)
+        if (part == 0 && j < pxsom_bmu::kFilterMaxChannels) {
+            mu32[j] = m;
+            s_m[j] = m;
+        }
+    }
     __syncthreads();
+    // word 128: the vector's norm (the steps cap their power-of-two scale with it: pxsom_batch_step.hip)
     if (threadIdx.x < 64) {
         const double a = (double)s_m[threadIdx.x], b = (double)s_m[threadIdx.x + 64];
         double n2 = a * a + b * b;
@@ -1930,7 +1967,7 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
     if (g_begin == 0) {   // the first step's statistics buffer; every later one is cleared by the step before it
         // (w0: the codebook the run starts from, where the caller holds it -- copied into wbuf[0] by the launch that is there anyway)
         if (centred_run) {
-            hipLaunchKernelGGL(centring_vector_kernel, dim3(1), dim3(256), 0, st, w0 ? w0 : wbuf, k, c, mu32, ring, (int)nstats,
+            hipLaunchKernelGGL(centring_vector_kernel, dim3(1), dim3(1024), 0, st, w0 ? w0 : wbuf, k, c, mu32, ring, (int)nstats,
                                w0 ? wbuf : (double *)nullptr);
             PXSOM_LAUNCH_CHECK("centring_vector_kernel");
         } else {
@@ -1938,7 +1975,11 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
             PXSOM_HIP_TRY(hipMemsetAsync(ring, 0, nstats * sizeof(double), st));
         }
     }
-    const bool gathered = !fused_shape && sc.any_wide();
+    // Round 6: where every kernel of the generic route takes row views (pxsom_common.h RowView: more than 64 channels of binary32 /
+    // binary16 rows, contiguous in the caller's matrix) the steps read their rows where they lie -- no gathered copy of the matrix
+    // at the head of every pass (config 4: 217 us of 2.0 ms, 800 MB of traffic)
+    const bool viewed = !fused_shape && sc.any_wide() && c <= pxsom_bmu::kFilterMaxChannels && sums_take_views<T>(x, c, ldx, k);
+    const bool gathered = !fused_shape && sc.any_wide() && !viewed;
     if (gathered && g_begin == 0 && n > 0) {
         int rc = launch_gather<T>(x, n, c, ldx, xg, sc, st);
         if (rc) return rc;
@@ -1970,7 +2011,8 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
         const int wd = sc.width(g);
         // the step's rows as a strided matrix: phase view (one phase), or its slice of the gathered copy
         const T *xv = gathered ? xg + (size_t)sc.offset(n, g) * c : x + (size_t)sc.e0(g) * ldx;
-        const int64_t ldv = gathered ? c : ldx * sc.phases;
+        const int64_t ldv = gathered ? c : ((viewed && wd > 1) ? ldx : ldx * sc.phases);
+        const pxsom::RowViewScope view_scope((viewed && wd > 1) ? pxsom::make_row_view(wd, (int64_t)sc.phases * ldx) : pxsom::RowView{});
         if (rows >= (int64_t)1 << 31) return pxsom::fail(PXSOM_ERR_UNSUPPORTED, "pxsom_batch_train: a step of %lld rows", (long long)rows);
         double *w_prev = wbuf + (size_t)((gg + 1) % 2) * nw, *w_cur = wbuf + (size_t)(gg % 2) * nw;
         double *s_prev = ring + (size_t)((gg + 2) % 3) * nstats, *s_cur = ring + (size_t)(gg % 3) * nstats,
@@ -2017,7 +2059,7 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
         // pinned at 0.5) on any grid, the windowed ones on grids up to 16 x 16
         if constexpr (sizeof(T) >= 4) {
             const bool bmu_only = gg > 0 && thr == 0.5;
-            constexpr int64_t win_cap = 4096;   // (windowed steps beyond ~4 K rows run as fast on the launch-per-phase route: profiles/r04)
+            constexpr int64_t win_cap = PXSOM_WIDE_WIN_CAP;   // (rows of a windowed step the wide one-launch kernel takes)
             if (!(flags & PXSOM_TRAIN_UNFUSED) && rows <= pxsom_bmu::step_wide_max_rows() && pxsom_bmu::step_wide_shape<T>(c, k) &&
                 (bmu_only || (rows <= win_cap && pxsom_bmu::step_wide_windowed(xdim, ydim, c)))) {
                 pxsom_bmu::StepArgs sa;

@@ -286,3 +286,42 @@ def test_one_launch_steps_equal_the_launch_per_phase_route_and_the_oracle(gpu, o
                                   quantum=quantum)
     # exact sums + a gain free of library calls: the whole run is the oracle's, bit for bit
     np.testing.assert_array_equal(wa.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("c,dtype,pad", [
+    (100, np.float32, 0),     # config 4's shape: every kernel of the generic route reads the step's rows where they lie (RowView)
+    (100, np.float32, 4),     # the same rows inside a wider matrix (ldx = 104): the gathered copy, as before
+    (96, np.float16, 0),      # binary16: packed-K filter + the sums kernel's eight-element vectors on the view
+    (72, np.float32, 0),      # three channel chunks
+    (48, np.float32, 0),      # <= 64 channels: the wave-private sums kernels address flat ranges -- gathered
+])
+def test_generic_route_on_row_views_matches_the_oracle(gpu, oracle, c, dtype, pad):
+    """Round 6: the launch-per-phase route and the wide one-launch step without the gathered copy of the matrix.  Whole run against
+    orc_som_batch_sched on data whose sums are exact (bit for bit), for shapes on both sides of the decision."""
+    xdim = ydim = 10
+    k, n = 100, 41_003
+    sch = MIXED
+    x = synth.make_fov_numpy(n, c, seed=61, dtype=np.float32)
+    x = (np.round(x.astype(np.float64) * 4096.0) / 4096.0).astype(dtype)
+    w0 = _codebook(synth.make_fov_numpy(4 * k, c, seed=62, dtype=np.float64), k, seed=9)
+    w0[k - 2] = w0[3]
+    host = np.zeros((n, c + pad), dtype=dtype)
+    host[:, :c] = x
+    xd = torch.from_numpy(host).to(gpu)[:, :c]
+    rr = default_radius_range(xdim, ydim)
+    total = sch.steps
+    st = sd.BatchTrainState(n, c, xdim, ydim, sch, gpu, dtype=xd.dtype)
+    st.wbuf[0].copy_(torch.from_numpy(w0))
+    sd.batch_train_steps(xd, st, 0, total, total, (0.05, 0.01), rr)
+    w = torch.empty((k, c), dtype=torch.float64, device=gpu)
+    sd.batch_train_finish(st, total, total, (0.05, 0.01), rr, w)
+    want = oracle.som_batch_sched(x.astype(np.float64), w0, xdim, ydim, 1, (0.05, 0.01), rr, sch.phases, sch.edges)
+    np.testing.assert_array_equal(w.cpu().numpy(), want)
+    # and step by step from another state (the multi-call form: a view needs no state between calls)
+    st2 = sd.BatchTrainState(n, c, xdim, ydim, sch, gpu, dtype=xd.dtype)
+    st2.wbuf[0].copy_(torch.from_numpy(w0))
+    for g in range(total):
+        sd.batch_train_steps(xd, st2, g, g + 1, total, (0.05, 0.01), rr)
+    w2 = torch.empty((k, c), dtype=torch.float64, device=gpu)
+    sd.batch_train_finish(st2, total, total, (0.05, 0.01), rr, w2)
+    assert torch.equal(w, w2)
