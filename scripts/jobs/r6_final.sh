@@ -18,3 +18,4 @@ python scripts/preprocess_bench.py --fovs 30 > $O/create_pixel_matrix.json 2>/de
 python scripts/debug/label_coherence_probe.py 2>/dev/null | tee $O/label_coherence.txt | tail -8
 python scripts/debug/f64_assign_probe.py 2>/dev/null | tee $O/f64_assign_probe.txt | tail -4
 bash scripts/jobs/r6_phase.sh > /dev/null 2>&1
+BENCH_ARGS="--config cfg4" N=80 bash scripts/jobs/r6_timeline.sh > /dev/null 2>&1
