@@ -54,7 +54,7 @@ constexpr int kWideMaxNodes = 256;
 
 struct WideShape {
     int nb, nch, cpl, cs, kp;   // kp: k rounded up to a multiple of 64 (per-node arrays, node slots of the exact path)
-    unsigned cmagic;            // ceil(2^32 / c): e / c == __umulhi(e, cmagic) for e < 2^32 / c (element indices stay below 2^15 c)
+    unsigned cmagic;            // ceil(2^32 / c): e / c == __umulhi(e, cmagic) for e < 2^32 / c (element indices stay below 2^15 c); 0 for c == 1: e itself
     size_t off_frag, off_bias, off_misc, total;
 };
 inline WideShape wide_shape(int c, int k)
@@ -65,7 +65,7 @@ inline WideShape wide_shape(int c, int k)
     s.cpl = (c + 4 * s.nch - 1) / (4 * s.nch);
     s.cs = (c + 1) | 1;   // W_g row stride, words: odd, and wide enough for [c sums | count] rows while the window sums are formed
     s.kp = (k + 63) & ~63;
-    s.cmagic = (unsigned)((0x100000000ull + (unsigned long long)c - 1ull) / (unsigned long long)c);
+    s.cmagic = c > 1 ? (unsigned)((0x100000000ull + (unsigned long long)c - 1ull) / (unsigned long long)c) : 0u;   // (c == 1: 2^32 does not fit)
     s.off_frag = pxsom::align_up((size_t)k * s.cs * sizeof(double), 16);
     s.off_bias = s.off_frag + (size_t)s.nb * 2 * s.nch * 64 * sizeof(half8);
     s.off_misc = s.off_bias + (size_t)s.nb * 64 * sizeof(f32x4);
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
             for (int u = 0; u < kInFlight; u++) {
                 const int e = e0 + u * kWideThreads;
                 if (e < kc) {
-                    const int node = (int)__umulhi((unsigned)e, ws.cmagic), j = e - node * c;
+                    const int node = (ws.cmagic ? (int)__umulhi((unsigned)e, ws.cmagic) : e), j = e - node * c;
                     const double gain = gain_l[node];
                     double v = wo[u];
                     if (gain >= 0.0) {
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
         for (int u = 0; u < kMaxE; u++) {   // new node values into registers: every read of the window sums comes first
             const int e = tid + kWideThreads * u;
             if (e < kc) {
-                const int node = (int)__umulhi((unsigned)e, ws.cmagic), j = e - node * c;
+                const int node = (ws.cmagic ? (int)__umulhi((unsigned)e, ws.cmagic) : e), j = e - node * c;
                 const double gain = gain_l[node];
                 if (gain >= 0.0) {
                     const double mean = wl[(size_t)node * cs + j] * inv_l[node];
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
         for (int u = 0; u < kMaxE; u++) {
             const int e = tid + kWideThreads * u;
             if (e < kc) {
-                const int node = (int)__umulhi((unsigned)e, ws.cmagic), j = e - node * c;
+                const int node = (ws.cmagic ? (int)__umulhi((unsigned)e, ws.cmagic) : e), j = e - node * c;
                 wl[(size_t)node * cs + j] = wold[u];
                 if (sa.w_out && blockIdx.x == 0) sa.w_out[e] = wold[u];
             }

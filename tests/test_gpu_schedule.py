@@ -33,6 +33,8 @@ def _codebook(x, k, seed):
     (40, np.float16, 40_000, 20, SMALL_TWO_PHASE, 1),
     (7, np.float32, 12_345, 10, MIXED, 1),               # odd channel count: 2-byte / 4-byte gather chunks
     (40, np.float64, 9_000, 20, MIXED, 2),
+    (1, np.float32, 17_474, 16, SMALL_TWO_PHASE, 1),     # one channel (round 6: the wide step's e / c by a multiplication has no 2^32 / 1)
+    (1, np.float64, 2_999, 10, MIXED, 1),
 ])
 def test_scheduled_steps_match_the_oracle_per_step(gpu, oracle, c, dtype, n, grid, sch, passes):
     xdim = ydim = grid
