@@ -63,6 +63,28 @@ __host__ __device__ inline double filter_accum_units(int c, int terms)
     const int nch = (c + 31) / 32;
     return 2.0 * (4.0 * nch * terms) * (1.0 + 0x1p-10) + 2.0;
 }
+// Round 6, the streamed filter on more than one channel chunk and the wide one-launch step: the cross terms (Wh*Xl, Wl*Xh) are
+// accumulated in a register set of their OWN, started from zero, and join the Wh*Xh chain in one binary32 addition at the end.
+// Their 8 NCH group additions then round against a running magnitude of at most (terms - 1) 2^-11 |X'||W'| instead of the whole
+// score's, and the main chain commits only its own 4 NCH group additions:
+//   2 x 4 NCH (1 + 2^-10)                       the Wh*Xh chain, as above
+//   2 x 4 NCH (terms - 1) x (terms - 1) 2^-11   the cross chain (below 0.1 unit at four chunks)
+//   + 1                                         the joining addition (round to nearest: half a unit of the sum, rounded up)
+//   + 2                                         the bias the chain starts from and the rounding of |X'|^2
+// -- 35 units at C = 100 where the single chain commits 98.  The cuts inside the groups (filter_cut_abs) are what they were.
+__host__ __device__ inline double filter_accum_units_split(int c, int terms)
+{
+    if (PXSOM_TOL_SLOTWISE) return (double)terms * c + 2.0;
+    const int nch = (c + 31) / 32;
+    return 2.0 * (4.0 * nch) * (1.0 + 0x1p-10) + 2.0 * (4.0 * nch) * (terms - 1) * (terms - 1) * 0x1p-11 * (1.0 + 0x1p-10) + 1.0 + 2.0;
+}
+// which of the two the streamed filter (bmu_filter_kernel) runs on: the split accumulation from two channel chunks on (one chunk:
+// the register-resident kernels share the workspace's tolerance and keep the single chain); packed-K fragments keep the single chain
+__host__ __device__ inline bool filter_split_accumulation(int c, int npk) { return c > 32 && npk == 0; }
+__host__ __device__ inline double filter_accum_units_for(int c, int terms, int npk)
+{
+    return filter_split_accumulation(c, npk) ? filter_accum_units_split(c, terms) : filter_accum_units(c, terms);
+}
 __host__ __device__ inline double filter_cut_abs(int c)
 {
     if (PXSOM_TOL_SLOTWISE) return 0.0;

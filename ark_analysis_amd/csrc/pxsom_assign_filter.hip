@@ -80,7 +80,12 @@ __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_kernel(
     // (a centred workspace -- binary32 / binary64 rows only, pxsom_assign.hip -- keeps the full split: x * scale - mu_s is not
     // a binary16 number)
     const bool lo_needed = sizeof(T) != 2 || scale < 1.f || hdr->centred != 0;
-    if (!lo_needed) tol_rel -= 2.5f * ((float)(filter_accum_units(c, 3) - filter_accum_units(c, 2)) * 0x1p-24f + (0x1p-19f - 0x1p-21f));
+    // (NCH >= 2: the cross terms have an accumulator of their own, filter_accum_units_split -- the workspace's tolerance was formed
+    // with the same rule, filter_accum_units_for)
+    constexpr bool SPLIT = NCH >= 2;
+    if (!lo_needed)
+        tol_rel -= 2.5f * ((float)(SPLIT ? filter_accum_units_split(c, 3) - filter_accum_units_split(c, 2) : filter_accum_units(c, 3) - filter_accum_units(c, 2)) * 0x1p-24f +
+                           (0x1p-19f - 0x1p-21f));
 
     const int lane = threadIdx.x & 63;
     const int pix = lane & 15, q = lane >> 4;
@@ -252,10 +257,12 @@ __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_kernel(
             if constexpr (NB_T > 0) {
 #pragma unroll
                 for (int b = 0; b < NB_T; b++) {
-                    f32x4 acc[TP];
+                    f32x4 acc[TP], accx[SPLIT ? TP : 1];
 #pragma unroll
                     for (int u = 0; u < TP; u++) acc[u] = breg[b];
-                    // per chunk: Wh*Xh + Wh*Xl + Wl*Xh, the TP chains interleaved
+#pragma unroll
+                    for (int u = 0; u < (SPLIT ? TP : 1); u++) accx[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    // per chunk: Wh*Xh + Wh*Xl + Wl*Xh, the TP chains interleaved (SPLIT: the cross terms in accx)
 #pragma unroll
                     for (int h = 0; h < NCH; h++) {
 #pragma unroll
@@ -266,26 +273,37 @@ __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_kernel(
 #pragma unroll
                         for (int u = 0; u < TP; u++) {
                             const int sl = PREFETCH ? t0 + u : u;
-                            if constexpr (XLO)
-                                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b][2 * h], bl[sl][h], acc[u], 0, 0, 0);
+                            if constexpr (XLO) {
+                                if constexpr (SPLIT) accx[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b][2 * h], bl[sl][h], accx[u], 0, 0, 0);
+                                else acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b][2 * h], bl[sl][h], acc[u], 0, 0, 0);
+                            }
                         }
 #pragma unroll
                         for (int u = 0; u < TP; u++) {
                             const int sl = PREFETCH ? t0 + u : u;
-                            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b][2 * h + 1], bh[sl][h], acc[u], 0, 0, 0);
+                            if constexpr (SPLIT) accx[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b][2 * h + 1], bh[sl][h], accx[u], 0, 0, 0);
+                            else acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[b][2 * h + 1], bh[sl][h], acc[u], 0, 0, 0);
                         }
+                    }
+                    if constexpr (SPLIT) {
+#pragma unroll
+                        for (int u = 0; u < TP; u++)
+#pragma unroll
+                            for (int r = 0; r < 4; r++) acc[u][r] = acc[u][r] + accx[u][r];
                     }
 #pragma unroll
                     for (int u = 0; u < TP; u++) absorb(u, acc[u], b);
                 }
             } else {
                 for (int b = 0; b < nb; b++) {
-                    f32x4 acc[TP];
+                    f32x4 acc[TP], accx[SPLIT ? TP : 1];
                     f32x4 bv;
                     if constexpr (LDSW) bv = lbias[b * 64 + lane];
                     else bv = bias[b * 64 + lane];
 #pragma unroll
                     for (int u = 0; u < TP; u++) acc[u] = bv;
+#pragma unroll
+                    for (int u = 0; u < (SPLIT ? TP : 1); u++) accx[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int h = 0; h < NCH; h++) {
                         half8 wh, wl;
@@ -300,10 +318,20 @@ __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_kernel(
                         for (int u = 0; u < TP; u++) {
                             const int sl = PREFETCH ? t0 + u : u;
                             acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh[sl][h], acc[u], 0, 0, 0);
-                            if constexpr (XLO)
-                                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl[sl][h], acc[u], 0, 0, 0);
-                            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh[sl][h], acc[u], 0, 0, 0);
+                            if constexpr (SPLIT) {
+                                if constexpr (XLO) accx[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl[sl][h], accx[u], 0, 0, 0);
+                                accx[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh[sl][h], accx[u], 0, 0, 0);
+                            } else {
+                                if constexpr (XLO) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl[sl][h], acc[u], 0, 0, 0);
+                                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh[sl][h], acc[u], 0, 0, 0);
+                            }
                         }
+                    }
+                    if constexpr (SPLIT) {
+#pragma unroll
+                        for (int u = 0; u < TP; u++)
+#pragma unroll
+                            for (int r = 0; r < 4; r++) acc[u][r] = acc[u][r] + accx[u][r];
                     }
 #pragma unroll
                     for (int u = 0; u < TP; u++) absorb(u, acc[u], b);

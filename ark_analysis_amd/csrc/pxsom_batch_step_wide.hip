@@ -436,14 +436,17 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
                 }
             float m1 = kNegBig, m2 = kNegBig;
             for (int b = 0; b < nb; b++) {
-                f32x4 acc = biasl[(size_t)b * 64 + lane];
+                // (the cross terms in an accumulator of their own, joined at the end: filter_accum_units_split, pxsom_assign.h)
+                f32x4 acc = biasl[(size_t)b * 64 + lane], accx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int h = 0; h < NCH; h++) {
                     const half8 whi = frag[(size_t)(b * 2 * NCH + 2 * h) * 64 + lane], wlo = frag[(size_t)(b * 2 * NCH + 2 * h + 1) * 64 + lane];
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, bh[h], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, bl[h], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, bh[h], acc, 0, 0, 0);
+                    accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, bl[h], accx, 0, 0, 0);
+                    accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, bh[h], accx, 0, 0, 0);
                 }
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[r] = acc[r] + accx[r];
                 top2_quad(m1, m2, pack_idx(acc[0], (unsigned)(b * 4 + 0), idx_mask), pack_idx(acc[1], (unsigned)(b * 4 + 1), idx_mask),
                           pack_idx(acc[2], (unsigned)(b * 4 + 2), idx_mask), pack_idx(acc[3], (unsigned)(b * 4 + 3), idx_mask));
             }

@@ -203,7 +203,7 @@ __device__ __forceinline__ void prep_body(const double *wl, int k, int c, Assign
         //   f64->f32 input rounding 2^-23;  tol = 2 * 1.25 * E
         //   centred filter: + 2^-24, the rounding of x' = fl(x * scale - mu_s) (one fused operation)
         const double coef = ldexp(1.0, -(23 - idx_bits)) +
-                            filter_accum_units(c, 3) * ldexp(1.0, -24) + ldexp(1.0, -19) + ldexp(1.0, -23) + (center ? ldexp(1.0, -24) : 0.0);
+                            filter_accum_units_for(c, 3, npk) * ldexp(1.0, -24) + ldexp(1.0, -19) + ldexp(1.0, -23) + (center ? ldexp(1.0, -24) : 0.0);
         hdr->tol_rel = (float)(2.5 * coef);
         // first stage of the register-resident filter: Wh*Xh alone.  |X'.W' - Xh.Wh| <= (2^-11 + 2^-11 (1 + 2^-11)) |X'||W'|
         // (binary16 unit roundoff 2^-11 on either factor), C products + the bias in the fp32 accumulation

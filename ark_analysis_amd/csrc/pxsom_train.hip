@@ -2074,7 +2074,7 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
             sa.sat = pxsom_bmu::batch_gain_saturation(sa.q);
                 sa.mu32 = (centred_run && !no_centre) ? mu32 : nullptr;
                 // (5 index bits in the scores -- 6 from 129 nodes on --, three-term split, centred rows)
-                sa.tol_rel = (float)(2.5 * (ldexp(1.0, -(23 - (k > 128 ? 6 : 5))) + pxsom_bmu::filter_accum_units(c, 3) * ldexp(1.0, -24) + ldexp(1.0, -19) + ldexp(1.0, -23) +
+                sa.tol_rel = (float)(2.5 * (ldexp(1.0, -(23 - (k > 128 ? 6 : 5))) + pxsom_bmu::filter_accum_units_split(c, 3) * ldexp(1.0, -24) + ldexp(1.0, -19) + ldexp(1.0, -23) +
                                             ldexp(1.0, -24)));
                 sa.tol_abs = fused_tol_abs;
                 sa.qmagic = qmagic;
@@ -2102,7 +2102,7 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
             // the generic filter is centred on the run's vector too (binary32 / binary64 rows): + 2^-24, the rounding of
             // x' = fl(x * scale - mu_s)
             sa.mu32 = (centred_run && !no_centre && npk == 0) ? mu32 : nullptr;
-            sa.tol_rel = (float)(2.5 * (ldexp(1.0, -(23 - L.idx_bits)) + pxsom_bmu::filter_accum_units(c, 3) * ldexp(1.0, -24) + ldexp(1.0, -19) +
+            sa.tol_rel = (float)(2.5 * (ldexp(1.0, -(23 - L.idx_bits)) + pxsom_bmu::filter_accum_units_for(c, 3, npk) * ldexp(1.0, -24) + ldexp(1.0, -19) +
                                         ldexp(1.0, -23) + (sa.mu32 ? ldexp(1.0, -24) : 0.0)));
             sa.tol_abs = (float)pxsom_bmu::filter_tol_abs(c);
             int rc = PXSOM_OK;
