@@ -92,6 +92,13 @@ __host__ __device__ inline double filter_cut_abs(int c)
     // (1 + 2^-9: the cross terms' groups, 2^-11 of the Wh*Xh ones, and the roundings of the two high parts)
     return 8.0 * (4.0 * nch) * (1.0 + 0x1p-9) * 256.0 * 0x1p-24;
 }
+// Every term of the bound is relative to |X'| or |W'|max: on a row that sits exactly on the centring vector of a codebook whose nodes
+// all equal it (an all-zero table and an all-zero codebook: tests/test_gpu_fuzz_parity.py found it, round 6) the tolerance was 0 while
+// the index bits packed into scores of +0 still made them differ by up to 127 subnormal steps (binary32 subnormals are not flushed) --
+// and the kernels that do not mask duplicate nodes (wide one-launch step, BMU-only fused steps) vouched for the LAST of the equal
+// nodes instead of listing the row.  A floor far above 127 x 2^-149 and far below any gap the scaled scores can show settles it:
+// such rows are listed.
+constexpr float kTolFloor = 0x1p-100f;
 // the absolute coefficient every filter multiplies by |X'| + |W'|max: binary16 subnormal floor + the cuts
 __host__ __device__ inline double filter_tol_abs(int c) { return 2.5 * (0x1p-24 * sqrt((double)c) + filter_cut_abs(c)); }
 

@@ -377,7 +377,7 @@ __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_kernel(
             tmerge(0, 2, true);
             // |X| up to 2^-20 relative; integer test catches NaN/Inf rows under finite-math
             const float xn = __builtin_amdgcn_sqrtf(gs[0]) * 1.000001f;
-            const float tol = tol_rel * (xn * wn_max + 0.5f * wn_max * wn_max) + tol_abs * (xn + wn_max);
+            const float tol = tol_rel * (xn * wn_max + 0.5f * wn_max * wn_max) + tol_abs * (xn + wn_max) + kTolFloor;
             // launder the bits through an empty asm: under -ffinite-math-only the optimiser would
             // otherwise fold this exponent test (it recognises it as an is-nan-or-inf query) to false
             unsigned sbits = __float_as_uint(gs[0]);
@@ -668,7 +668,7 @@ __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_packed_kerne
                 tmerge(0, 2, true);
                 {
                     const float xn = __builtin_amdgcn_sqrtf(s2[0]) * 1.000001f;
-                    const float tol = tol_rel * (xn * wn_max + 0.5f * wn_max * wn_max) + tol_abs * (xn + wn_max);
+                    const float tol = tol_rel * (xn * wn_max + 0.5f * wn_max * wn_max) + tol_abs * (xn + wn_max) + kTolFloor;
                     unsigned sbits = __float_as_uint(s2[0]);
                     asm volatile("" : "+v"(sbits));
                     const bool nonfinite = (sbits & 0x7f800000u) == 0x7f800000u;
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(BD, BD == 256 ? 2 : 1) void bmu_filter_packed_kerne
                 merge_step(true);
                 if (q == t0 + u) {
                     const float xn = __builtin_amdgcn_sqrtf(s2) * 1.000001f;
-                    const float tol = tol_rel * (xn * wn_max + 0.5f * wn_max * wn_max) + tol_abs * (xn + wn_max);
+                    const float tol = tol_rel * (xn * wn_max + 0.5f * wn_max * wn_max) + tol_abs * (xn + wn_max) + kTolFloor;
                     unsigned sbits = __float_as_uint(s2);
                     asm volatile("" : "+v"(sbits));
                     const bool nonfinite = (sbits & 0x7f800000u) == 0x7f800000u;

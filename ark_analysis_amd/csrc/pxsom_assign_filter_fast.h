@@ -393,9 +393,9 @@ __global__ __launch_bounds__(fast_threads(ACC, FIX), (ACC && FIX && PXSOM_ONE_WG
     const bool force_exact = hdr->force_exact != 0;
     const unsigned long long force_m = force_exact ? ~0ull : 0ull;
     // (the coefficients a shade up, the range bound a shade down: the fused form never vouches for a row the term-by-term one listed)
-    const float tol_a = (tol_rel * wn_max + tol_abs) * 1.0011f, tol_b = (0.5f * tol_rel * wn_max * wn_max + tol_abs * wn_max) * 1.0001f;
+    const float tol_a = (tol_rel * wn_max + tol_abs) * 1.0011f, tol_b = (0.5f * tol_rel * wn_max * wn_max + tol_abs * wn_max) * 1.0001f + kTolFloor;
     const float tol_a_coarse = (tol_rel_coarse * wn_max + tol_abs) * 1.0011f,
-                tol_b_coarse = (0.5f * tol_rel_coarse * wn_max * wn_max + tol_abs * wn_max) * 1.0001f;
+                tol_b_coarse = (0.5f * tol_rel_coarse * wn_max * wn_max + tol_abs * wn_max) * 1.0001f + kTolFloor;
     const unsigned s2_limit_bits = __float_as_uint(fminf((x_limit / 1.001f) * (x_limit / 1.001f) * 0.9999f, 3.0e38f));
     FixPoint fx = {};
     if constexpr (FIX) {

@@ -349,7 +349,7 @@ __global__ __launch_bounds__(THREADS, WPE) void bmu_onepass_kernel(const T *__re
         const unsigned sbits = __float_as_uint(s2);
         const unsigned unfit = (unsigned)!(xn < x_limit) | (unsigned)((sbits & 0x7f800000u) == 0x7f800000u) | (unsigned)force_exact;
         const float trel = FULL ? tol_rel : tol_rel_coarse;
-        const float tol = trel * (xn * wn_max + 0.5f * wn_max * wn_max) + tol_abs * (xn + wn_max);
+        const float tol = trel * (xn * wn_max + 0.5f * wn_max * wn_max) + tol_abs * (xn + wn_max) + kTolFloor;
         bool my_amb = (((unsigned)!((a1 - a2) > tol)) | unfit) != 0u;
 
         const int tile = q & 1;

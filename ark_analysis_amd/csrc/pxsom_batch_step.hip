@@ -638,7 +638,7 @@ __global__ __launch_bounds__(kStepThreads) void batch_step_kernel(const T *__res
             }
             // |Xh| <= |X| (1 + 2^-11): folded into the 1.001 factor with the sqrt's ulp
             const float xn = __builtin_amdgcn_sqrtf(s2) * 1.001f;
-            const float tol = tol_rel * (xn * wn_max + 0.5f * wn_max * wn_max) + tol_abs * (xn + wn_max);
+            const float tol = tol_rel * (xn * wn_max + 0.5f * wn_max * wn_max) + tol_abs * (xn + wn_max) + kTolFloor;
             const unsigned nonfinite = (unsigned)((__float_as_uint(s2) & 0x7f800000u) == 0x7f800000u);
             const int64_t row = blk * kRowsPerWg + (int64_t)wv * kRowsPerWave + t * 16 + pix;
             const bool valid = row < n;

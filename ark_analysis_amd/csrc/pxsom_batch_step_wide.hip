@@ -473,7 +473,7 @@ __global__ __launch_bounds__(kWideThreads) void batch_step_wide_kernel(const T *
             }
             const float xn = __builtin_amdgcn_sqrtf(ss) * 1.001f;
             const bool finite_n = (__float_as_uint(ss) & 0x7f800000u) != 0x7f800000u;
-            const float tol = sa.tol_rel * (xn * wn_max + 0.5f * wn_max * wn_max) + sa.tol_abs * (xn + wn_max);
+            const float tol = sa.tol_rel * (xn * wn_max + 0.5f * wn_max * wn_max) + sa.tol_abs * (xn + wn_max) + kTolFloor;
             const bool amb = !((f1 - f2) > tol) || !(xn < x_limit) || !finite_n || force_exact;
             const unsigned id = __float_as_uint(f1) & idx_mask;
             const int node = (int)(16u * (id >> 2) + 4u * wq + (id & 3u));

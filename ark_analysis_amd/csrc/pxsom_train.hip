@@ -1306,16 +1306,32 @@ int launch_sums_private(const T *x, int64_t n, int c, int64_t ldx, const int32_t
     return PXSOM_OK;
 }
 
+// Wave-private tables (cluster_sums_private_kernel, the pairs kernel): how many waves of a workgroup get one (0: the shape has no
+// such route) and how many workgroups a CU holds.
+inline int sums_private_waves(int c, int k, int *per_cu_out = nullptr)
+{
+    int nwv = 0, per_cu = 1;
+    if (c >= 13 && c <= 64) {
+        const size_t tbytes = ((size_t)(k + 1) * c + 64) * 8, budget = 160 * 1024 - 1024;
+        if (8 * tbytes + (size_t)k * 8 <= budget) nwv = 4, per_cu = 2;
+        else if (4 * tbytes + (size_t)k * 4 <= budget) nwv = 4;
+        else if (2 * tbytes + (size_t)k * 4 <= budget) nwv = 2;
+    }
+    if (per_cu_out) *per_cu_out = per_cu;
+    return nwv;
+}
+
 // The shapes whose sums kernel reads a scheduled step's rows where they lie (pxsom::RowView): cluster_sums_kernel's flat route
-// with rows of whole 16-byte vectors -- binary32 / binary16 rows, contiguous in the caller's matrix, more than 64 channels (below,
-// large inputs go to the wave-private kernels, which address flat ranges), table in LDS.
+// with rows of whole 16-byte vectors -- binary32 / binary16 rows, contiguous in the caller's matrix, table in LDS -- and no
+// wave-private route for the shape (those kernels address flat ranges; large inputs of 13 - 64 channels go there when their tables
+// fit: config 5's 400 x 40 table does not).
 template <typename T>
 bool sums_take_views(const T *x, int c, int64_t ldx, int k)
 {
     if (sizeof(T) > 4) return false;
     const int vec = 16 / (int)sizeof(T);
     const size_t lds_odd = ((size_t)k * (c | 1) + kSumsSpare) * 8 + (size_t)k * 4;
-    return c > 64 && c % vec == 0 && ldx == c && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+    return sums_private_waves(c, k) == 0 && c >= vec && c % vec == 0 && ldx == c && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
            std::min(lds_odd, ((size_t)k * c + kSumsSpare) * 8 + (size_t)k * 4) <= 150 * 1024;
 }
 
@@ -1333,11 +1349,8 @@ int cluster_sums_typed(const T *x, int64_t n, int c, int64_t ldx, const int32_t 
     // fill them, and a wave's byte range addressable by the 32-bit buffer offsets.  Measured against the
     // atomic kernel below on 2-4 M rows: 1.4-1.9x faster there, slower outside (c <= 8, one table per CU).
     if (c >= 13 && c <= 64 && n >= 32768 && qmagic == 0.0) {
-        const size_t tbytes = ((size_t)(k + 1) * c + 64) * 8, budget = 160 * 1024 - 1024;
-        int nwv = 0, per_cu = 1;
-        if (8 * tbytes + (size_t)k * 8 <= budget) nwv = 4, per_cu = 2;
-        else if (4 * tbytes + (size_t)k * 4 <= budget) nwv = 4;
-        else if (2 * tbytes + (size_t)k * 4 <= budget) nwv = 2;
+        int per_cu = 1;
+        const int nwv = sums_private_waves(c, k, &per_cu);
         const int64_t waves = (int64_t)pxsom::device_cu_count() * per_cu * (nwv ? nwv : 1);
         const bool addressable = ((n + waves - 1) / waves + 1024) * ldx * (int64_t)sizeof(T) < (1ll << 31);
         if (nwv && addressable) {
@@ -1978,7 +1991,7 @@ int train_steps_typed(const T *x, int64_t n, int c, int64_t ldx, int dtype, doub
     // Round 6: where every kernel of the generic route takes row views (pxsom_common.h RowView: more than 64 channels of binary32 /
     // binary16 rows, contiguous in the caller's matrix) the steps read their rows where they lie -- no gathered copy of the matrix
     // at the head of every pass (config 4: 217 us of 2.0 ms, 800 MB of traffic)
-    const bool viewed = !fused_shape && sc.any_wide() && c <= pxsom_bmu::kFilterMaxChannels && sums_take_views<T>(x, c, ldx, k);
+    const bool viewed = !fused_shape && sc.any_wide() && c > 32 && c <= pxsom_bmu::kFilterMaxChannels && sums_take_views<T>(x, c, ldx, k);
     const bool gathered = !fused_shape && sc.any_wide() && !viewed;
     if (gathered && g_begin == 0 && n > 0) {
         int rc = launch_gather<T>(x, n, c, ldx, xg, sc, st);

@@ -290,18 +290,20 @@ def test_one_launch_steps_equal_the_launch_per_phase_route_and_the_oracle(gpu, o
     np.testing.assert_array_equal(wa.cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("c,dtype,pad", [
-    (100, np.float32, 0),     # config 4's shape: every kernel of the generic route reads the step's rows where they lie (RowView)
-    (100, np.float32, 4),     # the same rows inside a wider matrix (ldx = 104): the gathered copy, as before
-    (96, np.float16, 0),      # binary16: packed-K filter + the sums kernel's eight-element vectors on the view
-    (72, np.float32, 0),      # three channel chunks
-    (48, np.float32, 0),      # <= 64 channels: the wave-private sums kernels address flat ranges -- gathered
+@pytest.mark.parametrize("c,dtype,pad,grid", [
+    (100, np.float32, 0, 10),     # config 4's shape: every kernel of the generic route reads the step's rows where they lie (RowView)
+    (100, np.float32, 4, 10),     # the same rows inside a wider matrix (ldx = 104): the gathered copy, as before
+    (96, np.float16, 0, 10),      # binary16: packed-K filter + the sums kernel's eight-element vectors on the view
+    (72, np.float32, 0, 10),      # three channel chunks
+    (48, np.float32, 0, 10),      # <= 64 channels, 100 nodes: the wave-private sums kernels address flat ranges -- gathered
+    (40, np.float16, 0, 20),      # config 5's shape: a 400 x 40 table has no wave-private route -- viewed
+    (40, np.float32, 0, 20),
 ])
-def test_generic_route_on_row_views_matches_the_oracle(gpu, oracle, c, dtype, pad):
+def test_generic_route_on_row_views_matches_the_oracle(gpu, oracle, c, dtype, pad, grid):
     """Round 6: the launch-per-phase route and the wide one-launch step without the gathered copy of the matrix.  Whole run against
     orc_som_batch_sched on data whose sums are exact (bit for bit), for shapes on both sides of the decision."""
-    xdim = ydim = 10
-    k, n = 100, 41_003
+    xdim = ydim = grid
+    k, n = grid * grid, 41_003
     sch = MIXED
     x = synth.make_fov_numpy(n, c, seed=61, dtype=np.float32)
     x = (np.round(x.astype(np.float64) * 4096.0) / 4096.0).astype(dtype)
@@ -327,3 +329,37 @@ def test_generic_route_on_row_views_matches_the_oracle(gpu, oracle, c, dtype, pa
     w2 = torch.empty((k, c), dtype=torch.float64, device=gpu)
     sd.batch_train_finish(st2, total, total, (0.05, 0.01), rr, w2)
     assert torch.equal(w, w2)
+
+
+@pytest.mark.parametrize("c,dtype,pad,sch", [
+    (2, np.float64, 7, BatchSchedule.equal(16)),     # the case the randomised sweep found (round 6): the wide one-launch step
+    (2, np.float32, 7, SMALL_TWO_PHASE),
+    (100, np.float32, 0, MIXED),                     # wide step + streamed filter
+    (22, np.float32, 0, SMALL_TWO_PHASE),            # the fused 10 x 10 step: windowed and BMU-only steps (no duplicate mask there)
+    (22, np.float64, 0, SMALL_TWO_PHASE),
+])
+def test_all_zero_table_and_codebook_take_the_first_node(gpu, oracle, c, dtype, pad, sch):
+    """Every node equals the centring vector and every row sits on it: all terms of the filter's tolerance vanish, while the index
+    bits packed into scores of +0 still differ by subnormal steps.  The tolerance has a floor for this (kTolFloor): the rows are
+    listed and the exact path takes the FIRST of the equal nodes, as the oracle does."""
+    xdim = ydim = 10
+    k, n = 100, 3_001
+    host = np.zeros((n, c + pad), dtype=dtype)
+    xd = torch.from_numpy(host).to(gpu)[:, :c]
+    w0 = np.zeros((k, c))
+    rr = default_radius_range(xdim, ydim)
+    total = sch.steps
+    for unfused in (False, True):
+        st = sd.BatchTrainState(n, c, xdim, ydim, sch, gpu, dtype=xd.dtype)
+        st.wbuf[0].copy_(torch.from_numpy(w0))
+        for g in range(total):
+            sd.batch_train_steps(xd, st, g, g + 1, total, (0.05, 0.01), rr, unfused=unfused)
+            counts = st.ring[g % 3][k * c:].cpu().numpy()
+            rows = len(sch.rows_of_step(n, g))
+            assert counts[0] == rows and counts[1:].sum() == 0, "step %d (unfused=%s): rows at nodes %s" % (g, unfused, np.nonzero(counts)[0])
+        w = torch.empty((k, c), dtype=torch.float64, device=gpu)
+        sd.batch_train_finish(st, total, total, (0.05, 0.01), rr, w)
+        assert float(w.abs().max()) == 0.0
+    # labelling calls on the same table: node 1 (labels are 1-based) for every row
+    lab, _ = sd.assign(xd, torch.zeros((k, c), dtype=torch.float64, device=gpu))
+    assert int(lab.min()) == 1 and int(lab.max()) == 1
