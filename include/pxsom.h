@@ -247,8 +247,10 @@ int pxsom_batch_train_finish(const double *wbuf_dev, const double *stats_ring_de
  * in the BMU-only tail reach the quality of 64 equal steps in under half the launches (DESIGN.md "K6b").
  * State (wbuf_dev, stats_ring_dev), routes, flags and comm as pxsom_batch_train_steps[_sharded]; steps are numbered
  * over the whole run, g in [0, num_passes * steps_per_pass); the call with g_begin == 0 must come first on a workspace
- * (it clears ring[0] and, for shapes outside the fused kernel with steps wider than one phase, gathers the rows into
- * step order inside the workspace -- one extra read + write of the matrix per run).  Every rank runs the same steps.
+ * (it clears ring[0] and, for shapes outside the fused kernel with steps wider than one phase whose kernels do not all read a
+ * step's rows where they lie -- 32 channels or fewer, binary64 rows, rows not contiguous in x, a per-cluster table small enough
+ * for the wave-private sums kernels --, gathers the rows into step order inside the workspace: one extra read + write of the
+ * matrix per run; round 6: other shapes are read in place).  Every rank runs the same steps.
  * The WORKSPACE IS RUN STATE, like wbuf and the ring: the g_begin == 0 call also leaves the run's centring vector (the
  * mean of W_0 per channel and its norm, read by every later step's filter) in it, so the calls of one run must be given
  * the same, untouched workspace; a later call on a fresh or foreign workspace would centre on whatever bytes it finds
